@@ -1,0 +1,189 @@
+/*
+ * llenv.h -- C ABI of the MI355X-native batched PMC tracking-environment stepper.
+ *
+ * The reference (Tencent-RoboticsX/lifelike-agility-and-play) has no C interface: its hot
+ * path is a Python gym env that drives the PyBullet shared library through ~24 API calls
+ * (SURVEY.md 2.3).  This header declares the entry points that a maintainer of the
+ * reference would bind with ctypes to replace that path; every function names the
+ * reference interface (file:line under src/lifelike/sim_envs/pybullet_envs/) it stands for.
+ *
+ *   PLE = primitive_level_env/primitive_level_env.py     ML = primitive_level_env/motion_lib.py
+ *   LR  = legged_robot/legged_robot.py                   CPE = create_pybullet_envs.py
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative LL_E* code; ll_last_error() gives text;
+ *   - one handle per GPU; calls on one handle are not re-entrant (the TLeague actor drives its
+ *     env from a single thread, learning/actors/distill_actor.py:205-247);
+ *   - the caller owns every buffer it passes in; buffers named d_* are DEVICE pointers,
+ *     h_* are HOST pointers;  all arrays are float32 unless stated otherwise;
+ *   - no torch types cross this boundary.
+ */
+#ifndef LLENV_H
+#define LLENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LL_ABI_VERSION 1
+
+/* per-env sizes (PLE:101-124) */
+#define LL_N_JOINTS 12
+#define LL_STATE_DIM 37     /* pos3 quat4(xyzw) linvel3 angvel3 q12 qd12 : LR:86-106 states_info */
+#define LL_ACTION_DIM 12    /* PLE:124 */
+#define LL_STACK 3          /* PLE:39 stack_frame_num (not overridable from the factory) */
+#define LL_PROP_FRAME_MAX 33
+#define LL_FUTURE_DIM 72    /* PLE:120 */
+#define LL_OBS_DIM_MAX (LL_STACK * LL_PROP_FRAME_MAX + LL_STACK * LL_ACTION_DIM + LL_FUTURE_DIM) /* 207 */
+#define LL_MOCAP_ROW 19     /* ML:91-96 */
+
+/* prop_type keys (PLE:102-108), ids used in ll_config.prop_order */
+#define LL_PROP_JOINT_POS 0
+#define LL_PROP_JOINT_VEL 1
+#define LL_PROP_ROOT_LIN_VEL_LOC 2
+#define LL_PROP_ROOT_ANG_VEL_LOC 3
+#define LL_PROP_E_G 4
+
+/* reward_weights order (PLE:352-357) */
+#define LL_RW_JOINT_POS 0
+#define LL_RW_JOINT_VEL 1
+#define LL_RW_END_EFFECTOR 2
+#define LL_RW_ROOT_POSE 3
+#define LL_RW_ROOT_VEL 4
+
+/* error codes */
+#define LL_OK 0
+#define LL_EINVAL (-1)
+#define LL_ENOMEM (-2)
+#define LL_EHIP (-3)      /* a HIP runtime call failed; message in ll_last_error() */
+#define LL_ESTATE (-4)    /* call sequence error (e.g. step before mocap load / reset) */
+#define LL_ENODEV (-5)    /* no usable GPU: the product path never falls back to the CPU */
+
+/* done-reason bits written to the done_reason buffer (PLE:337-348) */
+#define LL_DONE_FALL 1        /* LR:158-179 */
+#define LL_DONE_CLIP_END 2    /* ML:168-172 */
+#define LL_DONE_DIVERGED 4    /* PLE:319-335 */
+#define LL_DONE_COLLISION 8   /* PLE:341-346 (obstacle variant) */
+#define LL_DONE_NONFINITE 16  /* engine guard: a NaN/Inf state terminates the episode */
+
+/*
+ * Environment configuration = the reference's env_config dict (CPE:28-59) plus batching knobs.
+ * Field defaults below are the factory's (CPE), not PrimitiveLevelEnv's.
+ */
+typedef struct ll_config {
+  int32_t abi_version;          /* must be LL_ABI_VERSION */
+  int32_t n_envs;               /* number of environments stepped in lockstep on this GPU */
+  int32_t device;               /* HIP device ordinal */
+  int32_t auto_reset;           /* 1: envs that finish are re-seeded inside the step kernel
+                                   0: reference semantics, caller resets (PLE never auto-resets) */
+  double control_freq;          /* CPE:29 default 25.0 (scripts use 50.0) */
+  double sim_freq;              /* CPE:30 default 500.0 */
+  double kp;                    /* CPE:31 */
+  double kd;                    /* CPE:32 default 1.0 (scripts use 0.5) */
+  double max_tau;               /* CPE:33; a [lo,hi] list is drawn ONCE by the host (LR:244, quirk Q1) */
+  double foot_lateral_friction; /* CPE:48 */
+  double reward_weights[5];     /* CPE:42 / PLE:352-363 (pass PLE's defaults when the dict is None) */
+  int32_t prop_order[5];        /* prop_type list as LL_PROP_* ids, -1 terminated (PLE:101-113) */
+  int32_t set_obstacle;         /* CPE:39 (obstacle variant; flat-terrain configs pass 0) */
+  double obstacle_height;       /* CPE:40 default 0.0 (quirk Q7) */
+  double prioritized_sample_factor; /* CPE:38 */
+  int32_t solver_iterations;    /* LR:261 numSolverIterations = 10 */
+  int32_t reserved0;
+  uint64_t seed;                /* Philox key for clip / start-time sampling and synthetic actions */
+} ll_config;
+
+typedef struct ll_engine ll_engine; /* opaque */
+
+/* Text of the last error on this thread (never NULL). */
+const char* ll_last_error(void);
+int ll_abi_version(void);
+
+/* Length (doubles) of the model blob produced by the URDF compiler (urdf_model.py, = loadURDF LR:208-220). */
+int ll_model_blob_len(void);
+
+/*
+ * Build an engine: replaces PrimitiveLevelEnv.__init__ (PLE:27-148) +
+ * LeggedRobot._init_dynamic_model/_init_kinematic_model (LR:207-302) + loadURDF(plane) (PLE:81-82).
+ */
+int ll_create(const ll_config* cfg, const double* model_blob, int blob_len, ll_engine** out);
+int ll_destroy(ll_engine* e); /* PLE:428-435 close()/__del__ */
+
+/*
+ * Upload the packed clip table: replaces MotionLib._open_all_mocap_datas (ML:19-46).
+ * h_frames: [sum(clip_len)][19] float32 rows (ML:91-96 layout), clips concatenated.
+ */
+int ll_load_mocap(ll_engine* e, const float* h_frames, const int32_t* h_clip_len, int n_clips, double frame_step);
+
+/*
+ * Reset environments: PLE:150-171 + ML:48-63.
+ *   h_env_ids   NULL = all n_envs, else n ids
+ *   h_clip_idx  NULL = sample from the prioritized table (ML:59-63) with the engine's Philox stream
+ *   h_t0        NULL = sample U(0,1)*frame_step*(N-margin-1) (ML:50-51); else explicit start times (float64)
+ * After the call the obs buffer rows of those envs hold the first observation.
+ */
+int ll_reset(ll_engine* e, const int32_t* h_env_ids, int n, const int32_t* h_clip_idx, const double* h_t0);
+
+/*
+ * One 50 Hz control step for every env: PLE:195-245 (10 x {LR:119-148 PD torque, stepSimulation},
+ * ML:65-115 mocap lookup, PLE:276-317 obs, PLE:350-426 reward, PLE:337-348 termination,
+ * PLE:235-240 sampling-table update).  The real-time sleep of PLE:241-244 is NOT reproduced.
+ *   d_actions  device pointer [n_envs][12] float32, or NULL to use the engine's own action buffer
+ *              (see ll_device_ptrs) -- e.g. after ll_fill_random_actions().
+ * Asynchronous on the engine's stream; results land in the engine's device buffers.
+ */
+int ll_step(ll_engine* e, const float* d_actions);
+
+/* Synthetic random policy a ~ N(0, sigma^2) per joint (sigma = exp(-2)), generated on
+ * device by Philox keyed on (seed, env, step) into the engine's action buffer. */
+int ll_fill_random_actions(ll_engine* e, float sigma);
+
+/* Block until all queued work on the engine's stream has finished. */
+int ll_sync(ll_engine* e);
+
+/* Device buffers owned by the engine (valid until ll_destroy), for zero-copy consumers (torch, RCCL). */
+typedef struct ll_device_ptrs_t {
+  float* obs;            /* [n_envs][obs_dim]  prop | prop_a | future (PLE:292-296) */
+  float* reward;         /* [n_envs] */
+  uint8_t* done;         /* [n_envs] */
+  uint8_t* done_reason;  /* [n_envs] LL_DONE_* bits */
+  float* actions;        /* [n_envs][12] engine-owned action buffer */
+  float* terminal_obs;   /* [n_envs][obs_dim] obs of the finished episode (auto_reset=1 only) */
+  int32_t obs_dim;
+  int32_t n_envs;
+  void* stream;          /* hipStream_t the engine launches on */
+} ll_device_ptrs_t;
+int ll_device_ptrs(ll_engine* e, ll_device_ptrs_t* out);
+
+/* Host copies (synchronise the stream first). */
+int ll_get_obs(ll_engine* e, float* h_obs /*[n_envs][obs_dim]*/);
+int ll_get_reward_done(ll_engine* e, float* h_reward, uint8_t* h_done, uint8_t* h_done_reason);
+int ll_set_actions(ll_engine* e, const float* h_actions /*[n_envs][12]*/);
+
+/* Dynamic-robot state, LR:86-106 / LR:62-84 layout, float32 [n_envs][37] on the host. */
+int ll_get_state(ll_engine* e, float* h_state);
+int ll_set_state(ll_engine* e, const float* h_state);
+/* Kinematic ghost state (what PLE:218 writes into the ghost robot), [n_envs][37]. */
+int ll_get_ref_state(ll_engine* e, float* h_state);
+/* Episode bookkeeping: clip index (ML:60), env time in seconds as float64 (PLE:210), steps (PLE:197). */
+int ll_get_episode_info(ll_engine* e, int32_t* h_clip, double* h_time, int32_t* h_steps, float* h_reward_sum);
+/* Prioritized sampling table (PLE:131-136): probability[n_clips], avg_reward_sum[n_clips], avg_episode_len[n_clips]. */
+int ll_get_sampling_table(ll_engine* e, double* h_prob, double* h_avg_reward_sum, double* h_avg_episode_len);
+int ll_set_sampling_table(ll_engine* e, const double* h_avg_reward_sum);
+
+/* World positions of the four feet of the dynamic robot and of the ghost: LR:199-205 compute_end_effector_info. */
+int ll_get_feet(ll_engine* e, float* h_feet_dyn /*[n_envs][4][3]*/, float* h_feet_ref /*[n_envs][4][3]*/);
+
+/* Counters for bench/diagnostics: total env-steps executed, episodes finished, non-finite resets. */
+int ll_get_counters(ll_engine* e, uint64_t* steps, uint64_t* episodes, uint64_t* nonfinite);
+
+/* Average device time (ms) of the step kernel over the launches since the last call, measured with
+ * HIP events on the engine's own stream (bench.py roofline leg); also returns the launch count. */
+int ll_kernel_time_ms(ll_engine* e, double* avg_ms, int* n_launches);
+int ll_enable_kernel_timing(ll_engine* e, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLENV_H */

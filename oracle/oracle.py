@@ -1,0 +1,215 @@
+"""ctypes binding of oracle/pmc_oracle.c -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, '_build', 'libpmc_oracle.so')
+
+PROP_IDS = {'joint_pos': 0, 'joint_vel': 1, 'root_lin_vel_loc': 2, 'root_ang_vel_loc': 3, 'e_g': 4}
+RW_KEYS = ['joint_pos', 'joint_vel', 'end_effector', 'root_pose', 'root_vel']
+
+
+class LLConfig(C.Structure):
+    """Mirror of ll_config (include/llenv.h)."""
+    _fields_ = [('abi_version', C.c_int32), ('n_envs', C.c_int32), ('device', C.c_int32), ('auto_reset', C.c_int32),
+                ('control_freq', C.c_double), ('sim_freq', C.c_double), ('kp', C.c_double), ('kd', C.c_double),
+                ('max_tau', C.c_double), ('foot_lateral_friction', C.c_double), ('reward_weights', C.c_double * 5),
+                ('prop_order', C.c_int32 * 5), ('set_obstacle', C.c_int32), ('obstacle_height', C.c_double),
+                ('prioritized_sample_factor', C.c_double), ('solver_iterations', C.c_int32), ('reserved0', C.c_int32),
+                ('seed', C.c_uint64)]
+
+
+def make_config(n_envs=1, control_freq=50.0, sim_freq=500.0, kp=50.0, kd=0.5, max_tau=18.0, foot_lateral_friction=0.5,
+                reward_weights=None, prop_type=None, prioritized_sample_factor=3.0, auto_reset=0, seed=0, device=0,
+                set_obstacle=False, obstacle_height=0.0, solver_iterations=10):
+    cfg = LLConfig()
+    cfg.abi_version = 1
+    cfg.n_envs, cfg.device, cfg.auto_reset = n_envs, device, auto_reset
+    cfg.control_freq, cfg.sim_freq, cfg.kp, cfg.kd, cfg.max_tau = control_freq, sim_freq, kp, kd, max_tau
+    cfg.foot_lateral_friction = foot_lateral_friction
+    rw = reward_weights or {'joint_pos': 0.6, 'joint_vel': 0.05, 'end_effector': 0.1, 'root_pose': 0.15, 'root_vel': 0.1}
+    for i, k in enumerate(RW_KEYS):
+        cfg.reward_weights[i] = rw[k]
+    pt = prop_type if prop_type is not None else ['joint_pos', 'joint_vel', 'root_ang_vel_loc', 'root_lin_vel_loc', 'e_g']
+    for i in range(5):
+        cfg.prop_order[i] = PROP_IDS[pt[i]] if i < len(pt) else -1
+    cfg.set_obstacle, cfg.obstacle_height = int(set_obstacle), obstacle_height
+    cfg.prioritized_sample_factor = prioritized_sample_factor
+    cfg.solver_iterations = solver_iterations
+    cfg.seed = seed
+    return cfg
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, 'pmc_oracle.c')):
+        subprocess.check_call(['make', '-C', HERE, '-s'] + (['-B'] if force else []))
+    return LIB
+
+
+_lib = None
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(dp)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_create.restype = C.c_void_p
+        _lib.orc_reward.restype = C.c_double
+        _lib.orc_energy.restype = C.c_double
+        _lib.orc_motion_duration.restype = C.c_double
+    return _lib
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ---- stateless pieces -------------------------------------------------------------------------
+def mocap_locate(t, frame_step):
+    fid, frac = C.c_int32(), C.c_double()
+    lib().orc_mocap_locate(C.c_double(t), C.c_double(frame_step), C.byref(fid), C.byref(frac))
+    return fid.value, frac.value
+
+
+def mocap_interp(fc, fn, frac, frame_step):
+    out = np.zeros(37)
+    lib().orc_mocap_interp(_p(f64(fc)), _p(f64(fn)), C.c_double(frac), C.c_double(frame_step), _p(out))
+    return out
+
+
+def mocap_future(frames_at_fid, frac, frame_step):
+    out = np.zeros((4, 37))
+    fr = f64(frames_at_fid)
+    lib().orc_mocap_future(_p(fr), C.c_double(frac), C.c_double(frame_step), _p(out))
+    return out
+
+
+def prop(state, prop_order=(0, 1, 3, 2, 4)):
+    po = (C.c_int32 * 5)(*(list(prop_order) + [-1] * (5 - len(prop_order))))
+    out = np.zeros(33)
+    n = lib().orc_prop(_p(f64(state)), po, _p(out))
+    return out[:n]
+
+
+def calc_future(base_pos, base_orn, fut76):
+    out = np.zeros(72)
+    lib().orc_calc_future(_p(f64(base_pos)), _p(f64(base_orn)), _p(f64(fut76)), _p(out))
+    return out
+
+
+def reward(dyn, kin, feet_dyn, feet_kin, weights):
+    return lib().orc_reward(_p(f64(dyn)), _p(f64(kin)), _p(f64(feet_dyn).ravel()), _p(f64(feet_kin).ravel()), _p(f64(weights)))
+
+
+def check_fall(quat):
+    return bool(lib().orc_check_fall(_p(f64(quat))))
+
+
+def check_diverged(dyn, kin):
+    return bool(lib().orc_check_diverged(_p(f64(dyn)), _p(f64(kin))))
+
+
+# ---- batch env ----------------------------------------------------------------------------------
+class OracleBatch(object):
+    def __init__(self, cfg, model_blob, mocap_table):
+        self.cfg = cfg
+        blob = f64(model_blob)
+        self.h = C.c_void_p(lib().orc_create(C.byref(cfg), _p(blob), C.c_int(blob.size)))
+        assert self.h.value, 'orc_create failed'
+        fr = f64(mocap_table.frames)
+        cl = np.ascontiguousarray(mocap_table.clip_len, dtype=np.int32)
+        lib().orc_load_mocap(self.h, _p(fr), cl.ctypes.data_as(ip), C.c_int(len(cl)), C.c_double(mocap_table.frame_step))
+        self.n_envs = cfg.n_envs
+        self.n_clips = len(cl)
+        self.obs_dim = lib().orc_obs_dim(self.h)
+
+    def __del__(self):
+        if getattr(self, 'h', None) and self.h.value:
+            lib().orc_destroy(self.h)
+            self.h = None
+
+    def reset_env(self, env, clip, t0):
+        obs = np.zeros(self.obs_dim)
+        rc = lib().orc_reset_env(self.h, C.c_int(env), C.c_int(int(clip)), C.c_double(t0), _p(obs))
+        assert rc == 0, rc
+        return obs
+
+    def step_env(self, env, action, scripted_dyn=None, feet_dyn=None, feet_kin=None):
+        obs = np.zeros(self.obs_dim)
+        r, d = C.c_double(), C.c_int()
+        sd = _p(f64(scripted_dyn)) if scripted_dyn is not None else None
+        fd = _p(f64(feet_dyn).ravel()) if feet_dyn is not None else None
+        fk = _p(f64(feet_kin).ravel()) if feet_kin is not None else None
+        lib().orc_step_env(self.h, C.c_int(env), _p(f64(action)), sd, fd, fk, _p(obs), C.byref(r), C.byref(d))
+        return obs, r.value, bool(d.value)
+
+    def step_all(self, actions):
+        a = f64(actions)
+        obs = np.zeros((self.n_envs, self.obs_dim)); rew = np.zeros(self.n_envs); done = np.zeros(self.n_envs, dtype=np.int32)
+        lib().orc_step_all(self.h, _p(a), _p(obs), _p(rew), done.ctypes.data_as(ip))
+        return obs, rew, done.astype(bool)
+
+    def get_state(self, env):
+        s = np.zeros(37); lib().orc_get_state(self.h, C.c_int(env), _p(s)); return s
+
+    def set_state(self, env, s):
+        lib().orc_set_state(self.h, C.c_int(env), _p(f64(s)))
+
+    def get_ref_state(self, env):
+        s = np.zeros(37); lib().orc_get_ref_state(self.h, C.c_int(env), _p(s)); return s
+
+    def get_feet(self, env):
+        a, b = np.zeros((4, 3)), np.zeros((4, 3)); lib().orc_get_feet(self.h, C.c_int(env), _p(a), _p(b)); return a, b
+
+    def episode_info(self, env):
+        clip, steps, reason, fid = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        t, rs, frac = C.c_double(), C.c_double(), C.c_double()
+        lib().orc_get_episode_info(self.h, C.c_int(env), C.byref(clip), C.byref(t), C.byref(steps), C.byref(rs), C.byref(reason), C.byref(fid), C.byref(frac))
+        return dict(clip=clip.value, time=t.value, steps=steps.value, reward_sum=rs.value, done_reason=reason.value, frame_id=fid.value, frac=frac.value)
+
+    def sampling_table(self):
+        p, a, l = np.zeros(self.n_clips), np.zeros(self.n_clips), np.zeros(self.n_clips)
+        lib().orc_get_sampling_table(self.h, _p(p), _p(a), _p(l)); return p, a, l
+
+    def set_sampling_table(self, prob, avg_r):
+        lib().orc_set_sampling_table(self.h, _p(f64(prob)), _p(f64(avg_r)))
+
+    def meta(self):
+        m, fr = C.c_int32(), C.c_int32(); ms = np.zeros(self.n_clips)
+        lib().orc_get_margin(self.h, C.byref(m), C.byref(fr), _p(ms)); return m.value, fr.value, ms
+
+    def motion_duration(self, clip):
+        return lib().orc_motion_duration(self.h, C.c_int(clip))
+
+    def fk_feet(self, state):
+        out = np.zeros((4, 3)); lib().orc_fk_feet(self.h, _p(f64(state)), _p(out)); return out
+
+    def forward_dynamics(self, state, tau):
+        acc = np.zeros(18); rc = lib().orc_forward_dynamics(self.h, _p(f64(state)), _p(f64(tau)), _p(acc)); assert rc == 0; return acc
+
+    def substep(self, state, tau):
+        s = f64(state).copy(); nc = C.c_int32(); lam = np.zeros(12 + 3 * 24); acc = np.zeros(18)
+        rc = lib().orc_substep(self.h, _p(s), _p(f64(tau)), C.byref(nc), _p(lam), _p(acc)); assert rc == 0
+        return s, nc.value, lam, acc
+
+    def momentum(self, state):
+        out = np.zeros(6); lib().orc_momentum(self.h, _p(f64(state)), _p(out)); return out
+
+    def energy(self, state):
+        return lib().orc_energy(self.h, _p(f64(state)))
+
+
+def set_link_damping(k):
+    lib().orc_set_link_damping(C.c_double(k))

@@ -1,0 +1,1027 @@
+/*
+ * pmc_oracle.c -- CPU float64 restatement of the reference's PMC tracking-env hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (lifelike_agility_and_play_amd/, the C ABI, bench's timed
+ * GPU leg) may import, link or call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, as the checker / reported baseline.
+ *
+ * What it restates (file:line under /root/reference/src/lifelike/sim_envs/pybullet_envs/):
+ *   PLE = primitive_level_env/primitive_level_env.py, ML = primitive_level_env/motion_lib.py,
+ *   LR  = legged_robot/legged_robot.py
+ * Everything outside PyBullet follows the reference line by line and is PINNED against golden vectors
+ * produced by importing the reference (tests/golden/gen_golden.py -> pmc_golden.npz).
+ *
+ * Physics (what `stepSimulation()` does at PLE:206) lives in the third-party `pybullet` wheel, which
+ * is un-pinned (setup.py:20), absent from /root/reference and not installable here:
+ *     >>> PARITY UNPINNED for the physics substep <<<
+ * It is restated from Bullet's published algorithm (btMultiBody: Featherstone articulated-body
+ * forward dynamics, semi-implicit Euler, sequential-impulse (PGS) contact + joint-limit solve with
+ * ERP) -- see DESIGN.md "physics spec".  The oracle deliberately uses the textbook generic
+ * formulation (dense 6x6 spatial algebra, generic tree ABA, explicit Jacobians, explicit
+ * M^-1 by unit responses, lambda-space PGS) so that it is an independent check of the
+ * structure-exploiting HIP kernel.
+ */
+#define _USE_MATH_DEFINES
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/llenv.h"
+#include "../include/llenv_model.h"
+
+#define NB 13
+#define NDOF 18
+#define KC LLM_MAX_CONTACTS_PER_LEG
+#define MAXC (4 * KC)
+#define MAXROWS (12 + 3 * MAXC)
+
+/* ------------------------------------------------------------------------------------------------ */
+/* small linear algebra                                                                             */
+/* ------------------------------------------------------------------------------------------------ */
+static void v3cross(const double* a, const double* b, double* o) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static double v3dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void m3v(const double* m, const double* v, double* o) { /* o = M v (row-major) */
+  double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
+         z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static void m3tv(const double* m, const double* v, double* o) { /* o = M^T v */
+  double x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2],
+         z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static void m3m(const double* a, const double* b, double* o) {
+  double t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+  memcpy(o, t, sizeof t);
+}
+
+/* ---- quaternions, xyzw, following scipy.spatial.transform.Rotation semantics --------------------- */
+static void q_normalize(const double* q, double* o) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; i++) o[i] = q[i] / n;
+}
+static void q_mul(const double* p, const double* q, double* o) { /* Hamilton product p (x) q  == scipy `P * Q` */
+  double x = p[3] * q[0] + p[0] * q[3] + p[1] * q[2] - p[2] * q[1];
+  double y = p[3] * q[1] - p[0] * q[2] + p[1] * q[3] + p[2] * q[0];
+  double z = p[3] * q[2] + p[0] * q[1] - p[1] * q[0] + p[2] * q[3];
+  double w = p[3] * q[3] - p[0] * q[0] - p[1] * q[1] - p[2] * q[2];
+  o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+static void q_conj(const double* q, double* o) { o[0] = -q[0]; o[1] = -q[1]; o[2] = -q[2]; o[3] = q[3]; }
+static void q_to_mat(const double* q, double* m) { /* unit q -> R (row-major), scipy as_matrix */
+  double x = q[0], y = q[1], z = q[2], w = q[3];
+  double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w, xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
+  m[0] = x2 - y2 - z2 + w2; m[1] = 2 * (xy - zw); m[2] = 2 * (xz + yw);
+  m[3] = 2 * (xy + zw); m[4] = -x2 + y2 - z2 + w2; m[5] = 2 * (yz - xw);
+  m[6] = 2 * (xz - yw); m[7] = 2 * (yz + xw); m[8] = -x2 - y2 + z2 + w2;
+}
+static void q_as_rotvec(const double* qin, double* rv) { /* scipy as_rotvec: shortest arc, series below 1e-3 */
+  double q[4] = {qin[0], qin[1], qin[2], qin[3]};
+  if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+  double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+  double angle = 2.0 * atan2(nrm, q[3]);
+  double scale;
+  if (angle <= 1e-3) {
+    double a2 = angle * angle;
+    scale = 2.0 + a2 / 12.0 + 7.0 * a2 * a2 / 2880.0;
+  } else {
+    scale = angle / sin(angle / 2.0);
+  }
+  rv[0] = scale * q[0]; rv[1] = scale * q[1]; rv[2] = scale * q[2];
+}
+static void q_from_rotvec(const double* rv, double* q) { /* scipy from_rotvec */
+  double angle = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+  double scale;
+  if (angle <= 1e-3) {
+    double a2 = angle * angle;
+    scale = 0.5 - a2 / 48.0 + a2 * a2 / 3840.0;
+  } else {
+    scale = sin(angle / 2.0) / angle;
+  }
+  q[0] = scale * rv[0]; q[1] = scale * rv[1]; q[2] = scale * rv[2]; q[3] = cos(angle / 2.0);
+}
+/* PLE:19-23 quat2axisangle followed by axis*angle */
+static double quat_axis_angle(const double* quat, double* axis) {
+  double qn[4], rv[3];
+  q_normalize(quat, qn);
+  q_as_rotvec(qn, rv);
+  double angle = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+  for (int i = 0; i < 3; i++) axis[i] = rv[i] / (angle + 1e-8);
+  return angle;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* mocap (ML:65-172)                                                                                */
+/* ------------------------------------------------------------------------------------------------ */
+/* ML:65-67 */
+void orc_mocap_locate(double t, double frame_step, int32_t* frame_id, double* frac) {
+  int32_t f = (int32_t)floor(t / frame_step);
+  *frame_id = f;
+  *frac = (t - f * frame_step) / frame_step;
+}
+
+/* ML:88-166 _get_states_info_by_interpolation (interpolation=True, free_joint=True) -> state37 */
+void orc_mocap_interp(const double* fc, const double* fn, double frac, double frame_step, double* out) {
+  /* base_pos_interpolation ML:118-124 */
+  for (int i = 0; i < 3; i++) out[i] = fc[i] + frac * (fn[i] - fc[i]);
+  /* base_orn_interpolation ML:127-134 : scipy Slerp([0,1], [qc,qn])(frac) */
+  double qc[4], qn[4], qci[4], d[4], rv[3], dq[4];
+  q_normalize(fc + 3, qc);
+  q_normalize(fn + 3, qn);
+  q_conj(qc, qci);
+  q_mul(qci, qn, d);
+  q_as_rotvec(d, rv);
+  rv[0] *= frac; rv[1] *= frac; rv[2] *= frac;
+  q_from_rotvec(rv, dq);
+  q_mul(qc, dq, out + 3);
+  /* base_lin_vel_interpolation ML:137-140 */
+  for (int i = 0; i < 3; i++) out[7 + i] = (fn[i] - fc[i]) / frame_step;
+  /* base_ang_vel_interpolation ML:143-149 : rotvec(qn * qc^-1), axis*angle/dt with the 1e-8 renorm */
+  double e[4], rv2[3];
+  q_mul(qn, qci, e);
+  q_as_rotvec(e, rv2);
+  double angle = sqrt(rv2[0] * rv2[0] + rv2[1] * rv2[1] + rv2[2] * rv2[2]);
+  for (int i = 0; i < 3; i++) out[10 + i] = ((rv2[i] / (angle + 1e-8)) * angle) / frame_step;
+  /* joint_interpolation ML:152-160 */
+  for (int i = 0; i < 12; i++) {
+    out[13 + i] = fc[7 + i] + frac * (fn[7 + i] - fc[7 + i]);
+    out[25 + i] = (fn[7 + i] - fc[7 + i]) / frame_step;
+  }
+}
+
+/* ML:75-86 get_states_info_future; frames points at row `frame_id` of the clip. out: 4 x state37 */
+void orc_mocap_future(const double* frames_at_fid, double frac, double frame_step, double* out) {
+  const double time_future[4] = {1. / 30., 1. / 15., 1. / 3., 1.}; /* ML:44 */
+  for (int i = 0; i < 4; i++) {
+    double t = frame_step * frac + time_future[i];
+    int fid = (int)floor(t / frame_step);
+    double ff = t / frame_step - fid;
+    orc_mocap_interp(frames_at_fid + (size_t)fid * 19, frames_at_fid + (size_t)(fid + 1) * 19, ff, frame_step, out + 37 * i);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* observation (PLE:247-317)                                                                        */
+/* ------------------------------------------------------------------------------------------------ */
+/* PLE:247-260: full prop in the order given by prop_order (LL_PROP_* ids, -1 terminated); returns frame size */
+int orc_prop(const double* s, const int32_t* prop_order, double* out) {
+  double qn[4], R[9];
+  q_normalize(s + 3, qn);
+  q_to_mat(qn, R);
+  int n = 0;
+  for (int k = 0; k < 5 && prop_order[k] >= 0; k++) {
+    switch (prop_order[k]) {
+      case LL_PROP_JOINT_POS: memcpy(out + n, s + 13, 12 * sizeof(double)); n += 12; break;   /* PLE:249 */
+      case LL_PROP_JOINT_VEL: memcpy(out + n, s + 25, 12 * sizeof(double)); n += 12; break;   /* PLE:250 */
+      case LL_PROP_ROOT_LIN_VEL_LOC: m3tv(R, s + 7, out + n); n += 3; break;                   /* PLE:251 R^-1 v */
+      case LL_PROP_ROOT_ANG_VEL_LOC: m3tv(R, s + 10, out + n); n += 3; break;                  /* PLE:252 R^-1 w */
+      case LL_PROP_E_G: out[n] = R[6]; out[n + 1] = R[7]; out[n + 2] = R[8]; n += 3; break;   /* PLE:253 R[2,:] */
+      default: return -1;
+    }
+  }
+  return n;
+}
+
+/* PLE:299-317 calculate_future. fut: 4 x (pos3, quat4, joint_pos12) = 76 doubles -> out 72 */
+void orc_calc_future(const double* base_pos, const double* base_orn, const double* fut, double* out) {
+  double qb[4], qbi[4], Rb[9];
+  q_normalize(base_orn, qb);
+  q_conj(qb, qbi);
+  q_to_mat(qb, Rb);
+  for (int i = 0; i < 4; i++) {
+    const double* f = fut + 19 * i;
+    double qi[4], d[4], axis[3], pd[3];
+    q_normalize(f + 3, qi);
+    q_mul(qbi, qi, d);                                  /* PLE:307 */
+    double angle = quat_axis_angle(d, axis);           /* PLE:308 */
+    for (int k = 0; k < 3; k++) pd[k] = f[k] - base_pos[k];   /* PLE:310 */
+    m3tv(Rb, pd, out + 18 * i);                         /* PLE:311 r_b.inv().apply */
+    for (int k = 0; k < 3; k++) out[18 * i + 3 + k] = axis[k] * angle;   /* PLE:313 */
+    memcpy(out + 18 * i + 6, f + 7, 12 * sizeof(double));                 /* PLE:315 */
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* reward + termination (PLE:319-426, LR:158-179)                                                   */
+/* ------------------------------------------------------------------------------------------------ */
+static double base_angle_between(const double* q_dyn, const double* q_kin) { /* PLE:327-328, :410-411 */
+  double a[4], b[4], bi[4], d[4], axis[3];
+  q_normalize(q_kin, a);
+  q_normalize(q_dyn, b);
+  q_conj(b, bi);
+  q_mul(a, bi, d);
+  return quat_axis_angle(d, axis);
+}
+
+double orc_reward(const double* dyn, const double* kin, const double* feet_dyn, const double* feet_kin, const double* w_in) {
+  double w[5], sw = 0;
+  for (int i = 0; i < 5; i++) sw += w_in[i];             /* PLE:365 */
+  for (int i = 0; i < 5; i++) w[i] = w_in[i] / sw;       /* PLE:366-370 */
+  double e_jp = 0, e_jv = 0, e_ee = 0, e_p = 0, e_v = 0, e_w = 0;
+  for (int i = 0; i < 12; i++) {
+    double d = dyn[13 + i] - kin[13 + i]; e_jp += d * d;             /* PLE:384-386 */
+    double dv = dyn[25 + i] - kin[25 + i]; e_jv += dv * dv;          /* PLE:389-391 */
+    double de = feet_dyn[i] - feet_kin[i]; e_ee += de * de;          /* PLE:402 */
+  }
+  for (int i = 0; i < 3; i++) {
+    double d = dyn[i] - kin[i]; e_p += d * d;                         /* PLE:413 */
+    double dv = dyn[7 + i] - kin[7 + i]; e_v += dv * dv;              /* PLE:418 */
+    double dw = dyn[10 + i] - kin[10 + i]; e_w += dw * dw;            /* PLE:419 */
+  }
+  double angle = base_angle_between(dyn + 3, kin + 3);
+  double r_jp = exp(-1.0 * e_jp), r_jv = exp(-0.1 * e_jv), r_ee = exp(-40.0 * e_ee);           /* PLE:373-375 */
+  double r_pose = exp(-20.0 * e_p + -10.0 * (angle * angle));                                     /* PLE:413-414 */
+  double r_vel = exp(-2 * e_v + -0.2 * e_w);                                                      /* PLE:418-419 */
+  return w[0] * r_jp + w[1] * r_jv + w[2] * r_ee + w[3] * r_pose + w[4] * r_vel;                  /* PLE:421-425 */
+}
+
+int orc_check_fall(const double* quat) { /* LR:158-179 */
+  double qn[4], R[9];
+  q_normalize(quat, qn);
+  q_to_mat(qn, R);
+  double fwd[3] = {R[0], R[3], R[6]}, up[3] = {R[2], R[5], R[8]};
+  double left_z = up[0] * fwd[1] - up[1] * fwd[0];
+  int term = 0;
+  if (left_z > sin(45.0 * M_PI / 180.0) || left_z < sin(-45.0 * M_PI / 180.0)) term = 1;
+  if (up[2] < cos(60.0 * M_PI / 180.0)) term = 1;
+  return term;
+}
+
+int orc_check_diverged(const double* dyn, const double* kin) { /* PLE:319-335 */
+  int term = 0;
+  double angle = base_angle_between(dyn + 3, kin + 3);
+  if (fabs(angle) > 1.0) term = 1;
+  double e = 0;
+  for (int i = 0; i < 3; i++) e += (dyn[i] - kin[i]) * (dyn[i] - kin[i]);
+  if (e > 1.0) term = 1;
+  return term;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* robot model                                                                                      */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int type;
+  double size[3], pos[3], rot[9];
+} OPrim;
+
+typedef struct {
+  int parent[NB];
+  double r[NB][3], axis[NB][3], mass[NB], com[NB][3], Ic[NB][9];
+  double I6[NB][36]; /* spatial inertia about the body origin, body axes */
+  double qlo[12], qhi[12], damp[12], foot[4][3];
+  OPrim base_prims[LLM_N_BASE_PRIMS], leg_prims[4][LLM_N_LEG_PRIMS];
+} OModel;
+
+static void skew(const double* v, double* m) {
+  m[0] = 0; m[1] = -v[2]; m[2] = v[1]; m[3] = v[2]; m[4] = 0; m[5] = -v[0]; m[6] = -v[1]; m[7] = v[0]; m[8] = 0;
+}
+
+static void rigid_inertia(double m, const double* c, const double* Ic, double* I6) {
+  /* [[Ic + m cx cx^T, m cx], [m cx^T, m 1]]  (Featherstone RBDA eq. 2.63) */
+  double cx[9], cxcxT[9];
+  skew(c, cx);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0;
+      for (int k = 0; k < 3; k++) s += cx[3 * i + k] * cx[3 * j + k];
+      cxcxT[3 * i + j] = s;
+    }
+  memset(I6, 0, 36 * sizeof(double));
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      I6[6 * i + j] = Ic[3 * i + j] + m * cxcxT[3 * i + j];
+      I6[6 * i + 3 + j] = m * cx[3 * i + j];
+      I6[6 * (3 + i) + j] = m * cx[3 * j + i];
+    }
+  for (int i = 0; i < 3; i++) I6[6 * (3 + i) + 3 + i] = m;
+}
+
+static void read_prim(const double* b, OPrim* p) {
+  p->type = (int)b[0];
+  memcpy(p->size, b + 1, 24); memcpy(p->pos, b + 4, 24); memcpy(p->rot, b + 7, 72);
+}
+
+static void model_from_blob(const double* b, OModel* M) {
+  memset(M, 0, sizeof *M);
+  M->parent[0] = -1;
+  M->mass[0] = b[LLM_OFF_BASE_MASS];
+  memcpy(M->com[0], b + LLM_OFF_BASE_COM, 24);
+  memcpy(M->Ic[0], b + LLM_OFF_BASE_INERTIA, 72);
+  for (int i = 0; i < 12; i++) {
+    int bi = i + 1;
+    M->parent[bi] = (i % 3 == 0) ? 0 : bi - 1;
+    memcpy(M->r[bi], b + LLM_OFF_JOINT_ORIGIN + 3 * i, 24);
+    memcpy(M->axis[bi], b + LLM_OFF_JOINT_AXIS + 3 * i, 24);
+    M->mass[bi] = b[LLM_OFF_LINK_MASS + i];
+    memcpy(M->com[bi], b + LLM_OFF_LINK_COM + 3 * i, 24);
+    memcpy(M->Ic[bi], b + LLM_OFF_LINK_INERTIA + 9 * i, 72);
+    M->qlo[i] = b[LLM_OFF_Q_LO + i]; M->qhi[i] = b[LLM_OFF_Q_HI + i]; M->damp[i] = b[LLM_OFF_DAMPING + i];
+  }
+  for (int i = 0; i < NB; i++) rigid_inertia(M->mass[i], M->com[i], M->Ic[i], M->I6[i]);
+  memcpy(M->foot, b + LLM_OFF_FOOT_POS, 96);
+  for (int i = 0; i < LLM_N_BASE_PRIMS; i++) read_prim(b + LLM_OFF_BASE_PRIMS + i * LLM_PRIM_STRIDE, &M->base_prims[i]);
+  for (int l = 0; l < 4; l++)
+    for (int i = 0; i < LLM_N_LEG_PRIMS; i++)
+      read_prim(b + LLM_OFF_LEG_PRIMS + (l * LLM_N_LEG_PRIMS + i) * LLM_PRIM_STRIDE, &M->leg_prims[l][i]);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* kinematics                                                                                       */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  double E[NB][9];   /* coordinate rotation parent -> body  ( = (rotation of body in parent)^T ) */
+  double Rw[NB][9];  /* body -> world rotation */
+  double pw[NB][3];  /* body origin in world */
+  double v[NB][6];   /* spatial velocity, body coordinates [ang; lin] */
+} OKin;
+
+static void axis_angle_mat(const double* a, double q, double* m) { /* Rodrigues, rotation by q about unit a */
+  double c = cos(q), s = sin(q), t = 1 - c;
+  m[0] = t * a[0] * a[0] + c; m[1] = t * a[0] * a[1] - s * a[2]; m[2] = t * a[0] * a[2] + s * a[1];
+  m[3] = t * a[0] * a[1] + s * a[2]; m[4] = t * a[1] * a[1] + c; m[5] = t * a[1] * a[2] - s * a[0];
+  m[6] = t * a[0] * a[2] - s * a[1]; m[7] = t * a[1] * a[2] + s * a[0]; m[8] = t * a[2] * a[2] + c;
+}
+
+/* motion transform parent->child: v_c = [E w ; E (v + w x r)] */
+static void xform_motion(const double* E, const double* r, const double* vp, double* vc) {
+  double t[3], u[3];
+  v3cross(vp, r, t);
+  for (int i = 0; i < 3; i++) u[i] = vp[3 + i] + t[i];
+  m3v(E, vp, vc);
+  m3v(E, u, vc + 3);
+}
+/* force transform child->parent: f_p = [E^T n + r x (E^T f) ; E^T f] */
+static void xform_force_T(const double* E, const double* r, const double* fc, double* fp) {
+  double n[3], f[3], t[3];
+  m3tv(E, fc, n);
+  m3tv(E, fc + 3, f);
+  v3cross(r, f, t);
+  for (int i = 0; i < 3; i++) { fp[i] = n[i] + t[i]; fp[3 + i] = f[i]; }
+}
+static void xform_matrix(const double* E, const double* r, double* X) { /* 6x6 [E 0; -E rx, E] */
+  double rx[9], Erx[9];
+  skew(r, rx);
+  m3m(E, rx, Erx);
+  memset(X, 0, 36 * sizeof(double));
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      X[6 * i + j] = E[3 * i + j];
+      X[6 * (3 + i) + 3 + j] = E[3 * i + j];
+      X[6 * (3 + i) + j] = -Erx[3 * i + j];
+    }
+}
+
+/* positions + velocities of every body.  state = LR:86-106 layout; nu (optional) overrides velocities
+ * with generalized body-frame velocity [w_b, v_b, qd] */
+static void kinematics(const OModel* M, const double* state, const double* nu, OKin* K) {
+  double qn[4];
+  q_normalize(state + 3, qn);
+  q_to_mat(qn, K->Rw[0]);
+  memcpy(K->pw[0], state, 24);
+  for (int i = 0; i < 9; i++) K->E[0][i] = (i % 4 == 0);
+  if (nu) {
+    memcpy(K->v[0], nu, 48);
+  } else {
+    m3tv(K->Rw[0], state + 10, K->v[0]);
+    m3tv(K->Rw[0], state + 7, K->v[0] + 3);
+  }
+  for (int b = 1; b < NB; b++) {
+    int p = M->parent[b];
+    double q = state[13 + b - 1], qd = nu ? nu[6 + b - 1] : state[25 + b - 1];
+    double Rj[9], t[3];
+    axis_angle_mat(M->axis[b], q, Rj);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) K->E[b][3 * i + j] = Rj[3 * j + i];
+    m3m(K->Rw[p], Rj, K->Rw[b]);
+    m3v(K->Rw[p], M->r[b], t);
+    for (int i = 0; i < 3; i++) K->pw[b][i] = K->pw[p][i] + t[i];
+    xform_motion(K->E[b], M->r[b], K->v[p], K->v[b]);
+    for (int i = 0; i < 3; i++) K->v[b][i] += M->axis[b][i] * qd;
+  }
+}
+
+/* LR:199-205 compute_end_effector_info: world positions of the 4 foot links */
+void orc_fk_feet_model(const OModel* M, const double* state, double* feet) {
+  OKin K;
+  kinematics(M, state, NULL, &K);
+  for (int l = 0; l < 4; l++) {
+    int b = 3 + 3 * l;
+    double t[3];
+    m3v(K.Rw[b], M->foot[l], t);
+    for (int i = 0; i < 3; i++) feet[3 * l + i] = K.pw[b][i] + t[i];
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* articulated-body algorithm (Featherstone, RBDA table 7.1 + floating base 9.4), body coordinates   */
+/* ------------------------------------------------------------------------------------------------ */
+static void cross_motion(const double* v, const double* m, double* o) { /* v x m */
+  double a[3], b[3], c[3];
+  v3cross(v, m, a);
+  v3cross(v, m + 3, b);
+  v3cross(v + 3, m, c);
+  for (int i = 0; i < 3; i++) { o[i] = a[i]; o[3 + i] = b[i] + c[i]; }
+}
+static void cross_force(const double* v, const double* f, double* o) { /* v x* f */
+  double a[3], b[3], c[3];
+  v3cross(v, f, a);
+  v3cross(v + 3, f + 3, b);
+  v3cross(v, f + 3, c);
+  for (int i = 0; i < 3; i++) { o[i] = a[i] + b[i]; o[3 + i] = c[i]; }
+}
+static void m6v(const double* m, const double* v, double* o) {
+  double t[6];
+  for (int i = 0; i < 6; i++) {
+    double s = 0;
+    for (int j = 0; j < 6; j++) s += m[6 * i + j] * v[j];
+    t[i] = s;
+  }
+  memcpy(o, t, sizeof t);
+}
+static int solve6(const double* A, const double* b, double* x) { /* SPD solve by Cholesky */
+  double L[36];
+  memset(L, 0, sizeof L);
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = A[6 * i + j];
+      for (int k = 0; k < j; k++) s -= L[6 * i + k] * L[6 * j + k];
+      if (i == j) {
+        if (!(s > 0)) return -1;
+        L[6 * i + i] = sqrt(s);
+      } else {
+        L[6 * i + j] = s / L[6 * j + j];
+      }
+    }
+  double y[6];
+  for (int i = 0; i < 6; i++) {
+    double s = b[i];
+    for (int k = 0; k < i; k++) s -= L[6 * i + k] * y[k];
+    y[i] = s / L[6 * i + i];
+  }
+  for (int i = 5; i >= 0; i--) {
+    double s = y[i];
+    for (int k = i + 1; k < 6; k++) s -= L[6 * k + i] * x[k];
+    x[i] = s / L[6 * i + i];
+  }
+  return 0;
+}
+
+/* fext[b] = external spatial force acting ON body b, body coordinates (NULL = none).
+ * out: a0 = spatial acceleration of the base (body coords), qdd[12].  with_bias=0 drops velocity terms. */
+static int aba(const OModel* M, const OKin* K, const double* qd, const double* tau, const double (*fext)[6],
+               int with_bias, double* a0, double* qdd) {
+  double IA[NB][36], pA[NB][6], c[NB][6], U[NB][6], D[NB], u[NB];
+  for (int b = 0; b < NB; b++) {
+    memcpy(IA[b], M->I6[b], sizeof IA[b]);
+    double Iv[6];
+    if (with_bias) {
+      m6v(M->I6[b], K->v[b], Iv);
+      cross_force(K->v[b], Iv, pA[b]);
+    } else {
+      memset(pA[b], 0, sizeof pA[b]);
+    }
+    if (fext)
+      for (int i = 0; i < 6; i++) pA[b][i] -= fext[b][i];
+    memset(c[b], 0, sizeof c[b]);
+    if (b > 0 && with_bias) {
+      double Sqd[6] = {M->axis[b][0] * qd[b - 1], M->axis[b][1] * qd[b - 1], M->axis[b][2] * qd[b - 1], 0, 0, 0};
+      cross_motion(K->v[b], Sqd, c[b]);
+    }
+  }
+  for (int b = NB - 1; b >= 1; b--) {
+    int p = M->parent[b];
+    double S[6] = {M->axis[b][0], M->axis[b][1], M->axis[b][2], 0, 0, 0};
+    m6v(IA[b], S, U[b]);
+    D[b] = 0;
+    for (int i = 0; i < 6; i++) D[b] += S[i] * U[b][i];
+    double sp = 0;
+    for (int i = 0; i < 6; i++) sp += S[i] * pA[b][i];
+    u[b] = tau[b - 1] - sp;
+    double Ia[36], pa[6], Iac[6];
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) Ia[6 * i + j] = IA[b][6 * i + j] - U[b][i] * U[b][j] / D[b];
+    m6v(Ia, c[b], Iac);
+    for (int i = 0; i < 6; i++) pa[i] = pA[b][i] + Iac[i] + U[b][i] * u[b] / D[b];
+    double X[36], XtIa[36], fp[6];
+    xform_matrix(K->E[b], M->r[b], X);
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) {
+        double s = 0;
+        for (int k = 0; k < 6; k++) s += X[6 * k + i] * Ia[6 * k + j];
+        XtIa[6 * i + j] = s;
+      }
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) {
+        double s = 0;
+        for (int k = 0; k < 6; k++) s += XtIa[6 * i + k] * X[6 * k + j];
+        IA[p][6 * i + j] += s;
+      }
+    xform_force_T(K->E[b], M->r[b], pa, fp);
+    for (int i = 0; i < 6; i++) pA[p][i] += fp[i];
+  }
+  double rhs[6], a[NB][6];
+  for (int i = 0; i < 6; i++) rhs[i] = -pA[0][i];
+  if (solve6(IA[0], rhs, a[0])) return -1;
+  for (int b = 1; b < NB; b++) {
+    int p = M->parent[b];
+    double ap[6];
+    xform_motion(K->E[b], M->r[b], a[p], ap);
+    for (int i = 0; i < 6; i++) ap[i] += c[b][i];
+    double s = 0;
+    for (int i = 0; i < 6; i++) s += U[b][i] * ap[i];
+    qdd[b - 1] = (u[b] - s) / D[b];
+    for (int i = 0; i < 6; i++) a[b][i] = ap[i];
+    for (int i = 0; i < 3; i++) a[b][i] += M->axis[b][i] * qdd[b - 1];
+  }
+  memcpy(a0, a[0], 48);
+  return 0;
+}
+
+/* gravity + Bullet's per-link velocity damping as external spatial forces (body coords) */
+static double g_link_damping = LLM_LINK_DAMPING;
+void orc_set_link_damping(double k) { g_link_damping = k; } /* tests: 0 makes free flight conservative */
+static void external_forces(const OModel* M, const OKin* K, double (*fext)[6]) {
+  const double k1 = g_link_damping, k2 = g_link_damping;
+  for (int b = 0; b < NB; b++) {
+    const double* w = K->v[b];
+    double vc[3], t[3], f[3], n[3], Iw[3], gw[3] = {0, 0, -M->mass[b] * LLM_GRAVITY}, gb[3];
+    v3cross(w, M->com[b], t);
+    for (int i = 0; i < 3; i++) vc[i] = K->v[b][3 + i] + t[i];
+    double sv = sqrt(v3dot(vc, vc)), sw = sqrt(v3dot(w, w));
+    m3tv(K->Rw[b], gw, gb);
+    m3v(M->Ic[b], w, Iw);
+    for (int i = 0; i < 3; i++) {
+      f[i] = gb[i] - M->mass[b] * vc[i] * (k1 + k2 * sv);
+      n[i] = -Iw[i] * (k1 + k2 * sw);
+    }
+    v3cross(M->com[b], f, t);
+    for (int i = 0; i < 3; i++) { fext[b][i] = n[i] + t[i]; fext[b][3 + i] = f[i]; }
+  }
+}
+
+/* unconstrained forward dynamics: generalized acceleration [a0(6) body-coord spatial ; qdd(12)] */
+int orc_forward_dynamics_model(const OModel* M, const double* state, const double* tau, double* acc18) {
+  OKin K;
+  double fext[NB][6];
+  kinematics(M, state, NULL, &K);
+  external_forces(M, &K, fext);
+  return aba(M, &K, state + 25, tau, fext, 1, acc18, acc18 + 6);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* contacts                                                                                         */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int body;       /* body index the point is attached to */
+  double P[3];    /* world position of the contact point on the robot surface */
+  double depth;   /* signed distance to the plane z=0 (negative = penetrating) */
+  double mu;
+  int leg, slot;
+} OContact;
+
+static int add_candidate(OContact* out, int n, int* nleg, int leg, int body, const double* P, double mu) {
+  if (P[2] < LLM_CONTACT_MARGIN && *nleg < KC) {
+    out[n].body = body; memcpy(out[n].P, P, 24); out[n].depth = P[2]; out[n].mu = mu; out[n].leg = leg; out[n].slot = *nleg;
+    (*nleg)++;
+    return n + 1;
+  }
+  return n;
+}
+
+/* candidate points of one primitive attached to a body with pose (Rw, pw); calls add for each */
+static int prim_candidates(const OPrim* p, const double* Rw, const double* pw, OContact* out, int n, int* nleg, int leg,
+                           int body, double mu, int only_vertex_mask) {
+  double c[3], t[3], Rp[9];
+  m3v(Rw, p->pos, t);
+  for (int i = 0; i < 3; i++) c[i] = pw[i] + t[i];
+  m3m(Rw, p->rot, Rp); /* prim -> world */
+  if (p->type == LLM_PRIM_SPHERE) {
+    double P[3] = {c[0], c[1], c[2] - p->size[0]};
+    n = add_candidate(out, n, nleg, leg, body, P, mu);
+  } else if (p->type == LLM_PRIM_BOX) {
+    for (int j = 0; j < 8; j++) {
+      if (only_vertex_mask >= 0 && (j & 3) != only_vertex_mask) continue;
+      double l[3] = {(j & 1) ? p->size[0] : -p->size[0], (j & 2) ? p->size[1] : -p->size[1], (j & 4) ? p->size[2] : -p->size[2]};
+      double P[3];
+      m3v(Rp, l, P);
+      for (int i = 0; i < 3; i++) P[i] += c[i];
+      n = add_candidate(out, n, nleg, leg, body, P, mu);
+    }
+  } else { /* cylinder, axis = local z: deepest rim point of each cap */
+    double a[3] = {Rp[2], Rp[5], Rp[8]};
+    double proj[3] = {-a[2] * a[0], -a[2] * a[1], 1.0 - a[2] * a[2]}; /* n - (n.a) a, n = +z */
+    double len = sqrt(v3dot(proj, proj)), dir[3];
+    if (len < 1e-6) { dir[0] = Rp[0]; dir[1] = Rp[3]; dir[2] = Rp[6]; }
+    else { for (int i = 0; i < 3; i++) dir[i] = proj[i] / len; }
+    for (int s = 0; s < 2; s++) {
+      double sg = s ? -1.0 : 1.0, P[3];
+      for (int i = 0; i < 3; i++) P[i] = c[i] + sg * p->size[1] * a[i] - p->size[0] * dir[i];
+      n = add_candidate(out, n, nleg, leg, body, P, mu);
+    }
+  }
+  return n;
+}
+
+/* DESIGN.md "contact candidates": per leg lane, fixed priority order, first KC within the margin */
+static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double mu_link, OContact* out) {
+  static const int order[LLM_N_LEG_PRIMS] = {6, 5, 4, 1, 2, 3, 0};
+  static const int links[LLM_N_LEG_PRIMS] = LLM_LEG_PRIM_LINKS;
+  int n = 0;
+  for (int l = 0; l < 4; l++) {
+    int nleg = 0;
+    for (int k = 0; k < LLM_N_LEG_PRIMS; k++) {
+      int pi = order[k], body = 1 + 3 * l + links[pi];
+      n = prim_candidates(&M->leg_prims[l][pi], K->Rw[body], K->pw[body], out, n, &nleg, l, body, pi == 6 ? mu_foot : mu_link, -1);
+    }
+    /* base candidates owned by this lane: box vertices j with (j&3)==l, front handle -> lane 0, hind -> lane 2 */
+    n = prim_candidates(&M->base_prims[0], K->Rw[0], K->pw[0], out, n, &nleg, l, 0, mu_link, l);
+    if (l == 0) n = prim_candidates(&M->base_prims[1], K->Rw[0], K->pw[0], out, n, &nleg, l, 0, mu_link, -1);
+    if (l == 2) n = prim_candidates(&M->base_prims[2], K->Rw[0], K->pw[0], out, n, &nleg, l, 0, mu_link, -1);
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* one physics substep  ==  what stepSimulation() does at PLE:206 (spec: DESIGN.md)                  */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int n_contacts, n_rows;
+  double lambda[MAXROWS];
+  double acc_free[NDOF];
+} OSubstepDiag;
+
+int orc_substep_model(const OModel* M, double dt, int n_iter, double mu_foot, double* state, const double* tau_in,
+                      OSubstepDiag* diag) {
+  OKin K;
+  double fext[NB][6], acc[NDOF], tau[12];
+  kinematics(M, state, NULL, &K);
+  external_forces(M, &K, fext);
+  for (int i = 0; i < 12; i++) tau[i] = tau_in[i] - M->damp[i] * state[25 + i]; /* URDF joint damping (Bullet adds -d*qd) */
+  if (aba(M, &K, state + 25, tau, fext, 1, acc, acc + 6)) return -1;
+  if (diag) memcpy(diag->acc_free, acc, sizeof acc);
+
+  /* velocities after the unconstrained update, generalized body-frame coordinates nu = [w_b, v_b, qd] */
+  double nu[NDOF], wxv[3];
+  v3cross(K.v[0], K.v[0] + 3, wxv);
+  for (int i = 0; i < 3; i++) {
+    nu[i] = K.v[0][i] + dt * acc[i];
+    nu[3 + i] = K.v[0][3 + i] + dt * (acc[3 + i] + wxv[i]) - 0.0; /* classical accel of the origin, frozen frame */
+  }
+  /* NOTE: d/dt(world velocity) = R (a_lin + w x v); expressed in the (frozen) body frame of this substep */
+  for (int i = 0; i < 12; i++) nu[6 + i] = state[25 + i] + dt * acc[6 + i];
+
+  /* ---- constraint rows --------------------------------------------------------------------------- */
+  OContact C[MAXC];
+  int nc = find_contacts(M, &K, mu_foot, LLM_LINK_FRICTION * LLM_PLANE_FRICTION, C);
+  static double J[MAXROWS][NDOF], MiJt[MAXROWS][NDOF], A[MAXROWS][MAXROWS];
+  double bias[MAXROWS], lo[MAXROWS], hi[MAXROWS], lam[MAXROWS];
+  int fric_of[MAXROWS]; double mu_row[MAXROWS];
+  int nr = 0;
+  /* joint limits: one unilateral row per joint toward its nearer limit (URDF <limit>, Bullet btMultiBodyJointLimitConstraint) */
+  for (int i = 0; i < 12; i++) {
+    double dl = state[13 + i] - M->qlo[i], dh = M->qhi[i] - state[13 + i];
+    double d = dl <= dh ? dl : dh, sgn = dl <= dh ? 1.0 : -1.0;
+    memset(J[nr], 0, sizeof J[nr]);
+    J[nr][6 + i] = sgn;
+    bias[nr] = d > 0 ? d / dt : LLM_ERP * d / dt;
+    lo[nr] = 0; hi[nr] = INFINITY; fric_of[nr] = -1; mu_row[nr] = 0;
+    nr++;
+  }
+  /* contacts: normal + two friction rows, directions n=+z, t1=(0,-1,0), t2=(1,0,0) (btPlaneSpace1 of +z) */
+  static const double dirs[3][3] = {{0, 0, 1}, {0, -1, 0}, {1, 0, 0}};
+  for (int c = 0; c < nc; c++) {
+    int b = C[c].body;
+    double ploc[3], d3[3];
+    for (int i = 0; i < 3; i++) d3[i] = C[c].P[i] - K.pw[b][i];
+    m3tv(K.Rw[b], d3, ploc);
+    for (int r = 0; r < 3; r++) {
+      for (int d = 0; d < NDOF; d++) {
+        double e[NDOF];
+        memset(e, 0, sizeof e);
+        e[d] = 1.0;
+        OKin Kd;
+        kinematics(M, state, e, &Kd);
+        double t[3], vl[3], vw[3];
+        v3cross(Kd.v[b], ploc, t);
+        for (int i = 0; i < 3; i++) vl[i] = Kd.v[b][3 + i] + t[i];
+        m3v(K.Rw[b], vl, vw);
+        J[nr][d] = v3dot(dirs[r], vw);
+      }
+      if (r == 0) {
+        bias[nr] = C[c].depth > 0 ? C[c].depth / dt : LLM_ERP * C[c].depth / dt;
+        lo[nr] = 0; hi[nr] = INFINITY; fric_of[nr] = -1; mu_row[nr] = 0;
+      } else {
+        bias[nr] = 0; lo[nr] = 0; hi[nr] = 0; fric_of[nr] = nr - r; mu_row[nr] = C[c].mu;
+      }
+      nr++;
+    }
+  }
+  /* M^-1 J^T by unit responses of the ABA at zero velocity */
+  {
+    static double Minv[NDOF][NDOF];
+    double zero12[12] = {0};
+    for (int d = 0; d < NDOF; d++) {
+      double fe[NB][6], t12[12] = {0}, col[NDOF];
+      memset(fe, 0, sizeof fe);
+      if (d < 6) fe[0][d] = 1.0; else t12[d - 6] = 1.0;
+      if (aba(M, &K, zero12, t12, fe, 0, col, col + 6)) return -1;
+      for (int i = 0; i < NDOF; i++) Minv[i][d] = col[i];
+    }
+    for (int r = 0; r < nr; r++)
+      for (int i = 0; i < NDOF; i++) {
+        double s = 0;
+        for (int k = 0; k < NDOF; k++) s += Minv[i][k] * J[r][k];
+        MiJt[r][i] = s;
+      }
+    for (int r = 0; r < nr; r++)
+      for (int s2 = 0; s2 < nr; s2++) {
+        double s = 0;
+        for (int k = 0; k < NDOF; k++) s += J[r][k] * MiJt[s2][k];
+        A[r][s2] = s;
+      }
+  }
+  /* projected Gauss-Seidel, LR:261 numSolverIterations (10); rows in order: limits, then per contact n,t1,t2 */
+  double v0[MAXROWS];
+  for (int r = 0; r < nr; r++) {
+    double s = 0;
+    for (int k = 0; k < NDOF; k++) s += J[r][k] * nu[k];
+    v0[r] = s; lam[r] = 0;
+  }
+  for (int it = 0; it < n_iter; it++) {
+    for (int r = 0; r < nr; r++) {
+      double w = v0[r] + bias[r];
+      for (int s2 = 0; s2 < nr; s2++) w += A[r][s2] * lam[s2];
+      double l_new = lam[r] - w / A[r][r];
+      double l_lo = lo[r], l_hi = hi[r];
+      if (fric_of[r] >= 0) { l_hi = mu_row[r] * lam[fric_of[r]]; l_lo = -l_hi; }
+      if (l_new < l_lo) l_new = l_lo;
+      if (l_new > l_hi) l_new = l_hi;
+      lam[r] = l_new;
+    }
+  }
+  for (int r = 0; r < nr; r++)
+    for (int k = 0; k < NDOF; k++) nu[k] += MiJt[r][k] * lam[r];
+  if (diag) { diag->n_contacts = nc; diag->n_rows = nr; memcpy(diag->lambda, lam, nr * sizeof(double)); }
+
+  /* ---- integrate positions with the NEW velocities (semi-implicit Euler) -------------------------- */
+  double vw[3], ww[3];
+  m3v(K.Rw[0], nu, ww);
+  m3v(K.Rw[0], nu + 3, vw);
+  for (int i = 0; i < 3; i++) { state[7 + i] = vw[i]; state[10 + i] = ww[i]; state[i] += dt * vw[i]; }
+  double rv[3] = {ww[0] * dt, ww[1] * dt, ww[2] * dt}, dq[4], qn[4], qo[4];
+  q_from_rotvec(rv, dq);
+  q_normalize(state + 3, qn);
+  q_mul(dq, qn, qo);
+  q_normalize(qo, state + 3);
+  for (int i = 0; i < 12; i++) { state[25 + i] = nu[6 + i]; state[13 + i] += dt * nu[6 + i]; }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* the environment (PLE:26-435) -- a batch of envs sharing one prioritized-sampling table            */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  double state[37], kin[37], time, reward_sum, frac;
+  double hist_prop[LL_STACK][LL_PROP_FRAME_MAX], hist_act[LL_STACK][12];
+  int hist_n, clip, frame_id, ep_steps, done_reason;
+  double feet_dyn[12], feet_kin[12];
+} OEnv;
+
+typedef struct {
+  OModel model;
+  ll_config cfg;
+  int n_envs, n_clips, frame_rate, margin, n_sub, prop_dim, obs_dim;
+  double dt, policy_step, frame_step, mu_foot;
+  double* frames;     /* [total][19] */
+  int32_t *clip_off, *clip_len;
+  double *max_steps, *prob, *avg_reward_sum, *avg_episode_len;
+  OEnv* envs;
+} OBatch;
+
+OBatch* orc_create(const ll_config* cfg, const double* blob, int blob_len) {
+  if (blob_len != LLM_BLOB_LEN || cfg->abi_version != LL_ABI_VERSION) return NULL;
+  OBatch* B = (OBatch*)calloc(1, sizeof(OBatch));
+  model_from_blob(blob, &B->model);
+  B->cfg = *cfg;
+  B->n_envs = cfg->n_envs;
+  B->policy_step = 1.0 / cfg->control_freq;                      /* PLE:47 */
+  B->dt = 1.0 / cfg->sim_freq;                                   /* PLE:49 */
+  B->n_sub = (int)(B->policy_step / B->dt);                      /* PLE:52 */
+  B->mu_foot = cfg->foot_lateral_friction * LLM_PLANE_FRICTION;  /* LR:304-308 x plane.urdf:5 */
+  B->prop_dim = 0;
+  for (int k = 0; k < 5 && cfg->prop_order[k] >= 0; k++)
+    B->prop_dim += (cfg->prop_order[k] <= LL_PROP_JOINT_VEL) ? 12 : 3;    /* PLE:102-111 */
+  B->obs_dim = LL_STACK * B->prop_dim + LL_STACK * 12 + LL_FUTURE_DIM;   /* PLE:114-121 */
+  B->envs = (OEnv*)calloc(B->n_envs, sizeof(OEnv));
+  return B;
+}
+
+void orc_destroy(OBatch* B) {
+  if (!B) return;
+  free(B->frames); free(B->clip_off); free(B->clip_len); free(B->max_steps); free(B->prob);
+  free(B->avg_reward_sum); free(B->avg_episode_len); free(B->envs); free(B);
+}
+
+int orc_obs_dim(const OBatch* B) { return B->obs_dim; }
+
+/* ML:19-46 */
+int orc_load_mocap(OBatch* B, const double* frames, const int32_t* clip_len, int n_clips, double frame_step) {
+  size_t total = 0;
+  for (int c = 0; c < n_clips; c++) total += clip_len[c];
+  B->frames = (double*)malloc(total * 19 * sizeof(double));
+  memcpy(B->frames, frames, total * 19 * sizeof(double));
+  B->n_clips = n_clips;
+  B->clip_len = (int32_t*)malloc(n_clips * 4); B->clip_off = (int32_t*)malloc(n_clips * 4);
+  B->max_steps = (double*)malloc(n_clips * 8); B->prob = (double*)malloc(n_clips * 8);
+  B->avg_reward_sum = (double*)calloc(n_clips, 8); B->avg_episode_len = (double*)calloc(n_clips, 8);
+  B->frame_step = frame_step;                                            /* ML:33 */
+  B->frame_rate = (int)(1.0 / frame_step);                               /* ML:34 */
+  B->margin = (int)ceil(B->policy_step / frame_step) + B->frame_rate + 2; /* ML:35 */
+  int off = 0;
+  for (int c = 0; c < n_clips; c++) {
+    B->clip_len[c] = clip_len[c]; B->clip_off[c] = off; off += clip_len[c];
+    B->max_steps[c] = (clip_len[c] - B->margin) * frame_step / B->policy_step;   /* ML:45 */
+    B->prob[c] = 1.0 / n_clips;                                                  /* ML:46 */
+  }
+  return 0;
+}
+
+static const double* clip_row(const OBatch* B, int clip, int fid) { return B->frames + ((size_t)B->clip_off[clip] + fid) * 19; }
+
+/* PLE:276-297 _prepare_obs */
+static void prepare_obs(OBatch* B, OEnv* e, const double* action, double* obs) {
+  double fut4[4 * 37], fut[76], prop[LL_PROP_FRAME_MAX];
+  orc_mocap_future(clip_row(B, e->clip, e->frame_id), e->frac, B->frame_step, fut4);     /* PLE:166/222 */
+  for (int i = 0; i < 4; i++) {
+    memcpy(fut + 19 * i, fut4 + 37 * i, 7 * 8);
+    memcpy(fut + 19 * i + 7, fut4 + 37 * i + 13, 12 * 8);
+  }
+  int P = B->prop_dim;
+  orc_prop(e->state, B->cfg.prop_order, prop);
+  if (e->hist_n == 0) {                                  /* PLE:282-283, :287-288 deque pre-fill */
+    for (int k = 0; k < LL_STACK; k++) { memcpy(e->hist_prop[k], prop, P * 8); memcpy(e->hist_act[k], action, 96); }
+    e->hist_n = LL_STACK;
+  } else {                                               /* PLE:284, :289 append to a maxlen-3 deque */
+    for (int k = 0; k < LL_STACK - 1; k++) { memcpy(e->hist_prop[k], e->hist_prop[k + 1], P * 8); memcpy(e->hist_act[k], e->hist_act[k + 1], 96); }
+    memcpy(e->hist_prop[LL_STACK - 1], prop, P * 8); memcpy(e->hist_act[LL_STACK - 1], action, 96);
+  }
+  for (int k = 0; k < LL_STACK; k++) {
+    memcpy(obs + k * P, e->hist_prop[k], P * 8);
+    memcpy(obs + LL_STACK * P + 12 * k, e->hist_act[k], 96);
+  }
+  orc_calc_future(e->state, e->state + 3, fut, obs + LL_STACK * P + LL_STACK * 12);
+}
+
+/* PLE:150-171 with explicit (clip, t0) -- the parity mode of SURVEY 8c; obs_out [obs_dim] */
+int orc_reset_env(OBatch* B, int env, int clip, double t0, double* obs_out) {
+  if (env < 0 || env >= B->n_envs || clip < 0 || clip >= B->n_clips) return LL_EINVAL;
+  OEnv* e = &B->envs[env];
+  e->clip = clip; e->time = t0; e->reward_sum = 0; e->ep_steps = 0; e->hist_n = 0; e->done_reason = 0;
+  orc_mocap_locate(t0, B->frame_step, &e->frame_id, &e->frac);                              /* ML:52-53 */
+  orc_mocap_interp(clip_row(B, clip, e->frame_id), clip_row(B, clip, e->frame_id + 1), e->frac, B->frame_step, e->kin);
+  memcpy(e->state, e->kin, sizeof e->kin);                                                  /* PLE:162-163 */
+  double zero[12] = {0};
+  prepare_obs(B, e, zero, obs_out);                                                         /* PLE:168-170 */
+  return 0;
+}
+
+/* upper bound of the start-time window of a clip, ML:50 */
+double orc_motion_duration(const OBatch* B, int clip) { return B->frame_step * (B->clip_len[clip] - B->margin - 1); }
+
+/*
+ * PLE:195-245 for one env.  scripted_dyn / feet_* (nullable) replace the physics result / FK, which is
+ * how the golden harness (fake BulletClient) drove the reference.
+ */
+int orc_step_env(OBatch* B, int env, const double* action, const double* scripted_dyn, const double* feet_dyn_in,
+                 const double* feet_kin_in, double* obs_out, double* reward_out, int* done_out) {
+  OEnv* e = &B->envs[env];
+  e->ep_steps += 1;                                                       /* PLE:197 */
+  double tgt[12], tau[12];
+  for (int i = 0; i < 12; i++) {
+    tgt[i] = e->state[13 + i] + action[i];                                /* PLE:199-200 */
+    if (tgt[i] > 3.0) tgt[i] = 3.0;                                       /* LR:126-127 */
+    if (tgt[i] < -3.0) tgt[i] = -3.0;
+  }
+  int bad = 0;
+  for (int s = 0; s < B->n_sub; s++) {                                    /* PLE:202 */
+    for (int i = 0; i < 12; i++) {                                        /* LR:137-141 */
+      double t = B->cfg.kp * (tgt[i] - e->state[13 + i]) + B->cfg.kd * (0.0 - e->state[25 + i]);
+      if (t > B->cfg.max_tau) t = B->cfg.max_tau;
+      if (t < -B->cfg.max_tau) t = -B->cfg.max_tau;
+      tau[i] = t;
+    }
+    if (!scripted_dyn)
+      if (orc_substep_model(&B->model, B->dt, B->cfg.solver_iterations, B->mu_foot, e->state, tau, NULL)) bad = 1;   /* PLE:206 */
+    orc_mocap_locate(e->time, B->frame_step, &e->frame_id, &e->frac);      /* PLE:208 (time BEFORE the increment, quirk Q2) */
+    e->time += B->dt;                                                      /* PLE:210 */
+  }
+  if (scripted_dyn) memcpy(e->state, scripted_dyn, sizeof e->state);
+  for (int i = 0; i < 37; i++) if (!isfinite(e->state[i])) bad = 1;
+  orc_mocap_interp(clip_row(B, e->clip, e->frame_id), clip_row(B, e->clip, e->frame_id + 1), e->frac, B->frame_step, e->kin); /* PLE:217-218 */
+  prepare_obs(B, e, action, obs_out);                                      /* PLE:221-227 (raw action, quirk Q3) */
+  if (feet_dyn_in) memcpy(e->feet_dyn, feet_dyn_in, 96); else orc_fk_feet_model(&B->model, e->state, e->feet_dyn);   /* PLE:397 */
+  if (feet_kin_in) memcpy(e->feet_kin, feet_kin_in, 96); else orc_fk_feet_model(&B->model, e->kin, e->feet_kin);     /* PLE:398 */
+  double r = orc_reward(e->state, e->kin, e->feet_dyn, e->feet_kin, B->cfg.reward_weights);                          /* PLE:230 */
+  e->reward_sum += r;                                                      /* PLE:231 */
+  int reason = 0;
+  if (orc_check_fall(e->state + 3)) reason |= LL_DONE_FALL;                                     /* PLE:338 */
+  if (e->frame_id >= B->clip_len[e->clip] - B->margin - 1) reason |= LL_DONE_CLIP_END;          /* PLE:339, ML:168-172 */
+  if (orc_check_diverged(e->state, e->kin)) reason |= LL_DONE_DIVERGED;                         /* PLE:340 */
+  if (bad) reason |= LL_DONE_NONFINITE;
+  e->done_reason = reason;
+  if (reason) {                                                            /* PLE:235-240 */
+    int c = e->clip;
+    B->avg_reward_sum[c] = e->reward_sum / B->max_steps[c];
+    B->avg_episode_len[c] = e->ep_steps / (B->max_steps[c] + 1);
+    double sum = 0;
+    for (int k = 0; k < B->n_clips; k++) { B->prob[k] = pow(1 - B->avg_reward_sum[k], B->cfg.prioritized_sample_factor); sum += B->prob[k]; }
+    for (int k = 0; k < B->n_clips; k++) B->prob[k] /= sum;
+  }
+  *reward_out = r;
+  *done_out = reason != 0;
+  return 0;
+}
+
+/* accessors used by the tests */
+void orc_get_state(const OBatch* B, int env, double* s37) { memcpy(s37, B->envs[env].state, 37 * 8); }
+void orc_set_state(OBatch* B, int env, const double* s37) { memcpy(B->envs[env].state, s37, 37 * 8); }
+void orc_get_ref_state(const OBatch* B, int env, double* s37) { memcpy(s37, B->envs[env].kin, 37 * 8); }
+void orc_get_feet(const OBatch* B, int env, double* fd, double* fk) { memcpy(fd, B->envs[env].feet_dyn, 96); memcpy(fk, B->envs[env].feet_kin, 96); }
+void orc_get_episode_info(const OBatch* B, int env, int32_t* clip, double* time, int32_t* steps, double* rsum, int32_t* reason, int32_t* frame_id, double* frac) {
+  const OEnv* e = &B->envs[env];
+  *clip = e->clip; *time = e->time; *steps = e->ep_steps; *rsum = e->reward_sum; *reason = e->done_reason; *frame_id = e->frame_id; *frac = e->frac;
+}
+void orc_get_sampling_table(const OBatch* B, double* prob, double* avg_r, double* avg_len) {
+  memcpy(prob, B->prob, B->n_clips * 8); memcpy(avg_r, B->avg_reward_sum, B->n_clips * 8); memcpy(avg_len, B->avg_episode_len, B->n_clips * 8);
+}
+void orc_set_sampling_table(OBatch* B, const double* prob, const double* avg_r) {
+  memcpy(B->prob, prob, B->n_clips * 8); memcpy(B->avg_reward_sum, avg_r, B->n_clips * 8);
+}
+void orc_get_margin(const OBatch* B, int32_t* margin, int32_t* frame_rate, double* max_steps) {
+  *margin = B->margin; *frame_rate = B->frame_rate; memcpy(max_steps, B->max_steps, B->n_clips * 8);
+}
+
+/* thin wrappers taking the batch's model (ctypes-friendly) */
+void orc_fk_feet(const OBatch* B, const double* state, double* feet) { orc_fk_feet_model(&B->model, state, feet); }
+int orc_forward_dynamics(const OBatch* B, const double* state, const double* tau, double* acc18) {
+  return orc_forward_dynamics_model(&B->model, state, tau, acc18);
+}
+int orc_substep(const OBatch* B, double* state, const double* tau, int32_t* n_contacts, double* lambda_out, double* acc_free) {
+  OSubstepDiag d;
+  int rc = orc_substep_model(&B->model, B->dt, B->cfg.solver_iterations, B->mu_foot, state, tau, &d);
+  if (n_contacts) *n_contacts = d.n_contacts;
+  if (lambda_out) memcpy(lambda_out, d.lambda, d.n_rows * sizeof(double));
+  if (acc_free) memcpy(acc_free, d.acc_free, sizeof d.acc_free);
+  return rc;
+}
+/* inverse-dynamics style check value: kinetic + potential energy of a state (tests) */
+double orc_energy(const OBatch* B, const double* state) {
+  const OModel* M = &B->model;
+  OKin K;
+  kinematics(M, state, NULL, &K);
+  double E = 0;
+  for (int b = 0; b < NB; b++) {
+    double Iv[6];
+    m6v(M->I6[b], K.v[b], Iv);
+    double ke = 0;
+    for (int i = 0; i < 6; i++) ke += 0.5 * K.v[b][i] * Iv[i];
+    double cw[3];
+    m3v(K.Rw[b], M->com[b], cw);
+    E += ke + M->mass[b] * LLM_GRAVITY * (K.pw[b][2] + cw[2]);
+  }
+  return E;
+}
+
+/* linear momentum (world) and angular momentum about the world origin (tests) */
+void orc_momentum(const OBatch* B, const double* state, double* out6) {
+  const OModel* M = &B->model;
+  OKin K;
+  kinematics(M, state, NULL, &K);
+  memset(out6, 0, 48);
+  for (int b = 0; b < NB; b++) {
+    double h[6], n[3], f[3], t[3];
+    m6v(M->I6[b], K.v[b], h);              /* spatial momentum about the body origin, body coords */
+    m3v(K.Rw[b], h, n);
+    m3v(K.Rw[b], h + 3, f);
+    v3cross(K.pw[b], f, t);
+    for (int i = 0; i < 3; i++) { out6[i] += f[i]; out6[3 + i] += n[i] + t[i]; }
+  }
+}
+
+/* step every env (index order), as bench.py's cpu_baseline leg times it */
+int orc_step_all(OBatch* B, const double* actions, double* obs, double* reward, int32_t* done) {
+  for (int i = 0; i < B->n_envs; i++) {
+    int d;
+    orc_step_env(B, i, actions + 12 * i, NULL, NULL, NULL, obs + (size_t)B->obs_dim * i, reward + i, &d);
+    done[i] = d;
+  }
+  return 0;
+}

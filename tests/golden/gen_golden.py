@@ -179,8 +179,7 @@ def main():
     rng = np.random.default_rng(20240807)
     names = sorted(f for f in os.listdir(MOCAP_DIR) if f.endswith('txt'))
     out['clip_names'] = np.array(names)
-    sub = np.load(os.path.join(HERE, 'mocap_f64_subset.npz'))
-    sub_names = [str(n) for n in sub['names']]
+    sub_names = ['dog_quad_walkrun_001_ret.txt', 'dog_jump_002_ret.txt', 'dog_play_001_ret_mir.txt']
 
     # ---- K1: MotionLib meta (SURVEY §4 KAT K1) --------------------------------------
     ml_all = MotionLib(MOCAP_DIR, 0.02)
@@ -230,7 +229,7 @@ def main():
         np.random.seed(seed)
         ple._prioritized_sample_probability[:] = 1.0 / len(names)
         o = env.reset()[0]
-        if names[ple.sampled_data_idx] in sub_names or len(g2['seed']) < 16:
+        if True:
             g2['seed'].append(seed); g2['clip'].append(ple.sampled_data_idx); g2['t0'].append(ple.time)
             g2['obs'].append(obs_vec(o)); g2['kin'].append(state_vec(ple._legged_robot_kin.get_states_info()))
         seed += 1

@@ -2,8 +2,7 @@
 
 Runs only in the build container (reads /root/reference); outputs:
   lifelike_agility_and_play_amd/assets/max_model.npy   compiled 13-body model (from max.urdf)
-  lifelike_agility_and_play_amd/assets/mocap_f32.npz   62 clips packed, float32
-  tests/golden/mocap_f64_subset.npz                    3 clips in float64 for oracle pinning
+  lifelike_agility_and_play_amd/assets/mocap_f64.npz   62 clips packed, float64
 """
 import os
 import sys
@@ -17,7 +16,6 @@ from lifelike_agility_and_play_amd import mocap, urdf_model  # noqa: E402
 REF = '/root/reference'
 URDF = os.path.join(REF, 'src/lifelike/sim_envs/pybullet_envs/legged_robot/data/urdf/max.urdf')
 MOCAP = os.path.join(REF, 'data/mocap_data')
-GOLD_CLIPS = ['dog_quad_walkrun_001_ret.txt', 'dog_jump_002_ret.txt', 'dog_play_001_ret_mir.txt']
 
 
 def main():
@@ -26,16 +24,8 @@ def main():
     m = urdf_model.UrdfModel(URDF)
     np.save(os.path.join(assets, 'max_model.npy'), m.blob())
     frames, lens, step, names = mocap.load_json_clips(MOCAP)
-    mocap.save_packed(os.path.join(assets, 'mocap_f32.npz'), frames, lens, step, names)
+    mocap.save_packed(os.path.join(assets, 'mocap_f64.npz'), frames, lens, step, names)
     print('packed', len(lens), 'clips', frames.shape, 'frame_step', repr(step))
-    off = np.concatenate([[0], np.cumsum(lens)])
-    sub, sublens = [], []
-    for n in GOLD_CLIPS:
-        i = names.index(n)
-        sub.append(frames[off[i]:off[i + 1]])
-        sublens.append(lens[i])
-    mocap.save_packed(os.path.join(ROOT, 'tests', 'golden', 'mocap_f64_subset.npz'),
-                      np.concatenate(sub, 0), sublens, step, GOLD_CLIPS, dtype=np.float64)
 
 
 if __name__ == '__main__':
