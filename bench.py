@@ -1,0 +1,160 @@
+"""bench.py -- env-steps/sec of the PMC tracking-env hot path on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 300 --warmup 30
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one 50 Hz control step (10 x 2 ms physics substeps + mocap lookup + obs + reward + termination +
+in-kernel re-seed of finished episodes) of 4096 environments per GPU on all 62 mocap clips, flat terrain, with
+the random policy a ~ N(0, e^-2) drawn on device.  Inputs are resident in HBM before the timed region.  Weak scaling:
+every rank owns 4096 envs; for N > 1 every rank also records its (obs, action, reward, done) rows and rank 0 gathers
+the trajectory batches over RCCL inside the timed region.
+
+Rank 0 prints ONE JSON line (see the driver contract), including
+  roofline     : HBM roofline of the step kernel from HIP-event timings taken on the engine's launch stream
+  cpu_baseline : the float64 CPU oracle timed on this box's host cores on a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+ENVS_PER_GPU = 4096
+SIGMA = math.exp(-2.0)
+ALGO_BYTES_PER_ENV_STEP = 2552          # SURVEY.md 8(d) / DESIGN.md "algorithmic bytes"
+HBM_PEAK_GBPS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s spec
+UNROLL = 128                            # example_pmc_train.sh:145 unroll_length
+
+PMC_REWARD_WEIGHTS = {'joint_pos': 0.3, 'joint_vel': 0.05, 'end_effector': 0.1, 'root_pose': 0.5, 'root_vel': 0.05}
+PMC_PROP_TYPE = ['joint_pos', 'joint_vel', 'root_ang_vel_loc', 'root_lin_vel_loc', 'e_g']
+
+
+def cpu_baseline(blob, table, budget_s=15.0):
+    """The oracle (a port, not the product) on a bounded sample of the same workload: 64 envs, random policy."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from oracle import oracle as orc
+    n = 64
+    cfg = orc.make_config(n_envs=n, reward_weights=PMC_REWARD_WEIGHTS, prop_type=PMC_PROP_TYPE, prioritized_sample_factor=3.0)
+    B = orc.OracleBatch(cfg, blob, table)
+    rng = np.random.default_rng(0)
+
+    def reseed(i):
+        c = int(rng.integers(0, B.n_clips))
+        B.reset_env(i, c, float(rng.uniform(0, 1) * B.motion_duration(c)))
+    for i in range(n):
+        reseed(i)
+    steps, t0 = 0, time.time()
+    while time.time() - t0 < budget_s:
+        _, _, d = B.step_all(rng.normal(size=(n, 12)) * SIGMA)
+        steps += n
+        for i in np.where(d)[0]:
+            reseed(int(i))
+    dt = time.time() - t0
+    return {'value': steps / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d env-steps: 64 envs, all clips, random policy, %.0f s of the float64 oracle (oracle/pmc_oracle.c, 1 thread)' % (steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from lifelike_agility_and_play_amd import capi, mocap, urdf_model, gather
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    n = args.envs_per_gpu
+    blob = urdf_model.default_model_blob()
+    table = mocap.load_mocap('', 1.0 / 50.0)
+    cfg = capi.make_config(n, control_freq=50.0, sim_freq=500.0, kp=50.0, kd=0.5, max_tau=18.0,
+                           reward_weights=PMC_REWARD_WEIGHTS, prop_type=PMC_PROP_TYPE, prioritized_sample_factor=3.0,
+                           auto_reset=1, seed=1234 + rank, device=local_rank)
+    eng = capi.Engine(cfg, blob, table)
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)                 # step kernels and torch ops share one stream
+    eng.reset()
+    traj = gather.TrajectoryBuffer(eng, UNROLL) if world > 1 else None
+
+    def one_step(t):
+        eng.fill_random_actions(SIGMA)
+        eng.step()
+        if traj is not None:
+            traj.record(t % UNROLL)
+            if (t + 1) % UNROLL == 0:
+                traj.gather_to(0)
+
+    for t in range(args.warmup):
+        one_step(t)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.enable_kernel_timing(True)
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        one_step(t)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_n = eng.kernel_time_ms()
+    eng.enable_kernel_timing(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    counters = eng.counters()
+
+    if rank == 0:
+        total_env_steps = world * n * args.steps
+        value = total_env_steps / elapsed
+        achieved = (n * ALGO_BYTES_PER_ENV_STEP) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+        out = {
+            'metric': 'env-steps/sec (whole node), PMC tracking env, random policy',
+            'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'PMC tracking env, %d parallel envs per MI355X, flat terrain, full mocap_data clip set '
+                                   '(62 clips), random-policy actions N(0, e^-2), auto-reset%s' % (n, ', RCCL trajectory gather to rank 0 every %d steps' % UNROLL if world > 1 else ''),
+                       'envs_per_gpu': n, 'substeps_per_step': 10, 'solver_iterations': 10,
+                       'episodes_finished_rank0': counters['episodes'], 'nonfinite_resets_rank0': counters['nonfinite']},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': (achieved / HBM_PEAK_GBPS) if achieved else None, 'traffic': None,
+                         'kernel': 'pmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
+                         'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP,
+                         'note': 'latency/VALU-bound by construction (~4e5 flop per env-step vs 2.5 KB); see DESIGN.md'},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(blob, table)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -115,6 +115,9 @@ int ll_destroy(ll_engine* e); /* PLE:428-435 close()/__del__ */
  * h_frames: [sum(clip_len)][19] float32 rows (ML:91-96 layout), clips concatenated.
  */
 int ll_load_mocap(ll_engine* e, const float* h_frames, const int32_t* h_clip_len, int n_clips, double frame_step);
+/* Same with float64 rows -- the numbers the reference parses from JSON (ML:31).  Preferred: reference velocities are
+ * finite differences of neighbouring rows over 1/120 s (ML:137-160), so float32 rows already cost ~1e-4 m/s. */
+int ll_load_mocap_f64(ll_engine* e, const double* h_frames, const int32_t* h_clip_len, int n_clips, double frame_step);
 
 /*
  * Reset environments: PLE:150-171 + ML:48-63.
@@ -141,6 +144,10 @@ int ll_fill_random_actions(ll_engine* e, float sigma);
 
 /* Block until all queued work on the engine's stream has finished. */
 int ll_sync(ll_engine* e);
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream) instead of the engine's own, so that the
+ * producer of d_actions and the consumers of the obs buffer are stream-ordered with the step kernel. NULL restores
+ * the engine's private stream. */
+int ll_set_stream(ll_engine* e, void* hip_stream);
 
 /* Device buffers owned by the engine (valid until ll_destroy), for zero-copy consumers (torch, RCCL). */
 typedef struct ll_device_ptrs_t {
@@ -158,6 +165,7 @@ int ll_device_ptrs(ll_engine* e, ll_device_ptrs_t* out);
 
 /* Host copies (synchronise the stream first). */
 int ll_get_obs(ll_engine* e, float* h_obs /*[n_envs][obs_dim]*/);
+int ll_get_terminal_obs(ll_engine* e, float* h_obs /*[n_envs][obs_dim]*/);
 int ll_get_reward_done(ll_engine* e, float* h_reward, uint8_t* h_done, uint8_t* h_done_reason);
 int ll_set_actions(ll_engine* e, const float* h_actions /*[n_envs][12]*/);
 

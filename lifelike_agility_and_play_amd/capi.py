@@ -1,0 +1,258 @@
+"""ctypes binding of the C ABI in include/llenv.h (libllenv.so, built from csrc/llenv.hip for gfx950).
+
+This is the thin layer the north star asks for: Python keeps the reference's env API (envs.py) and calls
+the HIP batch stepper through plain pointers and sizes.  There is no CPU fallback: if the shared library is
+missing, or no GPU is visible, constructing an Engine raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, 'csrc', 'libllenv.so')
+
+PROP_IDS = {'joint_pos': 0, 'joint_vel': 1, 'root_lin_vel_loc': 2, 'root_ang_vel_loc': 3, 'e_g': 4}   # PLE:102-108
+PROP_SIZES = {'joint_pos': 12, 'joint_vel': 12, 'root_lin_vel_loc': 3, 'root_ang_vel_loc': 3, 'e_g': 3}
+RW_KEYS = ['joint_pos', 'joint_vel', 'end_effector', 'root_pose', 'root_vel']                          # PLE:352-357
+PLE_DEFAULT_REWARD_WEIGHTS = {'joint_pos': 0.6, 'joint_vel': 0.05, 'end_effector': 0.1, 'root_pose': 0.15,
+                              'root_vel': 0.1}                                                       # PLE:359-363
+
+DONE_FALL, DONE_CLIP_END, DONE_DIVERGED, DONE_COLLISION, DONE_NONFINITE = 1, 2, 4, 8, 16
+
+
+class LLConfig(C.Structure):
+    """struct ll_config (include/llenv.h)."""
+    _fields_ = [('abi_version', C.c_int32), ('n_envs', C.c_int32), ('device', C.c_int32), ('auto_reset', C.c_int32),
+                ('control_freq', C.c_double), ('sim_freq', C.c_double), ('kp', C.c_double), ('kd', C.c_double),
+                ('max_tau', C.c_double), ('foot_lateral_friction', C.c_double), ('reward_weights', C.c_double * 5),
+                ('prop_order', C.c_int32 * 5), ('set_obstacle', C.c_int32), ('obstacle_height', C.c_double),
+                ('prioritized_sample_factor', C.c_double), ('solver_iterations', C.c_int32), ('reserved0', C.c_int32),
+                ('seed', C.c_uint64)]
+
+
+class LLDevicePtrs(C.Structure):
+    _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('done', C.c_void_p), ('done_reason', C.c_void_p),
+                ('actions', C.c_void_p), ('terminal_obs', C.c_void_p), ('obs_dim', C.c_int32), ('n_envs', C.c_int32),
+                ('stream', C.c_void_p)]
+
+
+class LLError(RuntimeError):
+    def __init__(self, code, msg):
+        super(LLError, self).__init__('llenv error %d: %s' % (code, msg))
+        self.code = code
+
+
+def make_config(n_envs, control_freq=25.0, sim_freq=500.0, kp=50.0, kd=1.0, max_tau=18.0, foot_lateral_friction=0.5,
+                reward_weights=None, prop_type=None, prioritized_sample_factor=0.0, set_obstacle=False,
+                obstacle_height=0.0, auto_reset=0, seed=0, device=0, solver_iterations=10):
+    """Defaults are the factory's (create_pybullet_envs.py:28-59)."""
+    if not isinstance(prop_type, (list, tuple)):
+        raise TypeError("Expected 'prop_type' to be a list.")                     # PLE:113
+    cfg = LLConfig()
+    cfg.abi_version = 1
+    cfg.n_envs, cfg.device, cfg.auto_reset = int(n_envs), int(device), int(auto_reset)
+    cfg.control_freq, cfg.sim_freq, cfg.kp, cfg.kd = float(control_freq), float(sim_freq), float(kp), float(kd)
+    cfg.max_tau, cfg.foot_lateral_friction = float(max_tau), float(foot_lateral_friction)
+    rw = reward_weights if reward_weights is not None else PLE_DEFAULT_REWARD_WEIGHTS
+    for i, k in enumerate(RW_KEYS):
+        cfg.reward_weights[i] = float(rw[k])
+    if len(prop_type) > 5 or len(set(prop_type)) != len(prop_type):
+        raise ValueError('prop_type entries must be distinct keys of %s' % sorted(PROP_IDS))
+    for i in range(5):
+        cfg.prop_order[i] = PROP_IDS[prop_type[i]] if i < len(prop_type) else -1   # KeyError mirrors PLE:111
+    cfg.set_obstacle, cfg.obstacle_height = int(bool(set_obstacle)), float(obstacle_height)
+    cfg.prioritized_sample_factor = float(prioritized_sample_factor)
+    cfg.solver_iterations = int(solver_iterations)
+    cfg.seed = int(seed)
+    return cfg
+
+
+_SIGS = {
+    'll_last_error': (C.c_char_p, []),
+    'll_abi_version': (C.c_int, []),
+    'll_model_blob_len': (C.c_int, []),
+    'll_create': (C.c_int, [C.POINTER(LLConfig), C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    'll_destroy': (C.c_int, [C.c_void_p]),
+    'll_load_mocap': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]),
+    'll_load_mocap_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]),
+    'll_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'll_step': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'll_fill_random_actions': (C.c_int, [C.c_void_p, C.c_float]),
+    'll_sync': (C.c_int, [C.c_void_p]),
+    'll_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'll_device_ptrs': (C.c_int, [C.c_void_p, C.POINTER(LLDevicePtrs)]),
+    'll_get_obs': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'll_get_terminal_obs': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'll_get_reward_done': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'll_set_actions': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'll_get_state': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'll_set_state': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'll_get_ref_state': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'll_get_episode_info': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'll_get_sampling_table': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'll_set_sampling_table': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'll_get_feet': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'll_get_counters': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'll_kernel_time_ms': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    'll_enable_kernel_timing': (C.c_int, [C.c_void_p, C.c_int]),
+}
+EXPORTED_SYMBOLS = sorted(_SIGS)
+
+_libs = {}
+
+
+def load_library(path=None):
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise ImportError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                              '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % path)
+        lib = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)           # AttributeError if the library lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _libs[path] = lib
+    return _libs[path]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Engine(object):
+    """One batch of environments on one GPU (ll_engine)."""
+
+    def __init__(self, cfg, model_blob, mocap_table, lib_path=None):
+        self.lib = load_library(lib_path)
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        blob = np.ascontiguousarray(model_blob, dtype=np.float64)
+        self._chk(self.lib.ll_create(C.byref(cfg), _ptr(blob), int(blob.size), C.byref(self.h)))
+        frames = np.ascontiguousarray(mocap_table.frames)
+        clip_len = np.ascontiguousarray(mocap_table.clip_len, dtype=np.int32)
+        if frames.dtype == np.float64:
+            self._chk(self.lib.ll_load_mocap_f64(self.h, _ptr(frames), _ptr(clip_len), len(clip_len), float(mocap_table.frame_step)))
+        else:
+            frames = frames.astype(np.float32)
+            self._chk(self.lib.ll_load_mocap(self.h, _ptr(frames), _ptr(clip_len), len(clip_len), float(mocap_table.frame_step)))
+        self.n_envs = cfg.n_envs
+        self.n_clips = len(clip_len)
+        p = self.device_ptrs()
+        self.obs_dim = p.obs_dim
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise LLError(rc, self.lib.ll_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.ll_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- control ------------------------------------------------------------------------------------
+    def reset(self, env_ids=None, clip=None, t0=None):
+        ids = np.ascontiguousarray(env_ids, dtype=np.int32) if env_ids is not None else None
+        n = len(ids) if ids is not None else self.n_envs
+        cl = np.ascontiguousarray(clip, dtype=np.int32) if clip is not None else None
+        tt = np.ascontiguousarray(t0, dtype=np.float64) if t0 is not None else None
+        for a in (cl, tt):
+            if a is not None and len(a) != n:
+                raise ValueError('clip / t0 must have one entry per reset env')
+        self._chk(self.lib.ll_reset(self.h, _ptr(ids), n, _ptr(cl), _ptr(tt)))
+
+    def step(self, d_actions_ptr=None):
+        """d_actions_ptr: integer device address of float32 [n_envs][12], or None for the engine's action buffer."""
+        self._chk(self.lib.ll_step(self.h, C.c_void_p(d_actions_ptr) if d_actions_ptr else None))
+
+    def step_host(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n_envs, 12)
+        self._chk(self.lib.ll_set_actions(self.h, _ptr(a)))
+        self.step(None)
+
+    def fill_random_actions(self, sigma):
+        self._chk(self.lib.ll_fill_random_actions(self.h, float(sigma)))
+
+    def sync(self):
+        self._chk(self.lib.ll_sync(self.h))
+
+    def set_stream(self, stream_handle):
+        self._chk(self.lib.ll_set_stream(self.h, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def device_ptrs(self):
+        p = LLDevicePtrs()
+        self._chk(self.lib.ll_device_ptrs(self.h, C.byref(p)))
+        return p
+
+    # ---- host copies ------------------------------------------------------------------------------------
+    def obs(self):
+        o = np.empty((self.n_envs, self.obs_dim), dtype=np.float32)
+        self._chk(self.lib.ll_get_obs(self.h, _ptr(o)))
+        return o
+
+    def terminal_obs(self):
+        o = np.empty((self.n_envs, self.obs_dim), dtype=np.float32)
+        self._chk(self.lib.ll_get_terminal_obs(self.h, _ptr(o)))
+        return o
+
+    def reward_done(self):
+        r = np.empty(self.n_envs, dtype=np.float32)
+        d = np.empty(self.n_envs, dtype=np.uint8)
+        why = np.empty(self.n_envs, dtype=np.uint8)
+        self._chk(self.lib.ll_get_reward_done(self.h, _ptr(r), _ptr(d), _ptr(why)))
+        return r, d.astype(bool), why
+
+    def state(self):
+        s = np.empty((self.n_envs, 37), dtype=np.float32)
+        self._chk(self.lib.ll_get_state(self.h, _ptr(s)))
+        return s
+
+    def set_state(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float32).reshape(self.n_envs, 37)
+        self._chk(self.lib.ll_set_state(self.h, _ptr(s)))
+
+    def ref_state(self):
+        s = np.empty((self.n_envs, 37), dtype=np.float32)
+        self._chk(self.lib.ll_get_ref_state(self.h, _ptr(s)))
+        return s
+
+    def feet(self):
+        a = np.empty((self.n_envs, 4, 3), dtype=np.float32)
+        b = np.empty((self.n_envs, 4, 3), dtype=np.float32)
+        self._chk(self.lib.ll_get_feet(self.h, _ptr(a), _ptr(b)))
+        return a, b
+
+    def episode_info(self):
+        clip = np.empty(self.n_envs, dtype=np.int32); steps = np.empty(self.n_envs, dtype=np.int32)
+        t = np.empty(self.n_envs, dtype=np.float64); rs = np.empty(self.n_envs, dtype=np.float32)
+        self._chk(self.lib.ll_get_episode_info(self.h, _ptr(clip), _ptr(t), _ptr(steps), _ptr(rs)))
+        return dict(clip=clip, time=t, steps=steps, reward_sum=rs)
+
+    def sampling_table(self):
+        p, a, l = (np.empty(self.n_clips) for _ in range(3))
+        self._chk(self.lib.ll_get_sampling_table(self.h, _ptr(p), _ptr(a), _ptr(l)))
+        return p, a, l
+
+    def set_sampling_table(self, avg_reward_sum):
+        a = np.ascontiguousarray(avg_reward_sum, dtype=np.float64)
+        assert a.shape == (self.n_clips,)
+        self._chk(self.lib.ll_set_sampling_table(self.h, _ptr(a)))
+
+    def counters(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.ll_get_counters(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(env_steps=a.value, episodes=b.value, nonfinite=c.value)
+
+    def enable_kernel_timing(self, on=True):
+        self._chk(self.lib.ll_enable_kernel_timing(self.h, int(on)))
+
+    def kernel_time_ms(self):
+        ms, n = C.c_double(), C.c_int()
+        self._chk(self.lib.ll_kernel_time_ms(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

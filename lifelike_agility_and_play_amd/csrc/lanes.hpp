@@ -1,0 +1,104 @@
+// lanes.hpp -- the "quad" execution model of the PMC step kernel.
+//
+// One environment is stepped by FOUR lanes of a wavefront, one per leg (LegOrder FR, FL, HR, HL): the MAX
+// quadruped is a star (base + 4 independent 3-joint chains), so leg-local work (FK, leg inertia, contact
+// candidates, constraint rows) runs lane-parallel and everything that couples legs goes through the base,
+// i.e. through a reduction / broadcast over the quad (DPP quad_perm on gfx950: no LDS, no barrier).
+//
+// Values come in two classes:
+//   * quad-uniform  ("base" values: pose, twist, 6x6 factors, time...) -- plain float/int/double;
+//   * lane-varying  (one value per leg)                              -- L::F / L::I / L::D / L::B.
+// The kernel body (pmc_step.hpp) is written once against this interface.  GpuLanes (below) maps it to one
+// hardware lane per leg.  tests/emul/ instantiates the same source with a 4-wide host type to debug the
+// kernel logic on a machine without a GPU; that build is test infrastructure and is never linked into
+// the product library.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define LL_HD __host__ __device__ __forceinline__
+#define LL_D __device__ __forceinline__
+#else
+#define LL_HD inline
+#define LL_D inline
+#endif
+
+namespace lm {
+// scalar (quad-uniform) overloads of the math vocabulary used by the generic code
+LL_HD float sel(bool m, float a, float b) { return m ? a : b; }
+LL_HD int sel(bool m, int a, int b) { return m ? a : b; }
+LL_HD float sqrt_(float x) { return sqrtf(x); }
+LL_HD float rsqrt_(float x) { return 1.0f / sqrtf(x); }
+LL_HD float sin_(float x) { return sinf(x); }
+LL_HD float cos_(float x) { return cosf(x); }
+LL_HD float atan2_(float y, float x) { return atan2f(y, x); }
+LL_HD float exp_(float x) { return expf(x); }
+LL_HD float abs_(float x) { return fabsf(x); }
+LL_HD float min_(float a, float b) { return fminf(a, b); }
+LL_HD float max_(float a, float b) { return fmaxf(a, b); }
+LL_HD bool and_(bool a, bool b) { return a && b; }
+LL_HD bool or_(bool a, bool b) { return a || b; }
+LL_HD bool not_(bool a) { return !a; }
+}  // namespace lm
+
+#if defined(__HIPCC__)
+// ---------------------------------------------------------------------------------------------------
+// GPU mapping: lane = leg.  64-thread workgroups = one wavefront = 16 environments.
+// ---------------------------------------------------------------------------------------------------
+struct GpuLanes {
+  using F = float;
+  using I = int;
+  using D = double;
+  using B = bool;
+  static constexpr int kWave = 64;
+
+  int leg_;        // 0..3
+  int lane_;       // 0..63 within the wave
+  float* lds_;     // workgroup LDS scratch, word w of this lane lives at lds_[w * 64 + lane_]
+
+  LL_D GpuLanes(float* lds) : leg_(threadIdx.x & 3), lane_(threadIdx.x & 63), lds_(lds) {}
+
+  LL_D I leg() const { return leg_; }
+  LL_D F legf() const { return (float)leg_; }
+  LL_D B is_leg(int l) const { return leg_ == l; }
+  LL_D F lane_f(float x) const { return x; }   // promote a uniform to lane-varying
+
+  // quad reductions / broadcasts (DPP quad_perm, row-local, no LDS traffic)
+  template <int S>
+  static LL_D float bcast(F x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), S | (S << 2) | (S << 4) | (S << 6), 0xf, 0xf, true));
+  }
+  static LL_D float bcast_rt(F x, int src) {   // runtime (wave-uniform) source leg
+    return __shfl(x, (int)((threadIdx.x & 60) | src), 64);
+  }
+  static LL_D float qsum(F x) {
+    // x + swap-pairs, then + swap-halves of the quad: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E
+    float y = x + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));
+    return y + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, y), 0x4E, 0xf, 0xf, true));
+  }
+  static LL_D bool qany(B m) { return qsum(m ? 1.0f : 0.0f) > 0.0f; }
+  static LL_D bool any(B m) { return __any(m); }   // wave-level: guards wave-uniform branches
+
+  // per-leg constant table [field][4]
+  LL_D F legc(const float* tbl, int field) const { return tbl[field * 4 + leg_]; }
+  // lane pick for 3-vectors: leg 0 -> x, 1 -> y, 2,3 -> z
+  LL_D F pick3(float x, float y, float z) const { return leg_ == 0 ? x : (leg_ == 1 ? y : z); }
+
+  // global memory, per-leg strided access: element (base + stride * leg)
+  LL_D F ldl(const float* p, long base, long stride) const { return p[base + stride * leg_]; }
+  LL_D void stl(float* p, long base, long stride, F v) const { p[base + stride * leg_] = v; }
+  LL_D void stl_if(B m, float* p, long base, long stride, F v) const { if (m) p[base + stride * leg_] = v; }
+  LL_D D lddl(const double* p, long base, long stride) const { return p[base + stride * leg_]; }
+  static LL_D F d2f(D x) { return (float)x; }
+
+  // LDS scratch: word w (uniform or lane-varying) of this lane
+  LL_D F lds_ld(I w) const { return lds_[w * kWave + lane_]; }
+  LL_D void lds_st(I w, F v) const { lds_[w * kWave + lane_] = v; }
+  LL_D void lds_st_if(B m, I w, F v) const { if (m) lds_[w * kWave + lane_] = v; }
+  static LL_D F i2f(I x) { return (float)x; }
+  static LL_D I f2i(F x) { return (int)x; }
+};
+#endif  // __HIPCC__

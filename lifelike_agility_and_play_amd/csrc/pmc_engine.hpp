@@ -1,0 +1,191 @@
+// pmc_engine.hpp -- host-side engine behind the C ABI (include/llenv.h): buffer ownership, SoA<->row
+// conversion at the boundary, launch sequencing.  Generic over a Backend that allocates memory and launches the
+// three kernels (pre-step, step, reset); the product instantiates it with the HIP backend (llenv.hip).
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "pmc_params.hpp"
+#include "pmc_tables.hpp"
+
+struct PmcError : public std::runtime_error {
+  int code;
+  PmcError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+template <class BK>
+struct PmcEngine {
+  BK bk;
+  ll_config cfg;
+  StepParams P;
+  bool have_mocap = false, have_reset = false;
+  // table state (device, float64)
+  double *d_avg_reward = nullptr, *d_avg_len = nullptr, *d_prob = nullptr, *d_cdf = nullptr;
+  float* d_actions = nullptr;       // engine-owned action buffer
+  int32_t* d_reset_ids = nullptr;   // scratch for ll_reset
+  int32_t* d_reset_clip = nullptr;
+  double* d_reset_t0 = nullptr;
+  std::vector<void*> allocs;
+  std::vector<double> h_max_steps;
+  std::vector<int32_t> h_clip_len;
+
+  template <class T>
+  T* dalloc(size_t n) {
+    void* p = bk.alloc(n * sizeof(T));
+    bk.zero(p, n * sizeof(T));
+    allocs.push_back(p);
+    return (T*)p;
+  }
+
+  PmcEngine(const ll_config& c, const double* blob, int blob_len) : bk(c.device), cfg(c) {
+    std::string e = pmc_fill_params(cfg, P);
+    if (!e.empty()) throw PmcError(LL_EINVAL, e);
+    std::vector<float> legc, basec;
+    e = pmc_build_tables(blob, blob_len, legc, basec);
+    if (!e.empty()) throw PmcError(LL_EINVAL, e);
+    const size_t N = (size_t)P.n_envs;
+    float* lc = dalloc<float>(legc.size());
+    float* bc = dalloc<float>(basec.size());
+    bk.h2d(lc, legc.data(), legc.size() * 4);
+    bk.h2d(bc, basec.data(), basec.size() * 4);
+    P.legc = lc; P.basec = bc;
+    P.state = dalloc<float>(37 * N); P.kin = dalloc<float>(37 * N); P.feet = dalloc<float>(24 * N);
+    P.time = dalloc<double>(N); P.clip = dalloc<int32_t>(N); P.ep_steps = dalloc<int32_t>(N);
+    P.reward_sum = dalloc<float>(N); P.ep_count = dalloc<uint32_t>(N);
+    P.obs = dalloc<float>(N * P.obs_dim); P.term_obs = dalloc<float>(N * P.obs_dim);
+    P.reward = dalloc<float>(N); P.done = dalloc<uint8_t>(N); P.done_reason = dalloc<uint8_t>(N);
+    d_actions = dalloc<float>(N * 12);
+    P.actions = d_actions;
+    P.counters = dalloc<unsigned long long>(4);
+    d_reset_ids = dalloc<int32_t>(N); d_reset_clip = dalloc<int32_t>(N); d_reset_t0 = dalloc<double>(N);
+  }
+  ~PmcEngine() {
+    for (void* p : allocs) bk.release(p);
+  }
+
+  // ML:19-46
+  void load_mocap(const double* frames, const int32_t* clip_len, int n_clips, double frame_step) {
+    if (have_mocap) throw PmcError(LL_ESTATE, "mocap table already loaded");
+    if (n_clips <= 0 || !(frame_step > 0)) throw PmcError(LL_EINVAL, "bad mocap table");
+    pmc_fill_mocap(P, n_clips, frame_step);
+    size_t total = 0;
+    std::vector<int32_t> off(n_clips);
+    h_max_steps.resize(n_clips);
+    h_clip_len.assign(clip_len, clip_len + n_clips);
+    for (int c = 0; c < n_clips; c++) {
+      if (clip_len[c] <= P.margin + 1 + P.frame_rate + 2) throw PmcError(LL_EINVAL, "clip shorter than the sampling margin (ML:35,50)");
+      off[c] = (int32_t)total;
+      total += clip_len[c];
+      h_max_steps[c] = (clip_len[c] - P.margin) * frame_step / P.policy_step;    // ML:45
+    }
+    double* fr = dalloc<double>(total * 19);
+    bk.h2d(fr, frames, total * 19 * 8);
+    int32_t* dco = dalloc<int32_t>(n_clips);
+    int32_t* dcl = dalloc<int32_t>(n_clips);
+    double* dms = dalloc<double>(n_clips);
+    bk.h2d(dco, off.data(), n_clips * 4);
+    bk.h2d(dcl, clip_len, n_clips * 4);
+    bk.h2d(dms, h_max_steps.data(), n_clips * 8);
+    P.frames = fr; P.clip_off = dco; P.clip_len = dcl; P.max_steps = dms;
+    d_avg_reward = dalloc<double>(n_clips); d_avg_len = dalloc<double>(n_clips);
+    d_prob = dalloc<double>(n_clips); d_cdf = dalloc<double>(n_clips);
+    P.pending_reward = dalloc<unsigned long long>(n_clips);
+    P.pending_len = dalloc<unsigned long long>(n_clips);
+    std::vector<double> prob(n_clips, 1.0 / n_clips), cdf(n_clips);            // ML:46
+    double acc = 0;
+    for (int c = 0; c < n_clips; c++) { acc += prob[c]; cdf[c] = acc; }
+    cdf[n_clips - 1] = 1.0;
+    bk.h2d(d_prob, prob.data(), n_clips * 8);
+    bk.h2d(d_cdf, cdf.data(), n_clips * 8);
+    P.cdf = d_cdf;
+    have_mocap = true;
+  }
+
+  void need(bool mocap, bool reset) const {
+    if (mocap && !have_mocap) throw PmcError(LL_ESTATE, "ll_load_mocap must be called first");
+    if (reset && !have_reset) throw PmcError(LL_ESTATE, "ll_reset must be called before ll_step");
+  }
+
+  // PLE:150-171
+  void reset(const int32_t* env_ids, int n, const int32_t* clip, const double* t0) {
+    need(true, false);
+    const int N = P.n_envs;
+    if (!env_ids) n = N;
+    if (n <= 0 || n > N) throw PmcError(LL_EINVAL, "bad env count in ll_reset");
+    if (env_ids) {
+      for (int i = 0; i < n; i++)
+        if (env_ids[i] < 0 || env_ids[i] >= N) throw PmcError(LL_EINVAL, "env id out of range");
+      bk.h2d(d_reset_ids, env_ids, n * 4);
+    }
+    if (clip) {
+      for (int i = 0; i < n; i++)
+        if (clip[i] < 0 || clip[i] >= P.n_clips) throw PmcError(LL_EINVAL, "clip index out of range");
+      bk.h2d(d_reset_clip, clip, n * 4);
+    }
+    if (t0) {
+      for (int i = 0; i < n; i++) {
+        if (clip) {
+          double dur = P.frame_step * (h_clip_len[clip[i]] - 2);
+          if (!(t0[i] >= 0) || t0[i] > dur) throw PmcError(LL_EINVAL, "start time outside the clip");
+        } else if (!(t0[i] >= 0)) {
+          throw PmcError(LL_EINVAL, "negative start time");
+        }
+      }
+      bk.h2d(d_reset_t0, t0, n * 8);
+    }
+    bk.launch_prestep(P, d_avg_reward, d_avg_len, d_prob, d_cdf, nullptr, 0.0f);   // fold pending statistics first
+    bk.launch_reset(P, env_ids ? d_reset_ids : nullptr, n, clip ? d_reset_clip : nullptr, t0 ? d_reset_t0 : nullptr);
+    have_reset = true;
+  }
+
+  // PLE:195-245
+  void step(const float* d_act) {
+    need(true, true);
+    StepParams Q = P;
+    Q.actions = d_act ? d_act : d_actions;
+    bk.launch_prestep(P, d_avg_reward, d_avg_len, d_prob, d_cdf, nullptr, 0.0f);
+    bk.launch_step(Q);
+    P.step_count += 1;
+  }
+  void fill_random_actions(float sigma) {
+    need(true, false);
+    bk.launch_prestep(P, d_avg_reward, d_avg_len, d_prob, d_cdf, d_actions, sigma);
+  }
+
+  // ---- boundary copies: rows on the host, SoA on the device ---------------------------------------------
+  void get_soa(const float* d, int nf, float* h_rows) {
+    const size_t N = P.n_envs;
+    std::vector<float> tmp(nf * N);
+    bk.sync();
+    bk.d2h(tmp.data(), d, tmp.size() * 4);
+    for (size_t e = 0; e < N; e++)
+      for (int f = 0; f < nf; f++) h_rows[e * nf + f] = tmp[f * N + e];
+  }
+  void set_soa(float* d, int nf, const float* h_rows) {
+    const size_t N = P.n_envs;
+    std::vector<float> tmp(nf * N);
+    for (size_t e = 0; e < N; e++)
+      for (int f = 0; f < nf; f++) tmp[f * N + e] = h_rows[e * nf + f];
+    bk.sync();
+    bk.h2d(d, tmp.data(), tmp.size() * 4);
+  }
+  template <class T>
+  void get_vec(const T* d, T* h, size_t n) {
+    bk.sync();
+    bk.d2h(h, d, n * sizeof(T));
+  }
+  void set_sampling_table(const double* avg_r) {
+    need(true, false);
+    const int C = P.n_clips;
+    std::vector<double> prob(C), cdf(C);
+    double sum = 0, acc = 0;
+    for (int c = 0; c < C; c++) { prob[c] = pow(1.0 - avg_r[c], P.sample_factor); sum += prob[c]; }   // PLE:239-240
+    for (int c = 0; c < C; c++) { prob[c] /= sum; acc += prob[c]; cdf[c] = acc; }
+    cdf[C - 1] = 1.0;
+    bk.sync();
+    bk.h2d(d_avg_reward, avg_r, C * 8);
+    bk.h2d(d_prob, prob.data(), C * 8);
+    bk.h2d(d_cdf, cdf.data(), C * 8);
+  }
+};

@@ -1,0 +1,89 @@
+// pmc_params.hpp -- kernel argument block and constant-table layouts of the PMC step engine.
+#pragma once
+#include <stdint.h>
+
+#define PMC_K 6            // contact slots per leg lane (== LLM_MAX_CONTACTS_PER_LEG)
+#define PMC_WAVE 64
+#define PMC_ENVS_PER_WAVE 16
+
+// ---- per-leg constant table: legc[field * 4 + leg] ---------------------------------------------------
+enum LegConst {
+  LC_R1 = 0,          // 3  hip joint origin in F0
+  LC_R2 = 3,          // 3  thigh joint origin in hip frame
+  LC_R3 = 6,          // 3  shank joint origin in thigh frame
+  LC_M = 9,           // 3  link masses
+  LC_COM = 12,        // 9  link COMs (link frame)
+  LC_IC = 21,         // 18 link inertias about COM: xx xy xz yy yz zz
+  LC_QLO = 39,        // 3
+  LC_QHI = 42,        // 3
+  LC_JDAMP = 45,      // 3
+  LC_FOOT = 48,       // 3  foot link origin in the shank frame
+  LC_BSX = 51,        // base-box vertex sign x owned by this lane
+  LC_BSY = 52,        // base-box vertex sign y owned by this lane
+  LC_HANDLE = 53,     // 4  handle sphere centre (F0) + radius
+  LC_HAS_HANDLE = 57, // 1.0 if this lane owns a handle sphere
+  LC_HIPCYL = 58,     // 11 cylinder on the hip link:   c(3) axis(3) fallback-dir(3) r h
+  LC_THBOX = 69,      // 12 box on the thigh link:      c(3) ua(3) ub(3) uc(3)   (scaled half-axis vectors)
+  LC_THCYL0 = 81,     // 11
+  LC_THCYL1 = 92,     // 11
+  LC_WHEEL = 103,     // 11 wheel cylinder (welded to the thigh)
+  LC_SHBOX = 114,     // 12 box on the shank link
+  LC_FOOTSPH = 126,   // 4  foot sphere on the shank link: c(3) r
+  LC_COUNT = 130
+};
+
+// ---- base constant table (quad-uniform) ----------------------------------------------------------------
+enum BaseConst {
+  BC_MASS = 0,
+  BC_H = 1,       // 3  m * com
+  BC_IO = 4,      // 6  inertia about the F0 origin: xx xy xz yy yz zz
+  BC_COM = 10,    // 3
+  BC_ICOM = 13,   // 6  inertia about the COM
+  BC_BOX = 19,    // 12 body box: c(3) ua(3) ub(3) uc(3)
+  BC_COUNT = 31
+};
+
+struct StepParams {
+  int32_t n_envs, n_sub, n_iter, auto_reset;
+  int32_t n_clips, prop_dim, obs_dim, frame_rate;
+  int32_t margin, pad0;
+  int32_t prop_off[5];      // offset of each LL_PROP_* key inside one prop frame, or -1
+  int32_t pad1;
+  float dt, kp, kd, max_tau;
+  float mu_foot, mu_link, gravity, link_damping;
+  float erp, margin_dist, pad2, pad3;
+  float rw[5];              // normalised reward weights (PLE:365-370)
+  float pad4;
+  double dt_d, frame_step, policy_step, sample_factor;
+  uint64_t seed;
+  uint64_t step_count;      // control steps executed so far (salts the Philox stream)
+
+  // per-env state, SoA [field][n_envs]
+  float* state;             // 37 fields: pos3 quat4 linvel3 angvel3 q12 qd12
+  float* kin;               // 37 fields: ghost (reference) state
+  float* feet;              // 24 fields: dyn feet 4x3, ghost feet 4x3 (world)
+  double* time;             // [n_envs] env time (PLE:210)
+  int32_t* clip;            // [n_envs]
+  int32_t* ep_steps;        // [n_envs]
+  float* reward_sum;        // [n_envs]
+  uint32_t* ep_count;       // [n_envs] episodes started (Philox counter)
+  // per-env outputs, AoS rows
+  float* obs;               // [n_envs][obs_dim]   also the history store (frames 1,2 feed the next step)
+  float* term_obs;          // [n_envs][obs_dim]
+  float* reward;            // [n_envs]
+  uint8_t* done;            // [n_envs]
+  uint8_t* done_reason;     // [n_envs]
+  const float* actions;     // [n_envs][12]
+  // mocap
+  const double* frames;     // [total][19]
+  const int32_t* clip_off;
+  const int32_t* clip_len;
+  const double* max_steps;  // [n_clips]
+  const double* cdf;        // [n_clips] inclusive prefix sums of the sampling probabilities
+  unsigned long long* pending_reward;  // [n_clips] packed (env+1)<<32 | float bits of reward_sum/max_steps
+  unsigned long long* pending_len;     // [n_clips] packed (env+1)<<32 | float bits of avg_episode_len
+  unsigned long long* counters;        // [4] env-steps, episodes, non-finite resets, -
+  // constants
+  const float* legc;        // [LC_COUNT][4]
+  const float* basec;       // [BC_COUNT]
+};

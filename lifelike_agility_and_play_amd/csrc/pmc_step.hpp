@@ -1,0 +1,901 @@
+// pmc_step.hpp -- one 50 Hz control step of the PMC tracking environment, fused:
+//   10 x { PD torque (LR:119-148) + physics substep (what PyBullet's stepSimulation does at PLE:206) }
+//   + mocap reference lookup (ML:65-115) + observation packing (PLE:276-317) + tracking reward (PLE:350-426)
+//   + termination (PLE:337-348) + sampling-table bookkeeping (PLE:235-240) + optional in-kernel re-seed.
+// PLE = primitive_level_env.py, ML = motion_lib.py, LR = legged_robot.py of the reference.
+//
+// Execution model: one environment = one quad of lanes, lane = leg (lanes.hpp).  State lives in registers
+// across the 10 substeps; HBM is touched once per control step.
+//
+// Physics formulation (DESIGN.md "physics spec"): the robot is a star -- base + four 3-joint chains -- so the
+// articulated-body elimination is done per leg lane in closed form.  All spatial quantities are expressed in
+// the base frame F0 about the F0 origin:
+//   leg lane:  FK, link inertias in F0, bias forces (recursive Newton-Euler), composite inertias,
+//              3x3 joint-space inertia M_ll and its Cholesky factor Lm, Y = M_bl Lm^-T  (6x3)
+//   quad sum:  S = I_base + sum_legs I^c_leg - sum_legs Y Y^T     == articulated-body inertia of the base
+//   base:      Cholesky S = Lb Lb^T, base acceleration, back-substitution into the legs
+// Contacts / joint limits are rows of a projected Gauss-Seidel solve carried in the whitened coordinates
+//   gt = Lb^-1 (J_b - Y jt),  jt = Lm^-1 J_l,   A_rs = gt_r.gt_s + [same leg] jt_r.jt_s
+// so a row update touches 6 shared numbers (quad broadcast) and 3 lane-private ones.
+#pragma once
+#include "pmc_math.hpp"
+#include "pmc_params.hpp"
+
+#define LLS_DONE_FALL 1
+#define LLS_DONE_CLIP_END 2
+#define LLS_DONE_DIVERGED 4
+#define LLS_DONE_NONFINITE 16
+
+// LDS words per lane (see lanes.hpp lds_ld/lds_st)
+#define LW_CAND(s, f) ((s) * 6 + (f))                       // P(3) link depth mu
+#define LW_ROW(s, r, f) (36 + ((s) * 3 + (r)) * 11 + (f))   // gt(6) jt(3) c(=v0+bias) invA
+#define LW_LAM(s, r) (234 + (s) * 3 + (r))
+#define LW_COUNT 252
+
+// PLE:235-240 for the batch: fold the statistics published by finished episodes into the per-clip table and rebuild
+// the sampling distribution  p ~ (1 - avg_reward_sum)^factor  (stored as an inclusive CDF).  Run by ONE thread
+// between control steps (pre-step kernel), so every env of a step samples from the same table.
+LL_HD void pmc_finalize_table(const StepParams& P, double* avg_reward_sum, double* avg_episode_len, double* prob, double* cdf) {
+  bool any = false;
+  for (int c = 0; c < P.n_clips; c++) {
+    unsigned long long pr = P.pending_reward[c], pl = P.pending_len[c];
+    if (pr) {
+      union { float f; uint32_t u; } a, b;
+      a.u = (uint32_t)pr; b.u = (uint32_t)pl;
+      avg_reward_sum[c] = (double)a.f;
+      avg_episode_len[c] = (double)b.f;
+      P.pending_reward[c] = 0ull;
+      P.pending_len[c] = 0ull;
+      any = true;
+    }
+  }
+  if (!any) return;
+  double sum = 0.0;
+  for (int c = 0; c < P.n_clips; c++) {
+    prob[c] = pow(1.0 - avg_reward_sum[c], P.sample_factor);
+    sum += prob[c];
+  }
+  double acc = 0.0;
+  for (int c = 0; c < P.n_clips; c++) {
+    prob[c] /= sum;
+    acc += prob[c];
+    cdf[c] = acc;
+  }
+  cdf[P.n_clips - 1] = 1.0;
+}
+
+template <class L>
+struct Pmc {
+  typedef typename L::F F;
+  typedef typename L::B B;
+  typedef typename L::I I;
+  typedef typename L::D D;
+  typedef V3<float> V3u;
+  typedef V3<F> V3l;
+
+  // ---------------------------------------------------------------------------------------------------
+  struct Base {   // quad-uniform dynamic state of the base
+    V3u p;        // world position of the F0 origin
+    Q4 q;         // world <- base
+    V3u v, w;     // world linear / angular velocity
+  };
+
+  struct LegKin {
+    M3<F> R1, R2, R3;     // link -> base rotations
+    V3l p1, p2, p3;       // joint origins in F0
+    V3l a2;               // common axis of joints 2 and 3 in F0 (joint 1 axis is +x)
+    V3l s1, s2, s3;       // linear parts of the motion subspaces: p_j x a_j
+  };
+
+  static LL_HD V3l ld3c(const L& ln, const float* legc, int f) {
+    return mk3<F>(ln.legc(legc, f), ln.legc(legc, f + 1), ln.legc(legc, f + 2));
+  }
+
+  static LL_HD LegKin leg_fk(const L& ln, const float* legc, F q1, F q2, F q3) {
+    LegKin k;
+    F c1 = lm::cos_(q1), s1 = lm::sin_(q1), c2 = lm::cos_(q2), s2 = lm::sin_(q2);
+    F q23 = q2 + q3;
+    F c3 = lm::cos_(q23), s3 = lm::sin_(q23);
+    F zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f);
+    // R1 = Rx(q1);  R2 = R1 * R(-y, q2);  R3 = R1 * R(-y, q2+q3)   (hip axis +x, thigh/shank axis -y)
+    k.R1.m[0] = one; k.R1.m[1] = zero; k.R1.m[2] = zero;
+    k.R1.m[3] = zero; k.R1.m[4] = c1; k.R1.m[5] = zero - s1;
+    k.R1.m[6] = zero; k.R1.m[7] = s1; k.R1.m[8] = c1;
+    k.R2.m[0] = c2; k.R2.m[1] = zero; k.R2.m[2] = zero - s2;
+    k.R2.m[3] = zero - s1 * s2; k.R2.m[4] = c1; k.R2.m[5] = zero - s1 * c2;
+    k.R2.m[6] = c1 * s2; k.R2.m[7] = s1; k.R2.m[8] = c1 * c2;
+    k.R3.m[0] = c3; k.R3.m[1] = zero; k.R3.m[2] = zero - s3;
+    k.R3.m[3] = zero - s1 * s3; k.R3.m[4] = c1; k.R3.m[5] = zero - s1 * c3;
+    k.R3.m[6] = c1 * s3; k.R3.m[7] = s1; k.R3.m[8] = c1 * c3;
+    k.p1 = ld3c(ln, legc, LC_R1);
+    k.p2 = k.p1 + mul(k.R1, ld3c(ln, legc, LC_R2));
+    k.p3 = k.p2 + mul(k.R2, ld3c(ln, legc, LC_R3));
+    k.a2 = mk3<F>(zero, zero - c1, zero - s1);
+    V3l a1 = mk3<F>(one, zero, zero);
+    k.s1 = cross(k.p1, a1);
+    k.s2 = cross(k.p2, k.a2);
+    k.s3 = cross(k.p3, k.a2);
+    return k;
+  }
+
+  // world position of this lane's foot (LR:199-205 compute_end_effector_info)
+  static LL_HD V3l foot_world(const L& ln, const float* legc, const V3u& p, const M3<float>& R, F q1, F q2, F q3) {
+    LegKin k = leg_fk(ln, legc, q1, q2, q3);
+    V3l fb = k.p3 + mul(k.R3, ld3c(ln, legc, LC_FOOT));
+    V3l fw = mul(R, fb);
+    return mk3<F>(fw.x + p.x, fw.y + p.y, fw.z + p.z);
+  }
+
+  // link inertia about the F0 origin, F0 axes
+  static LL_HD RI<F> link_inertia(const L& ln, const float* legc, int k, const M3<F>& R, const V3l& p, V3l* com_out, S3<F>* icom_out) {
+    F m = ln.legc(legc, LC_M + k);
+    V3l c = p + mul(R, ld3c(ln, legc, LC_COM + 3 * k));
+    S3<F> ic;
+    ic.xx = ln.legc(legc, LC_IC + 6 * k + 0); ic.xy = ln.legc(legc, LC_IC + 6 * k + 1); ic.xz = ln.legc(legc, LC_IC + 6 * k + 2);
+    ic.yy = ln.legc(legc, LC_IC + 6 * k + 3); ic.yz = ln.legc(legc, LC_IC + 6 * k + 4); ic.zz = ln.legc(legc, LC_IC + 6 * k + 5);
+    S3<F> ib = rot_sym(R, ic);
+    RI<F> I;
+    I.m = m;
+    I.h = scale(c, m);
+    F cc = dot(c, c);
+    I.io.xx = ib.xx + m * (cc - c.x * c.x); I.io.xy = ib.xy - m * c.x * c.y; I.io.xz = ib.xz - m * c.x * c.z;
+    I.io.yy = ib.yy + m * (cc - c.y * c.y); I.io.yz = ib.yz - m * c.y * c.z; I.io.zz = ib.zz + m * (cc - c.z * c.z);
+    *com_out = c;
+    *icom_out = ib;
+    return I;
+  }
+
+  // external (non-gravity) force on a body: Bullet's per-link velocity damping, about the F0 origin
+  template <class T>
+  static LL_HD SV<T> damping_force(const SV<T>& v, const V3<T>& com, const S3<T>& icom, const T& m, float kd) {
+    V3<T> vc = v.l + cross(v.a, com);
+    T sv = lm::sqrt_(dot(vc, vc)), sw = lm::sqrt_(dot(v.a, v.a));
+    V3<T> f = scale(vc, (kd + kd * sv) * m * (-1.0f));
+    V3<T> n = scale(mul(icom, v.a), (kd + kd * sw) * (-1.0f));
+    SV<T> r;
+    r.a = n + cross(com, f);
+    r.l = f;
+    return r;
+  }
+
+  // 6x6 SPD Cholesky on the packed lower triangle a[i*(i+1)/2 + j], in place; d[i] = 1/L_ii
+  static LL_HD void chol6(float* a, float* d) {
+    for (int i = 0; i < 6; i++) {
+      for (int j = 0; j <= i; j++) {
+        float s = a[i * (i + 1) / 2 + j];
+        for (int k = 0; k < j; k++) s -= a[i * (i + 1) / 2 + k] * a[j * (j + 1) / 2 + k];
+        if (i == j) {
+          float r = lm::rsqrt_(s);
+          d[i] = r;
+          a[i * (i + 1) / 2 + i] = s * r;
+        } else {
+          a[i * (i + 1) / 2 + j] = s * d[j];
+        }
+      }
+    }
+  }
+  template <class T>
+  static LL_HD void fwd6(const float* a, const float* d, T* x) {   // x <- Lb^-1 x
+    for (int i = 0; i < 6; i++) {
+      T s = x[i];
+      for (int k = 0; k < i; k++) s = s - x[k] * a[i * (i + 1) / 2 + k];
+      x[i] = s * d[i];
+    }
+  }
+  template <class T>
+  static LL_HD void bwd6(const float* a, const float* d, T* x) {   // x <- Lb^-T x
+    for (int i = 5; i >= 0; i--) {
+      T s = x[i];
+      for (int k = i + 1; k < 6; k++) s = s - x[k] * a[k * (k + 1) / 2 + i];
+      x[i] = s * d[i];
+    }
+  }
+
+  struct LegFactor {   // Cholesky of the lane's 3x3 joint-space inertia + the coupling block
+    F l11, l21, l31, l22, l32, l33, i11, i22, i33;   // Lm and 1/diag
+    SV<F> y1, y2, y3;                                // columns of Y = M_bl Lm^-T
+  };
+  static LL_HD void lm_fwd(const LegFactor& f, F* b) {   // b <- Lm^-1 b
+    b[0] = b[0] * f.i11;
+    b[1] = (b[1] - f.l21 * b[0]) * f.i22;
+    b[2] = (b[2] - f.l31 * b[0] - f.l32 * b[1]) * f.i33;
+  }
+  static LL_HD void lm_bwd(const LegFactor& f, F* u) {   // u <- Lm^-T u
+    u[2] = u[2] * f.i33;
+    u[1] = (u[1] - f.l32 * u[2]) * f.i22;
+    u[0] = (u[0] - f.l21 * u[1] - f.l31 * u[2]) * f.i11;
+  }
+
+  static LL_HD void sv_to6(const SV<F>& v, F* o) { o[0] = v.a.x; o[1] = v.a.y; o[2] = v.a.z; o[3] = v.l.x; o[4] = v.l.y; o[5] = v.l.z; }
+
+  // ---------------------------------------------------------------------------------------------------
+  // contact candidates (DESIGN.md "contact candidates"): fixed priority order per lane, first PMC_K within margin
+  // ---------------------------------------------------------------------------------------------------
+  struct CandCtx {
+    I n;            // contacts stored so far on this lane
+    float pz;       // world height of the F0 origin
+    V3u ezb;        // world up in F0 coordinates
+    float margin;
+  };
+  static LL_HD void cand_push(const L& ln, CandCtx& cc, B pass, const V3l& Pb, F depth, float link, F mu) {
+    B ok = lm::and_(pass, cc.n < PMC_K);
+    if (L::any(ok)) {
+      I w = cc.n * 6;
+      ln.lds_st_if(ok, w + 0, Pb.x); ln.lds_st_if(ok, w + 1, Pb.y); ln.lds_st_if(ok, w + 2, Pb.z);
+      ln.lds_st_if(ok, w + 3, ln.lane_f(link)); ln.lds_st_if(ok, w + 4, depth); ln.lds_st_if(ok, w + 5, mu);
+      cc.n = lm::sel(ok, cc.n + 1, cc.n);
+    }
+  }
+  // a link-attached point x (link frame): world height = z0 + ezk.x ; F0 position = p + R x
+  static LL_HD void cand_sphere(const L& ln, CandCtx& cc, const M3<F>& R, const V3l& p, F z0, const V3l& ezk, const V3l& c, F r,
+                                float link, F mu) {
+    F depth = z0 + dot(ezk, c) - r;
+    B pass = depth < cc.margin;
+    if (L::any(pass)) {
+      V3l Pb = p + mul(R, c) - scale(cvt3<F>(cc.ezb), r);
+      cand_push(ln, cc, pass, Pb, depth, link, mu);
+    }
+  }
+  static LL_HD void cand_box_vertex(const L& ln, CandCtx& cc, const M3<F>& R, const V3l& p, F zc, F za, F zb, F zcc, const V3l& c,
+                                    const V3l& ua, const V3l& ub, const V3l& uc, F sa, F sb, F sc, float link, F mu) {
+    F depth = zc + sa * za + sb * zb + sc * zcc;
+    B pass = depth < cc.margin;
+    if (L::any(pass)) {
+      V3l x = c + scale(ua, sa) + scale(ub, sb) + scale(uc, sc);
+      cand_push(ln, cc, pass, p + mul(R, x), depth, link, mu);
+    }
+  }
+  static LL_HD void cand_box(const L& ln, CandCtx& cc, const float* legc, int f, const M3<F>& R, const V3l& p, F z0, const V3l& ezk,
+                             float link, F mu) {
+    V3l c = ld3c(ln, legc, f), ua = ld3c(ln, legc, f + 3), ub = ld3c(ln, legc, f + 6), uc = ld3c(ln, legc, f + 9);
+    F zc = z0 + dot(ezk, c), za = dot(ezk, ua), zb = dot(ezk, ub), zcc = dot(ezk, uc);
+    F lo = zc - lm::abs_(za) - lm::abs_(zb) - lm::abs_(zcc);
+    if (!L::any(lo < cc.margin)) return;
+    for (int j = 0; j < 8; j++) {
+      F sa = ln.lane_f((j & 1) ? 1.0f : -1.0f), sb = ln.lane_f((j & 2) ? 1.0f : -1.0f), sc = ln.lane_f((j & 4) ? 1.0f : -1.0f);
+      cand_box_vertex(ln, cc, R, p, zc, za, zb, zcc, c, ua, ub, uc, sa, sb, sc, link, mu);
+    }
+  }
+  static LL_HD void cand_cyl(const L& ln, CandCtx& cc, const float* legc, int f, const M3<F>& R, const V3l& p, F z0, const V3l& ezk,
+                             float link, F mu) {
+    V3l c = ld3c(ln, legc, f), ax = ld3c(ln, legc, f + 3), fb = ld3c(ln, legc, f + 6);
+    F r = ln.legc(legc, f + 9), h = ln.legc(legc, f + 10);
+    F az = dot(ezk, ax);                        // cos(angle between the cylinder axis and world up)
+    F len2 = lm::max_(ln.lane_f(1.0f) - az * az, ln.lane_f(0.0f));
+    F len = lm::sqrt_(len2);
+    B degenerate = len < 1e-6f;
+    F zc = z0 + dot(ezk, c);
+    // rim direction in the link frame: (ezk - az*ax)/len, or the fallback axis when the cap is level
+    F inv = lm::sel(degenerate, ln.lane_f(0.0f), ln.lane_f(1.0f) / lm::max_(len, ln.lane_f(1e-12f)));
+    V3l dir = mk3<F>(lm::sel(degenerate, fb.x, (ezk.x - az * ax.x) * inv), lm::sel(degenerate, fb.y, (ezk.y - az * ax.y) * inv),
+                     lm::sel(degenerate, fb.z, (ezk.z - az * ax.z) * inv));
+    F dz = dot(ezk, dir);
+    for (int s = 0; s < 2; s++) {
+      F sg = ln.lane_f(s ? -1.0f : 1.0f);
+      F depth = zc + sg * h * az - r * dz;
+      B pass = depth < cc.margin;
+      if (L::any(pass)) {
+        V3l x = c + scale(ax, sg * h) - scale(dir, r);
+        cand_push(ln, cc, pass, p + mul(R, x), depth, link, mu);
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------------------------------------------
+  // one physics substep
+  // ---------------------------------------------------------------------------------------------------
+  static LL_HD void substep(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt) {
+    const float* legc = P.legc;
+    const float* bc = P.basec;
+    const float dt = P.dt;
+    M3<float> R = qmat(bs.q);
+    SV<float> v0;
+    v0.a = mulT(R, bs.w);
+    v0.l = mulT(R, bs.v);
+    V3u ezb = mk3<float>(R.m[6], R.m[7], R.m[8]);
+
+    // --- PD torque with clip (LR:126-141) + URDF joint damping --------------------------------------------
+    F tau[3];
+    for (int j = 0; j < 3; j++) {
+      F t = (tgt[j] - q[j]) * P.kp + (ln.lane_f(0.0f) - qd[j]) * P.kd;
+      t = lm::min_(lm::max_(t, ln.lane_f(-P.max_tau)), ln.lane_f(P.max_tau));
+      tau[j] = t - ln.legc(legc, LC_JDAMP + j) * qd[j];
+    }
+
+    // --- leg kinematics, velocities -------------------------------------------------------------------------
+    LegKin k = leg_fk(ln, legc, q[0], q[1], q[2]);
+    F zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f);
+    SV<F> S1, S2, S3v;
+    S1.a = mk3<F>(one, zero, zero); S1.l = k.s1;
+    S2.a = k.a2; S2.l = k.s2;
+    S3v.a = k.a2; S3v.l = k.s3;
+    SV<F> vb = cvt6<F>(v0);
+    SV<F> v1 = vb + scale(S1, qd[0]);
+    SV<F> v2 = v1 + scale(S2, qd[1]);
+    SV<F> v3 = v2 + scale(S3v, qd[2]);
+    // velocity-product accelerations (frame falling with gravity, base acceleration zero)
+    SV<F> a1 = scale(crm(vb, S1), qd[0]);
+    SV<F> a2 = a1 + scale(crm(v1, S2), qd[1]);
+    SV<F> a3 = a2 + scale(crm(v2, S3v), qd[2]);
+
+    // --- link inertias, bias forces --------------------------------------------------------------------------
+    V3l c1, c2, c3;
+    S3<F> ic1, ic2, ic3;
+    RI<F> I1 = link_inertia(ln, legc, 0, k.R1, k.p1, &c1, &ic1);
+    RI<F> I2 = link_inertia(ln, legc, 1, k.R2, k.p2, &c2, &ic2);
+    RI<F> I3 = link_inertia(ln, legc, 2, k.R3, k.p3, &c3, &ic3);
+    SV<F> f3 = apply(I3, a3) + crf(v3, apply(I3, v3)) + scale(damping_force<F>(v3, c3, ic3, I3.m, P.link_damping), ln.lane_f(-1.0f));
+    SV<F> f2 = apply(I2, a2) + crf(v2, apply(I2, v2)) + scale(damping_force<F>(v2, c2, ic2, I2.m, P.link_damping), ln.lane_f(-1.0f));
+    SV<F> f1 = apply(I1, a1) + crf(v1, apply(I1, v1)) + scale(damping_force<F>(v1, c1, ic1, I1.m, P.link_damping), ln.lane_f(-1.0f));
+    SV<F> f23 = f2 + f3;
+    SV<F> f123 = f1 + f23;
+    F b[3];
+    b[0] = tau[0] - dot(S1, f123);
+    b[1] = tau[1] - dot(S2, f23);
+    b[2] = tau[2] - dot(S3v, f3);
+
+    // --- composite inertias, joint-space inertia of the leg, coupling to the base ------------------------------
+    RI<F> Ic2 = add(I2, I3);
+    RI<F> Ic1 = add(I1, Ic2);
+    SV<F> F3 = apply(I3, S3v), F2 = apply(Ic2, S2), F1 = apply(Ic1, S1);
+    F m33 = dot(S3v, F3), m23 = dot(S2, F3), m13 = dot(S1, F3), m22 = dot(S2, F2), m12 = dot(S1, F2), m11 = dot(S1, F1);
+    LegFactor lf;
+    lf.i11 = lm::rsqrt_(m11); lf.l11 = m11 * lf.i11;
+    lf.l21 = m12 * lf.i11; lf.l31 = m13 * lf.i11;
+    F d22 = m22 - lf.l21 * lf.l21;
+    lf.i22 = lm::rsqrt_(d22); lf.l22 = d22 * lf.i22;
+    lf.l32 = (m23 - lf.l31 * lf.l21) * lf.i22;
+    F d33 = m33 - lf.l31 * lf.l31 - lf.l32 * lf.l32;
+    lf.i33 = lm::rsqrt_(d33); lf.l33 = d33 * lf.i33;
+    lf.y1 = scale(F1, lf.i11);
+    lf.y2 = scale(F2 + scale(lf.y1, zero - lf.l21), lf.i22);
+    lf.y3 = scale(F3 + scale(lf.y1, zero - lf.l31) + scale(lf.y2, zero - lf.l32), lf.i33);
+
+    // --- base: S = I_base + sum I^c_leg - sum Y Y^T ; packed lower triangle, index order [wx wy wz vx vy vz] ----
+    float Sb[21], Sd[6];
+    {
+      float m = bc[BC_MASS] + L::qsum(Ic1.m);
+      float hx = bc[BC_H + 0] + L::qsum(Ic1.h.x), hy = bc[BC_H + 1] + L::qsum(Ic1.h.y), hz = bc[BC_H + 2] + L::qsum(Ic1.h.z);
+      float ixx = bc[BC_IO + 0] + L::qsum(Ic1.io.xx), ixy = bc[BC_IO + 1] + L::qsum(Ic1.io.xy), ixz = bc[BC_IO + 2] + L::qsum(Ic1.io.xz);
+      float iyy = bc[BC_IO + 3] + L::qsum(Ic1.io.yy), iyz = bc[BC_IO + 4] + L::qsum(Ic1.io.yz), izz = bc[BC_IO + 5] + L::qsum(Ic1.io.zz);
+      // [[Io, hx],[-hx, m]] with hx = skew(h): rows 3..5 x cols 0..2 hold -skew(h) = [[0,hz,-hy],[-hz,0,hx],[hy,-hx,0]]
+      Sb[0] = ixx;
+      Sb[1] = ixy; Sb[2] = iyy;
+      Sb[3] = ixz; Sb[4] = iyz; Sb[5] = izz;
+      Sb[6] = 0.0f; Sb[7] = hz; Sb[8] = -hy; Sb[9] = m;
+      Sb[10] = -hz; Sb[11] = 0.0f; Sb[12] = hx; Sb[13] = 0.0f; Sb[14] = m;
+      Sb[15] = hy; Sb[16] = -hx; Sb[17] = 0.0f; Sb[18] = 0.0f; Sb[19] = 0.0f; Sb[20] = m;
+      F y1[6], y2[6], y3[6];
+      sv_to6(lf.y1, y1); sv_to6(lf.y2, y2); sv_to6(lf.y3, y3);
+      for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) Sb[i * (i + 1) / 2 + j] -= L::qsum(y1[i] * y1[j] + y2[i] * y2[j] + y3[i] * y3[j]);
+      chol6(Sb, Sd);
+    }
+
+    // --- unconstrained accelerations ---------------------------------------------------------------------------
+    lm_fwd(lf, b);                                              // bt = Lm^-1 (tau - C_l)
+    SV<F> z = scale(lf.y1, b[0]) + scale(lf.y2, b[1]) + scale(lf.y3, b[2]);
+    float xb[6];
+    {
+      RI<float> I0;
+      I0.m = bc[BC_MASS];
+      I0.h = mk3<float>(bc[BC_H], bc[BC_H + 1], bc[BC_H + 2]);
+      I0.io.xx = bc[BC_IO]; I0.io.xy = bc[BC_IO + 1]; I0.io.xz = bc[BC_IO + 2]; I0.io.yy = bc[BC_IO + 3]; I0.io.yz = bc[BC_IO + 4]; I0.io.zz = bc[BC_IO + 5];
+      S3<float> ic0;
+      ic0.xx = bc[BC_ICOM]; ic0.xy = bc[BC_ICOM + 1]; ic0.xz = bc[BC_ICOM + 2]; ic0.yy = bc[BC_ICOM + 3]; ic0.yz = bc[BC_ICOM + 4]; ic0.zz = bc[BC_ICOM + 5];
+      V3u com0 = mk3<float>(bc[BC_COM], bc[BC_COM + 1], bc[BC_COM + 2]);
+      SV<float> f0 = crf(v0, apply(I0, v0)) + scale(damping_force<float>(v0, com0, ic0, I0.m, P.link_damping), -1.0f);
+      xb[0] = -(f0.a.x + L::qsum(f123.a.x + z.a.x)); xb[1] = -(f0.a.y + L::qsum(f123.a.y + z.a.y)); xb[2] = -(f0.a.z + L::qsum(f123.a.z + z.a.z));
+      xb[3] = -(f0.l.x + L::qsum(f123.l.x + z.l.x)); xb[4] = -(f0.l.y + L::qsum(f123.l.y + z.l.y)); xb[5] = -(f0.l.z + L::qsum(f123.l.z + z.l.z));
+      fwd6(Sb, Sd, xb);
+      bwd6(Sb, Sd, xb);
+    }
+    SV<float> ab;
+    ab.a = mk3<float>(xb[0], xb[1], xb[2]); ab.l = mk3<float>(xb[3], xb[4], xb[5]);
+    F u[3];
+    u[0] = b[0] - dot(lf.y1, ab); u[1] = b[1] - dot(lf.y2, ab); u[2] = b[2] - dot(lf.y3, ab);
+    lm_bwd(lf, u);                                              // qdd
+
+    // --- velocities after the unconstrained update (frozen F0 coordinates) -------------------------------------------
+    float xi[6];
+    {
+      V3u wxv = cross(v0.a, v0.l);
+      float g = -P.gravity;
+      xi[0] = v0.a.x + dt * ab.a.x; xi[1] = v0.a.y + dt * ab.a.y; xi[2] = v0.a.z + dt * ab.a.z;
+      xi[3] = v0.l.x + dt * (ab.l.x + wxv.x + g * ezb.x); xi[4] = v0.l.y + dt * (ab.l.y + wxv.y + g * ezb.y); xi[5] = v0.l.z + dt * (ab.l.z + wxv.z + g * ezb.z);
+    }
+    F qs[3];
+    for (int j = 0; j < 3; j++) qs[j] = qd[j] + u[j] * dt;
+
+    // --- joint-limit rows (kept in registers) ----------------------------------------------------------------------------
+    F lgt[3][6], ljt[3][3], lc_[3], linv[3], llam[3];
+    B lvalid[3];
+    float inv_dt = 1.0f / dt;
+    for (int j = 0; j < 3; j++) {
+      F dl = q[j] - ln.legc(legc, LC_QLO + j), dh = ln.legc(legc, LC_QHI + j) - q[j];
+      B lower = dl <= dh;
+      F d = lm::sel(lower, dl, dh), sg = lm::sel(lower, one, zero - one);
+      lvalid[j] = d < 0.25f;
+      F jt[3] = {zero, zero, zero};
+      jt[j] = sg;
+      lm_fwd(lf, jt);
+      SV<F> g6 = scale(scale(lf.y1, jt[0]) + scale(lf.y2, jt[1]) + scale(lf.y3, jt[2]), zero - one);
+      F gt[6];
+      sv_to6(g6, gt);
+      fwd6(Sb, Sd, gt);
+      F nn = jt[0] * jt[0] + jt[1] * jt[1] + jt[2] * jt[2];
+      for (int i = 0; i < 6; i++) { lgt[j][i] = gt[i]; nn = nn + gt[i] * gt[i]; }
+      for (int i = 0; i < 3; i++) ljt[j][i] = jt[i];
+      linv[j] = one / nn;
+      lc_[j] = sg * qs[j] + lm::sel(d > 0.0f, d * inv_dt, d * (P.erp * inv_dt));
+      llam[j] = zero;
+    }
+
+    // --- contact candidates -----------------------------------------------------------------------------------------------
+    CandCtx cc;
+    cc.n = L::f2i(zero);
+    cc.pz = bs.p.z;
+    cc.ezb = ezb;
+    cc.margin = P.margin_dist;
+    {
+      F mu_l = ln.lane_f(P.mu_link), mu_f = ln.lane_f(P.mu_foot);
+      V3l ez = cvt3<F>(ezb);
+      V3l ez1 = mulT(k.R1, ez), ez2 = mulT(k.R2, ez), ez3 = mulT(k.R3, ez);
+      F z1 = dot(ez, k.p1) + cc.pz, z2 = dot(ez, k.p2) + cc.pz, z3 = dot(ez, k.p3) + cc.pz;
+      // priority: foot, shank box, wheel, thigh box, thigh cylinders, hip cylinder, then the lane's share of the base
+      cand_sphere(ln, cc, k.R3, k.p3, z3, ez3, ld3c(ln, legc, LC_FOOTSPH), ln.legc(legc, LC_FOOTSPH + 3), 3.0f, mu_f);
+      cand_box(ln, cc, legc, LC_SHBOX, k.R3, k.p3, z3, ez3, 3.0f, mu_l);
+      cand_cyl(ln, cc, legc, LC_WHEEL, k.R2, k.p2, z2, ez2, 2.0f, mu_l);
+      cand_box(ln, cc, legc, LC_THBOX, k.R2, k.p2, z2, ez2, 2.0f, mu_l);
+      cand_cyl(ln, cc, legc, LC_THCYL0, k.R2, k.p2, z2, ez2, 2.0f, mu_l);
+      cand_cyl(ln, cc, legc, LC_THCYL1, k.R2, k.p2, z2, ez2, 2.0f, mu_l);
+      cand_cyl(ln, cc, legc, LC_HIPCYL, k.R1, k.p1, z1, ez1, 1.0f, mu_l);
+      // base box: this lane owns the two vertices with its (sx, sy) signs
+      {
+        V3u c = mk3<float>(bc[BC_BOX], bc[BC_BOX + 1], bc[BC_BOX + 2]);
+        V3u ua = mk3<float>(bc[BC_BOX + 3], bc[BC_BOX + 4], bc[BC_BOX + 5]), ub = mk3<float>(bc[BC_BOX + 6], bc[BC_BOX + 7], bc[BC_BOX + 8]),
+            uc = mk3<float>(bc[BC_BOX + 9], bc[BC_BOX + 10], bc[BC_BOX + 11]);
+        float zc = cc.pz + dot(ezb, c), za = dot(ezb, ua), zb = dot(ezb, ub), zcc = dot(ezb, uc);
+        float lo = zc - fabsf(za) - fabsf(zb) - fabsf(zcc);
+        if (lo < cc.margin) {
+          F sx = ln.legc(legc, LC_BSX), sy = ln.legc(legc, LC_BSY);
+          for (int s = 0; s < 2; s++) {
+            F sz = ln.lane_f(s ? 1.0f : -1.0f);
+            F depth = sx * za + sy * zb + sz * zcc + zc;
+            B pass = depth < cc.margin;
+            if (L::any(pass)) {
+              V3l Pb = cvt3<F>(c) + scale(cvt3<F>(ua), sx) + scale(cvt3<F>(ub), sy) + scale(cvt3<F>(uc), sz);
+              cand_push(ln, cc, pass, Pb, depth, 0.0f, mu_l);
+            }
+          }
+        }
+        // handle spheres (lanes 0 and 2)
+        B has = ln.legc(legc, LC_HAS_HANDLE) > 0.5f;
+        V3l hc = ld3c(ln, legc, LC_HANDLE);
+        F hr = ln.legc(legc, LC_HANDLE + 3);
+        F depth = dot(cvt3<F>(ezb), hc) + cc.pz - hr;
+        B pass = lm::and_(has, depth < cc.margin);
+        if (L::any(pass)) cand_push(ln, cc, pass, hc - scale(cvt3<F>(ezb), hr), depth, 0.0f, mu_l);
+      }
+    }
+
+    // --- contact rows: n = +z, t1 = -y, t2 = +x (world), expressed in F0 ------------------------------------------------------
+    int max_n = 0;
+    for (int s = 0; s < PMC_K; s++) {
+      B valid = cc.n > s;
+      if (!L::any(valid)) break;
+      max_n = s + 1;
+      V3l Pb = mk3<F>(ln.lds_ld(LW_CAND(s, 0)), ln.lds_ld(LW_CAND(s, 1)), ln.lds_ld(LW_CAND(s, 2)));
+      F link = ln.lds_ld(LW_CAND(s, 3)), depth = ln.lds_ld(LW_CAND(s, 4));
+      F bias = lm::sel(depth > 0.0f, depth * inv_dt, depth * (P.erp * inv_dt));
+      // joint j moves the point iff the point's link is at or below joint j: link >= j+1
+      F on1 = lm::sel(link > 0.5f, one, zero), on2 = lm::sel(link > 1.5f, one, zero), on3 = lm::sel(link > 2.5f, one, zero);
+      V3l r1 = Pb - k.p1, r2 = Pb - k.p2, r3 = Pb - k.p3;
+      V3l a1v = mk3<F>(one, zero, zero);
+      V3l d1 = scale(cross(a1v, r1), on1), d2 = scale(cross(k.a2, r2), on2), d3 = scale(cross(k.a2, r3), on3);
+      for (int r = 0; r < 3; r++) {
+        V3u ub = (r == 0) ? ezb : (r == 1 ? mk3<float>(-R.m[3], -R.m[4], -R.m[5]) : mk3<float>(R.m[0], R.m[1], R.m[2]));
+        V3l uu = cvt3<F>(ub);
+        F jl[3];
+        jl[0] = dot(uu, d1); jl[1] = dot(uu, d2); jl[2] = dot(uu, d3);
+        V3l pxu = cross(Pb, uu);
+        // free row velocity J_b xi + J_l qd*
+        F vrow = pxu.x * xi[0] + pxu.y * xi[1] + pxu.z * xi[2] + uu.x * xi[3] + uu.y * xi[4] + uu.z * xi[5] + jl[0] * qs[0] + jl[1] * qs[1] + jl[2] * qs[2];
+        lm_fwd(lf, jl);                                            // jt
+        SV<F> yj = scale(lf.y1, jl[0]) + scale(lf.y2, jl[1]) + scale(lf.y3, jl[2]);
+        F gt[6];
+        gt[0] = pxu.x - yj.a.x; gt[1] = pxu.y - yj.a.y; gt[2] = pxu.z - yj.a.z;
+        gt[3] = uu.x - yj.l.x; gt[4] = uu.y - yj.l.y; gt[5] = uu.z - yj.l.z;
+        fwd6(Sb, Sd, gt);
+        F nn = jl[0] * jl[0] + jl[1] * jl[1] + jl[2] * jl[2];
+        for (int i = 0; i < 6; i++) { nn = nn + gt[i] * gt[i]; ln.lds_st(LW_ROW(s, r, i), gt[i]); }
+        for (int i = 0; i < 3; i++) ln.lds_st(LW_ROW(s, r, 6 + i), jl[i]);
+        ln.lds_st(LW_ROW(s, r, 9), (r == 0) ? vrow + bias : vrow);
+        ln.lds_st(LW_ROW(s, r, 10), one / nn);
+        ln.lds_st(LW_LAM(s, r), zero);
+      }
+    }
+
+    // --- projected Gauss-Seidel in whitened coordinates -------------------------------------------------------------------------
+    float dx[6] = {0, 0, 0, 0, 0, 0};      // shared:  sum gt * lambda
+    F dq[3] = {zero, zero, zero};          // private: sum jt * lambda
+    for (int it = 0; it < P.n_iter; it++) {
+      // row order of the spec: the 12 joint-limit rows (leg, joint), then the contacts (leg, slot; n, t1, t2)
+      pgs_limits<0>(ln, lgt, ljt, lc_, linv, llam, lvalid, dx, dq);
+      pgs_limits<1>(ln, lgt, ljt, lc_, linv, llam, lvalid, dx, dq);
+      pgs_limits<2>(ln, lgt, ljt, lc_, linv, llam, lvalid, dx, dq);
+      pgs_limits<3>(ln, lgt, ljt, lc_, linv, llam, lvalid, dx, dq);
+      pgs_contacts<0>(ln, cc.n, max_n, dx, dq);
+      pgs_contacts<1>(ln, cc.n, max_n, dx, dq);
+      pgs_contacts<2>(ln, cc.n, max_n, dx, dq);
+      pgs_contacts<3>(ln, cc.n, max_n, dx, dq);
+    }
+    // back to velocities: d(xi) = Lb^-T dx ; d(qd) = Lm^-T (dq - Y^T d(xi))
+    bwd6(Sb, Sd, dx);
+    SV<float> dxi;
+    dxi.a = mk3<float>(dx[0], dx[1], dx[2]); dxi.l = mk3<float>(dx[3], dx[4], dx[5]);
+    F du[3];
+    du[0] = dq[0] - dot(lf.y1, dxi); du[1] = dq[1] - dot(lf.y2, dxi); du[2] = dq[2] - dot(lf.y3, dxi);
+    lm_bwd(lf, du);
+    for (int i = 0; i < 6; i++) xi[i] += dx[i];
+    for (int j = 0; j < 3; j++) qs[j] = qs[j] + du[j];
+
+    // --- integrate positions with the new velocities (semi-implicit Euler) ---------------------------------------------------------
+    bs.w = mul(R, mk3<float>(xi[0], xi[1], xi[2]));
+    bs.v = mul(R, mk3<float>(xi[3], xi[4], xi[5]));
+    bs.p = bs.p + scale(bs.v, dt);
+    Q4 dqt = quat_of_rotvec(scale(bs.w, dt));
+    bs.q = qnormalize(qmul(dqt, qnormalize(bs.q)));
+    for (int j = 0; j < 3; j++) {
+      qd[j] = qs[j];
+      q[j] = q[j] + qs[j] * dt;
+    }
+  }
+
+  // rows owned by leg LEG take their Gauss-Seidel turn; only that lane commits, the shared update is quad-broadcast
+  template <int LEG>
+  static LL_HD void pgs_limits(const L& ln, F (*lgt)[6], F (*ljt)[3], F* lc_, F* linv, F* llam, B* lvalid, float* dx, F* dq) {
+    B mine = ln.is_leg(LEG);
+    F zero = ln.lane_f(0.0f);
+    for (int j = 0; j < 3; j++) {
+      B act = lm::and_(mine, lvalid[j]);
+      if (!L::any(act)) continue;
+      F w = lc_[j] + ljt[j][0] * dq[0] + ljt[j][1] * dq[1] + ljt[j][2] * dq[2];
+      for (int i = 0; i < 6; i++) w = w + lgt[j][i] * dx[i];
+      F ln_new = lm::max_(llam[j] - w * linv[j], zero);
+      F dl = lm::sel(act, ln_new - llam[j], zero);
+      llam[j] = llam[j] + dl;
+      for (int i = 0; i < 3; i++) dq[i] = dq[i] + ljt[j][i] * dl;
+      for (int i = 0; i < 6; i++) dx[i] += L::template bcast<LEG>(lgt[j][i] * dl);
+    }
+  }
+  template <int LEG>
+  static LL_HD void pgs_contacts(const L& ln, I n, int max_n, float* dx, F* dq) {
+    B mine = ln.is_leg(LEG);
+    F zero = ln.lane_f(0.0f);
+    for (int s = 0; s < max_n; s++) {
+      B act = lm::and_(mine, n > s);
+      if (!L::any(act)) continue;
+      F mu = ln.lds_ld(LW_CAND(s, 5));
+      F lam_n = zero;
+      for (int r = 0; r < 3; r++) {
+        F gt[6], jt[3];
+        for (int i = 0; i < 6; i++) gt[i] = ln.lds_ld(LW_ROW(s, r, i));
+        for (int i = 0; i < 3; i++) jt[i] = ln.lds_ld(LW_ROW(s, r, 6 + i));
+        F w = ln.lds_ld(LW_ROW(s, r, 9)) + jt[0] * dq[0] + jt[1] * dq[1] + jt[2] * dq[2];
+        for (int i = 0; i < 6; i++) w = w + gt[i] * dx[i];
+        F lam = ln.lds_ld(LW_LAM(s, r));
+        F cand = lam - w * ln.lds_ld(LW_ROW(s, r, 10));
+        F hi = mu * lam_n;
+        F lnew = (r == 0) ? lm::max_(cand, zero) : lm::min_(lm::max_(cand, zero - hi), hi);
+        F dl = lm::sel(act, lnew - lam, zero);
+        lam = lam + dl;
+        if (r == 0) lam_n = lam;
+        ln.lds_st(LW_LAM(s, r), lam);
+        for (int i = 0; i < 3; i++) dq[i] = dq[i] + jt[i] * dl;
+        for (int i = 0; i < 6; i++) dx[i] += L::template bcast<LEG>(gt[i] * dl);
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------------------------------------------
+  // mocap reference (ML:65-166)
+  // ---------------------------------------------------------------------------------------------------
+  struct RefPose {
+    V3u p;
+    Q4 q;
+    V3u v, w;
+    F jp[3], jv[3];
+  };
+  // interpolate between two rows of the clip (ML:88-166); velocities only when want_vel
+  static LL_HD RefPose mocap_interp(const L& ln, const double* fc, const double* fn, double frac, double frame_step, bool want_vel) {
+    RefPose o;
+    o.p = mk3<float>((float)(fc[0] + frac * (fn[0] - fc[0])), (float)(fc[1] + frac * (fn[1] - fc[1])), (float)(fc[2] + frac * (fn[2] - fc[2])));
+    // quaternion difference formed from the float64 row delta so the small rotation keeps its precision
+    Q4 qc = {(float)fc[3], (float)fc[4], (float)fc[5], (float)fc[6]};
+    Q4 dl = {(float)(fn[3] - fc[3]), (float)(fn[4] - fc[4]), (float)(fn[5] - fc[5]), (float)(fn[6] - fc[6])};
+    Q4 qci = qconj(qc);
+    Q4 e = qmul(qci, dl);                                   // qc^-1 qn = 1 + qc^-1 (qn - qc)
+    V3u rv = rotvec_of(mk3<float>(e.x, e.y, e.z), 1.0f + e.w);   // ML:127-134 (scipy Slerp)
+    float ff = (float)frac;
+    Q4 dq = quat_of_rotvec(mk3<float>(rv.x * ff, rv.y * ff, rv.z * ff));
+    o.q = qmul(qc, dq);
+    for (int j = 0; j < 3; j++) {
+      D c = ln.lddl(fc, 7 + j, 3), n = ln.lddl(fn, 7 + j, 3);
+      o.jp[j] = L::d2f(c + (n - c) * frac);                 // ML:157
+      o.jv[j] = L::d2f((n - c) * (1.0 / frame_step));       // ML:158
+    }
+    if (want_vel) {
+      double inv = 1.0 / frame_step;
+      o.v = mk3<float>((float)((fn[0] - fc[0]) * inv), (float)((fn[1] - fc[1]) * inv), (float)((fn[2] - fc[2]) * inv));   // ML:137-140
+      Q4 e2 = qmul(dl, qci);                                // qn qc^-1 = 1 + (qn - qc) qc^-1            ML:143-149
+      V3u rv2 = rotvec_of(mk3<float>(e2.x, e2.y, e2.z), 1.0f + e2.w);
+      float ang = sqrtf(rv2.x * rv2.x + rv2.y * rv2.y + rv2.z * rv2.z);
+      float kk = ang / (ang + 1e-8f) * (float)inv;
+      o.w = mk3<float>(rv2.x * kk, rv2.y * kk, rv2.z * kk);
+    } else {
+      o.v = mk3<float>(0.f, 0.f, 0.f);
+      o.w = o.v;
+    }
+    return o;
+  }
+
+  // ---------------------------------------------------------------------------------------------------
+  // observation (PLE:247-317).  The obs row doubles as the history store: frames 1,2 of the previous row are
+  // frames 0,1 of the new one (deque maxlen 3, PLE:145-147); `fill` = reset pre-fill (PLE:282-290).
+  // ---------------------------------------------------------------------------------------------------
+  static LL_HD void write_obs(const L& ln, const StepParams& P, int env, float* row, const float* hist_row, bool fill, const Base& bs,
+                              const M3<float>& R, const F* q, const F* qd, const F* act, const double* clip_rows, int frame_id, double frac) {
+    const int Pd = P.prop_dim;
+    B lane3 = ln.legf() < 2.5f;
+    long a0 = 3L * Pd;
+    // --- history shift (or pre-fill handled below) ---
+    if (!fill) {
+      for (int i = 0; i < (2 * Pd + 3) / 4; i++) {
+        F idx = ln.legf() + (float)(4 * i);
+        B ok = idx < (float)(2 * Pd);
+        F v = ln.ldl(hist_row, Pd + 4 * i, 1);
+        ln.stl_if(ok, row, 4 * i, 1, lm::sel(ok, v, ln.lane_f(0.0f)));
+      }
+      for (int i = 0; i < 6; i++) {                               // 24 action history floats
+        F v = ln.ldl(hist_row, a0 + 12 + 4 * i, 1);
+        ln.stl(row, a0 + 4 * i, 1, v);
+      }
+    }
+    // --- newest prop frame (PLE:247-260) ---
+    V3u wl = mulT(R, bs.w), vl = mulT(R, bs.v);
+    for (int kf = (fill ? 0 : 2); kf < 3; kf++) {
+      long fb = (long)kf * Pd;
+      if (P.prop_off[0] >= 0) for (int j = 0; j < 3; j++) ln.stl(row, fb + P.prop_off[0] + j, 3, q[j]);      // joint_pos
+      if (P.prop_off[1] >= 0) for (int j = 0; j < 3; j++) ln.stl(row, fb + P.prop_off[1] + j, 3, qd[j]);     // joint_vel
+      if (P.prop_off[2] >= 0) ln.stl_if(lane3, row, fb + P.prop_off[2], 1, ln.pick3(vl.x, vl.y, vl.z));      // R^-1 v
+      if (P.prop_off[3] >= 0) ln.stl_if(lane3, row, fb + P.prop_off[3], 1, ln.pick3(wl.x, wl.y, wl.z));      // R^-1 w
+      if (P.prop_off[4] >= 0) ln.stl_if(lane3, row, fb + P.prop_off[4], 1, ln.pick3(R.m[6], R.m[7], R.m[8])); // R[2,:]
+      for (int j = 0; j < 3; j++) ln.stl(row, a0 + 12 * kf + j, 3, act[j]);                                   // raw action (quirk Q3)
+    }
+    // --- future goals (ML:75-86 + PLE:299-317) ---
+    const double hz[4] = {1. / 30., 1. / 15., 1. / 3., 1.};
+    long f0 = a0 + 36;
+    Q4 qbi = qconj(qnormalize(bs.q));
+    for (int h = 0; h < 4; h++) {
+      double t = P.frame_step * frac + hz[h];
+      int fid = (int)floor(t / P.frame_step);
+      double ff = t / P.frame_step - fid;
+      const double* fc = clip_rows + (long)(frame_id + fid) * 19;
+      RefPose rp = mocap_interp(ln, fc, fc + 19, ff, P.frame_step, false);
+      V3u dp = mulT(R, mk3<float>(rp.p.x - bs.p.x, rp.p.y - bs.p.y, rp.p.z - bs.p.z));
+      V3u aa;
+      axis_angle_scaled(qmul(qbi, qnormalize(rp.q)), &aa);
+      ln.stl_if(lane3, row, f0 + 18 * h, 1, ln.pick3(dp.x, dp.y, dp.z));
+      ln.stl_if(lane3, row, f0 + 18 * h + 3, 1, ln.pick3(aa.x, aa.y, aa.z));
+      for (int j = 0; j < 3; j++) ln.stl(row, f0 + 18 * h + 6 + j, 3, rp.jp[j]);
+    }
+  }
+
+  // ---------------------------------------------------------------------------------------------------
+  // state I/O (SoA [field][n_envs])
+  // ---------------------------------------------------------------------------------------------------
+  static LL_HD void load_state(const L& ln, const float* s, int N, int env, Base& bs, F* q, F* qd) {
+    bs.p = mk3<float>(s[0 * N + env], s[1 * N + env], s[2 * N + env]);
+    bs.q.x = s[3 * N + env]; bs.q.y = s[4 * N + env]; bs.q.z = s[5 * N + env]; bs.q.w = s[6 * N + env];
+    bs.v = mk3<float>(s[7 * N + env], s[8 * N + env], s[9 * N + env]);
+    bs.w = mk3<float>(s[10 * N + env], s[11 * N + env], s[12 * N + env]);
+    for (int j = 0; j < 3; j++) {
+      q[j] = ln.ldl(s, (long)(13 + j) * N + env, 3L * N);
+      qd[j] = ln.ldl(s, (long)(25 + j) * N + env, 3L * N);
+    }
+  }
+  static LL_HD void store_state(const L& ln, float* s, int N, int env, const Base& bs, const F* q, const F* qd) {
+    B lane3 = ln.legf() < 2.5f;
+    ln.stl_if(lane3, s, env, N, ln.pick3(bs.p.x, bs.p.y, bs.p.z));
+    ln.stl(s, 3L * N + env, N, lm::sel(ln.is_leg(3), ln.lane_f(bs.q.w), ln.pick3(bs.q.x, bs.q.y, bs.q.z)));
+    ln.stl_if(lane3, s, 7L * N + env, N, ln.pick3(bs.v.x, bs.v.y, bs.v.z));
+    ln.stl_if(lane3, s, 10L * N + env, N, ln.pick3(bs.w.x, bs.w.y, bs.w.z));
+    for (int j = 0; j < 3; j++) {
+      ln.stl(s, (long)(13 + j) * N + env, 3L * N, q[j]);
+      ln.stl(s, (long)(25 + j) * N + env, 3L * N, qd[j]);
+    }
+  }
+
+  // ---------------------------------------------------------------------------------------------------
+  // reset one env at (clip, t0): PLE:150-171 + ML:48-57.  Writes state, ghost, bookkeeping and the first obs.
+  // ---------------------------------------------------------------------------------------------------
+  static LL_HD void reset_env(const L& ln, const StepParams& P, int env, int clip, double t0) {
+    const int N = P.n_envs;
+    int fid = (int)floor(t0 / P.frame_step);                                  // ML:52
+    double frac = (t0 - fid * P.frame_step) / P.frame_step;                    // ML:53
+    const double* rows = P.frames + (long)P.clip_off[clip] * 19;
+    RefPose rp = mocap_interp(ln, rows + (long)fid * 19, rows + (long)(fid + 1) * 19, frac, P.frame_step, true);
+    Base bs;
+    bs.p = rp.p; bs.q = rp.q; bs.v = rp.v; bs.w = rp.w;
+    store_state(ln, P.kin, N, env, bs, rp.jp, rp.jv);                          // PLE:162
+    store_state(ln, P.state, N, env, bs, rp.jp, rp.jv);                        // PLE:163
+    M3<float> R = qmat(qnormalize(bs.q));
+    F zero3[3] = {ln.lane_f(0.0f), ln.lane_f(0.0f), ln.lane_f(0.0f)};
+    float* row = P.obs + (long)env * P.obs_dim;
+    write_obs(ln, P, env, row, row, true, bs, R, rp.jp, rp.jv, zero3, rows, fid, frac);   // PLE:168-170
+    V3l fw = foot_world(ln, P.legc, bs.p, R, rp.jp[0], rp.jp[1], rp.jp[2]);
+    for (int c = 0; c < 3; c++) {
+      F v = (c == 0) ? fw.x : (c == 1 ? fw.y : fw.z);
+      ln.stl(P.feet, (long)c * N + env, 3L * N, v);
+      ln.stl(P.feet, (long)(12 + c) * N + env, 3L * N, v);
+    }
+    // quad-uniform bookkeeping: every lane of the quad writes the same value
+    P.time[env] = t0;
+    P.clip[env] = clip;
+    P.ep_steps[env] = 0;
+    P.reward_sum[env] = 0.0f;
+  }
+
+  // sample (clip, t0) for a new episode: ML:59-63 + ML:50-51, Philox stream keyed on (seed; env, episode)
+  static LL_HD void sample_start(const StepParams& P, int env, uint32_t episode, int* clip, double* t0) {
+    uint32_t r[4];
+    philox4x32((uint32_t)env, episode, 0x5eedu, 0u, (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r);
+    double u1 = u01_from(r[0], r[1]), u2 = u01_from(r[2], r[3]);
+    int c = P.n_clips - 1;
+    for (int i = 0; i < P.n_clips; i++) {
+      if (u1 < P.cdf[i]) { c = i; break; }
+    }
+    *clip = c;
+    *t0 = u2 * (P.frame_step * (double)(P.clip_len[c] - P.margin - 1));
+  }
+
+  // ---------------------------------------------------------------------------------------------------
+  // the control step
+  // ---------------------------------------------------------------------------------------------------
+  static LL_HD void clear_scratch(const L& ln) {   // stale rows must at least be finite (they are multiplied by 0)
+    for (int w = 0; w < LW_COUNT; w++) ln.lds_st(w, ln.lane_f(0.0f));
+  }
+
+  static LL_HD void step_env(const L& ln, const StepParams& P, int env) {
+    const int N = P.n_envs;
+    Base bs;
+    F q[3], qd[3], act[3], tgt[3];
+    load_state(ln, P.state, N, env, bs, q, qd);
+    for (int j = 0; j < 3; j++) {
+      act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
+      F t = q[j] + act[j];                                                   // PLE:199-200
+      tgt[j] = lm::min_(lm::max_(t, ln.lane_f(-3.0f)), ln.lane_f(3.0f));     // LR:126-127
+    }
+    double t = P.time[env], t_loc = t;
+    const int clip = P.clip[env];
+    for (int s = 0; s < P.n_sub; s++) {                                      // PLE:202
+      substep(ln, P, bs, q, qd, tgt);                                        // PLE:204-206
+      t_loc = t;                                                             // PLE:208 motion.step(time BEFORE the increment), quirk Q2
+      t += P.dt_d;                                                           // PLE:210
+    }
+    int fid = (int)floor(t_loc / P.frame_step);                              // ML:66
+    {                                                                        // keep a done-but-still-stepped env inside its clip
+      int fmax = P.clip_len[clip] - P.frame_rate - 3;
+      if (fid > fmax) fid = fmax;
+    }
+    double frac = (t_loc - fid * P.frame_step) / P.frame_step;               // ML:67
+    const double* rows = P.frames + (long)P.clip_off[clip] * 19;
+    RefPose rp = mocap_interp(ln, rows + (long)fid * 19, rows + (long)(fid + 1) * 19, frac, P.frame_step, true);   // PLE:217
+
+    // non-finite guard
+    F fin = q[0] + q[1] + q[2] + qd[0] + qd[1] + qd[2];
+    float chk = L::qsum(fin) + bs.p.x + bs.p.y + bs.p.z + bs.q.x + bs.q.y + bs.q.z + bs.q.w + bs.v.x + bs.v.y + bs.v.z + bs.w.x + bs.w.y + bs.w.z;
+    bool bad = !(fabsf(chk) < 1e30f);
+
+    Q4 qn = qnormalize(bs.q);
+    M3<float> R = qmat(qn);
+    float* row = P.obs + (long)env * P.obs_dim;
+    const int ar = P.auto_reset;
+
+    // --- reward (PLE:350-426) ---
+    Base gb;
+    gb.p = rp.p; gb.q = rp.q; gb.v = rp.v; gb.w = rp.w;
+    Q4 gqn = qnormalize(rp.q);
+    M3<float> Rg = qmat(gqn);
+    V3l fd = foot_world(ln, P.legc, bs.p, R, q[0], q[1], q[2]);                                 // PLE:397
+    V3l fk = foot_world(ln, P.legc, gb.p, Rg, rp.jp[0], rp.jp[1], rp.jp[2]);                    // PLE:398
+    F ejp = ln.lane_f(0.0f), ejv = ln.lane_f(0.0f);
+    for (int j = 0; j < 3; j++) {
+      F d = q[j] - rp.jp[j], dv = qd[j] - rp.jv[j];
+      ejp = ejp + d * d;
+      ejv = ejv + dv * dv;
+    }
+    V3l df = fd - fk;
+    float e_jp = L::qsum(ejp), e_jv = L::qsum(ejv), e_ee = L::qsum(dot(df, df));
+    V3u dpv = bs.p - gb.p, dvv = bs.v - gb.v, dwv = bs.w - gb.w;
+    float e_p = dot(dpv, dpv), e_v = dot(dvv, dvv), e_w = dot(dwv, dwv);
+    V3u aa;
+    float angle = axis_angle_scaled(qmul(gqn, qconj(qn)), &aa);                                  // PLE:410-411
+    float reward = P.rw[0] * expf(-1.0f * e_jp) + P.rw[1] * expf(-0.1f * e_jv) + P.rw[2] * expf(-40.0f * e_ee) +
+                   P.rw[3] * expf(-20.0f * e_p - 10.0f * angle * angle) + P.rw[4] * expf(-2.0f * e_v - 0.2f * e_w);   // PLE:386-425
+    if (bad) reward = 0.0f;
+
+    // --- termination (PLE:337-348) ---
+    int reason = 0;
+    {
+      float left_z = R.m[2] * R.m[3] - R.m[5] * R.m[0];                       // up.x*fwd.y - up.y*fwd.x   LR:171-172
+      if (left_z > 0.70710678118654752f || left_z < -0.70710678118654752f) reason |= LLS_DONE_FALL;
+      if (R.m[8] < 0.5f) reason |= LLS_DONE_FALL;                             // cos(60 deg)  LR:176
+      if (fid >= P.clip_len[clip] - P.margin - 1) reason |= LLS_DONE_CLIP_END;   // ML:168-172
+      if (fabsf(angle) > 1.0f || e_p > 1.0f) reason |= LLS_DONE_DIVERGED;     // PLE:319-335
+      if (bad) reason |= LLS_DONE_NONFINITE;
+    }
+    const int steps = P.ep_steps[env] + 1;                                    // PLE:197
+    const float rsum = P.reward_sum[env] + reward;                            // PLE:231
+
+    // --- observation: into term_obs when the episode ends under auto-reset, else in place ---
+    float* out_row = (reason && ar) ? (P.term_obs + (long)env * P.obs_dim) : row;
+    write_obs(ln, P, env, out_row, row, false, bs, R, q, qd, act, rows, fid, frac);               // PLE:227
+
+    // --- stores ---
+    store_state(ln, P.state, N, env, bs, q, qd);
+    store_state(ln, P.kin, N, env, gb, rp.jp, rp.jv);
+    for (int c = 0; c < 3; c++) {
+      ln.stl(P.feet, (long)c * N + env, 3L * N, (c == 0) ? fd.x : (c == 1 ? fd.y : fd.z));
+      ln.stl(P.feet, (long)(12 + c) * N + env, 3L * N, (c == 0) ? fk.x : (c == 1 ? fk.y : fk.z));
+    }
+    P.time[env] = t;
+    P.ep_steps[env] = steps;
+    P.reward_sum[env] = rsum;
+    P.reward[env] = reward;
+    P.done[env] = reason ? 1 : 0;
+    P.done_reason[env] = (uint8_t)reason;
+
+    if (reason) {
+      // PLE:235-240: publish this episode's per-clip statistics; the pre-step kernel folds them into the table
+      // (highest env index wins when several envs finish the same clip in one step == sequential overwrite order)
+      double ms = P.max_steps[clip];
+      float avg_r = (float)((double)rsum / ms), avg_l = (float)((double)steps / (ms + 1.0));
+      if (bad) avg_r = 0.0f;
+      unsigned long long tag = ((unsigned long long)(env + 1)) << 32;
+      publish_max(ln, P.pending_reward + clip, tag | (unsigned long long)f2u(avg_r));
+      publish_max(ln, P.pending_len + clip, tag | (unsigned long long)f2u(avg_l));
+      count_add(ln, P.counters + 1);
+      if (bad) count_add(ln, P.counters + 2);
+      if (ar) {
+        int nclip;
+        double nt0;
+        uint32_t ep = P.ep_count[env] + 1;
+        sample_start(P, env, ep, &nclip, &nt0);
+        P.ep_count[env] = ep;
+        reset_env(ln, P, env, nclip, nt0);
+      }
+    }
+  }
+
+  static LL_HD uint32_t f2u(float x) {
+    union { float f; uint32_t u; } c;
+    c.f = x;
+    return c.u;
+  }
+  static LL_HD void count_add(const L& ln, unsigned long long* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ln.is_leg(0)) atomicAdd(p, 1ull);
+#else
+    *p += 1ull;
+#endif
+  }
+  static LL_HD void publish_max(const L& ln, unsigned long long* p, unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ln.is_leg(0)) atomicMax(p, v);
+#else
+    if (*p < v) *p = v;
+#endif
+  }
+};

@@ -1,0 +1,149 @@
+// pmc_tables.hpp -- host side: model blob (include/llenv_model.h) + ll_config -> kernel constant tables and scalars.
+#pragma once
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/llenv.h"
+#include "../../include/llenv_model.h"
+#include "pmc_params.hpp"
+
+struct PmcPrimView {
+  int type;
+  const double *size, *pos, *rot;
+};
+static inline PmcPrimView pmc_prim(const double* b) {
+  PmcPrimView p;
+  p.type = (int)b[0]; p.size = b + 1; p.pos = b + 4; p.rot = b + 7;
+  return p;
+}
+
+// Returns "" on success, else a message.  legc: [LC_COUNT][4], basec: [BC_COUNT]
+static inline std::string pmc_build_tables(const double* blob, int blob_len, std::vector<float>& legc, std::vector<float>& basec) {
+  if (blob_len != LLM_BLOB_LEN) return "model blob has the wrong length";
+  legc.assign(LC_COUNT * 4, 0.0f);
+  basec.assign(BC_COUNT, 0.0f);
+  auto L = [&](int field, int leg) -> float& { return legc[field * 4 + leg]; };
+  static const int links[LLM_N_LEG_PRIMS] = LLM_LEG_PRIM_LINKS;
+  (void)links;
+  for (int l = 0; l < 4; l++) {
+    for (int k = 0; k < 3; k++) {
+      int i = 3 * l + k;
+      const double* ax = blob + LLM_OFF_JOINT_AXIS + 3 * i;
+      // the kernel's closed-form leg kinematics assume hip axis +x, thigh/shank axis -y (true for max.urdf)
+      const double want[3] = {k == 0 ? 1.0 : 0.0, k == 0 ? 0.0 : -1.0, 0.0};
+      for (int c = 0; c < 3; c++)
+        if (fabs(ax[c] - want[c]) > 1e-9) return "unsupported joint axis layout (kernel expects hip +x, thigh/shank -y)";
+      for (int c = 0; c < 3; c++) {
+        L((k == 0 ? LC_R1 : (k == 1 ? LC_R2 : LC_R3)) + c, l) = (float)blob[LLM_OFF_JOINT_ORIGIN + 3 * i + c];
+        L(LC_COM + 3 * k + c, l) = (float)blob[LLM_OFF_LINK_COM + 3 * i + c];
+      }
+      L(LC_M + k, l) = (float)blob[LLM_OFF_LINK_MASS + i];
+      const double* I = blob + LLM_OFF_LINK_INERTIA + 9 * i;
+      L(LC_IC + 6 * k + 0, l) = (float)I[0]; L(LC_IC + 6 * k + 1, l) = (float)I[1]; L(LC_IC + 6 * k + 2, l) = (float)I[2];
+      L(LC_IC + 6 * k + 3, l) = (float)I[4]; L(LC_IC + 6 * k + 4, l) = (float)I[5]; L(LC_IC + 6 * k + 5, l) = (float)I[8];
+      L(LC_QLO + k, l) = (float)blob[LLM_OFF_Q_LO + i];
+      L(LC_QHI + k, l) = (float)blob[LLM_OFF_Q_HI + i];
+      L(LC_JDAMP + k, l) = (float)blob[LLM_OFF_DAMPING + i];
+    }
+    for (int c = 0; c < 3; c++) L(LC_FOOT + c, l) = (float)blob[LLM_OFF_FOOT_POS + 3 * l + c];
+    L(LC_BSX, l) = (l & 1) ? 1.0f : -1.0f;
+    L(LC_BSY, l) = (l & 2) ? 1.0f : -1.0f;
+    int handle = (l == 0) ? 1 : (l == 2 ? 2 : -1);
+    if (handle > 0) {
+      PmcPrimView h = pmc_prim(blob + LLM_OFF_BASE_PRIMS + handle * LLM_PRIM_STRIDE);
+      if (h.type != LLM_PRIM_SPHERE) return "base primitive 1/2 must be the handle spheres";
+      for (int c = 0; c < 3; c++) L(LC_HANDLE + c, l) = (float)h.pos[c];
+      L(LC_HANDLE + 3, l) = (float)h.size[0];
+      L(LC_HAS_HANDLE, l) = 1.0f;
+    }
+    // leg primitive slots: 0 hip cyl | 1 thigh box, 2 thigh cyl, 3 thigh cyl, 4 wheel cyl | 5 shank box, 6 foot sphere
+    static const int slot_field[LLM_N_LEG_PRIMS] = {LC_HIPCYL, LC_THBOX, LC_THCYL0, LC_THCYL1, LC_WHEEL, LC_SHBOX, LC_FOOTSPH};
+    static const int slot_type[LLM_N_LEG_PRIMS] = {LLM_PRIM_CYL, LLM_PRIM_BOX, LLM_PRIM_CYL, LLM_PRIM_CYL, LLM_PRIM_CYL, LLM_PRIM_BOX, LLM_PRIM_SPHERE};
+    for (int s = 0; s < LLM_N_LEG_PRIMS; s++) {
+      PmcPrimView p = pmc_prim(blob + LLM_OFF_LEG_PRIMS + (l * LLM_N_LEG_PRIMS + s) * LLM_PRIM_STRIDE);
+      if (p.type != slot_type[s]) return "leg primitive slots do not match the expected layout";
+      int f = slot_field[s];
+      for (int c = 0; c < 3; c++) L(f + c, l) = (float)p.pos[c];
+      if (p.type == LLM_PRIM_SPHERE) {
+        L(f + 3, l) = (float)p.size[0];
+      } else if (p.type == LLM_PRIM_BOX) {
+        for (int a = 0; a < 3; a++)
+          for (int c = 0; c < 3; c++) L(f + 3 + 3 * a + c, l) = (float)(p.rot[3 * c + a] * p.size[a]);   // column a of rot, scaled
+      } else {
+        for (int c = 0; c < 3; c++) { L(f + 3 + c, l) = (float)p.rot[3 * c + 2]; L(f + 6 + c, l) = (float)p.rot[3 * c + 0]; }
+        L(f + 9, l) = (float)p.size[0];
+        L(f + 10, l) = (float)p.size[1];
+      }
+    }
+  }
+  // base
+  double m = blob[LLM_OFF_BASE_MASS];
+  const double* c = blob + LLM_OFF_BASE_COM;
+  const double* I = blob + LLM_OFF_BASE_INERTIA;
+  basec[BC_MASS] = (float)m;
+  for (int k = 0; k < 3; k++) { basec[BC_H + k] = (float)(m * c[k]); basec[BC_COM + k] = (float)c[k]; }
+  double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+  basec[BC_IO + 0] = (float)(I[0] + m * (cc - c[0] * c[0])); basec[BC_IO + 1] = (float)(I[1] - m * c[0] * c[1]);
+  basec[BC_IO + 2] = (float)(I[2] - m * c[0] * c[2]); basec[BC_IO + 3] = (float)(I[4] + m * (cc - c[1] * c[1]));
+  basec[BC_IO + 4] = (float)(I[5] - m * c[1] * c[2]); basec[BC_IO + 5] = (float)(I[8] + m * (cc - c[2] * c[2]));
+  basec[BC_ICOM + 0] = (float)I[0]; basec[BC_ICOM + 1] = (float)I[1]; basec[BC_ICOM + 2] = (float)I[2];
+  basec[BC_ICOM + 3] = (float)I[4]; basec[BC_ICOM + 4] = (float)I[5]; basec[BC_ICOM + 5] = (float)I[8];
+  PmcPrimView bx = pmc_prim(blob + LLM_OFF_BASE_PRIMS);
+  if (bx.type != LLM_PRIM_BOX) return "base primitive 0 must be the body box";
+  for (int k = 0; k < 3; k++) basec[BC_BOX + k] = (float)bx.pos[k];
+  for (int a = 0; a < 3; a++)
+    for (int k = 0; k < 3; k++) basec[BC_BOX + 3 + 3 * a + k] = (float)(bx.rot[3 * k + a] * bx.size[a]);
+  return "";
+}
+
+// scalar part of StepParams from the reference-style config; returns "" or an error
+static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
+  if (cfg.abi_version != LL_ABI_VERSION) return "ll_config.abi_version mismatch";
+  if (cfg.n_envs <= 0) return "n_envs must be positive";
+  if (!(cfg.control_freq > 0) || !(cfg.sim_freq > 0)) return "control_freq and sim_freq must be positive";
+  memset(&P, 0, sizeof P);
+  P.n_envs = cfg.n_envs;
+  P.policy_step = 1.0 / cfg.control_freq;                 // PLE:47
+  P.dt_d = 1.0 / cfg.sim_freq;                            // PLE:49
+  P.n_sub = (int)(P.policy_step / P.dt_d);                // PLE:52
+  if (P.n_sub < 1) return "sim_freq must be >= control_freq";
+  P.dt = (float)P.dt_d;
+  P.n_iter = cfg.solver_iterations > 0 ? cfg.solver_iterations : 10;   // LR:261
+  P.auto_reset = cfg.auto_reset;
+  P.kp = (float)cfg.kp; P.kd = (float)cfg.kd; P.max_tau = (float)cfg.max_tau;
+  P.mu_foot = (float)(cfg.foot_lateral_friction * LLM_PLANE_FRICTION);   // LR:304-308 x plane.urdf:5
+  P.mu_link = (float)(LLM_LINK_FRICTION * LLM_PLANE_FRICTION);
+  P.gravity = (float)LLM_GRAVITY;
+  P.link_damping = (float)LLM_LINK_DAMPING;
+  P.erp = (float)LLM_ERP;
+  P.margin_dist = (float)LLM_CONTACT_MARGIN;
+  double sw = 0;
+  for (int i = 0; i < 5; i++) sw += cfg.reward_weights[i];               // PLE:365
+  if (!(sw > 0)) return "reward_weights must sum to a positive number";
+  for (int i = 0; i < 5; i++) P.rw[i] = (float)(cfg.reward_weights[i] / sw);
+  int off = 0;
+  for (int k = 0; k < 5; k++) P.prop_off[k] = -1;
+  for (int k = 0; k < 5 && cfg.prop_order[k] >= 0; k++) {               // PLE:101-113
+    int id = cfg.prop_order[k];
+    if (id > 4 || P.prop_off[id] >= 0) return "bad prop_order";
+    P.prop_off[id] = off;
+    off += (id <= LL_PROP_JOINT_VEL) ? 12 : 3;
+  }
+  if (off == 0) return "prop_type must not be empty";
+  P.prop_dim = off;
+  P.obs_dim = LL_STACK * off + LL_STACK * 12 + LL_FUTURE_DIM;           // PLE:114-121
+  P.sample_factor = cfg.prioritized_sample_factor;
+  P.seed = cfg.seed;
+  return "";
+}
+
+// mocap-derived scalars (ML:33-35)
+static inline void pmc_fill_mocap(StepParams& P, int n_clips, double frame_step) {
+  P.n_clips = n_clips;
+  P.frame_step = frame_step;
+  P.frame_rate = (int)(1.0 / frame_step);
+  P.margin = (int)ceil(P.policy_step / frame_step) + P.frame_rate + 2;
+}

@@ -1,0 +1,73 @@
+"""Trajectory hand-off to the learner rank over RCCL/xGMI.
+
+The reference's actor pushes one unroll (unroll_length = 128 steps of the flattened PGData row) to the learner over
+ZeroMQ (learning/actors/distill_actor.py:84-176, push at :167).  Here each GPU rank keeps an [unroll][n_envs][row]
+ring in HBM and, once per unroll, the rows are gathered to the learner rank with one RCCL collective
+(torch.distributed backend "nccl" IS RCCL on ROCm).  Envs never communicate per step.
+
+Row layout (float32): obs[obs_dim] | action[12] | reward | done   (222 floats for the PMC obs of 207).
+xGMI is point-to-point: a gather into rank 0 arrives over 7 different links, so it is per-link bound
+(~153 GB/s per peer): 4096 envs x 128 steps x 888 B = 466 MB per rank per unroll ~ 3 ms, once per 128 steps.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class _DevArray(object):
+    """Zero-copy view of an engine-owned device buffer for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (int(ptr), False), 'version': 2}
+
+
+def device_tensor(ptr, shape, dtype=torch.float32, device=None):
+    typestr = {torch.float32: '<f4', torch.uint8: '|u1', torch.int32: '<i4', torch.float64: '<f8'}[dtype]
+    return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device if device is not None else torch.device('cuda', torch.cuda.current_device()))
+
+
+def engine_tensors(engine):
+    """torch views of the engine's output/action buffers (no copies)."""
+    p = engine.device_ptrs()
+    n, od = p.n_envs, p.obs_dim
+    return dict(obs=device_tensor(p.obs, (n, od)), reward=device_tensor(p.reward, (n,)),
+                done=device_tensor(p.done, (n,), torch.uint8), actions=device_tensor(p.actions, (n, 12)),
+                terminal_obs=device_tensor(p.terminal_obs, (n, od)))
+
+
+def pack_rows(obs, actions, reward, done, out):
+    """out[n_envs][obs_dim+14] <- obs | action | reward | done   (works for CPU tensors too: used by the gloo test)."""
+    od = obs.shape[1]
+    out[:, :od].copy_(obs)
+    out[:, od:od + 12].copy_(actions)
+    out[:, od + 12].copy_(reward)
+    out[:, od + 13].copy_(done.to(out.dtype))
+    return out
+
+
+def gather_unroll(local, dst=0, group=None):
+    """Gather every rank's [unroll][n_envs][row] block to rank `dst`; returns [world][unroll][n_envs][row] there, else None."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if rank == dst:
+        outs = [torch.empty_like(local) for _ in range(world)]
+        dist.gather(local, gather_list=outs, dst=dst, group=group)
+        return torch.stack(outs, 0)
+    dist.gather(local, gather_list=None, dst=dst, group=group)
+    return None
+
+
+class TrajectoryBuffer(object):
+    def __init__(self, engine, unroll):
+        self.t = engine_tensors(engine)
+        n, od = self.t['obs'].shape
+        self.unroll = unroll
+        self.buf = torch.empty((unroll, n, od + 14), dtype=torch.float32, device=self.t['obs'].device)
+        self.last = None
+
+    def record(self, t):
+        pack_rows(self.t['obs'], self.t['actions'], self.t['reward'], self.t['done'], self.buf[t])
+
+    def gather_to(self, dst=0):
+        self.last = gather_unroll(self.buf, dst)
+        return self.last

@@ -1,0 +1,93 @@
+// emul.cpp -- TEST INFRASTRUCTURE.  Runs the kernel body (csrc/pmc_step.hpp) and the engine host logic
+// (csrc/pmc_engine.hpp) on the host through lanes_host.hpp, exporting the same ll_* entry points as the product
+// library so one Python harness drives both.  Purpose: debug the kernel's logic against the oracle on a machine
+// without a GPU.  Built only by the tests into tests/emul/_build/; the product never loads it.
+#include "lanes_host.hpp"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../lifelike_agility_and_play_amd/csrc/pmc_engine.hpp"
+#include "../../lifelike_agility_and_play_amd/csrc/pmc_step.hpp"
+
+typedef Pmc<HostLanes> K;
+
+struct HostBackend {
+  explicit HostBackend(int) {}
+  void set_stream(void*) {}
+  void* stream_handle() { return nullptr; }
+  void* alloc(size_t bytes) { return malloc(bytes ? bytes : 4); }
+  void release(void* p) { free(p); }
+  void zero(void* p, size_t bytes) { memset(p, 0, bytes); }
+  void h2d(void* d, const void* h, size_t bytes) { memcpy(d, h, bytes); }
+  void d2h(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); }
+  void sync() {}
+  void launch_step(const StepParams& P) {
+    std::vector<float> lds(LW_COUNT * 4, 0.0f);
+    HostLanes ln(&lds);
+    for (int env = 0; env < P.n_envs; env++) {
+      K::clear_scratch(ln);
+      K::step_env(ln, P, env);
+    }
+  }
+  void launch_reset(const StepParams& P, const int32_t* ids, int n, const int32_t* clip, const double* t0) {
+    std::vector<float> lds(LW_COUNT * 4, 0.0f);
+    HostLanes ln(&lds);
+    for (int i = 0; i < n; i++) {
+      int env = ids ? ids[i] : i, c;
+      double t;
+      uint32_t ep = P.ep_count[env] + 1;
+      K::sample_start(P, env, ep, &c, &t);
+      P.ep_count[env] = ep;
+      if (clip) c = clip[i];
+      if (t0) t = t0[i];
+      K::reset_env(ln, P, env, c, t);
+      P.done[env] = 0;
+      P.done_reason[env] = 0;
+    }
+  }
+  void launch_prestep(const StepParams& P, double* avg_r, double* avg_l, double* prob, double* cdf, float* actions, float sigma) {
+    pmc_finalize_table(P, avg_r, avg_l, prob, cdf);
+    if (actions) {
+      for (int gid = 0; gid < P.n_envs * 3; gid++) {
+        uint32_t r[4];
+        philox4x32((uint32_t)gid, (uint32_t)P.step_count, (uint32_t)(P.step_count >> 32), 0xAC710u, (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r);
+        const float k = 2.3283064365386963e-10f;
+        float u1 = fminf(((float)r[0] + 1.0f) * k, 1.0f), u2 = (float)r[1] * k, u3 = fminf(((float)r[2] + 1.0f) * k, 1.0f), u4 = (float)r[3] * k;
+        float m1 = sqrtf(-2.0f * logf(u1)), m2 = sqrtf(-2.0f * logf(u3));
+        actions[4 * gid + 0] = sigma * m1 * cosf(6.283185307179586f * u2); actions[4 * gid + 1] = sigma * m1 * sinf(6.283185307179586f * u2);
+        actions[4 * gid + 2] = sigma * m2 * cosf(6.283185307179586f * u4); actions[4 * gid + 3] = sigma * m2 * sinf(6.283185307179586f * u4);
+      }
+    }
+  }
+  void enable_timing(bool) {}
+  void collect_timing(double* avg_ms, int* n) { *avg_ms = 0; *n = 0; }
+};
+
+typedef PmcEngine<HostBackend> ENGINE;
+#include "../../lifelike_agility_and_play_amd/csrc/pmc_capi.inc"
+
+extern "C" {
+// single physics substep on explicit state (staged comparison with the oracle); tgt = PD target joint angles
+int emu_substep(ll_engine* h, float* state37, const float* tgt12) {
+  const StepParams& P = h->e->P;
+  std::vector<float> lds(LW_COUNT * 4, 0.0f);
+  HostLanes ln(&lds);
+  K::Base bs;
+  bs.p = mk3<float>(state37[0], state37[1], state37[2]);
+  bs.q.x = state37[3]; bs.q.y = state37[4]; bs.q.z = state37[5]; bs.q.w = state37[6];
+  bs.v = mk3<float>(state37[7], state37[8], state37[9]);
+  bs.w = mk3<float>(state37[10], state37[11], state37[12]);
+  f4 q[3], qd[3], tgt[3];
+  for (int j = 0; j < 3; j++)
+    for (int l = 0; l < 4; l++) { q[j].v[l] = state37[13 + 3 * l + j]; qd[j].v[l] = state37[25 + 3 * l + j]; tgt[j].v[l] = tgt12[3 * l + j]; }
+  K::substep(ln, P, bs, q, qd, tgt);
+  state37[0] = bs.p.x; state37[1] = bs.p.y; state37[2] = bs.p.z;
+  state37[3] = bs.q.x; state37[4] = bs.q.y; state37[5] = bs.q.z; state37[6] = bs.q.w;
+  state37[7] = bs.v.x; state37[8] = bs.v.y; state37[9] = bs.v.z;
+  state37[10] = bs.w.x; state37[11] = bs.w.y; state37[12] = bs.w.z;
+  for (int j = 0; j < 3; j++)
+    for (int l = 0; l < 4; l++) { state37[13 + 3 * l + j] = q[j].v[l]; state37[25 + 3 * l + j] = qd[j].v[l]; }
+  return 0;
+}
+}

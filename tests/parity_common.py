@@ -1,0 +1,135 @@
+"""Parity checks shared by the CPU kernel-logic tests (host emulation of the kernel body) and the GPU tests
+(the real HIP library through the C ABI).  Every check compares an Engine (float32) with the float64 oracle or
+with reference-generated goldens on identical inputs.
+
+Tolerances (float32 engine vs float64 reference/oracle), as stated in BASELINE.md §5:
+  * non-physics math (mocap, obs, reward, flags): 1e-5
+  * physics: one control step (10 substeps, contacts included): state error <= 1e-4 for the configuration
+    (base position, quaternion, joint angles) and, for velocities -- joint rates reach 35 rad/s on links that weigh
+    170 g, so an absolute 1e-4 is below float32 resolution of the accelerations involved -- 1e-4 RELATIVE to
+    (1 + largest joint rate of that env) at the 99th percentile, with a hard cap of 20x on the worst sample
+    (a contact that switches on in one arithmetic and not in the other).
+"""
+import numpy as np
+
+from conftest import PMC_PROP_TYPE, PMC_REWARD_WEIGHTS, make_oracle_batch
+from lifelike_agility_and_play_amd import capi
+
+NONPHYS_TOL = 1e-5
+PHYS_STEP_TOL = 1e-4
+SIGMA = float(np.exp(-2.0))          # SURVEY 8d synthetic action scale
+
+
+def make_engine(model_blob, table, n_envs, lib_path=None, **kw):
+    kw.setdefault('control_freq', 50.0)
+    kw.setdefault('kd', 0.5)
+    kw.setdefault('reward_weights', PMC_REWARD_WEIGHTS)
+    kw.setdefault('prop_type', PMC_PROP_TYPE)
+    kw.setdefault('prioritized_sample_factor', 3.0)
+    cfg = capi.make_config(n_envs, **kw)
+    return capi.Engine(cfg, model_blob, table, lib_path=lib_path)
+
+
+def quat_align(a, ref):
+    """flip the sign of quaternion rows of `a` to match `ref` (q and -q are the same rotation)."""
+    a = a.copy()
+    s = np.sign(np.sum(a[..., 3:7] * ref[..., 3:7], axis=-1, keepdims=True))
+    s[s == 0] = 1
+    a[..., 3:7] *= s
+    return a
+
+
+def check_reset_against_goldens(golden, model_blob, table, lib_path):
+    """PLE:150-171 / ML:48-57 at explicit (clip, t0): first obs + ghost state vs the imported reference."""
+    n = len(golden['g2_seed'])
+    E = make_engine(model_blob, table, n, lib_path)
+    E.reset(clip=golden['g2_clip'], t0=golden['g2_t0'])
+    np.testing.assert_allclose(E.obs(), golden['g2_obs'], rtol=NONPHYS_TOL, atol=NONPHYS_TOL)
+    kin = quat_align(E.ref_state().astype(np.float64), golden['g2_kin'])
+    np.testing.assert_allclose(kin, golden['g2_kin'], rtol=NONPHYS_TOL, atol=2e-5)
+    np.testing.assert_array_equal(E.state(), E.ref_state())
+    info = E.episode_info()
+    np.testing.assert_array_equal(info['clip'], golden['g2_clip'])
+    np.testing.assert_array_equal(info['time'], golden['g2_t0'])          # float64, bit exact
+    assert (info['steps'] == 0).all()
+    # partial reset leaves the other envs untouched
+    before = E.obs()
+    E.reset(env_ids=[3, 5], clip=[golden['g2_clip'][0]] * 2, t0=[golden['g2_t0'][0]] * 2)
+    after = E.obs()
+    np.testing.assert_allclose(after[3], golden['g2_obs'][0], rtol=NONPHYS_TOL, atol=NONPHYS_TOL)
+    np.testing.assert_array_equal(after[5], after[3])
+    mask = np.ones(n, bool); mask[[3, 5]] = False
+    np.testing.assert_array_equal(after[mask], before[mask])
+    E.close()
+
+
+def run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True, sigma=SIGMA):
+    """Step engine and oracle side by side from golden (clip, t0) starts with the same random actions.
+    With resync the oracle is re-seeded with the engine's float32 state after every control step, so every step
+    is an independent single-control-step comparison."""
+    rng = np.random.default_rng(seed)
+    pick = rng.integers(0, len(golden['g2_clip']), n_envs)
+    clip, t0 = golden['g2_clip'][pick], golden['g2_t0'][pick]
+    E = make_engine(model_blob, table, n_envs, lib_path)
+    B = make_oracle_batch(orc, model_blob, table, n_envs=n_envs)
+    E.reset(clip=clip, t0=t0)
+    for i in range(n_envs):
+        B.reset_env(i, int(clip[i]), float(t0[i]))
+        B.set_state(i, E.state()[i].astype(np.float64))
+    stats = dict(config=[], vel=[], obs=[], obs_vel=[], reward=[], feet=[], done_mismatch=0, done=0)
+    prev_obs = None
+    alive = np.ones(n_envs, bool)
+    for t in range(n_steps):
+        act = (rng.normal(size=(n_envs, 12)) * sigma).astype(np.float32)
+        E.step_host(act)
+        eo, (er, ed, ew), es, ek = E.obs(), E.reward_done(), E.state(), E.ref_state()
+        efd, efk = E.feet()
+        for i in range(n_envs):
+            if not alive[i]:
+                continue
+            oo, orr, od = B.step_env(i, act[i].astype(np.float64))
+            os_ = B.get_state(i)
+            err = np.abs(quat_align(es[i].astype(np.float64), os_) - os_)
+            vscale = 1.0 + np.abs(os_[25:37]).max()
+            stats['config'].append(max(err[0:7].max(), err[13:25].max()))
+            stats['vel'].append(max(err[7:13].max(), err[25:37].max()) / vscale)
+            oe = np.abs(eo[i] - oo)
+            # newest prop frame: joint_pos | joint_vel | ang_vel_loc | lin_vel_loc | e_g  (PMC_PROP_TYPE order)
+            stats['obs'].append(max(oe[66:78].max(), oe[96:99].max(), oe[99:].max()))            # configuration-like entries
+            stats['obs_vel'].append(oe[78:96].max() / vscale)                                      # velocity entries
+            if prev_obs is not None:                                                               # deque shift, bit exact
+                assert np.array_equal(eo[i][0:66], prev_obs[i][33:99]) and np.array_equal(eo[i][99:123], prev_obs[i][111:135])
+            stats['reward'].append(abs(er[i] - orr))
+            ofd, ofk = B.get_feet(i)
+            stats['feet'].append(max(np.abs(efd[i] - ofd).max(), np.abs(efk[i] - ofk).max()))
+            if bool(ed[i]) != od:
+                stats['done_mismatch'] += 1
+            if od or ed[i]:
+                stats['done'] += 1
+                alive[i] = False             # reference semantics: a finished env waits for reset()
+            elif resync:
+                B.set_state(i, es[i].astype(np.float64))
+        prev_obs = eo
+    E.close()
+    return {k: (np.array(v) if isinstance(v, list) else v) for k, v in stats.items()}
+
+
+def check_single_step_parity(golden, orc, model_blob, table, lib_path, n_envs=32, n_steps=12, seed=7):
+    st = run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True)
+    assert len(st['config']) > n_envs * n_steps * 0.5
+    assert st['config'].max() < PHYS_STEP_TOL, np.percentile(st['config'], [50, 90, 99, 100])
+    assert np.percentile(st['vel'], 99) < PHYS_STEP_TOL, np.percentile(st['vel'], [50, 90, 99, 100])
+    assert st['vel'].max() < 20 * PHYS_STEP_TOL, st['vel'].max()
+    assert st['obs'].max() < PHYS_STEP_TOL, np.percentile(st['obs'], [50, 90, 99, 100])
+    assert np.percentile(st['obs_vel'], 99) < PHYS_STEP_TOL, np.percentile(st['obs_vel'], [50, 90, 99, 100])
+    assert st['obs_vel'].max() < 20 * PHYS_STEP_TOL
+    assert st['reward'].max() < PHYS_STEP_TOL
+    assert st['feet'].max() < PHYS_STEP_TOL
+    assert st['done_mismatch'] <= max(1, st['done'] // 10)
+    return st
+
+
+def check_rollout_statistics(golden, orc, model_blob, table, lib_path, n_envs=24, n_steps=60, seed=11):
+    """Free-running (no resync) rollouts: chaotic contact dynamics diverge sample-wise, so compare distributions."""
+    st = run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=False)
+    return st

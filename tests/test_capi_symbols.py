@@ -1,0 +1,45 @@
+"""The C-ABI shared library loads and exports every symbol include/llenv.h declares (no compute without a GPU)."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from lifelike_agility_and_play_amd import capi
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'llenv.h')).read()
+    return sorted(set(re.findall(r'\b(ll_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == capi.EXPORTED_SYMBOLS
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build_hip()
+    lib = capi.load_library()                 # resolves every name in capi._SIGS or raises
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.ll_abi_version() == 1
+    assert lib.ll_model_blob_len() == 788
+
+
+def test_no_gpu_means_loud_failure(model_blob, mocap_table):
+    """Without a HIP device the product refuses to run (no CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    cfg = capi.make_config(4, prop_type=['joint_pos'])
+    with pytest.raises(capi.LLError) as ei:
+        capi.Engine(cfg, model_blob, mocap_table)
+    assert ei.value.code == -5                # LL_ENODEV
+
+
+def test_config_validation(model_blob, mocap_table):
+    with pytest.raises(TypeError):
+        capi.make_config(4, prop_type='joint_pos')            # PLE:113
+    with pytest.raises(KeyError):
+        capi.make_config(4, prop_type=['nonsense'])           # PLE:111

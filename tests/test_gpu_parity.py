@@ -1,0 +1,59 @@
+"""GPU parity tests: the real HIP library (lifelike_agility_and_play_amd/csrc/libllenv.so) through the C ABI,
+against the reference goldens and the float64 oracle.  Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+import parity_common as pc
+from lifelike_agility_and_play_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def test_library_is_the_hip_build():
+    lib = capi.load_library()
+    assert lib.ll_abi_version() == 1
+
+
+def test_reset_against_reference_goldens(golden, model_blob, mocap_table):
+    pc.check_reset_against_goldens(golden, model_blob, mocap_table, None)
+
+
+def test_single_control_step_parity(golden, orc, model_blob, mocap_table):
+    st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, None, n_envs=48, n_steps=12)
+    print('config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
+
+
+def test_partial_wave_and_odd_batch_sizes(golden, orc, model_blob, mocap_table):
+    for n in (1, 5, 17):
+        st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, None, n_envs=n, n_steps=3, seed=n)
+        assert len(st['config']) > 0
+
+
+def test_full_size_invariants(golden, model_blob, mocap_table):
+    """BASELINE config 2 size (4096 envs, all clips, random policy, auto-reset): size-independent properties."""
+    n = 4096
+    E = pc.make_engine(model_blob, mocap_table, n, None, auto_reset=1, seed=3)
+    E.reset()
+    info0 = E.episode_info()
+    assert info0['clip'].min() >= 0 and info0['clip'].max() < E.n_clips and len(np.unique(info0['clip'])) > 40
+    done_total, rew = 0, []
+    for t in range(60):
+        E.fill_random_actions(pc.SIGMA)
+        E.step()
+        r, d, why = E.reward_done()
+        s, o = E.state(), E.obs()
+        assert np.isfinite(s).all() and np.isfinite(o).all()
+        np.testing.assert_allclose(np.linalg.norm(s[:, 3:7], axis=1), 1.0, atol=1e-5)     # unit quaternions
+        assert (r >= 0).all() and (r <= 1.0 + 1e-6).all()                                   # convex combination of exp(-x)
+        assert ((why != 0) == d).all()
+        done_total += int(d.sum())
+        rew.append(r.mean())
+        info = E.episode_info()
+        assert (info['steps'][d] == 0).all()                                               # re-seeded inside the kernel
+        assert (info['steps'][~d] >= 1).all()
+    c = E.counters()
+    assert c['env_steps'] == 60 * n and c['episodes'] == done_total and c['nonfinite'] == 0
+    assert done_total > 0
+    p, avg_r, avg_l = E.sampling_table()
+    assert abs(p.sum() - 1.0) < 1e-9 and (p > 0).all()
+    E.close()
