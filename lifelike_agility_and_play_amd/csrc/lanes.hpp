@@ -42,6 +42,9 @@ LL_HD float max_(float a, float b) { return fmaxf(a, b); }
 LL_HD bool and_(bool a, bool b) { return a && b; }
 LL_HD bool or_(bool a, bool b) { return a || b; }
 LL_HD bool not_(bool a) { return !a; }
+LL_HD float rint_(float x) { return rintf(x); }
+LL_HD bool odd_(int k) { return (k & 1) != 0; }
+LL_HD bool bit1_(int k) { return (k & 2) != 0; }
 }  // namespace lm
 
 #if defined(__HIPCC__)

@@ -9,6 +9,8 @@
 // There is no CPU path: without a HIP device ll_create fails with LL_ENODEV.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <new>
 
 #include "lanes.hpp"
@@ -25,8 +27,11 @@ typedef Pmc<GpuLanes> K;
 
 __global__ __launch_bounds__(PMC_WAVE) void pmc_step_kernel(StepParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int env = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 2);
-  if (env >= P.n_envs) return;
+  // envs_per_wave < 16 leaves lanes idle on purpose: at 4096 envs there are more SIMDs (1024) than 16-env waves (256),
+  // and the solver's wave-uniform work is the union over the envs of a wave, so fewer envs per wave = shorter kernel.
+  const int quad = threadIdx.x >> 2;
+  const int env = blockIdx.x * P.envs_per_wave + quad;
+  if (quad >= P.envs_per_wave || env >= P.n_envs) return;
   GpuLanes ln(lds);
   K::clear_scratch(ln);
   K::step_env(ln, P, env);
@@ -85,6 +90,10 @@ struct HipBackend {
     HIPCHK(hipSetDevice(dev));
     HIPCHK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
     stream = own;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    n_simd = prop.multiProcessorCount * 4;
+    if (const char* e = getenv("LL_ENVS_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= PMC_ENVS_PER_WAVE) epw_override = v; }
   }
   ~HipBackend() {
     (void)hipSetDevice(device);
@@ -115,9 +124,17 @@ struct HipBackend {
   void sync() { use(); HIPCHK(hipStreamSynchronize(stream)); }
 
   static size_t lds_bytes() { return (size_t)LW_COUNT * PMC_WAVE * sizeof(float); }
-  void launch_step(const StepParams& P) {
+  int epw_override = 0, n_simd = 1024;
+  int envs_per_wave(int n_envs) const {
+    if (epw_override > 0) return epw_override;
+    int e = (n_envs + n_simd - 1) / n_simd;       // aim for at least one wave per SIMD
+    return e < 1 ? 1 : (e > PMC_ENVS_PER_WAVE ? PMC_ENVS_PER_WAVE : e);
+  }
+  void launch_step(const StepParams& Pin) {
     use();
-    const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
+    StepParams P = Pin;
+    P.envs_per_wave = envs_per_wave(P.n_envs);
+    const int blocks = (P.n_envs + P.envs_per_wave - 1) / P.envs_per_wave;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (timing) {
       if (ev_used == evs.size()) {

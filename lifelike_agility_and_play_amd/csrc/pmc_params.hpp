@@ -46,12 +46,12 @@ enum BaseConst {
 struct StepParams {
   int32_t n_envs, n_sub, n_iter, auto_reset;
   int32_t n_clips, prop_dim, obs_dim, frame_rate;
-  int32_t margin, pad0;
+  int32_t margin, envs_per_wave;
   int32_t prop_off[5];      // offset of each LL_PROP_* key inside one prop frame, or -1
   int32_t pad1;
   float dt, kp, kd, max_tau;
   float mu_foot, mu_link, gravity, link_damping;
-  float erp, margin_dist, pad2, pad3;
+  float erp, margin_dist, limit_gate, pad3;
   float rw[5];              // normalised reward weights (PLE:365-370)
   float pad4;
   double dt_d, frame_step, policy_step, sample_factor;

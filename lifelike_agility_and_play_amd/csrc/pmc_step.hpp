@@ -91,11 +91,30 @@ struct Pmc {
     return mk3<F>(ln.legc(legc, f), ln.legc(legc, f + 1), ln.legc(legc, f + 2));
   }
 
+  // sin/cos for joint angles (|x| < ~1e3): two-constant Cody-Waite reduction to [-pi/4, pi/4] + minimax polynomials,
+  // ~1 ulp, branch-free -- no large-argument path, which the library sincosf would inline six times per substep
+  static LL_HD void sincos_joint(const L& ln, const F& x, F* s, F* c) {
+    F kf = lm::rint_(x * 0.63661977236758134f);
+    F r = x - kf * 1.5707962512969971f;            // pi/2 high part (float)
+    r = r - kf * 7.5497894158615964e-08f;          // pi/2 low part
+    F r2 = r * r;
+    F sp = r + r * r2 * (-0.16666654611f + r2 * (0.0083321608736f + r2 * (-0.00019515295891f)));
+    F cp = ln.lane_f(1.0f) + r2 * (-0.5f + r2 * (0.041666645683f + r2 * (-0.0013887316255f + r2 * 0.000024433157117f)));
+    I k = L::f2i(kf);
+    B swap = lm::odd_(k);
+    B neg_s = lm::bit1_(k);                         // k mod 4 in {2,3}
+    B neg_c = lm::bit1_(k + 1);                     // k mod 4 in {1,2}
+    F ss = lm::sel(swap, cp, sp), cs = lm::sel(swap, sp, cp);
+    *s = lm::sel(neg_s, ln.lane_f(0.0f) - ss, ss);
+    *c = lm::sel(neg_c, ln.lane_f(0.0f) - cs, cs);
+  }
+
   static LL_HD LegKin leg_fk(const L& ln, const float* legc, F q1, F q2, F q3) {
     LegKin k;
-    F c1 = lm::cos_(q1), s1 = lm::sin_(q1), c2 = lm::cos_(q2), s2 = lm::sin_(q2);
-    F q23 = q2 + q3;
-    F c3 = lm::cos_(q23), s3 = lm::sin_(q23);
+    F c1, s1, c2, s2, c3, s3;
+    sincos_joint(ln, q1, &s1, &c1);
+    sincos_joint(ln, q2, &s2, &c2);
+    sincos_joint(ln, q2 + q3, &s3, &c3);
     F zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f);
     // R1 = Rx(q1);  R2 = R1 * R(-y, q2);  R3 = R1 * R(-y, q2+q3)   (hip axis +x, thigh/shank axis -y)
     k.R1.m[0] = one; k.R1.m[1] = zero; k.R1.m[2] = zero;
@@ -415,7 +434,6 @@ struct Pmc {
       F dl = q[j] - ln.legc(legc, LC_QLO + j), dh = ln.legc(legc, LC_QHI + j) - q[j];
       B lower = dl <= dh;
       F d = lm::sel(lower, dl, dh), sg = lm::sel(lower, one, zero - one);
-      lvalid[j] = d < 0.25f;
       F jt[3] = {zero, zero, zero};
       jt[j] = sg;
       lm_fwd(lf, jt);
@@ -428,6 +446,7 @@ struct Pmc {
       for (int i = 0; i < 3; i++) ljt[j][i] = jt[i];
       linv[j] = one / nn;
       lc_[j] = sg * qs[j] + lm::sel(d > 0.0f, d * inv_dt, d * (P.erp * inv_dt));
+      lvalid[j] = lc_[j] < P.limit_gate;        // rows that cannot act this substep stay out of the solve
       llam[j] = zero;
     }
 
@@ -519,16 +538,49 @@ struct Pmc {
     // --- projected Gauss-Seidel in whitened coordinates -------------------------------------------------------------------------
     float dx[6] = {0, 0, 0, 0, 0, 0};      // shared:  sum gt * lambda
     F dq[3] = {zero, zero, zero};          // private: sum jt * lambda
+    // row order of the spec: limit rows joint-major (legs 0..3 per joint), then per slot the normal rows of legs 0..3,
+    // their t1 rows, their t2 rows.  A row is loaded once; the four lanes of the quad then take their Gauss-Seidel turn
+    // on the shared 6-vector dx (only the lane whose turn it is commits), and the lane-private dq is updated afterwards.
+    bool lim_any[3];
+    for (int j = 0; j < 3; j++) lim_any[j] = L::any(lvalid[j]);
     for (int it = 0; it < P.n_iter; it++) {
-      // row order of the spec: the 12 joint-limit rows (leg, joint), then the contacts (leg, slot; n, t1, t2)
-      pgs_limits<0>(ln, lgt, ljt, lc_, linv, llam, lvalid, dx, dq);
-      pgs_limits<1>(ln, lgt, ljt, lc_, linv, llam, lvalid, dx, dq);
-      pgs_limits<2>(ln, lgt, ljt, lc_, linv, llam, lvalid, dx, dq);
-      pgs_limits<3>(ln, lgt, ljt, lc_, linv, llam, lvalid, dx, dq);
-      pgs_contacts<0>(ln, cc.n, max_n, dx, dq);
-      pgs_contacts<1>(ln, cc.n, max_n, dx, dq);
-      pgs_contacts<2>(ln, cc.n, max_n, dx, dq);
-      pgs_contacts<3>(ln, cc.n, max_n, dx, dq);
+      for (int j = 0; j < 3; j++) {
+        if (!lim_any[j]) continue;
+        F base = lc_[j] + ljt[j][0] * dq[0] + ljt[j][1] * dq[1] + ljt[j][2] * dq[2];
+        F lam0 = llam[j];
+        F lam = lam0;
+        gs_turn<0>(ln, lvalid[j], base, lgt[j], linv[j], zero, ln.lane_f(3.0e38f), lam, dx);
+        gs_turn<1>(ln, lvalid[j], base, lgt[j], linv[j], zero, ln.lane_f(3.0e38f), lam, dx);
+        gs_turn<2>(ln, lvalid[j], base, lgt[j], linv[j], zero, ln.lane_f(3.0e38f), lam, dx);
+        gs_turn<3>(ln, lvalid[j], base, lgt[j], linv[j], zero, ln.lane_f(3.0e38f), lam, dx);
+        F dl = lam - lam0;
+        llam[j] = lam;
+        for (int i = 0; i < 3; i++) dq[i] = dq[i] + ljt[j][i] * dl;
+      }
+      for (int s = 0; s < max_n; s++) {
+        B valid = cc.n > s;
+        F mu = ln.lds_ld(LW_CAND(s, 5));
+        F lam_n = zero;
+        for (int r = 0; r < 3; r++) {
+          F gt[6], jt[3];
+          for (int i = 0; i < 6; i++) gt[i] = ln.lds_ld(LW_ROW(s, r, i));
+          for (int i = 0; i < 3; i++) jt[i] = ln.lds_ld(LW_ROW(s, r, 6 + i));
+          F base = ln.lds_ld(LW_ROW(s, r, 9)) + jt[0] * dq[0] + jt[1] * dq[1] + jt[2] * dq[2];
+          F inv = ln.lds_ld(LW_ROW(s, r, 10));
+          F lam0 = ln.lds_ld(LW_LAM(s, r));
+          F lam = lam0;
+          F hi = (r == 0) ? ln.lane_f(3.0e38f) : mu * lam_n;
+          F lo = (r == 0) ? zero : zero - hi;
+          gs_turn<0>(ln, valid, base, gt, inv, lo, hi, lam, dx);
+          gs_turn<1>(ln, valid, base, gt, inv, lo, hi, lam, dx);
+          gs_turn<2>(ln, valid, base, gt, inv, lo, hi, lam, dx);
+          gs_turn<3>(ln, valid, base, gt, inv, lo, hi, lam, dx);
+          if (r == 0) lam_n = lam;
+          ln.lds_st(LW_LAM(s, r), lam);
+          F dl = lam - lam0;
+          for (int i = 0; i < 3; i++) dq[i] = dq[i] + jt[i] * dl;
+        }
+      }
     }
     // back to velocities: d(xi) = Lb^-T dx ; d(qd) = Lm^-T (dq - Y^T d(xi))
     bwd6(Sb, Sd, dx);
@@ -552,50 +604,15 @@ struct Pmc {
     }
   }
 
-  // rows owned by leg LEG take their Gauss-Seidel turn; only that lane commits, the shared update is quad-broadcast
+  // Gauss-Seidel turn of leg LEG on one row per lane: w = base + gt.dx ; lam <- clamp(lam - w/A) ; dx += gt * dlam (quad broadcast)
   template <int LEG>
-  static LL_HD void pgs_limits(const L& ln, F (*lgt)[6], F (*ljt)[3], F* lc_, F* linv, F* llam, B* lvalid, float* dx, F* dq) {
-    B mine = ln.is_leg(LEG);
-    F zero = ln.lane_f(0.0f);
-    for (int j = 0; j < 3; j++) {
-      B act = lm::and_(mine, lvalid[j]);
-      if (!L::any(act)) continue;
-      F w = lc_[j] + ljt[j][0] * dq[0] + ljt[j][1] * dq[1] + ljt[j][2] * dq[2];
-      for (int i = 0; i < 6; i++) w = w + lgt[j][i] * dx[i];
-      F ln_new = lm::max_(llam[j] - w * linv[j], zero);
-      F dl = lm::sel(act, ln_new - llam[j], zero);
-      llam[j] = llam[j] + dl;
-      for (int i = 0; i < 3; i++) dq[i] = dq[i] + ljt[j][i] * dl;
-      for (int i = 0; i < 6; i++) dx[i] += L::template bcast<LEG>(lgt[j][i] * dl);
-    }
-  }
-  template <int LEG>
-  static LL_HD void pgs_contacts(const L& ln, I n, int max_n, float* dx, F* dq) {
-    B mine = ln.is_leg(LEG);
-    F zero = ln.lane_f(0.0f);
-    for (int s = 0; s < max_n; s++) {
-      B act = lm::and_(mine, n > s);
-      if (!L::any(act)) continue;
-      F mu = ln.lds_ld(LW_CAND(s, 5));
-      F lam_n = zero;
-      for (int r = 0; r < 3; r++) {
-        F gt[6], jt[3];
-        for (int i = 0; i < 6; i++) gt[i] = ln.lds_ld(LW_ROW(s, r, i));
-        for (int i = 0; i < 3; i++) jt[i] = ln.lds_ld(LW_ROW(s, r, 6 + i));
-        F w = ln.lds_ld(LW_ROW(s, r, 9)) + jt[0] * dq[0] + jt[1] * dq[1] + jt[2] * dq[2];
-        for (int i = 0; i < 6; i++) w = w + gt[i] * dx[i];
-        F lam = ln.lds_ld(LW_LAM(s, r));
-        F cand = lam - w * ln.lds_ld(LW_ROW(s, r, 10));
-        F hi = mu * lam_n;
-        F lnew = (r == 0) ? lm::max_(cand, zero) : lm::min_(lm::max_(cand, zero - hi), hi);
-        F dl = lm::sel(act, lnew - lam, zero);
-        lam = lam + dl;
-        if (r == 0) lam_n = lam;
-        ln.lds_st(LW_LAM(s, r), lam);
-        for (int i = 0; i < 3; i++) dq[i] = dq[i] + jt[i] * dl;
-        for (int i = 0; i < 6; i++) dx[i] += L::template bcast<LEG>(gt[i] * dl);
-      }
-    }
+  static LL_HD void gs_turn(const L& ln, const B& valid, const F& base, const F* gt, const F& inv, const F& lo, const F& hi, F& lam, float* dx) {
+    F w = base;
+    for (int i = 0; i < 6; i++) w = w + gt[i] * dx[i];
+    F cand = lm::min_(lm::max_(lam - w * inv, lo), hi);
+    F dl = lm::sel(lm::and_(ln.is_leg(LEG), valid), cand - lam, ln.lane_f(0.0f));
+    lam = lam + dl;
+    for (int i = 0; i < 6; i++) dx[i] += L::template bcast<LEG>(gt[i] * dl);
   }
 
   // ---------------------------------------------------------------------------------------------------

@@ -120,6 +120,7 @@ static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
   P.link_damping = (float)LLM_LINK_DAMPING;
   P.erp = (float)LLM_ERP;
   P.margin_dist = (float)LLM_CONTACT_MARGIN;
+  P.limit_gate = (float)LLM_LIMIT_GATE;
   double sw = 0;
   for (int i = 0; i < 5; i++) sw += cfg.reward_weights[i];               // PLE:365
   if (!(sw > 0)) return "reward_weights must sum to a positive number";

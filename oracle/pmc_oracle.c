@@ -685,20 +685,30 @@ int orc_substep_model(const OModel* M, double dt, int n_iter, double mu_foot, do
   double bias[MAXROWS], lo[MAXROWS], hi[MAXROWS], lam[MAXROWS];
   int fric_of[MAXROWS]; double mu_row[MAXROWS];
   int nr = 0;
-  /* joint limits: one unilateral row per joint toward its nearer limit (URDF <limit>, Bullet btMultiBodyJointLimitConstraint) */
+  /* joint limits: one unilateral row per joint toward its nearer limit (URDF <limit>, Bullet
+   * btMultiBodyJointLimitConstraint).  A row can only ever act if its free approach speed s*qd* + bias is small,
+   * so rows with s*qd* + bias >= LLM_LIMIT_GATE are left out of the solve (DESIGN.md "joint limits"). */
+  int lim_row[12];
   for (int i = 0; i < 12; i++) {
     double dl = state[13 + i] - M->qlo[i], dh = M->qhi[i] - state[13 + i];
     double d = dl <= dh ? dl : dh, sgn = dl <= dh ? 1.0 : -1.0;
+    double bz = d > 0 ? d / dt : LLM_ERP * d / dt;
+    lim_row[i] = -1;
+    if (!(sgn * nu[6 + i] + bz < LLM_LIMIT_GATE)) continue;
     memset(J[nr], 0, sizeof J[nr]);
     J[nr][6 + i] = sgn;
-    bias[nr] = d > 0 ? d / dt : LLM_ERP * d / dt;
+    bias[nr] = bz;
     lo[nr] = 0; hi[nr] = INFINITY; fric_of[nr] = -1; mu_row[nr] = 0;
+    lim_row[i] = nr;
     nr++;
   }
   /* contacts: normal + two friction rows, directions n=+z, t1=(0,-1,0), t2=(1,0,0) (btPlaneSpace1 of +z) */
   static const double dirs[3][3] = {{0, 0, 1}, {0, -1, 0}, {1, 0, 0}};
+  int con_row[4][KC];
+  for (int l = 0; l < 4; l++) for (int k = 0; k < KC; k++) con_row[l][k] = -1;
   for (int c = 0; c < nc; c++) {
     int b = C[c].body;
+    con_row[C[c].leg][C[c].slot] = nr;
     double ploc[3], d3[3];
     for (int i = 0; i < 3; i++) d3[i] = C[c].P[i] - K.pw[b][i];
     m3tv(K.Rw[b], d3, ploc);
@@ -748,7 +758,17 @@ int orc_substep_model(const OModel* M, double dt, int n_iter, double mu_foot, do
         A[r][s2] = s;
       }
   }
-  /* projected Gauss-Seidel, LR:261 numSolverIterations (10); rows in order: limits, then per contact n,t1,t2 */
+  /* projected Gauss-Seidel, LR:261 numSolverIterations (10).  Row order of the spec: limit rows joint-major
+   * (hip of legs 0..3, thigh of legs 0..3, shank of legs 0..3), then per contact slot: the normal rows of legs 0..3,
+   * their t1 rows, their t2 rows. */
+  int order[MAXROWS], no = 0;
+  for (int j = 0; j < 3; j++)
+    for (int l = 0; l < 4; l++)
+      if (lim_row[3 * l + j] >= 0) order[no++] = lim_row[3 * l + j];
+  for (int k = 0; k < KC; k++)
+    for (int r = 0; r < 3; r++)
+      for (int l = 0; l < 4; l++)
+        if (con_row[l][k] >= 0) order[no++] = con_row[l][k] + r;
   double v0[MAXROWS];
   for (int r = 0; r < nr; r++) {
     double s = 0;
@@ -756,7 +776,8 @@ int orc_substep_model(const OModel* M, double dt, int n_iter, double mu_foot, do
     v0[r] = s; lam[r] = 0;
   }
   for (int it = 0; it < n_iter; it++) {
-    for (int r = 0; r < nr; r++) {
+    for (int oi = 0; oi < no; oi++) {
+      int r = order[oi];
       double w = v0[r] + bias[r];
       for (int s2 = 0; s2 < nr; s2++) w += A[r][s2] * lam[s2];
       double l_new = lam[r] - w / A[r][r];
@@ -769,7 +790,13 @@ int orc_substep_model(const OModel* M, double dt, int n_iter, double mu_foot, do
   }
   for (int r = 0; r < nr; r++)
     for (int k = 0; k < NDOF; k++) nu[k] += MiJt[r][k] * lam[r];
-  if (diag) { diag->n_contacts = nc; diag->n_rows = nr; memcpy(diag->lambda, lam, nr * sizeof(double)); }
+  if (diag) {   /* fixed layout for the tests: [12 limit rows (0 when gated out)] [3 rows per contact, contact order] */
+    diag->n_contacts = nc; diag->n_rows = 12 + 3 * nc;
+    memset(diag->lambda, 0, sizeof diag->lambda);
+    for (int i = 0; i < 12; i++) if (lim_row[i] >= 0) diag->lambda[i] = lam[lim_row[i]];
+    for (int c = 0; c < nc; c++)
+      for (int r = 0; r < 3; r++) diag->lambda[12 + 3 * c + r] = lam[con_row[C[c].leg][C[c].slot] + r];
+  }
 
   /* ---- integrate positions with the NEW velocities (semi-implicit Euler) -------------------------- */
   double vw[3], ww[3];

@@ -54,6 +54,9 @@ inline f4 sel(const b4& m, const f4& a, const f4& b) { f4 r; for (int i = 0; i <
 inline i4 sel(const b4& m, const i4& a, const i4& b) { i4 r; for (int i = 0; i < 4; i++) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
 inline b4 and_(const b4& a, const b4& b) { b4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] && b.v[i]; return r; }
 inline b4 or_(const b4& a, const b4& b) { b4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] || b.v[i]; return r; }
+inline f4 rint_(const f4& a) { f4 r; for (int i = 0; i < 4; i++) r.v[i] = rintf(a.v[i]); return r; }
+inline b4 odd_(const i4& k) { b4 r; for (int i = 0; i < 4; i++) r.v[i] = (k.v[i] & 1) != 0; return r; }
+inline b4 bit1_(const i4& k) { b4 r; for (int i = 0; i < 4; i++) r.v[i] = (k.v[i] & 2) != 0; return r; }
 inline b4 not_(const b4& a) { b4 r; for (int i = 0; i < 4; i++) r.v[i] = !a.v[i]; return r; }
 }  // namespace lm
 
