@@ -27,10 +27,15 @@
 #define LLS_DONE_NONFINITE 16
 
 // LDS words per lane (see lanes.hpp lds_ld/lds_st)
-#define LW_CAND(s, f) ((s) * 6 + (f))                       // P(3) link depth mu
-#define LW_ROW(s, r, f) (36 + ((s) * 3 + (r)) * 11 + (f))   // gt(6) jt(3) c(=v0+bias) invA
-#define LW_LAM(s, r) (234 + (s) * 3 + (r))
-#define LW_COUNT 252
+#define LW_CAND(s, f) ((s) * 6 + (f))                          // contact slot s: P(3) link depth mu
+#define LW_ROW(row, f) (PMC_K * 6 + (row) * 12 + (f))           // row record: gt(6) jt(3) c(=v0+bias) invA lambda
+#define LW_COUNT (PMC_K * 6 + (3 + 3 * PMC_K) * 12)
+
+#if defined(__HIPCC__)
+#define LL_NOUNROLL _Pragma("nounroll")
+#else
+#define LL_NOUNROLL _Pragma("GCC unroll 1")
+#endif
 
 // PLE:235-240 for the batch: fold the statistics published by finished episodes into the per-clip table and rebuild
 // the sampling distribution  p ~ (1 - avg_reward_sum)^factor  (stored as an inclusive CDF).  Run by ONE thread
@@ -270,6 +275,7 @@ struct Pmc {
     F zc = z0 + dot(ezk, c), za = dot(ezk, ua), zb = dot(ezk, ub), zcc = dot(ezk, uc);
     F lo = zc - lm::abs_(za) - lm::abs_(zb) - lm::abs_(zcc);
     if (!L::any(lo < cc.margin)) return;
+    LL_NOUNROLL
     for (int j = 0; j < 8; j++) {
       F sa = ln.lane_f((j & 1) ? 1.0f : -1.0f), sb = ln.lane_f((j & 2) ? 1.0f : -1.0f), sc = ln.lane_f((j & 4) ? 1.0f : -1.0f);
       cand_box_vertex(ln, cc, R, p, zc, za, zb, zcc, c, ua, ub, uc, sa, sb, sc, link, mu);
@@ -426,30 +432,6 @@ struct Pmc {
     F qs[3];
     for (int j = 0; j < 3; j++) qs[j] = qd[j] + u[j] * dt;
 
-    // --- joint-limit rows (kept in registers) ----------------------------------------------------------------------------
-    F lgt[3][6], ljt[3][3], lc_[3], linv[3], llam[3];
-    B lvalid[3];
-    float inv_dt = 1.0f / dt;
-    for (int j = 0; j < 3; j++) {
-      F dl = q[j] - ln.legc(legc, LC_QLO + j), dh = ln.legc(legc, LC_QHI + j) - q[j];
-      B lower = dl <= dh;
-      F d = lm::sel(lower, dl, dh), sg = lm::sel(lower, one, zero - one);
-      F jt[3] = {zero, zero, zero};
-      jt[j] = sg;
-      lm_fwd(lf, jt);
-      SV<F> g6 = scale(scale(lf.y1, jt[0]) + scale(lf.y2, jt[1]) + scale(lf.y3, jt[2]), zero - one);
-      F gt[6];
-      sv_to6(g6, gt);
-      fwd6(Sb, Sd, gt);
-      F nn = jt[0] * jt[0] + jt[1] * jt[1] + jt[2] * jt[2];
-      for (int i = 0; i < 6; i++) { lgt[j][i] = gt[i]; nn = nn + gt[i] * gt[i]; }
-      for (int i = 0; i < 3; i++) ljt[j][i] = jt[i];
-      linv[j] = one / nn;
-      lc_[j] = sg * qs[j] + lm::sel(d > 0.0f, d * inv_dt, d * (P.erp * inv_dt));
-      lvalid[j] = lc_[j] < P.limit_gate;        // rows that cannot act this substep stay out of the solve
-      llam[j] = zero;
-    }
-
     // --- contact candidates -----------------------------------------------------------------------------------------------
     CandCtx cc;
     cc.n = L::f2i(zero);
@@ -461,13 +443,13 @@ struct Pmc {
       V3l ez = cvt3<F>(ezb);
       V3l ez1 = mulT(k.R1, ez), ez2 = mulT(k.R2, ez), ez3 = mulT(k.R3, ez);
       F z1 = dot(ez, k.p1) + cc.pz, z2 = dot(ez, k.p2) + cc.pz, z3 = dot(ez, k.p3) + cc.pz;
-      // priority: foot, shank box, wheel, thigh box, thigh cylinders, hip cylinder, then the lane's share of the base
+      // priority: foot, shank box, wheel, thigh cylinders, thigh box, hip cylinder, then the lane's share of the base
       cand_sphere(ln, cc, k.R3, k.p3, z3, ez3, ld3c(ln, legc, LC_FOOTSPH), ln.legc(legc, LC_FOOTSPH + 3), 3.0f, mu_f);
       cand_box(ln, cc, legc, LC_SHBOX, k.R3, k.p3, z3, ez3, 3.0f, mu_l);
-      cand_cyl(ln, cc, legc, LC_WHEEL, k.R2, k.p2, z2, ez2, 2.0f, mu_l);
+      LL_NOUNROLL
+      for (int cy = 0; cy < 3; cy++)              // wheel, thigh cylinder 0, thigh cylinder 1
+        cand_cyl(ln, cc, legc, cy == 0 ? LC_WHEEL : (cy == 1 ? LC_THCYL0 : LC_THCYL1), k.R2, k.p2, z2, ez2, 2.0f, mu_l);
       cand_box(ln, cc, legc, LC_THBOX, k.R2, k.p2, z2, ez2, 2.0f, mu_l);
-      cand_cyl(ln, cc, legc, LC_THCYL0, k.R2, k.p2, z2, ez2, 2.0f, mu_l);
-      cand_cyl(ln, cc, legc, LC_THCYL1, k.R2, k.p2, z2, ez2, 2.0f, mu_l);
       cand_cyl(ln, cc, legc, LC_HIPCYL, k.R1, k.p1, z1, ez1, 1.0f, mu_l);
       // base box: this lane owns the two vertices with its (sx, sy) signs
       {
@@ -498,8 +480,36 @@ struct Pmc {
       }
     }
 
+    // --- constraint rows live in LDS as uniform records  [gt(6) jt(3) c inv lambda]:  rows 0..2 = this lane's joint limits,
+    //     rows 3+3s+r = contact slot s, r = normal / t1 / t2.  inv = 0 marks a row that is not in the solve. ---------------------
+    float inv_dt = 1.0f / dt;
+    LL_NOUNROLL
+    for (int j = 0; j < 3; j++) {
+      F qj = (j == 0) ? q[0] : (j == 1 ? q[1] : q[2]);
+      F qsj = (j == 0) ? qs[0] : (j == 1 ? qs[1] : qs[2]);
+      F dl = qj - ln.legc(legc, LC_QLO + j), dh = ln.legc(legc, LC_QHI + j) - qj;
+      B lower = dl <= dh;
+      F d = lm::sel(lower, dl, dh), sg = lm::sel(lower, one, zero - one);
+      F jt[3];
+      jt[0] = (j == 0) ? sg : zero; jt[1] = (j == 1) ? sg : zero; jt[2] = (j == 2) ? sg : zero;
+      lm_fwd(lf, jt);
+      SV<F> g6 = scale(scale(lf.y1, jt[0]) + scale(lf.y2, jt[1]) + scale(lf.y3, jt[2]), zero - one);
+      F gt[6];
+      sv_to6(g6, gt);
+      fwd6(Sb, Sd, gt);
+      F nn = jt[0] * jt[0] + jt[1] * jt[1] + jt[2] * jt[2];
+      for (int i = 0; i < 6; i++) { nn = nn + gt[i] * gt[i]; ln.lds_st(LW_ROW(j, i), gt[i]); }
+      for (int i = 0; i < 3; i++) ln.lds_st(LW_ROW(j, 6 + i), jt[i]);
+      F cj = sg * qsj + lm::sel(d > 0.0f, d * inv_dt, d * (P.erp * inv_dt));
+      B lvalid = cj < P.limit_gate;              // rows that cannot act this substep stay out of the solve
+      ln.lds_st(LW_ROW(j, 9), cj);
+      ln.lds_st(LW_ROW(j, 10), lm::sel(lvalid, one / nn, zero));
+      ln.lds_st(LW_ROW(j, 11), zero);
+    }
+
     // --- contact rows: n = +z, t1 = -y, t2 = +x (world), expressed in F0 ------------------------------------------------------
     int max_n = 0;
+    LL_NOUNROLL
     for (int s = 0; s < PMC_K; s++) {
       B valid = cc.n > s;
       if (!L::any(valid)) break;
@@ -512,6 +522,7 @@ struct Pmc {
       V3l r1 = Pb - k.p1, r2 = Pb - k.p2, r3 = Pb - k.p3;
       V3l a1v = mk3<F>(one, zero, zero);
       V3l d1 = scale(cross(a1v, r1), on1), d2 = scale(cross(k.a2, r2), on2), d3 = scale(cross(k.a2, r3), on3);
+      LL_NOUNROLL
       for (int r = 0; r < 3; r++) {
         V3u ub = (r == 0) ? ezb : (r == 1 ? mk3<float>(-R.m[3], -R.m[4], -R.m[5]) : mk3<float>(R.m[0], R.m[1], R.m[2]));
         V3l uu = cvt3<F>(ub);
@@ -527,59 +538,50 @@ struct Pmc {
         gt[3] = uu.x - yj.l.x; gt[4] = uu.y - yj.l.y; gt[5] = uu.z - yj.l.z;
         fwd6(Sb, Sd, gt);
         F nn = jl[0] * jl[0] + jl[1] * jl[1] + jl[2] * jl[2];
-        for (int i = 0; i < 6; i++) { nn = nn + gt[i] * gt[i]; ln.lds_st(LW_ROW(s, r, i), gt[i]); }
-        for (int i = 0; i < 3; i++) ln.lds_st(LW_ROW(s, r, 6 + i), jl[i]);
-        ln.lds_st(LW_ROW(s, r, 9), (r == 0) ? vrow + bias : vrow);
-        ln.lds_st(LW_ROW(s, r, 10), one / nn);
-        ln.lds_st(LW_LAM(s, r), zero);
+        const int row = 3 + 3 * s + r;
+        for (int i = 0; i < 6; i++) { nn = nn + gt[i] * gt[i]; ln.lds_st(LW_ROW(row, i), gt[i]); }
+        for (int i = 0; i < 3; i++) ln.lds_st(LW_ROW(row, 6 + i), jl[i]);
+        ln.lds_st(LW_ROW(row, 9), (r == 0) ? vrow + bias : vrow);
+        ln.lds_st(LW_ROW(row, 10), lm::sel(valid, one / nn, zero));
+        ln.lds_st(LW_ROW(row, 11), zero);
       }
     }
 
     // --- projected Gauss-Seidel in whitened coordinates -------------------------------------------------------------------------
+    // Row order of the spec: limit rows joint-major (legs 0..3 per joint), then per slot the normal rows of legs 0..3, their t1
+    // rows, their t2 rows.  A row record is loaded once; the four lanes of the quad then take their Gauss-Seidel turn on the
+    // shared 6-vector dx (only the lane whose turn it is commits), and the lane-private dq is updated afterwards.
     float dx[6] = {0, 0, 0, 0, 0, 0};      // shared:  sum gt * lambda
     F dq[3] = {zero, zero, zero};          // private: sum jt * lambda
-    // row order of the spec: limit rows joint-major (legs 0..3 per joint), then per slot the normal rows of legs 0..3,
-    // their t1 rows, their t2 rows.  A row is loaded once; the four lanes of the quad then take their Gauss-Seidel turn
-    // on the shared 6-vector dx (only the lane whose turn it is commits), and the lane-private dq is updated afterwards.
-    bool lim_any[3];
-    for (int j = 0; j < 3; j++) lim_any[j] = L::any(lvalid[j]);
+    const int n_rows = 3 + 3 * max_n;
+    const F big = ln.lane_f(3.0e38f);
+    LL_NOUNROLL
     for (int it = 0; it < P.n_iter; it++) {
-      for (int j = 0; j < 3; j++) {
-        if (!lim_any[j]) continue;
-        F base = lc_[j] + ljt[j][0] * dq[0] + ljt[j][1] * dq[1] + ljt[j][2] * dq[2];
-        F lam0 = llam[j];
+      F lam_n = zero;
+      LL_NOUNROLL
+      for (int row = 0; row < n_rows; row++) {
+        F inv = ln.lds_ld(LW_ROW(row, 10));
+        if (!L::any(inv > 0.0f)) continue;
+        F gt[6], jt[3];
+        for (int i = 0; i < 6; i++) gt[i] = ln.lds_ld(LW_ROW(row, i));
+        for (int i = 0; i < 3; i++) jt[i] = ln.lds_ld(LW_ROW(row, 6 + i));
+        F base = ln.lds_ld(LW_ROW(row, 9)) + jt[0] * dq[0] + jt[1] * dq[1] + jt[2] * dq[2];
+        F lam0 = ln.lds_ld(LW_ROW(row, 11));
         F lam = lam0;
-        gs_turn<0>(ln, lvalid[j], base, lgt[j], linv[j], zero, ln.lane_f(3.0e38f), lam, dx);
-        gs_turn<1>(ln, lvalid[j], base, lgt[j], linv[j], zero, ln.lane_f(3.0e38f), lam, dx);
-        gs_turn<2>(ln, lvalid[j], base, lgt[j], linv[j], zero, ln.lane_f(3.0e38f), lam, dx);
-        gs_turn<3>(ln, lvalid[j], base, lgt[j], linv[j], zero, ln.lane_f(3.0e38f), lam, dx);
-        F dl = lam - lam0;
-        llam[j] = lam;
-        for (int i = 0; i < 3; i++) dq[i] = dq[i] + ljt[j][i] * dl;
-      }
-      for (int s = 0; s < max_n; s++) {
-        B valid = cc.n > s;
-        F mu = ln.lds_ld(LW_CAND(s, 5));
-        F lam_n = zero;
-        for (int r = 0; r < 3; r++) {
-          F gt[6], jt[3];
-          for (int i = 0; i < 6; i++) gt[i] = ln.lds_ld(LW_ROW(s, r, i));
-          for (int i = 0; i < 3; i++) jt[i] = ln.lds_ld(LW_ROW(s, r, 6 + i));
-          F base = ln.lds_ld(LW_ROW(s, r, 9)) + jt[0] * dq[0] + jt[1] * dq[1] + jt[2] * dq[2];
-          F inv = ln.lds_ld(LW_ROW(s, r, 10));
-          F lam0 = ln.lds_ld(LW_LAM(s, r));
-          F lam = lam0;
-          F hi = (r == 0) ? ln.lane_f(3.0e38f) : mu * lam_n;
-          F lo = (r == 0) ? zero : zero - hi;
-          gs_turn<0>(ln, valid, base, gt, inv, lo, hi, lam, dx);
-          gs_turn<1>(ln, valid, base, gt, inv, lo, hi, lam, dx);
-          gs_turn<2>(ln, valid, base, gt, inv, lo, hi, lam, dx);
-          gs_turn<3>(ln, valid, base, gt, inv, lo, hi, lam, dx);
-          if (r == 0) lam_n = lam;
-          ln.lds_st(LW_LAM(s, r), lam);
-          F dl = lam - lam0;
-          for (int i = 0; i < 3; i++) dq[i] = dq[i] + jt[i] * dl;
+        const int rr = (row < 3) ? 0 : (row % 3);                  // 0: unilateral row, 1/2: friction rows of the same contact
+        F hi = big, lo = zero;
+        if (rr != 0) {
+          hi = ln.lds_ld(LW_CAND((row - 3) / 3, 5)) * lam_n;
+          lo = zero - hi;
         }
+        gs_turn<0>(ln, base, gt, inv, lo, hi, lam, dx);
+        gs_turn<1>(ln, base, gt, inv, lo, hi, lam, dx);
+        gs_turn<2>(ln, base, gt, inv, lo, hi, lam, dx);
+        gs_turn<3>(ln, base, gt, inv, lo, hi, lam, dx);
+        if (rr == 0) lam_n = lam;
+        ln.lds_st(LW_ROW(row, 11), lam);
+        F dl = lam - lam0;
+        for (int i = 0; i < 3; i++) dq[i] = dq[i] + jt[i] * dl;
       }
     }
     // back to velocities: d(xi) = Lb^-T dx ; d(qd) = Lm^-T (dq - Y^T d(xi))
@@ -606,11 +608,11 @@ struct Pmc {
 
   // Gauss-Seidel turn of leg LEG on one row per lane: w = base + gt.dx ; lam <- clamp(lam - w/A) ; dx += gt * dlam (quad broadcast)
   template <int LEG>
-  static LL_HD void gs_turn(const L& ln, const B& valid, const F& base, const F* gt, const F& inv, const F& lo, const F& hi, F& lam, float* dx) {
+  static LL_HD void gs_turn(const L& ln, const F& base, const F* gt, const F& inv, const F& lo, const F& hi, F& lam, float* dx) {
     F w = base;
     for (int i = 0; i < 6; i++) w = w + gt[i] * dx[i];
     F cand = lm::min_(lm::max_(lam - w * inv, lo), hi);
-    F dl = lm::sel(lm::and_(ln.is_leg(LEG), valid), cand - lam, ln.lane_f(0.0f));
+    F dl = lm::sel(ln.is_leg(LEG), cand - lam, ln.lane_f(0.0f));      // inv == 0 (row not in the solve) gives cand == lam
     lam = lam + dl;
     for (int i = 0; i < 6; i++) dx[i] += L::template bcast<LEG>(gt[i] * dl);
   }

@@ -632,7 +632,7 @@ static int prim_candidates(const OPrim* p, const double* Rw, const double* pw, O
 
 /* DESIGN.md "contact candidates": per leg lane, fixed priority order, first KC within the margin */
 static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double mu_link, OContact* out) {
-  static const int order[LLM_N_LEG_PRIMS] = {6, 5, 4, 1, 2, 3, 0};
+  static const int order[LLM_N_LEG_PRIMS] = {6, 5, 4, 2, 3, 1, 0};   /* foot, shank box, wheel, thigh cyls, thigh box, hip */
   static const int links[LLM_N_LEG_PRIMS] = LLM_LEG_PRIM_LINKS;
   int n = 0;
   for (int l = 0; l < 4; l++) {
