@@ -1,0 +1,9 @@
+"""lifelike_agility_and_play_amd -- MI355X-native batched rollout engine for the PMC tracking environment of
+Tencent-RoboticsX/lifelike-agility-and-play (hot path only).
+
+``--outer_env lifelike_agility_and_play_amd.create_tracking_game`` replaces
+``--outer_env lifelike.sim_envs.pybullet_envs.create_tracking_game`` (bin/run_pg_actor.py:81-83).
+"""
+from .envs import BatchedTrackingEnv, TrackingGame, create_tracking_env, create_tracking_game  # noqa: F401
+
+__all__ = ['create_tracking_game', 'create_tracking_env', 'TrackingGame', 'BatchedTrackingEnv']

@@ -1,0 +1,128 @@
+"""The reference's plug-in surface (create_pybullet_envs.py) over the engine.  CPU tests drive it through the host
+emulation library (kernel logic) -- the product default is the HIP library, exercised in test_gpu_env_api.py."""
+import os
+import subprocess
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+
+import lifelike_agility_and_play_amd as lla
+from conftest import PMC_PROP_TYPE, PMC_REWARD_WEIGHTS
+
+EMUL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emul')
+EMUL_LIB = os.path.join(EMUL_DIR, '_build', 'libllenv_emul.so')
+
+
+def pmc_config(**kw):
+    cfg = dict(arena_id='LeggedRobotTracking', render=False, data_path='', control_freq=50.0, prop_type=list(PMC_PROP_TYPE),
+               prioritized_sample_factor=3.0, set_obstacle=False, kp=50.0, kd=0.5, max_tau=18, reward_weights=dict(PMC_REWARD_WEIGHTS))
+    cfg.update(kw)
+    return cfg
+
+
+@pytest.fixture(scope='module')
+def emul_lib():
+    subprocess.check_call(['make', '-C', EMUL_DIR, '-s'])
+    return EMUL_LIB
+
+
+def check_single_env_contract(golden, lib_path):
+    env = lla.create_tracking_game(**pmc_config(lib_path=lib_path))
+    # spaces (PLE:117-124, CPE:9-10)
+    assert len(env.observation_space.spaces) == 1 and len(env.action_space.spaces) == 1
+    sp = env.observation_space.spaces[0].spaces
+    assert list(sp.keys()) == ['prop', 'prop_a', 'future']
+    assert [sp[k].shape for k in sp] == [(99,), (36,), (72,)] and env.action_space.spaces[0].shape == (12,)
+    np.testing.assert_array_equal(golden['obs_space_shapes'], [99, 36, 72])
+    # reset: same NumPy draws as the reference => same (clip, t0) and the same first observation
+    for k in range(6):
+        np.random.seed(int(golden['g2_seed'][k]))
+        out = env.reset(inter_kwargs={'anything': 1})                      # kwargs accepted and ignored (CPE:12)
+        assert isinstance(out, tuple) and len(out) == 1 and isinstance(out[0], OrderedDict)
+        assert env.env.sampled_data_idx == int(golden['g2_clip'][k])
+        assert env.env.time == float(golden['g2_t0'][k])
+        obs = np.concatenate([out[0]['prop'], out[0]['prop_a'], out[0]['future']])
+        np.testing.assert_allclose(obs, golden['g2_obs'][k], rtol=1e-5, atol=1e-5)
+    # step: tuple API, python scalars, empty info (CPE:16-18, PLE:245)
+    (o,), (r,), d, info = env.step([np.zeros(12)])
+    assert isinstance(r, float) and isinstance(d, bool) and info == {}
+    assert o['prop'].shape == (99,) and o['prop_a'].shape == (36,) and o['future'].shape == (72,)
+    np.testing.assert_array_equal(o['prop_a'], 0.0)
+    a = np.linspace(-0.1, 0.1, 12)
+    (o2,), _, _, _ = env.step([a])
+    np.testing.assert_allclose(o2['prop_a'][24:], a, rtol=1e-6)            # newest action = raw policy action (quirk Q3)
+    np.testing.assert_array_equal(o2['prop_a'][:24], 0.0)
+    np.testing.assert_array_equal(o2['prop'][:66], o['prop'][33:])         # deque shift
+    # never auto-resets: run to termination with wild actions, then the env stays done until reset()
+    rng = np.random.default_rng(0)
+    for t in range(400):
+        _, _, d, _ = env.step([rng.normal(size=12) * 2.0])
+        if d:
+            break
+    assert d
+    env.reset()
+    env.close()
+    e2 = lla.create_tracking_env(**pmc_config(lib_path=lib_path))
+    assert list(e2.observation_space.spaces.keys()) == ['prop', 'prop_a', 'future'] and e2.action_space.shape == (12,)   # CPE:143-147
+    e2.close()
+
+
+def test_single_env_contract(golden, emul_lib):
+    check_single_env_contract(golden, emul_lib)
+
+
+def test_factory_errors(emul_lib):
+    with pytest.raises(AssertionError):
+        lla.create_tracking_game(**pmc_config(arena_id='Playground', lib_path=emul_lib))       # CPE:23
+    with pytest.raises(KeyError):
+        lla.create_tracking_game(render=False)                                                  # CPE:22 env_config["arena_id"]
+    with pytest.raises(TypeError):
+        lla.create_tracking_game(**pmc_config(prop_type='joint_pos', lib_path=emul_lib))       # PLE:113
+    with pytest.raises(FileNotFoundError):
+        lla.create_tracking_game(**pmc_config(data_path='/nonexistent/mocap', lib_path=emul_lib))
+    with pytest.raises(NotImplementedError):
+        lla.create_tracking_game(**pmc_config(set_obstacle=True, lib_path=emul_lib))
+
+
+def test_prop_type_subset_changes_layout(emul_lib):
+    env = lla.create_tracking_game(**pmc_config(prop_type=['e_g', 'joint_pos'], lib_path=emul_lib))
+    sp = env.observation_space.spaces[0].spaces
+    assert sp['prop'].shape == (45,)
+    np.random.seed(1)
+    (o,) = env.reset()
+    assert o['prop'].shape == (45,) and o['future'].shape == (72,)
+    eg = o['prop'][30:33]
+    assert abs(np.linalg.norm(eg) - 1.0) < 1e-5                            # e_g is a unit vector (row of R)
+    env.close()
+
+
+def test_json_data_path_matches_packed_table(tmp_path, emul_lib, mocap_table):
+    """data_path may be a reference-format JSON clip (ML:19-31)."""
+    import json
+    c = mocap_table.names.index('dog_quad_walkrun_001_ret.txt')
+    f = tmp_path / 'clip_ret.txt'
+    f.write_text(json.dumps({'FrameDuration': mocap_table.frame_step, 'LegOrder': ['FR', 'FL', 'HR', 'HL'],
+                             'Frames': mocap_table.clip(c).tolist()}))
+    env = lla.create_tracking_game(**pmc_config(data_path=str(f), lib_path=emul_lib))
+    np.random.seed(123)
+    (o,) = env.reset()
+    assert env.env.sampled_data_idx == 0 and abs(env.env.time - 2.4345688415361453) < 1e-12
+    env.close()
+
+
+def test_batched_env(golden, emul_lib):
+    env = lla.create_tracking_game(**pmc_config(num_envs=8, seed=5, lib_path=emul_lib))
+    obs = env.reset()
+    assert obs.shape == (8, 207) and obs.dtype == np.float32
+    total_done = 0
+    for t in range(40):
+        obs, r, d, info = env.step(np.random.default_rng(t).normal(size=(8, 12)) * 0.5)
+        assert obs.shape == (8, 207) and r.shape == (8,) and d.dtype == bool and np.isfinite(obs).all()
+        total_done += int(d.sum())
+        if d.any():
+            np.testing.assert_array_equal(obs[d][:, 99:135], 0.0)          # re-seeded: action history is zero again
+    assert total_done > 0
+    parts = env.split(obs)
+    assert parts['prop'].shape == (8, 99)
+    env.close()
