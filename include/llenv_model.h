@@ -47,7 +47,7 @@
 #define LLM_CONTACT_MARGIN 0.02        /* Bullet contact breaking threshold */
 #define LLM_ERP 0.2                    /* PyBullet default erp / contactERP */
 #define LLM_LINK_DAMPING 0.04          /* btMultiBody default linear & angular damping (quirk Q12) */
-#define LLM_MAX_CONTACTS_PER_LEG 5     /* contact slots per leg lane */
+#define LLM_MAX_CONTACTS_PER_LEG 4     /* contact slots per leg lane */
 #define LLM_LIMIT_GATE 20.0             /* a joint-limit row enters the solve iff  s*qd* + bias < this [rad/s] */
 
 #endif

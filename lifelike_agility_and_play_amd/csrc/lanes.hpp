@@ -61,8 +61,21 @@ struct GpuLanes {
   int leg_;        // 0..3
   int lane_;       // 0..63 within the wave
   float* lds_;     // workgroup LDS scratch, word w of this lane lives at lds_[w * 64 + lane_]
+  mutable int cbase_;  // LDS word offset of the per-leg constant table copy (+ leg), see stage_consts()
 
-  LL_D GpuLanes(float* lds) : leg_(threadIdx.x & 3), lane_(threadIdx.x & 63), lds_(lds) {}
+  LL_D GpuLanes(float* lds) : leg_(threadIdx.x & 3), lane_(threadIdx.x & 63), lds_(lds), cbase_(0) {}
+
+  // Copy the per-leg constant table [n_fields][4] behind the per-lane scratch (scratch_words * 64 floats) so that a
+  // constant costs one ds_read with an immediate offset instead of a VGPR held across the whole substep loop.
+  LL_D void stage_consts(const float* tbl, int n_fields, int scratch_words) {
+    const int base = scratch_words * kWave;
+    for (int i = lane_; i < n_fields * 4; i += kWave) lds_[base + i] = tbl[i];
+    cbase_ = base + leg_;
+    __builtin_amdgcn_s_waitcnt(0);          // single-wave workgroup: program order + waitcnt is enough
+  }
+  // make the table offset opaque again so the compiler re-reads constants per substep instead of hoisting ~130 of
+  // them into registers for the whole 10-substep loop
+  LL_D void refresh_consts() const { asm volatile("" : "+v"(cbase_)); }
 
   LL_D I leg() const { return leg_; }
   LL_D F legf() const { return (float)leg_; }
@@ -86,7 +99,7 @@ struct GpuLanes {
   static LL_D bool any(B m) { return __any(m); }   // wave-level: guards wave-uniform branches
 
   // per-leg constant table [field][4]
-  LL_D F legc(const float* tbl, int field) const { return tbl[field * 4 + leg_]; }
+  LL_D F legc(const float*, int field) const { return lds_[cbase_ + field * 4]; }
   // lane pick for 3-vectors: leg 0 -> x, 1 -> y, 2,3 -> z
   LL_D F pick3(float x, float y, float z) const { return leg_ == 0 ? x : (leg_ == 1 ? y : z); }
 

@@ -3,8 +3,8 @@
 //   pmc_step_kernel     one 50 Hz control step of every env, fully fused (pmc_step.hpp); 1 env = 4 lanes,
 //                       64-thread workgroups (one wavefront, 16 envs), contact rows staged in LDS
 //   pmc_reset_kernel    PLE:150-171 for a list of envs
-//   pmc_prestep_kernel  folds finished-episode statistics into the sampling table (PLE:235-240) and, on request,
-//                       draws the synthetic random-policy actions (Philox + Box-Muller)
+//   pmc_table_kernel    folds finished-episode statistics into the prioritized sampling table (PLE:235-240)
+//   pmc_actions_kernel  draws the synthetic random-policy actions (Philox + Box-Muller)
 //
 // There is no CPU path: without a HIP device ll_create fails with LL_ENODEV.
 #include <hip/hip_runtime.h>
@@ -31,8 +31,9 @@ __global__ __launch_bounds__(PMC_WAVE) void pmc_step_kernel(StepParams P) {
   // and the solver's wave-uniform work is the union over the envs of a wave, so fewer envs per wave = shorter kernel.
   const int quad = threadIdx.x >> 2;
   const int env = blockIdx.x * P.envs_per_wave + quad;
-  if (quad >= P.envs_per_wave || env >= P.n_envs) return;
   GpuLanes ln(lds);
+  ln.stage_consts(P.legc, LC_COUNT, LW_COUNT);          // all 64 lanes copy, also those without an env
+  if (quad >= P.envs_per_wave || env >= P.n_envs) return;
   K::clear_scratch(ln);
   K::step_env(ln, P, env);
 }
@@ -40,8 +41,9 @@ __global__ __launch_bounds__(PMC_WAVE) void pmc_step_kernel(StepParams P) {
 __global__ __launch_bounds__(PMC_WAVE) void pmc_reset_kernel(StepParams P, const int32_t* ids, int n, const int32_t* clip, const double* t0) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int i = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 2);
-  if (i >= n) return;
   GpuLanes ln(lds);
+  ln.stage_consts(P.legc, LC_COUNT, 0);
+  if (i >= n) return;
   const int env = ids ? ids[i] : i;
   int c;
   double t;
@@ -55,24 +57,61 @@ __global__ __launch_bounds__(PMC_WAVE) void pmc_reset_kernel(StepParams P, const
   P.done_reason[env] = 0;
 }
 
-__global__ void pmc_prestep_kernel(StepParams P, double* avg_r, double* avg_l, double* prob, double* cdf, float* actions, float sigma) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid == 0) pmc_finalize_table(P, avg_r, avg_l, prob, cdf);
-  if (actions) {
-    const int total = P.n_envs * 3;              // four normals per thread
-    if (gid < total) {
-      uint32_t r[4];
-      philox4x32((uint32_t)gid, (uint32_t)P.step_count, (uint32_t)(P.step_count >> 32), 0xAC710u, (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r);
-      const float k = 2.3283064365386963e-10f;   // 2^-32
-      float u1 = ((float)r[0] + 1.0f) * k, u2 = (float)r[1] * k, u3 = ((float)r[2] + 1.0f) * k, u4 = (float)r[3] * k;
-      u1 = fminf(u1, 1.0f); u3 = fminf(u3, 1.0f);
-      float m1 = sqrtf(-2.0f * logf(u1)), m2 = sqrtf(-2.0f * logf(u3));
-      float4 o;
-      o.x = sigma * m1 * cosf(6.283185307179586f * u2); o.y = sigma * m1 * sinf(6.283185307179586f * u2);
-      o.z = sigma * m2 * cosf(6.283185307179586f * u4); o.w = sigma * m2 * sinf(6.283185307179586f * u4);
-      reinterpret_cast<float4*>(actions)[gid] = o;
+// PLE:235-240 for the batch, one 256-thread block: fold the statistics published by finished episodes into the per-clip
+// table (one thread per clip), then rebuild p ~ (1 - avg_reward_sum)^factor and its inclusive CDF.
+__global__ __launch_bounds__(256) void pmc_table_kernel(StepParams P, double* avg_r, double* avg_l, double* prob, double* cdf) {
+  __shared__ double red[256];
+  __shared__ int any_pending;
+  const int tid = threadIdx.x;
+  if (tid == 0) any_pending = 0;
+  __syncthreads();
+  for (int c = tid; c < P.n_clips; c += 256) {
+    unsigned long long pr = P.pending_reward[c], pl = P.pending_len[c];
+    if (pr) {
+      avg_r[c] = (double)__uint_as_float((uint32_t)pr);
+      avg_l[c] = (double)__uint_as_float((uint32_t)pl);
+      P.pending_reward[c] = 0ull;
+      P.pending_len[c] = 0ull;
+      any_pending = 1;
     }
   }
+  __syncthreads();
+  if (!any_pending) return;
+  double part = 0.0;
+  for (int c = tid; c < P.n_clips; c += 256) {
+    double p = pow(1.0 - avg_r[c], P.sample_factor);
+    prob[c] = p;
+    part += p;
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const double inv = 1.0 / red[0];
+  for (int c = tid; c < P.n_clips; c += 256) prob[c] *= inv;
+  __syncthreads();
+  if (tid == 0) {
+    double acc = 0.0;
+    for (int c = 0; c < P.n_clips; c++) { acc += prob[c]; cdf[c] = acc; }
+    cdf[P.n_clips - 1] = 1.0;
+  }
+}
+
+// synthetic random policy: a ~ N(0, sigma^2), Philox4x32-10 keyed on (seed; element, step) + Box-Muller, four per thread
+__global__ void pmc_actions_kernel(StepParams P, float* actions, float sigma) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= P.n_envs * 3) return;
+  uint32_t r[4];
+  philox4x32((uint32_t)gid, (uint32_t)P.step_count, (uint32_t)(P.step_count >> 32), 0xAC710u, (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r);
+  const float k = 2.3283064365386963e-10f;   // 2^-32
+  float u1 = fminf(((float)r[0] + 1.0f) * k, 1.0f), u2 = (float)r[1] * k, u3 = fminf(((float)r[2] + 1.0f) * k, 1.0f), u4 = (float)r[3] * k;
+  float m1 = sqrtf(-2.0f * logf(u1)), m2 = sqrtf(-2.0f * logf(u3));
+  float4 o;
+  o.x = sigma * m1 * cosf(6.283185307179586f * u2); o.y = sigma * m1 * sinf(6.283185307179586f * u2);
+  o.z = sigma * m2 * cosf(6.283185307179586f * u4); o.w = sigma * m2 * sinf(6.283185307179586f * u4);
+  reinterpret_cast<float4*>(actions)[gid] = o;
 }
 
 struct HipBackend {
@@ -93,6 +132,8 @@ struct HipBackend {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, dev));
     n_simd = prop.multiProcessorCount * 4;
+    // the solver's row records need more than the default 64 KB of dynamic LDS per workgroup (gfx950 has 160 KB per CU)
+    HIPCHK(hipFuncSetAttribute((const void*)pmc_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes()));
     if (const char* e = getenv("LL_ENVS_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= PMC_ENVS_PER_WAVE) epw_override = v; }
   }
   ~HipBackend() {
@@ -123,12 +164,13 @@ struct HipBackend {
   }
   void sync() { use(); HIPCHK(hipStreamSynchronize(stream)); }
 
-  static size_t lds_bytes() { return (size_t)LW_COUNT * PMC_WAVE * sizeof(float); }
+  static size_t lds_bytes() { return ((size_t)LW_COUNT * PMC_WAVE + (size_t)LC_COUNT * 4) * sizeof(float); }
+  static size_t reset_lds_bytes() { return (size_t)LC_COUNT * 4 * sizeof(float); }
   int epw_override = 0, n_simd = 1024;
-  int envs_per_wave(int n_envs) const {
-    if (epw_override > 0) return epw_override;
-    int e = (n_envs + n_simd - 1) / n_simd;       // aim for at least one wave per SIMD
-    return e < 1 ? 1 : (e > PMC_ENVS_PER_WAVE ? PMC_ENVS_PER_WAVE : e);
+  int envs_per_wave(int) const {
+    // measured on MI355X (profiles/r01_sweep.txt): a wave costs the same whether it carries 1 or 16 envs (the solver's
+    // instruction stream is wave-uniform), so full waves always win; the override exists for experiments only
+    return epw_override > 0 ? epw_override : PMC_ENVS_PER_WAVE;
   }
   void launch_step(const StepParams& Pin) {
     use();
@@ -153,15 +195,18 @@ struct HipBackend {
   void launch_reset(const StepParams& P, const int32_t* ids, int n, const int32_t* clip, const double* t0) {
     use();
     const int blocks = (n + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
-    hipLaunchKernelGGL(pmc_reset_kernel, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P, ids, n, clip, t0);
+    hipLaunchKernelGGL(pmc_reset_kernel, dim3(blocks), dim3(PMC_WAVE), reset_lds_bytes(), stream, P, ids, n, clip, t0);   // constants only, no solver scratch
     HIPCHK(hipGetLastError());
   }
   void launch_prestep(const StepParams& P, double* avg_r, double* avg_l, double* prob, double* cdf, float* actions, float sigma) {
     use();
-    const int threads = 256;
-    const int blocks = actions ? (P.n_envs * 3 + threads - 1) / threads : 1;
-    hipLaunchKernelGGL(pmc_prestep_kernel, dim3(blocks), dim3(actions ? threads : 64), 0, stream, P, avg_r, avg_l, prob, cdf, actions, sigma);
+    hipLaunchKernelGGL(pmc_table_kernel, dim3(1), dim3(256), 0, stream, P, avg_r, avg_l, prob, cdf);
     HIPCHK(hipGetLastError());
+    if (actions) {
+      const int threads = 256;
+      hipLaunchKernelGGL(pmc_actions_kernel, dim3((P.n_envs * 3 + threads - 1) / threads), dim3(threads), 0, stream, P, actions, sigma);
+      HIPCHK(hipGetLastError());
+    }
   }
   void enable_timing(bool on) { timing = on; }
   void collect_timing(double* avg_ms, int* n) {

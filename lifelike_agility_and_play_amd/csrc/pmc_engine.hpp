@@ -20,6 +20,7 @@ struct PmcEngine {
   ll_config cfg;
   StepParams P;
   bool have_mocap = false, have_reset = false;
+  bool table_fresh = false;   // sampling table already folded since the last step
   // table state (device, float64)
   double *d_avg_reward = nullptr, *d_avg_len = nullptr, *d_prob = nullptr, *d_cdf = nullptr;
   float* d_actions = nullptr;       // engine-owned action buffer
@@ -144,13 +145,15 @@ struct PmcEngine {
     need(true, true);
     StepParams Q = P;
     Q.actions = d_act ? d_act : d_actions;
-    bk.launch_prestep(P, d_avg_reward, d_avg_len, d_prob, d_cdf, nullptr, 0.0f);
+    if (!table_fresh) bk.launch_prestep(P, d_avg_reward, d_avg_len, d_prob, d_cdf, nullptr, 0.0f);
     bk.launch_step(Q);
+    table_fresh = false;                 // the step may have published new episode statistics
     P.step_count += 1;
   }
   void fill_random_actions(float sigma) {
     need(true, false);
     bk.launch_prestep(P, d_avg_reward, d_avg_len, d_prob, d_cdf, d_actions, sigma);
+    table_fresh = true;
   }
 
   // ---- boundary copies: rows on the host, SoA on the device ---------------------------------------------

@@ -215,6 +215,18 @@ LL_HD Q4 quat_of_rotvec(const V3<float>& rv) {  // scipy from_rotvec
   Q4 q = {s * rv.x, s * rv.y, s * rv.z, cosf(0.5f * angle)};
   return q;
 }
+// exp map for the per-substep base rotation w*dt (|angle| far below pi): polynomial sin/cos of the half angle, no
+// library call.  Falls back to the general form for |angle| >= 1 (an angular rate above 500 rad/s at dt = 2 ms).
+LL_HD Q4 quat_of_small_rotvec(const V3<float>& rv) {
+  float a2 = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
+  if (a2 >= 1.0f) return quat_of_rotvec(rv);
+  float h2 = 0.25f * a2;                           // (angle/2)^2
+  // sin(h)/h * 0.5 and cos(h), h = angle/2, Taylor to h^8 (error < 1e-9 for h <= 0.5)
+  float s = 0.5f * (1.0f + h2 * (-1.0f / 6.0f + h2 * (1.0f / 120.0f + h2 * (-1.0f / 5040.0f + h2 * (1.0f / 362880.0f)))));
+  float c = 1.0f + h2 * (-0.5f + h2 * (1.0f / 24.0f + h2 * (-1.0f / 720.0f + h2 * (1.0f / 40320.0f))));
+  Q4 q = {s * rv.x, s * rv.y, s * rv.z, c};
+  return q;
+}
 // PLE:19-23 quat2axisangle then axis*angle; returns angle, writes axis*angle
 LL_HD float axis_angle_scaled(const Q4& q, V3<float>* aa) {
   V3<float> rv = rotvec_of(mk3<float>(q.x, q.y, q.z), q.w);

@@ -2,7 +2,7 @@
 #pragma once
 #include <stdint.h>
 
-#define PMC_K 5            // contact slots per leg lane (== LLM_MAX_CONTACTS_PER_LEG)
+#define PMC_K 4            // contact slots per leg lane (== LLM_MAX_CONTACTS_PER_LEG)
 #define PMC_WAVE 64
 #define PMC_ENVS_PER_WAVE 16
 

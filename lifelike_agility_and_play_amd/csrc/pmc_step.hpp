@@ -28,8 +28,8 @@
 
 // LDS words per lane (see lanes.hpp lds_ld/lds_st)
 #define LW_CAND(s, f) ((s) * 6 + (f))                          // contact slot s: P(3) link depth mu
-#define LW_ROW(row, f) (PMC_K * 6 + (row) * 12 + (f))           // row record: gt(6) jt(3) c(=v0+bias) invA lambda
-#define LW_COUNT (PMC_K * 6 + (3 + 3 * PMC_K) * 12)
+#define LW_ROW(row, f) (PMC_K * 6 + (row) * 16 + (f))           // row record: gt(6) jt(3) c(=v0+bias) invA lambda gram(4)
+#define LW_COUNT (PMC_K * 6 + (3 + 3 * PMC_K) * 16)
 
 #if defined(__HIPCC__)
 #define LL_NOUNROLL _Pragma("nounroll")
@@ -242,12 +242,30 @@ struct Pmc {
     float margin;
   };
   static LL_HD void cand_push(const L& ln, CandCtx& cc, B pass, const V3l& Pb, F depth, float link, F mu) {
-    B ok = lm::and_(pass, cc.n < PMC_K);
+    // DESIGN.md "contact candidates": a lane keeps the PMC_K DEEPEST of its candidates.  While slots are free a candidate
+    // takes the next one; once full it replaces the shallowest stored contact if it is deeper than that one.
+    B room = cc.n < PMC_K;
+    I slot = cc.n;
+    B full = lm::and_(pass, lm::not_(room));
+    B ok = lm::and_(pass, room);
+    if (L::any(full)) {
+      F worst = ln.lds_ld(LW_CAND(0, 4));
+      I wslot = L::f2i(ln.lane_f(0.0f));
+      for (int s2 = 1; s2 < PMC_K; s2++) {
+        F d2 = ln.lds_ld(LW_CAND(s2, 4));
+        B shallower = d2 > worst;
+        worst = lm::sel(shallower, d2, worst);
+        wslot = lm::sel(shallower, wslot * 0 + s2, wslot);
+      }
+      B repl = lm::and_(full, depth < worst);
+      slot = lm::sel(repl, wslot, slot);
+      ok = lm::or_(ok, repl);
+    }
     if (L::any(ok)) {
-      I w = cc.n * 6;
+      I w = slot * 6;
       ln.lds_st_if(ok, w + 0, Pb.x); ln.lds_st_if(ok, w + 1, Pb.y); ln.lds_st_if(ok, w + 2, Pb.z);
       ln.lds_st_if(ok, w + 3, ln.lane_f(link)); ln.lds_st_if(ok, w + 4, depth); ln.lds_st_if(ok, w + 5, mu);
-      cc.n = lm::sel(ok, cc.n + 1, cc.n);
+      cc.n = lm::sel(lm::and_(ok, room), cc.n + 1, cc.n);
     }
   }
   // a link-attached point x (link frame): world height = z0 + ezk.x ; F0 position = p + R x
@@ -313,6 +331,7 @@ struct Pmc {
     const float* legc = P.legc;
     const float* bc = P.basec;
     const float dt = P.dt;
+    ln.refresh_consts();
     M3<float> R = qmat(bs.q);
     SV<float> v0;
     v0.a = mulT(R, bs.w);
@@ -505,6 +524,7 @@ struct Pmc {
       ln.lds_st(LW_ROW(j, 9), cj);
       ln.lds_st(LW_ROW(j, 10), lm::sel(lvalid, one / nn, zero));
       ln.lds_st(LW_ROW(j, 11), zero);
+      store_gram(ln, LW_ROW(j, 12), gt);
     }
 
     // --- contact rows: n = +z, t1 = -y, t2 = +x (world), expressed in F0 ------------------------------------------------------
@@ -544,6 +564,7 @@ struct Pmc {
         ln.lds_st(LW_ROW(row, 9), (r == 0) ? vrow + bias : vrow);
         ln.lds_st(LW_ROW(row, 10), lm::sel(valid, one / nn, zero));
         ln.lds_st(LW_ROW(row, 11), zero);
+        store_gram(ln, LW_ROW(row, 12), gt);
       }
     }
 
@@ -562,10 +583,14 @@ struct Pmc {
       for (int row = 0; row < n_rows; row++) {
         F inv = ln.lds_ld(LW_ROW(row, 10));
         if (!L::any(inv > 0.0f)) continue;
-        F gt[6], jt[3];
+        F gt[6], jt[3], gr[4];
         for (int i = 0; i < 6; i++) gt[i] = ln.lds_ld(LW_ROW(row, i));
         for (int i = 0; i < 3; i++) jt[i] = ln.lds_ld(LW_ROW(row, 6 + i));
-        F base = ln.lds_ld(LW_ROW(row, 9)) + jt[0] * dq[0] + jt[1] * dq[1] + jt[2] * dq[2];
+        for (int i = 0; i < 4; i++) gr[i] = ln.lds_ld(LW_ROW(row, 12 + i));
+        // residual velocity of this lane's row for the current (dx, dq); kept up to date through the four turns with the
+        // Gram scalars gr[L] = gt . gt_L instead of being recomputed from dx after every commit
+        F w = ln.lds_ld(LW_ROW(row, 9)) + jt[0] * dq[0] + jt[1] * dq[1] + jt[2] * dq[2];
+        for (int i = 0; i < 6; i++) w = w + gt[i] * dx[i];
         F lam0 = ln.lds_ld(LW_ROW(row, 11));
         F lam = lam0;
         const int rr = (row < 3) ? 0 : (row % 3);                  // 0: unilateral row, 1/2: friction rows of the same contact
@@ -574,14 +599,15 @@ struct Pmc {
           hi = ln.lds_ld(LW_CAND((row - 3) / 3, 5)) * lam_n;
           lo = zero - hi;
         }
-        gs_turn<0>(ln, base, gt, inv, lo, hi, lam, dx);
-        gs_turn<1>(ln, base, gt, inv, lo, hi, lam, dx);
-        gs_turn<2>(ln, base, gt, inv, lo, hi, lam, dx);
-        gs_turn<3>(ln, base, gt, inv, lo, hi, lam, dx);
+        gs_turn<0>(ln, gr[0], inv, lo, hi, lam, w);
+        gs_turn<1>(ln, gr[1], inv, lo, hi, lam, w);
+        gs_turn<2>(ln, gr[2], inv, lo, hi, lam, w);
+        gs_turn<3>(ln, gr[3], inv, lo, hi, lam, w);
         if (rr == 0) lam_n = lam;
         ln.lds_st(LW_ROW(row, 11), lam);
         F dl = lam - lam0;
         for (int i = 0; i < 3; i++) dq[i] = dq[i] + jt[i] * dl;
+        for (int i = 0; i < 6; i++) dx[i] += L::qsum(gt[i] * dl);
       }
     }
     // back to velocities: d(xi) = Lb^-T dx ; d(qd) = Lm^-T (dq - Y^T d(xi))
@@ -598,7 +624,7 @@ struct Pmc {
     bs.w = mul(R, mk3<float>(xi[0], xi[1], xi[2]));
     bs.v = mul(R, mk3<float>(xi[3], xi[4], xi[5]));
     bs.p = bs.p + scale(bs.v, dt);
-    Q4 dqt = quat_of_rotvec(scale(bs.w, dt));
+    Q4 dqt = quat_of_small_rotvec(scale(bs.w, dt));
     bs.q = qnormalize(qmul(dqt, qnormalize(bs.q)));
     for (int j = 0; j < 3; j++) {
       qd[j] = qs[j];
@@ -606,15 +632,25 @@ struct Pmc {
     }
   }
 
-  // Gauss-Seidel turn of leg LEG on one row per lane: w = base + gt.dx ; lam <- clamp(lam - w/A) ; dx += gt * dlam (quad broadcast)
+  // Gauss-Seidel turn of leg LEG on the four rows (one per lane) of a row index: the lane whose turn it is commits
+  // lam <- clamp(lam - w/A); every lane then moves its residual by (gt . gt_LEG) * dlam_LEG (one quad broadcast).
   template <int LEG>
-  static LL_HD void gs_turn(const L& ln, const F& base, const F* gt, const F& inv, const F& lo, const F& hi, F& lam, float* dx) {
-    F w = base;
-    for (int i = 0; i < 6; i++) w = w + gt[i] * dx[i];
+  static LL_HD void gs_turn(const L& ln, const F& gram, const F& inv, const F& lo, const F& hi, F& lam, F& w) {
     F cand = lm::min_(lm::max_(lam - w * inv, lo), hi);
     F dl = lm::sel(ln.is_leg(LEG), cand - lam, ln.lane_f(0.0f));      // inv == 0 (row not in the solve) gives cand == lam
     lam = lam + dl;
-    for (int i = 0; i < 6; i++) dx[i] += L::template bcast<LEG>(gt[i] * dl);
+    w = w + gram * L::template bcast<LEG>(dl);
+  }
+  // gram[L] = gt . gt_L for the four lanes' rows of one row index
+  static LL_HD void store_gram(const L& ln, int word, const F* gt) {
+    F g0 = ln.lane_f(0.0f), g1 = g0, g2 = g0, g3 = g0;
+    for (int i = 0; i < 6; i++) {
+      g0 = g0 + gt[i] * L::template bcast<0>(gt[i]);
+      g1 = g1 + gt[i] * L::template bcast<1>(gt[i]);
+      g2 = g2 + gt[i] * L::template bcast<2>(gt[i]);
+      g3 = g3 + gt[i] * L::template bcast<3>(gt[i]);
+    }
+    ln.lds_st(word + 0, g0); ln.lds_st(word + 1, g1); ln.lds_st(word + 2, g2); ln.lds_st(word + 3, g3);
   }
 
   // ---------------------------------------------------------------------------------------------------

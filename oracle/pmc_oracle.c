@@ -587,12 +587,22 @@ typedef struct {
   int leg, slot;
 } OContact;
 
+/* A leg lane keeps the KC deepest of its candidates: free slots are taken in arrival order; once full a candidate
+ * replaces the shallowest stored contact (first one on ties) if it is deeper than it.  `first` = index in out[] of the lane's slot 0. */
 static int add_candidate(OContact* out, int n, int* nleg, int leg, int body, const double* P, double mu) {
-  if (P[2] < LLM_CONTACT_MARGIN && *nleg < KC) {
-    out[n].body = body; memcpy(out[n].P, P, 24); out[n].depth = P[2]; out[n].mu = mu; out[n].leg = leg; out[n].slot = *nleg;
-    (*nleg)++;
-    return n + 1;
+  if (!(P[2] < LLM_CONTACT_MARGIN)) return n;
+  int first = n - *nleg, slot;
+  if (*nleg < KC) {
+    slot = (*nleg)++;
+    n = n + 1;
+  } else {
+    slot = 0;
+    for (int k = 1; k < KC; k++)
+      if (out[first + k].depth > out[first + slot].depth) slot = k;
+    if (!(P[2] < out[first + slot].depth)) return n;
   }
+  OContact* c = &out[first + slot];
+  c->body = body; memcpy(c->P, P, 24); c->depth = P[2]; c->mu = mu; c->leg = leg; c->slot = slot;
   return n;
 }
 

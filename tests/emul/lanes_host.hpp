@@ -77,6 +77,7 @@ struct HostLanes {
   static float qsum(const F& x) { return (x.v[0] + x.v[1]) + (x.v[2] + x.v[3]); }   // same association as the DPP tree
   static bool qany(const B& m) { return m.v[0] || m.v[1] || m.v[2] || m.v[3]; }
   static bool any(const B& m) { return qany(m); }
+  void refresh_consts() const {}
   F legc(const float* tbl, int field) const { f4 r; for (int i = 0; i < 4; i++) r.v[i] = tbl[field * 4 + i]; return r; }
   F pick3(float x, float y, float z) const { f4 r; r.v[0] = x; r.v[1] = y; r.v[2] = z; r.v[3] = z; return r; }
   F ldl(const float* p, long base, long stride) const { f4 r; for (int i = 0; i < 4; i++) r.v[i] = p[base + stride * i]; return r; }

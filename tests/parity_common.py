@@ -133,3 +133,44 @@ def check_rollout_statistics(golden, orc, model_blob, table, lib_path, n_envs=24
     """Free-running (no resync) rollouts: chaotic contact dynamics diverge sample-wise, so compare distributions."""
     st = run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=False)
     return st
+
+
+def check_contact_rich_parity(golden, orc, model_blob, table, lib_path, n_envs=16, seed=3):
+    """Collapsed / rolled-over robots: every lane overflows its contact slots (deepest-K selection), joints sit on their
+    limits.  One control step from identical hand-made states, engine vs oracle."""
+    from scipy.spatial.transform import Rotation as R
+    rng = np.random.default_rng(seed)
+    clip, t0 = golden['g2_clip'][:n_envs], golden['g2_t0'][:n_envs]
+    E = make_engine(model_blob, table, n_envs, lib_path)
+    B = make_oracle_batch(orc, model_blob, table, n_envs=n_envs)
+    E.reset(clip=clip, t0=t0)
+    st = E.state().astype(np.float64)
+    for i in range(n_envs):
+        st[i, 2] = rng.uniform(0.05, 0.12)                                        # belly on (or in) the ground
+        st[i, 3:7] = (R.from_quat(st[i, 3:7]) * R.from_euler('xyz', [rng.uniform(-1.4, 1.4) if i % 2 else 0.0, rng.uniform(-0.3, 0.3), 0])).as_quat()
+        st[i, 7:13] = rng.normal(size=6) * 0.3
+        st[i, 13:25] = np.tile([0.0, -1.4, 2.5], 4) + rng.normal(size=12) * 0.15   # folded legs, shanks at their upper limit
+        st[i, 25:37] = rng.normal(size=12)
+    E.set_state(st)
+    st32 = E.state().astype(np.float64)
+    out = dict(config=[], vel=[])
+    act = (rng.normal(size=(n_envs, 12)) * SIGMA).astype(np.float32)
+    for i in range(n_envs):
+        B.reset_env(i, int(clip[i]), float(t0[i]))
+        B.set_state(i, st32[i])
+    E.step_host(act)
+    es = E.state().astype(np.float64)
+    for i in range(n_envs):
+        B.step_env(i, act[i].astype(np.float64))
+        os_ = B.get_state(i)
+        err = np.abs(quat_align(es[i], os_) - os_)
+        out['config'].append(max(err[0:7].max(), err[13:25].max()))
+        out['vel'].append(max(err[7:13].max(), err[25:37].max()) / (1.0 + np.abs(os_[25:37]).max()))
+    E.close()
+    out = {k: np.array(v) for k, v in out.items()}
+    assert np.isfinite(es).all()
+    # a penetrating start makes a stiff, many-contact solve: parity is looser than in free motion, but the two
+    # arithmetics must still tell the same story
+    assert np.median(out['config']) < 1e-4 and out['config'].max() < 5e-3, out['config']
+    assert np.median(out['vel']) < 1e-3 and out['vel'].max() < 5e-2, out['vel']
+    return out

@@ -57,3 +57,8 @@ def test_full_size_invariants(golden, model_blob, mocap_table):
     p, avg_r, avg_l = E.sampling_table()
     assert abs(p.sum() - 1.0) < 1e-9 and (p > 0).all()
     E.close()
+
+
+def test_contact_rich_parity(golden, orc, model_blob, mocap_table):
+    out = pc.check_contact_rich_parity(golden, orc, model_blob, mocap_table, None)
+    print('contact-rich: config err', np.percentile(out['config'], [50, 100]), 'vel', np.percentile(out['vel'], [50, 100]))

@@ -27,3 +27,8 @@ def test_reset_against_reference_goldens(golden, model_blob, mocap_table, emul_l
 def test_single_control_step_parity(golden, orc, model_blob, mocap_table, emul_lib):
     st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, emul_lib, n_envs=24, n_steps=10)
     print('config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
+
+
+def test_contact_rich_parity(golden, orc, model_blob, mocap_table, emul_lib):
+    out = pc.check_contact_rich_parity(golden, orc, model_blob, mocap_table, emul_lib)
+    print('contact-rich: config err', np.percentile(out['config'], [50, 100]), 'vel', np.percentile(out['vel'], [50, 100]))
