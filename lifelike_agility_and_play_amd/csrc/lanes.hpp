@@ -43,6 +43,13 @@ LL_HD bool and_(bool a, bool b) { return a && b; }
 LL_HD bool or_(bool a, bool b) { return a || b; }
 LL_HD bool not_(bool a) { return !a; }
 LL_HD float rint_(float x) { return rintf(x); }
+LL_HD float med3_(float x, float lo, float hi) {   // clamp for lo <= hi: one v_med3_f32 on the GPU
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fmed3f(x, lo, hi);
+#else
+  return fminf(fmaxf(x, lo), hi);
+#endif
+}
 LL_HD bool odd_(int k) { return (k & 1) != 0; }
 LL_HD bool bit1_(int k) { return (k & 2) != 0; }
 }  // namespace lm
@@ -87,6 +94,10 @@ struct GpuLanes {
   static LL_D float bcast(F x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), S | (S << 2) | (S << 4) | (S << 6), 0xf, 0xf, true));
   }
+  // acc += bcast<S>(x) * k as ONE instruction (VOP2 v_fmac_f32 with a DPP source).  x is usually produced by the
+  // instruction just before: a VALU write followed by a DPP read of the same VGPR needs 2 wait states (s_nop 1).
+  template <int S>
+  static LL_D void fmac_bcast(F& acc, F x, F k);
   static LL_D float bcast_rt(F x, int src) {   // runtime (wave-uniform) source leg
     return __shfl(x, (int)((threadIdx.x & 60) | src), 64);
   }
@@ -114,7 +125,26 @@ struct GpuLanes {
   LL_D F lds_ld(I w) const { return lds_[w * kWave + lane_]; }
   LL_D void lds_st(I w, F v) const { lds_[w * kWave + lane_] = v; }
   LL_D void lds_st_if(B m, I w, F v) const { if (m) lds_[w * kWave + lane_] = v; }
+  // 16-byte groups: group g of this lane at float offset (base_word * 64) + (g * 64 + lane) * 4   (ds_*_b128, conflict free)
+  LL_D void lds_ld4(int base_word, int g, F* out) const {
+    const float4 v = reinterpret_cast<const float4*>(lds_ + base_word * kWave)[g * kWave + lane_];
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+  }
+  LL_D void lds_st4(int base_word, int g, const F* in) const {
+    reinterpret_cast<float4*>(lds_ + base_word * kWave)[g * kWave + lane_] = make_float4(in[0], in[1], in[2], in[3]);
+  }
+  LL_D void lds_st1(int base_word, int g, int j, F v) const { lds_[base_word * kWave + (g * kWave + lane_) * 4 + j] = v; }
   static LL_D F i2f(I x) { return (float)x; }
   static LL_D I f2i(F x) { return (int)x; }
 };
+#define LL_FMAC_BCAST(S, PERM)                                                                                          \
+  template <>                                                                                                           \
+  LL_D void GpuLanes::fmac_bcast<S>(float& acc, float x, float k) {                                                     \
+    asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(k)); \
+  }
+LL_FMAC_BCAST(0, "[0,0,0,0]")
+LL_FMAC_BCAST(1, "[1,1,1,1]")
+LL_FMAC_BCAST(2, "[2,2,2,2]")
+LL_FMAC_BCAST(3, "[3,3,3,3]")
+#undef LL_FMAC_BCAST
 #endif  // __HIPCC__

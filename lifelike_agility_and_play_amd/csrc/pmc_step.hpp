@@ -28,7 +28,10 @@
 
 // LDS words per lane (see lanes.hpp lds_ld/lds_st)
 #define LW_CAND(s, f) ((s) * 6 + (f))                          // contact slot s: P(3) link depth mu
-#define LW_ROW(row, f) (PMC_K * 6 + (row) * 16 + (f))           // row record: gt(6) jt(3) c(=v0+bias) invA lambda gram(4)
+// constraint-row records live behind the slots as 16-byte groups (ds_read_b128 / ds_write_b128):
+//   group 0: gt0..3 | group 1: gt4 gt5 jt0 jt1 | group 2: jt2 c(=v0+bias) invA lambda | group 3: -k0..3 (Gram scalars * invA)
+#define LW_ROWBASE (PMC_K * 6)                                  // first word of the row region (per-lane word units)
+#define LQ_ROW(row, g) ((row) * 4 + (g))                        // 16-byte group index inside the row region
 #define LW_COUNT (PMC_K * 6 + (3 + 3 * PMC_K) * 16)
 
 #if defined(__HIPCC__)
@@ -502,6 +505,7 @@ struct Pmc {
     // --- constraint rows live in LDS as uniform records  [gt(6) jt(3) c inv lambda]:  rows 0..2 = this lane's joint limits,
     //     rows 3+3s+r = contact slot s, r = normal / t1 / t2.  inv = 0 marks a row that is not in the solve. ---------------------
     float inv_dt = 1.0f / dt;
+    bool lim_any[3] = {false, false, false};
     LL_NOUNROLL
     for (int j = 0; j < 3; j++) {
       F qj = (j == 0) ? q[0] : (j == 1 ? q[1] : q[2]);
@@ -517,14 +521,12 @@ struct Pmc {
       sv_to6(g6, gt);
       fwd6(Sb, Sd, gt);
       F nn = jt[0] * jt[0] + jt[1] * jt[1] + jt[2] * jt[2];
-      for (int i = 0; i < 6; i++) { nn = nn + gt[i] * gt[i]; ln.lds_st(LW_ROW(j, i), gt[i]); }
-      for (int i = 0; i < 3; i++) ln.lds_st(LW_ROW(j, 6 + i), jt[i]);
+      for (int i = 0; i < 6; i++) nn = nn + gt[i] * gt[i];
       F cj = sg * qsj + lm::sel(d > 0.0f, d * inv_dt, d * (P.erp * inv_dt));
       B lvalid = cj < P.limit_gate;              // rows that cannot act this substep stay out of the solve
-      ln.lds_st(LW_ROW(j, 9), cj);
-      ln.lds_st(LW_ROW(j, 10), lm::sel(lvalid, one / nn, zero));
-      ln.lds_st(LW_ROW(j, 11), zero);
-      store_gram(ln, LW_ROW(j, 12), gt);
+      F invj = lm::sel(lvalid, one / nn, zero);
+      store_row(ln, j, gt, jt, cj, invj);
+      lim_any[j] = L::any(lvalid);
     }
 
     // --- contact rows: n = +z, t1 = -y, t2 = +x (world), expressed in F0 ------------------------------------------------------
@@ -559,12 +561,9 @@ struct Pmc {
         fwd6(Sb, Sd, gt);
         F nn = jl[0] * jl[0] + jl[1] * jl[1] + jl[2] * jl[2];
         const int row = 3 + 3 * s + r;
-        for (int i = 0; i < 6; i++) { nn = nn + gt[i] * gt[i]; ln.lds_st(LW_ROW(row, i), gt[i]); }
-        for (int i = 0; i < 3; i++) ln.lds_st(LW_ROW(row, 6 + i), jl[i]);
-        ln.lds_st(LW_ROW(row, 9), (r == 0) ? vrow + bias : vrow);
-        ln.lds_st(LW_ROW(row, 10), lm::sel(valid, one / nn, zero));
-        ln.lds_st(LW_ROW(row, 11), zero);
-        store_gram(ln, LW_ROW(row, 12), gt);
+        for (int i = 0; i < 6; i++) nn = nn + gt[i] * gt[i];
+        F invr = lm::sel(valid, one / nn, zero);
+        store_row(ln, row, gt, jl, (r == 0) ? vrow + bias : vrow, invr);
       }
     }
 
@@ -576,38 +575,24 @@ struct Pmc {
     F dq[3] = {zero, zero, zero};          // private: sum jt * lambda
     const int n_rows = 3 + 3 * max_n;
     const F big = ln.lane_f(3.0e38f);
+    // One row index = one row per lane.  Per row: load the record (4 x ds_read_b128), form the unclamped increment u, let the
+    // four lanes take their turn (gs_turn), fold the committed increments into dx (quad sum) and dq.
     LL_NOUNROLL
     for (int it = 0; it < P.n_iter; it++) {
-      F lam_n = zero;
       LL_NOUNROLL
-      for (int row = 0; row < n_rows; row++) {
-        F inv = ln.lds_ld(LW_ROW(row, 10));
-        if (!L::any(inv > 0.0f)) continue;
-        F gt[6], jt[3], gr[4];
-        for (int i = 0; i < 6; i++) gt[i] = ln.lds_ld(LW_ROW(row, i));
-        for (int i = 0; i < 3; i++) jt[i] = ln.lds_ld(LW_ROW(row, 6 + i));
-        for (int i = 0; i < 4; i++) gr[i] = ln.lds_ld(LW_ROW(row, 12 + i));
-        // residual velocity of this lane's row for the current (dx, dq); kept up to date through the four turns with the
-        // Gram scalars gr[L] = gt . gt_L instead of being recomputed from dx after every commit
-        F w = ln.lds_ld(LW_ROW(row, 9)) + jt[0] * dq[0] + jt[1] * dq[1] + jt[2] * dq[2];
-        for (int i = 0; i < 6; i++) w = w + gt[i] * dx[i];
-        F lam0 = ln.lds_ld(LW_ROW(row, 11));
-        F lam = lam0;
-        const int rr = (row < 3) ? 0 : (row % 3);                  // 0: unilateral row, 1/2: friction rows of the same contact
-        F hi = big, lo = zero;
-        if (rr != 0) {
-          hi = ln.lds_ld(LW_CAND((row - 3) / 3, 5)) * lam_n;
-          lo = zero - hi;
-        }
-        gs_turn<0>(ln, gr[0], inv, lo, hi, lam, w);
-        gs_turn<1>(ln, gr[1], inv, lo, hi, lam, w);
-        gs_turn<2>(ln, gr[2], inv, lo, hi, lam, w);
-        gs_turn<3>(ln, gr[3], inv, lo, hi, lam, w);
-        if (rr == 0) lam_n = lam;
-        ln.lds_st(LW_ROW(row, 11), lam);
-        F dl = lam - lam0;
-        for (int i = 0; i < 3; i++) dq[i] = dq[i] + jt[i] * dl;
-        for (int i = 0; i < 6; i++) dx[i] += L::qsum(gt[i] * dl);
+      for (int j = 0; j < 3; j++) {
+        if (!lim_any[j]) continue;
+        RowRec rj = load_row(ln, j);
+        gs_row(ln, j, rj, zero, big, dx, dq);
+      }
+      LL_NOUNROLL
+      for (int s = 0; s < max_n; s++) {
+        RowRec rn = load_row(ln, 3 + 3 * s), r1 = load_row(ln, 4 + 3 * s), r2 = load_row(ln, 5 + 3 * s);
+        F mu = ln.lds_ld(LW_CAND(s, 5));
+        F lam_n = gs_row(ln, 3 + 3 * s, rn, zero, big, dx, dq);
+        F hi = mu * lam_n;
+        gs_row(ln, 4 + 3 * s, r1, zero - hi, hi, dx, dq);
+        gs_row(ln, 5 + 3 * s, r2, zero - hi, hi, dx, dq);
       }
     }
     // back to velocities: d(xi) = Lb^-T dx ; d(qd) = Lm^-T (dq - Y^T d(xi))
@@ -632,17 +617,23 @@ struct Pmc {
     }
   }
 
-  // Gauss-Seidel turn of leg LEG on the four rows (one per lane) of a row index: the lane whose turn it is commits
-  // lam <- clamp(lam - w/A); every lane then moves its residual by (gt . gt_LEG) * dlam_LEG (one quad broadcast).
-  template <int LEG>
-  static LL_HD void gs_turn(const L& ln, const F& gram, const F& inv, const F& lo, const F& hi, F& lam, F& w) {
-    F cand = lm::min_(lm::max_(lam - w * inv, lo), hi);
-    F dl = lm::sel(ln.is_leg(LEG), cand - lam, ln.lane_f(0.0f));      // inv == 0 (row not in the solve) gives cand == lam
-    lam = lam + dl;
-    w = w + gram * L::template bcast<LEG>(dl);
+  struct RowRec {
+    F gt[6], jt[3], c, inv, lam, nk[4];
+  };
+  static LL_HD RowRec load_row(const L& ln, int row) {
+    RowRec r;
+    F a[4], b[4], c[4];
+    ln.lds_ld4(LW_ROWBASE, LQ_ROW(row, 0), a);
+    ln.lds_ld4(LW_ROWBASE, LQ_ROW(row, 1), b);
+    ln.lds_ld4(LW_ROWBASE, LQ_ROW(row, 2), c);
+    ln.lds_ld4(LW_ROWBASE, LQ_ROW(row, 3), r.nk);
+    r.gt[0] = a[0]; r.gt[1] = a[1]; r.gt[2] = a[2]; r.gt[3] = a[3]; r.gt[4] = b[0]; r.gt[5] = b[1];
+    r.jt[0] = b[2]; r.jt[1] = b[3]; r.jt[2] = c[0];
+    r.c = c[1]; r.inv = c[2]; r.lam = c[3];
+    return r;
   }
-  // gram[L] = gt . gt_L for the four lanes' rows of one row index
-  static LL_HD void store_gram(const L& ln, int word, const F* gt) {
+  // row record with lambda = 0 and the negated Gram scalars -k[L] = -(gt . gt_L) * inv of the four lanes' rows
+  static LL_HD void store_row(const L& ln, int row, const F* gt, const F* jt, const F& c, const F& inv) {
     F g0 = ln.lane_f(0.0f), g1 = g0, g2 = g0, g3 = g0;
     for (int i = 0; i < 6; i++) {
       g0 = g0 + gt[i] * L::template bcast<0>(gt[i]);
@@ -650,9 +641,43 @@ struct Pmc {
       g2 = g2 + gt[i] * L::template bcast<2>(gt[i]);
       g3 = g3 + gt[i] * L::template bcast<3>(gt[i]);
     }
-    ln.lds_st(word + 0, g0); ln.lds_st(word + 1, g1); ln.lds_st(word + 2, g2); ln.lds_st(word + 3, g3);
+    F ninv = ln.lane_f(0.0f) - inv;
+    F a[4] = {gt[0], gt[1], gt[2], gt[3]}, b[4] = {gt[4], gt[5], jt[0], jt[1]}, cc[4] = {jt[2], c, inv, ln.lane_f(0.0f)};
+    F d[4] = {g0 * ninv, g1 * ninv, g2 * ninv, g3 * ninv};
+    ln.lds_st4(LW_ROWBASE, LQ_ROW(row, 0), a);
+    ln.lds_st4(LW_ROWBASE, LQ_ROW(row, 1), b);
+    ln.lds_st4(LW_ROWBASE, LQ_ROW(row, 2), cc);
+    ln.lds_st4(LW_ROWBASE, LQ_ROW(row, 3), d);
   }
-
+  // one Gauss-Seidel visit of a row index; returns this lane's new multiplier
+  static LL_HD F gs_row(const L& ln, int row, const RowRec& r, const F& lo, const F& hi, float* dx, F* dq) {
+    F zero = ln.lane_f(0.0f);
+    if (!L::any(r.inv > 0.0f)) return zero;
+    F cq = r.c + r.jt[0] * dq[0] + r.jt[1] * dq[1] + r.jt[2] * dq[2];
+    F s0 = r.gt[0] * dx[0] + r.gt[1] * dx[1], s1 = r.gt[2] * dx[2] + r.gt[3] * dx[3], s2 = r.gt[4] * dx[4] + r.gt[5] * dx[5];
+    // u = unclamped increment of this lane's multiplier; the admissible increment interval is [lo - lam, hi - lam]
+    F u = (zero - ((s0 + s1) + (s2 + cq))) * r.inv;
+    F lo_d = lo - r.lam, hi_d = hi - r.lam;
+    F dl = zero;
+    gs_turn<0>(ln, r.nk[0], lo_d, hi_d, dl, u);
+    gs_turn<1>(ln, r.nk[1], lo_d, hi_d, dl, u);
+    gs_turn<2>(ln, r.nk[2], lo_d, hi_d, dl, u);
+    gs_turn<3>(ln, r.nk[3], lo_d, hi_d, dl, u);
+    F lam = r.lam + dl;
+    ln.lds_st1(LW_ROWBASE, LQ_ROW(row, 2), 3, lam);
+    for (int i = 0; i < 3; i++) dq[i] = dq[i] + r.jt[i] * dl;
+    for (int i = 0; i < 6; i++) dx[i] += L::qsum(r.gt[i] * dl);
+    return lam;
+  }
+  // Gauss-Seidel turn of leg LEG on the four rows (one per lane) of a row index.  Every lane clamps its own increment
+  // (one v_med3); the quad broadcast picks lane LEG's, which then shifts every lane's pending increment by -nk[LEG] * d
+  // (one v_fmac with a DPP operand).  Two dependent instructions per turn.
+  template <int LEG>
+  static LL_HD void gs_turn(const L& ln, const F& nkL, const F& lo_d, const F& hi_d, F& dl, F& u) {
+    F d = lm::med3_(u, lo_d, hi_d);
+    dl = lm::sel(ln.is_leg(LEG), d, dl);
+    L::template fmac_bcast<LEG>(u, d, nkL);
+  }
   // ---------------------------------------------------------------------------------------------------
   // mocap reference (ML:65-166)
   // ---------------------------------------------------------------------------------------------------

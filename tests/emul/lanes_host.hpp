@@ -54,6 +54,7 @@ inline f4 sel(const b4& m, const f4& a, const f4& b) { f4 r; for (int i = 0; i <
 inline i4 sel(const b4& m, const i4& a, const i4& b) { i4 r; for (int i = 0; i < 4; i++) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
 inline b4 and_(const b4& a, const b4& b) { b4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] && b.v[i]; return r; }
 inline b4 or_(const b4& a, const b4& b) { b4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] || b.v[i]; return r; }
+inline f4 med3_(const f4& x, const f4& lo, const f4& hi) { f4 r; for (int i = 0; i < 4; i++) r.v[i] = fminf(fmaxf(x.v[i], lo.v[i]), hi.v[i]); return r; }
 inline f4 rint_(const f4& a) { f4 r; for (int i = 0; i < 4; i++) r.v[i] = rintf(a.v[i]); return r; }
 inline b4 odd_(const i4& k) { b4 r; for (int i = 0; i < 4; i++) r.v[i] = (k.v[i] & 1) != 0; return r; }
 inline b4 bit1_(const i4& k) { b4 r; for (int i = 0; i < 4; i++) r.v[i] = (k.v[i] & 2) != 0; return r; }
@@ -74,6 +75,7 @@ struct HostLanes {
   F lane_f(float x) const { return f4(x); }
   template <int S> static float bcast(const F& x) { return x.v[S]; }
   static float bcast_rt(const F& x, int s) { return x.v[s]; }
+  template <int S> static void fmac_bcast(F& acc, const F& x, const F& k) { for (int i = 0; i < 4; i++) acc.v[i] = acc.v[i] + x.v[S] * k.v[i]; }
   static float qsum(const F& x) { return (x.v[0] + x.v[1]) + (x.v[2] + x.v[3]); }   // same association as the DPP tree
   static bool qany(const B& m) { return m.v[0] || m.v[1] || m.v[2] || m.v[3]; }
   static bool any(const B& m) { return qany(m); }
@@ -88,6 +90,10 @@ struct HostLanes {
   F lds_ld(const I& w) const { f4 r; for (int i = 0; i < 4; i++) r.v[i] = (*lds_)[w.v[i] * 4 + i]; return r; }
   void lds_st(const I& w, const F& v) const { for (int i = 0; i < 4; i++) (*lds_)[w.v[i] * 4 + i] = v.v[i]; }
   void lds_st_if(const B& m, const I& w, const F& v) const { for (int i = 0; i < 4; i++) if (m.v[i]) (*lds_)[w.v[i] * 4 + i] = v.v[i]; }
+  // 16-byte groups behind `base_word` per-lane words (the host array is [word][4 lanes]; groups use the same storage)
+  void lds_ld4(int base_word, int g, F* out) const { for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) out[j].v[i] = (*lds_)[(base_word + g * 4 + j) * 4 + i]; }
+  void lds_st4(int base_word, int g, const F* in) const { for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) (*lds_)[(base_word + g * 4 + j) * 4 + i] = in[j].v[i]; }
+  void lds_st1(int base_word, int g, int j, const F& v) const { for (int i = 0; i < 4; i++) (*lds_)[(base_word + g * 4 + j) * 4 + i] = v.v[i]; }
   static F i2f(const I& x) { f4 r; for (int i = 0; i < 4; i++) r.v[i] = (float)x.v[i]; return r; }
   static I f2i(const F& x) { i4 r; for (int i = 0; i < 4; i++) r.v[i] = (int)x.v[i]; return r; }
 };
