@@ -401,10 +401,13 @@ struct Pmc {
     // --- base: S = I_base + sum I^c_leg - sum Y Y^T ; packed lower triangle, index order [wx wy wz vx vy vz] ----
     float Sb[21], Sd[6];
     {
-      float m = bc[BC_MASS] + L::qsum(Ic1.m);
-      float hx = bc[BC_H + 0] + L::qsum(Ic1.h.x), hy = bc[BC_H + 1] + L::qsum(Ic1.h.y), hz = bc[BC_H + 2] + L::qsum(Ic1.h.z);
-      float ixx = bc[BC_IO + 0] + L::qsum(Ic1.io.xx), ixy = bc[BC_IO + 1] + L::qsum(Ic1.io.xy), ixz = bc[BC_IO + 2] + L::qsum(Ic1.io.xz);
-      float iyy = bc[BC_IO + 3] + L::qsum(Ic1.io.yy), iyz = bc[BC_IO + 4] + L::qsum(Ic1.io.yz), izz = bc[BC_IO + 5] + L::qsum(Ic1.io.zz);
+      F cin[12] = {Ic1.m, Ic1.h.x, Ic1.h.y, Ic1.h.z, Ic1.io.xx, Ic1.io.xy, Ic1.io.xz, Ic1.io.yy, Ic1.io.yz, Ic1.io.zz, zero, zero};
+      float cs[12];
+      L::qsum6(cin, cs); L::qsum6(cin + 6, cs + 6);
+      float m = bc[BC_MASS] + cs[0];
+      float hx = bc[BC_H + 0] + cs[1], hy = bc[BC_H + 1] + cs[2], hz = bc[BC_H + 2] + cs[3];
+      float ixx = bc[BC_IO + 0] + cs[4], ixy = bc[BC_IO + 1] + cs[5], ixz = bc[BC_IO + 2] + cs[6];
+      float iyy = bc[BC_IO + 3] + cs[7], iyz = bc[BC_IO + 4] + cs[8], izz = bc[BC_IO + 5] + cs[9];
       // [[Io, hx],[-hx, m]] with hx = skew(h): rows 3..5 x cols 0..2 hold -skew(h) = [[0,hz,-hy],[-hz,0,hx],[hy,-hx,0]]
       Sb[0] = ixx;
       Sb[1] = ixy; Sb[2] = iyy;
@@ -414,8 +417,13 @@ struct Pmc {
       Sb[15] = hy; Sb[16] = -hx; Sb[17] = 0.0f; Sb[18] = 0.0f; Sb[19] = 0.0f; Sb[20] = m;
       F y1[6], y2[6], y3[6];
       sv_to6(lf.y1, y1); sv_to6(lf.y2, y2); sv_to6(lf.y3, y3);
+      F yy[24];
+      float ys[24];
       for (int i = 0; i < 6; i++)
-        for (int j = 0; j <= i; j++) Sb[i * (i + 1) / 2 + j] -= L::qsum(y1[i] * y1[j] + y2[i] * y2[j] + y3[i] * y3[j]);
+        for (int j = 0; j <= i; j++) yy[i * (i + 1) / 2 + j] = y1[i] * y1[j] + y2[i] * y2[j] + y3[i] * y3[j];
+      yy[21] = yy[22] = yy[23] = zero;
+      L::qsum6(yy, ys); L::qsum6(yy + 6, ys + 6); L::qsum6(yy + 12, ys + 12); L::qsum6(yy + 18, ys + 18);
+      for (int i = 0; i < 21; i++) Sb[i] -= ys[i];
       chol6(Sb, Sd);
     }
 
@@ -432,8 +440,11 @@ struct Pmc {
       ic0.xx = bc[BC_ICOM]; ic0.xy = bc[BC_ICOM + 1]; ic0.xz = bc[BC_ICOM + 2]; ic0.yy = bc[BC_ICOM + 3]; ic0.yz = bc[BC_ICOM + 4]; ic0.zz = bc[BC_ICOM + 5];
       V3u com0 = mk3<float>(bc[BC_COM], bc[BC_COM + 1], bc[BC_COM + 2]);
       SV<float> f0 = crf(v0, apply(I0, v0)) + scale(damping_force<float>(v0, com0, ic0, I0.m, P.link_damping), -1.0f);
-      xb[0] = -(f0.a.x + L::qsum(f123.a.x + z.a.x)); xb[1] = -(f0.a.y + L::qsum(f123.a.y + z.a.y)); xb[2] = -(f0.a.z + L::qsum(f123.a.z + z.a.z));
-      xb[3] = -(f0.l.x + L::qsum(f123.l.x + z.l.x)); xb[4] = -(f0.l.y + L::qsum(f123.l.y + z.l.y)); xb[5] = -(f0.l.z + L::qsum(f123.l.z + z.l.z));
+      F fz[6] = {f123.a.x + z.a.x, f123.a.y + z.a.y, f123.a.z + z.a.z, f123.l.x + z.l.x, f123.l.y + z.l.y, f123.l.z + z.l.z};
+      float fs[6];
+      L::qsum6(fz, fs);
+      xb[0] = -(f0.a.x + fs[0]); xb[1] = -(f0.a.y + fs[1]); xb[2] = -(f0.a.z + fs[2]);
+      xb[3] = -(f0.l.x + fs[3]); xb[4] = -(f0.l.y + fs[4]); xb[5] = -(f0.l.z + fs[5]);
       fwd6(Sb, Sd, xb);
       bwd6(Sb, Sd, xb);
     }
@@ -666,7 +677,11 @@ struct Pmc {
     F lam = r.lam + dl;
     ln.lds_st1(LW_ROWBASE, LQ_ROW(row, 2), 3, lam);
     for (int i = 0; i < 3; i++) dq[i] = dq[i] + r.jt[i] * dl;
-    for (int i = 0; i < 6; i++) dx[i] += L::qsum(r.gt[i] * dl);
+    F prod[6];
+    float red[6];
+    for (int i = 0; i < 6; i++) prod[i] = r.gt[i] * dl;
+    L::qsum6(prod, red);
+    for (int i = 0; i < 6; i++) dx[i] += red[i];
     return lam;
   }
   // Gauss-Seidel turn of leg LEG on the four rows (one per lane) of a row index.  Every lane clamps its own increment

@@ -77,6 +77,7 @@ struct HostLanes {
   static float bcast_rt(const F& x, int s) { return x.v[s]; }
   template <int S> static void fmac_bcast(F& acc, const F& x, const F& k) { for (int i = 0; i < 4; i++) acc.v[i] = acc.v[i] + x.v[S] * k.v[i]; }
   static float qsum(const F& x) { return (x.v[0] + x.v[1]) + (x.v[2] + x.v[3]); }   // same association as the DPP tree
+  static void qsum6(const F* x, float* out) { for (int i = 0; i < 6; i++) out[i] = qsum(x[i]); }
   static bool qany(const B& m) { return m.v[0] || m.v[1] || m.v[2] || m.v[3]; }
   static bool any(const B& m) { return qany(m); }
   void refresh_consts() const {}
