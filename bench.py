@@ -133,6 +133,13 @@ def main():
         total_env_steps = world * n * args.steps
         value = total_env_steps / elapsed
         achieved = (n * ALGO_BYTES_PER_ENV_STEP) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+        traffic = None                       # PMC counters cannot be read from inside this process: the value comes from
+        tj = os.path.join(ROOT, 'profiles', 'traffic.json')   # the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if os.path.exists(tj) and n == ENVS_PER_GPU:
+            try:
+                traffic = json.load(open(tj))['traffic_bytes']
+            except Exception:                # noqa: BLE001
+                traffic = None
         out = {
             'metric': 'env-steps/sec (whole node), PMC tracking env, random policy',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -143,10 +150,11 @@ def main():
                        'envs_per_gpu': n, 'substeps_per_step': 10, 'solver_iterations': 10,
                        'episodes_finished_rank0': counters['episodes'], 'nonfinite_resets_rank0': counters['nonfinite']},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': (achieved / HBM_PEAK_GBPS) if achieved else None, 'traffic': None,
+                         'frac': (achieved / HBM_PEAK_GBPS) if achieved else None, 'traffic': traffic,
+                         'traffic_source': 'profiles/traffic.json (bytes per launch, FETCH_SIZE + WRITE_SIZE, uncorrected; see DESIGN.md 5.1)',
                          'kernel': 'pmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
                          'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP,
-                         'note': 'latency/VALU-bound by construction (~4e5 flop per env-step vs 2.5 KB); see DESIGN.md'},
+                         'note': 'bound by single-wave instruction issue, not HBM (about 1.5e5 instructions per wave per step vs 2.5 KB per env); see DESIGN.md 5.1'},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(blob, table)
