@@ -1,0 +1,30 @@
+"""NumPy forward pass of the reference's trained PMC policy (networks/legged_robot/pmc_net/pmc_net.py:117-178, :99-114):
+running-mean/std normalisation clipped to +-5, VQ encoder 207->256->256->32, nearest code of a (32, 256) codebook,
+low-level controller  [relu(prop 135->64) | relu(z 32->32)] -> 256 -> 256 -> 12  (mean action).
+
+Not part of the hot path: it exists for the trained-policy sanity run that validates the simulator's physics
+ and as the natural next fusion target (policy inference on device)."""
+import numpy as np
+
+
+class PmcPolicy(object):
+    def __init__(self, npz_path):
+        z = np.load(npz_path)
+        self.w = [z['w%02d' % i].astype(np.float64) for i in range(28)]
+
+    def act(self, obs):
+        """obs: [N, 207] = prop 99 | prop_a 36 | future 72  ->  mean action [N, 12]"""
+        w = self.w
+        relu = lambda x: np.maximum(x, 0.0)
+        prop, future = obs[:, :135], obs[:, 135:]                       # pmc_net.py:123-127 (append_hist_a)
+        prop_rms = np.clip((prop - w[0]) / (w[1] + 1e-8), -5.0, 5.0)     # layers.py:55 + pmc_net.py:131-135
+        future_rms = np.clip((future - w[2]) / (w[3] + 1e-8), -5.0, 5.0)
+        ob = np.concatenate([prop_rms, future_rms], axis=1)
+        h = relu(relu(ob @ w[10] + w[11]) @ w[12] + w[13])
+        ze = h @ w[14] + w[15]                                           # vq_encoder pmc_net.py:41-46
+        cb = w[16]                                                       # (32, 256)
+        dist = (ze ** 2).sum(1, keepdims=True) - 2 * ze @ cb + (cb ** 2).sum(0, keepdims=True)   # pmc_net.py:155-157
+        q = cb.T[np.argmax(-dist, 1)]
+        s = np.concatenate([relu(prop_rms @ w[17] + w[18]), relu(q @ w[19] + w[20])], axis=1)     # llc pmc_net.py:99-108
+        h = relu(relu(s @ w[21] + w[22]) @ w[23] + w[24])
+        return h @ w[25] + w[26]                                         # decoder mean

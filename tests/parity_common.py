@@ -174,3 +174,36 @@ def check_contact_rich_parity(golden, orc, model_blob, table, lib_path, n_envs=1
     assert np.median(out['config']) < 1e-4 and out['config'].max() < 5e-3, out['config']
     assert np.median(out['vel']) < 1e-3 and out['vel'].max() < 5e-2, out['vel']
     return out
+
+
+def check_trained_policy_tracks(lib_path, n_envs=16, n_steps=200, seed=7):
+    """SURVEY.md 8f-3, the strongest available check on the UNPINNED physics: the reference's PMC policy
+    (data/models/primitive_level.model, trained against PyBullet; weights extracted by tools/extract_policy.py into
+    tests/golden/pmc_policy.npz) drives our simulator closed-loop.  If our contact/articulated dynamics were not
+    Bullet-like the policy would fall within a second; instead it tracks walk / run / jump / idle clips to the end."""
+    import os
+    import lifelike_agility_and_play_amd as lla
+    from conftest import GOLDEN_DIR
+    from lifelike_agility_and_play_amd.pmc_policy import PmcPolicy
+    pol = PmcPolicy(os.path.join(GOLDEN_DIR, 'pmc_policy.npz'))
+    env = lla.create_tracking_game(arena_id='LeggedRobotTracking', data_path='', control_freq=50.0, prop_type=list(PMC_PROP_TYPE),
+                                   prioritized_sample_factor=3.0, kp=50.0, kd=0.5, max_tau=18, reward_weights=dict(PMC_REWARD_WEIGHTS),
+                                   num_envs=n_envs, seed=seed, auto_reset=False, lib_path=lib_path)
+    obs = env.reset()
+    alive = np.ones(n_envs, bool)
+    steps, rsum, why = np.zeros(n_envs, int), np.zeros(n_envs), np.zeros(n_envs, int)
+    for t in range(n_steps):
+        obs, r, d, info = env.step(pol.act(obs.astype(np.float64)))
+        rsum += np.where(alive, r, 0.0)
+        steps += alive
+        newly = alive & d
+        why[newly] = info['done_reason'][newly]
+        alive &= ~d
+        if not alive.any():
+            break
+    env.close()
+    ok = alive | (why == capi.DONE_CLIP_END)              # still tracking at the horizon, or reached the end of the clip
+    mean_r = rsum.sum() / steps.sum()
+    assert ok.mean() >= 0.75, (ok, why)
+    assert mean_r > 0.7, mean_r
+    return dict(mean_reward=mean_r, tracked=ok.mean(), steps=steps, why=why)

@@ -62,3 +62,8 @@ def test_full_size_invariants(golden, model_blob, mocap_table):
 def test_contact_rich_parity(golden, orc, model_blob, mocap_table):
     out = pc.check_contact_rich_parity(golden, orc, model_blob, mocap_table, None)
     print('contact-rich: config err', np.percentile(out['config'], [50, 100]), 'vel', np.percentile(out['vel'], [50, 100]))
+
+
+def test_trained_reference_policy_tracks_in_our_simulator():
+    out = pc.check_trained_policy_tracks(None, n_envs=256, n_steps=300)
+    print('trained PMC policy on GPU: mean reward/step %.3f, tracked %.0f%%' % (out['mean_reward'], 100 * out['tracked']))

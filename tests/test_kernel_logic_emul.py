@@ -32,3 +32,8 @@ def test_single_control_step_parity(golden, orc, model_blob, mocap_table, emul_l
 def test_contact_rich_parity(golden, orc, model_blob, mocap_table, emul_lib):
     out = pc.check_contact_rich_parity(golden, orc, model_blob, mocap_table, emul_lib)
     print('contact-rich: config err', np.percentile(out['config'], [50, 100]), 'vel', np.percentile(out['vel'], [50, 100]))
+
+
+def test_trained_reference_policy_tracks_in_our_simulator(emul_lib):
+    out = pc.check_trained_policy_tracks(emul_lib)
+    print('trained PMC policy: mean reward/step %.3f, tracked %.0f%%' % (out['mean_reward'], 100 * out['tracked']))
