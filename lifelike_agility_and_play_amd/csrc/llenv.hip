@@ -1,7 +1,7 @@
 // llenv.hip -- the product: HIP kernels for gfx950 + the C ABI of include/llenv.h.
 //
-//   pmc_step_kernel     one 50 Hz control step of every env, fully fused (pmc_step.hpp); 1 env = 4 lanes,
-//                       64-thread workgroups (one wavefront, 16 envs), contact rows staged in LDS
+//   pmc_step_kernel     one 50 Hz control step of every env, fully fused (pmc_step.hpp); 1 env = one 16-lane DPP row,
+//                       64-thread workgroups (one wavefront, 4 envs), constraint rows in registers, LDS only for constants
 //   pmc_reset_kernel    PLE:150-171 for a list of envs
 //   pmc_table_kernel    folds finished-episode statistics into the prioritized sampling table (PLE:235-240)
 //   pmc_actions_kernel  draws the synthetic random-policy actions (Philox + Box-Muller)
@@ -25,29 +25,25 @@
 
 typedef Pmc<GpuLanes> K;
 
-__global__ __launch_bounds__(PMC_WAVE) void pmc_step_kernel(StepParams P) {
+__global__ __launch_bounds__(PMC_WAVE, 2) void pmc_step_kernel(StepParams P) {   // <= 256 registers: two waves per SIMD
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  // envs_per_wave < 16 leaves lanes idle on purpose: at 4096 envs there are more SIMDs (1024) than 16-env waves (256),
-  // and the solver's wave-uniform work is the union over the envs of a wave, so fewer envs per wave = shorter kernel.
-  const int quad = threadIdx.x >> 2;
-  const int env = blockIdx.x * P.envs_per_wave + quad;
+  const int env = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);      // one env = one 16-lane DPP row
   GpuLanes ln(lds);
-  ln.stage_consts(P.legc, LC_COUNT, LW_COUNT);          // all 64 lanes copy, also those without an env
-  if (quad >= P.envs_per_wave || env >= P.n_envs) return;
-  K::clear_scratch(ln);
+  ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);           // all 64 lanes copy, also those without an env
+  if (env >= P.n_envs) return;
   K::step_env(ln, P, env);
 }
 
 __global__ __launch_bounds__(PMC_WAVE) void pmc_reset_kernel(StepParams P, const int32_t* ids, int n, const int32_t* clip, const double* t0) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int i = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 2);
+  const int i = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
   GpuLanes ln(lds);
-  ln.stage_consts(P.legc, LC_COUNT, 0);
+  ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
   if (i >= n) return;
   const int env = ids ? ids[i] : i;
   int c;
   double t;
-  uint32_t ep = P.ep_count[env] + 1;          // the four lanes of the quad read, then write, the same value
+  uint32_t ep = P.ep_count[env] + 1;          // the sixteen lanes of the row read, then write, the same value
   K::sample_start(P, env, ep, &c, &t);         // ML:59-63, ML:50-51
   P.ep_count[env] = ep;
   if (clip) c = clip[i];
@@ -129,12 +125,6 @@ struct HipBackend {
     HIPCHK(hipSetDevice(dev));
     HIPCHK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
     stream = own;
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, dev));
-    n_simd = prop.multiProcessorCount * 4;
-    // the solver's row records need more than the default 64 KB of dynamic LDS per workgroup (gfx950 has 160 KB per CU)
-    HIPCHK(hipFuncSetAttribute((const void*)pmc_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes()));
-    if (const char* e = getenv("LL_ENVS_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= PMC_ENVS_PER_WAVE) epw_override = v; }
   }
   ~HipBackend() {
     (void)hipSetDevice(device);
@@ -164,19 +154,10 @@ struct HipBackend {
   }
   void sync() { use(); HIPCHK(hipStreamSynchronize(stream)); }
 
-  static size_t lds_bytes() { return ((size_t)LW_COUNT * PMC_WAVE + (size_t)LC_COUNT * 4) * sizeof(float); }
-  static size_t reset_lds_bytes() { return (size_t)LC_COUNT * 4 * sizeof(float); }
-  int epw_override = 0, n_simd = 1024;
-  int envs_per_wave(int) const {
-    // measured on MI355X (profiles/r01_sweep.txt): a wave costs the same whether it carries 1 or 16 envs (the solver's
-    // instruction stream is wave-uniform), so full waves always win; the override exists for experiments only
-    return epw_override > 0 ? epw_override : PMC_ENVS_PER_WAVE;
-  }
-  void launch_step(const StepParams& Pin) {
+  static size_t lds_bytes() { return ((size_t)LC_COUNT * 4 + (size_t)CAND_TABLE_WORDS * PMC_ROW) * sizeof(float); }
+  void launch_step(const StepParams& P) {
     use();
-    StepParams P = Pin;
-    P.envs_per_wave = envs_per_wave(P.n_envs);
-    const int blocks = (P.n_envs + P.envs_per_wave - 1) / P.envs_per_wave;
+    const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (timing) {
       if (ev_used == evs.size()) {
@@ -195,7 +176,7 @@ struct HipBackend {
   void launch_reset(const StepParams& P, const int32_t* ids, int n, const int32_t* clip, const double* t0) {
     use();
     const int blocks = (n + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
-    hipLaunchKernelGGL(pmc_reset_kernel, dim3(blocks), dim3(PMC_WAVE), reset_lds_bytes(), stream, P, ids, n, clip, t0);   // constants only, no solver scratch
+    hipLaunchKernelGGL(pmc_reset_kernel, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P, ids, n, clip, t0);
     HIPCHK(hipGetLastError());
   }
   void launch_prestep(const StepParams& P, double* avg_r, double* avg_l, double* prob, double* cdf, float* actions, float sigma) {

@@ -51,6 +51,12 @@ struct PmcEngine {
     bk.h2d(lc, legc.data(), legc.size() * 4);
     bk.h2d(bc, basec.data(), basec.size() * 4);
     P.legc = lc; P.basec = bc;
+    std::vector<float> candc;
+    e = pmc_build_cand_table(blob, candc);
+    if (!e.empty()) throw PmcError(LL_EINVAL, e);
+    float* cc = dalloc<float>(candc.size());
+    bk.h2d(cc, candc.data(), candc.size() * 4);
+    P.candc = cc;
     P.state = dalloc<float>(37 * N); P.kin = dalloc<float>(37 * N); P.feet = dalloc<float>(24 * N);
     P.time = dalloc<double>(N); P.clip = dalloc<int32_t>(N); P.ep_steps = dalloc<int32_t>(N);
     P.reward_sum = dalloc<float>(N); P.ep_count = dalloc<uint32_t>(N);

@@ -4,7 +4,7 @@
 
 #define PMC_K 4            // contact slots per leg lane (== LLM_MAX_CONTACTS_PER_LEG)
 #define PMC_WAVE 64
-#define PMC_ENVS_PER_WAVE 16
+#define PMC_ENVS_PER_WAVE 4     // one env = one 16-lane DPP row
 
 // ---- per-leg constant table: legc[field * 4 + leg] ---------------------------------------------------
 enum LegConst {
@@ -31,6 +31,13 @@ enum LegConst {
   LC_FOOTSPH = 126,   // 4  foot sphere on the shank link: c(3) r
   LC_COUNT = 130
 };
+
+// ---- contact candidate table: candc[(jj * CF_WORDS + field) * 16 + leg * 4 + sub], 7 candidates per (leg, sub) --------------
+//   a candidate is a point of a link:  P = A - r * n(ez_link),  n = unit(ez - (ez.ax) ax)  (fb if degenerate)
+//   sphere: A = centre, ax = 0;  box vertex: A = vertex, r = 0;  cylinder cap: A = cap centre, ax = axis
+enum CandField { CF_A = 0, CF_AX = 3, CF_FB = 6, CF_R = 9, CF_LINK = 10, CF_KIND = 11, CF_WORDS = 12 };
+#define CAND_PER_SUB 7
+#define CAND_TABLE_WORDS (CAND_PER_SUB * CF_WORDS)
 
 // ---- base constant table (quad-uniform) ----------------------------------------------------------------
 enum BaseConst {
@@ -85,5 +92,6 @@ struct StepParams {
   unsigned long long* counters;        // [4] env-steps, episodes, non-finite resets, -
   // constants
   const float* legc;        // [LC_COUNT][4]
+  const float* candc;       // [CAND_TABLE_WORDS][16]
   const float* basec;       // [BC_COUNT]
 };

@@ -26,20 +26,6 @@
 #define LLS_DONE_DIVERGED 4
 #define LLS_DONE_NONFINITE 16
 
-// LDS words per lane (see lanes.hpp lds_ld/lds_st)
-#define LW_CAND(s, f) ((s) * 6 + (f))                          // contact slot s: P(3) link depth mu
-// constraint-row records live behind the slots as 16-byte groups (ds_read_b128 / ds_write_b128):
-//   group 0: gt0..3 | group 1: gt4 gt5 jt0 jt1 | group 2: jt2 c(=v0+bias) invA lambda | group 3: -k0..3 (Gram scalars * invA)
-#define LW_ROWBASE (PMC_K * 6)                                  // first word of the row region (per-lane word units)
-#define LQ_ROW(row, g) ((row) * 4 + (g))                        // 16-byte group index inside the row region
-#define LW_COUNT (PMC_K * 6 + (3 + 3 * PMC_K) * 16)
-
-#if defined(__HIPCC__)
-#define LL_NOUNROLL _Pragma("nounroll")
-#else
-#define LL_NOUNROLL _Pragma("GCC unroll 1")
-#endif
-
 // PLE:235-240 for the batch: fold the statistics published by finished episodes into the per-clip table and rebuild
 // the sampling distribution  p ~ (1 - avg_reward_sum)^factor  (stored as an inclusive CDF).  Run by ONE thread
 // between control steps (pre-step kernel), so every env of a step samples from the same table.
@@ -236,95 +222,76 @@ struct Pmc {
   static LL_HD void sv_to6(const SV<F>& v, F* o) { o[0] = v.a.x; o[1] = v.a.y; o[2] = v.a.z; o[3] = v.l.x; o[4] = v.l.y; o[5] = v.l.z; }
 
   // ---------------------------------------------------------------------------------------------------
-  // contact candidates (DESIGN.md "contact candidates"): fixed priority order per lane, first PMC_K within margin
+  // constraint rows: one per lane and round (limit row of joint `sub`, normal / t1 / t2 row of contact slot `sub`),
+  // held in registers in whitened coordinates together with the Gram scalars against the 16 rows of the same round
   // ---------------------------------------------------------------------------------------------------
-  struct CandCtx {
-    I n;            // contacts stored so far on this lane
-    float pz;       // world height of the F0 origin
-    V3u ezb;        // world up in F0 coordinates
-    float margin;
+  struct Row {
+    F gt[6], jt[3], c, inv, lam;
+    F nk[16];      // -(gt . gt_L + [same leg] jt . jt_L) * inv   for L = lane of the env row
   };
-  static LL_HD void cand_push(const L& ln, CandCtx& cc, B pass, const V3l& Pb, F depth, float link, F mu) {
-    // DESIGN.md "contact candidates": a lane keeps the PMC_K DEEPEST of its candidates.  While slots are free a candidate
-    // takes the next one; once full it replaces the shallowest stored contact if it is deeper than that one.
-    B room = cc.n < PMC_K;
-    I slot = cc.n;
-    B full = lm::and_(pass, lm::not_(room));
-    B ok = lm::and_(pass, room);
-    if (L::any(full)) {
-      F worst = ln.lds_ld(LW_CAND(0, 4));
-      I wslot = L::f2i(ln.lane_f(0.0f));
-      for (int s2 = 1; s2 < PMC_K; s2++) {
-        F d2 = ln.lds_ld(LW_CAND(s2, 4));
-        B shallower = d2 > worst;
-        worst = lm::sel(shallower, d2, worst);
-        wslot = lm::sel(shallower, wslot * 0 + s2, wslot);
-      }
-      B repl = lm::and_(full, depth < worst);
-      slot = lm::sel(repl, wslot, slot);
-      ok = lm::or_(ok, repl);
-    }
-    if (L::any(ok)) {
-      I w = slot * 6;
-      ln.lds_st_if(ok, w + 0, Pb.x); ln.lds_st_if(ok, w + 1, Pb.y); ln.lds_st_if(ok, w + 2, Pb.z);
-      ln.lds_st_if(ok, w + 3, ln.lane_f(link)); ln.lds_st_if(ok, w + 4, depth); ln.lds_st_if(ok, w + 5, mu);
-      cc.n = lm::sel(lm::and_(ok, room), cc.n + 1, cc.n);
-    }
+  template <int L_>
+  static LL_HD void gram_one(const L& ln, Row& r, const F* nj) {
+    F g = ln.lane_f(0.0f);
+    for (int i = 0; i < 6; i++) L::template fmac_rbcast<L_>(g, r.gt[i], r.gt[i]);
+    g = g + lm::sel(ln.is_leg(L_ >> 2), nj[L_ & 3], ln.lane_f(0.0f));
+    r.nk[L_] = g * (ln.lane_f(0.0f) - r.inv);
   }
-  // a link-attached point x (link frame): world height = z0 + ezk.x ; F0 position = p + R x
-  static LL_HD void cand_sphere(const L& ln, CandCtx& cc, const M3<F>& R, const V3l& p, F z0, const V3l& ezk, const V3l& c, F r,
-                                float link, F mu) {
-    F depth = z0 + dot(ezk, c) - r;
-    B pass = depth < cc.margin;
-    if (L::any(pass)) {
-      V3l Pb = p + mul(R, c) - scale(cvt3<F>(cc.ezb), r);
-      cand_push(ln, cc, pass, Pb, depth, link, mu);
-    }
+  static LL_HD void finish_row(const L& ln, Row& r) {
+    F nj[4];
+    nj[0] = r.jt[0] * L::template subbcast<0>(r.jt[0]) + r.jt[1] * L::template subbcast<0>(r.jt[1]) + r.jt[2] * L::template subbcast<0>(r.jt[2]);
+    nj[1] = r.jt[0] * L::template subbcast<1>(r.jt[0]) + r.jt[1] * L::template subbcast<1>(r.jt[1]) + r.jt[2] * L::template subbcast<1>(r.jt[2]);
+    nj[2] = r.jt[0] * L::template subbcast<2>(r.jt[0]) + r.jt[1] * L::template subbcast<2>(r.jt[1]) + r.jt[2] * L::template subbcast<2>(r.jt[2]);
+    nj[3] = r.jt[0] * L::template subbcast<3>(r.jt[0]) + r.jt[1] * L::template subbcast<3>(r.jt[1]) + r.jt[2] * L::template subbcast<3>(r.jt[2]);
+    gram_one<0>(ln, r, nj); gram_one<1>(ln, r, nj); gram_one<2>(ln, r, nj); gram_one<3>(ln, r, nj);
+    gram_one<4>(ln, r, nj); gram_one<5>(ln, r, nj); gram_one<6>(ln, r, nj); gram_one<7>(ln, r, nj);
+    gram_one<8>(ln, r, nj); gram_one<9>(ln, r, nj); gram_one<10>(ln, r, nj); gram_one<11>(ln, r, nj);
+    gram_one<12>(ln, r, nj); gram_one<13>(ln, r, nj); gram_one<14>(ln, r, nj); gram_one<15>(ln, r, nj);
+    r.lam = ln.lane_f(0.0f);
   }
-  static LL_HD void cand_box_vertex(const L& ln, CandCtx& cc, const M3<F>& R, const V3l& p, F zc, F za, F zb, F zcc, const V3l& c,
-                                    const V3l& ua, const V3l& ub, const V3l& uc, F sa, F sb, F sc, float link, F mu) {
-    F depth = zc + sa * za + sb * zb + sc * zcc;
-    B pass = depth < cc.margin;
-    if (L::any(pass)) {
-      V3l x = c + scale(ua, sa) + scale(ub, sb) + scale(uc, sc);
-      cand_push(ln, cc, pass, p + mul(R, x), depth, link, mu);
-    }
+  template <int K_>
+  static LL_HD void pick_rank(const L& ln, const F& rank, const F& me, const F& d, const F& sb, const F& jj, F& nd, F& ns, F& nj) {
+    B take = lm::abs_(L::template subbcast<K_>(rank) - me) < 0.5f;
+    nd = lm::sel(take, L::template subbcast<K_>(d), nd);
+    ns = lm::sel(take, L::template subbcast<K_>(sb), ns);
+    nj = lm::sel(take, L::template subbcast<K_>(jj), nj);
   }
-  static LL_HD void cand_box(const L& ln, CandCtx& cc, const float* legc, int f, const M3<F>& R, const V3l& p, F z0, const V3l& ezk,
-                             float link, F mu) {
-    V3l c = ld3c(ln, legc, f), ua = ld3c(ln, legc, f + 3), ub = ld3c(ln, legc, f + 6), uc = ld3c(ln, legc, f + 9);
-    F zc = z0 + dot(ezk, c), za = dot(ezk, ua), zb = dot(ezk, ub), zcc = dot(ezk, uc);
-    F lo = zc - lm::abs_(za) - lm::abs_(zb) - lm::abs_(zcc);
-    if (!L::any(lo < cc.margin)) return;
-    LL_NOUNROLL
-    for (int j = 0; j < 8; j++) {
-      F sa = ln.lane_f((j & 1) ? 1.0f : -1.0f), sb = ln.lane_f((j & 2) ? 1.0f : -1.0f), sc = ln.lane_f((j & 4) ? 1.0f : -1.0f);
-      cand_box_vertex(ln, cc, R, p, zc, za, zb, zcc, c, ua, ub, uc, sa, sb, sc, link, mu);
-    }
+  // Gauss-Seidel turn of lane L_: every lane clamps its own pending increment (one v_med3); the row broadcast picks lane
+  // L_'s, which shifts every lane's pending increment by nk[L_] * d (one v_fmac with a DPP operand).
+  template <int L_>
+  static LL_HD void gs_turn(const L& ln, const Row& r, const F& lo_d, const F& hi_d, F& dl, F& u) {
+    F d = lm::med3_(u, lo_d, hi_d);
+    dl = lm::sel(ln.is_lane(L_), d, dl);
+    L::template fmac_rbcast<L_>(u, d, r.nk[L_]);
   }
-  static LL_HD void cand_cyl(const L& ln, CandCtx& cc, const float* legc, int f, const M3<F>& R, const V3l& p, F z0, const V3l& ezk,
-                             float link, F mu) {
-    V3l c = ld3c(ln, legc, f), ax = ld3c(ln, legc, f + 3), fb = ld3c(ln, legc, f + 6);
-    F r = ln.legc(legc, f + 9), h = ln.legc(legc, f + 10);
-    F az = dot(ezk, ax);                        // cos(angle between the cylinder axis and world up)
-    F len2 = lm::max_(ln.lane_f(1.0f) - az * az, ln.lane_f(0.0f));
-    F len = lm::sqrt_(len2);
-    B degenerate = len < 1e-6f;
-    F zc = z0 + dot(ezk, c);
-    // rim direction in the link frame: (ezk - az*ax)/len, or the fallback axis when the cap is level
-    F inv = lm::sel(degenerate, ln.lane_f(0.0f), ln.lane_f(1.0f) / lm::max_(len, ln.lane_f(1e-12f)));
-    V3l dir = mk3<F>(lm::sel(degenerate, fb.x, (ezk.x - az * ax.x) * inv), lm::sel(degenerate, fb.y, (ezk.y - az * ax.y) * inv),
-                     lm::sel(degenerate, fb.z, (ezk.z - az * ax.z) * inv));
-    F dz = dot(ezk, dir);
-    for (int s = 0; s < 2; s++) {
-      F sg = ln.lane_f(s ? -1.0f : 1.0f);
-      F depth = zc + sg * h * az - r * dz;
-      B pass = depth < cc.margin;
-      if (L::any(pass)) {
-        V3l x = c + scale(ax, sg * h) - scale(dir, r);
-        cand_push(ln, cc, pass, p + mul(R, x), depth, link, mu);
-      }
-    }
+  // the four lanes (one per leg) that own slot / joint S_ take their turn, legs in order
+  template <int S_>
+  static LL_HD void gs_turns4(const L& ln, const Row& r, const F& lo_d, const F& hi_d, F& dl, F& u) {
+    gs_turn<S_>(ln, r, lo_d, hi_d, dl, u);
+    gs_turn<4 + S_>(ln, r, lo_d, hi_d, dl, u);
+    gs_turn<8 + S_>(ln, r, lo_d, hi_d, dl, u);
+    gs_turn<12 + S_>(ln, r, lo_d, hi_d, dl, u);
+  }
+  // one Gauss-Seidel round over the 16 rows of a kind; any4[s] = some lane of the wave has a live row in slot s
+  static LL_HD void gs_round(const L& ln, Row& r, const F& lo, const F& hi, const bool* any4, float* dx, F* dq) {
+    F zero = ln.lane_f(0.0f);
+    F cq = r.c + r.jt[0] * dq[0] + r.jt[1] * dq[1] + r.jt[2] * dq[2];
+    F s0 = r.gt[0] * dx[0] + r.gt[1] * dx[1], s1 = r.gt[2] * dx[2] + r.gt[3] * dx[3], s2 = r.gt[4] * dx[4] + r.gt[5] * dx[5];
+    F u = (zero - ((s0 + s1) + (s2 + cq))) * r.inv;       // unclamped increment; admissible interval [lo - lam, hi - lam]
+    F lo_d = lo - r.lam, hi_d = hi - r.lam;
+    F dl = zero;
+    if (any4[0]) gs_turns4<0>(ln, r, lo_d, hi_d, dl, u);
+    if (any4[1]) gs_turns4<1>(ln, r, lo_d, hi_d, dl, u);
+    if (any4[2]) gs_turns4<2>(ln, r, lo_d, hi_d, dl, u);
+    if (any4[3]) gs_turns4<3>(ln, r, lo_d, hi_d, dl, u);
+    r.lam = r.lam + dl;
+    F pj[3] = {r.jt[0] * dl, r.jt[1] * dl, r.jt[2] * dl}, sj[3];
+    L::subsum3(pj, sj);                                   // the slots of a leg share its joint velocities
+    for (int i = 0; i < 3; i++) dq[i] = dq[i] + sj[i];
+    F pg[6];
+    float sg[6];
+    for (int i = 0; i < 6; i++) pg[i] = r.gt[i] * dl;
+    L::rsum6(pg, sg);                                     // every row moves the base twist
+    for (int i = 0; i < 6; i++) dx[i] += sg[i];
   }
 
   // ---------------------------------------------------------------------------------------------------
@@ -465,147 +432,168 @@ struct Pmc {
     F qs[3];
     for (int j = 0; j < 3; j++) qs[j] = qd[j] + u[j] * dt;
 
-    // --- contact candidates -----------------------------------------------------------------------------------------------
-    CandCtx cc;
-    cc.n = L::f2i(zero);
-    cc.pz = bs.p.z;
-    cc.ezb = ezb;
-    cc.margin = P.margin_dist;
-    {
-      F mu_l = ln.lane_f(P.mu_link), mu_f = ln.lane_f(P.mu_foot);
-      V3l ez = cvt3<F>(ezb);
-      V3l ez1 = mulT(k.R1, ez), ez2 = mulT(k.R2, ez), ez3 = mulT(k.R3, ez);
-      F z1 = dot(ez, k.p1) + cc.pz, z2 = dot(ez, k.p2) + cc.pz, z3 = dot(ez, k.p3) + cc.pz;
-      // priority: foot, shank box, wheel, thigh cylinders, thigh box, hip cylinder, then the lane's share of the base
-      cand_sphere(ln, cc, k.R3, k.p3, z3, ez3, ld3c(ln, legc, LC_FOOTSPH), ln.legc(legc, LC_FOOTSPH + 3), 3.0f, mu_f);
-      cand_box(ln, cc, legc, LC_SHBOX, k.R3, k.p3, z3, ez3, 3.0f, mu_l);
-      LL_NOUNROLL
-      for (int cy = 0; cy < 3; cy++)              // wheel, thigh cylinder 0, thigh cylinder 1
-        cand_cyl(ln, cc, legc, cy == 0 ? LC_WHEEL : (cy == 1 ? LC_THCYL0 : LC_THCYL1), k.R2, k.p2, z2, ez2, 2.0f, mu_l);
-      cand_box(ln, cc, legc, LC_THBOX, k.R2, k.p2, z2, ez2, 2.0f, mu_l);
-      cand_cyl(ln, cc, legc, LC_HIPCYL, k.R1, k.p1, z1, ez1, 1.0f, mu_l);
-      // base box: this lane owns the two vertices with its (sx, sy) signs
-      {
-        V3u c = mk3<float>(bc[BC_BOX], bc[BC_BOX + 1], bc[BC_BOX + 2]);
-        V3u ua = mk3<float>(bc[BC_BOX + 3], bc[BC_BOX + 4], bc[BC_BOX + 5]), ub = mk3<float>(bc[BC_BOX + 6], bc[BC_BOX + 7], bc[BC_BOX + 8]),
-            uc = mk3<float>(bc[BC_BOX + 9], bc[BC_BOX + 10], bc[BC_BOX + 11]);
-        float zc = cc.pz + dot(ezb, c), za = dot(ezb, ua), zb = dot(ezb, ub), zcc = dot(ezb, uc);
-        float lo = zc - fabsf(za) - fabsf(zb) - fabsf(zcc);
-        if (lo < cc.margin) {
-          F sx = ln.legc(legc, LC_BSX), sy = ln.legc(legc, LC_BSY);
-          for (int s = 0; s < 2; s++) {
-            F sz = ln.lane_f(s ? 1.0f : -1.0f);
-            F depth = sx * za + sy * zb + sz * zcc + zc;
-            B pass = depth < cc.margin;
-            if (L::any(pass)) {
-              V3l Pb = cvt3<F>(c) + scale(cvt3<F>(ua), sx) + scale(cvt3<F>(ub), sy) + scale(cvt3<F>(uc), sz);
-              cand_push(ln, cc, pass, Pb, depth, 0.0f, mu_l);
-            }
-          }
-        }
-        // handle spheres (lanes 0 and 2)
-        B has = ln.legc(legc, LC_HAS_HANDLE) > 0.5f;
-        V3l hc = ld3c(ln, legc, LC_HANDLE);
-        F hr = ln.legc(legc, LC_HANDLE + 3);
-        F depth = dot(cvt3<F>(ezb), hc) + cc.pz - hr;
-        B pass = lm::and_(has, depth < cc.margin);
-        if (L::any(pass)) cand_push(ln, cc, pass, hc - scale(cvt3<F>(ezb), hr), depth, 0.0f, mu_l);
-      }
+    // --- contact candidates (DESIGN.md "contact candidates"): 28 points per leg, 7 per sub-lane, grouped by link --------------
+    //   jj 0..3 -> group A, 4..5 -> group B, 6 -> group C;  links  A: [3,3,2,2]  B: [2,2,2,1]  C: [3,0,0,0]  by sub-lane
+    const float inv_dt = 1.0f / dt;
+    V3l ez = cvt3<F>(ezb);
+    V3l ez1 = mulT(k.R1, ez), ez2 = mulT(k.R2, ez), ez3 = mulT(k.R3, ez);
+    F z1 = dot(ez, k.p1) + bs.p.z, z2 = dot(ez, k.p2) + bs.p.z, z3 = dot(ez, k.p3) + bs.p.z, z0b = ln.lane_f(bs.p.z);
+    B sub_lt2 = L::i2f(ln.sub()) < 1.5f, sub_lt3 = L::i2f(ln.sub()) < 2.5f, sub_0 = L::i2f(ln.sub()) < 0.5f;
+    V3l gez[3];
+    F gz0[3];
+    gez[0] = mk3<F>(lm::sel(sub_lt2, ez3.x, ez2.x), lm::sel(sub_lt2, ez3.y, ez2.y), lm::sel(sub_lt2, ez3.z, ez2.z));
+    gz0[0] = lm::sel(sub_lt2, z3, z2);
+    gez[1] = mk3<F>(lm::sel(sub_lt3, ez2.x, ez1.x), lm::sel(sub_lt3, ez2.y, ez1.y), lm::sel(sub_lt3, ez2.z, ez1.z));
+    gz0[1] = lm::sel(sub_lt3, z2, z1);
+    gez[2] = mk3<F>(lm::sel(sub_0, ez3.x, ez.x), lm::sel(sub_0, ez3.y, ez.y), lm::sel(sub_0, ez3.z, ez.z));
+    gz0[2] = lm::sel(sub_0, z3, z0b);
+    const F far_ = ln.lane_f(1.0e30f);
+    F depth[7];
+    for (int jj = 0; jj < 7; jj++) {
+      const int g = jj < 4 ? 0 : (jj < 6 ? 1 : 2);
+      V3l A = mk3<F>(ln.candc(jj * CF_WORDS + CF_A), ln.candc(jj * CF_WORDS + CF_A + 1), ln.candc(jj * CF_WORDS + CF_A + 2));
+      V3l ax = mk3<F>(ln.candc(jj * CF_WORDS + CF_AX), ln.candc(jj * CF_WORDS + CF_AX + 1), ln.candc(jj * CF_WORDS + CF_AX + 2));
+      F r = ln.candc(jj * CF_WORDS + CF_R), link = ln.candc(jj * CF_WORDS + CF_LINK);
+      F az = dot(gez[g], ax);
+      F len = lm::sqrt_(lm::max_(one - az * az, zero));      // 1 for spheres and vertices (ax = 0)
+      F dpt = gz0[g] + dot(gez[g], A) - r * len;
+      depth[jj] = lm::sel(lm::and_(dpt < P.margin_dist, link > -0.5f), dpt, far_);
     }
-
-    // --- constraint rows live in LDS as uniform records  [gt(6) jt(3) c inv lambda]:  rows 0..2 = this lane's joint limits,
-    //     rows 3+3s+r = contact slot s, r = normal / t1 / t2.  inv = 0 marks a row that is not in the solve. ---------------------
-    float inv_dt = 1.0f / dt;
-    bool lim_any[3] = {false, false, false};
-    LL_NOUNROLL
-    for (int j = 0; j < 3; j++) {
-      F qj = (j == 0) ? q[0] : (j == 1 ? q[1] : q[2]);
-      F qsj = (j == 0) ? qs[0] : (j == 1 ? qs[1] : qs[2]);
-      F dl = qj - ln.legc(legc, LC_QLO + j), dh = ln.legc(legc, LC_QHI + j) - qj;
-      B lower = dl <= dh;
-      F d = lm::sel(lower, dl, dh), sg = lm::sel(lower, one, zero - one);
-      F jt[3];
-      jt[0] = (j == 0) ? sg : zero; jt[1] = (j == 1) ? sg : zero; jt[2] = (j == 2) ? sg : zero;
-      lm_fwd(lf, jt);
-      SV<F> g6 = scale(scale(lf.y1, jt[0]) + scale(lf.y2, jt[1]) + scale(lf.y3, jt[2]), zero - one);
-      F gt[6];
-      sv_to6(g6, gt);
-      fwd6(Sb, Sd, gt);
-      F nn = jt[0] * jt[0] + jt[1] * jt[1] + jt[2] * jt[2];
-      for (int i = 0; i < 6; i++) nn = nn + gt[i] * gt[i];
-      F cj = sg * qsj + lm::sel(d > 0.0f, d * inv_dt, d * (P.erp * inv_dt));
-      B lvalid = cj < P.limit_gate;              // rows that cannot act this substep stay out of the solve
-      F invj = lm::sel(lvalid, one / nn, zero);
-      store_row(ln, j, gt, jt, cj, invj);
-      lim_any[j] = L::any(lvalid);
-    }
-
-    // --- contact rows: n = +z, t1 = -y, t2 = +x (world), expressed in F0 ------------------------------------------------------
-    int max_n = 0;
-    LL_NOUNROLL
+    // the leg keeps its 4 deepest candidates, slot s = s-th deepest: four rounds of (local min, quad min, claim)
+    F my_depth = far_, my_sub = zero, my_jj = zero;
     for (int s = 0; s < PMC_K; s++) {
-      B valid = cc.n > s;
-      if (!L::any(valid)) break;
-      max_n = s + 1;
-      V3l Pb = mk3<F>(ln.lds_ld(LW_CAND(s, 0)), ln.lds_ld(LW_CAND(s, 1)), ln.lds_ld(LW_CAND(s, 2)));
-      F link = ln.lds_ld(LW_CAND(s, 3)), depth = ln.lds_ld(LW_CAND(s, 4));
-      F bias = lm::sel(depth > 0.0f, depth * inv_dt, depth * (P.erp * inv_dt));
+      F m = depth[0], am = zero;
+      for (int jj = 1; jj < 7; jj++) {
+        B lt = depth[jj] < m;
+        m = lm::sel(lt, depth[jj], m);
+        am = lm::sel(lt, ln.lane_f((float)jj), am);
+      }
+      F mq = L::submin(m);
+      F code = lm::sel(lm::and_(m <= mq, m < far_), L::i2f(ln.sub()), ln.lane_f(4.0f));
+      F wsub = L::submin(code);                             // lowest sub-lane holding the minimum (4 = none)
+      B winner = lm::and_(code <= wsub, code < 3.5f);
+      F wjj = L::subsum(lm::sel(winner, am, zero));
+      for (int jj = 0; jj < 7; jj++) depth[jj] = lm::sel(lm::and_(winner, lm::abs_(am - (float)jj) < 0.5f), far_, depth[jj]);
+      B owner = ln.is_sub(s);
+      my_depth = lm::sel(owner, lm::sel(wsub < 3.5f, mq, far_), my_depth);
+      my_sub = lm::sel(owner, wsub, my_sub);
+      my_jj = lm::sel(owner, wjj, my_jj);
+    }
+    // store the kept candidates in candidate-index order (near-ties in depth must not reorder the solve): each slot lane
+    // ranks its candidate among the leg's four and picks up the one whose rank equals its slot
+    {
+      F idx = lm::sel(my_depth < 1.0e29f, my_sub * 7.0f + my_jj, ln.lane_f(1000.0f) + L::i2f(ln.sub()));
+      F i0 = L::template subbcast<0>(idx), i1 = L::template subbcast<1>(idx), i2 = L::template subbcast<2>(idx), i3 = L::template subbcast<3>(idx);
+      F rank = lm::sel(i0 < idx, one, zero) + lm::sel(i1 < idx, one, zero) + lm::sel(i2 < idx, one, zero) + lm::sel(i3 < idx, one, zero);
+      F me = L::i2f(ln.sub());
+      F nd = my_depth, ns = my_sub, nj = my_jj;
+      pick_rank<0>(ln, rank, me, my_depth, my_sub, my_jj, nd, ns, nj);
+      pick_rank<1>(ln, rank, me, my_depth, my_sub, my_jj, nd, ns, nj);
+      pick_rank<2>(ln, rank, me, my_depth, my_sub, my_jj, nd, ns, nj);
+      pick_rank<3>(ln, rank, me, my_depth, my_sub, my_jj, nd, ns, nj);
+      my_depth = nd; my_sub = ns; my_jj = nj;
+    }
+    const B cvalid = my_depth < 1.0e29f;
+    bool any_c[4], any_l[4] = {false, false, false, false};
+    any_c[0] = L::any(lm::and_(cvalid, ln.is_sub(0))); any_c[1] = L::any(lm::and_(cvalid, ln.is_sub(1)));
+    any_c[2] = L::any(lm::and_(cvalid, ln.is_sub(2))); any_c[3] = L::any(lm::and_(cvalid, ln.is_sub(3)));
+    const bool any_contact = any_c[0] || any_c[1] || any_c[2] || any_c[3];
+
+    // --- rows -------------------------------------------------------------------------------------------------------------------
+    Row rl, rn, r1, r2;
+    F mu = zero;
+    {   // joint-limit row of joint j = sub (sub-lane 3 holds none)
+      B has = sub_lt3;
+      F qj = lm::sel(sub_0, q[0], lm::sel(sub_lt2, q[1], q[2])), qsj = lm::sel(sub_0, qs[0], lm::sel(sub_lt2, qs[1], qs[2]));
+      F qlo = lm::sel(sub_0, ln.legc(legc, LC_QLO), lm::sel(sub_lt2, ln.legc(legc, LC_QLO + 1), ln.legc(legc, LC_QLO + 2)));
+      F qhi = lm::sel(sub_0, ln.legc(legc, LC_QHI), lm::sel(sub_lt2, ln.legc(legc, LC_QHI + 1), ln.legc(legc, LC_QHI + 2)));
+      F dlo = qj - qlo, dhi = qhi - qj;
+      B lower = dlo <= dhi;
+      F d = lm::sel(lower, dlo, dhi), sg = lm::sel(lower, one, zero - one);
+      rl.jt[0] = lm::sel(sub_0, sg, zero);
+      rl.jt[1] = lm::sel(lm::and_(sub_lt2, lm::not_(sub_0)), sg, zero);
+      rl.jt[2] = lm::sel(lm::and_(sub_lt3, lm::not_(sub_lt2)), sg, zero);
+      lm_fwd(lf, rl.jt);
+      SV<F> g6 = scale(scale(lf.y1, rl.jt[0]) + scale(lf.y2, rl.jt[1]) + scale(lf.y3, rl.jt[2]), zero - one);
+      sv_to6(g6, rl.gt);
+      fwd6(Sb, Sd, rl.gt);
+      F nn = rl.jt[0] * rl.jt[0] + rl.jt[1] * rl.jt[1] + rl.jt[2] * rl.jt[2];
+      for (int i = 0; i < 6; i++) nn = nn + rl.gt[i] * rl.gt[i];
+      rl.c = sg * qsj + lm::sel(d > 0.0f, d * inv_dt, d * (P.erp * inv_dt));
+      B lvalid = lm::and_(has, rl.c < P.limit_gate);     // rows that cannot act this substep stay out of the solve
+      rl.inv = lm::sel(lvalid, one / nn, zero);
+      any_l[0] = L::any(lm::and_(lvalid, ln.is_sub(0))); any_l[1] = L::any(lm::and_(lvalid, ln.is_sub(1)));
+      any_l[2] = L::any(lm::and_(lvalid, ln.is_sub(2)));
+      if (any_l[0] || any_l[1] || any_l[2]) finish_row(ln, rl);
+    }
+    if (any_contact) {
+      // geometry of this lane's contact: candidate (my_sub, my_jj) of the leg, re-evaluated from the table
+      I wsub = L::f2i(my_sub), wbase = L::f2i(my_jj) * CF_WORDS;
+      V3l A = mk3<F>(ln.candc_of(wsub, wbase + CF_A), ln.candc_of(wsub, wbase + CF_A + 1), ln.candc_of(wsub, wbase + CF_A + 2));
+      V3l ax = mk3<F>(ln.candc_of(wsub, wbase + CF_AX), ln.candc_of(wsub, wbase + CF_AX + 1), ln.candc_of(wsub, wbase + CF_AX + 2));
+      V3l fb = mk3<F>(ln.candc_of(wsub, wbase + CF_FB), ln.candc_of(wsub, wbase + CF_FB + 1), ln.candc_of(wsub, wbase + CF_FB + 2));
+      F r = ln.candc_of(wsub, wbase + CF_R), link = ln.candc_of(wsub, wbase + CF_LINK), kind = ln.candc_of(wsub, wbase + CF_KIND);
+      mu = lm::sel(kind > 0.5f, ln.lane_f(P.mu_foot), ln.lane_f(P.mu_link));
+      B l1 = link < 1.5f, l2 = link < 2.5f, l0 = link < 0.5f;       // link: 0 base, 1 hip, 2 thigh, 3 shank
+      V3l ezk = mk3<F>(lm::sel(l0, ez.x, lm::sel(l1, ez1.x, lm::sel(l2, ez2.x, ez3.x))), lm::sel(l0, ez.y, lm::sel(l1, ez1.y, lm::sel(l2, ez2.y, ez3.y))),
+                       lm::sel(l0, ez.z, lm::sel(l1, ez1.z, lm::sel(l2, ez2.z, ez3.z))));
+      F az = dot(ezk, ax);
+      F len = lm::sqrt_(lm::max_(one - az * az, zero));
+      B degenerate = len < 1e-6f;
+      F il = lm::sel(degenerate, zero, one / lm::max_(len, ln.lane_f(1e-12f)));
+      V3l dir = mk3<F>(lm::sel(degenerate, fb.x, (ezk.x - az * ax.x) * il), lm::sel(degenerate, fb.y, (ezk.y - az * ax.y) * il),
+                       lm::sel(degenerate, fb.z, (ezk.z - az * ax.z) * il));
+      V3l x = A - scale(dir, r);
+      // P_b = p_k + R_k x   (link 0: the base frame itself)
+      V3l x1 = k.p1 + mul(k.R1, x), x2 = k.p2 + mul(k.R2, x), x3 = k.p3 + mul(k.R3, x);
+      V3l Pb = mk3<F>(lm::sel(l0, x.x, lm::sel(l1, x1.x, lm::sel(l2, x2.x, x3.x))), lm::sel(l0, x.y, lm::sel(l1, x1.y, lm::sel(l2, x2.y, x3.y))),
+                      lm::sel(l0, x.z, lm::sel(l1, x1.z, lm::sel(l2, x2.z, x3.z))));
+      F depth_c = my_depth;
+      F bias = lm::sel(depth_c > 0.0f, depth_c * inv_dt, depth_c * (P.erp * inv_dt));
       // joint j moves the point iff the point's link is at or below joint j: link >= j+1
       F on1 = lm::sel(link > 0.5f, one, zero), on2 = lm::sel(link > 1.5f, one, zero), on3 = lm::sel(link > 2.5f, one, zero);
-      V3l r1 = Pb - k.p1, r2 = Pb - k.p2, r3 = Pb - k.p3;
+      V3l rr1 = Pb - k.p1, rr2 = Pb - k.p2, rr3 = Pb - k.p3;
       V3l a1v = mk3<F>(one, zero, zero);
-      V3l d1 = scale(cross(a1v, r1), on1), d2 = scale(cross(k.a2, r2), on2), d3 = scale(cross(k.a2, r3), on3);
-      LL_NOUNROLL
-      for (int r = 0; r < 3; r++) {
-        V3u ub = (r == 0) ? ezb : (r == 1 ? mk3<float>(-R.m[3], -R.m[4], -R.m[5]) : mk3<float>(R.m[0], R.m[1], R.m[2]));
+      V3l d1 = scale(cross(a1v, rr1), on1), d2 = scale(cross(k.a2, rr2), on2), d3 = scale(cross(k.a2, rr3), on3);
+      // rows n = +z, t1 = -y, t2 = +x (world), expressed in F0
+      for (int r_ = 0; r_ < 3; r_++) {
+        Row& rw = (r_ == 0) ? rn : (r_ == 1 ? r1 : r2);
+        V3u ub = (r_ == 0) ? ezb : (r_ == 1 ? mk3<float>(-R.m[3], -R.m[4], -R.m[5]) : mk3<float>(R.m[0], R.m[1], R.m[2]));
         V3l uu = cvt3<F>(ub);
-        F jl[3];
-        jl[0] = dot(uu, d1); jl[1] = dot(uu, d2); jl[2] = dot(uu, d3);
+        rw.jt[0] = dot(uu, d1); rw.jt[1] = dot(uu, d2); rw.jt[2] = dot(uu, d3);
         V3l pxu = cross(Pb, uu);
         // free row velocity J_b xi + J_l qd*
-        F vrow = pxu.x * xi[0] + pxu.y * xi[1] + pxu.z * xi[2] + uu.x * xi[3] + uu.y * xi[4] + uu.z * xi[5] + jl[0] * qs[0] + jl[1] * qs[1] + jl[2] * qs[2];
-        lm_fwd(lf, jl);                                            // jt
-        SV<F> yj = scale(lf.y1, jl[0]) + scale(lf.y2, jl[1]) + scale(lf.y3, jl[2]);
-        F gt[6];
-        gt[0] = pxu.x - yj.a.x; gt[1] = pxu.y - yj.a.y; gt[2] = pxu.z - yj.a.z;
-        gt[3] = uu.x - yj.l.x; gt[4] = uu.y - yj.l.y; gt[5] = uu.z - yj.l.z;
-        fwd6(Sb, Sd, gt);
-        F nn = jl[0] * jl[0] + jl[1] * jl[1] + jl[2] * jl[2];
-        const int row = 3 + 3 * s + r;
-        for (int i = 0; i < 6; i++) nn = nn + gt[i] * gt[i];
-        F invr = lm::sel(valid, one / nn, zero);
-        store_row(ln, row, gt, jl, (r == 0) ? vrow + bias : vrow, invr);
+        F vrow = pxu.x * xi[0] + pxu.y * xi[1] + pxu.z * xi[2] + uu.x * xi[3] + uu.y * xi[4] + uu.z * xi[5] + rw.jt[0] * qs[0] + rw.jt[1] * qs[1] + rw.jt[2] * qs[2];
+        lm_fwd(lf, rw.jt);
+        SV<F> yj = scale(lf.y1, rw.jt[0]) + scale(lf.y2, rw.jt[1]) + scale(lf.y3, rw.jt[2]);
+        rw.gt[0] = pxu.x - yj.a.x; rw.gt[1] = pxu.y - yj.a.y; rw.gt[2] = pxu.z - yj.a.z;
+        rw.gt[3] = uu.x - yj.l.x; rw.gt[4] = uu.y - yj.l.y; rw.gt[5] = uu.z - yj.l.z;
+        fwd6(Sb, Sd, rw.gt);
+        F nn = rw.jt[0] * rw.jt[0] + rw.jt[1] * rw.jt[1] + rw.jt[2] * rw.jt[2];
+        for (int i = 0; i < 6; i++) nn = nn + rw.gt[i] * rw.gt[i];
+        rw.c = (r_ == 0) ? vrow + bias : vrow;
+        rw.inv = lm::sel(cvalid, one / nn, zero);
+        finish_row(ln, rw);
       }
     }
 
-    // --- projected Gauss-Seidel in whitened coordinates -------------------------------------------------------------------------
-    // Row order of the spec: limit rows joint-major (legs 0..3 per joint), then per slot the normal rows of legs 0..3, their t1
-    // rows, their t2 rows.  A row record is loaded once; the four lanes of the quad then take their Gauss-Seidel turn on the
-    // shared 6-vector dx (only the lane whose turn it is commits), and the lane-private dq is updated afterwards.
-    float dx[6] = {0, 0, 0, 0, 0, 0};      // shared:  sum gt * lambda
-    F dq[3] = {zero, zero, zero};          // private: sum jt * lambda
-    const int n_rows = 3 + 3 * max_n;
+    // --- projected Gauss-Seidel in whitened coordinates, rows in registers ------------------------------------------------------
+    // Order of the spec: limit rows (joint, leg), then normal rows (slot, leg), t1 rows, t2 rows.
+    float dx[6] = {0, 0, 0, 0, 0, 0};      // env-uniform:  sum gt * lambda
+    F dq[3] = {zero, zero, zero};          // leg-uniform:  sum jt * lambda
     const F big = ln.lane_f(3.0e38f);
-    // One row index = one row per lane.  Per row: load the record (4 x ds_read_b128), form the unclamped increment u, let the
-    // four lanes take their turn (gs_turn), fold the committed increments into dx (quad sum) and dq.
+    const bool any_limit = any_l[0] || any_l[1] || any_l[2];
     LL_NOUNROLL
     for (int it = 0; it < P.n_iter; it++) {
-      LL_NOUNROLL
-      for (int j = 0; j < 3; j++) {
-        if (!lim_any[j]) continue;
-        RowRec rj = load_row(ln, j);
-        gs_row(ln, j, rj, zero, big, dx, dq);
-      }
-      LL_NOUNROLL
-      for (int s = 0; s < max_n; s++) {
-        RowRec rn = load_row(ln, 3 + 3 * s), r1 = load_row(ln, 4 + 3 * s), r2 = load_row(ln, 5 + 3 * s);
-        F mu = ln.lds_ld(LW_CAND(s, 5));
-        F lam_n = gs_row(ln, 3 + 3 * s, rn, zero, big, dx, dq);
-        F hi = mu * lam_n;
-        gs_row(ln, 4 + 3 * s, r1, zero - hi, hi, dx, dq);
-        gs_row(ln, 5 + 3 * s, r2, zero - hi, hi, dx, dq);
+      if (any_limit) gs_round(ln, rl, zero, big, any_l, dx, dq);
+      if (any_contact) {
+        gs_round(ln, rn, zero, big, any_c, dx, dq);
+        F hi = mu * rn.lam;
+        gs_round(ln, r1, zero - hi, hi, any_c, dx, dq);
+        gs_round(ln, r2, zero - hi, hi, any_c, dx, dq);
       }
     }
+
     // back to velocities: d(xi) = Lb^-T dx ; d(qd) = Lm^-T (dq - Y^T d(xi))
     bwd6(Sb, Sd, dx);
     SV<float> dxi;
@@ -628,71 +616,6 @@ struct Pmc {
     }
   }
 
-  struct RowRec {
-    F gt[6], jt[3], c, inv, lam, nk[4];
-  };
-  static LL_HD RowRec load_row(const L& ln, int row) {
-    RowRec r;
-    F a[4], b[4], c[4];
-    ln.lds_ld4(LW_ROWBASE, LQ_ROW(row, 0), a);
-    ln.lds_ld4(LW_ROWBASE, LQ_ROW(row, 1), b);
-    ln.lds_ld4(LW_ROWBASE, LQ_ROW(row, 2), c);
-    ln.lds_ld4(LW_ROWBASE, LQ_ROW(row, 3), r.nk);
-    r.gt[0] = a[0]; r.gt[1] = a[1]; r.gt[2] = a[2]; r.gt[3] = a[3]; r.gt[4] = b[0]; r.gt[5] = b[1];
-    r.jt[0] = b[2]; r.jt[1] = b[3]; r.jt[2] = c[0];
-    r.c = c[1]; r.inv = c[2]; r.lam = c[3];
-    return r;
-  }
-  // row record with lambda = 0 and the negated Gram scalars -k[L] = -(gt . gt_L) * inv of the four lanes' rows
-  static LL_HD void store_row(const L& ln, int row, const F* gt, const F* jt, const F& c, const F& inv) {
-    F g0 = ln.lane_f(0.0f), g1 = g0, g2 = g0, g3 = g0;
-    for (int i = 0; i < 6; i++) {
-      g0 = g0 + gt[i] * L::template bcast<0>(gt[i]);
-      g1 = g1 + gt[i] * L::template bcast<1>(gt[i]);
-      g2 = g2 + gt[i] * L::template bcast<2>(gt[i]);
-      g3 = g3 + gt[i] * L::template bcast<3>(gt[i]);
-    }
-    F ninv = ln.lane_f(0.0f) - inv;
-    F a[4] = {gt[0], gt[1], gt[2], gt[3]}, b[4] = {gt[4], gt[5], jt[0], jt[1]}, cc[4] = {jt[2], c, inv, ln.lane_f(0.0f)};
-    F d[4] = {g0 * ninv, g1 * ninv, g2 * ninv, g3 * ninv};
-    ln.lds_st4(LW_ROWBASE, LQ_ROW(row, 0), a);
-    ln.lds_st4(LW_ROWBASE, LQ_ROW(row, 1), b);
-    ln.lds_st4(LW_ROWBASE, LQ_ROW(row, 2), cc);
-    ln.lds_st4(LW_ROWBASE, LQ_ROW(row, 3), d);
-  }
-  // one Gauss-Seidel visit of a row index; returns this lane's new multiplier
-  static LL_HD F gs_row(const L& ln, int row, const RowRec& r, const F& lo, const F& hi, float* dx, F* dq) {
-    F zero = ln.lane_f(0.0f);
-    if (!L::any(r.inv > 0.0f)) return zero;
-    F cq = r.c + r.jt[0] * dq[0] + r.jt[1] * dq[1] + r.jt[2] * dq[2];
-    F s0 = r.gt[0] * dx[0] + r.gt[1] * dx[1], s1 = r.gt[2] * dx[2] + r.gt[3] * dx[3], s2 = r.gt[4] * dx[4] + r.gt[5] * dx[5];
-    // u = unclamped increment of this lane's multiplier; the admissible increment interval is [lo - lam, hi - lam]
-    F u = (zero - ((s0 + s1) + (s2 + cq))) * r.inv;
-    F lo_d = lo - r.lam, hi_d = hi - r.lam;
-    F dl = zero;
-    gs_turn<0>(ln, r.nk[0], lo_d, hi_d, dl, u);
-    gs_turn<1>(ln, r.nk[1], lo_d, hi_d, dl, u);
-    gs_turn<2>(ln, r.nk[2], lo_d, hi_d, dl, u);
-    gs_turn<3>(ln, r.nk[3], lo_d, hi_d, dl, u);
-    F lam = r.lam + dl;
-    ln.lds_st1(LW_ROWBASE, LQ_ROW(row, 2), 3, lam);
-    for (int i = 0; i < 3; i++) dq[i] = dq[i] + r.jt[i] * dl;
-    F prod[6];
-    float red[6];
-    for (int i = 0; i < 6; i++) prod[i] = r.gt[i] * dl;
-    L::qsum6(prod, red);
-    for (int i = 0; i < 6; i++) dx[i] += red[i];
-    return lam;
-  }
-  // Gauss-Seidel turn of leg LEG on the four rows (one per lane) of a row index.  Every lane clamps its own increment
-  // (one v_med3); the quad broadcast picks lane LEG's, which then shifts every lane's pending increment by -nk[LEG] * d
-  // (one v_fmac with a DPP operand).  Two dependent instructions per turn.
-  template <int LEG>
-  static LL_HD void gs_turn(const L& ln, const F& nkL, const F& lo_d, const F& hi_d, F& dl, F& u) {
-    F d = lm::med3_(u, lo_d, hi_d);
-    dl = lm::sel(ln.is_leg(LEG), d, dl);
-    L::template fmac_bcast<LEG>(u, d, nkL);
-  }
   // ---------------------------------------------------------------------------------------------------
   // mocap reference (ML:65-166)
   // ---------------------------------------------------------------------------------------------------
@@ -858,10 +781,6 @@ struct Pmc {
   // ---------------------------------------------------------------------------------------------------
   // the control step
   // ---------------------------------------------------------------------------------------------------
-  static LL_HD void clear_scratch(const L& ln) {   // stale rows must at least be finite (they are multiplied by 0)
-    for (int w = 0; w < LW_COUNT; w++) ln.lds_st(w, ln.lane_f(0.0f));
-  }
-
   static LL_HD void step_env(const L& ln, const StepParams& P, int env) {
     const int N = P.n_envs;
     Base bs;
@@ -981,14 +900,14 @@ struct Pmc {
   }
   static LL_HD void count_add(const L& ln, unsigned long long* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (ln.is_leg(0)) atomicAdd(p, 1ull);
+    if (ln.is_lane(0)) atomicAdd(p, 1ull);
 #else
     *p += 1ull;
 #endif
   }
   static LL_HD void publish_max(const L& ln, unsigned long long* p, unsigned long long v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (ln.is_leg(0)) atomicMax(p, v);
+    if (ln.is_lane(0)) atomicMax(p, v);
 #else
     if (*p < v) *p = v;
 #endif

@@ -99,6 +99,70 @@ static inline std::string pmc_build_tables(const double* blob, int blob_len, std
   return "";
 }
 
+// Contact candidate table (pmc_params.hpp CandField): 28 points per leg, 7 per sub-lane, laid out so that candidates jj 0..3
+// of a sub-lane sit on one link (group A), jj 4..5 on another (B), jj 6 on a third (C):
+//   sub 0: foot, shank box v0 v1 v2 | wheel caps +,- | shank box v3
+//   sub 1: shank box v4..v7         | thigh cylinder 0 caps | body box vertex (leg, z-)
+//   sub 2: thigh box v0..v3         | thigh cylinder 1 caps | body box vertex (leg, z+)
+//   sub 3: thigh box v4..v7         | hip cylinder caps     | handle sphere (legs 0 and 2; invalid elsewhere)
+static inline void pmc_put_cand(std::vector<float>& t, int lane16, int jj, const double* A, const double* ax, const double* fb, double r, int link, int kind) {
+  for (int c = 0; c < 3; c++) {
+    t[(jj * CF_WORDS + CF_A + c) * 16 + lane16] = (float)A[c];
+    t[(jj * CF_WORDS + CF_AX + c) * 16 + lane16] = ax ? (float)ax[c] : 0.0f;
+    t[(jj * CF_WORDS + CF_FB + c) * 16 + lane16] = fb ? (float)fb[c] : 0.0f;
+  }
+  t[(jj * CF_WORDS + CF_R) * 16 + lane16] = (float)r;
+  t[(jj * CF_WORDS + CF_LINK) * 16 + lane16] = (float)link;
+  t[(jj * CF_WORDS + CF_KIND) * 16 + lane16] = (float)kind;
+}
+static inline void pmc_box_vertex(const PmcPrimView& p, int v, double* A) {
+  for (int c = 0; c < 3; c++) {
+    A[c] = p.pos[c];
+    for (int a = 0; a < 3; a++) A[c] += (((v >> a) & 1) ? 1.0 : -1.0) * p.size[a] * p.rot[3 * c + a];
+  }
+}
+static inline void pmc_cyl_cap(const PmcPrimView& p, int s, double* A, double* ax, double* fb) {
+  for (int c = 0; c < 3; c++) {
+    ax[c] = p.rot[3 * c + 2];
+    fb[c] = p.rot[3 * c + 0];
+    A[c] = p.pos[c] + (s ? -1.0 : 1.0) * p.size[1] * ax[c];
+  }
+}
+static inline std::string pmc_build_cand_table(const double* blob, std::vector<float>& t) {
+  t.assign(CAND_TABLE_WORDS * 16, 0.0f);
+  PmcPrimView bbox = pmc_prim(blob + LLM_OFF_BASE_PRIMS);
+  for (int l = 0; l < 4; l++) {
+    PmcPrimView lp[LLM_N_LEG_PRIMS];
+    for (int s = 0; s < LLM_N_LEG_PRIMS; s++) lp[s] = pmc_prim(blob + LLM_OFF_LEG_PRIMS + (l * LLM_N_LEG_PRIMS + s) * LLM_PRIM_STRIDE);
+    double A[3], ax[3], fb[3];
+    const int L0 = l * 4;
+    // sub 0
+    pmc_put_cand(t, L0 + 0, 0, lp[6].pos, nullptr, nullptr, lp[6].size[0], 3, 1);
+    for (int v = 0; v < 3; v++) { pmc_box_vertex(lp[5], v, A); pmc_put_cand(t, L0 + 0, 1 + v, A, nullptr, nullptr, 0.0, 3, 0); }
+    for (int s = 0; s < 2; s++) { pmc_cyl_cap(lp[4], s, A, ax, fb); pmc_put_cand(t, L0 + 0, 4 + s, A, ax, fb, lp[4].size[0], 2, 0); }
+    pmc_box_vertex(lp[5], 3, A); pmc_put_cand(t, L0 + 0, 6, A, nullptr, nullptr, 0.0, 3, 0);
+    // sub 1
+    for (int v = 0; v < 4; v++) { pmc_box_vertex(lp[5], 4 + v, A); pmc_put_cand(t, L0 + 1, v, A, nullptr, nullptr, 0.0, 3, 0); }
+    for (int s = 0; s < 2; s++) { pmc_cyl_cap(lp[2], s, A, ax, fb); pmc_put_cand(t, L0 + 1, 4 + s, A, ax, fb, lp[2].size[0], 2, 0); }
+    pmc_box_vertex(bbox, l, A); pmc_put_cand(t, L0 + 1, 6, A, nullptr, nullptr, 0.0, 0, 0);
+    // sub 2
+    for (int v = 0; v < 4; v++) { pmc_box_vertex(lp[1], v, A); pmc_put_cand(t, L0 + 2, v, A, nullptr, nullptr, 0.0, 2, 0); }
+    for (int s = 0; s < 2; s++) { pmc_cyl_cap(lp[3], s, A, ax, fb); pmc_put_cand(t, L0 + 2, 4 + s, A, ax, fb, lp[3].size[0], 2, 0); }
+    pmc_box_vertex(bbox, l + 4, A); pmc_put_cand(t, L0 + 2, 6, A, nullptr, nullptr, 0.0, 0, 0);
+    // sub 3
+    for (int v = 0; v < 4; v++) { pmc_box_vertex(lp[1], 4 + v, A); pmc_put_cand(t, L0 + 3, v, A, nullptr, nullptr, 0.0, 2, 0); }
+    for (int s = 0; s < 2; s++) { pmc_cyl_cap(lp[0], s, A, ax, fb); pmc_put_cand(t, L0 + 3, 4 + s, A, ax, fb, lp[0].size[0], 1, 0); }
+    if (l == 0 || l == 2) {
+      PmcPrimView h = pmc_prim(blob + LLM_OFF_BASE_PRIMS + (l == 0 ? 1 : 2) * LLM_PRIM_STRIDE);
+      pmc_put_cand(t, L0 + 3, 6, h.pos, nullptr, nullptr, h.size[0], 0, 0);
+    } else {
+      const double z3[3] = {0, 0, 0};
+      pmc_put_cand(t, L0 + 3, 6, z3, nullptr, nullptr, 0.0, -1, 0);
+    }
+  }
+  return "";
+}
+
 // scalar part of StepParams from the reference-style config; returns "" or an error
 static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
   if (cfg.abi_version != LL_ABI_VERSION) return "ll_config.abi_version mismatch";

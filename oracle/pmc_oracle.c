@@ -587,74 +587,76 @@ typedef struct {
   int leg, slot;
 } OContact;
 
-/* A leg lane keeps the KC deepest of its candidates: free slots are taken in arrival order; once full a candidate
- * replaces the shallowest stored contact (first one on ties) if it is deeper than it.  `first` = index in out[] of the lane's slot 0. */
-static int add_candidate(OContact* out, int n, int* nleg, int leg, int body, const double* P, double mu) {
-  if (!(P[2] < LLM_CONTACT_MARGIN)) return n;
-  int first = n - *nleg, slot;
-  if (*nleg < KC) {
-    slot = (*nleg)++;
-    n = n + 1;
-  } else {
-    slot = 0;
-    for (int k = 1; k < KC; k++)
-      if (out[first + k].depth > out[first + slot].depth) slot = k;
-    if (!(P[2] < out[first + slot].depth)) return n;
-  }
-  OContact* c = &out[first + slot];
-  c->body = body; memcpy(c->P, P, 24); c->depth = P[2]; c->mu = mu; c->leg = leg; c->slot = slot;
-  return n;
-}
+/* DESIGN.md "contact candidates" (spec v2, order independent): every leg has 28 candidate points in a fixed index order
+ *   0 foot | 1-3 shank box v0-2 | 4,5 wheel caps | 6 shank v3 | 7-10 shank v4-7 | 11,12 thigh cyl 0 caps | 13 body box vertex z- |
+ *   14-17 thigh box v0-3 | 18,19 thigh cyl 1 caps | 20 body box vertex z+ | 21-24 thigh box v4-7 | 25,26 hip cyl caps | 27 handle
+ * and keeps the KC candidates of smallest depth below the margin (ties: lower index); the kept ones fill the slots in
+ * candidate-index order.  (The index order is the one of the kernel's table, pmc_tables.hpp pmc_build_cand_table.) */
+typedef struct { double P[3], depth, mu; int body, valid; } OCand;
 
-/* candidate points of one primitive attached to a body with pose (Rw, pw); calls add for each */
-static int prim_candidates(const OPrim* p, const double* Rw, const double* pw, OContact* out, int n, int* nleg, int leg,
-                           int body, double mu, int only_vertex_mask) {
-  double c[3], t[3], Rp[9];
+static void cand_point(const OPrim* p, const double* Rw, const double* pw, int which, OCand* c) {
+  double ctr[3], t[3], Rp[9];
   m3v(Rw, p->pos, t);
-  for (int i = 0; i < 3; i++) c[i] = pw[i] + t[i];
-  m3m(Rw, p->rot, Rp); /* prim -> world */
+  for (int i = 0; i < 3; i++) ctr[i] = pw[i] + t[i];
+  m3m(Rw, p->rot, Rp);
   if (p->type == LLM_PRIM_SPHERE) {
-    double P[3] = {c[0], c[1], c[2] - p->size[0]};
-    n = add_candidate(out, n, nleg, leg, body, P, mu);
+    c->P[0] = ctr[0]; c->P[1] = ctr[1]; c->P[2] = ctr[2] - p->size[0];
   } else if (p->type == LLM_PRIM_BOX) {
-    for (int j = 0; j < 8; j++) {
-      if (only_vertex_mask >= 0 && (j & 3) != only_vertex_mask) continue;
-      double l[3] = {(j & 1) ? p->size[0] : -p->size[0], (j & 2) ? p->size[1] : -p->size[1], (j & 4) ? p->size[2] : -p->size[2]};
-      double P[3];
-      m3v(Rp, l, P);
-      for (int i = 0; i < 3; i++) P[i] += c[i];
-      n = add_candidate(out, n, nleg, leg, body, P, mu);
-    }
-  } else { /* cylinder, axis = local z: deepest rim point of each cap */
+    double l[3] = {(which & 1) ? p->size[0] : -p->size[0], (which & 2) ? p->size[1] : -p->size[1], (which & 4) ? p->size[2] : -p->size[2]};
+    m3v(Rp, l, c->P);
+    for (int i = 0; i < 3; i++) c->P[i] += ctr[i];
+  } else { /* cylinder, axis = local z: lowest rim point of cap `which` (0: +h, 1: -h) */
     double a[3] = {Rp[2], Rp[5], Rp[8]};
-    double proj[3] = {-a[2] * a[0], -a[2] * a[1], 1.0 - a[2] * a[2]}; /* n - (n.a) a, n = +z */
+    double proj[3] = {-a[2] * a[0], -a[2] * a[1], 1.0 - a[2] * a[2]};
     double len = sqrt(v3dot(proj, proj)), dir[3];
     if (len < 1e-6) { dir[0] = Rp[0]; dir[1] = Rp[3]; dir[2] = Rp[6]; }
     else { for (int i = 0; i < 3; i++) dir[i] = proj[i] / len; }
-    for (int s = 0; s < 2; s++) {
-      double sg = s ? -1.0 : 1.0, P[3];
-      for (int i = 0; i < 3; i++) P[i] = c[i] + sg * p->size[1] * a[i] - p->size[0] * dir[i];
-      n = add_candidate(out, n, nleg, leg, body, P, mu);
-    }
+    double sg = which ? -1.0 : 1.0;
+    for (int i = 0; i < 3; i++) c->P[i] = ctr[i] + sg * p->size[1] * a[i] - p->size[0] * dir[i];
   }
-  return n;
+  c->depth = c->P[2];
+  c->valid = 1;
 }
 
-/* DESIGN.md "contact candidates": per leg lane, fixed priority order, first KC within the margin */
 static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double mu_link, OContact* out) {
-  static const int order[LLM_N_LEG_PRIMS] = {6, 5, 4, 2, 3, 1, 0};   /* foot, shank box, wheel, thigh cyls, thigh box, hip */
-  static const int links[LLM_N_LEG_PRIMS] = LLM_LEG_PRIM_LINKS;
   int n = 0;
   for (int l = 0; l < 4; l++) {
-    int nleg = 0;
-    for (int k = 0; k < LLM_N_LEG_PRIMS; k++) {
-      int pi = order[k], body = 1 + 3 * l + links[pi];
-      n = prim_candidates(&M->leg_prims[l][pi], K->Rw[body], K->pw[body], out, n, &nleg, l, body, pi == 6 ? mu_foot : mu_link, -1);
+    OCand c[28];
+    memset(c, 0, sizeof c);
+    int hip = 1 + 3 * l, thigh = 2 + 3 * l, shank = 3 + 3 * l, k = 0;
+    const OPrim* lp = M->leg_prims[l];   /* 0 hip cyl | 1 thigh box, 2 thigh cyl 0, 3 thigh cyl 1, 4 wheel | 5 shank box, 6 foot */
+#define CAND(prim, body_, which, mu_) do { cand_point(prim, K->Rw[body_], K->pw[body_], which, &c[k]); c[k].body = body_; c[k].mu = mu_; k++; } while (0)
+    CAND(&lp[6], shank, 0, mu_foot);                                        /*  0      foot                         */
+    for (int v = 0; v < 3; v++) CAND(&lp[5], shank, v, mu_link);             /*  1-3    shank box v0..v2             */
+    for (int s2 = 0; s2 < 2; s2++) CAND(&lp[4], thigh, s2, mu_link);         /*  4,5    wheel caps                   */
+    CAND(&lp[5], shank, 3, mu_link);                                        /*  6      shank box v3                 */
+    for (int v = 4; v < 8; v++) CAND(&lp[5], shank, v, mu_link);             /*  7-10   shank box v4..v7             */
+    for (int s2 = 0; s2 < 2; s2++) CAND(&lp[2], thigh, s2, mu_link);         /*  11,12  thigh cylinder 0 caps        */
+    CAND(&M->base_prims[0], 0, l, mu_link);                                 /*  13     body box vertex (leg, z-)    */
+    for (int v = 0; v < 4; v++) CAND(&lp[1], thigh, v, mu_link);             /*  14-17  thigh box v0..v3             */
+    for (int s2 = 0; s2 < 2; s2++) CAND(&lp[3], thigh, s2, mu_link);         /*  18,19  thigh cylinder 1 caps        */
+    CAND(&M->base_prims[0], 0, l + 4, mu_link);                             /*  20     body box vertex (leg, z+)    */
+    for (int v = 4; v < 8; v++) CAND(&lp[1], thigh, v, mu_link);             /*  21-24  thigh box v4..v7             */
+    for (int s2 = 0; s2 < 2; s2++) CAND(&lp[0], hip, s2, mu_link);           /*  25,26  hip cylinder caps            */
+    if (l == 0 || l == 2) CAND(&M->base_prims[l == 0 ? 1 : 2], 0, 0, mu_link); else k++;   /* 27 handle sphere (legs 0, 2) */
+#undef CAND
+    int taken[28] = {0}, nsel = 0;
+    for (int s = 0; s < KC; s++) {          /* the KC deepest (ties: lower index) ... */
+      int best = -1;
+      for (int i = 0; i < 28; i++)
+        if (c[i].valid && !taken[i] && c[i].depth < LLM_CONTACT_MARGIN && (best < 0 || c[i].depth < c[best].depth)) best = i;
+      if (best < 0) break;
+      taken[best] = 1;
+      nsel++;
     }
-    /* base candidates owned by this lane: box vertices j with (j&3)==l, front handle -> lane 0, hind -> lane 2 */
-    n = prim_candidates(&M->base_prims[0], K->Rw[0], K->pw[0], out, n, &nleg, l, 0, mu_link, l);
-    if (l == 0) n = prim_candidates(&M->base_prims[1], K->Rw[0], K->pw[0], out, n, &nleg, l, 0, mu_link, -1);
-    if (l == 2) n = prim_candidates(&M->base_prims[2], K->Rw[0], K->pw[0], out, n, &nleg, l, 0, mu_link, -1);
+    int slot = 0;
+    for (int i = 0; i < 28; i++) {          /* ... stored in candidate-index order, so near-ties in depth cannot reorder the solve */
+      if (!taken[i]) continue;
+      out[n].body = c[i].body; memcpy(out[n].P, c[i].P, 24); out[n].depth = c[i].depth; out[n].mu = c[i].mu;
+      out[n].leg = l; out[n].slot = slot++;
+      n++;
+    }
+    (void)nsel;
   }
   return n;
 }
@@ -768,15 +770,14 @@ int orc_substep_model(const OModel* M, double dt, int n_iter, double mu_foot, do
         A[r][s2] = s;
       }
   }
-  /* projected Gauss-Seidel, LR:261 numSolverIterations (10).  Row order of the spec: limit rows joint-major
-   * (hip of legs 0..3, thigh of legs 0..3, shank of legs 0..3), then per contact slot: the normal rows of legs 0..3,
-   * their t1 rows, their t2 rows. */
+  /* projected Gauss-Seidel, LR:261 numSolverIterations (10).  Row order of the spec: the limit rows
+   * (joint, leg), then all normal rows (slot, leg), all t1 rows, all t2 rows. */
   int order[MAXROWS], no = 0;
   for (int j = 0; j < 3; j++)
     for (int l = 0; l < 4; l++)
       if (lim_row[3 * l + j] >= 0) order[no++] = lim_row[3 * l + j];
-  for (int k = 0; k < KC; k++)
-    for (int r = 0; r < 3; r++)
+  for (int r = 0; r < 3; r++)
+    for (int k = 0; k < KC; k++)
       for (int l = 0; l < 4; l++)
         if (con_row[l][k] >= 0) order[no++] = con_row[l][k] + r;
   double v0[MAXROWS];

@@ -23,16 +23,11 @@ struct HostBackend {
   void d2h(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); }
   void sync() {}
   void launch_step(const StepParams& P) {
-    std::vector<float> lds(LW_COUNT * 4, 0.0f);
-    HostLanes ln(&lds);
-    for (int env = 0; env < P.n_envs; env++) {
-      K::clear_scratch(ln);
-      K::step_env(ln, P, env);
-    }
+    HostLanes ln(P.candc);
+    for (int env = 0; env < P.n_envs; env++) K::step_env(ln, P, env);
   }
   void launch_reset(const StepParams& P, const int32_t* ids, int n, const int32_t* clip, const double* t0) {
-    std::vector<float> lds(LW_COUNT * 4, 0.0f);
-    HostLanes ln(&lds);
+    HostLanes ln(P.candc);
     for (int i = 0; i < n; i++) {
       int env = ids ? ids[i] : i, c;
       double t;
@@ -71,23 +66,22 @@ extern "C" {
 // single physics substep on explicit state (staged comparison with the oracle); tgt = PD target joint angles
 int emu_substep(ll_engine* h, float* state37, const float* tgt12) {
   const StepParams& P = h->e->P;
-  std::vector<float> lds(LW_COUNT * 4, 0.0f);
-  HostLanes ln(&lds);
+  HostLanes ln(P.candc);
   K::Base bs;
   bs.p = mk3<float>(state37[0], state37[1], state37[2]);
   bs.q.x = state37[3]; bs.q.y = state37[4]; bs.q.z = state37[5]; bs.q.w = state37[6];
   bs.v = mk3<float>(state37[7], state37[8], state37[9]);
   bs.w = mk3<float>(state37[10], state37[11], state37[12]);
-  f4 q[3], qd[3], tgt[3];
+  fN q[3], qd[3], tgt[3];
   for (int j = 0; j < 3; j++)
-    for (int l = 0; l < 4; l++) { q[j].v[l] = state37[13 + 3 * l + j]; qd[j].v[l] = state37[25 + 3 * l + j]; tgt[j].v[l] = tgt12[3 * l + j]; }
+    for (int i = 0; i < EW; i++) { int l = i >> 2; q[j].v[i] = state37[13 + 3 * l + j]; qd[j].v[i] = state37[25 + 3 * l + j]; tgt[j].v[i] = tgt12[3 * l + j]; }
   K::substep(ln, P, bs, q, qd, tgt);
   state37[0] = bs.p.x; state37[1] = bs.p.y; state37[2] = bs.p.z;
   state37[3] = bs.q.x; state37[4] = bs.q.y; state37[5] = bs.q.z; state37[6] = bs.q.w;
   state37[7] = bs.v.x; state37[8] = bs.v.y; state37[9] = bs.v.z;
   state37[10] = bs.w.x; state37[11] = bs.w.y; state37[12] = bs.w.z;
   for (int j = 0; j < 3; j++)
-    for (int l = 0; l < 4; l++) { state37[13 + 3 * l + j] = q[j].v[l]; state37[25 + 3 * l + j] = qd[j].v[l]; }
+    for (int l = 0; l < 4; l++) { state37[13 + 3 * l + j] = q[j].v[4 * l]; state37[25 + 3 * l + j] = qd[j].v[4 * l]; }
   return 0;
 }
 }

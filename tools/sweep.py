@@ -10,7 +10,6 @@ for item in sys.argv[1].split(','):
     parts = [int(x) for x in item.split(':')]
     n, epw = parts[0], parts[1]
     iters = parts[2] if len(parts) > 2 else 10
-    os.environ['LL_ENVS_PER_WAVE'] = str(epw)
     cfg = capi.make_config(n, control_freq=50.0, kd=0.5, reward_weights=RW, prop_type=PT, prioritized_sample_factor=3.0, auto_reset=1, seed=1, solver_iterations=iters)
     E = capi.Engine(cfg, blob, table)
     E.reset()
@@ -22,5 +21,5 @@ for item in sys.argv[1].split(','):
         E.fill_random_actions(math.exp(-2)); E.step()
     E.sync(); dt = time.perf_counter() - t0
     ms, k = E.kernel_time_ms()
-    print('iters %2d' % iters, 'n_envs %6d epw %2d blocks %5d kernel %.3f ms  wall/step %.3f ms  -> %.2f M env-steps/s' % (n, epw, (n + epw - 1) // epw, ms, dt / 50 * 1e3, n * 50 / dt / 1e6), flush=True)
+    print('iters %2d' % iters, 'n_envs %6d epw %2d blocks %5d kernel %.3f ms  wall/step %.3f ms  -> %.2f M env-steps/s' % (n, epw, (n + 3) // 4, ms, dt / 50 * 1e3, n * 50 / dt / 1e6), flush=True)
     E.close()
