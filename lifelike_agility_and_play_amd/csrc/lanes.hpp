@@ -163,6 +163,11 @@ struct GpuLanes {
   // the same VGPR needs 2 wait states, hence the leading s_nop 1
   template <int L_>
   static LL_D void fmac_rbcast(F& acc, F x, F k);
+  // same without the wait states: only when x was NOT written by the two preceding instructions
+  template <int L_>
+  static LL_D void fmac_rbcast_settled(F& acc, F x, F k);
+  // returns x after two wait states, so that following DPP reads of the result are hazard free
+  static LL_D F settle(F x) { asm volatile("s_nop 1" : "+v"(x)); return x; }
   static LL_D bool any(B m) { return __any(m); }   // wave-level: guards wave-uniform branches
 
   // ---- constants -------------------------------------------------------------------------------------------------
@@ -186,6 +191,10 @@ struct GpuLanes {
   template <>                                                                                                           \
   LL_D void GpuLanes::fmac_rbcast<L_>(float& acc, float x, float k) {                                                    \
     asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:" #L_ " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(k)); \
+  }                                                                                                                     \
+  template <>                                                                                                           \
+  LL_D void GpuLanes::fmac_rbcast_settled<L_>(float& acc, float x, float k) {                                            \
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #L_ " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(k)); \
   }
 LL_FMAC_RBCAST(0) LL_FMAC_RBCAST(1) LL_FMAC_RBCAST(2) LL_FMAC_RBCAST(3) LL_FMAC_RBCAST(4) LL_FMAC_RBCAST(5) LL_FMAC_RBCAST(6) LL_FMAC_RBCAST(7)
 LL_FMAC_RBCAST(8) LL_FMAC_RBCAST(9) LL_FMAC_RBCAST(10) LL_FMAC_RBCAST(11) LL_FMAC_RBCAST(12) LL_FMAC_RBCAST(13) LL_FMAC_RBCAST(14) LL_FMAC_RBCAST(15)

@@ -230,9 +230,10 @@ struct Pmc {
     F nk[16];      // -(gt . gt_L + [same leg] jt . jt_L) * inv   for L = lane of the env row
   };
   template <int L_>
-  static LL_HD void gram_one(const L& ln, Row& r, const F* nj) {
-    F g = ln.lane_f(0.0f);
-    for (int i = 0; i < 6; i++) L::template fmac_rbcast<L_>(g, r.gt[i], r.gt[i]);
+  static LL_HD void gram_one(const L& ln, Row& r, const F* nj, const F* gs) {
+    // compiler-visible DPP (it schedules around the DPP read-after-write hazard and folds mov_dpp into the FMA where it can)
+    F g = gs[0] * L::template rbcast<L_>(gs[0]);
+    for (int i = 1; i < 6; i++) g = g + gs[i] * L::template rbcast<L_>(gs[i]);
     g = g + lm::sel(ln.is_leg(L_ >> 2), nj[L_ & 3], ln.lane_f(0.0f));
     r.nk[L_] = g * (ln.lane_f(0.0f) - r.inv);
   }
@@ -242,10 +243,13 @@ struct Pmc {
     nj[1] = r.jt[0] * L::template subbcast<1>(r.jt[0]) + r.jt[1] * L::template subbcast<1>(r.jt[1]) + r.jt[2] * L::template subbcast<1>(r.jt[2]);
     nj[2] = r.jt[0] * L::template subbcast<2>(r.jt[0]) + r.jt[1] * L::template subbcast<2>(r.jt[1]) + r.jt[2] * L::template subbcast<2>(r.jt[2]);
     nj[3] = r.jt[0] * L::template subbcast<3>(r.jt[0]) + r.jt[1] * L::template subbcast<3>(r.jt[1]) + r.jt[2] * L::template subbcast<3>(r.jt[2]);
-    gram_one<0>(ln, r, nj); gram_one<1>(ln, r, nj); gram_one<2>(ln, r, nj); gram_one<3>(ln, r, nj);
-    gram_one<4>(ln, r, nj); gram_one<5>(ln, r, nj); gram_one<6>(ln, r, nj); gram_one<7>(ln, r, nj);
-    gram_one<8>(ln, r, nj); gram_one<9>(ln, r, nj); gram_one<10>(ln, r, nj); gram_one<11>(ln, r, nj);
-    gram_one<12>(ln, r, nj); gram_one<13>(ln, r, nj); gram_one<14>(ln, r, nj); gram_one<15>(ln, r, nj);
+    // the DPP reads below must not follow the write of their source by less than two instructions: take copies first
+    F gs[6];
+    for (int i = 0; i < 6; i++) gs[i] = r.gt[i];
+    gram_one<0>(ln, r, nj, gs); gram_one<1>(ln, r, nj, gs); gram_one<2>(ln, r, nj, gs); gram_one<3>(ln, r, nj, gs);
+    gram_one<4>(ln, r, nj, gs); gram_one<5>(ln, r, nj, gs); gram_one<6>(ln, r, nj, gs); gram_one<7>(ln, r, nj, gs);
+    gram_one<8>(ln, r, nj, gs); gram_one<9>(ln, r, nj, gs); gram_one<10>(ln, r, nj, gs); gram_one<11>(ln, r, nj, gs);
+    gram_one<12>(ln, r, nj, gs); gram_one<13>(ln, r, nj, gs); gram_one<14>(ln, r, nj, gs); gram_one<15>(ln, r, nj, gs);
     r.lam = ln.lane_f(0.0f);
   }
   template <int K_>

@@ -88,6 +88,8 @@ struct HostLanes {
   template <int K_> static F subbcast(const F& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = x.v[(i & ~3) | K_]; return r; }
   template <int LEG_> static float bcast(const F& x) { return x.v[4 * LEG_]; }
   template <int L_> static void fmac_rbcast(F& acc, const F& x, const F& k) { for (int i = 0; i < EW; i++) acc.v[i] = acc.v[i] + x.v[L_] * k.v[i]; }
+  template <int L_> static void fmac_rbcast_settled(F& acc, const F& x, const F& k) { fmac_rbcast<L_>(acc, x, k); }
+  static F settle(const F& x) { return x; }
   static bool any(const B& m) { for (int i = 0; i < EW; i++) if (m.v[i]) return true; return false; }
   F legc(const float* tbl, int field) const { fN r; for (int i = 0; i < EW; i++) r.v[i] = tbl[field * 4 + (i >> 2)]; return r; }
   F candc(int word) const { fN r; for (int i = 0; i < EW; i++) r.v[i] = candc_[word * 16 + i]; return r; }
