@@ -163,6 +163,12 @@ typedef struct ll_device_ptrs_t {
 } ll_device_ptrs_t;
 int ll_device_ptrs(ll_engine* e, ll_device_ptrs_t* out);
 
+/* Trajectory ring for the learner hand-off (replaces the actor's unroll buffer, learning/actors/distill_actor.py:84-176):
+ * from now on every ll_step also writes, into slot (step index mod unroll) of a device buffer [unroll][n_envs][row_floats],
+ * the row  obs_t[obs_dim] | action_t[12] | reward_t | done_t  of the transition it computes (obs_t = the observation the
+ * action was chosen on).  Returns the device buffer (owned by the engine) and row_floats = obs_dim + 14. */
+int ll_enable_trajectory(ll_engine* e, int unroll, float** d_buffer, int* row_floats);
+
 /* Host copies (synchronise the stream first). */
 int ll_get_obs(ll_engine* e, float* h_obs /*[n_envs][obs_dim]*/);
 int ll_get_terminal_obs(ll_engine* e, float* h_obs /*[n_envs][obs_dim]*/);

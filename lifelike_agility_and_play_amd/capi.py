@@ -81,6 +81,7 @@ _SIGS = {
     'll_fill_random_actions': (C.c_int, [C.c_void_p, C.c_float]),
     'll_sync': (C.c_int, [C.c_void_p]),
     'll_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'll_enable_trajectory': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     'll_device_ptrs': (C.c_int, [C.c_void_p, C.POINTER(LLDevicePtrs)]),
     'll_get_obs': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_get_terminal_obs': (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -184,6 +185,12 @@ class Engine(object):
 
     def set_stream(self, stream_handle):
         self._chk(self.lib.ll_set_stream(self.h, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def enable_trajectory(self, unroll):
+        """-> (device address, row_floats) of the [unroll][n_envs][row_floats] ring written by every step"""
+        buf, w = C.c_void_p(), C.c_int()
+        self._chk(self.lib.ll_enable_trajectory(self.h, int(unroll), C.byref(buf), C.byref(w)))
+        return buf.value, w.value
 
     def device_ptrs(self):
         p = LLDevicePtrs()

@@ -182,6 +182,8 @@ struct GpuLanes {
   LL_D void stl(float* p, long base, long stride, F v) const { if (sub_ == 0) p[base + stride * leg_] = v; }
   LL_D void stl_if(B m, float* p, long base, long stride, F v) const { if (m && sub_ == 0) p[base + stride * leg_] = v; }
   LL_D D lddl(const double* p, long base, long stride) const { return p[base + stride * leg_]; }
+  // cooperative copy of up to 16 consecutive floats: lane i moves element i0 + i (if below n)
+  LL_D void copy16(float* dst, const float* src, int i0, int n) const { const int i = i0 + lane16_; if (i < n) dst[i] = src[i]; }
   static LL_D F d2f(D x) { return (float)x; }
   static LL_D F i2f(I x) { return (float)x; }
   static LL_D I f2i(F x) { return (int)x; }

@@ -24,6 +24,8 @@ struct PmcEngine {
   // table state (device, float64)
   double *d_avg_reward = nullptr, *d_avg_len = nullptr, *d_prob = nullptr, *d_cdf = nullptr;
   float* d_actions = nullptr;       // engine-owned action buffer
+  float* d_traj = nullptr;          // optional trajectory ring [unroll][n_envs][obs_dim + 14]
+  int traj_unroll = 0;
   int32_t* d_reset_ids = nullptr;   // scratch for ll_reset
   int32_t* d_reset_clip = nullptr;
   double* d_reset_t0 = nullptr;
@@ -151,10 +153,19 @@ struct PmcEngine {
     need(true, true);
     StepParams Q = P;
     Q.actions = d_act ? d_act : d_actions;
+    Q.traj = d_traj;
+    Q.traj_slot = traj_unroll ? (int)(P.step_count % (uint64_t)traj_unroll) : 0;
     if (!table_fresh) bk.launch_prestep(P, d_avg_reward, d_avg_len, d_prob, d_cdf, nullptr, 0.0f);
     bk.launch_step(Q);
     table_fresh = false;                 // the step may have published new episode statistics
     P.step_count += 1;
+  }
+  // keep the last `unroll` transitions of every env in HBM, in the layout the learner rank gathers
+  void enable_trajectory(int unroll) {
+    if (unroll <= 0) throw PmcError(LL_EINVAL, "unroll must be positive");
+    if (d_traj) throw PmcError(LL_ESTATE, "trajectory ring already enabled");
+    d_traj = dalloc<float>((size_t)unroll * P.n_envs * (P.obs_dim + 14));
+    traj_unroll = unroll;
   }
   void fill_random_actions(float sigma) {
     need(true, false);

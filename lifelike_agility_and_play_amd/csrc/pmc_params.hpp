@@ -81,6 +81,8 @@ struct StepParams {
   uint8_t* done;            // [n_envs]
   uint8_t* done_reason;     // [n_envs]
   const float* actions;     // [n_envs][12]
+  float* traj;              // optional [unroll][n_envs][obs_dim + 14] trajectory ring: obs_t | action_t | reward_t | done_t
+  int32_t traj_slot, traj_pad;
   // mocap
   const double* frames;     // [total][19]
   const int32_t* clip_off;

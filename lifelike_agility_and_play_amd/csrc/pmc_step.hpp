@@ -857,6 +857,17 @@ struct Pmc {
     const int steps = P.ep_steps[env] + 1;                                    // PLE:197
     const float rsum = P.reward_sum[env] + reward;                            // PLE:231
 
+    // --- trajectory row for the learner: the observation the policy acted on, its action, the reward
+    //     and done flag of this transition; written before the obs row is replaced ---
+    if (P.traj) {
+      const int W = P.obs_dim + 14;
+      float* tr = P.traj + ((long)P.traj_slot * N + env) * W;
+      for (int i0 = 0; i0 < P.obs_dim; i0 += PMC_ROW) ln.copy16(tr, row, i0, P.obs_dim);
+      for (int j = 0; j < 3; j++) ln.stl(tr, P.obs_dim + j, 3, act[j]);
+      tr[P.obs_dim + 12] = reward;
+      tr[P.obs_dim + 13] = reason ? 1.0f : 0.0f;
+    }
+
     // --- observation: into term_obs when the episode ends under auto-reset, else in place ---
     float* out_row = (reason && ar) ? (P.term_obs + (long)env * P.obs_dim) : row;
     write_obs(ln, P, env, out_row, row, false, bs, R, q, qd, act, rows, fid, frac);               // PLE:227

@@ -58,15 +58,14 @@ def gather_unroll(local, dst=0, group=None):
 
 
 class TrajectoryBuffer(object):
-    def __init__(self, engine, unroll):
-        self.t = engine_tensors(engine)
-        n, od = self.t['obs'].shape
-        self.unroll = unroll
-        self.buf = torch.empty((unroll, n, od + 14), dtype=torch.float32, device=self.t['obs'].device)
-        self.last = None
+    """The engine's own trajectory ring ([unroll][n_envs][obs|action|reward|done], written inside the step kernel)
+    as a torch tensor, plus the gather to the learner rank."""
 
-    def record(self, t):
-        pack_rows(self.t['obs'], self.t['actions'], self.t['reward'], self.t['done'], self.buf[t])
+    def __init__(self, engine, unroll):
+        ptr, w = engine.enable_trajectory(unroll)
+        self.unroll = unroll
+        self.buf = device_tensor(ptr, (unroll, engine.n_envs, w))
+        self.last = None
 
     def gather_to(self, dst=0):
         self.last = gather_unroll(self.buf, dst)

@@ -98,6 +98,7 @@ struct HostLanes {
   F ldl(const float* p, long base, long stride) const { fN r; for (int i = 0; i < EW; i++) r.v[i] = p[base + stride * (i >> 2)]; return r; }
   void stl(float* p, long base, long stride, const F& v) const { for (int i = 0; i < EW; i += 4) p[base + stride * (i >> 2)] = v.v[i]; }
   void stl_if(const B& m, float* p, long base, long stride, const F& v) const { for (int i = 0; i < EW; i += 4) if (m.v[i]) p[base + stride * (i >> 2)] = v.v[i]; }
+  void copy16(float* dst, const float* src, int i0, int n) const { for (int i = i0; i < i0 + EW && i < n; i++) dst[i] = src[i]; }
   D lddl(const double* p, long base, long stride) const { dN r; for (int i = 0; i < EW; i++) r.v[i] = p[base + stride * (i >> 2)]; return r; }
   static F d2f(const D& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = (float)x.v[i]; return r; }
   static F i2f(const I& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = (float)x.v[i]; return r; }

@@ -207,3 +207,28 @@ def check_trained_policy_tracks(lib_path, n_envs=16, n_steps=200, seed=7):
     assert ok.mean() >= 0.75, (ok, why)
     assert mean_r > 0.7, mean_r
     return dict(mean_reward=mean_r, tracked=ok.mean(), steps=steps, why=why)
+
+
+def check_trajectory_ring(model_blob, table, lib_path, read_ring):
+    """ll_enable_trajectory: every step writes  obs_t | action_t | reward_t | done_t  into slot (step mod unroll).
+    read_ring(address, shape) -> numpy copy of the ring (host memory for the emulation library, device memory on a GPU)."""
+    n, unroll = 24, 4
+    E = make_engine(model_blob, table, n, lib_path, auto_reset=1, seed=5)
+    E.reset()
+    ptr, w = E.enable_trajectory(unroll)
+    assert w == E.obs_dim + 14
+    rng = np.random.default_rng(0)
+    prev_obs = E.obs()
+    for t in range(7):
+        act = (rng.normal(size=(n, 12)) * 0.5).astype(np.float32)
+        E.step_host(act)
+        r, d, _ = E.reward_done()
+        E.sync()
+        ring = read_ring(ptr, (unroll, n, w))
+        row = ring[t % unroll]
+        np.testing.assert_array_equal(row[:, :E.obs_dim], prev_obs)           # the observation the action was chosen on
+        np.testing.assert_array_equal(row[:, E.obs_dim:E.obs_dim + 12], act)
+        np.testing.assert_array_equal(row[:, E.obs_dim + 12], r)
+        np.testing.assert_array_equal(row[:, E.obs_dim + 13], d.astype(np.float32))
+        prev_obs = E.obs()
+    E.close()

@@ -26,9 +26,14 @@ def test_batched_env_zero_copy_torch(golden):
     r, d, _ = env.engine.reward_done()
     np.testing.assert_array_equal(t['reward'].cpu().numpy(), r)
     np.testing.assert_allclose(t['obs'][:, 123:135].cpu().numpy(), act.cpu().numpy(), rtol=1e-6)   # newest action in prop_a
-    buf = gather.TrajectoryBuffer(env.engine, 4)
-    buf.record(0)
-    torch.cuda.synchronize()
-    np.testing.assert_array_equal(buf.buf[0, :, :207].cpu().numpy(), env.engine.obs())
-    np.testing.assert_array_equal(buf.buf[0, :, 219].cpu().numpy(), r)
     env.close()
+
+
+def test_trajectory_ring_gpu(model_blob, mocap_table):
+    import torch
+    import parity_common as pc
+    from lifelike_agility_and_play_amd import gather
+
+    def read_ring(addr, shape):
+        return gather.device_tensor(addr, shape).cpu().numpy()
+    pc.check_trajectory_ring(model_blob, mocap_table, None, read_ring)

@@ -37,3 +37,11 @@ def test_contact_rich_parity(golden, orc, model_blob, mocap_table, emul_lib):
 def test_trained_reference_policy_tracks_in_our_simulator(emul_lib):
     out = pc.check_trained_policy_tracks(emul_lib)
     print('trained PMC policy: mean reward/step %.3f, tracked %.0f%%' % (out['mean_reward'], 100 * out['tracked']))
+
+
+def test_trajectory_ring(model_blob, mocap_table, emul_lib):
+    import ctypes
+    def read_ring(addr, shape):
+        n = int(np.prod(shape))
+        return np.ctypeslib.as_array((ctypes.c_float * n).from_address(addr)).reshape(shape).copy()
+    pc.check_trajectory_ring(model_blob, mocap_table, emul_lib, read_ring)
