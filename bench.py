@@ -82,10 +82,15 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
+    # test hooks (a 1-GPU box cannot host two RCCL ranks): LL_BENCH_BACKEND=gloo LL_BENCH_ONE_DEVICE=1 runs the N>1
+    # control flow with every rank on device 0 and the gather staged through host memory
+    backend = os.environ.get('LL_BENCH_BACKEND', 'nccl')
+    if os.environ.get('LL_BENCH_ONE_DEVICE'):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     n = args.envs_per_gpu
     blob = urdf_model.default_model_blob()

@@ -49,6 +49,8 @@ def gather_unroll(local, dst=0, group=None):
     """Gather every rank's [unroll][n_envs][row] block to rank `dst`; returns [world][unroll][n_envs][row] there, else None."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if local.is_cuda and dist.get_backend(group) == 'gloo':     # test configuration only: gloo gathers host tensors
+        local = local.cpu()
     if rank == dst:
         outs = [torch.empty_like(local) for _ in range(world)]
         dist.gather(local, gather_list=outs, dst=dst, group=group)
