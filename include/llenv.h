@@ -120,6 +120,15 @@ int ll_load_mocap(ll_engine* e, const float* h_frames, const int32_t* h_clip_len
 int ll_load_mocap_f64(ll_engine* e, const double* h_frames, const int32_t* h_clip_len, int n_clips, double frame_step);
 
 /*
+ * Jump obstacles (only used when ll_config.set_obstacle != 0): replaces utils/obstacle.py:6-33 as consumed at
+ * PLE:173-193 (_create_obstacle) and PLE:262-268 (_update_obstacle).  h_count[n_clips] obstacles per clip,
+ * h_table[sum(count)][4] = x, y, yaw, peak time (float64).  The box is 0.05 x 1.0 x 2*obstacle_height, centred on the
+ * ground (PLE:184-193).  The engine uses it for the termination test of PLE:341-346 only (any robot shape within the
+ * contact distance of the box ends the episode); see DESIGN.md for the missing physical response.
+ */
+int ll_load_obstacles(ll_engine* e, const int32_t* h_count, const double* h_table, int n_clips);
+
+/*
  * Reset environments: PLE:150-171 + ML:48-63.
  *   h_env_ids   NULL = all n_envs, else n ids
  *   h_clip_idx  NULL = sample from the prioritized table (ML:59-63) with the engine's Philox stream

@@ -76,6 +76,7 @@ _SIGS = {
     'll_destroy': (C.c_int, [C.c_void_p]),
     'll_load_mocap': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]),
     'll_load_mocap_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]),
+    'll_load_obstacles': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     'll_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'll_step': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_fill_random_actions': (C.c_int, [C.c_void_p, C.c_float]),
@@ -139,6 +140,10 @@ class Engine(object):
             self._chk(self.lib.ll_load_mocap(self.h, _ptr(frames), _ptr(clip_len), len(clip_len), float(mocap_table.frame_step)))
         self.n_envs = cfg.n_envs
         self.n_clips = len(clip_len)
+        if cfg.set_obstacle:                                   # PLE:159-160 / utils/obstacle.py
+            cnt, tab = mocap_table.obstacles()
+            tab = np.ascontiguousarray(tab, dtype=np.float64)
+            self._chk(self.lib.ll_load_obstacles(self.h, _ptr(cnt), _ptr(tab) if len(tab) else None, len(cnt)))
         p = self.device_ptrs()
         self.obs_dim = p.obs_dim
 

@@ -111,9 +111,33 @@ struct PmcEngine {
     have_mocap = true;
   }
 
+  // utils/obstacle.py:6-33 tables, computed by the host (scipy find_peaks, as the reference does)
+  bool have_obstacles = false;
+  void load_obstacles(const int32_t* count, const double* table, int n_clips) {
+    need(true, false);
+    if (n_clips != P.n_clips) throw PmcError(LL_EINVAL, "obstacle table does not match the clip table");
+    std::vector<int32_t> off(n_clips);
+    int total = 0;
+    for (int c = 0; c < n_clips; c++) {
+      if (count[c] < 0) throw PmcError(LL_EINVAL, "negative obstacle count");
+      off[c] = total;
+      total += count[c];
+    }
+    int32_t* doff = dalloc<int32_t>(n_clips);
+    int32_t* dcnt = dalloc<int32_t>(n_clips);
+    double* dtab = dalloc<double>((size_t)(total > 0 ? total : 1) * 4);
+    bk.h2d(doff, off.data(), n_clips * 4);
+    bk.h2d(dcnt, count, n_clips * 4);
+    if (total > 0) bk.h2d(dtab, table, (size_t)total * 4 * 8);
+    P.ob_off = doff; P.ob_cnt = dcnt; P.ob_table = dtab;
+    P.ob_id = dalloc<int32_t>(P.n_envs);
+    have_obstacles = true;
+  }
+
   void need(bool mocap, bool reset) const {
     if (mocap && !have_mocap) throw PmcError(LL_ESTATE, "ll_load_mocap must be called first");
     if (reset && !have_reset) throw PmcError(LL_ESTATE, "ll_reset must be called before ll_step");
+    if (reset && P.set_obstacle && !have_obstacles) throw PmcError(LL_ESTATE, "set_obstacle needs ll_load_obstacles");
   }
 
   // PLE:150-171
@@ -143,6 +167,7 @@ struct PmcEngine {
       }
       bk.h2d(d_reset_t0, t0, n * 8);
     }
+    if (P.set_obstacle && !have_obstacles) throw PmcError(LL_ESTATE, "set_obstacle needs ll_load_obstacles");
     bk.launch_prestep(P, d_avg_reward, d_avg_len, d_prob, d_cdf, nullptr, 0.0f);   // fold pending statistics first
     bk.launch_reset(P, env_ids ? d_reset_ids : nullptr, n, clip ? d_reset_clip : nullptr, t0 ? d_reset_t0 : nullptr);
     have_reset = true;

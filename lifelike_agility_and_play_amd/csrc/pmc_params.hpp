@@ -89,6 +89,13 @@ struct StepParams {
   const int32_t* clip_len;
   const double* max_steps;  // [n_clips]
   const double* cdf;        // [n_clips] inclusive prefix sums of the sampling probabilities
+  // jump obstacles (set_obstacle): per clip offset/count into ob_table[total][4] = x, y, yaw, peak time
+  const int32_t* ob_off;
+  const int32_t* ob_cnt;
+  const double* ob_table;
+  int32_t* ob_id;           // [n_envs] current obstacle of the episode (PLE:179,:264-265)
+  float ob_half_height, ob_pad;
+  int32_t set_obstacle, ob_pad2;
   unsigned long long* pending_reward;  // [n_clips] packed (env+1)<<32 | float bits of reward_sum/max_steps
   unsigned long long* pending_len;     // [n_clips] packed (env+1)<<32 | float bits of avg_episode_len
   unsigned long long* counters;        // [4] env-steps, episodes, non-finite resets, -

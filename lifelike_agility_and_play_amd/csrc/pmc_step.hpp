@@ -24,6 +24,7 @@
 #define LLS_DONE_FALL 1
 #define LLS_DONE_CLIP_END 2
 #define LLS_DONE_DIVERGED 4
+#define LLS_DONE_COLLISION 8
 #define LLS_DONE_NONFINITE 16
 
 // PLE:235-240 for the batch: fold the statistics published by finished episodes into the per-clip table and rebuild
@@ -767,6 +768,50 @@ struct Pmc {
     P.clip[env] = clip;
     P.ep_steps[env] = 0;
     P.reward_sum[env] = 0.0f;
+    if (P.set_obstacle) P.ob_id[env] = 0;                                     // PLE:179
+  }
+
+  // PLE:262-268 + PLE:341-346 for the batch: advance the episode's obstacle, then test the robot's collision shapes against
+  // the box (0.05 x 1.0 x 2h, centred on the ground at the peak's (x, y), yawed to the mocap heading).  Shapes are
+  // represented by their candidate points: box vertices, sphere centres and cylinder cap centres with their radius.
+  static LL_HD bool obstacle_contact(const L& ln, const StepParams& P, int env, int clip, double t, const V3u& p, const M3<float>& R,
+                                     const LegKin& k) {
+    const int oc = P.ob_cnt[clip];
+    if (oc <= 0) return false;                                          // PLE:342 `self._obstacle is not None`
+    const double* tab = P.ob_table + (long)P.ob_off[clip] * 4;
+    int ob = P.ob_id[env];
+    while (ob < oc - 1 && t > tab[ob * 4 + 3] + 0.5) ob++;              // PLE:264-265
+    P.ob_id[env] = ob;
+    const float cx = (float)tab[ob * 4 + 0], cy = (float)tab[ob * 4 + 1], yaw = (float)tab[ob * 4 + 2];
+    const float cyaw = cosf(yaw), syaw = sinf(yaw), hx = 0.025f, hy = 0.5f, hz = P.ob_half_height;   // PLE:184
+    F zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f);
+    B sub_lt2 = L::i2f(ln.sub()) < 1.5f, sub_lt3 = L::i2f(ln.sub()) < 2.5f, sub_0 = L::i2f(ln.sub()) < 0.5f;
+    // link frames of the three candidate groups of this sub-lane (A: [3,3,2,2], B: [2,2,2,1], C: [3,0,0,0])
+    M3<F> gR[3];
+    V3l gp[3];
+    for (int i = 0; i < 9; i++) {
+      gR[0].m[i] = lm::sel(sub_lt2, k.R3.m[i], k.R2.m[i]);
+      gR[1].m[i] = lm::sel(sub_lt3, k.R2.m[i], k.R1.m[i]);
+      gR[2].m[i] = lm::sel(sub_0, k.R3.m[i], ln.lane_f((i % 4 == 0) ? 1.0f : 0.0f));
+    }
+    gp[0] = mk3<F>(lm::sel(sub_lt2, k.p3.x, k.p2.x), lm::sel(sub_lt2, k.p3.y, k.p2.y), lm::sel(sub_lt2, k.p3.z, k.p2.z));
+    gp[1] = mk3<F>(lm::sel(sub_lt3, k.p2.x, k.p1.x), lm::sel(sub_lt3, k.p2.y, k.p1.y), lm::sel(sub_lt3, k.p2.z, k.p1.z));
+    gp[2] = mk3<F>(lm::sel(sub_0, k.p3.x, zero), lm::sel(sub_0, k.p3.y, zero), lm::sel(sub_0, k.p3.z, zero));
+    F hit = zero;
+    for (int jj = 0; jj < 7; jj++) {
+      const int g = jj < 4 ? 0 : (jj < 6 ? 1 : 2);
+      V3l A = mk3<F>(ln.candc(jj * CF_WORDS + CF_A), ln.candc(jj * CF_WORDS + CF_A + 1), ln.candc(jj * CF_WORDS + CF_A + 2));
+      F r = ln.candc(jj * CF_WORDS + CF_R), link = ln.candc(jj * CF_WORDS + CF_LINK);
+      V3l Pb = gp[g] + mul(gR[g], A);
+      V3l Pw = mul(R, Pb);
+      F dxw = Pw.x + (p.x - cx), dyw = Pw.y + (p.y - cy), lz = Pw.z + p.z;
+      F lx = dxw * cyaw + dyw * syaw, ly = dyw * cyaw - dxw * syaw;
+      F qx = lm::abs_(lx) - hx, qy = lm::abs_(ly) - hy, qz = lm::abs_(lz) - hz;
+      F ox = lm::max_(qx, zero), oy = lm::max_(qy, zero), oz = lm::max_(qz, zero);
+      F sdf = lm::sqrt_(ox * ox + oy * oy + oz * oz) + lm::min_(lm::max_(qx, lm::max_(qy, qz)), zero);
+      hit = lm::sel(lm::and_(sdf - r < P.margin_dist, link > -0.5f), one, hit);
+    }
+    return L::qsum(L::subsum(hit)) > 0.5f;
   }
 
   // sample (clip, t0) for a new episode: ML:59-63 + ML:50-51, Philox stream keyed on (seed; env, episode)
@@ -853,6 +898,10 @@ struct Pmc {
       if (fid >= P.clip_len[clip] - P.margin - 1) reason |= LLS_DONE_CLIP_END;   // ML:168-172
       if (fabsf(angle) > 1.0f || e_p > 1.0f) reason |= LLS_DONE_DIVERGED;     // PLE:319-335
       if (bad) reason |= LLS_DONE_NONFINITE;
+      if (P.set_obstacle && !bad) {
+        LegKin kf = leg_fk(ln, P.legc, q[0], q[1], q[2]);
+        if (obstacle_contact(ln, P, env, clip, t, bs.p, R, kf)) reason |= LLS_DONE_COLLISION;   // PLE:341-346
+      }
     }
     const int steps = P.ep_steps[env] + 1;                                    // PLE:197
     const float rsum = P.reward_sum[env] + reward;                            // PLE:231

@@ -201,6 +201,8 @@ static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
   P.prop_dim = off;
   P.obs_dim = LL_STACK * off + LL_STACK * 12 + LL_FUTURE_DIM;           // PLE:114-121
   P.sample_factor = cfg.prioritized_sample_factor;
+  P.set_obstacle = cfg.set_obstacle ? 1 : 0;
+  P.ob_half_height = (float)cfg.obstacle_height;                          // PLE:184 halfExtents z
   P.seed = cfg.seed;
   return "";
 }

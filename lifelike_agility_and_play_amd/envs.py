@@ -50,9 +50,6 @@ def _build_engine(env_config, num_envs, auto_reset):
         assert isinstance(video_path, str) and video_path.endswith('.mp4')  # PLE:54
     if enable_render or video_path is not None:
         warnings.warn('render / video_path are ignored: the batched engine has no GUI (PLE:58-60 is PyBullet-only)')
-    if set_obstacle:
-        raise NotImplementedError('set_obstacle=True (the jump-obstacle variant of PMC, PLE:173-193,:262-268,:341-346) is a '
-                                  '"next" row of SURVEY.md 8f and is not built yet; flat-terrain configs pass set_obstacle=False')
     if not isinstance(prop_type, list):
         raise TypeError("Expected 'prop_type' to be a list.")                # PLE:113
     if isinstance(max_tau, (list, tuple)):                                  # LR:244 draws once at construction;

@@ -133,6 +133,10 @@ class OracleBatch(object):
         lib().orc_load_mocap(self.h, _p(fr), cl.ctypes.data_as(ip), C.c_int(len(cl)), C.c_double(mocap_table.frame_step))
         self.n_envs = cfg.n_envs
         self.n_clips = len(cl)
+        if cfg.set_obstacle:
+            cnt, tab = mocap_table.obstacles()
+            tab = f64(tab)
+            lib().orc_load_obstacles(self.h, np.ascontiguousarray(cnt, dtype=np.int32).ctypes.data_as(ip), _p(tab), C.c_int(len(cnt)))
         self.obs_dim = lib().orc_obs_dim(self.h)
 
     def __del__(self):

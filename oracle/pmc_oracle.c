@@ -829,7 +829,7 @@ int orc_substep_model(const OModel* M, double dt, int n_iter, double mu_foot, do
 typedef struct {
   double state[37], kin[37], time, reward_sum, frac;
   double hist_prop[LL_STACK][LL_PROP_FRAME_MAX], hist_act[LL_STACK][12];
-  int hist_n, clip, frame_id, ep_steps, done_reason;
+  int hist_n, clip, frame_id, ep_steps, done_reason, ob_id;
   double feet_dyn[12], feet_kin[12];
 } OEnv;
 
@@ -841,6 +841,8 @@ typedef struct {
   double* frames;     /* [total][19] */
   int32_t *clip_off, *clip_len;
   double *max_steps, *prob, *avg_reward_sum, *avg_episode_len;
+  int32_t *ob_off, *ob_cnt;   /* jump obstacles per clip (utils/obstacle.py), table rows = x, y, yaw, peak time */
+  double* ob_table;
   OEnv* envs;
 } OBatch;
 
@@ -865,7 +867,7 @@ OBatch* orc_create(const ll_config* cfg, const double* blob, int blob_len) {
 void orc_destroy(OBatch* B) {
   if (!B) return;
   free(B->frames); free(B->clip_off); free(B->clip_len); free(B->max_steps); free(B->prob);
-  free(B->avg_reward_sum); free(B->avg_episode_len); free(B->envs); free(B);
+  free(B->avg_reward_sum); free(B->avg_episode_len); free(B->ob_off); free(B->ob_cnt); free(B->ob_table); free(B->envs); free(B);
 }
 
 int orc_obs_dim(const OBatch* B) { return B->obs_dim; }
@@ -893,6 +895,71 @@ int orc_load_mocap(OBatch* B, const double* frames, const int32_t* clip_len, int
 }
 
 static const double* clip_row(const OBatch* B, int clip, int fid) { return B->frames + ((size_t)B->clip_off[clip] + fid) * 19; }
+
+/* utils/obstacle.py:6-33 tables (computed by the host with scipy find_peaks, exactly as the reference does) */
+int orc_load_obstacles(OBatch* B, const int32_t* count, const double* table, int n_clips) {
+  if (n_clips != B->n_clips) return LL_EINVAL;
+  B->ob_off = (int32_t*)malloc(n_clips * 4); B->ob_cnt = (int32_t*)malloc(n_clips * 4);
+  int total = 0;
+  for (int c = 0; c < n_clips; c++) { B->ob_off[c] = total; B->ob_cnt[c] = count[c]; total += count[c]; }
+  B->ob_table = (double*)malloc((total > 0 ? total : 1) * 4 * sizeof(double));
+  if (total > 0) memcpy(B->ob_table, table, (size_t)total * 4 * sizeof(double));
+  return 0;
+}
+
+/* PLE:262-268 + PLE:341-346: advance the episode's obstacle, then test the robot's collision shapes against the box
+ * (PLE:184: half extents 0.025, 0.5, obstacle_height; PLE:191: centred on the ground at the peak's x, y; yawed).
+ * DESIGN.md "jump obstacle": shapes are represented by box vertices, sphere centres and cylinder cap centres with their
+ * radius; contact = within the contact margin (what getContactPoints reports). */
+static double box_sdf(const double* P, double cx, double cy, double yaw, double hz) {
+  double c = cos(yaw), s = sin(yaw), dx = P[0] - cx, dy = P[1] - cy;
+  double lx = dx * c + dy * s, ly = dy * c - dx * s, lz = P[2];
+  double qx = fabs(lx) - 0.025, qy = fabs(ly) - 0.5, qz = fabs(lz) - hz;
+  double ox = qx > 0 ? qx : 0, oy = qy > 0 ? qy : 0, oz = qz > 0 ? qz : 0;
+  double m = qx > qy ? qx : qy;
+  if (qz > m) m = qz;
+  return sqrt(ox * ox + oy * oy + oz * oz) + (m < 0 ? m : 0);
+}
+static int prim_hits_box(const OPrim* p, const double* Rw, const double* pw, double cx, double cy, double yaw, double hz) {
+  double ctr[3], t[3], Rp[9];
+  m3v(Rw, p->pos, t);
+  for (int i = 0; i < 3; i++) ctr[i] = pw[i] + t[i];
+  m3m(Rw, p->rot, Rp);
+  if (p->type == LLM_PRIM_SPHERE) return box_sdf(ctr, cx, cy, yaw, hz) - p->size[0] < LLM_CONTACT_MARGIN;
+  if (p->type == LLM_PRIM_BOX) {
+    for (int v = 0; v < 8; v++) {
+      double l[3] = {(v & 1) ? p->size[0] : -p->size[0], (v & 2) ? p->size[1] : -p->size[1], (v & 4) ? p->size[2] : -p->size[2]}, P[3];
+      m3v(Rp, l, P);
+      for (int i = 0; i < 3; i++) P[i] += ctr[i];
+      if (box_sdf(P, cx, cy, yaw, hz) < LLM_CONTACT_MARGIN) return 1;
+    }
+    return 0;
+  }
+  for (int s2 = 0; s2 < 2; s2++) {
+    double P[3];
+    for (int i = 0; i < 3; i++) P[i] = ctr[i] + (s2 ? -1.0 : 1.0) * p->size[1] * Rp[3 * i + 2];
+    if (box_sdf(P, cx, cy, yaw, hz) - p->size[0] < LLM_CONTACT_MARGIN) return 1;
+  }
+  return 0;
+}
+static int obstacle_contact(OBatch* B, OEnv* e) {
+  int oc = B->ob_cnt ? B->ob_cnt[e->clip] : 0;
+  if (oc <= 0) return 0;
+  const double* tab = B->ob_table + (size_t)B->ob_off[e->clip] * 4;
+  while (e->ob_id < oc - 1 && e->time > tab[e->ob_id * 4 + 3] + 0.5) e->ob_id++;          /* PLE:264-265 */
+  double cx = tab[e->ob_id * 4], cy = tab[e->ob_id * 4 + 1], yaw = tab[e->ob_id * 4 + 2], hz = B->cfg.obstacle_height;
+  OKin K;
+  kinematics(&B->model, e->state, NULL, &K);
+  static const int links[LLM_N_LEG_PRIMS] = LLM_LEG_PRIM_LINKS;
+  for (int i = 0; i < LLM_N_BASE_PRIMS; i++)
+    if (prim_hits_box(&B->model.base_prims[i], K.Rw[0], K.pw[0], cx, cy, yaw, hz)) return 1;
+  for (int l = 0; l < 4; l++)
+    for (int i = 0; i < LLM_N_LEG_PRIMS; i++) {
+      int body = 1 + 3 * l + links[i];
+      if (prim_hits_box(&B->model.leg_prims[l][i], K.Rw[body], K.pw[body], cx, cy, yaw, hz)) return 1;
+    }
+  return 0;
+}
 
 /* PLE:276-297 _prepare_obs */
 static void prepare_obs(OBatch* B, OEnv* e, const double* action, double* obs) {
@@ -922,7 +989,7 @@ static void prepare_obs(OBatch* B, OEnv* e, const double* action, double* obs) {
 int orc_reset_env(OBatch* B, int env, int clip, double t0, double* obs_out) {
   if (env < 0 || env >= B->n_envs || clip < 0 || clip >= B->n_clips) return LL_EINVAL;
   OEnv* e = &B->envs[env];
-  e->clip = clip; e->time = t0; e->reward_sum = 0; e->ep_steps = 0; e->hist_n = 0; e->done_reason = 0;
+  e->clip = clip; e->time = t0; e->reward_sum = 0; e->ep_steps = 0; e->hist_n = 0; e->done_reason = 0; e->ob_id = 0;   /* PLE:179 */
   orc_mocap_locate(t0, B->frame_step, &e->frame_id, &e->frac);                              /* ML:52-53 */
   orc_mocap_interp(clip_row(B, clip, e->frame_id), clip_row(B, clip, e->frame_id + 1), e->frac, B->frame_step, e->kin);
   memcpy(e->state, e->kin, sizeof e->kin);                                                  /* PLE:162-163 */
@@ -974,6 +1041,7 @@ int orc_step_env(OBatch* B, int env, const double* action, const double* scripte
   if (e->frame_id >= B->clip_len[e->clip] - B->margin - 1) reason |= LL_DONE_CLIP_END;          /* PLE:339, ML:168-172 */
   if (orc_check_diverged(e->state, e->kin)) reason |= LL_DONE_DIVERGED;                         /* PLE:340 */
   if (bad) reason |= LL_DONE_NONFINITE;
+  if (B->cfg.set_obstacle && !bad && obstacle_contact(B, e)) reason |= LL_DONE_COLLISION;      /* PLE:341-346 */
   e->done_reason = reason;
   if (reason) {                                                            /* PLE:235-240 */
     int c = e->clip;

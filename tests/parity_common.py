@@ -232,3 +232,47 @@ def check_trajectory_ring(model_blob, table, lib_path, read_ring):
         np.testing.assert_array_equal(row[:, E.obs_dim + 13], d.astype(np.float32))
         prev_obs = E.obs()
     E.close()
+
+
+def check_obstacle_variant(golden, orc, model_blob, table, lib_path, n_envs=24, n_steps=60, seed=2):
+    """set_obstacle=True (PLE:173-193, :262-268, :341-346): engine vs oracle on the jump clips, random policy.  The robot does
+    not clear the box, so episodes must end with the COLLISION bit in both, at the same step."""
+    cnt, tab = table.obstacles()
+    clips = np.where(cnt > 0)[0]
+    assert len(clips) == 20 and cnt.sum() == 78                          # SURVEY a21 [probe]
+    rng = np.random.default_rng(seed)
+    clip = rng.choice(clips, n_envs)
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    # start shortly before a jump peak: the robot inherits the mocap velocity and flies into the box
+    t0 = np.array([max(0.0, tab[off[c] + rng.integers(0, cnt[c]), 3] - 0.2) for c in clip])
+    t0 = np.minimum(t0, [table.frame_step * (table.clip_len[c] - table.margin - 2) for c in clip])
+    kw = dict(set_obstacle=True, obstacle_height=0.2)
+    E = make_engine(model_blob, table, n_envs, lib_path, **kw)
+    B = make_oracle_batch(orc, model_blob, table, n_envs=n_envs, **kw)
+    E.reset(clip=clip, t0=t0)
+    for i in range(n_envs):
+        B.reset_env(i, int(clip[i]), float(t0[i]))
+        B.set_state(i, E.state()[i].astype(np.float64))
+    alive = np.ones(n_envs, bool)
+    n_coll = mism = 0
+    for t in range(n_steps):
+        act = (rng.normal(size=(n_envs, 12)) * SIGMA).astype(np.float32)
+        E.step_host(act)
+        r, d, why = E.reward_done()
+        es = E.state()
+        for i in range(n_envs):
+            if not alive[i]:
+                continue
+            _, _, od = B.step_env(i, act[i].astype(np.float64))
+            oreason = B.episode_info(i)['done_reason']
+            if bool(d[i]) != od or (od and (int(why[i]) & 8) != (oreason & 8)):
+                mism += 1
+            if od or d[i]:
+                alive[i] = False
+                n_coll += int((oreason & 8) != 0)
+            else:
+                B.set_state(i, es[i].astype(np.float64))
+    E.close()
+    assert n_coll >= 3, n_coll
+    assert mism <= 1, mism
+    return n_coll

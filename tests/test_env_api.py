@@ -81,8 +81,6 @@ def test_factory_errors(emul_lib):
         lla.create_tracking_game(**pmc_config(prop_type='joint_pos', lib_path=emul_lib))       # PLE:113
     with pytest.raises(FileNotFoundError):
         lla.create_tracking_game(**pmc_config(data_path='/nonexistent/mocap', lib_path=emul_lib))
-    with pytest.raises(NotImplementedError):
-        lla.create_tracking_game(**pmc_config(set_obstacle=True, lib_path=emul_lib))
 
 
 def test_prop_type_subset_changes_layout(emul_lib):

@@ -67,3 +67,8 @@ def test_contact_rich_parity(golden, orc, model_blob, mocap_table):
 def test_trained_reference_policy_tracks_in_our_simulator():
     out = pc.check_trained_policy_tracks(None, n_envs=256, n_steps=300)
     print('trained PMC policy on GPU: mean reward/step %.3f, tracked %.0f%%' % (out['mean_reward'], 100 * out['tracked']))
+
+
+def test_obstacle_variant(golden, orc, model_blob, mocap_table):
+    n = pc.check_obstacle_variant(golden, orc, model_blob, mocap_table, None)
+    print('obstacle variant: %d episodes ended on the box' % n)

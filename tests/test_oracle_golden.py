@@ -135,3 +135,16 @@ def test_g5_scripted_episodes_and_sampling_table(golden, orc, model_blob, mocap_
         np.testing.assert_allclose(prob, golden['g5_prob_after'][e], rtol=1e-10, atol=1e-14)
         np.testing.assert_allclose(avg_len, golden['g5_avg_len_after'][e], rtol=1e-12)
     assert n_done >= 6
+
+
+def test_g7_obstacle_extraction(golden, mocap_table):
+    """utils/obstacle.py:6-33 (find_peaks + get_obstacle_pose) restated in mocap.MocapTable.obstacles()."""
+    from scipy.spatial.transform import Rotation as R
+    cnt, tab = mocap_table.obstacles()
+    assert cnt.sum() == len(golden['g7_clip']) == 78 and (cnt > 0).sum() == 20
+    np.testing.assert_array_equal(np.repeat(np.arange(mocap_table.n_clips), cnt), golden['g7_clip'])
+    np.testing.assert_allclose(tab[:, 0:2], golden['g7_pose'][:, 0:2], rtol=0, atol=0)
+    np.testing.assert_allclose(tab[:, 3], golden['g7_time'], rtol=1e-15)
+    yaw = R.from_quat(golden['g7_pose'][:, 3:7]).as_euler('xyz')[:, 2]
+    assert np.abs(np.angle(np.exp(1j * (tab[:, 2] - yaw)))).max() < 1e-12
+    np.testing.assert_array_equal(golden['g7_pose'][:, 2], 0.0)           # boxes sit on the ground (obstacle.py:28)
