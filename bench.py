@@ -104,14 +104,19 @@ def main():
     eng.reset()
     traj = gather.TrajectoryBuffer(eng, UNROLL) if world > 1 else None
 
-    def one_step(t):
+    n_done = [0]                                           # control steps executed so far == the engine's step index
+
+    def one_step(_):
         eng.fill_random_actions(SIGMA)
         eng.step()
-        if traj is not None and (t + 1) % UNROLL == 0:     # the step kernel itself records the rows (ll_enable_trajectory)
-            traj.gather_to(0)
+        n_done[0] += 1
+        if traj is not None and n_done[0] % UNROLL == 0:   # the step kernel itself records the rows (ll_enable_trajectory);
+            traj.gather_async(n_done[0] // UNROLL - 1, 0)  # the gather of this unroll overlaps with the next unroll's steps
 
     for t in range(args.warmup):
         one_step(t)
+    if traj is not None:
+        traj.wait()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -119,6 +124,8 @@ def main():
     t0 = time.perf_counter()
     for t in range(args.steps):
         one_step(t)
+    if traj is not None:
+        traj.wait()                                          # an in-flight gather belongs to the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

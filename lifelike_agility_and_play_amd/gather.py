@@ -60,15 +60,42 @@ def gather_unroll(local, dst=0, group=None):
 
 
 class TrajectoryBuffer(object):
-    """The engine's own trajectory ring ([unroll][n_envs][obs|action|reward|done], written inside the step kernel)
-    as a torch tensor, plus the gather to the learner rank."""
+    """The engine's own trajectory ring ([slots][n_envs][obs|action|reward|done], written inside the step kernel) as a torch
+    tensor, plus the hand-off to the learner rank.
+
+    The ring holds TWO unrolls: while the steps of unroll k+1 fill one half, the gather of unroll k (the other half) is in
+    flight on RCCL's own stream (``async_op``), so the collective overlaps with simulation instead of stalling it.  xGMI is
+    point-to-point, so rank 0 receives over 7 different links at once."""
 
     def __init__(self, engine, unroll):
-        ptr, w = engine.enable_trajectory(unroll)
+        ptr, w = engine.enable_trajectory(2 * unroll)
         self.unroll = unroll
-        self.buf = device_tensor(ptr, (unroll, engine.n_envs, w))
+        self.buf = device_tensor(ptr, (2 * unroll, engine.n_envs, w))
+        self.outs = None
+        self.work = None
         self.last = None
+        self.n_gathered = 0
 
-    def gather_to(self, dst=0):
-        self.last = gather_unroll(self.buf, dst)
-        return self.last
+    def half(self, k):
+        return self.buf[(k % 2) * self.unroll:(k % 2 + 1) * self.unroll]
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+    def gather_async(self, k, dst=0, group=None):
+        """Start gathering unroll k (the half the last `unroll` steps wrote); the previous gather must have finished."""
+        self.wait()
+        local = self.half(k)
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if local.is_cuda and dist.get_backend(group) == 'gloo':      # test configuration only: gloo gathers host tensors
+            local = local.cpu()
+        if rank == dst:
+            if self.outs is None or self.outs[0].device != local.device:
+                self.outs = [torch.empty_like(local) for _ in range(world)]
+            self.work = dist.gather(local, gather_list=self.outs, dst=dst, group=group, async_op=True)
+            self.last = self.outs
+        else:
+            self.work = dist.gather(local, gather_list=None, dst=dst, group=group, async_op=True)
+        self.n_gathered += 1
