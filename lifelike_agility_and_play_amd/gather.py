@@ -21,6 +21,13 @@ class _DevArray(object):
         self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (int(ptr), False), 'version': 2}
 
 
+def host_tensor(ptr, shape):
+    """float32 view of HOST memory (the test-only emulation library keeps its "device" buffers on the host)."""
+    import ctypes
+    n = int(np.prod(shape))
+    return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * n).from_address(int(ptr))).reshape(shape))
+
+
 def device_tensor(ptr, shape, dtype=torch.float32, device=None):
     typestr = {torch.float32: '<f4', torch.uint8: '|u1', torch.int32: '<i4', torch.float64: '<f8'}[dtype]
     return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device if device is not None else torch.device('cuda', torch.cuda.current_device()))
@@ -67,10 +74,11 @@ class TrajectoryBuffer(object):
     flight on RCCL's own stream (``async_op``), so the collective overlaps with simulation instead of stalling it.  xGMI is
     point-to-point, so rank 0 receives over 7 different links at once."""
 
-    def __init__(self, engine, unroll):
+    def __init__(self, engine, unroll, host_memory=False):
         ptr, w = engine.enable_trajectory(2 * unroll)
         self.unroll = unroll
-        self.buf = device_tensor(ptr, (2 * unroll, engine.n_envs, w))
+        mk = host_tensor if host_memory else device_tensor
+        self.buf = mk(ptr, (2 * unroll, engine.n_envs, w))
         self.outs = None
         self.work = None
         self.last = None
