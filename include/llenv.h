@@ -147,6 +147,15 @@ int ll_reset(ll_engine* e, const int32_t* h_env_ids, int n, const int32_t* h_cli
  */
 int ll_step(ll_engine* e, const float* d_actions);
 
+/*
+ * Parity hook: ll_step with the physics result supplied by the caller.  After the (still executed) substeps the dynamic
+ * state of every env is replaced by h_state[n_envs][37] and, if h_feet is given, the foot positions of LR:199-205 by
+ * h_feet[n_envs][24] (4x3 dynamic robot, 4x3 ghost): the protocol with which tests/golden/gen_golden.py drove the
+ * reference through a fake BulletClient.  Lets the mocap / observation / reward / termination / sampling-table code be
+ * compared with the reference's own outputs without any physics in between.
+ */
+int ll_step_scripted(ll_engine* e, const float* d_actions, const float* h_state, const float* h_feet);
+
 /* Synthetic random policy a ~ N(0, sigma^2) per joint (sigma = exp(-2)), generated on
  * device by Philox keyed on (seed, env, step) into the engine's action buffer. */
 int ll_fill_random_actions(ll_engine* e, float sigma);

@@ -79,6 +79,7 @@ _SIGS = {
     'll_load_obstacles': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     'll_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'll_step': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'll_step_scripted': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'll_fill_random_actions': (C.c_int, [C.c_void_p, C.c_float]),
     'll_sync': (C.c_int, [C.c_void_p]),
     'll_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -181,6 +182,14 @@ class Engine(object):
         a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n_envs, 12)
         self._chk(self.lib.ll_set_actions(self.h, _ptr(a)))
         self.step(None)
+
+    def step_scripted(self, actions, state, feet=None):
+        """Parity hook (ll_step_scripted): host actions [n][12], physics result state [n][37], optional feet [n][2][4][3]."""
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n_envs, 12)
+        s = np.ascontiguousarray(state, dtype=np.float32).reshape(self.n_envs, 37)
+        f = np.ascontiguousarray(feet, dtype=np.float32).reshape(self.n_envs, 24) if feet is not None else None
+        self._chk(self.lib.ll_set_actions(self.h, _ptr(a)))
+        self._chk(self.lib.ll_step_scripted(self.h, None, _ptr(s), _ptr(f)))
 
     def fill_random_actions(self, sigma):
         self._chk(self.lib.ll_fill_random_actions(self.h, float(sigma)))

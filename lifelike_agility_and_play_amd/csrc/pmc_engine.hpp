@@ -185,6 +185,28 @@ struct PmcEngine {
     table_fresh = false;                 // the step may have published new episode statistics
     P.step_count += 1;
   }
+  // parity hook: one control step whose physics result (and optionally foot positions) is supplied by the caller -- the
+  // fake-BulletClient protocol of tests/golden/gen_golden.py -- so that everything around the physics can be compared with
+  // the reference's own outputs directly
+  float *d_script_state = nullptr, *d_script_feet = nullptr;
+  void step_scripted(const float* d_act, const float* h_state, const float* h_feet) {
+    need(true, true);
+    const size_t N = P.n_envs;
+    if (!d_script_state) { d_script_state = dalloc<float>(N * 37); d_script_feet = dalloc<float>(N * 24); }
+    bk.sync();
+    bk.h2d(d_script_state, h_state, N * 37 * 4);
+    if (h_feet) bk.h2d(d_script_feet, h_feet, N * 24 * 4);
+    StepParams Q = P;
+    Q.actions = d_act ? d_act : d_actions;
+    Q.scripted_state = d_script_state;
+    Q.scripted_feet = h_feet ? d_script_feet : nullptr;
+    Q.traj = d_traj;
+    Q.traj_slot = traj_unroll ? (int)(P.step_count % (uint64_t)traj_unroll) : 0;
+    if (!table_fresh) bk.launch_prestep(P, d_avg_reward, d_avg_len, d_prob, d_cdf, nullptr, 0.0f);
+    bk.launch_step(Q);
+    table_fresh = false;
+    P.step_count += 1;
+  }
   // keep the last `unroll` transitions of every env in HBM, in the layout the learner rank gathers
   void enable_trajectory(int unroll) {
     if (unroll <= 0) throw PmcError(LL_EINVAL, "unroll must be positive");

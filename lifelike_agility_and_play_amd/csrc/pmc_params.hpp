@@ -81,6 +81,9 @@ struct StepParams {
   uint8_t* done;            // [n_envs]
   uint8_t* done_reason;     // [n_envs]
   const float* actions;     // [n_envs][12]
+  // parity hook (ll_step_scripted): physics result and foot positions supplied by the caller, rows [n_envs][37] / [n_envs][24]
+  const float* scripted_state;
+  const float* scripted_feet;
   float* traj;              // optional [unroll][n_envs][obs_dim + 14] trajectory ring: obs_t | action_t | reward_t | done_t
   int32_t traj_slot, traj_pad;
   // mocap

@@ -856,6 +856,14 @@ struct Pmc {
     const double* rows = P.frames + (long)P.clip_off[clip] * 19;
     RefPose rp = mocap_interp(ln, rows + (long)fid * 19, rows + (long)(fid + 1) * 19, frac, P.frame_step, true);   // PLE:217
 
+    if (P.scripted_state) {   // parity hook: the caller plays PyBullet (how the golden harness drove the reference)
+      const float* ss = P.scripted_state + (long)env * 37;
+      bs.p = mk3<float>(ss[0], ss[1], ss[2]);
+      bs.q.x = ss[3]; bs.q.y = ss[4]; bs.q.z = ss[5]; bs.q.w = ss[6];
+      bs.v = mk3<float>(ss[7], ss[8], ss[9]);
+      bs.w = mk3<float>(ss[10], ss[11], ss[12]);
+      for (int j = 0; j < 3; j++) { q[j] = ln.ldl(ss, 13 + j, 3); qd[j] = ln.ldl(ss, 25 + j, 3); }
+    }
     // non-finite guard
     F fin = q[0] + q[1] + q[2] + qd[0] + qd[1] + qd[2];
     float chk = L::qsum(fin) + bs.p.x + bs.p.y + bs.p.z + bs.q.x + bs.q.y + bs.q.z + bs.q.w + bs.v.x + bs.v.y + bs.v.z + bs.w.x + bs.w.y + bs.w.z;
@@ -873,6 +881,11 @@ struct Pmc {
     M3<float> Rg = qmat(gqn);
     V3l fd = foot_world(ln, P.legc, bs.p, R, q[0], q[1], q[2]);                                 // PLE:397
     V3l fk = foot_world(ln, P.legc, gb.p, Rg, rp.jp[0], rp.jp[1], rp.jp[2]);                    // PLE:398
+    if (P.scripted_feet) {    // parity hook: getLinkStates answered by the caller
+      const float* sf = P.scripted_feet + (long)env * 24;
+      fd = mk3<F>(ln.ldl(sf, 0, 3), ln.ldl(sf, 1, 3), ln.ldl(sf, 2, 3));
+      fk = mk3<F>(ln.ldl(sf, 12, 3), ln.ldl(sf, 13, 3), ln.ldl(sf, 14, 3));
+    }
     F ejp = ln.lane_f(0.0f), ejv = ln.lane_f(0.0f);
     for (int j = 0; j < 3; j++) {
       F d = q[j] - rp.jp[j], dv = qd[j] - rp.jv[j];

@@ -276,3 +276,32 @@ def check_obstacle_variant(golden, orc, model_blob, table, lib_path, n_envs=24, 
     assert n_coll >= 3, n_coll
     assert mism <= 1, mism
     return n_coll
+
+
+def check_scripted_episodes_against_goldens(golden, model_blob, table, lib_path):
+    """The engine's whole step() control flow against the REFERENCE's own outputs (golden G5): 12 scripted episodes driven
+    exactly as gen_golden.py drove the reference through its fake BulletClient -- physics result and foot positions
+    supplied, everything else (time keeping with the Q2 phase lag, mocap lookup, history stacking with raw actions,
+    5-term reward, the termination tests, PLE:235-240 table update) computed by the kernel."""
+    n_ep = len(golden['g5_seed'])
+    E = make_engine(model_blob, table, 1, lib_path)
+    n_done = 0
+    for e in range(n_ep):
+        E.reset(clip=[int(golden['g5_clip'][e])], t0=[float(golden['g5_t0'][e])])
+        np.testing.assert_allclose(E.obs()[0], golden['g5_reset_obs'][e], rtol=NONPHYS_TOL, atol=NONPHYS_TOL)
+        for t in range(int(golden['g5_n'][e])):
+            feet = np.stack([golden['g5_feet_dyn'][e, t], golden['g5_feet_kin'][e, t]])
+            E.step_scripted(golden['g5_actions'][e, t][None], golden['g5_dyn'][e, t][None], feet[None])
+            obs = E.obs()[0]
+            r, d, why = E.reward_done()
+            g = golden['g5_obs'][e, t]
+            # joint rates in the scripted states reach ~50 rad/s: float32 storage alone is 4e-6 there
+            np.testing.assert_allclose(obs, g, rtol=2e-6, atol=NONPHYS_TOL, err_msg='episode %d step %d' % (e, t))
+            assert abs(float(r[0]) - golden['g5_reward'][e, t]) < NONPHYS_TOL
+            assert bool(d[0]) == bool(golden['g5_done'][e, t]), (e, t, why)
+        n_done += bool(d[0])
+        prob, avg_r, avg_len = E.sampling_table()
+        np.testing.assert_allclose(prob, golden['g5_prob_after'][e], rtol=1e-5, atol=1e-8)       # PLE:239-240
+        np.testing.assert_allclose(avg_len, golden['g5_avg_len_after'][e], rtol=1e-6, atol=1e-9)  # PLE:237
+    E.close()
+    assert n_done >= 6

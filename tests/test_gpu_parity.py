@@ -72,3 +72,7 @@ def test_trained_reference_policy_tracks_in_our_simulator():
 def test_obstacle_variant(golden, orc, model_blob, mocap_table):
     n = pc.check_obstacle_variant(golden, orc, model_blob, mocap_table, None)
     print('obstacle variant: %d episodes ended on the box' % n)
+
+
+def test_scripted_episodes_against_reference_goldens(golden, model_blob, mocap_table):
+    pc.check_scripted_episodes_against_goldens(golden, model_blob, mocap_table, None)

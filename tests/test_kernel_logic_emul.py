@@ -50,3 +50,7 @@ def test_trajectory_ring(model_blob, mocap_table, emul_lib):
 def test_obstacle_variant(golden, orc, model_blob, mocap_table, emul_lib):
     n = pc.check_obstacle_variant(golden, orc, model_blob, mocap_table, emul_lib)
     print('obstacle variant: %d episodes ended on the box' % n)
+
+
+def test_scripted_episodes_against_reference_goldens(golden, model_blob, mocap_table, emul_lib):
+    pc.check_scripted_episodes_against_goldens(golden, model_blob, mocap_table, emul_lib)
