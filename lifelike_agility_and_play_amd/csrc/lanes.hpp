@@ -168,6 +168,41 @@ struct GpuLanes {
   static LL_D void fmac_rbcast_settled(F& acc, F x, F k);
   // returns x after two wait states, so that following DPP reads of the result are hazard free
   static LL_D F settle(F x) { asm volatile("s_nop 1" : "+v"(x)); return x; }
+  // g[L] = sum_i x[i] * rbcast<L>(x[i]) for L = 0..15: ONE block of 96 v_fmac_f32 with a DPP source.  The six inputs are not
+  // written inside the block, so after the leading wait states no DPP read-after-write hazard can occur.
+  static LL_D void gram16(const F* x, F* g) {
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f, g5 = 0.f, g6 = 0.f, g7 = 0.f, g8 = 0.f, g9 = 0.f, g10 = 0.f, g11 = 0.f, g12 = 0.f,
+          g13 = 0.f, g14 = 0.f, g15 = 0.f;
+#define LL_G1(O, L_, X) "v_fmac_f32_dpp " O ", " X ", " X " row_newbcast:" #L_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define LL_G6(O, L_) LL_G1(O, L_, "%16") LL_G1(O, L_, "%17") LL_G1(O, L_, "%18") LL_G1(O, L_, "%19") LL_G1(O, L_, "%20") LL_G1(O, L_, "%21")
+    asm("s_nop 1\n\t" LL_G6("%0", 0) LL_G6("%1", 1) LL_G6("%2", 2) LL_G6("%3", 3) LL_G6("%4", 4) LL_G6("%5", 5) LL_G6("%6", 6) LL_G6("%7", 7)
+        LL_G6("%8", 8) LL_G6("%9", 9) LL_G6("%10", 10) LL_G6("%11", 11) LL_G6("%12", 12) LL_G6("%13", 13) LL_G6("%14", 14) LL_G6("%15", 15)
+        : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4), "+v"(g5), "+v"(g6), "+v"(g7), "+v"(g8), "+v"(g9), "+v"(g10), "+v"(g11), "+v"(g12),
+          "+v"(g13), "+v"(g14), "+v"(g15)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]));
+#undef LL_G6
+#undef LL_G1
+    g[0] = g0; g[1] = g1; g[2] = g2; g[3] = g3; g[4] = g4; g[5] = g5; g[6] = g6; g[7] = g7;
+    g[8] = g8; g[9] = g9; g[10] = g10; g[11] = g11; g[12] = g12; g[13] = g13; g[14] = g14; g[15] = g15;
+  }
+  // Four Gauss-Seidel turns (lanes S, 4+S, 8+S, 12+S) as one block: v_med3 (clamp the pending increment), v_cndmask (the lane
+  // whose turn it is keeps its increment; masks m0..m3 are the lane masks of the four turns), one wait state, v_fmac with a
+  // DPP row broadcast (every lane's pending increment moves by nk * d).  4 issue slots per turn.
+  template <int S_>
+  static LL_D void turns4(F& u, F& dl, F lo, F hi, F k0, F k1, F k2, F k3) {
+    const unsigned long long m0 = 0x0001000100010001ull << S_, m1 = m0 << 4, m2 = m0 << 8, m3 = m0 << 12;
+    float d;
+#define LL_T1(K, M, L_)                                                                          \
+    "v_med3_f32 %2, %0, %3, %4\n\t"                                                            \
+    "v_cndmask_b32_e64 %1, %1, %2, " M "\n\t"                                                  \
+    "s_nop 0\n\t"                                                                              \
+    "v_fmac_f32_dpp %0, %2, " K " row_newbcast:" L_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    if (S_ == 0)      asm(LL_T1("%5", "%9", "0") LL_T1("%6", "%10", "4") LL_T1("%7", "%11", "8") LL_T1("%8", "%12", "12") : "+v"(u), "+v"(dl), "=&v"(d) : "v"(lo), "v"(hi), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
+    else if (S_ == 1) asm(LL_T1("%5", "%9", "1") LL_T1("%6", "%10", "5") LL_T1("%7", "%11", "9") LL_T1("%8", "%12", "13") : "+v"(u), "+v"(dl), "=&v"(d) : "v"(lo), "v"(hi), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
+    else if (S_ == 2) asm(LL_T1("%5", "%9", "2") LL_T1("%6", "%10", "6") LL_T1("%7", "%11", "10") LL_T1("%8", "%12", "14") : "+v"(u), "+v"(dl), "=&v"(d) : "v"(lo), "v"(hi), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
+    else              asm(LL_T1("%5", "%9", "3") LL_T1("%6", "%10", "7") LL_T1("%7", "%11", "11") LL_T1("%8", "%12", "15") : "+v"(u), "+v"(dl), "=&v"(d) : "v"(lo), "v"(hi), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
+#undef LL_T1
+  }
   static LL_D bool any(B m) { return __any(m); }   // wave-level: guards wave-uniform branches
 
   // ---- constants -------------------------------------------------------------------------------------------------

@@ -230,27 +230,17 @@ struct Pmc {
     F gt[6], jt[3], c, inv, lam;
     F nk[16];      // -(gt . gt_L + [same leg] jt . jt_L) * inv   for L = lane of the env row
   };
-  template <int L_>
-  static LL_HD void gram_one(const L& ln, Row& r, const F* nj, const F* gs) {
-    // compiler-visible DPP (it schedules around the DPP read-after-write hazard and folds mov_dpp into the FMA where it can)
-    F g = gs[0] * L::template rbcast<L_>(gs[0]);
-    for (int i = 1; i < 6; i++) g = g + gs[i] * L::template rbcast<L_>(gs[i]);
-    g = g + lm::sel(ln.is_leg(L_ >> 2), nj[L_ & 3], ln.lane_f(0.0f));
-    r.nk[L_] = g * (ln.lane_f(0.0f) - r.inv);
-  }
   static LL_HD void finish_row(const L& ln, Row& r) {
     F nj[4];
     nj[0] = r.jt[0] * L::template subbcast<0>(r.jt[0]) + r.jt[1] * L::template subbcast<0>(r.jt[1]) + r.jt[2] * L::template subbcast<0>(r.jt[2]);
     nj[1] = r.jt[0] * L::template subbcast<1>(r.jt[0]) + r.jt[1] * L::template subbcast<1>(r.jt[1]) + r.jt[2] * L::template subbcast<1>(r.jt[2]);
     nj[2] = r.jt[0] * L::template subbcast<2>(r.jt[0]) + r.jt[1] * L::template subbcast<2>(r.jt[1]) + r.jt[2] * L::template subbcast<2>(r.jt[2]);
     nj[3] = r.jt[0] * L::template subbcast<3>(r.jt[0]) + r.jt[1] * L::template subbcast<3>(r.jt[1]) + r.jt[2] * L::template subbcast<3>(r.jt[2]);
-    // the DPP reads below must not follow the write of their source by less than two instructions: take copies first
-    F gs[6];
-    for (int i = 0; i < 6; i++) gs[i] = r.gt[i];
-    gram_one<0>(ln, r, nj, gs); gram_one<1>(ln, r, nj, gs); gram_one<2>(ln, r, nj, gs); gram_one<3>(ln, r, nj, gs);
-    gram_one<4>(ln, r, nj, gs); gram_one<5>(ln, r, nj, gs); gram_one<6>(ln, r, nj, gs); gram_one<7>(ln, r, nj, gs);
-    gram_one<8>(ln, r, nj, gs); gram_one<9>(ln, r, nj, gs); gram_one<10>(ln, r, nj, gs); gram_one<11>(ln, r, nj, gs);
-    gram_one<12>(ln, r, nj, gs); gram_one<13>(ln, r, nj, gs); gram_one<14>(ln, r, nj, gs); gram_one<15>(ln, r, nj, gs);
+    F g[16];
+    L::gram16(r.gt, g);                                    // g[L] = gt . gt_L for the 16 rows of the round
+    F ninv = ln.lane_f(0.0f) - r.inv;
+    for (int L_ = 0; L_ < 16; L_++)
+      r.nk[L_] = (g[L_] + lm::sel(ln.is_leg(L_ >> 2), nj[L_ & 3], ln.lane_f(0.0f))) * ninv;
     r.lam = ln.lane_f(0.0f);
   }
   template <int K_>
@@ -260,22 +250,6 @@ struct Pmc {
     ns = lm::sel(take, L::template subbcast<K_>(sb), ns);
     nj = lm::sel(take, L::template subbcast<K_>(jj), nj);
   }
-  // Gauss-Seidel turn of lane L_: every lane clamps its own pending increment (one v_med3); the row broadcast picks lane
-  // L_'s, which shifts every lane's pending increment by nk[L_] * d (one v_fmac with a DPP operand).
-  template <int L_>
-  static LL_HD void gs_turn(const L& ln, const Row& r, const F& lo_d, const F& hi_d, F& dl, F& u) {
-    F d = lm::med3_(u, lo_d, hi_d);
-    dl = lm::sel(ln.is_lane(L_), d, dl);
-    L::template fmac_rbcast<L_>(u, d, r.nk[L_]);
-  }
-  // the four lanes (one per leg) that own slot / joint S_ take their turn, legs in order
-  template <int S_>
-  static LL_HD void gs_turns4(const L& ln, const Row& r, const F& lo_d, const F& hi_d, F& dl, F& u) {
-    gs_turn<S_>(ln, r, lo_d, hi_d, dl, u);
-    gs_turn<4 + S_>(ln, r, lo_d, hi_d, dl, u);
-    gs_turn<8 + S_>(ln, r, lo_d, hi_d, dl, u);
-    gs_turn<12 + S_>(ln, r, lo_d, hi_d, dl, u);
-  }
   // one Gauss-Seidel round over the 16 rows of a kind; any4[s] = some lane of the wave has a live row in slot s
   static LL_HD void gs_round(const L& ln, Row& r, const F& lo, const F& hi, const bool* any4, float* dx, F* dq) {
     F zero = ln.lane_f(0.0f);
@@ -284,10 +258,11 @@ struct Pmc {
     F u = (zero - ((s0 + s1) + (s2 + cq))) * r.inv;       // unclamped increment; admissible interval [lo - lam, hi - lam]
     F lo_d = lo - r.lam, hi_d = hi - r.lam;
     F dl = zero;
-    if (any4[0]) gs_turns4<0>(ln, r, lo_d, hi_d, dl, u);
-    if (any4[1]) gs_turns4<1>(ln, r, lo_d, hi_d, dl, u);
-    if (any4[2]) gs_turns4<2>(ln, r, lo_d, hi_d, dl, u);
-    if (any4[3]) gs_turns4<3>(ln, r, lo_d, hi_d, dl, u);
+    // a turn: the lane whose turn it is commits clamp(u) -- every lane's pending increment then moves by nk[L] * d_L
+    if (any4[0]) L::template turns4<0>(u, dl, lo_d, hi_d, r.nk[0], r.nk[4], r.nk[8], r.nk[12]);
+    if (any4[1]) L::template turns4<1>(u, dl, lo_d, hi_d, r.nk[1], r.nk[5], r.nk[9], r.nk[13]);
+    if (any4[2]) L::template turns4<2>(u, dl, lo_d, hi_d, r.nk[2], r.nk[6], r.nk[10], r.nk[14]);
+    if (any4[3]) L::template turns4<3>(u, dl, lo_d, hi_d, r.nk[3], r.nk[7], r.nk[11], r.nk[15]);
     r.lam = r.lam + dl;
     F pj[3] = {r.jt[0] * dl, r.jt[1] * dl, r.jt[2] * dl}, sj[3];
     L::subsum3(pj, sj);                                   // the slots of a leg share its joint velocities

@@ -90,6 +90,18 @@ struct HostLanes {
   template <int L_> static void fmac_rbcast(F& acc, const F& x, const F& k) { for (int i = 0; i < EW; i++) acc.v[i] = acc.v[i] + x.v[L_] * k.v[i]; }
   template <int L_> static void fmac_rbcast_settled(F& acc, const F& x, const F& k) { fmac_rbcast<L_>(acc, x, k); }
   static F settle(const F& x) { return x; }
+  static void gram16(const F* x, F* g) {
+    for (int L_ = 0; L_ < 16; L_++) { fN a(0.0f); for (int i = 0; i < 6; i++) for (int l = 0; l < EW; l++) a.v[l] = a.v[l] + x[i].v[l] * x[i].v[L_]; g[L_] = a; }
+  }
+  template <int S_> static void turns4(F& u, F& dl, const F& lo, const F& hi, const F& k0, const F& k1, const F& k2, const F& k3) {
+    const F* ks[4] = {&k0, &k1, &k2, &k3};
+    for (int t = 0; t < 4; t++) {
+      const int L_ = 4 * t + S_;
+      fN d = lm::med3_(u, lo, hi);
+      dl.v[L_] = d.v[L_];
+      for (int l = 0; l < EW; l++) u.v[l] = u.v[l] + d.v[L_] * ks[t]->v[l];
+    }
+  }
   static bool any(const B& m) { for (int i = 0; i < EW; i++) if (m.v[i]) return true; return false; }
   F legc(const float* tbl, int field) const { fN r; for (int i = 0; i < EW; i++) r.v[i] = tbl[field * 4 + (i >> 2)]; return r; }
   F candc(int word) const { fN r; for (int i = 0; i < EW; i++) r.v[i] = candc_[word * 16 + i]; return r; }
