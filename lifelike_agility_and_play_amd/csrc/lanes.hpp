@@ -219,6 +219,18 @@ struct GpuLanes {
   LL_D D lddl(const double* p, long base, long stride) const { return p[base + stride * leg_]; }
   // cooperative copy of up to 16 consecutive floats: lane i moves element i0 + i (if below n)
   LL_D void copy16(float* dst, const float* src, int i0, int n) const { const int i = i0 + lane16_; if (i < n) dst[i] = src[i]; }
+  // the two halves of copy16, so that a caller can issue every load of a row before its first store
+  LL_D F ld16(const float* src, int i0, int n) const { const int i = i0 + lane16_; return i < n ? src[i] : 0.0f; }
+  LL_D void st16(float* dst, int i0, int n, F v) const { const int i = i0 + lane16_; if (i < n) dst[i] = v; }
+  // number of entries of the non-decreasing table p[0..n) that are <= u: sixteen entries per round trip, row-summed
+  LL_D int count_le16(const double* p, int n, double u) const {
+    float c = 0.0f;
+    for (int i0 = 0; i0 < n; i0 += PMC_ROW) {
+      const int i = i0 + lane16_;
+      if (i < n && p[i] <= u) c += 1.0f;
+    }
+    return (int)qsum(subsum(c));
+  }
   static LL_D F d2f(D x) { return (float)x; }
   static LL_D F i2f(I x) { return (float)x; }
   static LL_D I f2i(F x) { return (int)x; }

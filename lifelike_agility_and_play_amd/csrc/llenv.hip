@@ -44,7 +44,7 @@ __global__ __launch_bounds__(PMC_WAVE) void pmc_reset_kernel(StepParams P, const
   int c;
   double t;
   uint32_t ep = P.ep_count[env] + 1;          // the sixteen lanes of the row read, then write, the same value
-  K::sample_start(P, env, ep, &c, &t);         // ML:59-63, ML:50-51
+  K::sample_start(ln, P, env, ep, &c, &t);     // ML:59-63, ML:50-51
   P.ep_count[env] = ep;
   if (clip) c = clip[i];
   if (t0) t = t0[i];

@@ -66,7 +66,7 @@ struct PmcEngine {
     P.reward = dalloc<float>(N); P.done = dalloc<uint8_t>(N); P.done_reason = dalloc<uint8_t>(N);
     d_actions = dalloc<float>(N * 12);
     P.actions = d_actions;
-    P.counters = dalloc<unsigned long long>(4);
+    P.counters = dalloc<unsigned long long>(4 + (size_t)PMC_TS_SLOTS * N);
     d_reset_ids = dalloc<int32_t>(N); d_reset_clip = dalloc<int32_t>(N); d_reset_t0 = dalloc<double>(N);
   }
   ~PmcEngine() {

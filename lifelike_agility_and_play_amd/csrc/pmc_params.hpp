@@ -50,6 +50,19 @@ enum BaseConst {
   BC_COUNT = 31
 };
 
+// Timing ablations (tools/ablate.sh builds a separate library with -DPMC_ABLATION; the shipped one has no such switch):
+// LL_DEBUG_FLAGS bit 1 drops contact rows, 2 drops limit rows, 4 returns after the substeps, 8 returns at kernel entry.
+// Bit 16 records per-env wall-clock stamps (100 MHz) at PMC_TS(k) marks into the words after P.counters[4].
+#if defined(PMC_ABLATION)
+#define PMC_ABL(bit) ((P.debug_flags & (bit)) != 0)
+#define PMC_TS_SLOTS 32
+#define PMC_TS(k) do { if (PMC_ABL(16) && ln.is_lane(0)) P.counters[4 + (long)env * PMC_TS_SLOTS + (k)] = wall_clock64(); } while (0)
+#else
+#define PMC_ABL(bit) false
+#define PMC_TS_SLOTS 0
+#define PMC_TS(k) do { } while (0)
+#endif
+
 struct StepParams {
   int32_t n_envs, n_sub, n_iter, auto_reset;
   int32_t n_clips, prop_dim, obs_dim, frame_rate;
@@ -98,7 +111,7 @@ struct StepParams {
   const double* ob_table;
   int32_t* ob_id;           // [n_envs] current obstacle of the episode (PLE:179,:264-265)
   float ob_half_height, ob_pad;
-  int32_t set_obstacle, ob_pad2;
+  int32_t set_obstacle, debug_flags;   // debug_flags: read only by builds with -DPMC_ABLATION (tools/ablate.sh), 0 otherwise
   unsigned long long* pending_reward;  // [n_clips] packed (env+1)<<32 | float bits of reward_sum/max_steps
   unsigned long long* pending_len;     // [n_clips] packed (env+1)<<32 | float bits of avg_episode_len
   unsigned long long* counters;        // [4] env-steps, episodes, non-finite resets, -

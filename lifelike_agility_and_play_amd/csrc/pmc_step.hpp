@@ -473,7 +473,7 @@ struct Pmc {
       pick_rank<3>(ln, rank, me, my_depth, my_sub, my_jj, nd, ns, nj);
       my_depth = nd; my_sub = ns; my_jj = nj;
     }
-    const B cvalid = my_depth < 1.0e29f;
+    const B cvalid = lm::and_(my_depth < 1.0e29f, ln.lane_f(PMC_ABL(1) ? 0.0f : 1.0f) > 0.5f);
     bool any_c[4], any_l[4] = {false, false, false, false};
     any_c[0] = L::any(lm::and_(cvalid, ln.is_sub(0))); any_c[1] = L::any(lm::and_(cvalid, ln.is_sub(1)));
     any_c[2] = L::any(lm::and_(cvalid, ln.is_sub(2))); any_c[3] = L::any(lm::and_(cvalid, ln.is_sub(3)));
@@ -500,7 +500,7 @@ struct Pmc {
       F nn = rl.jt[0] * rl.jt[0] + rl.jt[1] * rl.jt[1] + rl.jt[2] * rl.jt[2];
       for (int i = 0; i < 6; i++) nn = nn + rl.gt[i] * rl.gt[i];
       rl.c = sg * qsj + lm::sel(d > 0.0f, d * inv_dt, d * (P.erp * inv_dt));
-      B lvalid = lm::and_(has, rl.c < P.limit_gate);     // rows that cannot act this substep stay out of the solve
+      B lvalid = lm::and_(lm::and_(has, rl.c < P.limit_gate), ln.lane_f(PMC_ABL(2) ? 0.0f : 1.0f) > 0.5f);     // rows that cannot act this substep stay out of the solve
       rl.inv = lm::sel(lvalid, one / nn, zero);
       any_l[0] = L::any(lm::and_(lvalid, ln.is_sub(0))); any_l[1] = L::any(lm::and_(lvalid, ln.is_sub(1)));
       any_l[2] = L::any(lm::and_(lvalid, ln.is_sub(2)));
@@ -605,31 +605,46 @@ struct Pmc {
     V3u v, w;
     F jp[3], jv[3];
   };
-  // interpolate between two rows of the clip (ML:88-166); velocities only when want_vel
-  static LL_HD RefPose mocap_interp(const L& ln, const double* fc, const double* fn, double frac, double frame_step, bool want_vel) {
-    RefPose o;
-    o.p = mk3<float>((float)(fc[0] + frac * (fn[0] - fc[0])), (float)(fc[1] + frac * (fn[1] - fc[1])), (float)(fc[2] + frac * (fn[2] - fc[2])));
-    // quaternion difference formed from the float64 row delta so the small rotation keeps its precision
-    Q4 qc = {(float)fc[3], (float)fc[4], (float)fc[5], (float)fc[6]};
-    Q4 dl = {(float)(fn[3] - fc[3]), (float)(fn[4] - fc[4]), (float)(fn[5] - fc[5]), (float)(fn[6] - fc[6])};
-    Q4 qci = qconj(qc);
-    Q4 e = qmul(qci, dl);                                   // qc^-1 qn = 1 + qc^-1 (qn - qc)
-    V3u rv = rotvec_of(mk3<float>(e.x, e.y, e.z), 1.0f + e.w);   // ML:127-134 (scipy Slerp)
-    float ff = (float)frac;
-    Q4 dq = quat_of_rotvec(mk3<float>(rv.x * ff, rv.y * ff, rv.z * ff));
-    o.q = qmul(qc, dq);
+  // One interpolation site of a clip (ML:88-166) in two halves.  mocap_gather() does everything that touches the float64
+  // rows and leaves floats; mocap_finish() is pure arithmetic.  A caller gathers all its sites first, so that the loads of
+  // a control step are in flight together instead of one round trip per site (one wave per SIMD hides no latency).
+  struct RefRaw {
+    V3u p, vlin;        // interpolated position; finite-difference velocity (ML:137-140)
+    Q4 qc, dl;          // current-frame quaternion; next - current, formed in float64 so the small rotation keeps its precision
+    float ff;
+    F jp[3], jv[3];
+  };
+  static LL_HD RefRaw mocap_gather(const L& ln, const double* fc, const double* fn, double frac, double frame_step) {
+    RefRaw o;
+    const double inv = 1.0 / frame_step;
+    const double d0 = fn[0] - fc[0], d1 = fn[1] - fc[1], d2 = fn[2] - fc[2];
+    o.p = mk3<float>((float)(fc[0] + frac * d0), (float)(fc[1] + frac * d1), (float)(fc[2] + frac * d2));
+    o.vlin = mk3<float>((float)(d0 * inv), (float)(d1 * inv), (float)(d2 * inv));
+    o.qc.x = (float)fc[3]; o.qc.y = (float)fc[4]; o.qc.z = (float)fc[5]; o.qc.w = (float)fc[6];
+    o.dl.x = (float)(fn[3] - fc[3]); o.dl.y = (float)(fn[4] - fc[4]); o.dl.z = (float)(fn[5] - fc[5]); o.dl.w = (float)(fn[6] - fc[6]);
+    o.ff = (float)frac;
     for (int j = 0; j < 3; j++) {
       D c = ln.lddl(fc, 7 + j, 3), n = ln.lddl(fn, 7 + j, 3);
       o.jp[j] = L::d2f(c + (n - c) * frac);                 // ML:157
-      o.jv[j] = L::d2f((n - c) * (1.0 / frame_step));       // ML:158
+      o.jv[j] = L::d2f((n - c) * inv);                      // ML:158
     }
+    return o;
+  }
+  static LL_HD RefPose mocap_finish(const RefRaw& r, double frame_step, bool want_vel) {
+    RefPose o;
+    o.p = r.p;
+    Q4 qci = qconj(r.qc);
+    Q4 e = qmul(qci, r.dl);                                 // qc^-1 qn = 1 + qc^-1 (qn - qc)
+    V3u rv = rotvec_of(mk3<float>(e.x, e.y, e.z), 1.0f + e.w);   // ML:127-134 (scipy Slerp)
+    Q4 dq = quat_of_rotvec(mk3<float>(rv.x * r.ff, rv.y * r.ff, rv.z * r.ff));
+    o.q = qmul(r.qc, dq);
+    for (int j = 0; j < 3; j++) { o.jp[j] = r.jp[j]; o.jv[j] = r.jv[j]; }
     if (want_vel) {
-      double inv = 1.0 / frame_step;
-      o.v = mk3<float>((float)((fn[0] - fc[0]) * inv), (float)((fn[1] - fc[1]) * inv), (float)((fn[2] - fc[2]) * inv));   // ML:137-140
-      Q4 e2 = qmul(dl, qci);                                // qn qc^-1 = 1 + (qn - qc) qc^-1            ML:143-149
+      o.v = r.vlin;
+      Q4 e2 = qmul(r.dl, qci);                              // qn qc^-1 = 1 + (qn - qc) qc^-1            ML:143-149
       V3u rv2 = rotvec_of(mk3<float>(e2.x, e2.y, e2.z), 1.0f + e2.w);
       float ang = sqrtf(rv2.x * rv2.x + rv2.y * rv2.y + rv2.z * rv2.z);
-      float kk = ang / (ang + 1e-8f) * (float)inv;
+      float kk = ang / (ang + 1e-8f) * (float)(1.0 / frame_step);
       o.w = mk3<float>(rv2.x * kk, rv2.y * kk, rv2.z * kk);
     } else {
       o.v = mk3<float>(0.f, 0.f, 0.f);
@@ -641,24 +656,44 @@ struct Pmc {
   // ---------------------------------------------------------------------------------------------------
   // observation (PLE:247-317).  The obs row doubles as the history store: frames 1,2 of the previous row are
   // frames 0,1 of the new one (deque maxlen 3, PLE:145-147); `fill` = reset pre-fill (PLE:282-290).
+  // obs_gather() reads (history, the four future mocap sites), obs_emit() writes; every load of the row is issued
+  // before its first store because the compiler must assume the two alias.
   // ---------------------------------------------------------------------------------------------------
-  static LL_HD void write_obs(const L& ln, const StepParams& P, int env, float* row, const float* hist_row, bool fill, const Base& bs,
-                              const M3<float>& R, const F* q, const F* qd, const F* act, const double* clip_rows, int frame_id, double frac) {
+  static constexpr int OBS_HIST_CHUNKS = 5;   // 2 * prop_dim <= 66 floats, 16 per chunk
+  struct ObsIn {
+    F h[OBS_HIST_CHUNKS], ha[2];
+    RefRaw fut[4];
+  };
+  static LL_HD ObsIn obs_gather(const L& ln, const StepParams& P, const float* hist_row, bool fill, const double* clip_rows, int frame_id,
+                                double frac) {
+    ObsIn in;
+    const int Pd = P.prop_dim;
+    const long a0 = 3L * Pd;
+    if (!fill) {
+      for (int c = 0; c < OBS_HIST_CHUNKS; c++) in.h[c] = ln.ld16(hist_row + Pd, 16 * c, 2 * Pd);
+      for (int c = 0; c < 2; c++) in.ha[c] = ln.ld16(hist_row + a0 + 12, 16 * c, 24);
+    } else {
+      for (int c = 0; c < OBS_HIST_CHUNKS; c++) in.h[c] = ln.lane_f(0.0f);
+      in.ha[0] = in.ha[1] = ln.lane_f(0.0f);
+    }
+    const double hz[4] = {1. / 30., 1. / 15., 1. / 3., 1.};                     // ML:75-86
+    for (int h = 0; h < 4; h++) {
+      double t = P.frame_step * frac + hz[h];
+      int fid = (int)floor(t / P.frame_step);
+      double ff = t / P.frame_step - fid;
+      const double* fc = clip_rows + (long)(frame_id + fid) * 19;
+      in.fut[h] = mocap_gather(ln, fc, fc + 19, ff, P.frame_step);
+    }
+    return in;
+  }
+  static LL_HD void obs_emit(const L& ln, const StepParams& P, float* row, bool fill, const ObsIn& in, const Base& bs, const M3<float>& R,
+                             const F* q, const F* qd, const F* act) {
     const int Pd = P.prop_dim;
     B lane3 = ln.legf() < 2.5f;
-    long a0 = 3L * Pd;
-    // --- history shift (or pre-fill handled below) ---
-    if (!fill) {
-      for (int i = 0; i < (2 * Pd + 3) / 4; i++) {
-        F idx = ln.legf() + (float)(4 * i);
-        B ok = idx < (float)(2 * Pd);
-        F v = ln.ldl(hist_row, Pd + 4 * i, 1);
-        ln.stl_if(ok, row, 4 * i, 1, lm::sel(ok, v, ln.lane_f(0.0f)));
-      }
-      for (int i = 0; i < 6; i++) {                               // 24 action history floats
-        F v = ln.ldl(hist_row, a0 + 12 + 4 * i, 1);
-        ln.stl(row, a0 + 4 * i, 1, v);
-      }
+    const long a0 = 3L * Pd;
+    if (!fill) {                                                    // history shift
+      for (int c = 0; c < OBS_HIST_CHUNKS; c++) ln.st16(row, 16 * c, 2 * Pd, in.h[c]);
+      for (int c = 0; c < 2; c++) ln.st16(row + a0, 16 * c, 24, in.ha[c]);
     }
     // --- newest prop frame (PLE:247-260) ---
     V3u wl = mulT(R, bs.w), vl = mulT(R, bs.v);
@@ -672,15 +707,10 @@ struct Pmc {
       for (int j = 0; j < 3; j++) ln.stl(row, a0 + 12 * kf + j, 3, act[j]);                                   // raw action (quirk Q3)
     }
     // --- future goals (ML:75-86 + PLE:299-317) ---
-    const double hz[4] = {1. / 30., 1. / 15., 1. / 3., 1.};
     long f0 = a0 + 36;
     Q4 qbi = qconj(qnormalize(bs.q));
     for (int h = 0; h < 4; h++) {
-      double t = P.frame_step * frac + hz[h];
-      int fid = (int)floor(t / P.frame_step);
-      double ff = t / P.frame_step - fid;
-      const double* fc = clip_rows + (long)(frame_id + fid) * 19;
-      RefPose rp = mocap_interp(ln, fc, fc + 19, ff, P.frame_step, false);
+      RefPose rp = mocap_finish(in.fut[h], P.frame_step, false);
       V3u dp = mulT(R, mk3<float>(rp.p.x - bs.p.x, rp.p.y - bs.p.y, rp.p.z - bs.p.z));
       V3u aa;
       axis_angle_scaled(qmul(qbi, qnormalize(rp.q)), &aa);
@@ -723,15 +753,17 @@ struct Pmc {
     int fid = (int)floor(t0 / P.frame_step);                                  // ML:52
     double frac = (t0 - fid * P.frame_step) / P.frame_step;                    // ML:53
     const double* rows = P.frames + (long)P.clip_off[clip] * 19;
-    RefPose rp = mocap_interp(ln, rows + (long)fid * 19, rows + (long)(fid + 1) * 19, frac, P.frame_step, true);
+    RefRaw rr = mocap_gather(ln, rows + (long)fid * 19, rows + (long)(fid + 1) * 19, frac, P.frame_step);
+    float* row = P.obs + (long)env * P.obs_dim;
+    ObsIn oin = obs_gather(ln, P, row, true, rows, fid, frac);
+    RefPose rp = mocap_finish(rr, P.frame_step, true);
     Base bs;
     bs.p = rp.p; bs.q = rp.q; bs.v = rp.v; bs.w = rp.w;
     store_state(ln, P.kin, N, env, bs, rp.jp, rp.jv);                          // PLE:162
     store_state(ln, P.state, N, env, bs, rp.jp, rp.jv);                        // PLE:163
     M3<float> R = qmat(qnormalize(bs.q));
     F zero3[3] = {ln.lane_f(0.0f), ln.lane_f(0.0f), ln.lane_f(0.0f)};
-    float* row = P.obs + (long)env * P.obs_dim;
-    write_obs(ln, P, env, row, row, true, bs, R, rp.jp, rp.jv, zero3, rows, fid, frac);   // PLE:168-170
+    obs_emit(ln, P, row, true, oin, bs, R, rp.jp, rp.jv, zero3);               // PLE:168-170
     V3l fw = foot_world(ln, P.legc, bs.p, R, rp.jp[0], rp.jp[1], rp.jp[2]);
     for (int c = 0; c < 3; c++) {
       F v = (c == 0) ? fw.x : (c == 1 ? fw.y : fw.z);
@@ -790,14 +822,13 @@ struct Pmc {
   }
 
   // sample (clip, t0) for a new episode: ML:59-63 + ML:50-51, Philox stream keyed on (seed; env, episode)
-  static LL_HD void sample_start(const StepParams& P, int env, uint32_t episode, int* clip, double* t0) {
+  static LL_HD void sample_start(const L& ln, const StepParams& P, int env, uint32_t episode, int* clip, double* t0) {
     uint32_t r[4];
     philox4x32((uint32_t)env, episode, 0x5eedu, 0u, (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r);
     double u1 = u01_from(r[0], r[1]), u2 = u01_from(r[2], r[3]);
-    int c = P.n_clips - 1;
-    for (int i = 0; i < P.n_clips; i++) {
-      if (u1 < P.cdf[i]) { c = i; break; }
-    }
+    // first i with u1 < cdf[i] (np.random.choice's inverse-cdf search) == the number of entries <= u1, cdf being non-decreasing
+    int c = ln.count_le16(P.cdf, P.n_clips, u1);
+    if (c > P.n_clips - 1) c = P.n_clips - 1;
     *clip = c;
     *t0 = u2 * (P.frame_step * (double)(P.clip_len[c] - P.margin - 1));
   }
@@ -809,6 +840,8 @@ struct Pmc {
     const int N = P.n_envs;
     Base bs;
     F q[3], qd[3], act[3], tgt[3];
+    PMC_TS(0);
+    if (PMC_ABL(8)) return;
     load_state(ln, P.state, N, env, bs, q, qd);
     for (int j = 0; j < 3; j++) {
       act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
@@ -817,20 +850,38 @@ struct Pmc {
     }
     double t = P.time[env], t_loc = t;
     const int clip = P.clip[env];
+    const int clen = P.clip_len[clip];
+    const double* rows = P.frames + (long)P.clip_off[clip] * 19;
+    PMC_TS(1);
     for (int s = 0; s < P.n_sub; s++) {                                      // PLE:202
       substep(ln, P, bs, q, qd, tgt);                                        // PLE:204-206
       t_loc = t;                                                             // PLE:208 motion.step(time BEFORE the increment), quirk Q2
       t += P.dt_d;                                                           // PLE:210
+    PMC_TS(10 + (s < 20 ? s : 20));
     }
+    if (PMC_ABL(4)) { store_state(ln, P.state, N, env, bs, q, qd); P.time[env] = t; return; }
     int fid = (int)floor(t_loc / P.frame_step);                              // ML:66
     {                                                                        // keep a done-but-still-stepped env inside its clip
-      int fmax = P.clip_len[clip] - P.frame_rate - 3;
+      int fmax = clen - P.frame_rate - 3;
       if (fid > fmax) fid = fmax;
     }
     double frac = (t_loc - fid * P.frame_step) / P.frame_step;               // ML:67
-    const double* rows = P.frames + (long)P.clip_off[clip] * 19;
-    RefPose rp = mocap_interp(ln, rows + (long)fid * 19, rows + (long)(fid + 1) * 19, frac, P.frame_step, true);   // PLE:217
 
+    // --- gather: every load the rest of the step needs is issued here, ahead of the first store (one wave per SIMD hides
+    //     no memory latency, and the compiler may not move a load above a store it cannot prove distinct) ---
+    float* row = P.obs + (long)env * P.obs_dim;
+    RefRaw rr = mocap_gather(ln, rows + (long)fid * 19, rows + (long)(fid + 1) * 19, frac, P.frame_step);                  // PLE:217
+    ObsIn oin = obs_gather(ln, P, row, false, rows, fid, frac);
+    constexpr int TRAJ_CHUNKS = 13;                                          // obs_dim <= 207
+    F told[TRAJ_CHUNKS];
+    if (P.traj) for (int c = 0; c < TRAJ_CHUNKS; c++) told[c] = ln.ld16(row, 16 * c, P.obs_dim);
+    const int steps = P.ep_steps[env] + 1;                                    // PLE:197
+    const float rsum0 = P.reward_sum[env];
+    const double max_steps = P.max_steps[clip];
+    const uint32_t ep0 = P.ep_count[env];
+    RefPose rp = mocap_finish(rr, P.frame_step, true);
+
+    PMC_TS(2);
     if (P.scripted_state) {   // parity hook: the caller plays PyBullet (how the golden harness drove the reference)
       const float* ss = P.scripted_state + (long)env * 37;
       bs.p = mk3<float>(ss[0], ss[1], ss[2]);
@@ -846,7 +897,6 @@ struct Pmc {
 
     Q4 qn = qnormalize(bs.q);
     M3<float> R = qmat(qn);
-    float* row = P.obs + (long)env * P.obs_dim;
     const int ar = P.auto_reset;
 
     // --- reward (PLE:350-426) ---
@@ -877,13 +927,14 @@ struct Pmc {
                    P.rw[3] * expf(-20.0f * e_p - 10.0f * angle * angle) + P.rw[4] * expf(-2.0f * e_v - 0.2f * e_w);   // PLE:386-425
     if (bad) reward = 0.0f;
 
+    PMC_TS(3);
     // --- termination (PLE:337-348) ---
     int reason = 0;
     {
       float left_z = R.m[2] * R.m[3] - R.m[5] * R.m[0];                       // up.x*fwd.y - up.y*fwd.x   LR:171-172
       if (left_z > 0.70710678118654752f || left_z < -0.70710678118654752f) reason |= LLS_DONE_FALL;
       if (R.m[8] < 0.5f) reason |= LLS_DONE_FALL;                             // cos(60 deg)  LR:176
-      if (fid >= P.clip_len[clip] - P.margin - 1) reason |= LLS_DONE_CLIP_END;   // ML:168-172
+      if (fid >= clen - P.margin - 1) reason |= LLS_DONE_CLIP_END;   // ML:168-172
       if (fabsf(angle) > 1.0f || e_p > 1.0f) reason |= LLS_DONE_DIVERGED;     // PLE:319-335
       if (bad) reason |= LLS_DONE_NONFINITE;
       if (P.set_obstacle && !bad) {
@@ -891,15 +942,15 @@ struct Pmc {
         if (obstacle_contact(ln, P, env, clip, t, bs.p, R, kf)) reason |= LLS_DONE_COLLISION;   // PLE:341-346
       }
     }
-    const int steps = P.ep_steps[env] + 1;                                    // PLE:197
-    const float rsum = P.reward_sum[env] + reward;                            // PLE:231
+    const float rsum = rsum0 + reward;                                        // PLE:231
 
+    PMC_TS(4);
     // --- trajectory row for the learner: the observation the policy acted on, its action, the reward
     //     and done flag of this transition; written before the obs row is replaced ---
     if (P.traj) {
       const int W = P.obs_dim + 14;
       float* tr = P.traj + ((long)P.traj_slot * N + env) * W;
-      for (int i0 = 0; i0 < P.obs_dim; i0 += PMC_ROW) ln.copy16(tr, row, i0, P.obs_dim);
+      for (int c = 0; c < TRAJ_CHUNKS; c++) ln.st16(tr, 16 * c, P.obs_dim, told[c]);
       for (int j = 0; j < 3; j++) ln.stl(tr, P.obs_dim + j, 3, act[j]);
       tr[P.obs_dim + 12] = reward;
       tr[P.obs_dim + 13] = reason ? 1.0f : 0.0f;
@@ -907,8 +958,9 @@ struct Pmc {
 
     // --- observation: into term_obs when the episode ends under auto-reset, else in place ---
     float* out_row = (reason && ar) ? (P.term_obs + (long)env * P.obs_dim) : row;
-    write_obs(ln, P, env, out_row, row, false, bs, R, q, qd, act, rows, fid, frac);               // PLE:227
+    obs_emit(ln, P, out_row, false, oin, bs, R, q, qd, act);                                      // PLE:227
 
+    PMC_TS(5);
     // --- stores ---
     store_state(ln, P.state, N, env, bs, q, qd);
     store_state(ln, P.kin, N, env, gb, rp.jp, rp.jv);
@@ -923,10 +975,11 @@ struct Pmc {
     P.done[env] = reason ? 1 : 0;
     P.done_reason[env] = (uint8_t)reason;
 
+    PMC_TS(6);
     if (reason) {
       // PLE:235-240: publish this episode's per-clip statistics; the pre-step kernel folds them into the table
       // (highest env index wins when several envs finish the same clip in one step == sequential overwrite order)
-      double ms = P.max_steps[clip];
+      const double ms = max_steps;
       float avg_r = (float)((double)rsum / ms), avg_l = (float)((double)steps / (ms + 1.0));
       if (bad) avg_r = 0.0f;
       unsigned long long tag = ((unsigned long long)(env + 1)) << 32;
@@ -937,12 +990,13 @@ struct Pmc {
       if (ar) {
         int nclip;
         double nt0;
-        uint32_t ep = P.ep_count[env] + 1;
-        sample_start(P, env, ep, &nclip, &nt0);
-        P.ep_count[env] = ep;
+        const uint32_t ep = ep0 + 1;
+        sample_start(ln, P, env, ep, &nclip, &nt0);
         reset_env(ln, P, env, nclip, nt0);
+        P.ep_count[env] = ep;
       }
     }
+    PMC_TS(7);
   }
 
   static LL_HD uint32_t f2u(float x) {

@@ -1,6 +1,7 @@
 // pmc_tables.hpp -- host side: model blob (include/llenv_model.h) + ll_config -> kernel constant tables and scalars.
 #pragma once
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -202,6 +203,9 @@ static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
   P.obs_dim = LL_STACK * off + LL_STACK * 12 + LL_FUTURE_DIM;           // PLE:114-121
   P.sample_factor = cfg.prioritized_sample_factor;
   P.set_obstacle = cfg.set_obstacle ? 1 : 0;
+#if defined(PMC_ABLATION)
+  if (const char* dbg = getenv("LL_DEBUG_FLAGS")) P.debug_flags = atoi(dbg);
+#endif
   P.ob_half_height = (float)cfg.obstacle_height;                          // PLE:184 halfExtents z
   P.seed = cfg.seed;
   return "";

@@ -32,7 +32,7 @@ struct HostBackend {
       int env = ids ? ids[i] : i, c;
       double t;
       uint32_t ep = P.ep_count[env] + 1;
-      K::sample_start(P, env, ep, &c, &t);
+      K::sample_start(ln, P, env, ep, &c, &t);
       P.ep_count[env] = ep;
       if (clip) c = clip[i];
       if (t0) t = t0[i];

@@ -1,0 +1,40 @@
+"""Per-wave timeline of pmc_step_kernel from the PMC_TS wall-clock stamps of an ablation build (tools/ablate.sh build).
+
+    LL_DEBUG_FLAGS=16 LL_LIB=tools/_build/libllenv_abl.so python tools/timeline.py [n_envs]
+"""
+import os, sys, math, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np
+from lifelike_agility_and_play_amd import capi, mocap, urdf_model
+RW = {'joint_pos': 0.3, 'joint_vel': 0.05, 'end_effector': 0.1, 'root_pose': 0.5, 'root_vel': 0.05}
+PT = ['joint_pos', 'joint_vel', 'root_ang_vel_loc', 'root_lin_vel_loc', 'e_g']
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+blob = urdf_model.default_model_blob(); table = mocap.load_mocap('', 0.02)
+cfg = capi.make_config(n, control_freq=50.0, sim_freq=500.0, kd=0.5, reward_weights=RW, prop_type=PT, prioritized_sample_factor=3.0, auto_reset=1, seed=1)
+E = capi.Engine(cfg, blob, table, lib_path=os.environ['LL_LIB'])
+fn = E.lib.ll_debug_timestamps; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p]
+E.reset()
+NAMES = {0: 'entry', 1: 'state loaded', 2: 'mocap gathered', 3: 'reward', 4: 'termination', 5: 'obs emitted', 6: 'stores', 7: 'end (reset path)'}
+for k in range(10):
+    NAMES[10 + k] = 'substep %d' % k
+acc = []
+for it in range(60):
+    E.fill_random_actions(math.exp(-2)); E.step()
+    if it < 40:
+        continue
+    ts = np.zeros((n, 32), np.uint64)
+    assert fn(E.h, ts.ctypes.data_as(C.c_void_p)) == 0
+    done = E.reward_done()[1]
+    t = ts.astype(np.float64) * 0.01          # us (100 MHz)
+    t0 = t[:, 0].min()
+    acc.append((t - t0, np.asarray(done).astype(bool)))
+order = [0, 1] + list(range(10, 20)) + [2, 3, 4, 5, 6, 7]
+print('n_envs %d: stamps relative to the first wave entry, us; mean over 20 steps of [mean | max over envs], split by reset' % n)
+print('%-18s %8s %8s | %8s %8s (resetting envs)' % ('mark', 'mean', 'max', 'mean', 'max'))
+for k in order:
+    a = np.array([x[:, k].mean() for x, d in acc]).mean(); b = np.array([x[:, k].max() for x, d in acc]).mean()
+    rs = [x[d, k] for x, d in acc if d.any()]
+    c = np.mean([r.mean() for r in rs]) if rs else float('nan'); e = np.mean([r.max() for r in rs]) if rs else float('nan')
+    print('%-18s %8.2f %8.2f | %8.2f %8.2f' % (NAMES[k], a, b, c, e))
+print('resets per step: %.1f' % np.mean([d.sum() for x, d in acc]))
+E.close()
