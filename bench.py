@@ -107,8 +107,7 @@ def main():
     n_done = [0]                                           # control steps executed so far == the engine's step index
 
     def one_step(_):
-        eng.fill_random_actions(SIGMA)
-        eng.step()
+        eng.step_random(SIGMA)                             # ONE launch: draws a ~ N(0, sigma^2) on device and steps
         n_done[0] += 1
         if traj is not None and n_done[0] % UNROLL == 0:   # the step kernel itself records the rows (ll_enable_trajectory);
             traj.gather_async(n_done[0] // UNROLL - 1, 0)  # the gather of this unroll overlaps with the next unroll's steps

@@ -160,6 +160,11 @@ int ll_step_scripted(ll_engine* e, const float* d_actions, const float* h_state,
  * device by Philox keyed on (seed, env, step) into the engine's action buffer. */
 int ll_fill_random_actions(ll_engine* e, float sigma);
 
+/* ll_fill_random_actions(e, sigma) followed by ll_step(e, NULL), as ONE kernel launch: the step kernel draws the same
+ * Philox stream itself, records the actions in the engine's action buffer and applies them.  Stands for the reference
+ * actor's random-policy loop (`env.step(np.random.randn(12) * sigma)`, learning/actors: SURVEY 8d). */
+int ll_step_random(ll_engine* e, float sigma);
+
 /* Block until all queued work on the engine's stream has finished. */
 int ll_sync(ll_engine* e);
 /* Launch on a caller-owned hipStream_t (e.g. torch's current stream) instead of the engine's own, so that the

@@ -81,6 +81,7 @@ _SIGS = {
     'll_step': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_step_scripted': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'll_fill_random_actions': (C.c_int, [C.c_void_p, C.c_float]),
+    'll_step_random': (C.c_int, [C.c_void_p, C.c_float]),
     'll_sync': (C.c_int, [C.c_void_p]),
     'll_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_enable_trajectory': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
@@ -193,6 +194,10 @@ class Engine(object):
 
     def fill_random_actions(self, sigma):
         self._chk(self.lib.ll_fill_random_actions(self.h, float(sigma)))
+
+    def step_random(self, sigma):
+        """fill_random_actions(sigma) + step() as one kernel launch."""
+        self._chk(self.lib.ll_step_random(self.h, float(sigma)))
 
     def sync(self):
         self._chk(self.lib.ll_sync(self.h))

@@ -27,10 +27,12 @@
 #define LL_HD __host__ __device__ __forceinline__
 #define LL_D __device__ __forceinline__
 #define LL_NOUNROLL _Pragma("nounroll")
+#define LL_UNROLL _Pragma("unroll")
 #else
 #define LL_HD inline
 #define LL_D inline
 #define LL_NOUNROLL _Pragma("GCC unroll 1")
+#define LL_UNROLL
 #endif
 
 namespace lm {
@@ -75,6 +77,7 @@ struct GpuLanes {
   float* lds_;
   mutable int cbase_;   // LDS word of the per-leg constant table (+ leg)
   mutable int tbase_;   // LDS word of the candidate table (+ lane16)
+  mutable unsigned long long tm_[16];
 
   LL_D GpuLanes(float* lds) : leg_((threadIdx.x >> 2) & 3), sub_(threadIdx.x & 3), lane16_(threadIdx.x & 15), lds_(lds), cbase_(0), tbase_(0) {}
 
@@ -189,8 +192,8 @@ struct GpuLanes {
   // whose turn it is keeps its increment; masks m0..m3 are the lane masks of the four turns), one wait state, v_fmac with a
   // DPP row broadcast (every lane's pending increment moves by nk * d).  4 issue slots per turn.
   template <int S_>
-  static LL_D void turns4(F& u, F& dl, F lo, F hi, F k0, F k1, F k2, F k3) {
-    const unsigned long long m0 = 0x0001000100010001ull << S_, m1 = m0 << 4, m2 = m0 << 8, m3 = m0 << 12;
+  LL_D void turns4(F& u, F& dl, F lo, F hi, F k0, F k1, F k2, F k3) const {
+    const unsigned long long m0 = tm_[S_], m1 = tm_[4 + S_], m2 = tm_[8 + S_], m3 = tm_[12 + S_];
     float d;
 #define LL_T1(K, M, L_)                                                                          \
     "v_med3_f32 %2, %0, %3, %4\n\t"                                                            \
@@ -202,6 +205,15 @@ struct GpuLanes {
     else if (S_ == 2) asm(LL_T1("%5", "%9", "2") LL_T1("%6", "%10", "6") LL_T1("%7", "%11", "10") LL_T1("%8", "%12", "14") : "+v"(u), "+v"(dl), "=&v"(d) : "v"(lo), "v"(hi), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
     else              asm(LL_T1("%5", "%9", "3") LL_T1("%6", "%10", "7") LL_T1("%7", "%11", "11") LL_T1("%8", "%12", "15") : "+v"(u), "+v"(dl), "=&v"(d) : "v"(lo), "v"(hi), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
 #undef LL_T1
+  }
+  // the sixteen turn masks (lane t of every row), made opaque so they stay resident in SGPR pairs across the solver loop
+  // instead of being rebuilt from a 32-bit half before every turn
+  LL_D void prepare_turn_masks() const {
+    for (int t = 0; t < 16; t++) {
+      unsigned long long m = 0x0001000100010001ull << t;
+      asm volatile("" : "+s"(m));
+      tm_[t] = m;
+    }
   }
   static LL_D bool any(B m) { return __any(m); }   // wave-level: guards wave-uniform branches
 
@@ -220,7 +232,8 @@ struct GpuLanes {
   // cooperative copy of up to 16 consecutive floats: lane i moves element i0 + i (if below n)
   LL_D void copy16(float* dst, const float* src, int i0, int n) const { const int i = i0 + lane16_; if (i < n) dst[i] = src[i]; }
   // the two halves of copy16, so that a caller can issue every load of a row before its first store
-  LL_D F ld16(const float* src, int i0, int n) const { const int i = i0 + lane16_; return i < n ? src[i] : 0.0f; }
+  // (the index is clamped rather than the load predicated: a predicated load is a branch, and a wait, per chunk; n >= 1)
+  LL_D F ld16(const float* src, int i0, int n) const { const int i = i0 + lane16_; const float v = src[i < n ? i : n - 1]; return i < n ? v : 0.0f; }
   LL_D void st16(float* dst, int i0, int n, F v) const { const int i = i0 + lane16_; if (i < n) dst[i] = v; }
   // number of entries of the non-decreasing table p[0..n) that are <= u: sixteen entries per round trip, row-summed
   LL_D int count_le16(const double* p, int n, double u) const {

@@ -25,13 +25,103 @@
 
 typedef Pmc<GpuLanes> K;
 
-__global__ __launch_bounds__(PMC_WAVE, 2) void pmc_step_kernel(StepParams P) {   // <= 256 registers: two waves per SIMD
+// PLE:235-240 for the batch, by one wavefront: fold the statistics published by finished episodes into the per-clip table
+// (lane = clip, 64 per pass), then rebuild p ~ (1 - avg_reward_sum)^factor and its inclusive CDF.  Called by the last
+// workgroup of a step kernel to finish, so the table a step leaves behind already contains the episodes it ended.
+__device__ __forceinline__ double wave_sum(double x) {
+  for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
+  return x;
+}
+__device__ __forceinline__ void table_fold_wave(const StepParams& P) {
+  const int lane = threadIdx.x & 63, n = P.n_clips;
+  bool mine = false;
+  for (int c = lane; c < n; c += PMC_WAVE) {
+    const unsigned long long pr = __hip_atomic_load(P.pending_reward + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long pl = __hip_atomic_load(P.pending_len + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (pr) {
+      P.avg_reward[c] = (double)__uint_as_float((uint32_t)pr);
+      P.avg_len[c] = (double)__uint_as_float((uint32_t)pl);
+      __hip_atomic_store(P.pending_reward + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(P.pending_len + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mine = true;
+    }
+  }
+  if (!__any(mine)) return;
+  double part = 0.0;
+  for (int c = lane; c < n; c += PMC_WAVE) {
+    const double p = pow(1.0 - P.avg_reward[c], P.sample_factor);
+    P.prob[c] = p;
+    part += p;
+  }
+  const double inv = 1.0 / wave_sum(part);
+  double carry = 0.0;
+  for (int c0 = 0; c0 < n; c0 += PMC_WAVE) {       // inclusive scan, 64 clips per pass
+    const int c = c0 + lane;
+    double x = 0.0;
+    if (c < n) { x = P.prob[c] * inv; P.prob[c] = x; }
+    for (int d = 1; d < PMC_WAVE; d <<= 1) {
+      const double y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    x += carry;
+    if (c < n) P.cdf[c] = (c == n - 1) ? 1.0 : x;
+    carry = __shfl(x, PMC_WAVE - 1);
+  }
+}
+
+// The synthetic random policy a ~ N(0, sigma^2): Philox4x32-10 keyed on (seed; group of four actions, step) + Box-Muller.
+__device__ __forceinline__ float4 random_action_group(const StepParams& P, uint32_t gid, float sigma) {
+  uint32_t r[4];
+  philox4x32(gid, (uint32_t)P.step_count, (uint32_t)(P.step_count >> 32), 0xAC710u, (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r);
+  const float k = 2.3283064365386963e-10f;   // 2^-32
+  float u1 = fminf(((float)r[0] + 1.0f) * k, 1.0f), u2 = (float)r[1] * k, u3 = fminf(((float)r[2] + 1.0f) * k, 1.0f), u4 = (float)r[3] * k;
+  float m1 = sqrtf(-2.0f * logf(u1)), m2 = sqrtf(-2.0f * logf(u3));
+  float4 o;
+  o.x = sigma * m1 * cosf(6.283185307179586f * u2); o.y = sigma * m1 * sinf(6.283185307179586f * u2);
+  o.z = sigma * m2 * cosf(6.283185307179586f * u4); o.w = sigma * m2 * sinf(6.283185307179586f * u4);
+  return o;
+}
+
+// OCC = wavefronts per SIMD the register budget allows: 1 (512 registers, nothing spills to scratch) while the grid fits the
+// chip one wavefront per SIMD, 2 (256 registers) for larger batches, where a second resident wavefront hides issue stalls.
+template <int OCC>
+__global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int env = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);      // one env = one 16-lane DPP row
+  const int row = threadIdx.x >> 4;                                         // one env = one 16-lane DPP row
+  const int env = blockIdx.x * PMC_ENVS_PER_WAVE + row;
   GpuLanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);           // all 64 lanes copy, also those without an env
-  if (env >= P.n_envs) return;
-  K::step_env(ln, P, env);
+  if (env < P.n_envs) {
+    float act[3];
+    if (P.action_sigma > 0.0f) {
+      // lanes 0..2 of the row draw the env's three groups of four actions, record them, and hand them to the leg lanes via LDS
+      float* stash = lds + LC_COUNT * 4 + CAND_TABLE_WORDS * PMC_ROW + row * 12;
+      const int l16 = threadIdx.x & 15;
+      const uint32_t g = (uint32_t)(l16 < 3 ? l16 : 0);
+      const float4 o = random_action_group(P, (uint32_t)env * 3u + g, P.action_sigma);
+      if (l16 < 3) {
+        reinterpret_cast<float4*>(P.actions_out)[(long)env * 3 + l16] = o;
+        reinterpret_cast<float4*>(stash)[l16] = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the row's LDS writes have landed (one wave)
+      for (int j = 0; j < 3; j++) act[j] = stash[ln.leg() * 3 + j];
+    } else {
+      for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
+    }
+    K::step_env(ln, P, env, act);
+  }
+  // The last workgroup to get here folds this step's finished episodes into the sampling table.  The statistics travel by
+  // device-scope atomics only (publish_max), so no cache write-back is needed -- a __threadfence() here would flush this
+  // XCD's L2 once per workgroup.  Waiting for the wave's own atomics to be acknowledged before it takes its ticket orders
+  // them ahead of the ticket; the folding wave reads them back with device-scope atomic loads.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned int ticket = 0;
+  if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(P.block_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket == gridDim.x - 1) {
+    table_fold_wave(P);
+    if (threadIdx.x == 0) __hip_atomic_store(P.block_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 __global__ __launch_bounds__(PMC_WAVE) void pmc_reset_kernel(StepParams P, const int32_t* ids, int n, const int32_t* clip, const double* t0) {
@@ -53,67 +143,17 @@ __global__ __launch_bounds__(PMC_WAVE) void pmc_reset_kernel(StepParams P, const
   P.done_reason[env] = 0;
 }
 
-// PLE:235-240 for the batch, one 256-thread block: fold the statistics published by finished episodes into the per-clip
-// table (one thread per clip), then rebuild p ~ (1 - avg_reward_sum)^factor and its inclusive CDF.
-__global__ __launch_bounds__(256) void pmc_table_kernel(StepParams P, double* avg_r, double* avg_l, double* prob, double* cdf) {
-  __shared__ double red[256];
-  __shared__ int any_pending;
-  const int tid = threadIdx.x;
-  if (tid == 0) any_pending = 0;
-  __syncthreads();
-  for (int c = tid; c < P.n_clips; c += 256) {
-    unsigned long long pr = P.pending_reward[c], pl = P.pending_len[c];
-    if (pr) {
-      avg_r[c] = (double)__uint_as_float((uint32_t)pr);
-      avg_l[c] = (double)__uint_as_float((uint32_t)pl);
-      P.pending_reward[c] = 0ull;
-      P.pending_len[c] = 0ull;
-      any_pending = 1;
-    }
-  }
-  __syncthreads();
-  if (!any_pending) return;
-  double part = 0.0;
-  for (int c = tid; c < P.n_clips; c += 256) {
-    double p = pow(1.0 - avg_r[c], P.sample_factor);
-    prob[c] = p;
-    part += p;
-  }
-  red[tid] = part;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) red[tid] += red[tid + s];
-    __syncthreads();
-  }
-  const double inv = 1.0 / red[0];
-  for (int c = tid; c < P.n_clips; c += 256) prob[c] *= inv;
-  __syncthreads();
-  if (tid == 0) {
-    double acc = 0.0;
-    for (int c = 0; c < P.n_clips; c++) { acc += prob[c]; cdf[c] = acc; }
-    cdf[P.n_clips - 1] = 1.0;
-  }
-}
-
-// synthetic random policy: a ~ N(0, sigma^2), Philox4x32-10 keyed on (seed; element, step) + Box-Muller, four per thread
 __global__ void pmc_actions_kernel(StepParams P, float* actions, float sigma) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= P.n_envs * 3) return;
-  uint32_t r[4];
-  philox4x32((uint32_t)gid, (uint32_t)P.step_count, (uint32_t)(P.step_count >> 32), 0xAC710u, (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r);
-  const float k = 2.3283064365386963e-10f;   // 2^-32
-  float u1 = fminf(((float)r[0] + 1.0f) * k, 1.0f), u2 = (float)r[1] * k, u3 = fminf(((float)r[2] + 1.0f) * k, 1.0f), u4 = (float)r[3] * k;
-  float m1 = sqrtf(-2.0f * logf(u1)), m2 = sqrtf(-2.0f * logf(u3));
-  float4 o;
-  o.x = sigma * m1 * cosf(6.283185307179586f * u2); o.y = sigma * m1 * sinf(6.283185307179586f * u2);
-  o.z = sigma * m2 * cosf(6.283185307179586f * u4); o.w = sigma * m2 * sinf(6.283185307179586f * u4);
-  reinterpret_cast<float4*>(actions)[gid] = o;
+  reinterpret_cast<float4*>(actions)[gid] = random_action_group(P, (uint32_t)gid, sigma);
 }
 
 struct HipBackend {
   int device;
   hipStream_t own = nullptr, stream = nullptr;
   bool timing = false;
+  int simds = 1024;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
   size_t ev_used = 0;
 
@@ -124,6 +164,9 @@ struct HipBackend {
     if (dev < 0 || dev >= n) throw PmcError(LL_EINVAL, "device ordinal out of range");
     HIPCHK(hipSetDevice(dev));
     HIPCHK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    simds = prop.multiProcessorCount * 4;             // four SIMDs per compute unit
     stream = own;
   }
   ~HipBackend() {
@@ -154,7 +197,7 @@ struct HipBackend {
   }
   void sync() { use(); HIPCHK(hipStreamSynchronize(stream)); }
 
-  static size_t lds_bytes() { return ((size_t)LC_COUNT * 4 + (size_t)CAND_TABLE_WORDS * PMC_ROW) * sizeof(float); }
+  static size_t lds_bytes() { return ((size_t)LC_COUNT * 4 + (size_t)CAND_TABLE_WORDS * PMC_ROW + PMC_ENVS_PER_WAVE * 12) * sizeof(float); }
   void launch_step(const StepParams& P) {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
@@ -169,7 +212,8 @@ struct HipBackend {
       ev = &evs[ev_used++];
       HIPCHK(hipEventRecord(ev->first, stream));
     }
-    hipLaunchKernelGGL(pmc_step_kernel, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
+    if (blocks <= simds) hipLaunchKernelGGL(pmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
+    else                 hipLaunchKernelGGL(pmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->second, stream));
   }
@@ -179,15 +223,11 @@ struct HipBackend {
     hipLaunchKernelGGL(pmc_reset_kernel, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P, ids, n, clip, t0);
     HIPCHK(hipGetLastError());
   }
-  void launch_prestep(const StepParams& P, double* avg_r, double* avg_l, double* prob, double* cdf, float* actions, float sigma) {
+  void launch_actions(const StepParams& P, float* actions, float sigma) {
     use();
-    hipLaunchKernelGGL(pmc_table_kernel, dim3(1), dim3(256), 0, stream, P, avg_r, avg_l, prob, cdf);
+    const int threads = 256;
+    hipLaunchKernelGGL(pmc_actions_kernel, dim3((P.n_envs * 3 + threads - 1) / threads), dim3(threads), 0, stream, P, actions, sigma);
     HIPCHK(hipGetLastError());
-    if (actions) {
-      const int threads = 256;
-      hipLaunchKernelGGL(pmc_actions_kernel, dim3((P.n_envs * 3 + threads - 1) / threads), dim3(threads), 0, stream, P, actions, sigma);
-      HIPCHK(hipGetLastError());
-    }
   }
   void enable_timing(bool on) { timing = on; }
   void collect_timing(double* avg_ms, int* n) {

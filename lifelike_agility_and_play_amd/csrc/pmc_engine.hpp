@@ -20,7 +20,6 @@ struct PmcEngine {
   ll_config cfg;
   StepParams P;
   bool have_mocap = false, have_reset = false;
-  bool table_fresh = false;   // sampling table already folded since the last step
   // table state (device, float64)
   double *d_avg_reward = nullptr, *d_avg_len = nullptr, *d_prob = nullptr, *d_cdf = nullptr;
   float* d_actions = nullptr;       // engine-owned action buffer
@@ -67,6 +66,8 @@ struct PmcEngine {
     d_actions = dalloc<float>(N * 12);
     P.actions = d_actions;
     P.counters = dalloc<unsigned long long>(4 + (size_t)PMC_TS_SLOTS * N);
+    P.block_ticket = dalloc<unsigned int>(2);
+    P.actions_out = d_actions;
     d_reset_ids = dalloc<int32_t>(N); d_reset_clip = dalloc<int32_t>(N); d_reset_t0 = dalloc<double>(N);
   }
   ~PmcEngine() {
@@ -107,7 +108,7 @@ struct PmcEngine {
     cdf[n_clips - 1] = 1.0;
     bk.h2d(d_prob, prob.data(), n_clips * 8);
     bk.h2d(d_cdf, cdf.data(), n_clips * 8);
-    P.cdf = d_cdf;
+    P.cdf = d_cdf; P.prob = d_prob; P.avg_reward = d_avg_reward; P.avg_len = d_avg_len;
     have_mocap = true;
   }
 
@@ -168,22 +169,27 @@ struct PmcEngine {
       bk.h2d(d_reset_t0, t0, n * 8);
     }
     if (P.set_obstacle && !have_obstacles) throw PmcError(LL_ESTATE, "set_obstacle needs ll_load_obstacles");
-    bk.launch_prestep(P, d_avg_reward, d_avg_len, d_prob, d_cdf, nullptr, 0.0f);   // fold pending statistics first
     bk.launch_reset(P, env_ids ? d_reset_ids : nullptr, n, clip ? d_reset_clip : nullptr, t0 ? d_reset_t0 : nullptr);
     have_reset = true;
   }
 
   // PLE:195-245
-  void step(const float* d_act) {
+  // One launch: the step kernel folds the statistics of the episodes it finishes into the sampling table itself (its last
+  // workgroup does, PLE:235-240), and with sigma > 0 it also draws the actions a ~ N(0, sigma^2) it then applies -- the same
+  // Philox stream as fill_random_actions(), so step_random(s) == fill_random_actions(s); step(nullptr).
+  void step(const float* d_act, float sigma = 0.0f) {
     need(true, true);
     StepParams Q = P;
     Q.actions = d_act ? d_act : d_actions;
+    Q.action_sigma = sigma;
     Q.traj = d_traj;
     Q.traj_slot = traj_unroll ? (int)(P.step_count % (uint64_t)traj_unroll) : 0;
-    if (!table_fresh) bk.launch_prestep(P, d_avg_reward, d_avg_len, d_prob, d_cdf, nullptr, 0.0f);
     bk.launch_step(Q);
-    table_fresh = false;                 // the step may have published new episode statistics
     P.step_count += 1;
+  }
+  void step_random(float sigma) {
+    if (!(sigma > 0.0f)) throw PmcError(LL_EINVAL, "sigma must be positive");
+    step(nullptr, sigma);
   }
   // parity hook: one control step whose physics result (and optionally foot positions) is supplied by the caller -- the
   // fake-BulletClient protocol of tests/golden/gen_golden.py -- so that everything around the physics can be compared with
@@ -202,9 +208,7 @@ struct PmcEngine {
     Q.scripted_feet = h_feet ? d_script_feet : nullptr;
     Q.traj = d_traj;
     Q.traj_slot = traj_unroll ? (int)(P.step_count % (uint64_t)traj_unroll) : 0;
-    if (!table_fresh) bk.launch_prestep(P, d_avg_reward, d_avg_len, d_prob, d_cdf, nullptr, 0.0f);
     bk.launch_step(Q);
-    table_fresh = false;
     P.step_count += 1;
   }
   // keep the last `unroll` transitions of every env in HBM, in the layout the learner rank gathers
@@ -216,8 +220,7 @@ struct PmcEngine {
   }
   void fill_random_actions(float sigma) {
     need(true, false);
-    bk.launch_prestep(P, d_avg_reward, d_avg_len, d_prob, d_cdf, d_actions, sigma);
-    table_fresh = true;
+    bk.launch_actions(P, d_actions, sigma);
   }
 
   // ---- boundary copies: rows on the host, SoA on the device ---------------------------------------------

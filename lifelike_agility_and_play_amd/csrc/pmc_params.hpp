@@ -104,7 +104,13 @@ struct StepParams {
   const int32_t* clip_off;
   const int32_t* clip_len;
   const double* max_steps;  // [n_clips]
-  const double* cdf;        // [n_clips] inclusive prefix sums of the sampling probabilities
+  double* cdf;              // [n_clips] inclusive prefix sums of the sampling probabilities
+  double* prob;             // [n_clips] p ~ (1 - avg_reward_sum)^factor, normalised (PLE:239-240)
+  double* avg_reward;       // [n_clips] _avg_reward_sum (PLE:235-238)
+  double* avg_len;          // [n_clips] avg_episode_len
+  unsigned int* block_ticket;   // workgroups of the running step kernel that have finished; the last one folds the table
+  float* actions_out;       // where a step that draws its own actions (action_sigma > 0) records them, [n_envs][12]
+  float action_sigma, pad5;
   // jump obstacles (set_obstacle): per clip offset/count into ob_table[total][4] = x, y, yaw, peak time
   const int32_t* ob_off;
   const int32_t* ob_cnt;

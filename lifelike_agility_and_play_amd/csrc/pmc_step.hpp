@@ -259,10 +259,10 @@ struct Pmc {
     F lo_d = lo - r.lam, hi_d = hi - r.lam;
     F dl = zero;
     // a turn: the lane whose turn it is commits clamp(u) -- every lane's pending increment then moves by nk[L] * d_L
-    if (any4[0]) L::template turns4<0>(u, dl, lo_d, hi_d, r.nk[0], r.nk[4], r.nk[8], r.nk[12]);
-    if (any4[1]) L::template turns4<1>(u, dl, lo_d, hi_d, r.nk[1], r.nk[5], r.nk[9], r.nk[13]);
-    if (any4[2]) L::template turns4<2>(u, dl, lo_d, hi_d, r.nk[2], r.nk[6], r.nk[10], r.nk[14]);
-    if (any4[3]) L::template turns4<3>(u, dl, lo_d, hi_d, r.nk[3], r.nk[7], r.nk[11], r.nk[15]);
+    if (any4[0]) ln.template turns4<0>(u, dl, lo_d, hi_d, r.nk[0], r.nk[4], r.nk[8], r.nk[12]);
+    if (any4[1]) ln.template turns4<1>(u, dl, lo_d, hi_d, r.nk[1], r.nk[5], r.nk[9], r.nk[13]);
+    if (any4[2]) ln.template turns4<2>(u, dl, lo_d, hi_d, r.nk[2], r.nk[6], r.nk[10], r.nk[14]);
+    if (any4[3]) ln.template turns4<3>(u, dl, lo_d, hi_d, r.nk[3], r.nk[7], r.nk[11], r.nk[15]);
     r.lam = r.lam + dl;
     F pj[3] = {r.jt[0] * dl, r.jt[1] * dl, r.jt[2] * dl}, sj[3];
     L::subsum3(pj, sj);                                   // the slots of a leg share its joint velocities
@@ -277,7 +277,8 @@ struct Pmc {
   // ---------------------------------------------------------------------------------------------------
   // one physics substep
   // ---------------------------------------------------------------------------------------------------
-  static LL_HD void substep(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt) {
+  static LL_HD void substep(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env = 0, int sidx = -1) {
+#define PMC_TSS(k) do { if (sidx == 5) PMC_TS(k); } while (0)
     const float* legc = P.legc;
     const float* bc = P.basec;
     const float dt = P.dt;
@@ -345,6 +346,7 @@ struct Pmc {
     lf.y2 = scale(F2 + scale(lf.y1, zero - lf.l21), lf.i22);
     lf.y3 = scale(F3 + scale(lf.y1, zero - lf.l31) + scale(lf.y2, zero - lf.l32), lf.i33);
 
+    PMC_TSS(21);
     // --- base: S = I_base + sum I^c_leg - sum Y Y^T ; packed lower triangle, index order [wx wy wz vx vy vz] ----
     float Sb[21], Sd[6];
     {
@@ -374,6 +376,7 @@ struct Pmc {
       chol6(Sb, Sd);
     }
 
+    PMC_TSS(22);
     // --- unconstrained accelerations ---------------------------------------------------------------------------
     lm_fwd(lf, b);                                              // bt = Lm^-1 (tau - C_l)
     SV<F> z = scale(lf.y1, b[0]) + scale(lf.y2, b[1]) + scale(lf.y3, b[2]);
@@ -412,6 +415,7 @@ struct Pmc {
     F qs[3];
     for (int j = 0; j < 3; j++) qs[j] = qd[j] + u[j] * dt;
 
+    PMC_TSS(23);
     // --- contact candidates (DESIGN.md "contact candidates"): 28 points per leg, 7 per sub-lane, grouped by link --------------
     //   jj 0..3 -> group A, 4..5 -> group B, 6 -> group C;  links  A: [3,3,2,2]  B: [2,2,2,1]  C: [3,0,0,0]  by sub-lane
     const float inv_dt = 1.0f / dt;
@@ -479,6 +483,7 @@ struct Pmc {
     any_c[2] = L::any(lm::and_(cvalid, ln.is_sub(2))); any_c[3] = L::any(lm::and_(cvalid, ln.is_sub(3)));
     const bool any_contact = any_c[0] || any_c[1] || any_c[2] || any_c[3];
 
+    PMC_TSS(24);
     // --- rows -------------------------------------------------------------------------------------------------------------------
     Row rl, rn, r1, r2;
     F mu = zero;
@@ -506,6 +511,7 @@ struct Pmc {
       any_l[2] = L::any(lm::and_(lvalid, ln.is_sub(2)));
       if (any_l[0] || any_l[1] || any_l[2]) finish_row(ln, rl);
     }
+    PMC_TSS(25);
     if (any_contact) {
       // geometry of this lane's contact: candidate (my_sub, my_jj) of the leg, re-evaluated from the table
       I wsub = L::f2i(my_sub), wbase = L::f2i(my_jj) * CF_WORDS;
@@ -557,12 +563,20 @@ struct Pmc {
       }
     }
 
+    PMC_TSS(26);
+#if defined(PMC_ABLATION)
+    if (PMC_ABL(16) && ln.is_lane(0)) {   // solver occupancy: active 4-turn blocks of this wave, contact and limit
+      P.counters[4 + (long)env * PMC_TS_SLOTS + 30] += (unsigned long long)(any_c[0] + any_c[1] + any_c[2] + any_c[3]);
+      P.counters[4 + (long)env * PMC_TS_SLOTS + 31] += (unsigned long long)(any_l[0] + any_l[1] + any_l[2]);
+    }
+#endif
     // --- projected Gauss-Seidel in whitened coordinates, rows in registers ------------------------------------------------------
     // Order of the spec: limit rows (joint, leg), then normal rows (slot, leg), t1 rows, t2 rows.
     float dx[6] = {0, 0, 0, 0, 0, 0};      // env-uniform:  sum gt * lambda
     F dq[3] = {zero, zero, zero};          // leg-uniform:  sum jt * lambda
     const F big = ln.lane_f(3.0e38f);
     const bool any_limit = any_l[0] || any_l[1] || any_l[2];
+    ln.prepare_turn_masks();
     LL_NOUNROLL
     for (int it = 0; it < P.n_iter; it++) {
       if (any_limit) gs_round(ln, rl, zero, big, any_l, dx, dq);
@@ -574,6 +588,7 @@ struct Pmc {
       }
     }
 
+    PMC_TSS(27);
     // back to velocities: d(xi) = Lb^-T dx ; d(qd) = Lm^-T (dq - Y^T d(xi))
     bwd6(Sb, Sd, dx);
     SV<float> dxi;
@@ -677,6 +692,7 @@ struct Pmc {
       in.ha[0] = in.ha[1] = ln.lane_f(0.0f);
     }
     const double hz[4] = {1. / 30., 1. / 15., 1. / 3., 1.};                     // ML:75-86
+    LL_UNROLL
     for (int h = 0; h < 4; h++) {
       double t = P.frame_step * frac + hz[h];
       int fid = (int)floor(t / P.frame_step);
@@ -709,6 +725,7 @@ struct Pmc {
     // --- future goals (ML:75-86 + PLE:299-317) ---
     long f0 = a0 + 36;
     Q4 qbi = qconj(qnormalize(bs.q));
+    LL_UNROLL
     for (int h = 0; h < 4; h++) {
       RefPose rp = mocap_finish(in.fut[h], P.frame_step, false);
       V3u dp = mulT(R, mk3<float>(rp.p.x - bs.p.x, rp.p.y - bs.p.y, rp.p.z - bs.p.z));
@@ -836,7 +853,8 @@ struct Pmc {
   // ---------------------------------------------------------------------------------------------------
   // the control step
   // ---------------------------------------------------------------------------------------------------
-  static LL_HD void step_env(const L& ln, const StepParams& P, int env) {
+  // act_in: the env's actions, one register per joint of the lane's leg (read from P.actions or drawn by the caller)
+  static LL_HD void step_env(const L& ln, const StepParams& P, int env, const F* act_in) {
     const int N = P.n_envs;
     Base bs;
     F q[3], qd[3], act[3], tgt[3];
@@ -844,7 +862,7 @@ struct Pmc {
     if (PMC_ABL(8)) return;
     load_state(ln, P.state, N, env, bs, q, qd);
     for (int j = 0; j < 3; j++) {
-      act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
+      act[j] = act_in[j];
       F t = q[j] + act[j];                                                   // PLE:199-200
       tgt[j] = lm::min_(lm::max_(t, ln.lane_f(-3.0f)), ln.lane_f(3.0f));     // LR:126-127
     }
@@ -854,7 +872,7 @@ struct Pmc {
     const double* rows = P.frames + (long)P.clip_off[clip] * 19;
     PMC_TS(1);
     for (int s = 0; s < P.n_sub; s++) {                                      // PLE:202
-      substep(ln, P, bs, q, qd, tgt);                                        // PLE:204-206
+      substep(ln, P, bs, q, qd, tgt, env, s);                                // PLE:204-206
       t_loc = t;                                                             // PLE:208 motion.step(time BEFORE the increment), quirk Q2
       t += P.dt_d;                                                           // PLE:210
     PMC_TS(10 + (s < 20 ? s : 20));
@@ -874,7 +892,10 @@ struct Pmc {
     ObsIn oin = obs_gather(ln, P, row, false, rows, fid, frac);
     constexpr int TRAJ_CHUNKS = 13;                                          // obs_dim <= 207
     F told[TRAJ_CHUNKS];
-    if (P.traj) for (int c = 0; c < TRAJ_CHUNKS; c++) told[c] = ln.ld16(row, 16 * c, P.obs_dim);
+    if (P.traj) {
+      LL_UNROLL
+      for (int c = 0; c < TRAJ_CHUNKS; c++) told[c] = ln.ld16(row, 16 * c, P.obs_dim);
+    }
     const int steps = P.ep_steps[env] + 1;                                    // PLE:197
     const float rsum0 = P.reward_sum[env];
     const double max_steps = P.max_steps[clip];
@@ -950,6 +971,7 @@ struct Pmc {
     if (P.traj) {
       const int W = P.obs_dim + 14;
       float* tr = P.traj + ((long)P.traj_slot * N + env) * W;
+      LL_UNROLL
       for (int c = 0; c < TRAJ_CHUNKS; c++) ln.st16(tr, 16 * c, P.obs_dim, told[c]);
       for (int j = 0; j < 3; j++) ln.stl(tr, P.obs_dim + j, 3, act[j]);
       tr[P.obs_dim + 12] = reward;

@@ -24,7 +24,13 @@ struct HostBackend {
   void sync() {}
   void launch_step(const StepParams& P) {
     HostLanes ln(P.candc);
-    for (int env = 0; env < P.n_envs; env++) K::step_env(ln, P, env);
+    if (P.action_sigma > 0.0f) launch_actions(P, P.actions_out, P.action_sigma);
+    for (int env = 0; env < P.n_envs; env++) {
+      fN act[3];
+      for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
+      K::step_env(ln, P, env, act);
+    }
+    pmc_finalize_table(P, P.avg_reward, P.avg_len, P.prob, P.cdf);
   }
   void launch_reset(const StepParams& P, const int32_t* ids, int n, const int32_t* clip, const double* t0) {
     HostLanes ln(P.candc);
@@ -41,18 +47,15 @@ struct HostBackend {
       P.done_reason[env] = 0;
     }
   }
-  void launch_prestep(const StepParams& P, double* avg_r, double* avg_l, double* prob, double* cdf, float* actions, float sigma) {
-    pmc_finalize_table(P, avg_r, avg_l, prob, cdf);
-    if (actions) {
-      for (int gid = 0; gid < P.n_envs * 3; gid++) {
-        uint32_t r[4];
-        philox4x32((uint32_t)gid, (uint32_t)P.step_count, (uint32_t)(P.step_count >> 32), 0xAC710u, (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r);
-        const float k = 2.3283064365386963e-10f;
-        float u1 = fminf(((float)r[0] + 1.0f) * k, 1.0f), u2 = (float)r[1] * k, u3 = fminf(((float)r[2] + 1.0f) * k, 1.0f), u4 = (float)r[3] * k;
-        float m1 = sqrtf(-2.0f * logf(u1)), m2 = sqrtf(-2.0f * logf(u3));
-        actions[4 * gid + 0] = sigma * m1 * cosf(6.283185307179586f * u2); actions[4 * gid + 1] = sigma * m1 * sinf(6.283185307179586f * u2);
-        actions[4 * gid + 2] = sigma * m2 * cosf(6.283185307179586f * u4); actions[4 * gid + 3] = sigma * m2 * sinf(6.283185307179586f * u4);
-      }
+  void launch_actions(const StepParams& P, float* actions, float sigma) {
+    for (int gid = 0; gid < P.n_envs * 3; gid++) {
+      uint32_t r[4];
+      philox4x32((uint32_t)gid, (uint32_t)P.step_count, (uint32_t)(P.step_count >> 32), 0xAC710u, (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r);
+      const float k = 2.3283064365386963e-10f;
+      float u1 = fminf(((float)r[0] + 1.0f) * k, 1.0f), u2 = (float)r[1] * k, u3 = fminf(((float)r[2] + 1.0f) * k, 1.0f), u4 = (float)r[3] * k;
+      float m1 = sqrtf(-2.0f * logf(u1)), m2 = sqrtf(-2.0f * logf(u3));
+      actions[4 * gid + 0] = sigma * m1 * cosf(6.283185307179586f * u2); actions[4 * gid + 1] = sigma * m1 * sinf(6.283185307179586f * u2);
+      actions[4 * gid + 2] = sigma * m2 * cosf(6.283185307179586f * u4); actions[4 * gid + 3] = sigma * m2 * sinf(6.283185307179586f * u4);
     }
   }
   void enable_timing(bool) {}

@@ -70,6 +70,7 @@ struct HostLanes {
 
   explicit HostLanes(const float* candc) : candc_(candc) {}
   void refresh_consts() const {}
+  void prepare_turn_masks() const {}
   I leg() const { iN r; for (int i = 0; i < EW; i++) r.v[i] = i >> 2; return r; }
   I sub() const { iN r; for (int i = 0; i < EW; i++) r.v[i] = i & 3; return r; }
   F legf() const { fN r; for (int i = 0; i < EW; i++) r.v[i] = (float)(i >> 2); return r; }

@@ -59,6 +59,25 @@ def test_full_size_invariants(golden, model_blob, mocap_table):
     E.close()
 
 
+def test_step_random_is_fill_then_step(model_blob, mocap_table):
+    """ll_step_random (actions drawn inside the step kernel) == ll_fill_random_actions + ll_step, bit for bit, including the
+    recorded actions and the sampling table the step leaves behind; two batch sizes, so both kernel variants run."""
+    for n in (70, 4200):
+        A = pc.make_engine(model_blob, mocap_table, n, None, auto_reset=1, seed=11)
+        B = pc.make_engine(model_blob, mocap_table, n, None, auto_reset=1, seed=11)
+        A.reset(); B.reset()
+        for t in range(25):
+            A.fill_random_actions(pc.SIGMA); A.step()
+            B.step_random(pc.SIGMA)
+        assert np.array_equal(A.obs(), B.obs()) and np.array_equal(A.state(), B.state())
+        ra, rb = A.reward_done(), B.reward_done()
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[2], rb[2])
+        ta, tb = A.sampling_table(), B.sampling_table()
+        assert all(np.array_equal(x, y) for x, y in zip(ta, tb))
+        assert A.counters() == B.counters() and A.counters()['episodes'] > 0
+        A.close(); B.close()
+
+
 def test_contact_rich_parity(golden, orc, model_blob, mocap_table):
     out = pc.check_contact_rich_parity(golden, orc, model_blob, mocap_table, None)
     print('contact-rich: config err', np.percentile(out['config'], [50, 100]), 'vel', np.percentile(out['vel'], [50, 100]))

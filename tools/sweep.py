@@ -15,11 +15,11 @@ for item in sys.argv[1].split(','):
     E = capi.Engine(cfg, blob, table, lib_path=os.environ.get('LL_LIB'))
     E.reset()
     for _ in range(30):
-        E.fill_random_actions(math.exp(-2)); E.step()
+        E.step_random(math.exp(-2))
     E.sync(); E.enable_kernel_timing(True)
     t0 = time.perf_counter()
     for _ in range(50):
-        E.fill_random_actions(math.exp(-2)); E.step()
+        E.step_random(math.exp(-2))
     E.sync(); dt = time.perf_counter() - t0
     ms, k = E.kernel_time_ms()
     print('iters %2d nsub %2d' % (iters, nsub), 'n_envs %6d epw %2d blocks %5d kernel %.3f ms  wall/step %.3f ms  -> %.2f M env-steps/s' % (n, epw, (n + 3) // 4, ms, dt / 50 * 1e3, n * 50 / dt / 1e6), flush=True)

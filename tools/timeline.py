@@ -17,18 +17,22 @@ E.reset()
 NAMES = {0: 'entry', 1: 'state loaded', 2: 'mocap gathered', 3: 'reward', 4: 'termination', 5: 'obs emitted', 6: 'stores', 7: 'end (reset path)'}
 for k in range(10):
     NAMES[10 + k] = 'substep %d' % k
+for k, nm in zip(range(21, 28), ['kinematics+inertias', 'base S factor', 'free accelerations', 'candidates+selection', 'limit rows', 'contact rows', 'PGS']):
+    NAMES[k] = '  s5: ' + nm
 acc = []
+raw = []
 for it in range(60):
-    E.fill_random_actions(math.exp(-2)); E.step()
+    E.step_random(math.exp(-2))
     if it < 40:
         continue
     ts = np.zeros((n, 32), np.uint64)
     assert fn(E.h, ts.ctypes.data_as(C.c_void_p)) == 0
     done = E.reward_done()[1]
+    raw.append(ts.astype(np.float64))
     t = ts.astype(np.float64) * 0.01          # us (100 MHz)
     t0 = t[:, 0].min()
     acc.append((t - t0, np.asarray(done).astype(bool)))
-order = [0, 1] + list(range(10, 20)) + [2, 3, 4, 5, 6, 7]
+order = [0, 1] + list(range(10, 15)) + list(range(21, 28)) + list(range(15, 20)) + [2, 3, 4, 5, 6, 7]
 print('n_envs %d: stamps relative to the first wave entry, us; mean over 20 steps of [mean | max over envs], split by reset' % n)
 print('%-18s %8s %8s | %8s %8s (resetting envs)' % ('mark', 'mean', 'max', 'mean', 'max'))
 for k in order:
@@ -36,5 +40,8 @@ for k in order:
     rs = [x[d, k] for x, d in acc if d.any()]
     c = np.mean([r.mean() for r in rs]) if rs else float('nan'); e = np.mean([r.max() for r in rs]) if rs else float('nan')
     print('%-18s %8.2f %8.2f | %8.2f %8.2f' % (NAMES[k], a, b, c, e))
+occ = np.array([x[:, 30:32] for x in raw])          # cumulative block counts per env
+d = (occ[-1] - occ[0]) / (len(raw) - 1) / 10.0
+print('active 4-turn blocks per substep (wave level): contact %.2f of 4, limit %.2f of 3' % (d[:, 0].mean(), d[:, 1].mean()))
 print('resets per step: %.1f' % np.mean([d.sum() for x, d in acc]))
 E.close()
