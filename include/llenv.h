@@ -90,7 +90,8 @@ typedef struct ll_config {
   double obstacle_height;       /* CPE:40 default 0.0 (quirk Q7) */
   double prioritized_sample_factor; /* CPE:38 */
   int32_t solver_iterations;    /* LR:261 numSolverIterations = 10 */
-  int32_t reserved0;
+  int32_t keep_terminal_obs;    /* auto_reset=1 only: also emit the obs of the finished episode (ll_get_terminal_obs).
+                                   0 (default): an env that finishes writes one obs per step, the first of its next episode */
   uint64_t seed;                /* Philox key for clip / start-time sampling and synthetic actions */
 } ll_config;
 
@@ -179,7 +180,7 @@ typedef struct ll_device_ptrs_t {
   uint8_t* done;         /* [n_envs] */
   uint8_t* done_reason;  /* [n_envs] LL_DONE_* bits */
   float* actions;        /* [n_envs][12] engine-owned action buffer */
-  float* terminal_obs;   /* [n_envs][obs_dim] obs of the finished episode (auto_reset=1 only) */
+  float* terminal_obs;   /* [n_envs][obs_dim] obs of the finished episode (auto_reset=1 and keep_terminal_obs=1 only) */
   int32_t obs_dim;
   int32_t n_envs;
   void* stream;          /* hipStream_t the engine launches on */

@@ -27,7 +27,7 @@ class LLConfig(C.Structure):
                 ('control_freq', C.c_double), ('sim_freq', C.c_double), ('kp', C.c_double), ('kd', C.c_double),
                 ('max_tau', C.c_double), ('foot_lateral_friction', C.c_double), ('reward_weights', C.c_double * 5),
                 ('prop_order', C.c_int32 * 5), ('set_obstacle', C.c_int32), ('obstacle_height', C.c_double),
-                ('prioritized_sample_factor', C.c_double), ('solver_iterations', C.c_int32), ('reserved0', C.c_int32),
+                ('prioritized_sample_factor', C.c_double), ('solver_iterations', C.c_int32), ('keep_terminal_obs', C.c_int32),
                 ('seed', C.c_uint64)]
 
 
@@ -45,7 +45,7 @@ class LLError(RuntimeError):
 
 def make_config(n_envs, control_freq=25.0, sim_freq=500.0, kp=50.0, kd=1.0, max_tau=18.0, foot_lateral_friction=0.5,
                 reward_weights=None, prop_type=None, prioritized_sample_factor=0.0, set_obstacle=False,
-                obstacle_height=0.0, auto_reset=0, seed=0, device=0, solver_iterations=10):
+                obstacle_height=0.0, auto_reset=0, seed=0, device=0, solver_iterations=10, keep_terminal_obs=False):
     """Defaults are the factory's (create_pybullet_envs.py:28-59)."""
     if not isinstance(prop_type, (list, tuple)):
         raise TypeError("Expected 'prop_type' to be a list.")                     # PLE:113
@@ -64,6 +64,7 @@ def make_config(n_envs, control_freq=25.0, sim_freq=500.0, kp=50.0, kd=1.0, max_
     cfg.set_obstacle, cfg.obstacle_height = int(bool(set_obstacle)), float(obstacle_height)
     cfg.prioritized_sample_factor = float(prioritized_sample_factor)
     cfg.solver_iterations = int(solver_iterations)
+    cfg.keep_terminal_obs = int(bool(keep_terminal_obs))
     cfg.seed = int(seed)
     return cfg
 

@@ -68,7 +68,7 @@ struct StepParams {
   int32_t n_clips, prop_dim, obs_dim, frame_rate;
   int32_t margin, envs_per_wave;
   int32_t prop_off[5];      // offset of each LL_PROP_* key inside one prop frame, or -1
-  int32_t pad1;
+  int32_t keep_term_obs;    // auto-reset: also write the finished episode's last obs to term_obs
   float dt, kp, kd, max_tau;
   float mu_foot, mu_link, gravity, link_damping;
   float erp, margin_dist, limit_gate, pad3;

@@ -679,6 +679,17 @@ struct Pmc {
     F h[OBS_HIST_CHUNKS], ha[2];
     RefRaw fut[4];
   };
+  static LL_HD void obs_gather_futures(const L& ln, const StepParams& P, ObsIn& in, const double* clip_rows, int frame_id, double frac) {
+    const double hz[4] = {1. / 30., 1. / 15., 1. / 3., 1.};                     // ML:75-86
+    LL_UNROLL
+    for (int h = 0; h < 4; h++) {
+      double t = P.frame_step * frac + hz[h];
+      int fid = (int)floor(t / P.frame_step);
+      double ff = t / P.frame_step - fid;
+      const double* fc = clip_rows + (long)(frame_id + fid) * 19;
+      in.fut[h] = mocap_gather(ln, fc, fc + 19, ff, P.frame_step);
+    }
+  }
   static LL_HD ObsIn obs_gather(const L& ln, const StepParams& P, const float* hist_row, bool fill, const double* clip_rows, int frame_id,
                                 double frac) {
     ObsIn in;
@@ -691,15 +702,7 @@ struct Pmc {
       for (int c = 0; c < OBS_HIST_CHUNKS; c++) in.h[c] = ln.lane_f(0.0f);
       in.ha[0] = in.ha[1] = ln.lane_f(0.0f);
     }
-    const double hz[4] = {1. / 30., 1. / 15., 1. / 3., 1.};                     // ML:75-86
-    LL_UNROLL
-    for (int h = 0; h < 4; h++) {
-      double t = P.frame_step * frac + hz[h];
-      int fid = (int)floor(t / P.frame_step);
-      double ff = t / P.frame_step - fid;
-      const double* fc = clip_rows + (long)(frame_id + fid) * 19;
-      in.fut[h] = mocap_gather(ln, fc, fc + 19, ff, P.frame_step);
-    }
+    obs_gather_futures(ln, P, in, clip_rows, frame_id, frac);
     return in;
   }
   static LL_HD void obs_emit(const L& ln, const StepParams& P, float* row, bool fill, const ObsIn& in, const Base& bs, const M3<float>& R,
@@ -711,9 +714,10 @@ struct Pmc {
       for (int c = 0; c < OBS_HIST_CHUNKS; c++) ln.st16(row, 16 * c, 2 * Pd, in.h[c]);
       for (int c = 0; c < 2; c++) ln.st16(row + a0, 16 * c, 24, in.ha[c]);
     }
-    // --- newest prop frame (PLE:247-260) ---
+    // --- newest prop frame (PLE:247-260); a reset pre-fills all three frames with it (PLE:282-290) ---
     V3u wl = mulT(R, bs.w), vl = mulT(R, bs.v);
-    for (int kf = (fill ? 0 : 2); kf < 3; kf++) {
+    LL_NOUNROLL
+    for (int kf = 2; kf >= (fill ? 0 : 2); kf--) {
       long fb = (long)kf * Pd;
       if (P.prop_off[0] >= 0) for (int j = 0; j < 3; j++) ln.stl(row, fb + P.prop_off[0] + j, 3, q[j]);      // joint_pos
       if (P.prop_off[1] >= 0) for (int j = 0; j < 3; j++) ln.stl(row, fb + P.prop_off[1] + j, 3, qd[j]);     // joint_vel
@@ -978,31 +982,16 @@ struct Pmc {
       tr[P.obs_dim + 13] = reason ? 1.0f : 0.0f;
     }
 
-    // --- observation: into term_obs when the episode ends under auto-reset, else in place ---
-    float* out_row = (reason && ar) ? (P.term_obs + (long)env * P.obs_dim) : row;
-    obs_emit(ln, P, out_row, false, oin, bs, R, q, qd, act);                                      // PLE:227
-
     PMC_TS(5);
-    // --- stores ---
-    store_state(ln, P.state, N, env, bs, q, qd);
-    store_state(ln, P.kin, N, env, gb, rp.jp, rp.jv);
-    for (int c = 0; c < 3; c++) {
-      ln.stl(P.feet, (long)c * N + env, 3L * N, (c == 0) ? fd.x : (c == 1 ? fd.y : fd.z));
-      ln.stl(P.feet, (long)(12 + c) * N + env, 3L * N, (c == 0) ? fk.x : (c == 1 ? fk.y : fk.z));
-    }
-    P.time[env] = t;
-    P.ep_steps[env] = steps;
-    P.reward_sum[env] = rsum;
-    P.reward[env] = reward;
-    P.done[env] = reason ? 1 : 0;
-    P.done_reason[env] = (uint8_t)reason;
-
-    PMC_TS(6);
+    // --- end of episode (PLE:235-240): publish the per-clip statistics; the last workgroup of the kernel folds them into the
+    //     table (highest env index wins when several envs finish the same clip in one step == sequential overwrite order) ---
+    int steps_out = steps, clip_out = clip;
+    float rsum_out = rsum;
+    bool fill = false;
+    F oq[3] = {q[0], q[1], q[2]}, oqd[3] = {qd[0], qd[1], qd[2]}, oact[3] = {act[0], act[1], act[2]};
+    F gjp[3] = {rp.jp[0], rp.jp[1], rp.jp[2]}, gjv[3] = {rp.jv[0], rp.jv[1], rp.jv[2]};
     if (reason) {
-      // PLE:235-240: publish this episode's per-clip statistics; the pre-step kernel folds them into the table
-      // (highest env index wins when several envs finish the same clip in one step == sequential overwrite order)
-      const double ms = max_steps;
-      float avg_r = (float)((double)rsum / ms), avg_l = (float)((double)steps / (ms + 1.0));
+      float avg_r = (float)((double)rsum / max_steps), avg_l = (float)((double)steps / (max_steps + 1.0));
       if (bad) avg_r = 0.0f;
       unsigned long long tag = ((unsigned long long)(env + 1)) << 32;
       publish_max(ln, P.pending_reward + clip, tag | (unsigned long long)f2u(avg_r));
@@ -1010,14 +999,50 @@ struct Pmc {
       count_add(ln, P.counters + 1);
       if (bad) count_add(ln, P.counters + 2);
       if (ar) {
+        // auto-reset inside the step (PLE:150-171 + ML:48-63): the env continues from a freshly sampled (clip, t0); only what
+        // differs from a running env is done here -- the pose and the four future sites are re-read at the new place, and
+        // the common tail below writes the one observation, state and ghost of the step
+        if (P.keep_term_obs) obs_emit(ln, P, P.term_obs + (long)env * P.obs_dim, false, oin, bs, R, q, qd, act);   // PLE:227
         int nclip;
         double nt0;
-        const uint32_t ep = ep0 + 1;
-        sample_start(ln, P, env, ep, &nclip, &nt0);
-        reset_env(ln, P, env, nclip, nt0);
-        P.ep_count[env] = ep;
+        sample_start(ln, P, env, ep0 + 1, &nclip, &nt0);
+        const int fid2 = (int)floor(nt0 / P.frame_step);                      // ML:52
+        const double frac2 = (nt0 - fid2 * P.frame_step) / P.frame_step;      // ML:53
+        const double* rows2 = P.frames + (long)P.clip_off[nclip] * 19;
+        RefRaw rr2 = mocap_gather(ln, rows2 + (long)fid2 * 19, rows2 + (long)(fid2 + 1) * 19, frac2, P.frame_step);
+        obs_gather_futures(ln, P, oin, rows2, fid2, frac2);
+        RefPose rp2 = mocap_finish(rr2, P.frame_step, true);
+        bs.p = rp2.p; bs.q = rp2.q; bs.v = rp2.v; bs.w = rp2.w;               // PLE:162-163 dynamic robot := ghost := mocap
+        gb = bs;
+        R = qmat(qnormalize(bs.q));
+        for (int j = 0; j < 3; j++) {
+          oq[j] = rp2.jp[j]; oqd[j] = rp2.jv[j]; gjp[j] = rp2.jp[j]; gjv[j] = rp2.jv[j];
+          oact[j] = ln.lane_f(0.0f);
+        }
+        fd = foot_world(ln, P.legc, bs.p, R, oq[0], oq[1], oq[2]);
+        fk = fd;
+        fill = true;                                                          // PLE:168-170
+        t = nt0; steps_out = 0; rsum_out = 0.0f; clip_out = nclip;
+        P.ep_count[env] = ep0 + 1;
+        if (P.set_obstacle) P.ob_id[env] = 0;                                 // PLE:179
       }
     }
+    PMC_TS(6);
+    // --- observation (PLE:227), state, ghost, feet, bookkeeping ---
+    obs_emit(ln, P, row, fill, oin, bs, R, oq, oqd, oact);
+    store_state(ln, P.state, N, env, bs, oq, oqd);
+    store_state(ln, P.kin, N, env, gb, gjp, gjv);
+    for (int c = 0; c < 3; c++) {
+      ln.stl(P.feet, (long)c * N + env, 3L * N, (c == 0) ? fd.x : (c == 1 ? fd.y : fd.z));
+      ln.stl(P.feet, (long)(12 + c) * N + env, 3L * N, (c == 0) ? fk.x : (c == 1 ? fk.y : fk.z));
+    }
+    P.time[env] = t;
+    P.clip[env] = clip_out;
+    P.ep_steps[env] = steps_out;
+    P.reward_sum[env] = rsum_out;
+    P.reward[env] = reward;
+    P.done[env] = reason ? 1 : 0;
+    P.done_reason[env] = (uint8_t)reason;
     PMC_TS(7);
   }
 

@@ -178,6 +178,7 @@ static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
   P.dt = (float)P.dt_d;
   P.n_iter = cfg.solver_iterations > 0 ? cfg.solver_iterations : 10;   // LR:261
   P.auto_reset = cfg.auto_reset;
+  P.keep_term_obs = (cfg.auto_reset && cfg.keep_terminal_obs) ? 1 : 0;
   P.kp = (float)cfg.kp; P.kd = (float)cfg.kd; P.max_tau = (float)cfg.max_tau;
   P.mu_foot = (float)(cfg.foot_lateral_friction * LLM_PLANE_FRICTION);   // LR:304-308 x plane.urdf:5
   P.mu_link = (float)(LLM_LINK_FRICTION * LLM_PLANE_FRICTION);

@@ -21,7 +21,7 @@ class LLConfig(C.Structure):
                 ('control_freq', C.c_double), ('sim_freq', C.c_double), ('kp', C.c_double), ('kd', C.c_double),
                 ('max_tau', C.c_double), ('foot_lateral_friction', C.c_double), ('reward_weights', C.c_double * 5),
                 ('prop_order', C.c_int32 * 5), ('set_obstacle', C.c_int32), ('obstacle_height', C.c_double),
-                ('prioritized_sample_factor', C.c_double), ('solver_iterations', C.c_int32), ('reserved0', C.c_int32),
+                ('prioritized_sample_factor', C.c_double), ('solver_iterations', C.c_int32), ('keep_terminal_obs', C.c_int32),
                 ('seed', C.c_uint64)]
 
 

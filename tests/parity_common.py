@@ -305,3 +305,56 @@ def check_scripted_episodes_against_goldens(golden, model_blob, table, lib_path)
         np.testing.assert_allclose(avg_len, golden['g5_avg_len_after'][e], rtol=1e-6, atol=1e-9)  # PLE:237
     E.close()
     assert n_done >= 6
+
+
+def check_auto_reset_equals_manual_reset(model_blob, table, lib_path, n_envs=24, n_steps=40):
+    """An env that finishes under auto_reset=1 is re-seeded INSIDE the step kernel (the merged tail of step_env); the same
+    episode driven with auto_reset=0 and an explicit ll_reset at the engine-chosen (clip, t0) must give the same
+    observation, state, ghost, feet and bookkeeping.  With keep_terminal_obs the finished episode's last observation must be
+    the one the non-resetting engine reports."""
+    # the host build runs one instruction stream for both engines (exact); on the GPU the in-kernel re-seed and ll_reset are
+    # different kernels, whose fused multiply-adds the compiler may contract differently (a few ulp)
+    def same(x, y):
+        if lib_path is not None:
+            np.testing.assert_array_equal(x, y)
+        else:
+            np.testing.assert_allclose(x, y, rtol=2e-6, atol=2e-6)
+    A = make_engine(model_blob, table, n_envs, lib_path, auto_reset=1, seed=21, keep_terminal_obs=True)
+    B = make_engine(model_blob, table, n_envs, lib_path, auto_reset=0, seed=21)
+    A.reset(); B.reset()
+    assert np.array_equal(A.obs(), B.obs())
+    rng = np.random.default_rng(5)
+    n_reset = 0
+    for t in range(n_steps):
+        a = (rng.normal(size=(n_envs, 12)) * 0.6).astype(np.float32)      # wild enough to end episodes quickly
+        A.step_host(a); B.step_host(a)
+        ra, da, wa = A.reward_done()
+        rb, db, wb = B.reward_done()
+        assert np.array_equal(da, db) and np.array_equal(wa, wb) and np.array_equal(ra, rb)
+        if da.any():
+            ids = np.where(da)[0]
+            same(A.terminal_obs()[ids], B.obs()[ids])        # PLE:227 of the finished episode
+            info = A.episode_info()
+            B.reset(env_ids=ids, clip=info['clip'][ids], t0=info['time'][ids])        # what A did by itself
+            if lib_path is None:
+                same(A.state(), B.state())
+                B.set_state(A.state())       # keep ulp differences of the two reset kernels from growing through the physics
+            n_reset += len(ids)
+        same(A.obs(), B.obs())
+        same(A.state(), B.state())
+        same(A.ref_state(), B.ref_state())
+        fa, fb = A.feet(), B.feet()
+        same(fa[0], fb[0]); same(fa[1], fb[1])
+        ia, ib = A.episode_info(), B.episode_info()
+        for k in ('clip', 'time', 'steps', 'reward_sum'):
+            same(ia[k], ib[k])
+    C = make_engine(model_blob, table, 4, lib_path, auto_reset=1)
+    C.reset()
+    try:
+        C.terminal_obs()
+        raise AssertionError('terminal_obs must be refused when keep_terminal_obs is off')
+    except capi.LLError:
+        pass
+    A.close(); B.close(); C.close()
+    assert n_reset >= 5
+    return n_reset

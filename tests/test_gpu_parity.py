@@ -95,3 +95,7 @@ def test_obstacle_variant(golden, orc, model_blob, mocap_table):
 
 def test_scripted_episodes_against_reference_goldens(golden, model_blob, mocap_table):
     pc.check_scripted_episodes_against_goldens(golden, model_blob, mocap_table, None)
+
+
+def test_auto_reset_equals_manual_reset(model_blob, mocap_table):
+    assert pc.check_auto_reset_equals_manual_reset(model_blob, mocap_table, None, n_envs=70) >= 5

@@ -54,3 +54,7 @@ def test_obstacle_variant(golden, orc, model_blob, mocap_table, emul_lib):
 
 def test_scripted_episodes_against_reference_goldens(golden, model_blob, mocap_table, emul_lib):
     pc.check_scripted_episodes_against_goldens(golden, model_blob, mocap_table, emul_lib)
+
+
+def test_auto_reset_equals_manual_reset(model_blob, mocap_table, emul_lib):
+    assert pc.check_auto_reset_equals_manual_reset(model_blob, mocap_table, emul_lib) >= 5

@@ -14,7 +14,7 @@ cfg = capi.make_config(n, control_freq=50.0, sim_freq=500.0, kd=0.5, reward_weig
 E = capi.Engine(cfg, blob, table, lib_path=os.environ['LL_LIB'])
 fn = E.lib.ll_debug_timestamps; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p]
 E.reset()
-NAMES = {0: 'entry', 1: 'state loaded', 2: 'mocap gathered', 3: 'reward', 4: 'termination', 5: 'obs emitted', 6: 'stores', 7: 'end (reset path)'}
+NAMES = {0: 'entry', 1: 'state loaded', 2: 'mocap gathered', 3: 'reward', 4: 'termination', 5: 'trajectory row', 6: 'episode end/re-seed', 7: 'obs + stores (end)'}
 for k in range(10):
     NAMES[10 + k] = 'substep %d' % k
 for k, nm in zip(range(21, 28), ['kinematics+inertias', 'base S factor', 'free accelerations', 'candidates+selection', 'limit rows', 'contact rows', 'PGS']):
