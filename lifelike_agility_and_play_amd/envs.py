@@ -6,7 +6,7 @@ Mirrors ``lifelike.sim_envs.pybullet_envs.create_pybullet_envs`` (CPE) for the P
     create_tracking_env(**env_config)    CPE:143-147  -> same object with the two spaces un-tupled
 
 ``env_config`` takes the reference's keys with the reference's defaults (CPE:28-59).  Extra, optional keys select the
-batched engine: ``num_envs`` (default 1), ``device``, ``seed``, ``auto_reset``, ``lib_path``.
+batched engine: ``num_envs`` (default 1), ``device``, ``seed``, ``auto_reset``, ``keep_terminal_obs``, ``lib_path``.
 
 * ``num_envs == 1``  -> :class:`TrackingGame`: drop-in for an unmodified TLeague actor -- ``reset(**kw)`` returns
   ``(OrderedDict(prop, prop_a, future),)``, ``step([a])`` returns ``((obs,), (reward,), done, {})``; episodes never
@@ -25,7 +25,7 @@ import numpy as np
 from . import capi, mocap, urdf_model
 from .spaces import Box, Dict, Tuple
 
-ENGINE_KEYS = ('num_envs', 'device', 'seed', 'auto_reset', 'lib_path', 'urdf_path')
+ENGINE_KEYS = ('num_envs', 'device', 'seed', 'auto_reset', 'keep_terminal_obs', 'lib_path', 'urdf_path')
 KNOWN_KEYS = ('arena_id', 'render', 'control_freq', 'sim_freq', 'kp', 'kd', 'max_tau', 'data_path', 'prop_type',
               'prioritized_sample_factor', 'set_obstacle', 'obstacle_height', 'reward_weights', 'foot_lateral_friction',
               'video_path', 'enable_gui') + ENGINE_KEYS
@@ -63,6 +63,7 @@ def _build_engine(env_config, num_envs, auto_reset):
                            reward_weights=reward_weights, prop_type=prop_type,
                            prioritized_sample_factor=prioritized_sample_factor, set_obstacle=set_obstacle,
                            obstacle_height=obstacle_height, auto_reset=auto_reset,
+                           keep_terminal_obs=bool(env_config.get('keep_terminal_obs', False)) and bool(auto_reset),
                            seed=env_config.get('seed', 0), device=env_config.get('device', 0))
     eng = capi.Engine(cfg, blob, table, lib_path=env_config.get('lib_path', None))
     return eng, table, list(prop_type)
@@ -141,8 +142,8 @@ class _UntupledSpaces(object):
 
 class BatchedTrackingEnv(object):
     """num_envs robots in lockstep on one GPU.  Arrays in, arrays out; finished envs are re-seeded inside the step
-    kernel when ``auto_reset`` (default) -- ``obs`` then holds the first observation of the new episode and
-    ``terminal_obs()`` the last one of the finished episode."""
+    kernel when ``auto_reset`` (default) -- ``obs`` then holds the first observation of the new episode; with
+    ``keep_terminal_obs=True`` the last one of the finished episode is kept in ``terminal_obs()`` as well."""
 
     def __init__(self, env_config):
         self.num_envs = int(env_config['num_envs'])

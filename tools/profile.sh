@@ -1,0 +1,26 @@
+#!/bin/bash
+# Everything profiles/ is built from, in one gpurun call:
+#   gpurun --timeout 900 -- 'tools/profile.sh r01'      then here:   python tools/profile_summarize.py r01
+# 1. bench.py as the driver runs it (with the CPU baseline)       -> gpurun_out/<tag>/bench.log
+# 2. rocprofv3 --kernel-trace --stats of the same command          -> .../stats
+# 3. PMC passes, each on its own (no trace domains mixed in): SQ issue counters, FETCH_SIZE, WRITE_SIZE
+# 4. batch-size sweep and the per-wave timeline of the ablation build (if tools/_build/libllenv_abl.so travelled)
+TAG=${1:-r01}
+cd "$(dirname "$0")/.." || exit 1
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python bench.py --gpus 1 --steps 300 --warmup 30 > $OUT/bench.log 2>$OUT/bench.err
+B="python bench.py --gpus 1 --steps 300 --warmup 30 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > $OUT/bench_under_rocprof.log 2>&1
+S="python bench.py --gpus 1 --steps 30 --warmup 3 --no-cpu-baseline"
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq -- $S > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -- $S > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -- $S > /dev/null 2>&1
+python tools/sweep.py "1024:4,2048:4,4096:4,8192:4,16384:4,32768:4,65536:4" > $OUT/sweep.txt 2>&1
+if [ -f tools/_build/libllenv_abl.so ]; then
+  LL_DEBUG_FLAGS=16 LL_LIB=tools/_build/libllenv_abl.so python tools/timeline.py 4096 > $OUT/timeline.txt 2>&1
+  tools/ablate.sh run "0 1 2 3" "4096:4:10:10,4096:4:1:10" > $OUT/ablation.txt 2>&1
+fi
+find $OUT -name "*.csv" -size +20M -delete
+tail -c 600 $OUT/bench.log
