@@ -36,29 +36,36 @@ PMC_REWARD_WEIGHTS = {'joint_pos': 0.3, 'joint_vel': 0.05, 'end_effector': 0.1, 
 PMC_PROP_TYPE = ['joint_pos', 'joint_vel', 'root_ang_vel_loc', 'root_lin_vel_loc', 'e_g']
 
 
-def cpu_baseline(blob, table, budget_s=15.0):
-    """The oracle (a port, not the product) on a bounded sample of the same workload: 64 envs, random policy."""
+def cpu_baseline(blob, table, budget_s=8.0):
+    """The oracle (a port, not the product) on a bounded sample of the same workload, random policy: first on one core,
+    then on every core of this host (OpenMP over the independent envs).  The all-cores figure is the reported value."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from oracle import oracle as orc
-    n = 64
-    cfg = orc.make_config(n_envs=n, reward_weights=PMC_REWARD_WEIGHTS, prop_type=PMC_PROP_TYPE, prioritized_sample_factor=3.0)
-    B = orc.OracleBatch(cfg, blob, table)
-    rng = np.random.default_rng(0)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
 
-    def reseed(i):
-        c = int(rng.integers(0, B.n_clips))
-        B.reset_env(i, c, float(rng.uniform(0, 1) * B.motion_duration(c)))
-    for i in range(n):
-        reseed(i)
-    steps, t0 = 0, time.time()
-    while time.time() - t0 < budget_s:
-        _, _, d = B.step_all(rng.normal(size=(n, 12)) * SIGMA)
-        steps += n
-        for i in np.where(d)[0]:
-            reseed(int(i))
-    dt = time.time() - t0
-    return {'value': steps / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d env-steps: 64 envs, all clips, random policy, %.0f s of the float64 oracle (oracle/pmc_oracle.c, 1 thread)' % (steps, dt)}
+    def run(n, threads, budget):
+        cfg = orc.make_config(n_envs=n, reward_weights=PMC_REWARD_WEIGHTS, prop_type=PMC_PROP_TYPE, prioritized_sample_factor=3.0)
+        B = orc.OracleBatch(cfg, blob, table)
+        rng = np.random.default_rng(0)
+
+        def reseed(i):
+            c = int(rng.integers(0, B.n_clips))
+            B.reset_env(i, c, float(rng.uniform(0, 1) * B.motion_duration(c)))
+        for i in range(n):
+            reseed(i)
+        steps, t0 = 0, time.time()
+        while time.time() - t0 < budget:
+            a = rng.normal(size=(n, 12)) * SIGMA
+            _, _, d = B.step_all_mt(a, threads) if threads > 1 else B.step_all(a)
+            steps += n
+            for i in np.where(d)[0]:
+                reseed(int(i))
+        return steps, time.time() - t0
+    s1, t1 = run(64, 1, budget_s)
+    sn, tn = run(max(64, 8 * cores), cores, budget_s) if cores > 1 else (s1, t1)
+    return {'value': sn / tn, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port', 'one_core_value': s1 / t1,
+            'sample': '%d env-steps on %d threads (%d envs) + %d env-steps on 1 thread (64 envs), all clips, random policy, %.0f s + %.0f s '
+                      'of the float64 oracle (oracle/pmc_oracle.c, OpenMP over envs)' % (sn, cores, max(64, 8 * cores), s1, tn, t1)}
 
 
 def main():

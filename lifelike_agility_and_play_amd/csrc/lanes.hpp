@@ -249,6 +249,22 @@ struct GpuLanes {
   static LL_D I f2i(F x) { return (int)x; }
 };
 
+// The same lanes with the per-leg constant table held in registers for the whole kernel instead of re-read from LDS in
+// every substep.  For the occupancy-1 build only: with one wavefront per SIMD nothing hides an LDS round trip (measured:
+// a quarter of the kernel's cycles sat in s_waitcnt on constant reads), while 256 AGPRs lie idle as spill space -- the
+// register allocator parks the table there and a use costs one v_accvgpr_read instead of a ds_read plus its latency.
+template <int N_LEG_FIELDS>
+struct GpuLanesPinned : GpuLanes {
+  float lc_[N_LEG_FIELDS];
+  LL_D GpuLanesPinned(float* lds) : GpuLanes(lds) {}
+  LL_D void stage_consts(const float* legc, int n_leg_fields, const float* candc, int n_cand_words) {
+    GpuLanes::stage_consts(legc, n_leg_fields, candc, n_cand_words);
+    LL_UNROLL
+    for (int i = 0; i < N_LEG_FIELDS; i++) lc_[i] = lds_[i * 4 + leg_];
+  }
+  LL_D F legc(const float*, int field) const { return lc_[field]; }
+};
+
 #define LL_FMAC_RBCAST(L_)                                                                                               \
   template <>                                                                                                           \
   LL_D void GpuLanes::fmac_rbcast<L_>(float& acc, float x, float k) {                                                    \

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include <new>
+#include <type_traits>
 
 #include "lanes.hpp"
 #include "pmc_engine.hpp"
@@ -24,6 +25,7 @@
   } while (0)
 
 typedef Pmc<GpuLanes> K;
+typedef GpuLanesPinned<LC_COUNT> GpuLanes1;
 
 // PLE:235-240 for the batch, by one wavefront: fold the statistics published by finished episodes into the per-clip table
 // (lane = clip, 64 per pass), then rebuild p ~ (1 - avg_reward_sum)^factor and its inclusive CDF.  Called by the last
@@ -89,7 +91,8 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int row = threadIdx.x >> 4;                                         // one env = one 16-lane DPP row
   const int env = blockIdx.x * PMC_ENVS_PER_WAVE + row;
-  GpuLanes ln(lds);
+  typedef typename std::conditional<OCC == 1, GpuLanes1, GpuLanes>::type Lanes;
+  Lanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);           // all 64 lanes copy, also those without an env
   if (env < P.n_envs) {
     float act[3];
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
     } else {
       for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
     }
-    K::step_env(ln, P, env, act);
+    Pmc<Lanes>::step_env(ln, P, env, act);
   }
   // The last workgroup to get here folds this step's finished episodes into the sampling table.  The statistics travel by
   // device-scope atomics only (publish_max), so no cache write-back is needed -- a __threadfence() here would flush this

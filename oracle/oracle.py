@@ -165,6 +165,13 @@ class OracleBatch(object):
         lib().orc_step_all(self.h, _p(a), _p(obs), _p(rew), done.ctypes.data_as(ip))
         return obs, rew, done.astype(bool)
 
+    def step_all_mt(self, actions, n_threads):
+        """step_all over the host's cores (bench.py's cpu_baseline leg only; table-update order is not deterministic)."""
+        a = f64(actions)
+        obs = np.zeros((self.n_envs, self.obs_dim)); rew = np.zeros(self.n_envs); done = np.zeros(self.n_envs, dtype=np.int32)
+        lib().orc_step_all_mt(self.h, _p(a), _p(obs), _p(rew), done.ctypes.data_as(ip), C.c_int(int(n_threads)))
+        return obs, rew, done.astype(bool)
+
     def get_state(self, env):
         s = np.zeros(37); lib().orc_get_state(self.h, C.c_int(env), _p(s)); return s
 

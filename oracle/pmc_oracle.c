@@ -693,7 +693,7 @@ int orc_substep_model(const OModel* M, double dt, int n_iter, double mu_foot, do
   /* ---- constraint rows --------------------------------------------------------------------------- */
   OContact C[MAXC];
   int nc = find_contacts(M, &K, mu_foot, LLM_LINK_FRICTION * LLM_PLANE_FRICTION, C);
-  static double J[MAXROWS][NDOF], MiJt[MAXROWS][NDOF], A[MAXROWS][MAXROWS];
+  static _Thread_local double J[MAXROWS][NDOF], MiJt[MAXROWS][NDOF], A[MAXROWS][MAXROWS];
   double bias[MAXROWS], lo[MAXROWS], hi[MAXROWS], lam[MAXROWS];
   int fric_of[MAXROWS]; double mu_row[MAXROWS];
   int nr = 0;
@@ -748,7 +748,7 @@ int orc_substep_model(const OModel* M, double dt, int n_iter, double mu_foot, do
   }
   /* M^-1 J^T by unit responses of the ABA at zero velocity */
   {
-    static double Minv[NDOF][NDOF];
+    static _Thread_local double Minv[NDOF][NDOF];
     double zero12[12] = {0};
     for (int d = 0; d < NDOF; d++) {
       double fe[NB][6], t12[12] = {0}, col[NDOF];
@@ -1043,7 +1043,9 @@ int orc_step_env(OBatch* B, int env, const double* action, const double* scripte
   if (bad) reason |= LL_DONE_NONFINITE;
   if (B->cfg.set_obstacle && !bad && obstacle_contact(B, e)) reason |= LL_DONE_COLLISION;      /* PLE:341-346 */
   e->done_reason = reason;
-  if (reason) {                                                            /* PLE:235-240 */
+  if (reason)                                                              /* PLE:235-240 */
+#pragma omp critical(orc_table)
+  {
     int c = e->clip;
     B->avg_reward_sum[c] = e->reward_sum / B->max_steps[c];
     B->avg_episode_len[c] = e->ep_steps / (B->max_steps[c] + 1);
@@ -1124,6 +1126,18 @@ void orc_momentum(const OBatch* B, const double* state, double* out6) {
 
 /* step every env (index order), as bench.py's cpu_baseline leg times it */
 int orc_step_all(OBatch* B, const double* actions, double* obs, double* reward, int32_t* done) {
+  for (int i = 0; i < B->n_envs; i++) {
+    int d;
+    orc_step_env(B, i, actions + 12 * i, NULL, NULL, NULL, obs + (size_t)B->obs_dim * i, reward + i, &d);
+    done[i] = d;
+  }
+  return 0;
+}
+
+/* the same over the host's cores (envs are independent; the per-clip table update is the one shared write and is serialised,
+ * in whatever order the threads get there) -- only bench.py's cpu_baseline leg uses this */
+int orc_step_all_mt(OBatch* B, const double* actions, double* obs, double* reward, int32_t* done, int n_threads) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
   for (int i = 0; i < B->n_envs; i++) {
     int d;
     orc_step_env(B, i, actions + 12 * i, NULL, NULL, NULL, obs + (size_t)B->obs_dim * i, reward + i, &d);
