@@ -1,0 +1,511 @@
+// epmc_step.hpp -- the EPMC (environmental-level) control step, generic over the lane policy like pmc_step.hpp.
+//
+// What it replaces, cited as
+//   PGE = src/lifelike/sim_envs/pybullet_envs/max_game_elements/playground_env.py
+//   BSE = src/lifelike/sim_envs/pybullet_envs/max_game_elements/bullet_static_entities.py
+//   PR  = src/lifelike/sim_envs/pybullet_envs/randomizer/push_randomizer.py
+//
+// The physics substep is Pmc<L>::substep (pmc_step.hpp) with two additions: the episode's foot friction and the push force
+// on the FR hip link.  Everything else here is per-env scalar work (every lane of the env's row computes it; stores come
+// from lane 0) except the 778 rays, which the 16 lanes of the row share out.
+#pragma once
+#include "pmc_step.hpp"
+
+#define EPMC_N_HEIGHT 325
+#define EPMC_N_HORIZ 128
+#define EPMC_N_FRONT 325
+#define EPMC_N_RAYS 778
+#define EPMC_MAX_STATICS 104
+#define EPMC_MAX_BOXES 40
+#define EPMC_MAX_DRAWS 64
+#define EPMC_EP_STRIDE 40
+
+// per-env scalar row (EpmcParams::ep)
+enum EpmcEpField {
+  EP_TARGET = 0,      // 3
+  EP_TARGET_SPD = 3,
+  EP_FRICTION = 4,    // the episode's foot lateralFriction (PGE:209)
+  EP_CMD_FREQ = 5,
+  EP_COUNTER = 6,
+  EP_PUSH_FORCE = 7,  // 3
+  EP_NOISE = 10,      // 4: pos_x, pos_y, yaw, pos_z bias
+  EP_LAST_DIFF = 14,
+  EP_INIT_DIFF = 15,  // -1 = None (element 0)
+  EP_TOTAL_SPD = 16,
+  EP_MAX_SPD = 17,
+  EP_REW = 18,        // 4: reward_vel, reward_rotation, reward_dist, reward_avg_spd
+  EP_PUSH_COUNT = 22,
+  EP_STEP_DRAWS = 23, // uniforms consumed by the steps of this episode (Philox counter)
+  EP_INIT_ORN = 24,   // 4: the start orientation, rotated in place at every reset (PGE:186-190)
+  EP_EPISODE = 28,
+  EP_N_BOXES = 29,
+  EP_N_STATICS = 30,
+};
+
+struct EpmcParams {
+  int32_t element_id, max_steps, push_enabled, push_count0;
+  int32_t push_interval_step, push_duration_step, cmd_freq_lo, cmd_freq_hi;
+  float friction_lo, friction_hi, hforce_lo, hforce_hi;
+  float vforce_lo, vforce_hi, push_ratio, plane_friction;
+  float spd_lo, spd_hi, aux_radius, hole_gap_lo;      // aux_radius < 0: no auxiliary cylinders
+  float hole_gap_hi, pad0, pad1, pad2;
+  int32_t noise_on[4];
+  float noise_lo[4], noise_hi[4];
+  const float* init_state;  // [37] LeggedRobot.get_init_states_info(), LR:116-117
+  // per-env buffers
+  float* ep;               // [n_envs][EPMC_EP_STRIDE]
+  float* info;             // [n_envs][6]
+  float* statics;          // [n_envs][EPMC_MAX_STATICS][8]
+  float* boxes;            // [n_envs][EPMC_MAX_BOXES][6]  centre, half extents of what the rays (and later the contacts) see
+  float* push_trace;       // [n_envs][n_sub][4]
+  float* ray_trace;        // optional [n_envs][778][8]: from 3, to 3, hit, fraction
+  // parity hooks (null in production)
+  const float* scr_state;    // [n_envs][37]
+  const uint8_t* scr_ray_hit;  // [n_envs][778]
+  const float* scr_ray_frac;   // [n_envs][778]
+  const float* scr_draws;    // [n_envs][scr_n_draws]
+  int32_t scr_n_draws, pad4;
+};
+
+// Uniform draws in the reference's call order: a recorded stream (parity) or Philox keyed on (seed; env, episode, index, salt).
+struct EpmcDraws {
+  const float* scr;
+  int n_scr, used;
+  uint64_t seed;
+  uint32_t env, episode, salt;
+  LL_HD float u01() {
+    const int i = used++;
+    if (scr) return i < n_scr ? scr[i] : 0.5f;
+    uint32_t r[4];
+    philox4x32(env, episode, (uint32_t)i, salt, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    return (float)(r[0] >> 8) * (1.0f / 16777216.0f);
+  }
+  LL_HD float uniform(float a, float b) { return a + (b - a) * u01(); }
+  LL_HD int randint(int a, int b) {                      // np.random.randint(a, b): a .. b-1
+    int k = (int)((float)(b - a) * u01());
+    if (k > b - a - 1) k = b - a - 1;
+    return a + k;
+  }
+};
+
+template <class L>
+struct Epmc {
+  typedef Pmc<L> K;
+  typedef typename L::F F;
+  typedef typename K::Base Base;
+
+  // ------------------------------------------------------------------------------------------------------------
+  // terrain (BSE:22-503): rows [kind, x, y, z, a, b, c, 0] in creation order + the compact box list the rays use
+  // ------------------------------------------------------------------------------------------------------------
+  struct Terrain {
+    float* rows;
+    float* boxes;
+    int n_rows, n_boxes;
+    bool store;
+    float gap, aux;
+    LL_HD void row(float kind, float x, float y, float z, float a, float b, float c) {
+      if (store && n_rows < EPMC_MAX_STATICS) {
+        float* r = rows + n_rows * 8;
+        r[0] = kind; r[1] = x; r[2] = y; r[3] = z; r[4] = a; r[5] = b; r[6] = c; r[7] = 0.0f;
+      }
+      n_rows++;
+    }
+    LL_HD void box(float x, float y, float z, float l, float w, float h, float flag) {
+      row(0.0f, x, y, z, l * 0.5f, w * 0.5f, h * 0.5f);
+      if (l > 0.0f && n_boxes < EPMC_MAX_BOXES) {
+        if (store) {
+          float* b = boxes + n_boxes * 6;
+          b[0] = x; b[1] = y; b[2] = z; b[3] = l * 0.5f; b[4] = w * 0.5f; b[5] = h * 0.5f;
+        }
+        n_boxes++;
+      }
+      if (flag != 0.0f && aux >= 0.0f) {                                       // BSE:43-104 edge cylinders along y
+        row(1.0f, x - l * 0.5f, y, z + h * 0.5f * flag, aux, w, 0.0f);
+        row(1.0f, x + l * 0.5f, y, z + h * 0.5f * flag, aux, w, 0.0f);
+      }
+    }
+  };
+  static LL_HD float hurdle(Terrain& T, EpmcDraws& d, float cur) {              // BSE:309-364
+    float height = d.uniform(0.05f, 0.15f);
+    float distance = d.uniform(1.0f, 3.0f);
+    T.box(cur + distance * 0.5f, 0.0f, height * 0.5f, 0.1f, T.gap, height, 1.0f);
+    return cur + distance + 0.1f;
+  }
+  static LL_HD float hole(Terrain& T, EpmcDraws& d, const EpmcParams& E, float cur) {   // BSE:366-425
+    float distance = d.uniform(1.0f, 3.0f);
+    float gap_height = d.uniform(E.hole_gap_lo, E.hole_gap_hi);
+    T.box(cur + distance * 0.5f, 0.0f, 0.15f + gap_height, 0.1f, T.gap, 0.3f, -1.0f);
+    return cur + distance + 0.1f;
+  }
+  static LL_HD float cube_set(Terrain& T, EpmcDraws& d, float cur) {            // BSE:427-503, easy=True (BSE:247)
+    cur += d.uniform(0.0f, 1.0f);
+    T.box(1.75f + cur, 0.0f, 0.125f, 0.5f, T.gap, 0.25f, 1.0f);
+    T.box(1.0f + cur, 0.0f, 0.05f, 0.5f, T.gap, 0.1f, 1.0f);
+    cur += 2.0f;
+    T.box(cur + 0.5f, 0.0f, 0.125f, 0.5f, T.gap, 0.25f, 1.0f);
+    T.box(cur + 1.25f, 0.0f, 0.05f, 0.5f, T.gap, 0.1f, 1.0f);
+    return cur + 3.0f;
+  }
+  static LL_HD void gen_terrain(Terrain& T, EpmcDraws& d, const EpmcParams& E, float* target) {
+    target[0] = 8.0f; target[1] = 0.0f; target[2] = 0.0f;
+    if (E.element_id == 0) {                                                   // joystick: the target marker only
+      T.box(8.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);
+      return;
+    }
+    float width = d.uniform(0.02f, 0.5f);                                       // PGE:165, BSE:166-170
+    float gap = d.uniform(1.0f, 20.0f);                                         // PGE:166
+    T.gap = gap;
+    float aux = T.aux;
+    T.aux = -1.0f;                                                              // the walls carry no edge cylinders
+    T.box(5.0f, gap * 0.5f + width * 0.5f, 1.0f, 200.0f, width, 2.0f, 0.0f);
+    T.box(5.0f, -(gap * 0.5f + width * 0.5f), 1.0f, 200.0f, width, 2.0f, 0.0f);
+    T.aux = aux;
+    float cur = 0.0f;
+    if (E.element_id == 1 || E.element_id == 2) {                              // BSE:200-222
+      int n = d.randint(1, 10);
+      for (int i = 0; i < n; i++) cur = (E.element_id == 1) ? hurdle(T, d, cur) : hole(T, d, E, cur);
+      target[0] = cur + d.uniform(-1.0f, 1.0f);
+      T.box(target[0], 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);
+      for (int i = 0; i < n; i++) cur = (E.element_id == 1) ? hurdle(T, d, cur) : hole(T, d, E, cur);
+    } else {                                                                    // BSE:187-198 cubes
+      int n = d.randint(1, 5);
+      for (int i = 0; i < n; i++) cur = cube_set(T, d, cur);
+      target[0] = cur + d.uniform(-3.0f, 3.0f);
+      T.box(target[0], 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);
+      for (int i = 0; i < n; i++) cur = cube_set(T, d, cur);
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------------------
+  // rays (PGE:25-52, :381-447).  cast(): this build's spec of rayTestBatch(mask 6): plane z = 0 and the boxes.
+  // ------------------------------------------------------------------------------------------------------------
+  static LL_HD float cast(const float* f, const float* t, const float* boxes, int n_boxes, bool* hit_out) {
+    const float d[3] = {t[0] - f[0], t[1] - f[1], t[2] - f[2]};
+    float best = 3.0e38f;
+    if (d[2] < 0.0f) {
+      float tz = -f[2] / d[2];
+      if (tz >= 0.0f && tz <= 1.0f) best = tz;
+    }
+    for (int b = 0; b < n_boxes; b++) {
+      const float* bx = boxes + b * 6;
+      float te = -3.0e38f, tl = 3.0e38f;
+      for (int a = 0; a < 3; a++) {
+        const float lo = bx[a] - bx[3 + a], hi = bx[a] + bx[3 + a];
+        if (d[a] == 0.0f) {
+          if (!(f[a] >= lo && f[a] <= hi)) { te = 3.0e38f; tl = -3.0e38f; }
+        } else {
+          const float inv = 1.0f / d[a];
+          float t1 = (lo - f[a]) * inv, t2 = (hi - f[a]) * inv;
+          te = fmaxf(te, fminf(t1, t2));
+          tl = fminf(tl, fmaxf(t1, t2));
+        }
+      }
+      if (te <= tl && te >= 0.0f && te <= 1.0f && te < best) best = te;       // origin inside a box: no hit
+    }
+    *hit_out = best < 2.0f;
+    return best < 2.0f ? best : 1.0f;
+  }
+  static LL_HD void grid_point(int i, float x0, float x1, float y0, float y1, float* gx, float* gy) {   // utils/constants.py:5-10, 25 x 13
+    const int ix = i / 13, iy = i - 13 * ix;
+    *gx = x0 + (x1 - x0) * (float)ix * (1.0f / 24.0f);
+    *gy = y0 + (y1 - y0) * (float)iy * (1.0f / 12.0f);
+  }
+  // end points of ray r in call order: 325 height, 128 horizontal, 325 front
+  static LL_HD void ray_ends(int r, const float* pos, const M3<float>& R, float yaw, float* f, float* t) {
+    if (r < EPMC_N_HEIGHT) {                                                    // PGE:431-441
+      float gx, gy;
+      grid_point(r, -1.2f, 1.2f, -0.6f, 0.6f, &gx, &gy);
+      f[0] = t[0] = R.m[0] * gx + R.m[1] * gy + pos[0];
+      f[1] = t[1] = R.m[3] * gx + R.m[4] * gy + pos[1];
+      f[2] = 10.0f; t[2] = -10.0f;
+    } else if (r < EPMC_N_HEIGHT + EPMC_N_HORIZ) {                              // PGE:30-38
+      const float a = yaw + 6.283185307179586f * (float)(r - EPMC_N_HEIGHT) * (1.0f / 128.0f);
+      f[0] = pos[0]; f[1] = pos[1]; f[2] = pos[2];
+      t[0] = pos[0] + 20.0f * cosf(a); t[1] = pos[1] + 20.0f * sinf(a); t[2] = pos[2];
+    } else {                                                                    // PGE:405-419: (0, gy, gz) -> (3, gy, gz) in the base frame
+      float gy, gz;
+      grid_point(r - EPMC_N_HEIGHT - EPMC_N_HORIZ, -0.25f, 0.25f, -0.3f, 0.1f, &gy, &gz);
+      for (int a = 0; a < 3; a++) {
+        const float o = R.m[3 * a + 1] * gy + R.m[3 * a + 2] * gz + pos[a];
+        f[a] = o; t[a] = o + 3.0f * R.m[3 * a];
+      }
+    }
+  }
+  // the three percep arrays straight into the obs row; lanes share the rays out
+  static LL_HD void observe_rays(const L& ln, const StepParams& P, const EpmcParams& E, int env, const float* pos, const M3<float>& R, float yaw,
+                                 const float* noise, const float* boxes, int n_boxes, float* percep) {
+    for (int r = ln.ray_first(); r < EPMC_N_RAYS; r += ln.ray_stride()) {
+      float f[3], t[3];
+      ray_ends(r, pos, R, yaw, f, t);
+      bool hit;
+      float frac;
+      if (E.scr_ray_hit) {
+        hit = E.scr_ray_hit[(long)env * EPMC_N_RAYS + r] != 0;
+        frac = E.scr_ray_frac[(long)env * EPMC_N_RAYS + r];
+      } else {
+        frac = cast(f, t, boxes, n_boxes, &hit);
+      }
+      if (E.ray_trace) {
+        float* tr = E.ray_trace + ((long)env * EPMC_N_RAYS + r) * 8;
+        tr[0] = f[0]; tr[1] = f[1]; tr[2] = f[2]; tr[3] = t[0]; tr[4] = t[1]; tr[5] = t[2]; tr[6] = hit ? 1.0f : 0.0f; tr[7] = frac;
+      }
+      const float hx = hit ? f[0] + frac * (t[0] - f[0]) : 0.0f, hy = hit ? f[1] + frac * (t[1] - f[1]) : 0.0f, hz = hit ? f[2] + frac * (t[2] - f[2]) : 0.0f;
+      float v;
+      if (r < EPMC_N_HEIGHT) {                                                  // PGE:442-446 hit height; a miss reports (0,0,0)
+        v = hz;
+        if (E.noise_on[3]) v = (v > 0.01f && v < 0.6f) ? v + noise[3] : 0.0f;
+      } else if (r < EPMC_N_HEIGHT + EPMC_N_HORIZ) {                            // PGE:399, :49-50: a miss measures |(0,0,0) - origin|
+        const float dx = hx - f[0], dy = hy - f[1], dz = hz - f[2];
+        v = sqrtf(dx * dx + dy * dy + dz * dz);
+      } else {                                                                  // PGE:425-427: a miss counts as the far end
+        const float px = hit ? hx : t[0], py = hit ? hy : t[1], pz = hit ? hz : t[2];
+        const float dx = px - f[0], dy = py - f[1], dz = pz - f[2];
+        v = sqrtf(dx * dx + dy * dy + dz * dz);
+      }
+      percep[r] = v;
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------------------
+  // observation: prop | prop_a history (as PMC) | percep_2d | percep_1d | percep_front | target (PGE:276-297, :381-403)
+  // ------------------------------------------------------------------------------------------------------------
+  static LL_HD void observe(const L& ln, const StepParams& P, const EpmcParams& E, int env, float* row, bool fill, const typename K::ObsIn& hist,
+                            const Base& bs, const F* q, const F* qd, const F* act, const float* ep, const float* target, float target_spd) {
+    const Q4 qn = qnormalize(bs.q);
+    const M3<float> R = qmat(qn);
+    K::obs_emit_core(ln, P, row, fill, hist, bs, R, q, qd, act);
+    float pos[3] = {bs.p.x, bs.p.y, bs.p.z};
+    float yaw = atan2f(R.m[3], R.m[0]);                                          // PGE:386
+    if (E.noise_on[0]) { pos[0] += ep[EP_NOISE + 0]; pos[1] += ep[EP_NOISE + 1]; }   // PGE:388-391
+    if (E.noise_on[2]) yaw += ep[EP_NOISE + 2];                                  // PGE:392-393
+    const long a0 = 3L * P.prop_dim + 36;
+    const int n_boxes = (int)ep[EP_N_BOXES];
+    observe_rays(ln, P, E, env, pos, R, yaw, ep + EP_NOISE, E.boxes + (long)env * EPMC_MAX_BOXES * 6, n_boxes, row + a0);
+    // target_info (PGE:400-403): the (x, y) of R^-1 (target - position), normalised, then the commanded speed
+    const float dx = target[0] - pos[0], dy = target[1] - pos[1], dz = target[2] - pos[2];
+    const float lx = R.m[0] * dx + R.m[3] * dy + R.m[6] * dz, ly = R.m[1] * dx + R.m[4] * dy + R.m[7] * dz;
+    const float inv = 1.0f / sqrtf(lx * lx + ly * ly);
+    if (ln.lane0()) {
+      row[a0 + EPMC_N_RAYS + 0] = lx * inv;
+      row[a0 + EPMC_N_RAYS + 1] = ly * inv;
+      row[a0 + EPMC_N_RAYS + 2] = target_spd;
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------------------
+  // reset (PGE:196-249): everything except the observation; the caller runs observe() afterwards
+  // ------------------------------------------------------------------------------------------------------------
+  static LL_HD void reset_scalars(const L& ln, const StepParams& P, const EpmcParams& E, int env, float* ep, EpmcDraws& d, Base& bs, F* q, F* qd,
+                                  const float* prev_orn) {
+    ep[EP_FRICTION] = d.uniform(E.friction_lo, E.friction_hi);                   // PGE:209
+    if (E.push_enabled) {                                                        // PGE:213-214, PR:52-54
+      ep[EP_PUSH_COUNT] = (float)E.push_count0;
+      randomize_force(E, d, ep);
+    }
+    Terrain T;
+    T.rows = E.statics + (long)env * EPMC_MAX_STATICS * 8;
+    T.boxes = E.boxes + (long)env * EPMC_MAX_BOXES * 6;
+    T.n_rows = T.n_boxes = 0; T.store = ln.lane0(); T.gap = 0.0f; T.aux = E.aux_radius;
+    gen_terrain(T, d, E, ep + EP_TARGET);                                         // PGE:216-221
+    ln.row_sync();                                                                // the rays of this step read the new boxes
+    ep[EP_N_BOXES] = (float)T.n_boxes; ep[EP_N_STATICS] = (float)(T.n_rows < EPMC_MAX_STATICS ? T.n_rows : EPMC_MAX_STATICS);
+    ep[EP_CMD_FREQ] = (float)d.randint(E.cmd_freq_lo, E.cmd_freq_hi);            // PGE:223
+    ep[EP_COUNTER] = 0.0f; ep[EP_TOTAL_SPD] = 0.0f; ep[EP_MAX_SPD] = 0.0f;
+    for (int i = 0; i < 4; i++) ep[EP_REW + i] = 0.0f;
+    for (int i = 0; i < 4; i++) ep[EP_NOISE + i] = E.noise_on[i] ? d.uniform(E.noise_lo[i], E.noise_hi[i]) : 0.0f;   // PGE:176-179 (dict order)
+    // PGE:181-195: start pose = the stored pose rotated IN PLACE about z by 360 * rand() degrees, at (0, 0, 0.5)
+    const float half = 0.5f * 360.0f * d.u01() * 0.017453292519943295f;
+    Q4 prev = {prev_orn[0], prev_orn[1], prev_orn[2], prev_orn[3]};
+    Q4 rz = {0.0f, 0.0f, sinf(half), cosf(half)};
+    Q4 orn = qmul(prev, rz);
+    ep[EP_INIT_ORN + 0] = orn.x; ep[EP_INIT_ORN + 1] = orn.y; ep[EP_INIT_ORN + 2] = orn.z; ep[EP_INIT_ORN + 3] = orn.w;
+    bs.p = mk3<float>(0.0f, 0.0f, 0.5f);
+    bs.q = orn;
+    bs.v = mk3<float>(E.init_state[7], E.init_state[8], E.init_state[9]);
+    bs.w = mk3<float>(E.init_state[10], E.init_state[11], E.init_state[12]);
+    for (int j = 0; j < 3; j++) { q[j] = ln.ldl(E.init_state, 13 + j, 3); qd[j] = ln.ldl(E.init_state, 25 + j, 3); }
+    const float ddx = bs.p.x - ep[EP_TARGET], ddy = bs.p.y - ep[EP_TARGET + 1];
+    ep[EP_LAST_DIFF] = sqrtf(ddx * ddx + ddy * ddy);                              // PGE:191-192
+    ep[EP_INIT_DIFF] = (E.element_id == 0) ? -1.0f : ep[EP_LAST_DIFF];
+    // (target_spd survives a reset, PGE:172; it is redrawn at counter 0)
+    ep[EP_STEP_DRAWS] = 0.0f;
+  }
+  static LL_HD void randomize_force(const EpmcParams& E, EpmcDraws& d, float* ep) {   // PR:88-98
+    const float theta = d.uniform(0.0f, 6.283185307179586f);
+    const float h = d.uniform(E.hforce_lo, E.hforce_hi), v = d.uniform(E.vforce_lo, E.vforce_hi);
+    ep[EP_PUSH_FORCE + 0] = h * cosf(theta); ep[EP_PUSH_FORCE + 1] = h * sinf(theta); ep[EP_PUSH_FORCE + 2] = v;
+  }
+  static LL_HD void load_ep(const float* g, float* ep) {
+    for (int i = 0; i < EPMC_EP_STRIDE; i++) ep[i] = g[i];
+  }
+  static LL_HD void store_ep(const L& ln, float* g, const float* ep) {
+    if (ln.lane0()) for (int i = 0; i < EPMC_EP_STRIDE; i++) g[i] = ep[i];
+  }
+  static LL_HD bool check_fall(const M3<float>& R) {                                // LR:159-179
+    const float left_z = R.m[2] * R.m[3] - R.m[5] * R.m[0];
+    return left_z > 0.70710678118654752f || left_z < -0.70710678118654752f || R.m[8] < 0.5f;
+  }
+
+  // kernel body of ll_epmc_reset
+  static LL_HD void reset_env(const L& ln, const StepParams& P, const EpmcParams& E, int env, const float* draws_row, const float* prev_orn_row) {
+    const int N = P.n_envs;
+    float ep[EPMC_EP_STRIDE];
+    load_ep(E.ep + (long)env * EPMC_EP_STRIDE, ep);
+    const uint32_t episode = (uint32_t)ep[EP_EPISODE] + 1u;
+    ep[EP_EPISODE] = (float)episode;
+    EpmcDraws d = {draws_row, EPMC_MAX_DRAWS, 0, P.seed, (uint32_t)env, episode, 0x7e44a1u};
+    Base bs;
+    F q[3], qd[3];
+    float prev[4];
+    for (int i = 0; i < 4; i++) prev[i] = prev_orn_row ? prev_orn_row[i] : ep[EP_INIT_ORN + i];
+    reset_scalars(ln, P, E, env, ep, d, bs, q, qd, prev);
+    F zero3[3] = {ln.lane_f(0.0f), ln.lane_f(0.0f), ln.lane_f(0.0f)};
+    typename K::ObsIn hist;
+    for (int c = 0; c < K::OBS_HIST_CHUNKS; c++) hist.h[c] = ln.lane_f(0.0f);
+    hist.ha[0] = hist.ha[1] = ln.lane_f(0.0f);
+    float* row = P.obs + (long)env * P.obs_dim;
+    store_ep(ln, E.ep + (long)env * EPMC_EP_STRIDE, ep);                          // the boxes and scalars observe() reads
+    observe(ln, P, E, env, row, true, hist, bs, q, qd, zero3, ep, ep + EP_TARGET, ep[EP_TARGET_SPD]);
+    K::store_state(ln, P.state, N, env, bs, q, qd);
+    P.done[env] = 0;
+    P.done_reason[env] = 0;
+  }
+
+  // ------------------------------------------------------------------------------------------------------------
+  // the control step (PGE:299-364)
+  // ------------------------------------------------------------------------------------------------------------
+  static LL_HD void step_env(const L& ln, const StepParams& P, const EpmcParams& E, int env, const F* act_in) {
+    const int N = P.n_envs;
+    Base bs;
+    F q[3], qd[3], act[3], tgt[3];
+    K::load_state(ln, P.state, N, env, bs, q, qd);
+    float ep[EPMC_EP_STRIDE];
+    load_ep(E.ep + (long)env * EPMC_EP_STRIDE, ep);
+    float* row = P.obs + (long)env * P.obs_dim;
+    typename K::ObsIn hist;
+    {
+      const int Pd = P.prop_dim;
+      for (int c = 0; c < K::OBS_HIST_CHUNKS; c++) hist.h[c] = ln.ld16(row + Pd, 16 * c, 2 * Pd);
+      for (int c = 0; c < 2; c++) hist.ha[c] = ln.ld16(row + 3L * Pd + 12, 16 * c, 24);
+    }
+    for (int j = 0; j < 3; j++) {
+      act[j] = act_in[j];
+      F t = q[j] + act[j];                                                     // PGE:323
+      tgt[j] = lm::min_(lm::max_(t, ln.lane_f(-3.0f)), ln.lane_f(3.0f));        // LR:126-127
+    }
+    EpmcDraws d = {E.scr_draws ? E.scr_draws + (long)env * E.scr_n_draws : nullptr, E.scr_n_draws, E.scr_draws ? 0 : (int)ep[EP_STEP_DRAWS], P.seed, (uint32_t)env,
+                   (uint32_t)ep[EP_EPISODE], 0x57e9d3u};
+    const int counter = (int)ep[EP_COUNTER], cmd_freq = (int)ep[EP_CMD_FREQ];
+    if (E.element_id == 0 && counter % cmd_freq == 0) {                          // PGE:300-311 joystick: a new target 100 m away
+      const float ang = d.uniform(0.0f, 6.283185307179586f);
+      ep[EP_TARGET + 0] = bs.p.x + cosf(ang) * 100.0f;
+      ep[EP_TARGET + 1] = bs.p.y + sinf(ang) * 100.0f;
+      ep[EP_TARGET + 2] = 0.0f;
+      const float ddx = bs.p.x - ep[EP_TARGET], ddy = bs.p.y - ep[EP_TARGET + 1];
+      ep[EP_LAST_DIFF] = sqrtf(ddx * ddx + ddy * ddy);
+    }
+    if (counter % cmd_freq == 0) ep[EP_TARGET_SPD] = d.uniform(E.spd_lo, E.spd_hi);   // PGE:312-313
+
+    typename K::SubstepExtra ex;
+    ex.mu_foot = ep[EP_FRICTION] * E.plane_friction;
+    float* ptrace = E.push_trace + (long)env * P.n_sub * 4;
+    for (int s = 0; s < P.n_sub; s++) {                                          // PGE:326-331
+      ex.has_push = false;
+      if (E.push_enabled) {                                                      // PR:56-86, counted in substeps
+        int c = (int)ep[EP_PUSH_COUNT] + 1;
+        if (c > 0) {
+          if (c % E.push_interval_step == 0) { randomize_force(E, d, ep); c = 0; }
+          if (c < E.push_duration_step) {
+            ex.has_push = true;
+            for (int i = 0; i < 3; i++) ex.push[i] = ep[EP_PUSH_FORCE + i] * E.push_ratio;
+          }
+        }
+        ep[EP_PUSH_COUNT] = (float)c;
+      }
+      if (ln.lane0()) {
+        ptrace[s * 4 + 0] = ex.has_push ? 1.0f : 0.0f;
+        for (int i = 0; i < 3; i++) ptrace[s * 4 + 1 + i] = ex.has_push ? ex.push[i] : 0.0f;
+      }
+      if (!E.scr_state) K::substep(ln, P, bs, q, qd, tgt, env, s, &ex);         // PGE:328-330
+    }
+    if (E.scr_state) {   // parity hook: the caller plays PyBullet
+      const float* ss = E.scr_state + (long)env * 37;
+      bs.p = mk3<float>(ss[0], ss[1], ss[2]);
+      bs.q.x = ss[3]; bs.q.y = ss[4]; bs.q.z = ss[5]; bs.q.w = ss[6];
+      bs.v = mk3<float>(ss[7], ss[8], ss[9]);
+      bs.w = mk3<float>(ss[10], ss[11], ss[12]);
+      for (int j = 0; j < 3; j++) { q[j] = ln.ldl(ss, 13 + j, 3); qd[j] = ln.ldl(ss, 25 + j, 3); }
+    }
+    F fin = q[0] + q[1] + q[2] + qd[0] + qd[1] + qd[2];
+    float chk = L::qsum(fin) + bs.p.x + bs.p.y + bs.p.z + bs.q.x + bs.q.y + bs.q.z + bs.q.w + bs.v.x + bs.v.y + bs.v.z + bs.w.x + bs.w.y + bs.w.z;
+    const bool bad = !(fabsf(chk) < 1e30f);
+
+    // --- termination (PGE:366-379) and reward (PGE:474-539) of this transition ---
+    const int cnt = counter + 1;                                                 // PGE:342
+    ep[EP_COUNTER] = (float)cnt;
+    const M3<float> R = qmat(qnormalize(bs.q));
+    const float gx = ep[EP_TARGET] - bs.p.x, gy = ep[EP_TARGET + 1] - bs.p.y;
+    const float dist = sqrtf(gx * gx + gy * gy);
+    int reason = 0;
+    if (check_fall(R)) reason |= 1;
+    if (cnt >= E.max_steps) reason |= 2;
+    const bool reach = dist < 0.5f;
+    if (reach) reason |= 4;
+    if (bad) reason |= 16;
+    const float ux = gx / dist, uy = gy / dist;
+    const float spd = fabsf(bs.v.x * ux + bs.v.y * uy);                           // PGE:478-480
+    ep[EP_TOTAL_SPD] += spd;
+    if (spd > ep[EP_MAX_SPD]) ep[EP_MAX_SPD] = spd;
+    const float yaw = atan2f(R.m[3], R.m[0]);
+    const float r_rot = expf((cosf(yaw) * ux + sinf(yaw) * uy - 1.0f) * 5.0f);
+    const float inv_ms = 1.0f / (float)E.max_steps;
+    float reward;
+    if (E.element_id == 0) {                                                      // joystick, PGE:474-497
+      const float r_vel = expf(-fabsf(spd - ep[EP_TARGET_SPD]));
+      reward = r_vel * r_rot * inv_ms;
+      ep[EP_REW + 1] += r_rot * inv_ms;
+      ep[EP_REW + 0] += r_vel * inv_ms;
+    } else {                                                                      // average speed, PGE:499-539
+      const float r_dist = ep[EP_INIT_DIFF] >= 0.0f ? (dist - ep[EP_LAST_DIFF]) / ep[EP_INIT_DIFF] : 0.0f;
+      ep[EP_LAST_DIFF] = dist;
+      const float s_rot = r_rot * inv_ms * 0.1f, s_dist = -r_dist * 0.1f;
+      reward = s_rot * 2.0f + s_dist;
+      ep[EP_REW + 1] += s_rot * 2.0f;
+      ep[EP_REW + 2] += s_dist;
+      if (reach) {
+        const float r_avg = expf(-fabsf(ep[EP_TOTAL_SPD] / (float)cnt - ep[EP_TARGET_SPD]));
+        reward += r_avg;
+        ep[EP_REW + 3] += r_avg;
+      }
+    }
+    if (bad) reward = 0.0f;
+    if (!E.scr_draws) ep[EP_STEP_DRAWS] = (float)d.used;
+
+    F oact[3] = {act[0], act[1], act[2]};
+    bool fill = false;
+    if (reason) {
+      if (ln.lane0()) {                                                           // PGE:356-362
+        float* inf = E.info + (long)env * 6;
+        inf[0] = ep[EP_TOTAL_SPD] / (float)cnt; inf[1] = ep[EP_MAX_SPD];
+        for (int i = 0; i < 4; i++) inf[2 + i] = ep[EP_REW + i];
+      }
+      K::count_add(ln, P.counters + 1);
+      if (bad) K::count_add(ln, P.counters + 2);
+      if (P.auto_reset) {                                                         // re-seed inside the step: new terrain, start pose, then the common tail
+        const uint32_t episode = (uint32_t)ep[EP_EPISODE] + 1u;
+        ep[EP_EPISODE] = (float)episode;
+        EpmcDraws dr = {nullptr, 0, 0, P.seed, (uint32_t)env, episode, 0x7e44a1u};
+        float prev[4] = {ep[EP_INIT_ORN], ep[EP_INIT_ORN + 1], ep[EP_INIT_ORN + 2], ep[EP_INIT_ORN + 3]};
+        reset_scalars(ln, P, E, env, ep, dr, bs, q, qd, prev);
+        for (int j = 0; j < 3; j++) oact[j] = ln.lane_f(0.0f);
+        fill = true;
+      }
+    }
+    store_ep(ln, E.ep + (long)env * EPMC_EP_STRIDE, ep);
+    observe(ln, P, E, env, row, fill, hist, bs, q, qd, oact, ep, ep + EP_TARGET, ep[EP_TARGET_SPD]);   // PGE:335-338 (raw action in the history)
+    K::store_state(ln, P.state, N, env, bs, q, qd);
+    P.reward[env] = reward;
+    P.done[env] = reason ? 1 : 0;
+    P.done_reason[env] = (uint8_t)reason;
+  }
+};

@@ -102,6 +102,11 @@ struct GpuLanes {
   LL_D B is_sub(int k) const { return sub_ == k; }
   LL_D B is_lane(int L) const { return lane16_ == L; }
   LL_D F lane_f(float x) const { return x; }
+  // per-env scalar code runs on every lane of the row; lane 0 does its stores.  Work lists (rays) are dealt out 16 ways.
+  LL_D bool lane0() const { return lane16_ == 0; }
+  LL_D int ray_first() const { return lane16_; }
+  LL_D int ray_stride() const { return PMC_ROW; }
+  LL_D void row_sync() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }   // lane 0's stores visible to the row
 
   // ---- reductions / broadcasts ------------------------------------------------------------------------------
   // sum over the four LEGS of a leg-uniform value (each leg's value is replicated in its 4 sub-lanes)

@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "lanes.hpp"
+#include "epmc_engine.hpp"
 #include "pmc_engine.hpp"
 #include "pmc_step.hpp"
 
@@ -127,6 +128,30 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
   }
 }
 
+// EPMC (epmc_step.hpp): one control step of PlayGroundEnv for every env; same execution model and register budgets as
+// pmc_step_kernel.  The 778 rays of an env are dealt out over the 16 lanes of its row.
+template <int OCC>
+__global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, EpmcParams E) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int env = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
+  typedef typename std::conditional<OCC == 1, GpuLanes1, GpuLanes>::type Lanes;
+  Lanes ln(lds);
+  ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
+  if (env >= P.n_envs) return;
+  float act[3];
+  for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
+  Epmc<Lanes>::step_env(ln, P, E, env, act);
+}
+__global__ __launch_bounds__(PMC_WAVE) void epmc_reset_kernel(StepParams P, EpmcParams E, const int32_t* ids, int n, const float* draws, const float* prev_orn) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int i = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
+  GpuLanes ln(lds);
+  ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
+  if (i >= n) return;
+  const int env = ids ? ids[i] : i;
+  Epmc<GpuLanes>::reset_env(ln, P, E, env, draws ? draws + (long)i * EPMC_MAX_DRAWS : nullptr, prev_orn ? prev_orn + (long)i * 4 : nullptr);
+}
+
 __global__ __launch_bounds__(PMC_WAVE) void pmc_reset_kernel(StepParams P, const int32_t* ids, int n, const int32_t* clip, const double* t0) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int i = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
@@ -201,20 +226,37 @@ struct HipBackend {
   void sync() { use(); HIPCHK(hipStreamSynchronize(stream)); }
 
   static size_t lds_bytes() { return ((size_t)LC_COUNT * 4 + (size_t)CAND_TABLE_WORDS * PMC_ROW + PMC_ENVS_PER_WAVE * 12) * sizeof(float); }
+  std::pair<hipEvent_t, hipEvent_t>* timing_begin() {
+    if (!timing) return nullptr;
+    if (ev_used == evs.size()) {
+      hipEvent_t a, b;
+      HIPCHK(hipEventCreate(&a));
+      HIPCHK(hipEventCreate(&b));
+      evs.push_back(std::make_pair(a, b));
+    }
+    std::pair<hipEvent_t, hipEvent_t>* ev = &evs[ev_used++];
+    HIPCHK(hipEventRecord(ev->first, stream));
+    return ev;
+  }
+  void launch_epmc_step(const StepParams& P, const EpmcParams& E) {
+    use();
+    const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
+    std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin();
+    if (blocks <= simds) hipLaunchKernelGGL(epmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P, E);
+    else                 hipLaunchKernelGGL(epmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P, E);
+    HIPCHK(hipGetLastError());
+    if (ev) HIPCHK(hipEventRecord(ev->second, stream));
+  }
+  void launch_epmc_reset(const StepParams& P, const EpmcParams& E, const int32_t* ids, int n, const float* draws, const float* prev_orn) {
+    use();
+    const int blocks = (n + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
+    hipLaunchKernelGGL(epmc_reset_kernel, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P, E, ids, n, draws, prev_orn);
+    HIPCHK(hipGetLastError());
+  }
   void launch_step(const StepParams& P) {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
-    std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-    if (timing) {
-      if (ev_used == evs.size()) {
-        hipEvent_t a, b;
-        HIPCHK(hipEventCreate(&a));
-        HIPCHK(hipEventCreate(&b));
-        evs.push_back(std::make_pair(a, b));
-      }
-      ev = &evs[ev_used++];
-      HIPCHK(hipEventRecord(ev->first, stream));
-    }
+    std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin();
     if (blocks <= simds) hipLaunchKernelGGL(pmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
     else                 hipLaunchKernelGGL(pmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
     HIPCHK(hipGetLastError());
@@ -249,3 +291,5 @@ struct HipBackend {
 
 typedef PmcEngine<HipBackend> ENGINE;
 #include "pmc_capi.inc"
+typedef EpmcEngine<HipBackend> EPMC_ENGINE;
+#include "epmc_capi.inc"

@@ -277,7 +277,16 @@ struct Pmc {
   // ---------------------------------------------------------------------------------------------------
   // one physics substep
   // ---------------------------------------------------------------------------------------------------
-  static LL_HD void substep(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env = 0, int sidx = -1) {
+  // what an env other than PMC adds to a substep (EPMC, epmc_step.hpp): the episode's foot friction coefficient and the
+  // push of randomizer/push_randomizer.py:72-77 -- applyExternalForce(linkIndex 0, LINK_FRAME): a force given in the FR hip
+  // link's frame, acting at that link's centre of mass
+  struct SubstepExtra {
+    float mu_foot;
+    bool has_push;
+    float push[3];
+  };
+  static LL_HD void substep(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env = 0, int sidx = -1,
+                            const SubstepExtra* ex = nullptr) {
 #define PMC_TSS(k) do { if (sidx == 5) PMC_TS(k); } while (0)
     const float* legc = P.legc;
     const float* bc = P.basec;
@@ -322,6 +331,12 @@ struct Pmc {
     SV<F> f3 = apply(I3, a3) + crf(v3, apply(I3, v3)) + scale(damping_force<F>(v3, c3, ic3, I3.m, P.link_damping), ln.lane_f(-1.0f));
     SV<F> f2 = apply(I2, a2) + crf(v2, apply(I2, v2)) + scale(damping_force<F>(v2, c2, ic2, I2.m, P.link_damping), ln.lane_f(-1.0f));
     SV<F> f1 = apply(I1, a1) + crf(v1, apply(I1, v1)) + scale(damping_force<F>(v1, c1, ic1, I1.m, P.link_damping), ln.lane_f(-1.0f));
+    if (ex && ex->has_push) {
+      V3l fb = scale(mul(k.R1, mk3<F>(ln.lane_f(ex->push[0]), ln.lane_f(ex->push[1]), ln.lane_f(ex->push[2]))), lm::sel(ln.is_leg(0), one, zero));
+      SV<F> fe;
+      fe.a = cross(c1, fb); fe.l = fb;
+      f1 = f1 + scale(fe, ln.lane_f(-1.0f));
+    }
     SV<F> f23 = f2 + f3;
     SV<F> f123 = f1 + f23;
     F b[3];
@@ -519,7 +534,7 @@ struct Pmc {
       V3l ax = mk3<F>(ln.candc_of(wsub, wbase + CF_AX), ln.candc_of(wsub, wbase + CF_AX + 1), ln.candc_of(wsub, wbase + CF_AX + 2));
       V3l fb = mk3<F>(ln.candc_of(wsub, wbase + CF_FB), ln.candc_of(wsub, wbase + CF_FB + 1), ln.candc_of(wsub, wbase + CF_FB + 2));
       F r = ln.candc_of(wsub, wbase + CF_R), link = ln.candc_of(wsub, wbase + CF_LINK), kind = ln.candc_of(wsub, wbase + CF_KIND);
-      mu = lm::sel(kind > 0.5f, ln.lane_f(P.mu_foot), ln.lane_f(P.mu_link));
+      mu = lm::sel(kind > 0.5f, ln.lane_f(ex ? ex->mu_foot : P.mu_foot), ln.lane_f(P.mu_link));
       B l1 = link < 1.5f, l2 = link < 2.5f, l0 = link < 0.5f;       // link: 0 base, 1 hip, 2 thigh, 3 shank
       V3l ezk = mk3<F>(lm::sel(l0, ez.x, lm::sel(l1, ez1.x, lm::sel(l2, ez2.x, ez3.x))), lm::sel(l0, ez.y, lm::sel(l1, ez1.y, lm::sel(l2, ez2.y, ez3.y))),
                        lm::sel(l0, ez.z, lm::sel(l1, ez1.z, lm::sel(l2, ez2.z, ez3.z))));
@@ -705,8 +720,9 @@ struct Pmc {
     obs_gather_futures(ln, P, in, clip_rows, frame_id, frac);
     return in;
   }
-  static LL_HD void obs_emit(const L& ln, const StepParams& P, float* row, bool fill, const ObsIn& in, const Base& bs, const M3<float>& R,
-                             const F* q, const F* qd, const F* act) {
+  // the part every env of the family shares: prop and action histories with the newest frame (PLE:247-260, :276-290; PGE:251-290)
+  static LL_HD void obs_emit_core(const L& ln, const StepParams& P, float* row, bool fill, const ObsIn& in, const Base& bs, const M3<float>& R,
+                                  const F* q, const F* qd, const F* act) {
     const int Pd = P.prop_dim;
     B lane3 = ln.legf() < 2.5f;
     const long a0 = 3L * Pd;
@@ -726,8 +742,13 @@ struct Pmc {
       if (P.prop_off[4] >= 0) ln.stl_if(lane3, row, fb + P.prop_off[4], 1, ln.pick3(R.m[6], R.m[7], R.m[8])); // R[2,:]
       for (int j = 0; j < 3; j++) ln.stl(row, a0 + 12 * kf + j, 3, act[j]);                                   // raw action (quirk Q3)
     }
+  }
+  static LL_HD void obs_emit(const L& ln, const StepParams& P, float* row, bool fill, const ObsIn& in, const Base& bs, const M3<float>& R,
+                             const F* q, const F* qd, const F* act) {
+    obs_emit_core(ln, P, row, fill, in, bs, R, q, qd, act);
+    B lane3 = ln.legf() < 2.5f;
     // --- future goals (ML:75-86 + PLE:299-317) ---
-    long f0 = a0 + 36;
+    long f0 = 3L * P.prop_dim + 36;
     Q4 qbi = qconj(qnormalize(bs.q));
     LL_UNROLL
     for (int h = 0; h < 4; h++) {

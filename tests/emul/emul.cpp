@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "../../lifelike_agility_and_play_amd/csrc/epmc_engine.hpp"
 #include "../../lifelike_agility_and_play_amd/csrc/pmc_engine.hpp"
 #include "../../lifelike_agility_and_play_amd/csrc/pmc_step.hpp"
 
@@ -58,12 +59,27 @@ struct HostBackend {
       actions[4 * gid + 2] = sigma * m2 * cosf(6.283185307179586f * u4); actions[4 * gid + 3] = sigma * m2 * sinf(6.283185307179586f * u4);
     }
   }
+  void launch_epmc_step(const StepParams& P, const EpmcParams& E) {
+    HostLanes ln(P.candc);
+    for (int env = 0; env < P.n_envs; env++) {
+      fN act[3];
+      for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
+      Epmc<HostLanes>::step_env(ln, P, E, env, act);
+    }
+  }
+  void launch_epmc_reset(const StepParams& P, const EpmcParams& E, const int32_t* ids, int n, const float* draws, const float* prev_orn) {
+    HostLanes ln(P.candc);
+    for (int i = 0; i < n; i++)
+      Epmc<HostLanes>::reset_env(ln, P, E, ids ? ids[i] : i, draws ? draws + (long)i * EPMC_MAX_DRAWS : nullptr, prev_orn ? prev_orn + (long)i * 4 : nullptr);
+  }
   void enable_timing(bool) {}
   void collect_timing(double* avg_ms, int* n) { *avg_ms = 0; *n = 0; }
 };
 
 typedef PmcEngine<HostBackend> ENGINE;
 #include "../../lifelike_agility_and_play_amd/csrc/pmc_capi.inc"
+typedef EpmcEngine<HostBackend> EPMC_ENGINE;
+#include "../../lifelike_agility_and_play_amd/csrc/epmc_capi.inc"
 
 extern "C" {
 // single physics substep on explicit state (staged comparison with the oracle); tgt = PD target joint angles

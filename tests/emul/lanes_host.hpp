@@ -70,6 +70,10 @@ struct HostLanes {
 
   explicit HostLanes(const float* candc) : candc_(candc) {}
   void refresh_consts() const {}
+  bool lane0() const { return true; }
+  int ray_first() const { return 0; }
+  int ray_stride() const { return 1; }
+  void row_sync() const {}
   void prepare_turn_masks() const {}
   I leg() const { iN r; for (int i = 0; i < EW; i++) r.v[i] = i >> 2; return r; }
   I sub() const { iN r; for (int i = 0; i < EW; i++) r.v[i] = i & 3; return r; }

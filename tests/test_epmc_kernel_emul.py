@@ -1,0 +1,33 @@
+"""EPMC kernel source (csrc/epmc_step.hpp) compiled for the host (tests/emul) against the reference goldens and the oracle.
+tests/test_gpu_epmc.py repeats the same checks on the HIP library."""
+import os
+import subprocess
+
+import pytest
+
+import epmc_parity_common as ec
+
+EMUL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emul')
+EMUL_LIB = os.path.join(EMUL_DIR, '_build', 'libllenv_emul.so')
+
+
+@pytest.fixture(scope='module')
+def emul_lib():
+    subprocess.check_call(['make', '-C', EMUL_DIR, '-s'])
+    return EMUL_LIB
+
+
+def test_terrain_and_reset_against_reference_goldens(emul_lib):
+    ec.check_terrain_and_reset_against_goldens(emul_lib)
+
+
+def test_scripted_episodes_against_reference_goldens(emul_lib):
+    ec.check_scripted_episodes_against_goldens(emul_lib)
+
+
+def test_ray_casting_against_oracle(emul_lib):
+    assert ec.check_ray_casting_against_oracle(emul_lib) > 100
+
+
+def test_free_running_invariants(emul_lib):
+    assert ec.check_free_running_invariants(emul_lib, n_envs=16, n_steps=70) > 0
