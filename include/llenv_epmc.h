@@ -47,7 +47,7 @@ typedef struct ll_epmc_config {
   int32_t solver_iterations;
   double friction_range[2];     /* PGE:92, :209 foot lateral friction ~ U(range) per episode */
   /* PR:8-54.  The three counts are (-start_time) // dt, interval_time // dt, duration_time // dt evaluated by the HOST with
-   * Python's float floor division (e.g. 0.2 // 0.002 == 99.0): the kernel must not re-derive them */
+   * Python's float floor division (e.g. 1.0 // 0.002 == 499.0, not 500): the kernel must not re-derive them */
   int32_t push_enabled;
   int32_t push_count0, push_interval_step, push_duration_step;
   double horizontal_force[2], vertical_force[2], push_strength_ratio;

@@ -18,6 +18,7 @@
 #define EPMC_MAX_STATICS 104
 #define EPMC_MAX_BOXES 40
 #define EPMC_MAX_DRAWS 64
+#define EPMC_BOX_WORDS 8
 #define EPMC_EP_STRIDE 40
 
 // per-env scalar row (EpmcParams::ep)
@@ -56,7 +57,7 @@ struct EpmcParams {
   float* ep;               // [n_envs][EPMC_EP_STRIDE]
   float* info;             // [n_envs][6]
   float* statics;          // [n_envs][EPMC_MAX_STATICS][8]
-  float* boxes;            // [n_envs][EPMC_MAX_BOXES][6]  centre, half extents of what the rays (and later the contacts) see
+  float* boxes;            // [n_envs][EPMC_MAX_BOXES][8]  x0 x1 y0 y1 z0 z1 - - of what the rays (and later the contacts) see
   float* push_trace;       // [n_envs][n_sub][4]
   float* ray_trace;        // optional [n_envs][778][8]: from 3, to 3, hit, fraction
   // parity hooks (null in production)
@@ -113,9 +114,9 @@ struct Epmc {
     LL_HD void box(float x, float y, float z, float l, float w, float h, float flag) {
       row(0.0f, x, y, z, l * 0.5f, w * 0.5f, h * 0.5f);
       if (l > 0.0f && n_boxes < EPMC_MAX_BOXES) {
-        if (store) {
-          float* b = boxes + n_boxes * 6;
-          b[0] = x; b[1] = y; b[2] = z; b[3] = l * 0.5f; b[4] = w * 0.5f; b[5] = h * 0.5f;
+        if (store) {                                                            // record: x0 x1 y0 y1 | z0 z1 - -
+          float* b = boxes + n_boxes * EPMC_BOX_WORDS;
+          b[0] = x - l * 0.5f; b[1] = x + l * 0.5f; b[2] = y - w * 0.5f; b[3] = y + w * 0.5f; b[4] = z - h * 0.5f; b[5] = z + h * 0.5f; b[6] = 0.0f; b[7] = 0.0f;
         }
         n_boxes++;
       }
@@ -179,23 +180,30 @@ struct Epmc {
   // ------------------------------------------------------------------------------------------------------------
   // rays (PGE:25-52, :381-447).  cast(): this build's spec of rayTestBatch(mask 6): plane z = 0 and the boxes.
   // ------------------------------------------------------------------------------------------------------------
-  static LL_HD float cast(const float* f, const float* t, const float* boxes, int n_boxes, bool* hit_out) {
+  // `cand` = bit b set for every box the segment may meet (a conservative pre-selection made once per env and ray family)
+  static LL_HD float cast(const float* f, const float* t, const float* boxes, unsigned long long cand, bool* hit_out) {
     const float d[3] = {t[0] - f[0], t[1] - f[1], t[2] - f[2]};
+    float inv[3];
+    for (int a = 0; a < 3; a++) inv[a] = d[a] != 0.0f ? 1.0f / d[a] : 0.0f;
     float best = 3.0e38f;
     if (d[2] < 0.0f) {
-      float tz = -f[2] / d[2];
+      float tz = -f[2] * inv[2];
       if (tz >= 0.0f && tz <= 1.0f) best = tz;
     }
-    for (int b = 0; b < n_boxes; b++) {
-      const float* bx = boxes + b * 6;
+    // a segment can only meet a box whose x and y extents overlap its own: most boxes are thin bars far from the ray
+    const float sx0 = fminf(f[0], t[0]), sx1 = fmaxf(f[0], t[0]), sy0 = fminf(f[1], t[1]), sy1 = fmaxf(f[1], t[1]);
+    while (cand) {
+      const int b = __builtin_ctzll(cand);
+      cand &= cand - 1;
+      const float* bx = boxes + b * EPMC_BOX_WORDS;                           // one 16-byte read decides most boxes
+      if (bx[1] < sx0 || bx[0] > sx1 || bx[3] < sy0 || bx[2] > sy1) continue;
       float te = -3.0e38f, tl = 3.0e38f;
       for (int a = 0; a < 3; a++) {
-        const float lo = bx[a] - bx[3 + a], hi = bx[a] + bx[3 + a];
+        const float lo = bx[2 * a], hi = bx[2 * a + 1];
         if (d[a] == 0.0f) {
           if (!(f[a] >= lo && f[a] <= hi)) { te = 3.0e38f; tl = -3.0e38f; }
         } else {
-          const float inv = 1.0f / d[a];
-          float t1 = (lo - f[a]) * inv, t2 = (hi - f[a]) * inv;
+          float t1 = (lo - f[a]) * inv[a], t2 = (hi - f[a]) * inv[a];
           te = fmaxf(te, fminf(t1, t2));
           tl = fminf(tl, fmaxf(t1, t2));
         }
@@ -234,6 +242,14 @@ struct Epmc {
   // the three percep arrays straight into the obs row; lanes share the rays out
   static LL_HD void observe_rays(const L& ln, const StepParams& P, const EpmcParams& E, int env, const float* pos, const M3<float>& R, float yaw,
                                  const float* noise, const float* boxes, int n_boxes, float* percep) {
+    // boxes within reach of the rays around the base: 3.6 m covers the height grid (1.35 m) and the front rays (3.4 m), 20.1 m
+    // the horizontal fan.  Evaluated once per env; a ray then visits only the boxes of its family's set.
+    unsigned long long near = 0ull, far = 0ull;
+    for (int b = 0; b < n_boxes; b++) {
+      const float* bx = boxes + b * EPMC_BOX_WORDS;
+      if (bx[1] >= pos[0] - 3.6f && bx[0] <= pos[0] + 3.6f && bx[3] >= pos[1] - 3.6f && bx[2] <= pos[1] + 3.6f) near |= 1ull << b;
+      if (bx[1] >= pos[0] - 20.1f && bx[0] <= pos[0] + 20.1f && bx[3] >= pos[1] - 20.1f && bx[2] <= pos[1] + 20.1f) far |= 1ull << b;
+    }
     for (int r = ln.ray_first(); r < EPMC_N_RAYS; r += ln.ray_stride()) {
       float f[3], t[3];
       ray_ends(r, pos, R, yaw, f, t);
@@ -243,7 +259,7 @@ struct Epmc {
         hit = E.scr_ray_hit[(long)env * EPMC_N_RAYS + r] != 0;
         frac = E.scr_ray_frac[(long)env * EPMC_N_RAYS + r];
       } else {
-        frac = cast(f, t, boxes, n_boxes, &hit);
+        frac = cast(f, t, boxes, (r >= EPMC_N_HEIGHT && r < EPMC_N_HEIGHT + EPMC_N_HORIZ) ? far : near, &hit);
       }
       if (E.ray_trace) {
         float* tr = E.ray_trace + ((long)env * EPMC_N_RAYS + r) * 8;
@@ -280,7 +296,8 @@ struct Epmc {
     if (E.noise_on[2]) yaw += ep[EP_NOISE + 2];                                  // PGE:392-393
     const long a0 = 3L * P.prop_dim + 36;
     const int n_boxes = (int)ep[EP_N_BOXES];
-    observe_rays(ln, P, E, env, pos, R, yaw, ep + EP_NOISE, E.boxes + (long)env * EPMC_MAX_BOXES * 6, n_boxes, row + a0);
+    const float* boxes = ln.stage_row(E.boxes + (long)env * EPMC_MAX_BOXES * EPMC_BOX_WORDS, n_boxes * EPMC_BOX_WORDS);   // LDS on the GPU
+    observe_rays(ln, P, E, env, pos, R, yaw, ep + EP_NOISE, boxes, n_boxes, row + a0);
     // target_info (PGE:400-403): the (x, y) of R^-1 (target - position), normalised, then the commanded speed
     const float dx = target[0] - pos[0], dy = target[1] - pos[1], dz = target[2] - pos[2];
     const float lx = R.m[0] * dx + R.m[3] * dy + R.m[6] * dz, ly = R.m[1] * dx + R.m[4] * dy + R.m[7] * dz;
@@ -304,7 +321,7 @@ struct Epmc {
     }
     Terrain T;
     T.rows = E.statics + (long)env * EPMC_MAX_STATICS * 8;
-    T.boxes = E.boxes + (long)env * EPMC_MAX_BOXES * 6;
+    T.boxes = E.boxes + (long)env * EPMC_MAX_BOXES * EPMC_BOX_WORDS;
     T.n_rows = T.n_boxes = 0; T.store = ln.lane0(); T.gap = 0.0f; T.aux = E.aux_radius;
     gen_terrain(T, d, E, ep + EP_TARGET);                                         // PGE:216-221
     ln.row_sync();                                                                // the rays of this step read the new boxes

@@ -61,6 +61,7 @@ LL_HD bool eq_(int a, int b) { return a == b; }
 }  // namespace lm
 
 #define PMC_ROW 16   // lanes per environment
+#define PMC_ROW_SCRATCH 320   // floats of LDS scratch per env row (EPMC: 40 boxes x 8)
 
 #if defined(__HIPCC__)
 // DPP helpers.  ctrl encodings (gfx9 DPP16): quad_perm 0x00-0xFF, row_shr:n 0x110+n, row_ror:n 0x120+n, row_newbcast:n 0x150+n.
@@ -77,6 +78,7 @@ struct GpuLanes {
   float* lds_;
   mutable int cbase_;   // LDS word of the per-leg constant table (+ leg)
   mutable int tbase_;   // LDS word of the candidate table (+ lane16)
+  int row_scratch_;     // LDS word where the per-row scratch areas start
   mutable unsigned long long tm_[16];
 
   LL_D GpuLanes(float* lds) : leg_((threadIdx.x >> 2) & 3), sub_(threadIdx.x & 3), lane16_(threadIdx.x & 15), lds_(lds), cbase_(0), tbase_(0) {}
@@ -90,6 +92,7 @@ struct GpuLanes {
     for (int i = lane; i < n2; i += kWave) lds_[n1 + i] = candc[i];
     cbase_ = leg_;
     tbase_ = n1 + lane16_;
+    row_scratch_ = n1 + n2 + 4 * 12;      // after the action stash of the step kernel
     __builtin_amdgcn_s_waitcnt(0);          // single-wave workgroup: program order + waitcnt is enough
   }
   // make the table offsets opaque again so the compiler re-reads constants per substep instead of hoisting them all
@@ -106,6 +109,15 @@ struct GpuLanes {
   LL_D bool lane0() const { return lane16_ == 0; }
   LL_D int ray_first() const { return lane16_; }
   LL_D int ray_stride() const { return PMC_ROW; }
+  // copy n floats (a multiple of 4, 16-byte aligned) of per-env data into the row's LDS scratch and return where they are: the
+  // row's 16 lanes then read them at LDS latency instead of issuing a global load each
+  LL_D const float* stage_row(const float* g, int n) const {
+    float* dst = lds_ + row_scratch_ + (threadIdx.x >> 4) * PMC_ROW_SCRATCH;
+    for (int i = lane16_ * 4; i < n; i += PMC_ROW * 4) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(g + i);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    return dst;
+  }
   LL_D void row_sync() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }   // lane 0's stores visible to the row
 
   // ---- reductions / broadcasts ------------------------------------------------------------------------------

@@ -226,6 +226,7 @@ struct HipBackend {
   void sync() { use(); HIPCHK(hipStreamSynchronize(stream)); }
 
   static size_t lds_bytes() { return ((size_t)LC_COUNT * 4 + (size_t)CAND_TABLE_WORDS * PMC_ROW + PMC_ENVS_PER_WAVE * 12) * sizeof(float); }
+  static size_t lds_bytes_epmc() { return lds_bytes() + (size_t)PMC_ENVS_PER_WAVE * PMC_ROW_SCRATCH * sizeof(float); }
   std::pair<hipEvent_t, hipEvent_t>* timing_begin() {
     if (!timing) return nullptr;
     if (ev_used == evs.size()) {
@@ -242,15 +243,15 @@ struct HipBackend {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin();
-    if (blocks <= simds) hipLaunchKernelGGL(epmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P, E);
-    else                 hipLaunchKernelGGL(epmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P, E);
+    if (blocks <= simds) hipLaunchKernelGGL(epmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, E);
+    else                 hipLaunchKernelGGL(epmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, E);
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->second, stream));
   }
   void launch_epmc_reset(const StepParams& P, const EpmcParams& E, const int32_t* ids, int n, const float* draws, const float* prev_orn) {
     use();
     const int blocks = (n + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
-    hipLaunchKernelGGL(epmc_reset_kernel, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P, E, ids, n, draws, prev_orn);
+    hipLaunchKernelGGL(epmc_reset_kernel, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, E, ids, n, draws, prev_orn);
     HIPCHK(hipGetLastError());
   }
   void launch_step(const StepParams& P) {

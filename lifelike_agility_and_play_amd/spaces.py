@@ -5,7 +5,7 @@ from collections import OrderedDict
 import numpy as np
 
 try:                                       # pragma: no cover - gym is absent in the build container
-    from gym.spaces import Box, Dict, Tuple  # noqa: F401
+    from gym.spaces import Box, Dict, Discrete, Tuple  # noqa: F401
     HAVE_GYM = True
 except Exception:                          # noqa: BLE001
     HAVE_GYM = False
@@ -16,6 +16,13 @@ except Exception:                          # noqa: BLE001
 
         def __repr__(self):
             return 'Box(%r)' % (self.shape,)
+
+    class Discrete(object):
+        def __init__(self, n):
+            self.n, self.shape, self.dtype = int(n), (), np.dtype(np.int64)
+
+        def __repr__(self):
+            return 'Discrete(%d)' % self.n
 
     class Dict(object):
         def __init__(self, spaces):

@@ -74,6 +74,7 @@ struct HostLanes {
   int ray_first() const { return 0; }
   int ray_stride() const { return 1; }
   void row_sync() const {}
+  const float* stage_row(const float* g, int) const { return g; }
   void prepare_turn_masks() const {}
   I leg() const { iN r; for (int i = 0; i < EW; i++) r.v[i] = i >> 2; return r; }
   I sub() const { iN r; for (int i = 0; i < EW; i++) r.v[i] = i & 3; return r; }

@@ -21,3 +21,8 @@ def test_ray_casting_against_oracle():
 def test_free_running_invariants():
     assert ec.check_free_running_invariants(None, n_envs=300, n_steps=80) > 0
     assert ec.check_free_running_invariants(None, n_envs=4200, n_steps=12, element=3) >= 0
+
+
+def test_env_api_contract_gpu():
+    from test_epmc_env_api import check_single_env_contract
+    check_single_env_contract(None)
