@@ -9,9 +9,9 @@
  * plain pointers and sizes, int return codes (LL_OK / LL_E*), ll_last_error() for the text; one engine per GPU, calls on
  * an engine are not re-entrant.  The robot model blob is the one ll_create takes (llenv_model.h).
  *
- * Round-1 scope: the whole env logic (terrain generation, 778 rays against plane + boxes, observation, the joystick and
- * average-speed rewards, termination, push schedule, per-episode friction) and the articulated-body physics of llenv.h
- * with the push force; the terrain boxes are seen by the rays but are NOT yet physical obstacles for the robot.
+ * Scope: the whole env logic (terrain generation, 778 rays against plane + boxes, observation, the joystick and average-speed
+ * rewards, termination, push schedule, per-episode friction) and the articulated-body physics of llenv.h with the push force
+ * and the terrain boxes / edge cylinders as obstacles.
  */
 #ifndef LLENV_EPMC_H
 #define LLENV_EPMC_H

@@ -56,6 +56,7 @@ struct EpmcEngine {
     E.spd_lo = (float)c.target_spd_range[0]; E.spd_hi = (float)c.target_spd_range[1];
     E.aux_radius = (float)c.auxiliary_radius;
     E.hole_gap_lo = (float)c.hole_gap_height[0]; E.hole_gap_hi = (float)c.hole_gap_height[1];
+    E.box_friction = 0.5f; E.terrain_contacts = 1;
     for (int i = 0; i < 4; i++) { E.noise_on[i] = c.noise_enabled[i] ? 1 : 0; E.noise_lo[i] = (float)c.noise_range[i][0]; E.noise_hi[i] = (float)c.noise_range[i][1]; }
     float init[37];
     for (int i = 0; i < 37; i++) init[i] = (float)init37[i];

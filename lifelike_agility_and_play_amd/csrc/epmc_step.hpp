@@ -19,6 +19,7 @@
 #define EPMC_MAX_BOXES 40
 #define EPMC_MAX_DRAWS 64
 #define EPMC_BOX_WORDS 8
+#define EPMC_MAX_NEAR 8       // boxes within reach of the robot's contact candidates during one control step
 #define EPMC_EP_STRIDE 40
 
 // per-env scalar row (EpmcParams::ep)
@@ -49,7 +50,8 @@ struct EpmcParams {
   float friction_lo, friction_hi, hforce_lo, hforce_hi;
   float vforce_lo, vforce_hi, push_ratio, plane_friction;
   float spd_lo, spd_hi, aux_radius, hole_gap_lo;      // aux_radius < 0: no auxiliary cylinders
-  float hole_gap_hi, pad0, pad1, pad2;
+  float hole_gap_hi, box_friction;                    // lateralFriction of a body made by createMultiBody: Bullet's default 0.5
+  int32_t terrain_contacts, pad2;                     // 0: the boxes are seen by the rays only
   int32_t noise_on[4];
   float noise_lo[4], noise_hi[4];
   const float* init_state;  // [37] LeggedRobot.get_init_states_info(), LR:116-117
@@ -114,9 +116,10 @@ struct Epmc {
     LL_HD void box(float x, float y, float z, float l, float w, float h, float flag) {
       row(0.0f, x, y, z, l * 0.5f, w * 0.5f, h * 0.5f);
       if (l > 0.0f && n_boxes < EPMC_MAX_BOXES) {
-        if (store) {                                                            // record: x0 x1 y0 y1 | z0 z1 - -
+        if (store) {                                                            // record: x0 x1 y0 y1 | z0 z1 rod r
           float* b = boxes + n_boxes * EPMC_BOX_WORDS;
-          b[0] = x - l * 0.5f; b[1] = x + l * 0.5f; b[2] = y - w * 0.5f; b[3] = y + w * 0.5f; b[4] = z - h * 0.5f; b[5] = z + h * 0.5f; b[6] = 0.0f; b[7] = 0.0f;
+          b[0] = x - l * 0.5f; b[1] = x + l * 0.5f; b[2] = y - w * 0.5f; b[3] = y + w * 0.5f; b[4] = z - h * 0.5f; b[5] = z + h * 0.5f;
+          b[6] = (flag != 0.0f && aux >= 0.0f) ? flag : 0.0f; b[7] = aux >= 0.0f ? aux : 0.0f;      // edge rods, for the contacts
         }
         n_boxes++;
       }
@@ -425,6 +428,26 @@ struct Epmc {
 
     typename K::SubstepExtra ex;
     ex.mu_foot = ep[EP_FRICTION] * E.plane_friction;
+    // terrain within reach of the robot's contact candidates during this control step: boxes whose footprint, grown by 0.9 m
+    // (leg reach 0.45 m + the distance covered in 20 ms + margin), contains the base; kept in the row's LDS scratch
+    {
+      float* near = ln.row_scratch();
+      const float* allb = E.boxes + (long)env * EPMC_MAX_BOXES * EPMC_BOX_WORDS;
+      const int nb = (int)ep[EP_N_BOXES];
+      int n_near = 0;
+      for (int b = 0; b < nb; b++) {
+        const float* bx = allb + b * EPMC_BOX_WORDS;
+        if (bs.p.x >= bx[0] - 0.9f && bs.p.x <= bx[1] + 0.9f && bs.p.y >= bx[2] - 0.9f && bs.p.y <= bx[3] + 0.9f && bs.p.z <= bx[5] + 0.9f) {
+          if (n_near < EPMC_MAX_NEAR && ln.lane0())
+            for (int i = 0; i < EPMC_BOX_WORDS; i++) near[n_near * EPMC_BOX_WORDS + i] = bx[i];
+          n_near++;
+        }
+      }
+      ln.row_sync();
+      ex.shapes = near;
+      ex.n_shapes = (E.terrain_contacts && !E.scr_state) ? (n_near < EPMC_MAX_NEAR ? n_near : EPMC_MAX_NEAR) : 0;
+      ex.box_mu_scale = E.box_friction / E.plane_friction;
+    }
     float* ptrace = E.push_trace + (long)env * P.n_sub * 4;
     for (int s = 0; s < P.n_sub; s++) {                                          // PGE:326-331
       ex.has_push = false;
@@ -443,7 +466,7 @@ struct Epmc {
         ptrace[s * 4 + 0] = ex.has_push ? 1.0f : 0.0f;
         for (int i = 0; i < 3; i++) ptrace[s * 4 + 1 + i] = ex.has_push ? ex.push[i] : 0.0f;
       }
-      if (!E.scr_state) K::substep(ln, P, bs, q, qd, tgt, env, s, &ex);         // PGE:328-330
+      if (!E.scr_state) K::template substep_impl<true>(ln, P, bs, q, qd, tgt, env, s, &ex);   // PGE:328-330
     }
     if (E.scr_state) {   // parity hook: the caller plays PyBullet
       const float* ss = E.scr_state + (long)env * 37;

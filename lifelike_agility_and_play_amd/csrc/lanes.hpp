@@ -111,8 +111,9 @@ struct GpuLanes {
   LL_D int ray_stride() const { return PMC_ROW; }
   // copy n floats (a multiple of 4, 16-byte aligned) of per-env data into the row's LDS scratch and return where they are: the
   // row's 16 lanes then read them at LDS latency instead of issuing a global load each
+  LL_D float* row_scratch() const { return lds_ + row_scratch_ + (threadIdx.x >> 4) * PMC_ROW_SCRATCH; }
   LL_D const float* stage_row(const float* g, int n) const {
-    float* dst = lds_ + row_scratch_ + (threadIdx.x >> 4) * PMC_ROW_SCRATCH;
+    float* dst = row_scratch();
     for (int i = lane16_ * 4; i < n; i += PMC_ROW * 4) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(g + i);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);

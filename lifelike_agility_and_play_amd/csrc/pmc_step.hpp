@@ -284,9 +284,64 @@ struct Pmc {
     float mu_foot;
     bool has_push;
     float push[3];
+    // terrain within reach of the robot (TERRAIN builds only): n_shapes records  x0 x1 y0 y1 | z0 z1 rod r  of axis-aligned
+    // boxes; rod = +1 / -1 / 0: thin cylinders of radius r along y on the two top / bottom x-edges (BSE:43-104), or none
+    const float* shapes;
+    int n_shapes;
+    float box_mu_scale;   // friction of a box relative to the plane's (default lateralFriction 0.5 vs plane.urdf 0.9)
   };
+  // Signed distance of point E to record s (box united with its edge rods) and the outward normal there.  Inside a box the
+  // face of least penetration gives both; near an edge outside, max(q) under-estimates the distance, which only makes a
+  // speculative contact start a little early.
+  template <class T>
+  static LL_HD void shape_sdf(const L& ln, const float* s, const V3<T>& E, T& d, V3<T>& n, T& is_box) {
+    const T zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f), neg = ln.lane_f(-1.0f);
+    T ax0 = ln.lane_f(s[0]) - E.x, ax1 = E.x - ln.lane_f(s[1]);
+    T ay0 = ln.lane_f(s[2]) - E.y, ay1 = E.y - ln.lane_f(s[3]);
+    T az0 = ln.lane_f(s[4]) - E.z, az1 = E.z - ln.lane_f(s[5]);
+    T qx = lm::max_(ax0, ax1), qy = lm::max_(ay0, ay1), qz = lm::max_(az0, az1);
+    T sx = lm::sel(ax1 > ax0, one, neg), sy = lm::sel(ay1 > ay0, one, neg), sz = lm::sel(az1 > az0, one, neg);
+    d = qx; n = mk3<T>(sx, zero, zero);
+    B by = qy > d;
+    d = lm::sel(by, qy, d); n = mk3<T>(lm::sel(by, zero, n.x), lm::sel(by, sy, zero), zero);
+    B bz = qz > d;
+    d = lm::sel(bz, qz, d); n = mk3<T>(lm::sel(bz, zero, n.x), lm::sel(bz, zero, n.y), lm::sel(bz, sz, zero));
+    is_box = one;
+    if (s[6] != 0.0f) {
+      const float ze = s[6] > 0.0f ? s[5] : s[4], rr = s[7];
+      B iny = lm::and_(qy <= 0.0f, one > zero);
+      for (int e = 0; e < 2; e++) {
+        T dx = E.x - ln.lane_f(s[e]), dz = E.z - ln.lane_f(ze);
+        T len = lm::sqrt_(dx * dx + dz * dz);
+        T dr = len - rr;
+        B better = lm::and_(iny, lm::and_(dr < d, len > 1e-6f));
+        T il = one / lm::max_(len, ln.lane_f(1e-6f));
+        d = lm::sel(better, dr, d);
+        n = mk3<T>(lm::sel(better, dx * il, n.x), lm::sel(better, zero, n.y), lm::sel(better, dz * il, n.z));
+        is_box = lm::sel(better, zero, is_box);
+      }
+    }
+  }
+  // Where a candidate is tested against the terrain: its lowest point (the point the plane test uses), in world coordinates;
+  // for a sphere the test is made at the centre with the radius subtracted (rs), so that a side wall is met sideways.
+  static LL_HD void cand_eval_point(const L& ln, const Base& bs, const M3<float>& R, const M3<F>& lR, const V3l& lp, const V3l& ez_link, const V3l& A,
+                                    const V3l& ax, const F& r, const F& az, const F& len, V3l& Ew, F& rs) {
+    const F zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f);
+    F il = lm::sel(len < 1e-6f, zero, one / lm::max_(len, ln.lane_f(1e-12f)));
+    V3l dir = mk3<F>((ez_link.x - az * ax.x) * il, (ez_link.y - az * ax.y) * il, (ez_link.z - az * ax.z) * il);
+    V3l x = A - scale(dir, r);
+    V3l Pb = lp + mul(lR, x);
+    V3l Pw = mul(R, Pb);
+    rs = lm::sel(dot(ax, ax) < 0.5f, r, zero);
+    Ew = mk3<F>(Pw.x + bs.p.x, Pw.y + bs.p.y, Pw.z + bs.p.z + rs);
+  }
   static LL_HD void substep(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env = 0, int sidx = -1,
                             const SubstepExtra* ex = nullptr) {
+    substep_impl<false>(ln, P, bs, q, qd, tgt, env, sidx, ex);
+  }
+  // TERRAIN: contact candidates are also tested against ex->shapes, and a contact's normal is that of the shape it touches
+  template <bool TERRAIN>
+  static LL_HD void substep_impl(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env, int sidx, const SubstepExtra* ex) {
 #define PMC_TSS(k) do { if (sidx == 5) PMC_TS(k); } while (0)
     const float* legc = P.legc;
     const float* bc = P.basec;
@@ -447,6 +502,23 @@ struct Pmc {
     gez[2] = mk3<F>(lm::sel(sub_0, ez3.x, ez.x), lm::sel(sub_0, ez3.y, ez.y), lm::sel(sub_0, ez3.z, ez.z));
     gz0[2] = lm::sel(sub_0, z3, z0b);
     const F far_ = ln.lane_f(1.0e30f);
+    // TERRAIN: link frames of the three candidate groups of this sub-lane (A: [3,3,2,2], B: [2,2,2,1], C: [3,0,0,0]), in F0
+    const int n_shapes = (TERRAIN && ex) ? ex->n_shapes : 0;
+    const bool terr = TERRAIN && L::any(ln.lane_f(n_shapes > 0 ? 1.0f : 0.0f) > 0.5f);
+    M3<F> tgR[3];
+    V3l tgp[3];
+    if (TERRAIN) {
+      if (terr) {
+        for (int i = 0; i < 9; i++) {
+          tgR[0].m[i] = lm::sel(sub_lt2, k.R3.m[i], k.R2.m[i]);
+          tgR[1].m[i] = lm::sel(sub_lt3, k.R2.m[i], k.R1.m[i]);
+          tgR[2].m[i] = lm::sel(sub_0, k.R3.m[i], ln.lane_f((i % 4 == 0) ? 1.0f : 0.0f));
+        }
+        tgp[0] = mk3<F>(lm::sel(sub_lt2, k.p3.x, k.p2.x), lm::sel(sub_lt2, k.p3.y, k.p2.y), lm::sel(sub_lt2, k.p3.z, k.p2.z));
+        tgp[1] = mk3<F>(lm::sel(sub_lt3, k.p2.x, k.p1.x), lm::sel(sub_lt3, k.p2.y, k.p1.y), lm::sel(sub_lt3, k.p2.z, k.p1.z));
+        tgp[2] = mk3<F>(lm::sel(sub_0, k.p3.x, zero), lm::sel(sub_0, k.p3.y, zero), lm::sel(sub_0, k.p3.z, zero));
+      }
+    }
     F depth[7];
     for (int jj = 0; jj < 7; jj++) {
       const int g = jj < 4 ? 0 : (jj < 6 ? 1 : 2);
@@ -456,6 +528,19 @@ struct Pmc {
       F az = dot(gez[g], ax);
       F len = lm::sqrt_(lm::max_(one - az * az, zero));      // 1 for spheres and vertices (ax = 0)
       F dpt = gz0[g] + dot(gez[g], A) - r * len;
+      if (TERRAIN) {
+        if (terr) {
+          V3l Ew;
+          F rs;
+          cand_eval_point(ln, bs, R, tgR[g], tgp[g], gez[g], A, ax, r, az, len, Ew, rs);
+          for (int si = 0; si < n_shapes; si++) {
+            F ds, isb;
+            V3l ns;
+            shape_sdf<F>(ln, ex->shapes + si * 8, Ew, ds, ns, isb);
+            dpt = lm::min_(dpt, ds - rs);
+          }
+        }
+      }
       depth[jj] = lm::sel(lm::and_(dpt < P.margin_dist, link > -0.5f), dpt, far_);
     }
     // the leg keeps its 4 deepest candidates, slot s = s-th deepest: four rounds of (local min, quad min, claim)
@@ -549,6 +634,42 @@ struct Pmc {
       V3l x1 = k.p1 + mul(k.R1, x), x2 = k.p2 + mul(k.R2, x), x3 = k.p3 + mul(k.R3, x);
       V3l Pb = mk3<F>(lm::sel(l0, x.x, lm::sel(l1, x1.x, lm::sel(l2, x2.x, x3.x))), lm::sel(l0, x.y, lm::sel(l1, x1.y, lm::sel(l2, x2.y, x3.y))),
                       lm::sel(l0, x.z, lm::sel(l1, x1.z, lm::sel(l2, x2.z, x3.z))));
+      // TERRAIN: which surface the kept candidate touches -- the plane (normal +z) or the nearest shape -- decides the row directions
+      V3l un = cvt3<F>(ezb), ut1 = mk3<F>(ln.lane_f(-R.m[3]), ln.lane_f(-R.m[4]), ln.lane_f(-R.m[5])), ut2 = mk3<F>(ln.lane_f(R.m[0]), ln.lane_f(R.m[1]), ln.lane_f(R.m[2]));
+      if (TERRAIN) {
+        if (terr) {
+          M3<F> lR;
+          V3l lp;
+          for (int i = 0; i < 9; i++) lR.m[i] = lm::sel(l0, ln.lane_f((i % 4 == 0) ? 1.0f : 0.0f), lm::sel(l1, k.R1.m[i], lm::sel(l2, k.R2.m[i], k.R3.m[i])));
+          lp = mk3<F>(lm::sel(l0, zero, lm::sel(l1, k.p1.x, lm::sel(l2, k.p2.x, k.p3.x))), lm::sel(l0, zero, lm::sel(l1, k.p1.y, lm::sel(l2, k.p2.y, k.p3.y))),
+                      lm::sel(l0, zero, lm::sel(l1, k.p1.z, lm::sel(l2, k.p2.z, k.p3.z))));
+          V3l Ew;
+          F rs;
+          cand_eval_point(ln, bs, R, lR, lp, ezk, A, ax, r, az, len, Ew, rs);
+          F best = Ew.z - rs;                                  // the plane
+          V3l nw = mk3<F>(zero, zero, one);
+          F scale_mu = one;
+          for (int si = 0; si < n_shapes; si++) {
+            F ds, isb;
+            V3l ns;
+            shape_sdf<F>(ln, ex->shapes + si * 8, Ew, ds, ns, isb);
+            B win = (ds - rs) < best;
+            best = lm::sel(win, ds - rs, best);
+            nw = mk3<F>(lm::sel(win, ns.x, nw.x), lm::sel(win, ns.y, nw.y), lm::sel(win, ns.z, nw.z));
+            scale_mu = lm::sel(win, lm::sel(isb > 0.5f, ln.lane_f(ex->box_mu_scale), one), scale_mu);
+          }
+          mu = mu * scale_mu;
+          // btPlaneSpace1(n): two tangents; for n = +z they are -y and +x, the directions of the flat-ground rows
+          B steep = lm::abs_(nw.z) > 0.7071067811865475f;
+          F a_s = nw.y * nw.y + nw.z * nw.z, a_f = nw.x * nw.x + nw.y * nw.y;
+          F ks = lm::rsqrt_(lm::max_(a_s, ln.lane_f(1e-12f))), kf = lm::rsqrt_(lm::max_(a_f, ln.lane_f(1e-12f)));
+          V3l p_s = mk3<F>(zero, zero - nw.z * ks, nw.y * ks), q_s = mk3<F>(a_s * ks, zero - nw.x * (nw.y * ks), nw.x * (zero - nw.z * ks));
+          V3l p_f = mk3<F>(zero - nw.y * kf, nw.x * kf, zero), q_f = mk3<F>(zero - nw.z * (nw.x * kf), nw.z * (zero - nw.y * kf), a_f * kf);
+          V3l t1w = mk3<F>(lm::sel(steep, p_s.x, p_f.x), lm::sel(steep, p_s.y, p_f.y), lm::sel(steep, p_s.z, p_f.z));
+          V3l t2w = mk3<F>(lm::sel(steep, q_s.x, q_f.x), lm::sel(steep, q_s.y, q_f.y), lm::sel(steep, q_s.z, q_f.z));
+          un = mulT(R, nw); ut1 = mulT(R, t1w); ut2 = mulT(R, t2w);
+        }
+      }
       F depth_c = my_depth;
       F bias = lm::sel(depth_c > 0.0f, depth_c * inv_dt, depth_c * (P.erp * inv_dt));
       // joint j moves the point iff the point's link is at or below joint j: link >= j+1
@@ -559,8 +680,7 @@ struct Pmc {
       // rows n = +z, t1 = -y, t2 = +x (world), expressed in F0
       for (int r_ = 0; r_ < 3; r_++) {
         Row& rw = (r_ == 0) ? rn : (r_ == 1 ? r1 : r2);
-        V3u ub = (r_ == 0) ? ezb : (r_ == 1 ? mk3<float>(-R.m[3], -R.m[4], -R.m[5]) : mk3<float>(R.m[0], R.m[1], R.m[2]));
-        V3l uu = cvt3<F>(ub);
+        V3l uu = (r_ == 0) ? un : (r_ == 1 ? ut1 : ut2);
         rw.jt[0] = dot(uu, d1); rw.jt[1] = dot(uu, d2); rw.jt[2] = dot(uu, d3);
         V3l pxu = cross(Pb, uu);
         // free row velocity J_b xi + J_l qd*

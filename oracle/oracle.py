@@ -215,6 +215,16 @@ class OracleBatch(object):
         rc = lib().orc_substep(self.h, _p(s), _p(f64(tau)), C.byref(nc), _p(lam), _p(acc)); assert rc == 0
         return s, nc.value, lam, acc
 
+    def substep_terrain(self, state, tau, mu_foot, shapes, box_mu_scale, push=None):
+        """One substep with EPMC terrain (records x0 x1 y0 y1 z0 z1 rod r) and the push on the FR hip link (epmc parity tests)."""
+        s = f64(state).copy(); nc = C.c_int32(); lam = np.zeros(12 + 3 * 24)
+        sh = f64(np.asarray(shapes).reshape(-1, 8)) if len(shapes) else np.zeros((0, 8))
+        pu = None if push is None else f64(push)
+        rc = lib().orc_substep_terrain(self.h, _p(s), _p(f64(tau)), C.c_double(mu_foot), C.c_int(len(sh)), _p(sh) if len(sh) else None, C.c_double(box_mu_scale),
+                                       _p(pu) if pu is not None else None, C.byref(nc), _p(lam))
+        assert rc == 0
+        return s, nc.value, lam
+
     def momentum(self, state):
         out = np.zeros(6); lib().orc_momentum(self.h, _p(f64(state)), _p(out)); return out
 

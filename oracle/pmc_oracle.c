@@ -585,14 +585,38 @@ typedef struct {
   double depth;   /* signed distance to the plane z=0 (negative = penetrating) */
   double mu;
   int leg, slot;
+  double n[3];    /* unit normal of the surface it touches (plane: +z), world */
 } OContact;
+
+/* EPMC terrain (epmc_step.hpp): axis-aligned boxes  x0 x1 y0 y1 z0 z1 rod r ; rod = +1 / -1 / 0: thin cylinders of
+ * radius r along y on the two top / bottom x-edges.  Signed distance and outward normal of point E; same spec as the kernel's
+ * shape_sdf (face of least penetration inside, max(q) outside). */
+typedef struct { int n; const double* rec; double box_mu_scale; } OTerrain;
+static double shape_sdf(const double* s, const double* E, double* n, int* is_box) {
+  double a0[3] = {s[0] - E[0], s[2] - E[1], s[4] - E[2]}, a1[3] = {E[0] - s[1], E[1] - s[3], E[2] - s[5]};
+  double q[3], sg[3];
+  for (int i = 0; i < 3; i++) { q[i] = a0[i] > a1[i] ? a0[i] : a1[i]; sg[i] = a1[i] > a0[i] ? 1.0 : -1.0; }
+  double d = q[0]; int ax = 0;
+  if (q[1] > d) { d = q[1]; ax = 1; }
+  if (q[2] > d) { d = q[2]; ax = 2; }
+  n[0] = n[1] = n[2] = 0; n[ax] = sg[ax];
+  *is_box = 1;
+  if (s[6] != 0.0) {
+    double ze = s[6] > 0 ? s[5] : s[4];
+    for (int e = 0; e < 2; e++) {
+      double dx = E[0] - s[e], dz = E[2] - ze, len = sqrt(dx * dx + dz * dz), dr = len - s[7];
+      if (q[1] <= 0.0 && dr < d && len > 1e-6) { d = dr; n[0] = dx / len; n[1] = 0; n[2] = dz / len; *is_box = 0; }
+    }
+  }
+  return d;
+}
 
 /* DESIGN.md "contact candidates" (spec v2, order independent): every leg has 28 candidate points in a fixed index order
  *   0 foot | 1-3 shank box v0-2 | 4,5 wheel caps | 6 shank v3 | 7-10 shank v4-7 | 11,12 thigh cyl 0 caps | 13 body box vertex z- |
  *   14-17 thigh box v0-3 | 18,19 thigh cyl 1 caps | 20 body box vertex z+ | 21-24 thigh box v4-7 | 25,26 hip cyl caps | 27 handle
  * and keeps the KC candidates of smallest depth below the margin (ties: lower index); the kept ones fill the slots in
  * candidate-index order.  (The index order is the one of the kernel's table, pmc_tables.hpp pmc_build_cand_table.) */
-typedef struct { double P[3], depth, mu; int body, valid; } OCand;
+typedef struct { double P[3], depth, mu, rs, n[3]; int body, valid; } OCand;   /* rs: radius when the primitive is a sphere (tested at its centre) */
 
 static void cand_point(const OPrim* p, const double* Rw, const double* pw, int which, OCand* c) {
   double ctr[3], t[3], Rp[9];
@@ -615,10 +639,12 @@ static void cand_point(const OPrim* p, const double* Rw, const double* pw, int w
     for (int i = 0; i < 3; i++) c->P[i] = ctr[i] + sg * p->size[1] * a[i] - p->size[0] * dir[i];
   }
   c->depth = c->P[2];
+  c->rs = p->type == LLM_PRIM_SPHERE ? p->size[0] : 0.0;
+  c->n[0] = 0; c->n[1] = 0; c->n[2] = 1;
   c->valid = 1;
 }
 
-static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double mu_link, OContact* out) {
+static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double mu_link, const OTerrain* T, OContact* out) {
   int n = 0;
   for (int l = 0; l < 4; l++) {
     OCand c[28];
@@ -640,6 +666,16 @@ static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double 
     for (int s2 = 0; s2 < 2; s2++) CAND(&lp[0], hip, s2, mu_link);           /*  25,26  hip cylinder caps            */
     if (l == 0 || l == 2) CAND(&M->base_prims[l == 0 ? 1 : 2], 0, 0, mu_link); else k++;   /* 27 handle sphere (legs 0, 2) */
 #undef CAND
+    if (T)                                   /* the nearest surface decides depth, normal and friction partner */
+      for (int i = 0; i < 28; i++) {
+        if (!c[i].valid) continue;
+        double E[3] = {c[i].P[0], c[i].P[1], c[i].P[2] + c[i].rs};
+        for (int si = 0; si < T->n; si++) {
+          double nn[3]; int isb;
+          double d = shape_sdf(T->rec + 8 * si, E, nn, &isb) - c[i].rs;
+          if (d < c[i].depth) { c[i].depth = d; memcpy(c[i].n, nn, 24); c[i].valid = isb ? 2 : 3; }   /* valid: 1 plane, 2 box, 3 edge cylinder */
+        }
+      }
     int taken[28] = {0}, nsel = 0;
     for (int s = 0; s < KC; s++) {          /* the KC deepest (ties: lower index) ... */
       int best = -1;
@@ -652,7 +688,9 @@ static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double 
     int slot = 0;
     for (int i = 0; i < 28; i++) {          /* ... stored in candidate-index order, so near-ties in depth cannot reorder the solve */
       if (!taken[i]) continue;
-      out[n].body = c[i].body; memcpy(out[n].P, c[i].P, 24); out[n].depth = c[i].depth; out[n].mu = c[i].mu;
+      out[n].body = c[i].body; memcpy(out[n].P, c[i].P, 24); out[n].depth = c[i].depth;
+      out[n].mu = c[i].mu * (c[i].valid == 2 && T ? T->box_mu_scale : 1.0);
+      memcpy(out[n].n, c[i].n, 24);
       out[n].leg = l; out[n].slot = slot++;
       n++;
     }
@@ -670,12 +708,25 @@ typedef struct {
   double acc_free[NDOF];
 } OSubstepDiag;
 
+static int substep_terrain(const OModel* M, double dt, int n_iter, double mu_foot, double* state, const double* tau_in, OSubstepDiag* diag,
+                           const OTerrain* T, const double* push);
 int orc_substep_model(const OModel* M, double dt, int n_iter, double mu_foot, double* state, const double* tau_in,
                       OSubstepDiag* diag) {
+  return substep_terrain(M, dt, n_iter, mu_foot, state, tau_in, diag, NULL, NULL);
+}
+/* T (nullable): EPMC terrain; push (nullable): PR:72-77 applyExternalForce(linkIndex 0, LINK_FRAME) -- a force in the FR hip link's
+ * frame at that link's centre of mass */
+static int substep_terrain(const OModel* M, double dt, int n_iter, double mu_foot, double* state, const double* tau_in, OSubstepDiag* diag,
+                           const OTerrain* T, const double* push) {
   OKin K;
   double fext[NB][6], acc[NDOF], tau[12];
   kinematics(M, state, NULL, &K);
   external_forces(M, &K, fext);
+  if (push) {
+    double t[3];
+    v3cross(M->com[1], push, t);
+    for (int i = 0; i < 3; i++) { fext[1][i] += t[i]; fext[1][3 + i] += push[i]; }
+  }
   for (int i = 0; i < 12; i++) tau[i] = tau_in[i] - M->damp[i] * state[25 + i]; /* URDF joint damping (Bullet adds -d*qd) */
   if (aba(M, &K, state + 25, tau, fext, 1, acc, acc + 6)) return -1;
   if (diag) memcpy(diag->acc_free, acc, sizeof acc);
@@ -692,7 +743,7 @@ int orc_substep_model(const OModel* M, double dt, int n_iter, double mu_foot, do
 
   /* ---- constraint rows --------------------------------------------------------------------------- */
   OContact C[MAXC];
-  int nc = find_contacts(M, &K, mu_foot, LLM_LINK_FRICTION * LLM_PLANE_FRICTION, C);
+  int nc = find_contacts(M, &K, mu_foot, LLM_LINK_FRICTION * LLM_PLANE_FRICTION, T, C);
   static _Thread_local double J[MAXROWS][NDOF], MiJt[MAXROWS][NDOF], A[MAXROWS][MAXROWS];
   double bias[MAXROWS], lo[MAXROWS], hi[MAXROWS], lam[MAXROWS];
   int fric_of[MAXROWS]; double mu_row[MAXROWS];
@@ -715,7 +766,6 @@ int orc_substep_model(const OModel* M, double dt, int n_iter, double mu_foot, do
     nr++;
   }
   /* contacts: normal + two friction rows, directions n=+z, t1=(0,-1,0), t2=(1,0,0) (btPlaneSpace1 of +z) */
-  static const double dirs[3][3] = {{0, 0, 1}, {0, -1, 0}, {1, 0, 0}};
   int con_row[4][KC];
   for (int l = 0; l < 4; l++) for (int k = 0; k < KC; k++) con_row[l][k] = -1;
   for (int c = 0; c < nc; c++) {
@@ -724,6 +774,20 @@ int orc_substep_model(const OModel* M, double dt, int n_iter, double mu_foot, do
     double ploc[3], d3[3];
     for (int i = 0; i < 3; i++) d3[i] = C[c].P[i] - K.pw[b][i];
     m3tv(K.Rw[b], d3, ploc);
+    double dirs[3][3];                      /* n and btPlaneSpace1(n): for n = +z these are +z, -y, +x */
+    {
+      const double* nn = C[c].n;
+      memcpy(dirs[0], nn, 24);
+      if (fabs(nn[2]) > 0.7071067811865475) {
+        double a = nn[1] * nn[1] + nn[2] * nn[2], kk = 1.0 / sqrt(a);
+        dirs[1][0] = 0; dirs[1][1] = -nn[2] * kk; dirs[1][2] = nn[1] * kk;
+        dirs[2][0] = a * kk; dirs[2][1] = -nn[0] * dirs[1][2]; dirs[2][2] = nn[0] * dirs[1][1];
+      } else {
+        double a = nn[0] * nn[0] + nn[1] * nn[1], kk = 1.0 / sqrt(a);
+        dirs[1][0] = -nn[1] * kk; dirs[1][1] = nn[0] * kk; dirs[1][2] = 0;
+        dirs[2][0] = -nn[2] * dirs[1][1]; dirs[2][1] = nn[2] * dirs[1][0]; dirs[2][2] = a * kk;
+      }
+    }
     for (int r = 0; r < 3; r++) {
       for (int d = 0; d < NDOF; d++) {
         double e[NDOF];
@@ -1056,6 +1120,17 @@ int orc_step_env(OBatch* B, int env, const double* action, const double* scripte
   *reward_out = r;
   *done_out = reason != 0;
   return 0;
+}
+
+/* one substep with EPMC terrain and push (tests/epmc parity): shapes [n][8] as in the kernel, push [3] or NULL */
+int orc_substep_terrain(const OBatch* B, double* state, const double* tau, double mu_foot, int n_shapes, const double* shapes, double box_mu_scale,
+                        const double* push, int32_t* n_contacts, double* lambda_out) {
+  OSubstepDiag d;
+  OTerrain T = {n_shapes, shapes, box_mu_scale};
+  int rc = substep_terrain(&B->model, B->dt, B->cfg.solver_iterations, mu_foot, state, tau, &d, n_shapes > 0 ? &T : NULL, push);
+  if (n_contacts) *n_contacts = d.n_contacts;
+  if (lambda_out) memcpy(lambda_out, d.lambda, sizeof d.lambda);
+  return rc;
 }
 
 /* accessors used by the tests */

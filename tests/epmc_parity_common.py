@@ -201,3 +201,83 @@ def check_free_running_invariants(lib_path, n_envs=64, n_steps=80, element=1):
         assert done_total > 0 and reasons[2] > 0 and pushed > 0                          # some episodes ran out of time; pushes happened
     E.close()
     return done_total
+
+
+def statics_to_records(rows):
+    """ll_epmc_get_statics rows (creation order: a box, then its two edge cylinders if any) -> the kernel's box records."""
+    recs, i = [], 0
+    while i < len(rows):
+        r = rows[i]
+        assert r[0] == 0
+        if r[4] > 0:
+            rec = [r[1] - r[4], r[1] + r[4], r[2] - r[5], r[2] + r[5], r[3] - r[6], r[3] + r[6], 0.0, 0.0]
+            if i + 2 < len(rows) + 0 and i + 1 < len(rows) and rows[i + 1][0] == 1:
+                rec[6] = 1.0 if rows[i + 1][3] > r[3] else -1.0
+                rec[7] = rows[i + 1][4]
+                i += 2
+            recs.append(rec)
+        i += 1
+    return np.array(recs, dtype=np.float64).reshape(-1, 8)
+
+
+def check_terrain_physics_against_oracle(lib_path, n_envs=16, seed=11):
+    """Robots standing on, straddling and pressed into cube steps and hurdles, with the push active: one control step of real
+    physics, engine (float32) vs the float64 oracle given the same terrain records, friction and push forces.  The two share the
+    spec (shape_sdf, nearest-surface normal, btPlaneSpace1 tangents) and nothing else."""
+    from conftest import make_oracle_batch
+    from oracle import oracle as orc
+    from lifelike_agility_and_play_amd import mocap
+    out = dict(config=[], vel=[], n_terrain=0)
+    for element in (3, 1):
+        cfg = env_config(element)
+        cfg['env_randomize_config']['disturb_force_config'] = {'start_time': 0.0, 'interval_time': 1.0, 'duration_time': 0.5, 'horizontal_force': [10, 50], 'vertical_force': [0, 10]}
+        E = make_engine(cfg, n_envs, lib_path, seed=seed)
+        E.reset()
+        rows, cnt = E.statics()
+        rng = np.random.default_rng(seed)
+        st = E.state().astype(np.float64)
+        recs_all = [statics_to_records(rows[i, :cnt[i]].astype(np.float64)) for i in range(n_envs)]
+        for i in range(n_envs):
+            rec = recs_all[i]
+            b = rec[2 + rng.integers(0, min(6, len(rec) - 2))]                      # one of the first obstacles (0, 1 are the walls)
+            st[i, 0] = rng.uniform(b[0] - 0.35, b[1] + 0.35); st[i, 1] = rng.uniform(-0.1, 0.1)
+            st[i, 2] = b[5] + rng.uniform(0.22, 0.33) if b[4] < 0.01 else rng.uniform(0.2, b[4] + 0.05)   # above a step / bar, or under a hanging bar
+            st[i, 7:13] = rng.normal(size=6) * 0.3
+            st[i, 25:37] = rng.normal(size=12)
+        E.set_state(st)
+        st32 = E.state().astype(np.float64)
+        act = (rng.normal(size=(n_envs, 12)) * 0.135).astype(np.float32)
+        ep = E.episode()
+        E.step_host(act)
+        es = E.state().astype(np.float64)
+        tr = E.push_trace().astype(np.float64)
+        B = make_oracle_batch(orc, urdf_model.default_model_blob(), mocap.load_mocap('', 0.02), n_envs=1, kd=0.5, max_tau=16.0)
+        for i in range(n_envs):
+            rec = recs_all[i]
+            p = st32[i, 0:3]
+            near = rec[(p[0] >= rec[:, 0] - 0.9) & (p[0] <= rec[:, 1] + 0.9) & (p[1] >= rec[:, 2] - 0.9) & (p[1] <= rec[:, 3] + 0.9) & (p[2] <= rec[:, 5] + 0.9)][:8]
+            s = st32[i].copy()
+            s_flat = st32[i].copy()                                                 # the same step with the terrain ignored
+            tgt = np.clip(s[13:25] + act[i].astype(np.float64), -3.0, 3.0)
+            nct = 0
+            for k in range(10):
+                tau = np.clip(50.0 * (tgt - s[13:25]) - 0.5 * s[25:37], -16.0, 16.0)
+                push = tr[i, k, 1:4] if tr[i, k, 0] > 0.5 else None
+                s, nc, lam = B.substep_terrain(s, tau, float(np.float32(ep['friction'][i]) * np.float32(0.9)), near, 0.5 / 0.9, push)
+                nct += nc
+                tau_f = np.clip(50.0 * (tgt - s_flat[13:25]) - 0.5 * s_flat[25:37], -16.0, 16.0)
+                s_flat, _, _ = B.substep_terrain(s_flat, tau_f, float(np.float32(ep['friction'][i]) * np.float32(0.9)), near[:0], 0.5 / 0.9, push)
+            if np.abs(s - s_flat).max() > 1e-3:
+                out['n_felt'] = out.get('n_felt', 0) + 1                              # the obstacle changed the motion
+            if len(near) and ((near[:, 1] - near[:, 0]) < 10.0).any():        # an obstacle (not just a side wall) within reach
+                out['n_terrain'] += 1
+            from parity_common import quat_align
+            err = np.abs(quat_align(es[i], s) - s)
+            out['config'].append(max(err[0:7].max(), err[13:25].max()))
+            out['vel'].append(max(err[7:13].max(), err[25:37].max()) / (1.0 + np.abs(s[25:37]).max()))
+        E.close()
+    c, v = np.array(out['config']), np.array(out['vel'])
+    assert out['n_terrain'] >= 10 and out.get('n_felt', 0) >= 8, (out['n_terrain'], out.get('n_felt', 0))
+    assert np.median(c) < 1e-4 and c.max() < 5e-3, c
+    assert np.median(v) < 1e-3 and v.max() < 5e-2, v
+    return out

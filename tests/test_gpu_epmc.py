@@ -26,3 +26,8 @@ def test_free_running_invariants():
 def test_env_api_contract_gpu():
     from test_epmc_env_api import check_single_env_contract
     check_single_env_contract(None)
+
+
+def test_terrain_physics_against_oracle():
+    out = ec.check_terrain_physics_against_oracle(None, n_envs=48)
+    assert out['n_terrain'] >= 30 and out['n_felt'] >= 20
