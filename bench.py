@@ -75,7 +75,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', choices=['pmc', 'epmc'], default='pmc',
+                    help="pmc = BASELINE config 2 (the contract line); epmc = config 4 (PlayGroundEnv, DESIGN.md 8), same JSON shape")
+    ap.add_argument('--element', type=int, default=1, help='epmc only: env_randomize_config element_id (0 joystick, 1 hurdles, 2 holes, 3 cubes)')
     args = ap.parse_args()
+    if args.workload == 'epmc':
+        return main_epmc(args)
 
     import torch
     import torch.distributed as dist
@@ -175,6 +180,75 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(blob, table)
         print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+EPMC_ALGO_BYTES_PER_ENV_STEP = 4 * (12 + 37 + 66 + 24 + 40 + 8 * 8) + 4 * (37 + 916 + 2 + 40)   # reads: action, state, older prop/action frames,
+# per-env scalars, ~8 box records in reach; writes: state, obs (prop 99 + prop_a 36 + 778 rays + target 3), reward/done, scalars
+
+
+def epmc_env_config(element_id):
+    """train_scripts/example_epmc_train.sh:90-117 with the element of BASELINE config 4."""
+    return {'arena_id': 'Playground', 'render': False, 'control_freq': 50.0, 'prop_type': list(PMC_PROP_TYPE), 'kp': 50.0, 'kd': 0.5, 'max_tau': 16,
+            'max_steps': 1000, 'obs_randomization': {},
+            'env_randomize_config': {'element_id': element_id, 'height_range': [0.0, 0.0], 'friction_range': [0.4, 3.0],
+                                     'disturb_force_config': {'start_time': 0.5, 'interval_time': 1.0, 'duration_time': 0.2, 'horizontal_force': [0, 50], 'vertical_force': [0, 10]},
+                                     'cmd_vary_freq_range': [9999, 10000], 'target_spd_range': [0.5, 3.0], 'auxiliary_radius': 0.02,
+                                     'hole_config': {'min_gap_height': 0.25, 'max_gap_height': 0.25}}}
+
+
+def main_epmc(args):
+    """Same measurement for the EPMC env (not the driver's contract line): env-steps/s of 4096 PlayGround envs per GPU."""
+    import torch
+    import torch.distributed as dist
+    from lifelike_agility_and_play_amd import epmc_capi, urdf_model
+    world = int(os.environ.get('WORLD_SIZE', '1')); rank = int(os.environ.get('RANK', '0')); local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(os.environ.get('LL_BENCH_BACKEND', 'nccl'), rank=rank, world_size=world)
+    n = args.envs_per_gpu
+    cfg = epmc_capi.make_epmc_config(n, epmc_env_config(args.element), auto_reset=1, seed=1234 + rank, device=local_rank)
+    eng = epmc_capi.EpmcEngine(cfg, urdf_model.default_model_blob())
+    eng.reset()
+
+    def one_step():
+        eng.fill_random_actions(SIGMA)
+        eng.step()
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    eng.sync(); torch.cuda.synchronize()
+    eng.enable_kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    eng.sync(); torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_n = eng.kernel_time_ms()
+    if world > 1:
+        tt = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        achieved = n * EPMC_ALGO_BYTES_PER_ENV_STEP / (k_ms * 1e-3) / 1e9
+        print(json.dumps({
+            'metric': 'env-steps/sec (whole node), EPMC PlayGround env, random policy', 'value': world * n * args.steps / elapsed, 'unit': 'env-steps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'EPMC PlayGround env (BASELINE config 4), %d envs per MI355X, element_id %d, 778 rays per env-step, push forces, '
+                                   'random-policy actions N(0, e^-2), auto-reset' % (n, args.element), 'envs_per_gpu': n, 'episodes_finished_rank0': eng.counters()['episodes']},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'kernel': 'epmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
+                         'algorithmic_bytes_per_env_step': EPMC_ALGO_BYTES_PER_ENV_STEP,
+                         'note': 'bound by single-wave instruction issue and per-(ray, box) LDS latency, not HBM; see DESIGN.md 8'}}), flush=True)
     eng.close()
     if world > 1:
         dist.destroy_process_group()
