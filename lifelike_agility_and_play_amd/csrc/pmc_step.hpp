@@ -259,10 +259,14 @@ struct Pmc {
     F lo_d = lo - r.lam, hi_d = hi - r.lam;
     F dl = zero;
     // a turn: the lane whose turn it is commits clamp(u) -- every lane's pending increment then moves by nk[L] * d_L
-    if (any4[0]) ln.template turns4<0>(u, dl, lo_d, hi_d, r.nk[0], r.nk[4], r.nk[8], r.nk[12]);
-    if (any4[1]) ln.template turns4<1>(u, dl, lo_d, hi_d, r.nk[1], r.nk[5], r.nk[9], r.nk[13]);
-    if (any4[2]) ln.template turns4<2>(u, dl, lo_d, hi_d, r.nk[2], r.nk[6], r.nk[10], r.nk[14]);
-    if (any4[3]) ln.template turns4<3>(u, dl, lo_d, hi_d, r.nk[3], r.nk[7], r.nk[11], r.nk[15]);
+    // all sixteen turns, unconditionally: a lane without a live row has inv = 0 and commits exactly zero.  (Skipping the 4-turn
+    // blocks no env of the wave occupies was measured slower: the contact blocks are all live anyway, and each wave-uniform
+    // test costs more issue slots in branch bubbles and mask bookkeeping than the 16 instructions it occasionally saves.)
+    (void)any4;
+    ln.template turns4<0>(u, dl, lo_d, hi_d, r.nk[0], r.nk[4], r.nk[8], r.nk[12]);
+    ln.template turns4<1>(u, dl, lo_d, hi_d, r.nk[1], r.nk[5], r.nk[9], r.nk[13]);
+    ln.template turns4<2>(u, dl, lo_d, hi_d, r.nk[2], r.nk[6], r.nk[10], r.nk[14]);
+    ln.template turns4<3>(u, dl, lo_d, hi_d, r.nk[3], r.nk[7], r.nk[11], r.nk[15]);
     r.lam = r.lam + dl;
     F pj[3] = {r.jt[0] * dl, r.jt[1] * dl, r.jt[2] * dl}, sj[3];
     L::subsum3(pj, sj);                                   // the slots of a leg share its joint velocities
