@@ -19,6 +19,7 @@
 #define EPMC_MAX_BOXES 40
 #define EPMC_MAX_DRAWS 64
 #define EPMC_BOX_WORDS 8
+#define EPMC_RAY_NEAR 10      // boxes the height and front rays test from registers
 #define EPMC_MAX_NEAR 8       // boxes within reach of the robot's contact candidates during one control step
 #define EPMC_EP_STRIDE 40
 
@@ -183,6 +184,21 @@ struct Epmc {
   // ------------------------------------------------------------------------------------------------------------
   // rays (PGE:25-52, :381-447).  cast(): this build's spec of rayTestBatch(mask 6): plane z = 0 and the boxes.
   // ------------------------------------------------------------------------------------------------------------
+  // entry parameter of segment f + s d (0 <= s <= 1) into the box lo/hi record x0 x1 y0 y1 z0 z1, or 3e38 (an origin inside: no hit)
+  static LL_HD float slab(const float* f, const float* d, const float* inv, const float* bx) {
+    float te = -3.0e38f, tl = 3.0e38f;
+    for (int a = 0; a < 3; a++) {
+      const float lo = bx[2 * a], hi = bx[2 * a + 1];
+      if (d[a] == 0.0f) {
+        if (!(f[a] >= lo && f[a] <= hi)) { te = 3.0e38f; tl = -3.0e38f; }
+      } else {
+        float t1 = (lo - f[a]) * inv[a], t2 = (hi - f[a]) * inv[a];
+        te = fmaxf(te, fminf(t1, t2));
+        tl = fminf(tl, fmaxf(t1, t2));
+      }
+    }
+    return (te <= tl && te >= 0.0f && te <= 1.0f) ? te : 3.0e38f;
+  }
   // `cand` = bit b set for every box the segment may meet (a conservative pre-selection made once per env and ray family)
   static LL_HD float cast(const float* f, const float* t, const float* boxes, unsigned long long cand, bool* hit_out) {
     const float d[3] = {t[0] - f[0], t[1] - f[1], t[2] - f[2]};
@@ -200,18 +216,7 @@ struct Epmc {
       cand &= cand - 1;
       const float* bx = boxes + b * EPMC_BOX_WORDS;                           // one 16-byte read decides most boxes
       if (bx[1] < sx0 || bx[0] > sx1 || bx[3] < sy0 || bx[2] > sy1) continue;
-      float te = -3.0e38f, tl = 3.0e38f;
-      for (int a = 0; a < 3; a++) {
-        const float lo = bx[2 * a], hi = bx[2 * a + 1];
-        if (d[a] == 0.0f) {
-          if (!(f[a] >= lo && f[a] <= hi)) { te = 3.0e38f; tl = -3.0e38f; }
-        } else {
-          float t1 = (lo - f[a]) * inv[a], t2 = (hi - f[a]) * inv[a];
-          te = fmaxf(te, fminf(t1, t2));
-          tl = fminf(tl, fmaxf(t1, t2));
-        }
-      }
-      if (te <= tl && te >= 0.0f && te <= 1.0f && te < best) best = te;       // origin inside a box: no hit
+      best = fminf(best, slab(f, d, inv, bx));
     }
     *hit_out = best < 2.0f;
     return best < 2.0f ? best : 1.0f;
@@ -246,14 +251,37 @@ struct Epmc {
   static LL_HD void observe_rays(const L& ln, const StepParams& P, const EpmcParams& E, int env, const float* pos, const M3<float>& R, float yaw,
                                  const float* noise, const float* boxes, int n_boxes, float* percep) {
     // boxes within reach of the rays around the base: 3.6 m covers the height grid (1.35 m) and the front rays (3.4 m), 20.1 m
-    // the horizontal fan.  Evaluated once per env; a ray then visits only the boxes of its family's set.
+    // the horizontal fan -- whose rays are exactly level (PGE:30-38), so only boxes whose height range contains the base height
+    // can be met.  Evaluated once per env.  The near set (up to EPMC_RAY_NEAR boxes) is then held in registers: a height or
+    // front ray tests it without a memory access; the horizontal fan walks its set in LDS.
     unsigned long long near = 0ull, far = 0ull;
     for (int b = 0; b < n_boxes; b++) {
       const float* bx = boxes + b * EPMC_BOX_WORDS;
       if (bx[1] >= pos[0] - 3.6f && bx[0] <= pos[0] + 3.6f && bx[3] >= pos[1] - 3.6f && bx[2] <= pos[1] + 3.6f) near |= 1ull << b;
-      if (bx[1] >= pos[0] - 20.1f && bx[0] <= pos[0] + 20.1f && bx[3] >= pos[1] - 20.1f && bx[2] <= pos[1] + 20.1f) far |= 1ull << b;
+      if (bx[1] >= pos[0] - 20.1f && bx[0] <= pos[0] + 20.1f && bx[3] >= pos[1] - 20.1f && bx[2] <= pos[1] + 20.1f && bx[4] <= pos[2] && bx[5] >= pos[2])
+        far |= 1ull << b;
     }
+    float nb[EPMC_RAY_NEAR][6];
+    int n_near = 0;
+    {
+      unsigned long long m = near;
+      for (int k = 0; k < EPMC_RAY_NEAR; k++) {
+        const bool have = m != 0ull;
+        const int b = have ? __builtin_ctzll(m) : 0;
+        if (have) m &= m - 1;
+        const float* bx = boxes + b * EPMC_BOX_WORDS;
+        for (int i = 0; i < 6; i++) nb[k][i] = have ? bx[i] : ((i & 1) ? -3.0e38f : 3.0e38f);     // an empty slot is an empty box
+        n_near += have ? 1 : 0;
+      }
+      near = m;                                                                 // whatever did not fit stays on the LDS path
+    }
+    int kmax = 0;                                                               // slots in use by any env of the wave (wave-uniform loop bound)
+    for (int k = 0; k < EPMC_RAY_NEAR; k++)
+      if (L::any(ln.lane_f(n_near > k ? 1.0f : 0.0f) > 0.5f)) kmax = k + 1;
+    if (PMC_ABL(32)) return;                                                     // ablation build only: no rays
     for (int r = ln.ray_first(); r < EPMC_N_RAYS; r += ln.ray_stride()) {
+      if (PMC_ABL(64) && r >= EPMC_N_HEIGHT) break;                              // ablation: height rays only
+      if (PMC_ABL(128) && (r < EPMC_N_HEIGHT || r >= EPMC_N_HEIGHT + EPMC_N_HORIZ)) continue;   // ablation: horizontal fan only
       float f[3], t[3];
       ray_ends(r, pos, R, yaw, f, t);
       bool hit;
@@ -261,8 +289,31 @@ struct Epmc {
       if (E.scr_ray_hit) {
         hit = E.scr_ray_hit[(long)env * EPMC_N_RAYS + r] != 0;
         frac = E.scr_ray_frac[(long)env * EPMC_N_RAYS + r];
+      } else if (r >= EPMC_N_HEIGHT && r < EPMC_N_HEIGHT + EPMC_N_HORIZ) {
+        frac = cast(f, t, boxes, far, &hit);
       } else {
-        frac = cast(f, t, boxes, (r >= EPMC_N_HEIGHT && r < EPMC_N_HEIGHT + EPMC_N_HORIZ) ? far : near, &hit);
+        float best = cast(f, t, boxes, near, &hit);                              // plane + overflow boxes (normally none)
+        if (!hit) best = 3.0e38f;
+        if (r < EPMC_N_HEIGHT) {                                                 // straight down from z = 10: the highest top under (x, y)
+          float top = -3.0e38f;
+          LL_UNROLL
+          for (int k = 0; k < EPMC_RAY_NEAR; k++) {
+            if (k >= kmax) break;
+            if (f[0] >= nb[k][0] && f[0] <= nb[k][1] && f[1] >= nb[k][2] && f[1] <= nb[k][3]) top = fmaxf(top, nb[k][5]);
+          }
+          if (top > -1.0e38f) best = fminf(best, (10.0f - top) * 0.05f);
+        } else {
+          const float d[3] = {t[0] - f[0], t[1] - f[1], t[2] - f[2]};
+          float inv[3];
+          for (int a = 0; a < 3; a++) inv[a] = d[a] != 0.0f ? 1.0f / d[a] : 0.0f;
+          LL_UNROLL
+          for (int k = 0; k < EPMC_RAY_NEAR; k++) {
+            if (k >= kmax) break;
+            best = fminf(best, slab(f, d, inv, nb[k]));
+          }
+        }
+        hit = best < 2.0f;
+        frac = hit ? best : 1.0f;
       }
       if (E.ray_trace) {
         float* tr = E.ray_trace + ((long)env * EPMC_N_RAYS + r) * 8;

@@ -15,7 +15,7 @@ def env_config(element_id):
 blob = urdf_model.default_model_blob()
 for item in sys.argv[1].split(','):
     n, el = [int(x) for x in item.split(':')]
-    E = epmc_capi.EpmcEngine(epmc_capi.make_epmc_config(n, env_config(el), auto_reset=1, seed=1), blob)
+    E = epmc_capi.EpmcEngine(epmc_capi.make_epmc_config(n, env_config(el), auto_reset=1, seed=1), blob, lib_path=os.environ.get('LL_LIB'))
     E.reset()
     for _ in range(30):
         E.fill_random_actions(math.exp(-2)); E.step()
