@@ -83,6 +83,10 @@ int ll_epmc_set_actions(ll_epmc_engine* e, const float* h_actions);
  * the uniforms the step consumes (h_draws [n_envs][n_draws]; PGE:303, :313, PR:88-98). */
 int ll_epmc_step_scripted(ll_epmc_engine* e, const float* h_actions, const float* h_state, const uint8_t* h_ray_hit, const float* h_ray_frac,
                           const float* h_draws, int n_draws);
+/* Uniforms in [0,1) for the draws of the NEXT ll_epmc_step only, [n_envs][n_draws], consumed in the reference's order (joystick
+ * target angle PGE:303, target speed PGE:313, push direction / horizontal / vertical PR:88-98) instead of the engine's Philox
+ * stream: lets a host that owns the random stream (the 1-env shim replays NumPy's global one) keep it authoritative. */
+int ll_epmc_set_step_draws(ll_epmc_engine* e, const float* h_draws, int n_draws);
 /* scripted ray answers for the NEXT ll_epmc_reset only (the reset observation casts rays too) */
 int ll_epmc_script_reset_rays(ll_epmc_engine* e, const uint8_t* h_ray_hit, const float* h_ray_frac);
 

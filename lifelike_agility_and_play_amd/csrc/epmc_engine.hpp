@@ -119,11 +119,25 @@ struct EpmcEngine {
     have_reset = true;
   }
 
+  int pending_step_draws = 0;
+  void set_step_draws(const float* h_draws, int n_draws) {
+    if (n_draws < 0) throw PmcError(LL_EINVAL, "negative draw count");
+    ensure_script_buffers(n_draws);
+    base.bk.sync();
+    if (n_draws > 0) base.bk.h2d(d_scr_draws, h_draws, (size_t)base.P.n_envs * n_draws * 4);
+    pending_step_draws = n_draws > 0 ? n_draws : -1;              // -1: the step must not draw at all
+  }
   void step(const float* d_act) {
     if (!have_reset) throw PmcError(LL_ESTATE, "ll_epmc_reset must be called before ll_epmc_step");
     StepParams Q = base.P;
     Q.actions = d_act ? d_act : base.d_actions;
-    base.bk.launch_epmc_step(Q, E);
+    EpmcParams R = E;
+    if (pending_step_draws != 0) {
+      if (!d_scr_draws) ensure_script_buffers(1);
+      R.scr_draws = d_scr_draws; R.scr_n_draws = pending_step_draws > 0 ? pending_step_draws : 0;
+      pending_step_draws = 0;
+    }
+    base.bk.launch_epmc_step(Q, R);
     base.P.step_count += 1;
   }
 

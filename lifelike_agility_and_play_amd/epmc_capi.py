@@ -86,6 +86,7 @@ _SIGS = {
     'll_epmc_set_actions': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_epmc_step_scripted': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     'll_epmc_script_reset_rays': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'll_epmc_set_step_draws': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     'll_epmc_sync': (C.c_int, [C.c_void_p]),
     'll_epmc_obs_dim': (C.c_int, [C.c_void_p]),
     'll_epmc_get_obs': (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -174,6 +175,11 @@ class EpmcEngine(object):
         f = np.ascontiguousarray(ray_frac, dtype=np.float32).reshape(self.n_envs, LLE_N_RAYS)
         d = None if draws is None else np.ascontiguousarray(draws, dtype=np.float32).reshape(self.n_envs, -1)
         self._chk(self.lib.ll_epmc_step_scripted(self.h, _ptr(a), _ptr(s), _ptr(h), _ptr(f), _ptr(d), 0 if d is None else d.shape[1]))
+
+    def set_step_draws(self, draws):
+        """Uniforms for the draws of the next step only, [n_envs][k] (k may be 0: the step must then not draw)."""
+        d = np.ascontiguousarray(draws, dtype=np.float32).reshape(self.n_envs, -1)
+        self._chk(self.lib.ll_epmc_set_step_draws(self.h, _ptr(d) if d.shape[1] else None, d.shape[1]))
 
     def script_reset_rays(self, ray_hit, ray_frac):
         h = np.ascontiguousarray(ray_hit, dtype=np.uint8).reshape(self.n_envs, LLE_N_RAYS)

@@ -7,9 +7,10 @@ returns an object with PlayGroundEnv's contract behind SingleAgentWrapper (CPE:6
     reset(**kw) -> (OrderedDict,)        step([a]) -> ((obs,), (reward,), done, info)       a = {'A_LLC': 12 floats} or 12 floats
 Extra keys switch to the batched engine: ``num_envs``, ``device``, ``seed``, ``auto_reset``, ``lib_path``.
 
-Randomness: the engine draws terrain, friction, pushes and joystick commands from its own Philox stream (keyed on seed, env,
-episode) in the reference's draw ORDER; it does not consume NumPy's global MT19937 stream, so `np.random.seed` does not
-reproduce the reference's episodes (the parity tests replay recorded draws through ll_epmc_reset / ll_epmc_step_scripted).
+Randomness: the reference draws terrain, friction, pushes and joystick commands from NumPy's global MT19937 stream.  The 1-env
+game does the same -- `_ReferenceDraws` makes the reference's np.random calls in the reference's order (including the friction
+drawn by the constructor, PGE:92) and hands the values to the engine -- so `np.random.seed(s)` reproduces the reference's
+terrain, targets and pushes.  The batched env draws from the engine's Philox stream (keyed on seed, env, episode) in the same order.
 """
 import warnings
 from collections import OrderedDict
@@ -57,6 +58,92 @@ def _llc(action):
     return np.asarray(a, dtype=np.float32)
 
 
+class _ReferenceDraws(object):
+    """The np.random calls of PlayGroundEnv / BulletStatics / PushRandomizer, in their order, returned as the uniforms in [0, 1)
+    that make the engine reproduce the drawn values (ll_epmc_reset h_draws, ll_epmc_set_step_draws)."""
+
+    def __init__(self, env_config):
+        self.rc = env_config['env_randomize_config']
+        self.element = int(self.rc['element_id'])
+        self.obs_rand = env_config.get('obs_randomization') or {}
+        self.push = self.rc.get('disturb_force_config')
+        self.n_sub = int((1.0 / env_config.get('control_freq', 50.0)) / epmc_capi.TIME_STEP)
+        self.u = []
+        np.random.uniform(*self.rc['friction_range'])                          # PGE:92: the constructor's own friction draw
+
+    def _uniform(self, a, b):
+        v = np.random.uniform(a, b)
+        self.u.append((v - a) / (b - a) if b > a else 0.0)
+        return v
+
+    def _randint(self, a, b):
+        v = np.random.randint(a, b)
+        self.u.append((v - a + 0.5) / (b - a))
+        return v
+
+    def _force(self):                                                          # PR:88-98
+        self._uniform(0, 2 * np.pi)
+        self._uniform(*self.push['horizontal_force'])
+        self._uniform(*self.push['vertical_force'])
+
+    def reset(self):
+        self.u = []
+        self._uniform(*self.rc['friction_range'])                              # PGE:209
+        if self.push is not None:                                              # PGE:213-214
+            self._force()
+            self.count = -self.push.get('start_time', 0.) // epmc_capi.TIME_STEP
+            self.interval = self.push.get('interval_time', 5.) // epmc_capi.TIME_STEP
+        if self.element != 0:                                                  # BSE:27-28, :166-170
+            self._uniform(0.02, 0.5)
+            self._uniform(1.0, 20.0)
+            if self.element in (1, 2):                                         # BSE:200-222
+                hc = self.rc['hole_config'] if self.element == 2 else {}
+                n = self._randint(1, 10)
+                for half in range(2):
+                    for _ in range(n):
+                        if self.element == 1:
+                            self._uniform(0.05, 0.15); self._uniform(1.0, 3.0)   # height, distance (BSE:325, :345)
+                        else:
+                            self._uniform(1.0, 3.0); self._uniform(hc.get('min_gap_height', 0.25), hc.get('max_gap_height', 0.3))   # BSE:400-401
+                    if half == 0:
+                        self._uniform(-1.0, 1.0)
+            else:                                                              # BSE:187-198
+                n = self._randint(1, 5)
+                for half in range(2):
+                    for _ in range(n):
+                        self._uniform(0.0, 1.0)
+                    if half == 0:
+                        self._uniform(-3.0, 3.0)
+        cr = self.rc.get('cmd_vary_freq_range', [25, 200])
+        self.cmd_freq = self._randint(*cr)                                     # PGE:223
+        drawn = {}
+        for k in self.obs_rand:                                                # PGE:176-179, in the dict's own order ...
+            n0 = len(self.u)
+            self._uniform(*self.obs_rand[k])
+            drawn[k] = self.u.pop(n0)
+        self.u += [drawn[k] for k in epmc_capi.NOISE_KEYS if k in drawn]       # ... handed over in the engine's fixed key order
+        self.u.append(float(np.random.rand()))                                 # PGE:183
+        self.counter = 0
+        out = np.full(epmc_capi.LLE_MAX_DRAWS, 0.5, np.float32)
+        out[:len(self.u)] = self.u
+        return out
+
+    def step(self):
+        self.u = []
+        if self.element == 0 and self.counter % self.cmd_freq == 0:
+            self._uniform(0, 2 * np.pi)                                        # PGE:303
+        if self.counter % self.cmd_freq == 0:
+            self._uniform(*self.rc['target_spd_range'])                        # PGE:313
+        if self.push is not None:
+            for _ in range(self.n_sub):                                        # PR:56-71
+                self.count += 1
+                if self.count > 0 and self.count % self.interval == 0:
+                    self._force()
+                    self.count = 0
+        self.counter += 1
+        return np.array(self.u, dtype=np.float32)
+
+
 class PlaygroundGame(object):
     """PlayGroundEnv behind SingleAgentWrapper, one robot, reference semantics (no auto-reset)."""
 
@@ -65,15 +152,17 @@ class PlaygroundGame(object):
         obs, act, self._prop = _spaces(env_config['prop_type'])
         self.observation_space, self.action_space = Tuple([obs]), Tuple([act])    # CPE:9-10
         self.env = self
+        self._draws = _ReferenceDraws(env_config)
 
     def _obs(self):
         return _split(self._engine.obs()[0].astype(np.float64), self._prop)
 
     def reset(self, **kwargs):                                                  # CPE:12-14
-        self._engine.reset()
+        self._engine.reset(draws=self._draws.reset()[None])
         return (self._obs(),)
 
     def step(self, action):                                                     # CPE:16-18 uses action[0]
+        self._engine.set_step_draws(self._draws.step()[None])
         self._engine.step_host(_llc(action[0]).reshape(1, 12))
         r, d, _ = self._engine.reward_done()
         info = {}

@@ -91,3 +91,70 @@ def test_header_binding_and_library_agree():
     lib = epmc_capi.load_library()                # resolves every ll_epmc_* name in the HIP build or raises
     for name in declared:
         assert hasattr(lib, name), name
+
+
+def check_numpy_stream_reproduces_reference(lib_path):
+    """`np.random.seed(s)` + create_playground_game(...).reset() builds the terrain, target, friction and command period the
+    REFERENCE built from the same seed (the 24 cases of golden set T), and consumes exactly as many draws."""
+    import numpy as np
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'epmc_golden.npz'))
+    for k in range(len(g['t_element'])):
+        element, seed = int(g['t_element'][k]), int(g['t_seed'][k])
+        np.random.seed(1000 * element + seed)                                # what gen_epmc_golden.py seeded the reference with
+        aux = None if np.isnan(g['t_aux'][k]) else float(g['t_aux'][k])
+        env = lla.create_playground_game(lib_path=lib_path, **env_config(element, aux=aux))
+        env.reset()
+        rows, cnt = env._engine.statics()
+        n = int(g['t_n_statics'][k])
+        assert cnt[0] == n
+        np.testing.assert_allclose(rows[0, :n], g['t_statics'][k][:n], rtol=1e-5, atol=2e-5)
+        ep = env._engine.episode()
+        np.testing.assert_allclose([ep['target_x'][0], ep['target_y'][0], ep['target_z'][0]], g['t_target'][k], atol=2e-5)
+        assert abs(ep['friction'][0] - g['t_friction'][k]) < 1e-5 and int(ep['cmd_vary_freq'][0]) == int(g['t_cmd_freq'][k])
+        np.testing.assert_allclose([ep['push_fx'][0], ep['push_fy'][0], ep['push_fz'][0]], g['t_push_force'][k], rtol=1e-5, atol=1e-4)
+        follow = np.random.uniform()                                           # the stream must now stand where the reference left it
+        np.random.seed(1000 * element + seed)
+        for kind, a, b, v in g['t_draws'][k][:g['t_n_draws'][k]]:
+            pass
+        np.random.uniform(0.4, 3.0)                                            # the constructor's draw (not in the recorded log)
+        for kind, a, b, v in g['t_draws'][k][:g['t_n_draws'][k]]:
+            got = np.random.uniform(a, b) if kind == 0 else (np.random.randint(int(a), int(b)) if kind == 1 else np.random.rand())
+            assert abs(got - v) < 1e-12
+        assert abs(np.random.uniform() - follow) < 1e-15
+        env.close()
+
+
+def check_numpy_stream_through_steps(lib_path):
+    """The same for the draws made while stepping (joystick targets, commanded speed, push forces): after reset() and as many
+    step() calls as the reference's golden episodes ran, NumPy's global stream stands exactly where the reference left it."""
+    import numpy as np
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'epmc_golden.npz'))
+    for e in range(len(g['e_element'])):
+        noise_on = not np.isnan(g['e_noise'][e][0])
+        obs_rand = {'pos_x_bias': [-0.1, 0.1], 'pos_y_bias': [-0.1, 0.1], 'yaw_bias': [-0.2, 0.2], 'pos_z_bias': [-0.02, 0.02]} if noise_on else None
+        cmd = {0: (7, 8), 1: (25, 200)}.get(e, (9999, 10000))
+        np.random.seed(5000 + e)
+        env = lla.create_playground_game(lib_path=lib_path, **env_config(int(g['e_element'][e]), obs_rand=obs_rand, cmd_range=cmd))
+        env.reset()
+        for t in range(int(g['e_n'][e])):
+            env.step([np.zeros(12)])
+        ep = env._engine.episode()
+        np.testing.assert_allclose([ep['target_x'][0], ep['target_y'][0]], g['e_target'][e][int(g['e_n'][e]) - 1][:2], rtol=1e-4, atol=1e-2) \
+            if int(g['e_element'][e]) != 0 else None                          # (a joystick target is relative to where the robot stands)
+        assert abs(ep['target_spd'][0] - g['e_target_spd'][e][int(g['e_n'][e]) - 1]) < 1e-5
+        follow = np.random.uniform()
+        np.random.seed(5000 + e)
+        np.random.uniform(0.4, 3.0)
+        for kind, a, b, v in g['e_draws'][e][:g['e_n_draws'][e]]:
+            got = np.random.uniform(a, b) if kind == 0 else (np.random.randint(int(a), int(b)) if kind == 1 else np.random.rand())
+            assert abs(got - v) < 1e-12
+        assert abs(np.random.uniform() - follow) < 1e-15, e
+        env.close()
+
+
+def test_numpy_stream_through_steps(emul_lib):
+    check_numpy_stream_through_steps(emul_lib)
+
+
+def test_numpy_stream_reproduces_reference(emul_lib):
+    check_numpy_stream_reproduces_reference(emul_lib)
