@@ -161,6 +161,17 @@ def main():
                 traffic = json.load(open(tj))['traffic_bytes']
             except Exception:                # noqa: BLE001
                 traffic = None
+        issue = None                         # the binding limit: one instruction per wave per quad-cycle, one wave per SIMD
+        cj = os.path.join(ROOT, 'profiles', 'r01_pmc_step_kernel_counters.json')
+        if os.path.exists(cj) and n == ENVS_PER_GPU:
+            try:
+                c = json.load(open(cj))
+                issue = {'instructions_per_wave': (c['SQ_INSTS_VALU'] + c['SQ_INSTS_SALU'] + c['SQ_INSTS_LDS']) / c['SQ_WAVES'],
+                         'issue_slots_per_wave': c['SQ_WAVE_CYCLES'] / c['SQ_WAVES'],
+                         'frac': (c['SQ_INSTS_VALU'] + c['SQ_INSTS_SALU'] + c['SQ_INSTS_LDS']) / c['SQ_WAVE_CYCLES'],
+                         'source': 'profiles/r01_pmc_step_kernel_counters.json (rocprofv3 --pmc SQ_INSTS_*, SQ_WAVE_CYCLES in quad-cycles)'}
+            except Exception:                # noqa: BLE001
+                issue = None
         out = {
             'metric': 'env-steps/sec (whole node), PMC tracking env, random policy',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -174,7 +185,7 @@ def main():
                          'frac': (achieved / HBM_PEAK_GBPS) if achieved else None, 'traffic': traffic,
                          'traffic_source': 'profiles/traffic.json (bytes per launch, FETCH_SIZE + WRITE_SIZE, uncorrected; see DESIGN.md 5.1)',
                          'kernel': 'pmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
-                         'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP,
+                         'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP, 'single_wave_issue': issue,
                          'note': 'bound by single-wave instruction issue, not HBM (about 1.5e5 instructions per wave per step vs 2.5 KB per env); see DESIGN.md 5.1'},
         }
         if world == 1 and not args.no_cpu_baseline:
