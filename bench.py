@@ -111,8 +111,7 @@ def main():
                            reward_weights=PMC_REWARD_WEIGHTS, prop_type=PMC_PROP_TYPE, prioritized_sample_factor=3.0,
                            auto_reset=1, seed=1234 + rank, device=local_rank)
     eng = capi.Engine(cfg, blob, table)
-    stream = torch.cuda.current_stream()
-    eng.set_stream(stream.cuda_stream)                 # step kernels and torch ops share one stream
+    stream = gather.bind_torch_stream(eng)             # step kernels, torch ops and the RCCL gather are ordered on one stream
     eng.reset()
     traj = gather.TrajectoryBuffer(eng, UNROLL) if world > 1 else None
 

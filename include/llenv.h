@@ -170,7 +170,8 @@ int ll_step_random(ll_engine* e, float sigma);
 int ll_sync(ll_engine* e);
 /* Launch on a caller-owned hipStream_t (e.g. torch's current stream) instead of the engine's own, so that the
  * producer of d_actions and the consumers of the obs buffer are stream-ordered with the step kernel. NULL restores
- * the engine's private stream. */
+ * the engine's private (non-blocking) stream -- so the legacy default stream, whose handle IS NULL, cannot be shared: give
+ * torch and the engine an explicit stream (gather.bind_torch_stream). */
 int ll_set_stream(ll_engine* e, void* hip_stream);
 
 /* Device buffers owned by the engine (valid until ll_destroy), for zero-copy consumers (torch, RCCL). */

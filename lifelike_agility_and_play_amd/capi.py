@@ -204,7 +204,11 @@ class Engine(object):
         self._chk(self.lib.ll_sync(self.h))
 
     def set_stream(self, stream_handle):
-        self._chk(self.lib.ll_set_stream(self.h, C.c_void_p(stream_handle) if stream_handle else None))
+        if stream_handle is not None and int(stream_handle) == 0:
+            # torch's default stream reports handle 0, which ll_set_stream reads as "back to the private stream": work queued by
+            # torch and by the engine would then be unordered.  Share an explicit stream instead (gather.bind_torch_stream).
+            raise ValueError('the legacy default stream (handle 0) cannot be shared; pass a torch.cuda.Stream handle, or None for the private stream')
+        self._chk(self.lib.ll_set_stream(self.h, C.c_void_p(int(stream_handle)) if stream_handle is not None else None))
 
     def enable_trajectory(self, unroll):
         """-> (device address, row_floats) of the [unroll][n_envs][row_floats] ring written by every step"""

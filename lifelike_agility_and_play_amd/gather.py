@@ -33,6 +33,16 @@ def device_tensor(ptr, shape, dtype=torch.float32, device=None):
     return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device if device is not None else torch.device('cuda', torch.cuda.current_device()))
 
 
+def bind_torch_stream(engine, stream=None):
+    """Make torch and the engine queue their work on ONE stream, so that a policy's kernels, the step kernel and the consumers
+    of its buffers are ordered without host synchronisation.  torch's default stream has handle 0 and cannot be named through
+    ll_set_stream, so a dedicated stream is created (or `stream` used), made torch's current stream, and given to the engine."""
+    s = stream if stream is not None else torch.cuda.Stream()
+    torch.cuda.set_stream(s)
+    engine.set_stream(s.cuda_stream)
+    return s
+
+
 def engine_tensors(engine):
     """torch views of the engine's output/action buffers (no copies)."""
     p = engine.device_ptrs()

@@ -1,0 +1,32 @@
+"""Closed loop entirely on the device: the reference's trained PMC policy (torch GEMMs on the engine's obs buffer) drives N
+environments; reports env-steps/s and the tracking reward.   python tools/rollout_policy.py [n_envs] [steps]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from lifelike_agility_and_play_amd import capi, gather, mocap, urdf_model
+from lifelike_agility_and_play_amd.pmc_policy_torch import TorchPmcPolicy
+RW = {'joint_pos': 0.3, 'joint_vel': 0.05, 'end_effector': 0.1, 'root_pose': 0.5, 'root_vel': 0.05}
+PT = ['joint_pos', 'joint_vel', 'root_ang_vel_loc', 'root_lin_vel_loc', 'e_g']
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+cfg = capi.make_config(n, control_freq=50.0, kd=0.5, reward_weights=RW, prop_type=PT, prioritized_sample_factor=3.0, auto_reset=1, seed=1)
+E = capi.Engine(cfg, urdf_model.default_model_blob(), mocap.load_mocap('', 0.02))
+gather.bind_torch_stream(E)                  # policy kernels and the step kernel on one stream
+T = gather.engine_tensors(E)
+pol = TorchPmcPolicy()
+E.reset()
+for _ in range(20):
+    pol.act(T['obs'], out=T['actions']); E.step()
+torch.cuda.synchronize()
+rsum = torch.zeros((), device='cuda'); dsum = torch.zeros((), device='cuda')
+t0 = time.perf_counter()
+for _ in range(steps):
+    pol.act(T['obs'], out=T['actions'])
+    E.step()
+    rsum += T['reward'].sum(); dsum += T['done'].sum()
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print('trained policy, %d envs: %.3f ms/step -> %.2f M env-steps/s; mean tracking reward %.3f, episodes ended %d (%.4f per env-step)'
+      % (n, dt / steps * 1e3, n * steps / dt / 1e6, float(rsum) / (n * steps), int(dsum), float(dsum) / (n * steps)))
+E.close()
