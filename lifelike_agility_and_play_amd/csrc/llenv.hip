@@ -294,3 +294,4 @@ typedef PmcEngine<HipBackend> ENGINE;
 #include "pmc_capi.inc"
 typedef EpmcEngine<HipBackend> EPMC_ENGINE;
 #include "epmc_capi.inc"
+#include "pmc_policy.inc"

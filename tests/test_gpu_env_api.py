@@ -67,3 +67,42 @@ def test_trained_policy_on_device_closed_loop(model_blob, mocap_table):
         rsum += float(T['reward'].mean())
     assert rsum / 150 > 0.7, rsum / 150
     E.close()
+
+
+def test_fused_mfma_policy_kernel(model_blob, mocap_table):
+    """ll_policy_act (one fused kernel, float32 MFMA) against the NumPy statement of the policy on real observations: the chosen
+    codes agree (a near-tie between two codes may fall either way in float32 -- allowed for < 0.5 % of envs), the actions of
+    agreeing envs match, and the closed loop on the device tracks the clips."""
+    import os
+    import torch
+    from conftest import GOLDEN_DIR, PMC_PROP_TYPE, PMC_REWARD_WEIGHTS
+    from lifelike_agility_and_play_amd import capi, gather
+    from lifelike_agility_and_play_amd.pmc_policy import PmcPolicy
+    from lifelike_agility_and_play_amd.pmc_policy_hip import HipPmcPolicy
+    for n in (1000, 4096):                                            # 1000: a partial last workgroup
+        cfg = capi.make_config(n, control_freq=50.0, kd=0.5, reward_weights=PMC_REWARD_WEIGHTS, prop_type=PMC_PROP_TYPE, prioritized_sample_factor=3.0,
+                               auto_reset=1, seed=3)
+        E = capi.Engine(cfg, model_blob, mocap_table)
+        gather.bind_torch_stream(E)
+        T = gather.engine_tensors(E)
+        pol, ref = HipPmcPolicy(), PmcPolicy(os.path.join(GOLDEN_DIR, 'pmc_policy.npz'))
+        code = torch.zeros(n, dtype=torch.int32, device='cuda')
+        E.reset()
+        rsum = 0.0
+        for t in range(120):
+            pol.act(E, d_code=code.data_ptr())
+            if t in (0, 40, 119):
+                obs = E.obs().astype(np.float64)                       # syncs the stream
+                a = T['actions'].cpu().numpy()
+                w = ref.w
+                prop = np.clip((obs[:, :135] - w[0]) / (w[1] + 1e-8), -5, 5); fut = np.clip((obs[:, 135:] - w[2]) / (w[3] + 1e-8), -5, 5)
+                h = np.maximum(np.maximum(np.concatenate([prop, fut], 1) @ w[10] + w[11], 0) @ w[12] + w[13], 0)
+                ze = h @ w[14] + w[15]
+                ref_code = np.argmax(-((ze ** 2).sum(1, keepdims=True) - 2 * ze @ w[16] + (w[16] ** 2).sum(0, keepdims=True)), 1)
+                same = code.cpu().numpy() == ref_code
+                assert same.mean() > 0.995, same.mean()
+                np.testing.assert_allclose(a[same], ref.act(obs)[same], rtol=2e-4, atol=2e-4)
+            E.step()
+            rsum += float(T['reward'].mean())
+        assert rsum / 120 > 0.8, rsum / 120
+        pol.close(); E.close()

@@ -1,11 +1,12 @@
 """Closed loop entirely on the device: the reference's trained PMC policy (torch GEMMs on the engine's obs buffer) drives N
-environments; reports env-steps/s and the tracking reward.   python tools/rollout_policy.py [n_envs] [steps]"""
+environments; reports env-steps/s and the tracking reward.   python tools/rollout_policy.py [n_envs] [steps] [hip|torch]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from lifelike_agility_and_play_amd import capi, gather, mocap, urdf_model
 from lifelike_agility_and_play_amd.pmc_policy_torch import TorchPmcPolicy
+from lifelike_agility_and_play_amd.pmc_policy_hip import HipPmcPolicy
 RW = {'joint_pos': 0.3, 'joint_vel': 0.05, 'end_effector': 0.1, 'root_pose': 0.5, 'root_vel': 0.05}
 PT = ['joint_pos', 'joint_vel', 'root_ang_vel_loc', 'root_lin_vel_loc', 'e_g']
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -14,19 +15,28 @@ cfg = capi.make_config(n, control_freq=50.0, kd=0.5, reward_weights=RW, prop_typ
 E = capi.Engine(cfg, urdf_model.default_model_blob(), mocap.load_mocap('', 0.02))
 gather.bind_torch_stream(E)                  # policy kernels and the step kernel on one stream
 T = gather.engine_tensors(E)
-pol = TorchPmcPolicy()
+kind = sys.argv[3] if len(sys.argv) > 3 else 'hip'
+pol = HipPmcPolicy() if kind == 'hip' else TorchPmcPolicy()
+act = (lambda: pol.act(E)) if kind == 'hip' else (lambda: pol.act(T['obs'], out=T['actions']))
 E.reset()
+racc = torch.zeros(n, device='cuda'); dacc = torch.zeros(n, device='cuda')
 for _ in range(20):
-    pol.act(T['obs'], out=T['actions']); E.step()
+    act(); E.step(); racc.add_(T['reward']); dacc.add_(T['done'])          # (the statistics kernels are warmed up too)
+racc.zero_(); dacc.zero_()
 torch.cuda.synchronize()
-rsum = torch.zeros((), device='cuda'); dsum = torch.zeros((), device='cuda')
 t0 = time.perf_counter()
 for _ in range(steps):
-    pol.act(T['obs'], out=T['actions'])
+    act()
     E.step()
-    rsum += T['reward'].sum(); dsum += T['done'].sum()
+    racc.add_(T['reward']); dacc.add_(T['done'])
 torch.cuda.synchronize()
+rsum, dsum = racc.sum(), dacc.sum()
 dt = time.perf_counter() - t0
-print('trained policy, %d envs: %.3f ms/step -> %.2f M env-steps/s; mean tracking reward %.3f, episodes ended %d (%.4f per env-step)'
-      % (n, dt / steps * 1e3, n * steps / dt / 1e6, float(rsum) / (n * steps), int(dsum), float(dsum) / (n * steps)))
+print('trained policy (%s%s), %d envs: %.3f ms/step -> %.2f M env-steps/s; mean tracking reward %.3f, episodes ended %d (%.4f per env-step)'
+      % (kind, '', n, dt / steps * 1e3, n * steps / dt / 1e6, float(rsum) / (n * steps), int(dsum), float(dsum) / (n * steps)))
+if kind == 'hip':
+    pol.enable_timing(True)
+    for _ in range(50):
+        act()
+    print('  fused policy kernel alone: %.1f us per launch' % (pol.time_ms()[0] * 1e3))
 E.close()
