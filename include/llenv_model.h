@@ -49,5 +49,8 @@
 #define LLM_LINK_DAMPING 0.04          /* btMultiBody default linear & angular damping (quirk Q12) */
 #define LLM_MAX_CONTACTS_PER_LEG 4     /* contact slots per leg lane */
 #define LLM_LIMIT_GATE 20.0             /* a joint-limit row enters the solve iff  s*qd* + bias < this [rad/s] */
+#define LLM_SELF_MARGIN 0.01            /* a capsule pair of two legs becomes a (speculative) row within this distance: covers closing
+                                           speeds up to 5 m/s per 2 ms substep; the capsules themselves are 35 mm thick */
+#define LLM_MAX_SELF 2                  /* self-collision rows per robot */
 
 #endif

@@ -132,6 +132,17 @@ struct GpuLanes {
     float y = x + LL_DPP_MOV(x, 0xB1);       // quad_perm [1,0,3,2]
     return y + LL_DPP_MOV(y, 0x4E);          // quad_perm [2,3,0,1]
   }
+  // value of x held by the same sub-lane of the PREVIOUS leg ((leg + 3) % 4) / of the leg two away (row_ror: data moves to
+  // higher lanes, lane i receives lane (i - n) mod 16)
+  static LL_D F from_prev_leg(F x) { return LL_DPP_MOV(x, 0x124); }
+  static LL_D F from_leg2(F x) { return LL_DPP_MOV(x, 0x128); }
+  // minimum over the 16 lanes of the row
+  static LL_D float rmin(F x) {
+    float y = fminf(x, LL_DPP_MOV(x, 0xB1));
+    y = fminf(y, LL_DPP_MOV(y, 0x4E));
+    y = fminf(y, LL_DPP_MOV(y, 0x124));
+    return fminf(y, LL_DPP_MOV(y, 0x128));
+  }
   static LL_D F submin(F x) {
     float y = fminf(x, LL_DPP_MOV(x, 0xB1));
     return fminf(y, LL_DPP_MOV(y, 0x4E));

@@ -29,7 +29,8 @@ enum LegConst {
   LC_WHEEL = 103,     // 11 wheel cylinder (welded to the thigh)
   LC_SHBOX = 114,     // 12 box on the shank link
   LC_FOOTSPH = 126,   // 4  foot sphere on the shank link: c(3) r
-  LC_COUNT = 130
+  LC_CAPS = 130,      // 14 self-collision capsules: thigh a(3) b(3) in the thigh frame, shank a(3) b(3) in the shank frame, r_thigh, r_shank
+  LC_COUNT = 144
 };
 
 // ---- contact candidate table: candc[(jj * CF_WORDS + field) * 16 + leg * 4 + sub], 7 candidates per (leg, sub) --------------
@@ -71,7 +72,7 @@ struct StepParams {
   int32_t keep_term_obs;    // auto-reset: also write the finished episode's last obs to term_obs
   float dt, kp, kd, max_tau;
   float mu_foot, mu_link, gravity, link_damping;
-  float erp, margin_dist, limit_gate, pad3;
+  float erp, margin_dist, limit_gate, self_collision;   // self_collision: 1 = links of different legs collide (LR:212-217)
   float rw[5];              // normalised reward weights (PLE:365-370)
   float pad4;
   double dt_d, frame_step, policy_step, sample_factor;

@@ -18,6 +18,7 @@
 //   gt = Lb^-1 (J_b - Y jt),  jt = Lm^-1 J_l,   A_rs = gt_r.gt_s + [same leg] jt_r.jt_s
 // so a row update touches 6 shared numbers (quad broadcast) and 3 lane-private ones.
 #pragma once
+#include "../../include/llenv_model.h"
 #include "pmc_math.hpp"
 #include "pmc_params.hpp"
 
@@ -326,6 +327,39 @@ struct Pmc {
       }
     }
   }
+  // closest points of the segments p1-q1 and p2-q2 (Ericson 5.1.9; same branches as the oracle's seg_seg)
+  static LL_HD void seg_seg(const L& ln, const V3l& p1, const V3l& q1, const V3l& p2, const V3l& q2, V3l& c1, V3l& c2) {
+    const F zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f);
+    V3l d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+    F a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2);
+    F den = a * e - b * b;
+    F s0 = lm::sel(den > 1e-9f, lm::min_(lm::max_((b * f - c * e) / lm::max_(den, ln.lane_f(1e-9f)), zero), one), zero);
+    F t0 = (b * s0 + f) / e;
+    B lt = t0 < 0.0f, gt = t0 > 1.0f;
+    F t = lm::sel(lt, zero, lm::sel(gt, one, t0));
+    F s_alt = lm::min_(lm::max_(lm::sel(lt, zero - c, b - c) / a, zero), one);
+    F s = lm::sel(lm::or_(lt, gt), s_alt, s0);
+    c1 = p1 + scale(d1, s);
+    c2 = p2 + scale(d2, t);
+  }
+  // self-collision row: frictionless, between a point on leg `own` and the same point on leg `other`
+  struct SelfRow {
+    F jt[3];
+    float gt[6];
+    float c, inv, lam;
+  };
+
+  static LL_HD void self_turn(SelfRow& rw, float* dx, F* dq) {
+    float w = rw.c + L::qsum(rw.jt[0] * dq[0] + rw.jt[1] * dq[1] + rw.jt[2] * dq[2]);
+    for (int i = 0; i < 6; i++) w += rw.gt[i] * dx[i];
+    float nl = rw.lam - w * rw.inv;
+    if (nl < 0.0f) nl = 0.0f;
+    const float d = nl - rw.lam;
+    rw.lam = nl;
+    for (int j = 0; j < 3; j++) dq[j] = dq[j] + rw.jt[j] * d;
+    for (int i = 0; i < 6; i++) dx[i] += rw.gt[i] * d;
+  }
+
   // Where a candidate is tested against the terrain: its lowest point (the point the plane test uses), in world coordinates;
   // for a sphere the test is made at the centre with the radius subtracted (rs), so that a side wall is met sideways.
   static LL_HD void cand_eval_point(const L& ln, const Base& bs, const M3<float>& R, const M3<F>& lR, const V3l& lp, const V3l& ez_link, const V3l& A,
@@ -702,8 +736,110 @@ struct Pmc {
       }
     }
 
+    // --- self-collision (LR:212-217: links of different legs): each leg is two capsules, the closest pairs within the
+    //     margin give up to two frictionless rows.  Lane (leg g, sub s) tests capsule (s & 2 ? shank : thigh) of its own leg against
+    //     capsule (s & 1 ? shank : thigh) of the previous leg, and -- legs 0 and 1 only -- of the leg two away: 24 pairs in two passes.
+    SelfRow sr[2];
+    sr[0].inv = sr[1].inv = 0.0f; sr[0].lam = sr[1].lam = 0.0f; sr[0].c = sr[1].c = 0.0f;
+    for (int i = 0; i < 3; i++) sr[0].jt[i] = sr[1].jt[i] = zero;
+    for (int i = 0; i < 6; i++) sr[0].gt[i] = sr[1].gt[i] = 0.0f;
+    bool any_self = false;
+    int n_self_w = 0;                   // self-collision slots in use by some env of the wave
+    if (P.self_collision > 0.5f && !PMC_ABL(512)) {                                 // (ablation 512: no self-collision at all)
+      V3l TA = k.p2 + mul(k.R2, ld3c(ln, legc, LC_CAPS)), TB = k.p2 + mul(k.R2, ld3c(ln, legc, LC_CAPS + 3));
+      V3l SA = k.p3 + mul(k.R3, ld3c(ln, legc, LC_CAPS + 6)), SB = k.p3 + mul(k.R3, ld3c(ln, legc, LC_CAPS + 9));
+      F rT = ln.legc(legc, LC_CAPS + 12), rS = ln.legc(legc, LC_CAPS + 13);
+      B oth_s = lm::odd_(ln.sub()), own_s = lm::bit1_(ln.sub());
+      V3l a1 = mk3<F>(lm::sel(own_s, SA.x, TA.x), lm::sel(own_s, SA.y, TA.y), lm::sel(own_s, SA.z, TA.z));
+      V3l b1 = mk3<F>(lm::sel(own_s, SB.x, TB.x), lm::sel(own_s, SB.y, TB.y), lm::sel(own_s, SB.z, TB.z));
+      F r1 = lm::sel(own_s, rS, rT);
+      F cd[2], cpair[2];
+      V3l cP[2], cN[2];
+      F subf = L::i2f(ln.sub()), legf = ln.legf();
+      for (int pass = 0; pass < 2; pass++) {
+        V3l oTA, oTB, oSA, oSB;
+        F orT, orS;
+        if (pass == 0) {
+          oTA = mk3<F>(L::from_prev_leg(TA.x), L::from_prev_leg(TA.y), L::from_prev_leg(TA.z)); oTB = mk3<F>(L::from_prev_leg(TB.x), L::from_prev_leg(TB.y), L::from_prev_leg(TB.z));
+          oSA = mk3<F>(L::from_prev_leg(SA.x), L::from_prev_leg(SA.y), L::from_prev_leg(SA.z)); oSB = mk3<F>(L::from_prev_leg(SB.x), L::from_prev_leg(SB.y), L::from_prev_leg(SB.z));
+          orT = L::from_prev_leg(rT); orS = L::from_prev_leg(rS);
+        } else {
+          oTA = mk3<F>(L::from_leg2(TA.x), L::from_leg2(TA.y), L::from_leg2(TA.z)); oTB = mk3<F>(L::from_leg2(TB.x), L::from_leg2(TB.y), L::from_leg2(TB.z));
+          oSA = mk3<F>(L::from_leg2(SA.x), L::from_leg2(SA.y), L::from_leg2(SA.z)); oSB = mk3<F>(L::from_leg2(SB.x), L::from_leg2(SB.y), L::from_leg2(SB.z));
+          orT = L::from_leg2(rT); orS = L::from_leg2(rS);
+        }
+        V3l a2 = mk3<F>(lm::sel(oth_s, oSA.x, oTA.x), lm::sel(oth_s, oSA.y, oTA.y), lm::sel(oth_s, oSA.z, oTA.z));
+        V3l b2 = mk3<F>(lm::sel(oth_s, oSB.x, oTB.x), lm::sel(oth_s, oSB.y, oTB.y), lm::sel(oth_s, oSB.z, oTB.z));
+        F r2 = lm::sel(oth_s, orS, orT);
+        V3l c1, c2;
+        seg_seg(ln, a1, b1, a2, b2, c1, c2);
+        V3l dd = c1 - c2;
+        F len = lm::sqrt_(dot(dd, dd));
+        F il = one / lm::max_(len, ln.lane_f(1e-9f));
+        cN[pass] = scale(dd, il);                                              // from the other leg's capsule to this leg's
+        cP[pass] = scale((c1 - scale(cN[pass], r1)) + (c2 + scale(cN[pass], r2)), ln.lane_f(0.5f));
+        F dep = len - r1 - r2;
+        // the oracle's pair index (tie-break and identity): leg pairs (0,1) (1,2) (2,3) (3,0) (0,2) (1,3), A first;
+        // capsule bits: bit 0 = A's, bit 1 = B's.  Pass 0: A = the previous leg (other), B = own; pass 1: A = own, B = other.
+        F lp = (pass == 0) ? lm::sel(legf < 0.5f, ln.lane_f(3.0f), legf - one) : legf + ln.lane_f(4.0f);
+        F sp = (pass == 0) ? subf : lm::sel(own_s, one, zero) + lm::sel(oth_s, ln.lane_f(2.0f), zero);
+        cpair[pass] = lp * 4.0f + sp;
+        B valid = lm::and_(dep < (float)LLM_SELF_MARGIN, len > 1e-9f);
+        if (pass == 1) valid = lm::and_(valid, legf < 1.5f);                    // pairs {0,2} and {1,3}, once each
+        cd[pass] = lm::sel(valid, dep, far_);
+      }
+      any_self = L::any(lm::min_(cd[0], cd[1]) < 1.0e29f) && !PMC_ABL(256);          // (ablation 256: detection only)
+      if (any_self) {
+        LL_UNROLL
+        for (int slot = 0; slot < 2; slot++) {
+          if (slot == 1 && !L::any(lm::min_(cd[0], cd[1]) < 1.0e29f)) break;        // nobody in the wave has a second one
+          n_self_w = slot + 1;
+          F dlane = lm::min_(cd[0], cd[1]);
+          float dmin = L::rmin(dlane);
+          B at0 = cd[0] <= ln.lane_f(dmin), at1 = cd[1] <= ln.lane_f(dmin);
+          F code = lm::min_(lm::sel(at0, cpair[0], ln.lane_f(1.0e9f)), lm::sel(at1, cpair[1], ln.lane_f(1.0e9f)));
+          float cmin = L::rmin(code);
+          const bool have = dmin < 1.0e29f;
+          B win0 = lm::and_(at0, lm::abs_(cpair[0] - cmin) < 0.5f), win1 = lm::and_(lm::and_(at1, lm::abs_(cpair[1] - cmin) < 0.5f), lm::not_(win0));
+          F w6[6];
+          float u6[6];
+          w6[0] = lm::sel(win0, cP[0].x, lm::sel(win1, cP[1].x, zero)); w6[1] = lm::sel(win0, cP[0].y, lm::sel(win1, cP[1].y, zero));
+          w6[2] = lm::sel(win0, cP[0].z, lm::sel(win1, cP[1].z, zero)); w6[3] = lm::sel(win0, cN[0].x, lm::sel(win1, cN[1].x, zero));
+          w6[4] = lm::sel(win0, cN[0].y, lm::sel(win1, cN[1].y, zero)); w6[5] = lm::sel(win0, cN[0].z, lm::sel(win1, cN[1].z, zero));
+          L::rsum6(w6, u6);
+          cd[0] = lm::sel(win0, far_, cd[0]); cd[1] = lm::sel(win1, far_, cd[1]);
+          // who is who: pair index -> (own leg: sign +, other leg: sign -) and the links (2 thigh, 3 shank)
+          const int pair = have ? (int)(cmin + 0.5f) : 0, lpi = pair >> 2, spi = pair & 3;
+          const int legA = lpi < 4 ? lpi : lpi - 4, legB = lpi < 4 ? ((lpi + 1) & 3) : lpi - 2;
+          const int own = lpi < 4 ? legB : legA, oth = lpi < 4 ? legA : legB;
+          const int own_link = 2 + (lpi < 4 ? (spi >> 1) : (spi & 1)), oth_link = 2 + (lpi < 4 ? (spi & 1) : (spi >> 1));
+          B is_own = ln.is_leg(own), is_oth = ln.is_leg(oth);
+          F sgn = lm::sel(is_own, one, lm::sel(is_oth, zero - one, zero));
+          F link = lm::sel(is_own, ln.lane_f((float)own_link), ln.lane_f((float)oth_link));
+          V3l Pb = mk3<F>(ln.lane_f(u6[0]), ln.lane_f(u6[1]), ln.lane_f(u6[2])), nb = mk3<F>(ln.lane_f(u6[3]), ln.lane_f(u6[4]), ln.lane_f(u6[5]));
+          F on3 = lm::sel(link > 2.5f, one, zero);
+          V3l a1v = mk3<F>(one, zero, zero);
+          V3l e1 = cross(a1v, Pb - k.p1), e2 = cross(k.a2, Pb - k.p2), e3 = scale(cross(k.a2, Pb - k.p3), on3);
+          SelfRow& rw = sr[slot];
+          rw.jt[0] = sgn * dot(nb, e1); rw.jt[1] = sgn * dot(nb, e2); rw.jt[2] = sgn * dot(nb, e3);
+          float vrow = L::qsum(rw.jt[0] * qs[0] + rw.jt[1] * qs[1] + rw.jt[2] * qs[2]);      // the base moves both points alike: no base part
+          lm_fwd(lf, rw.jt);
+          SV<F> yj = scale(lf.y1, rw.jt[0]) + scale(lf.y2, rw.jt[1]) + scale(lf.y3, rw.jt[2]);
+          F g6[6] = {zero - yj.a.x, zero - yj.a.y, zero - yj.a.z, zero - yj.l.x, zero - yj.l.y, zero - yj.l.z};
+          L::qsum6(g6, rw.gt);
+          fwd6(Sb, Sd, rw.gt);
+          float nn = L::qsum(rw.jt[0] * rw.jt[0] + rw.jt[1] * rw.jt[1] + rw.jt[2] * rw.jt[2]);
+          for (int i = 0; i < 6; i++) nn += rw.gt[i] * rw.gt[i];
+          rw.c = vrow + ((dmin > 0.0f) ? dmin * inv_dt : dmin * (P.erp * inv_dt));
+          rw.inv = have ? 1.0f / nn : 0.0f;
+          rw.lam = 0.0f;
+          if (!have) { for (int i = 0; i < 3; i++) rw.jt[i] = zero; for (int i = 0; i < 6; i++) rw.gt[i] = 0.0f; rw.c = 0.0f; }
+        }
+      }
+    }
     PMC_TSS(26);
 #if defined(PMC_ABLATION)
+    if (PMC_ABL(16) && ln.is_lane(0)) P.counters[4 + (long)env * PMC_TS_SLOTS + 28] += (unsigned long long)(any_self ? 1 : 0);
     if (PMC_ABL(16) && ln.is_lane(0)) {   // solver occupancy: active 4-turn blocks of this wave, contact and limit
       P.counters[4 + (long)env * PMC_TS_SLOTS + 30] += (unsigned long long)(any_c[0] + any_c[1] + any_c[2] + any_c[3]);
       P.counters[4 + (long)env * PMC_TS_SLOTS + 31] += (unsigned long long)(any_l[0] + any_l[1] + any_l[2]);
@@ -724,6 +860,10 @@ struct Pmc {
         F hi = mu * rn.lam;
         gs_round(ln, r1, zero - hi, hi, any_c, dx, dq);
         gs_round(ln, r2, zero - hi, hi, any_c, dx, dq);
+      }
+      if (any_self) {                                                        // then the self-collision rows, one after the other
+        self_turn(sr[0], dx, dq);
+        if (n_self_w > 1) self_turn(sr[1], dx, dq);
       }
     }
 

@@ -80,6 +80,24 @@ static inline std::string pmc_build_tables(const double* blob, int blob_len, std
       }
     }
   }
+  // self-collision capsules: thigh = long axis of the thigh box, radius its larger half thickness; shank = from the
+  // upper end of the shank box to the foot centre, radius the mean of the box's half thickness and the foot radius
+  for (int l = 0; l < 4; l++) {
+    PmcPrimView tb = pmc_prim(blob + LLM_OFF_LEG_PRIMS + (l * LLM_N_LEG_PRIMS + 1) * LLM_PRIM_STRIDE);
+    PmcPrimView sb = pmc_prim(blob + LLM_OFF_LEG_PRIMS + (l * LLM_N_LEG_PRIMS + 5) * LLM_PRIM_STRIDE);
+    PmcPrimView ft = pmc_prim(blob + LLM_OFF_LEG_PRIMS + (l * LLM_N_LEG_PRIMS + 6) * LLM_PRIM_STRIDE);
+    double d[3], len = 0;
+    for (int c = 0; c < 3; c++) { d[c] = ft.pos[c] - sb.pos[c]; len += d[c] * d[c]; }
+    len = sqrt(len);
+    for (int c = 0; c < 3; c++) {
+      L(LC_CAPS + 0 + c, l) = (float)(tb.pos[c] + tb.size[0] * tb.rot[3 * c]);
+      L(LC_CAPS + 3 + c, l) = (float)(tb.pos[c] - tb.size[0] * tb.rot[3 * c]);
+      L(LC_CAPS + 6 + c, l) = (float)(sb.pos[c] - sb.size[0] * d[c] / len);
+      L(LC_CAPS + 9 + c, l) = (float)ft.pos[c];
+    }
+    L(LC_CAPS + 12, l) = (float)(tb.size[1] > tb.size[2] ? tb.size[1] : tb.size[2]);
+    L(LC_CAPS + 13, l) = (float)(0.5 * ((sb.size[1] > sb.size[2] ? sb.size[1] : sb.size[2]) + ft.size[0]));
+  }
   // base
   double m = blob[LLM_OFF_BASE_MASS];
   const double* c = blob + LLM_OFF_BASE_COM;
@@ -187,6 +205,7 @@ static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
   P.erp = (float)LLM_ERP;
   P.margin_dist = (float)LLM_CONTACT_MARGIN;
   P.limit_gate = (float)LLM_LIMIT_GATE;
+  P.self_collision = 1.0f;
   double sw = 0;
   for (int i = 0; i < 5; i++) sw += cfg.reward_weights[i];               // PLE:365
   if (!(sw > 0)) return "reward_weights must sum to a positive number";

@@ -35,7 +35,7 @@
 #define NDOF 18
 #define KC LLM_MAX_CONTACTS_PER_LEG
 #define MAXC (4 * KC)
-#define MAXROWS (12 + 3 * MAXC)
+#define MAXROWS (12 + 3 * MAXC + 2)   /* limits + contacts (n, t1, t2) + self-collision rows */
 
 /* ------------------------------------------------------------------------------------------------ */
 /* small linear algebra                                                                             */
@@ -547,6 +547,8 @@ static int aba(const OModel* M, const OKin* K, const double* qd, const double* t
 
 /* gravity + Bullet's per-link velocity damping as external spatial forces (body coords) */
 static double g_link_damping = LLM_LINK_DAMPING;
+static int g_self_collision = 1;
+void orc_set_self_collision(int on) { g_self_collision = on; } /* tests: compare with / without */
 void orc_set_link_damping(double k) { g_link_damping = k; } /* tests: 0 makes free flight conservative */
 static void external_forces(const OModel* M, const OKin* K, double (*fext)[6]) {
   const double k1 = g_link_damping, k2 = g_link_damping;
@@ -700,6 +702,80 @@ static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double 
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+/* self-collision (LR:212-217 URDF_USE_SELF_COLLISION + ..._EXCLUDE_ALL_PARENTS): only links of DIFFERENT legs can touch     */
+/* (same-leg links and the body are ancestors of one another).  Spec of this build (unpinned): each leg is two  */
+/* capsules -- thigh: the long axis of the thigh box, radius = its larger half thickness; shank: from the upper end of the    */
+/* shank box to the foot centre, radius = the mean of the box's half thickness and the foot radius -- and the LLM_MAX_SELF   */
+/* closest capsule pairs within the contact margin give one frictionless row each.                                          */
+/* ------------------------------------------------------------------------------------------------ */
+#define MAX_SELF LLM_MAX_SELF
+typedef struct { int bodyA, bodyB; double P[3], n[3], depth; int pair; } OSelf;
+static void capsule(const OModel* M, const OKin* K, int leg, int which, double* a, double* b, double* r, int* body) {
+  const OPrim* lp = M->leg_prims[leg];
+  double la[3], lb[3];
+  if (which == 0) {                                   /* thigh */
+    const OPrim* bx = &lp[1];
+    for (int i = 0; i < 3; i++) { la[i] = bx->pos[i] + bx->size[0] * bx->rot[3 * i]; lb[i] = bx->pos[i] - bx->size[0] * bx->rot[3 * i]; }
+    *r = bx->size[1] > bx->size[2] ? bx->size[1] : bx->size[2];
+    *body = 2 + 3 * leg;
+  } else {                                            /* shank + foot */
+    const OPrim* bx = &lp[5]; const OPrim* ft = &lp[6];
+    double d[3], len;
+    for (int i = 0; i < 3; i++) d[i] = ft->pos[i] - bx->pos[i];
+    len = sqrt(v3dot(d, d));
+    for (int i = 0; i < 3; i++) { la[i] = bx->pos[i] - bx->size[0] * d[i] / len; lb[i] = ft->pos[i]; }
+    *r = 0.5 * ((bx->size[1] > bx->size[2] ? bx->size[1] : bx->size[2]) + ft->size[0]);
+    *body = 3 + 3 * leg;
+  }
+  double t[3];
+  m3v(K->Rw[*body], la, t); for (int i = 0; i < 3; i++) a[i] = K->pw[*body][i] + t[i];
+  m3v(K->Rw[*body], lb, t); for (int i = 0; i < 3; i++) b[i] = K->pw[*body][i] + t[i];
+}
+/* closest points of segments p1-q1, p2-q2 (Ericson, Real-Time Collision Detection 5.1.9) */
+static void seg_seg(const double* p1, const double* q1, const double* p2, const double* q2, double* c1, double* c2) {
+  double d1[3], d2[3], r[3];
+  for (int i = 0; i < 3; i++) { d1[i] = q1[i] - p1[i]; d2[i] = q2[i] - p2[i]; r[i] = p1[i] - p2[i]; }
+  double a = v3dot(d1, d1), e = v3dot(d2, d2), f = v3dot(d2, r), c = v3dot(d1, r), b = v3dot(d1, d2);
+  double den = a * e - b * b, s = den > 1e-12 ? (b * f - c * e) / den : 0.0, t;
+  if (s < 0) s = 0;
+  if (s > 1) s = 1;
+  t = (b * s + f) / e;
+  if (t < 0) { t = 0; s = -c / a; if (s < 0) s = 0; if (s > 1) s = 1; }
+  else if (t > 1) { t = 1; s = (b - c) / a; if (s < 0) s = 0; if (s > 1) s = 1; }
+  for (int i = 0; i < 3; i++) { c1[i] = p1[i] + s * d1[i]; c2[i] = p2[i] + t * d2[i]; }
+}
+/* pair index order: leg pairs (0,1) (1,2) (2,3) (3,0) (0,2) (1,3), then capsule pair (own, other) = (t,t) (s,t) (t,s) (s,s) */
+static int find_self_contacts(const OModel* M, const OKin* K, OSelf* out) {
+  static const int LA[6] = {0, 1, 2, 3, 0, 1}, LB[6] = {1, 2, 3, 0, 2, 3};
+  OSelf cand[24];
+  int nc = 0;
+  for (int lp = 0; lp < 6; lp++)
+    for (int sp = 0; sp < 4; sp++) {
+      double a1[3], b1[3], a2[3], b2[3], r1, r2, c1[3], c2[3], d[3];
+      int bA, bB;
+      capsule(M, K, LA[lp], sp & 1, a1, b1, &r1, &bA);
+      capsule(M, K, LB[lp], (sp >> 1) & 1, a2, b2, &r2, &bB);
+      seg_seg(a1, b1, a2, b2, c1, c2);
+      for (int i = 0; i < 3; i++) d[i] = c1[i] - c2[i];
+      double len = sqrt(v3dot(d, d));
+      if (len < 1e-9) continue;
+      OSelf* o = &cand[nc++];
+      o->bodyA = bA; o->bodyB = bB; o->depth = len - r1 - r2; o->pair = lp * 4 + sp;
+      for (int i = 0; i < 3; i++) { o->n[i] = d[i] / len; o->P[i] = 0.5 * ((c1[i] - r1 * o->n[i]) + (c2[i] + r2 * o->n[i])); }
+    }
+  int n = 0, taken[24] = {0};
+  for (int s = 0; s < MAX_SELF; s++) {
+    int best = -1;
+    for (int i = 0; i < nc; i++)
+      if (!taken[i] && cand[i].depth < LLM_SELF_MARGIN && (best < 0 || cand[i].depth < cand[best].depth)) best = i;
+    if (best < 0) break;
+    taken[best] = 1;
+    out[n++] = cand[best];
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
 /* one physics substep  ==  what stepSimulation() does at PLE:206 (spec: DESIGN.md)                  */
 /* ------------------------------------------------------------------------------------------------ */
 typedef struct {
@@ -810,6 +886,34 @@ static int substep_terrain(const OModel* M, double dt, int n_iter, double mu_foo
       nr++;
     }
   }
+  /* self-collision rows: n . (v_A(P) - v_B(P)) >= -depth/dt, no friction */
+  OSelf SC[MAX_SELF];
+  int ns = g_self_collision ? find_self_contacts(M, &K, SC) : 0, self_row[MAX_SELF];
+  for (int c = 0; c < ns; c++) {
+    self_row[c] = nr;
+    for (int d = 0; d < NDOF; d++) {
+      double e[NDOF];
+      memset(e, 0, sizeof e);
+      e[d] = 1.0;
+      OKin Kd;
+      kinematics(M, state, e, &Kd);
+      double rel = 0;
+      for (int side = 0; side < 2; side++) {
+        int b = side ? SC[c].bodyB : SC[c].bodyA;
+        double d3[3], ploc[3], t[3], vl[3], vw[3];
+        for (int i = 0; i < 3; i++) d3[i] = SC[c].P[i] - K.pw[b][i];
+        m3tv(K.Rw[b], d3, ploc);
+        v3cross(Kd.v[b], ploc, t);
+        for (int i = 0; i < 3; i++) vl[i] = Kd.v[b][3 + i] + t[i];
+        m3v(K.Rw[b], vl, vw);
+        rel += (side ? -1.0 : 1.0) * v3dot(SC[c].n, vw);
+      }
+      J[nr][d] = rel;
+    }
+    bias[nr] = SC[c].depth > 0 ? SC[c].depth / dt : LLM_ERP * SC[c].depth / dt;
+    lo[nr] = 0; hi[nr] = INFINITY; fric_of[nr] = -1; mu_row[nr] = 0;
+    nr++;
+  }
   /* M^-1 J^T by unit responses of the ABA at zero velocity */
   {
     static _Thread_local double Minv[NDOF][NDOF];
@@ -844,6 +948,7 @@ static int substep_terrain(const OModel* M, double dt, int n_iter, double mu_foo
     for (int k = 0; k < KC; k++)
       for (int l = 0; l < 4; l++)
         if (con_row[l][k] >= 0) order[no++] = con_row[l][k] + r;
+  for (int c = 0; c < ns; c++) order[no++] = self_row[c];      /* then the self-collision rows */
   double v0[MAXROWS];
   for (int r = 0; r < nr; r++) {
     double s = 0;
@@ -1131,6 +1236,19 @@ int orc_substep_terrain(const OBatch* B, double* state, const double* tau, doubl
   if (n_contacts) *n_contacts = d.n_contacts;
   if (lambda_out) memcpy(lambda_out, d.lambda, sizeof d.lambda);
   return rc;
+}
+
+/* tests: the self-collision candidates of a state: up to 2 rows [depth, pair index, P(3), n(3)]; returns how many */
+int orc_self_contacts(const OBatch* B, const double* state, double* rows8) {
+  OKin K;
+  kinematics(&B->model, state, NULL, &K);
+  OSelf sc[MAX_SELF];
+  int n = find_self_contacts(&B->model, &K, sc);
+  for (int i = 0; i < n; i++) {
+    rows8[8 * i] = sc[i].depth; rows8[8 * i + 1] = sc[i].pair;
+    for (int k = 0; k < 3; k++) { rows8[8 * i + 2 + k] = sc[i].P[k]; rows8[8 * i + 5 + k] = sc[i].n[k]; }
+  }
+  return n;
 }
 
 /* accessors used by the tests */

@@ -110,6 +110,9 @@ struct HostLanes {
       for (int l = 0; l < EW; l++) u.v[l] = u.v[l] + d.v[L_] * ks[t]->v[l];
     }
   }
+  static F from_prev_leg(const F& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = x.v[(i + 12) & 15]; return r; }
+  static F from_leg2(const F& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = x.v[(i + 8) & 15]; return r; }
+  static float rmin(const F& x) { float m = x.v[0]; for (int i = 1; i < EW; i++) m = fminf(m, x.v[i]); return m; }
   static bool any(const B& m) { for (int i = 0; i < EW; i++) if (m.v[i]) return true; return false; }
   F legc(const float* tbl, int field) const { fN r; for (int i = 0; i < EW; i++) r.v[i] = tbl[field * 4 + (i >> 2)]; return r; }
   F candc(int word) const { fN r; for (int i = 0; i < EW; i++) r.v[i] = candc_[word * 16 + i]; return r; }

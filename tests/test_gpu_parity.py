@@ -99,3 +99,8 @@ def test_scripted_episodes_against_reference_goldens(golden, model_blob, mocap_t
 
 def test_auto_reset_equals_manual_reset(model_blob, mocap_table):
     assert pc.check_auto_reset_equals_manual_reset(model_blob, mocap_table, None, n_envs=70) >= 5
+
+
+def test_self_collision_parity(golden, orc, model_blob, mocap_table):
+    out = pc.check_self_collision_parity(golden, orc, model_blob, mocap_table, None, n_envs=32)
+    assert out['stopped'] >= 16

@@ -58,3 +58,8 @@ def test_scripted_episodes_against_reference_goldens(golden, model_blob, mocap_t
 
 def test_auto_reset_equals_manual_reset(model_blob, mocap_table, emul_lib):
     assert pc.check_auto_reset_equals_manual_reset(model_blob, mocap_table, emul_lib) >= 5
+
+
+def test_self_collision_parity(golden, orc, model_blob, mocap_table, emul_lib):
+    out = pc.check_self_collision_parity(golden, orc, model_blob, mocap_table, emul_lib)
+    assert out['stopped'] >= 8

@@ -40,8 +40,9 @@ for k in order:
     rs = [x[d, k] for x, d in acc if d.any()]
     c = np.mean([r.mean() for r in rs]) if rs else float('nan'); e = np.mean([r.max() for r in rs]) if rs else float('nan')
     print('%-18s %8.2f %8.2f | %8.2f %8.2f' % (NAMES[k], a, b, c, e))
-occ = np.array([x[:, 30:32] for x in raw])          # cumulative block counts per env
+occ = np.array([x[:, 30:32] for x in raw]); occ_s = np.array([x[:, 28] for x in raw])          # cumulative block counts per env
 d = (occ[-1] - occ[0]) / (len(raw) - 1) / 10.0
 print('active 4-turn blocks per substep (wave level): contact %.2f of 4, limit %.2f of 3' % (d[:, 0].mean(), d[:, 1].mean()))
+print('substeps with a self-collision row somewhere in the wave: %.1f %%' % (100.0 * ((occ_s[-1] - occ_s[0]) / (len(raw) - 1) / 10.0).mean()))
 print('resets per step: %.1f' % np.mean([d.sum() for x, d in acc]))
 E.close()
