@@ -20,7 +20,12 @@ rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write 
 python tools/sweep.py "1024:4,2048:4,4096:4,8192:4,16384:4,32768:4,65536:4" > $OUT/sweep.txt 2>&1
 if [ -f tools/_build/libllenv_abl.so ]; then
   LL_DEBUG_FLAGS=16 LL_LIB=tools/_build/libllenv_abl.so python tools/timeline.py 4096 > $OUT/timeline.txt 2>&1
-  tools/ablate.sh run "0 1 2 3" "4096:4:10:10,4096:4:1:10" > $OUT/ablation.txt 2>&1
+  tools/ablate.sh run "0 1 2 3 256 512" "4096:4:10:10,4096:4:1:10" > $OUT/ablation.txt 2>&1
 fi
+# 5. the neighbours of the path: EPMC (bench line, kernel stats, element sweep) and the closed actor loop with the trained policy
+python bench.py --workload epmc --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/epmc_bench.log 2>$OUT/epmc_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/epmc_stats -- python bench.py --workload epmc --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2>&1
+python tools/sweep_epmc.py "4096:0,4096:1,4096:2,4096:3,16384:1,65536:1" > $OUT/epmc_sweep.txt 2>&1
+(python tools/rollout_policy.py 4096 300 hip; python tools/rollout_policy.py 65536 200 hip; python tools/rollout_policy.py 4096 300 torch) > $OUT/policy_rollout.txt 2>&1
 find $OUT -name "*.csv" -size +20M -delete
 tail -c 600 $OUT/bench.log
