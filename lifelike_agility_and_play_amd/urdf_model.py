@@ -191,6 +191,7 @@ class UrdfModel:
         self.q_hi = np.zeros(12)
         self.damping = np.zeros(12)
         self.foot_pos = np.zeros((4, 3))
+        self.wheel_pos = np.zeros((4, 3))                     # origin of the passive wheel link (joint_<leg>W) in the thigh frame
         self.joint_names = []
         leg_prims = []
         for l, leg in enumerate(LEG_NAMES):
@@ -210,6 +211,7 @@ class UrdfModel:
                 self.q_lo[i], self.q_hi[i], self.damping[i] = j['lo'], j['hi'], j['damping']
                 parent = j['child']
             self.foot_pos[l] = links['link_%s3' % leg].merged['joint_%s4' % leg][0]
+            self.wheel_pos[l] = links['link_%s2' % leg].merged['joint_%sW' % leg][0]
             # order this leg's primitives into the fixed slot structure
             slots = []
             pools = [list(links['link_%s%d' % (leg, k + 1)].prims) for k in range(3)]

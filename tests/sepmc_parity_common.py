@@ -1,0 +1,147 @@
+"""SEPMC parity checks shared by the oracle test, the CPU run of the kernel source (tests/emul) and the GPU run of libllenv.so:
+(a) the reference's own outputs in tests/golden/sepmc_golden.npz, (b) the float64 NumPy oracle (oracle/sepmc_oracle.py)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import sepmc_oracle as SO  # noqa: E402
+from oracle import epmc_oracle as EO  # noqa: E402
+
+TOL = 1e-9
+NOISE = {'pos_x_bias': [-0.1, 0.1], 'pos_y_bias': [-0.1, 0.1], 'yaw_bias': [-0.2, 0.2], 'pos_z_bias': [-0.02, 0.02]}
+N_FULL = 3
+
+
+def load_golden():
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'sepmc_golden.npz'))
+
+
+def env_config(elements, noisy=False, max_steps=1000):      # the dict gen_sepmc_golden.py passed to the reference
+    return {
+        'arena_id': 'CTG', 'render': False, 'control_freq': 50.0,
+        'prop_type': ['joint_pos', 'joint_vel', 'root_ang_vel_loc', 'root_lin_vel_loc', 'e_g'],
+        'kp': 50.0, 'kd': 0.5, 'max_tau': 16, 'max_steps': int(max_steps), 'obs_randomization': dict(NOISE) if noisy else {},
+        'env_randomize_config': {
+            'friction_range': [0.4, 3.0],
+            'disturb_force_config': {'start_time': 0.5, 'interval_time': 1.0, 'duration_time': 0.2, 'horizontal_force': [0, 50], 'vertical_force': [0, 10]},
+        },
+        'element_config': {'rand_cube': bool(elements[0]), 'hurdle': bool(elements[1]), 'hole': bool(elements[2])},
+    }
+
+
+def scripted_rays(call, n):          # the fake client's rayTestBatch answers (same arithmetic as gen_epmc_golden.scripted_rays)
+    i = np.arange(n)
+    return ((i * 7 + call * 13) % 10) < 7, (((i * 37 + call * 101) % 1009) + 0.5) / 1009.0
+
+
+def vis_blocked(drill, slot):        # the fake client's rayTest answers (gen_sepmc_golden.vis_blocked)
+    if drill % 4 == 0:
+        return True
+    if drill % 4 == 1:
+        return slot != 0
+    if drill % 4 == 2:
+        return slot != 1 + (drill % 10)
+    return slot != 11 + ((drill * 3) % 10)
+
+
+def drill_rays(drill, robot):
+    """(hit[778], frac[778]) of one robot in the engine's / oracle's ray order (height, horizontal, front); the reference casts
+    front r0, front r1, height r0, height r1, fan r0, fan r1 per drill (CTG:515-531)."""
+    hits, fracs = [], []
+    for call, n in ((6 * drill + 2 + robot, 325), (6 * drill + 4 + robot, 128), (6 * drill + robot, 325)):
+        h, f = scripted_rays(call, n)
+        hits.append(h); fracs.append(f)
+    return np.concatenate(hits), np.concatenate(fracs)
+
+
+def percep_checks(obs):
+    out = []
+    for a, b in ((135, 460), (460, 588), (588, 913)):
+        v = obs[a:b]
+        i = np.arange(len(v))
+        out += [v.sum(), (v * (i + 1)).sum() / len(v), (v * np.where(i % 2 == 0, 1.0, -1.0)).sum()]
+    return np.array(out)
+
+
+def core_of(obs):
+    return np.concatenate([obs[:135], obs[913:]])
+
+
+def contacts_of(rows):
+    return [tuple(int(x) for x in r) for r in rows if r[0] > -8.5]
+
+
+def make_oracle(g, model, elements, noisy, prev_orn, max_steps=1000):
+    init = g['init_states_info'].copy()
+    init[3:7] = prev_orn
+    return SO.SepmcOracleEnv(env_config(elements, noisy, max_steps), init, model)
+
+
+# ------------------------------------------------------------------------------------------------ oracle vs goldens
+def check_oracle_reset_case(g, model, k):
+    env = make_oracle(g, model, g['t_elements'][k], bool(g['t_noise_on'][k]), g['t_prev_orn'][k])
+    draws = SO.LoggedDraws(g['t_draws'][k][:g['t_n_draws'][k]])
+    obs = env.reset(draws, rays=lambda r, f, t: drill_rays(0, r), vis=lambda s, f, t: vis_blocked(0, s), contacts=lambda: [])
+    assert draws.exhausted()
+    n = g['t_n_boxes'][k]
+    assert len(env.statics) == n
+    np.testing.assert_allclose(env.statics, g['t_boxes'][k][:n], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(env.target_pos, g['t_flag'][k], atol=1e-12)
+    assert env.with_flag[0] == bool(g['t_with_flag'][k])
+    assert abs(env.foot_friction - g['t_friction'][k]) < 1e-12 and abs(env.episodic_fix_spd - g['t_fix_spd'][k]) < 1e-12
+    np.testing.assert_allclose(np.array(env.states), g['t_state'][k], atol=1e-12)
+    np.testing.assert_allclose(env.push.curr_force, g['t_push'][k], atol=1e-12)
+    assert abs(env.last_two_rob_pos_diff_len - g['t_last_two'][k]) < 1e-12 and abs(env.last_esc_flag_pos_diff_len - g['t_last_esc'][k]) < 1e-12
+    assert list(env.oppo_visible) == list(g['t_vis'][k])
+    if g['t_noise_on'][k]:
+        np.testing.assert_allclose([env.noise[key] for key in NOISE], g['t_noise'][k], atol=1e-12)
+    np.testing.assert_allclose(np.array(obs), g['t_obs'][k], rtol=0, atol=TOL)
+
+
+def check_oracle_episode(g, model, e):
+    n = int(g['e_n'][e])
+    env = make_oracle(g, model, g['e_elements'][e], bool(g['e_noise_on'][e]), g['e_prev_orn'][e], g['e_max_steps'][e])
+    draws = SO.LoggedDraws(g['e_draws'][e][:g['e_n_draws'][e]])
+    drill = [0]
+    kw = dict(rays=lambda r, f, t: drill_rays(drill[0], r), vis=lambda s, f, t: vis_blocked(drill[0], s))
+    obs = env.reset(draws, contacts=lambda: [], **kw)
+    np.testing.assert_allclose(np.array(obs), g['e_reset_obs'][e], rtol=0, atol=TOL)
+    np.testing.assert_allclose(np.array(env.states), g['e_init_state'][e], atol=1e-12)
+    vis_rows = g['e_vis'][e][:g['e_n_vis'][e]]
+
+    def check_rays(d):
+        for r in range(2):
+            np.testing.assert_allclose(env.ray_ends[r][0], g['e_ray_from'][e][d][r], atol=1e-9)
+            np.testing.assert_allclose(env.ray_ends[r][1], g['e_ray_to'][e][d][r], atol=1e-9)
+        want = vis_rows[vis_rows[:, 0] == d]
+        assert [s for (s, _, _) in env.vis_log] == [int(x) for x in want[:, 1]]            # same rayTest calls in the same order (early exits)
+        for (s, f, t), w in zip(env.vis_log, want):
+            np.testing.assert_allclose(np.concatenate([f, t]), w[2:8], atol=1e-9)
+    check_rays(0)
+    for t in range(n):
+        drill[0] = t + 1
+        st = [g['e_state'][e][0][t], g['e_state'][e][1][t]]
+        obs, rew, done, info = env.step([g['e_action'][e][0][t], g['e_action'][e][1][t]], draws, lambda k, tgt, f: st if k == env.n_sub - 1 else None,
+                                        contacts=lambda: contacts_of(g['e_contacts'][e][t]), **kw)
+        if t < N_FULL:
+            np.testing.assert_allclose(np.array(obs), g['e_obs_full'][e][t], rtol=0, atol=TOL)
+            check_rays(t + 1)
+        for r in range(2):
+            np.testing.assert_allclose(core_of(obs[r]), g['e_obs_core'][e][t][r], rtol=0, atol=TOL)
+            np.testing.assert_allclose(percep_checks(obs[r]), g['e_obs_checks'][e][t][r], rtol=1e-9, atol=1e-7)
+        np.testing.assert_allclose(rew, g['e_reward'][e][t], atol=1e-12)
+        assert done == bool(g['e_done'][e][t]), t
+        np.testing.assert_allclose(env.target_pos, g['e_flag'][e][t + 1], atol=1e-12)
+        assert env.with_flag[0] == bool(g['e_with_flag'][e][t + 1]) and env.switch_flag_at_this_frame == bool(g['e_switch'][e][t])
+        assert list(env.oppo_visible) == list(g['e_visible'][e][t + 1])
+        np.testing.assert_allclose(info, g['e_info'][e][t], atol=1e-12)
+        for k in range(10):
+            f = env.applied[k]
+            for r in range(2):
+                assert (f is not None) == bool(g['e_force_on'][e][t][k][r])
+                if f is not None:
+                    np.testing.assert_allclose(f[r], g['e_force'][e][t][k][r], atol=1e-12)
+    assert done and draws.exhausted()
