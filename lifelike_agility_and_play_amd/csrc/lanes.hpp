@@ -136,6 +136,14 @@ struct GpuLanes {
   // higher lanes, lane i receives lane (i - n) mod 16)
   static LL_D F from_prev_leg(F x) { return LL_DPP_MOV(x, 0x124); }
   static LL_D F from_leg2(F x) { return LL_DPP_MOV(x, 0x128); }
+  // value of x held by the same lane of the NEIGHBOURING row (row ^ 1 of the wave): the other robot of a SEPMC arena.
+  // gfx950 v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second.
+  LL_D F peer(F x) const {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+  }
+  LL_D float peer_u(float x) const { return peer(x); }
   // minimum over the 16 lanes of the row
   static LL_D float rmin(F x) {
     float y = fminf(x, LL_DPP_MOV(x, 0xB1));

@@ -16,6 +16,7 @@
 
 #include "lanes.hpp"
 #include "epmc_engine.hpp"
+#include "sepmc_engine.hpp"
 #include "pmc_engine.hpp"
 #include "pmc_step.hpp"
 
@@ -152,6 +153,30 @@ __global__ __launch_bounds__(PMC_WAVE) void epmc_reset_kernel(StepParams P, Epmc
   Epmc<GpuLanes>::reset_env(ln, P, E, env, draws ? draws + (long)i * EPMC_MAX_DRAWS : nullptr, prev_orn ? prev_orn + (long)i * 4 : nullptr);
 }
 
+// SEPMC (sepmc_step.hpp): one control step of ChaseTagGameEnv; row = 2 * arena + robot, the two robots of an arena are
+// neighbouring rows of one wave and exchange state with v_permlane16_swap.
+template <int OCC>
+__global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P, SepmcParams S) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int row = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
+  typedef typename std::conditional<OCC == 1, GpuLanes1, GpuLanes>::type Lanes;
+  Lanes ln(lds);
+  ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
+  if (row >= P.n_envs) return;
+  float act[3];
+  for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)row * 12 + j, 3);
+  Sepmc<Lanes>::step_env(ln, P, S, row, act);
+}
+__global__ __launch_bounds__(PMC_WAVE) void sepmc_reset_kernel(StepParams P, SepmcParams S, const int32_t* ids, int n, const float* draws, const float* prev_orn) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int i = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);     // ids lists rows in (robot 0, robot 1) pairs: pairs stay neighbours
+  GpuLanes ln(lds);
+  ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
+  if (i >= n) return;
+  const int row = ids ? ids[i] : i;
+  Sepmc<GpuLanes>::reset_env(ln, P, S, row, draws ? draws + (long)(i >> 1) * EPMC_MAX_DRAWS : nullptr, prev_orn ? prev_orn + (long)(i >> 1) * 4 : nullptr);
+}
+
 __global__ __launch_bounds__(PMC_WAVE) void pmc_reset_kernel(StepParams P, const int32_t* ids, int n, const int32_t* clip, const double* t0) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int i = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
@@ -254,6 +279,21 @@ struct HipBackend {
     hipLaunchKernelGGL(epmc_reset_kernel, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, E, ids, n, draws, prev_orn);
     HIPCHK(hipGetLastError());
   }
+  void launch_sepmc_step(const StepParams& P, const SepmcParams& S) {
+    use();
+    const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
+    std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin();
+    if (blocks <= simds) hipLaunchKernelGGL(sepmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, S);
+    else                 hipLaunchKernelGGL(sepmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, S);
+    HIPCHK(hipGetLastError());
+    if (ev) HIPCHK(hipEventRecord(ev->second, stream));
+  }
+  void launch_sepmc_reset(const StepParams& P, const SepmcParams& S, const int32_t* ids, int n, const float* draws, const float* prev_orn) {
+    use();
+    const int blocks = (n + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
+    hipLaunchKernelGGL(sepmc_reset_kernel, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, S, ids, n, draws, prev_orn);
+    HIPCHK(hipGetLastError());
+  }
   void launch_step(const StepParams& P) {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
@@ -294,4 +334,6 @@ typedef PmcEngine<HipBackend> ENGINE;
 #include "pmc_capi.inc"
 typedef EpmcEngine<HipBackend> EPMC_ENGINE;
 #include "epmc_capi.inc"
+typedef SepmcEngine<HipBackend> SEPMC_ENGINE;
+#include "sepmc_capi.inc"
 #include "pmc_policy.inc"

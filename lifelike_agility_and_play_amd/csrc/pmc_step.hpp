@@ -294,6 +294,12 @@ struct Pmc {
     const float* shapes;
     int n_shapes;
     float box_mu_scale;   // friction of a box relative to the plane's (default lateralFriction 0.5 vs plane.urdf 0.9)
+    // SEPMC (sepmc_step.hpp): when want_touch is set the substep also reports whether a leg / wheel link -- any link below the
+    // trunk except the foot sphere, CTG:427 -- has a contact point (within the margin) with the plane or a box other than
+    // shapes[flag_shape], and with shapes[flag_shape] (the flag); what getContactPoints() would list after this substep
+    bool want_touch;
+    int flag_shape;       // index into shapes, -1: none
+    mutable float touch_static, touch_flag;
   };
   // Signed distance of point E to record s (box united with its edge rods) and the outward normal there.  Inside a box the
   // face of least penetration gives both; near an edge outside, max(q) under-estimates the distance, which only makes a
@@ -558,6 +564,8 @@ struct Pmc {
       }
     }
     F depth[7];
+    const bool want_touch = TERRAIN && ex && ex->want_touch;
+    F tch_st = one, tch_fl = one;                             // 0 once a body link touches a static / the flag
     for (int jj = 0; jj < 7; jj++) {
       const int g = jj < 4 ? 0 : (jj < 6 ? 1 : 2);
       V3l A = mk3<F>(ln.candc(jj * CF_WORDS + CF_A), ln.candc(jj * CF_WORDS + CF_A + 1), ln.candc(jj * CF_WORDS + CF_A + 2));
@@ -566,6 +574,7 @@ struct Pmc {
       F az = dot(gez[g], ax);
       F len = lm::sqrt_(lm::max_(one - az * az, zero));      // 1 for spheres and vertices (ax = 0)
       F dpt = gz0[g] + dot(gez[g], A) - r * len;
+      F d_st = dpt, d_fl = far_;
       if (TERRAIN) {
         if (terr) {
           V3l Ew;
@@ -576,10 +585,26 @@ struct Pmc {
             V3l ns;
             shape_sdf<F>(ln, ex->shapes + si * 8, Ew, ds, ns, isb);
             dpt = lm::min_(dpt, ds - rs);
+            if (want_touch) {
+              B isf = ln.lane_f(si == ex->flag_shape ? 1.0f : 0.0f) > 0.5f;
+              d_fl = lm::sel(isf, lm::min_(d_fl, ds - rs), d_fl);
+              d_st = lm::sel(isf, d_st, lm::min_(d_st, ds - rs));
+            }
           }
+        }
+        if (want_touch) {
+          B body = lm::and_(link > 0.5f, ln.candc(jj * CF_WORDS + CF_KIND) < 0.5f);
+          tch_st = lm::sel(lm::and_(body, d_st < P.margin_dist), zero, tch_st);
+          tch_fl = lm::sel(lm::and_(body, d_fl < P.margin_dist), zero, tch_fl);
         }
       }
       depth[jj] = lm::sel(lm::and_(dpt < P.margin_dist, link > -0.5f), dpt, far_);
+    }
+    if (TERRAIN) {
+      if (want_touch) {
+        ex->touch_static = L::rmin(tch_st) < 0.5f ? 1.0f : 0.0f;
+        ex->touch_flag = L::rmin(tch_fl) < 0.5f ? 1.0f : 0.0f;
+      }
     }
     // the leg keeps its 4 deepest candidates, slot s = s-th deepest: four rounds of (local min, quad min, claim)
     F my_depth = far_, my_sub = zero, my_jj = zero;

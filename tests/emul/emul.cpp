@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "../../lifelike_agility_and_play_amd/csrc/epmc_engine.hpp"
+#include "../../lifelike_agility_and_play_amd/csrc/sepmc_engine.hpp"
 #include "../../lifelike_agility_and_play_amd/csrc/pmc_engine.hpp"
 #include "../../lifelike_agility_and_play_amd/csrc/pmc_step.hpp"
 
@@ -72,6 +73,33 @@ struct HostBackend {
     for (int i = 0; i < n; i++)
       Epmc<HostLanes>::reset_env(ln, P, E, ids ? ids[i] : i, draws ? draws + (long)i * EPMC_MAX_DRAWS : nullptr, prev_orn ? prev_orn + (long)i * 4 : nullptr);
   }
+  // SEPMC: the two robots of an arena run as two threads that meet in HostLanes::peer (on the GPU: two rows of one wave)
+  template <class FN>
+  static void run_pairs(const StepParams& P, int n_rows, FN fn) {
+    for (int i = 0; i + 1 < n_rows; i += 2) {
+      PairLink link;
+      std::thread t[2];
+      for (int side = 0; side < 2; side++)
+        t[side] = std::thread([&, side]() {
+          HostLanes ln(P.candc);
+          ln.link_ = &link; ln.side_ = side;
+          fn(ln, i + side);
+        });
+      t[0].join(); t[1].join();
+    }
+  }
+  void launch_sepmc_step(const StepParams& P, const SepmcParams& S) {
+    run_pairs(P, P.n_envs, [&](HostLanes& ln, int row) {
+      fN act[3];
+      for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)row * 12 + j, 3);
+      Sepmc<HostLanes>::step_env(ln, P, S, row, act);
+    });
+  }
+  void launch_sepmc_reset(const StepParams& P, const SepmcParams& S, const int32_t* ids, int n, const float* draws, const float* prev_orn) {
+    run_pairs(P, n, [&](HostLanes& ln, int i) {
+      Sepmc<HostLanes>::reset_env(ln, P, S, ids ? ids[i] : i, draws ? draws + (long)(i >> 1) * EPMC_MAX_DRAWS : nullptr, prev_orn ? prev_orn + (long)(i >> 1) * 4 : nullptr);
+    });
+  }
   void enable_timing(bool) {}
   void collect_timing(double* avg_ms, int* n) { *avg_ms = 0; *n = 0; }
 };
@@ -80,6 +108,8 @@ typedef PmcEngine<HostBackend> ENGINE;
 #include "../../lifelike_agility_and_play_amd/csrc/pmc_capi.inc"
 typedef EpmcEngine<HostBackend> EPMC_ENGINE;
 #include "../../lifelike_agility_and_play_amd/csrc/epmc_capi.inc"
+typedef SepmcEngine<HostBackend> SEPMC_ENGINE;
+#include "../../lifelike_agility_and_play_amd/csrc/sepmc_capi.inc"
 
 extern "C" {
 // single physics substep on explicit state (staged comparison with the oracle); tgt = PD target joint angles

@@ -5,6 +5,8 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #define EW 16
@@ -61,6 +63,23 @@ inline bN odd_(const iN& k) { bN r; for (int i = 0; i < EW; i++) r.v[i] = (k.v[i
 inline bN bit1_(const iN& k) { bN r; for (int i = 0; i < EW; i++) r.v[i] = (k.v[i] & 2) != 0; return r; }
 }  // namespace lm
 
+// Two robots of one SEPMC arena run as two host threads; peer() is their rendezvous (on the GPU: the neighbouring 16-lane row
+// of the same wave, v_permlane16_swap).  Both sides must make the same sequence of peer() calls.
+struct PairLink {
+  fN box[2];
+  std::atomic<int> arrived{0};
+  std::atomic<int> phase{0};
+  void barrier() {
+    const int ph = phase.load(std::memory_order_acquire);
+    if (arrived.fetch_add(1, std::memory_order_acq_rel) == 1) {
+      arrived.store(0, std::memory_order_relaxed);
+      phase.store(ph + 1, std::memory_order_release);
+    } else {
+      while (phase.load(std::memory_order_acquire) == ph) std::this_thread::yield();
+    }
+  }
+};
+
 struct HostLanes {
   typedef fN F;
   typedef iN I;
@@ -68,7 +87,18 @@ struct HostLanes {
   typedef bN B;
   const float* candc_;    // [words][16]
 
+  PairLink* link_ = nullptr;
+  int side_ = 0;
+
   explicit HostLanes(const float* candc) : candc_(candc) {}
+  F peer(const F& x) const {
+    link_->box[side_] = x;
+    link_->barrier();
+    F r = link_->box[1 - side_];
+    link_->barrier();
+    return r;
+  }
+  float peer_u(float x) const { return peer(fN(x)).v[0]; }
   void refresh_consts() const {}
   bool lane0() const { return true; }
   int ray_first() const { return 0; }

@@ -145,3 +145,143 @@ def check_oracle_episode(g, model, e):
                 if f is not None:
                     np.testing.assert_allclose(f[r], g['e_force'][e][t][k][r], atol=1e-12)
     assert done and draws.exhausted()
+
+
+# ------------------------------------------------------------------------------------------------ engine vs goldens
+OBS_TOL = 3e-5        # float32 engine vs float64 reference: ray lengths reach 20 m
+REW_TOL = 2e-6
+
+
+def draws_to_uniforms(log):
+    """(kind, a, b, value) rows of the reference's np.random log -> the U[0,1) numbers that reproduce them in the engine."""
+    u = np.zeros(len(log), dtype=np.float64)
+    for i, (k, a, b, v) in enumerate(log):
+        if int(k) == 0:
+            u[i] = (v - a) / (b - a) if b > a else 0.0
+        elif int(k) == 1:
+            u[i] = (v - a + 0.5) / (b - a)
+        else:
+            u[i] = v
+    return u.astype(np.float32)
+
+
+def make_engine(cfg_dict, n_arenas, lib_path, **kw):
+    from lifelike_agility_and_play_amd import sepmc_capi, urdf_model
+    cfg = sepmc_capi.make_sepmc_config(n_arenas, cfg_dict, **kw)
+    return sepmc_capi.SepmcEngine(cfg, urdf_model.default_model_blob(), lib_path=lib_path)
+
+
+def script_of(drill):
+    hit = np.array([drill_rays(drill, r)[0] for r in range(2)])
+    frac = np.array([drill_rays(drill, r)[1] for r in range(2)])
+    vis = np.array([vis_blocked(drill, s) for s in range(21)])
+    return hit, frac, vis
+
+
+def _reset_engine(E, g, draws_log, prev_orn):
+    from lifelike_agility_and_play_amd import sepmc_capi
+    u = np.full(sepmc_capi.LLS_MAX_DRAWS, 0.5, np.float32)
+    u[:len(draws_log)] = draws_to_uniforms(draws_log)
+    E.script_reset(*script_of(0))
+    E.reset(draws=u[None], prev_orn=np.asarray(prev_orn)[None])
+
+
+def _check_reset_state(E, boxes, flag, with_flag, friction, fix_spd, state, obs, push, noise, last_two, last_esc, visible):
+    rows, n = E.boxes()
+    assert n[0] == len(boxes)
+    np.testing.assert_allclose(rows[0][:n[0]], boxes[:, 1:7], atol=1e-6)
+    ep = E.episode()
+    np.testing.assert_allclose([ep['flag_x'][0], ep['flag_y'][0], ep['flag_z'][0]], flag, atol=1e-6)
+    assert bool(ep['with_flag0'][0] > 0.5) == bool(with_flag)
+    assert abs(ep['friction'][0] - friction) < 1e-6 and abs(ep['fix_spd'][0] - fix_spd) < 1e-6
+    np.testing.assert_allclose([ep['push_fx'][0], ep['push_fy'][0], ep['push_fz'][0]], push, atol=2e-5)
+    if noise is not None:
+        np.testing.assert_allclose([ep[k][0] for k in NOISE], noise, atol=1e-7)
+    assert abs(ep['last_two_rob_pos_diff_len'][0] - last_two) < 1e-5 and abs(ep['last_esc_flag_pos_diff_len'][0] - last_esc) < 1e-5
+    assert [bool(ep['visible0'][0] > 0.5), bool(ep['visible1'][0] > 0.5)] == [bool(x) for x in visible]
+    np.testing.assert_allclose(E.state()[0], state, atol=2e-6)
+    np.testing.assert_allclose(E.obs()[0], obs, rtol=0, atol=OBS_TOL)
+
+
+def check_engine_reset_cases(lib_path):
+    """CTG.reset() inside the engine from the reference's own draws: arena, flag, roles, friction, push, noise, both start poses
+    (incl. the shared in-place start orientation) and both first observations of the 15 golden cases."""
+    g = load_golden()
+    for k in range(len(g['t_seed'])):
+        noisy = bool(g['t_noise_on'][k])
+        E = make_engine(env_config(g['t_elements'][k], noisy), 1, lib_path)
+        _reset_engine(E, g, g['t_draws'][k][:g['t_n_draws'][k]], g['t_prev_orn'][k])
+        _check_reset_state(E, g['t_boxes'][k][:g['t_n_boxes'][k]], g['t_flag'][k], g['t_with_flag'][k], g['t_friction'][k], g['t_fix_spd'][k], g['t_state'][k],
+                           g['t_obs'][k], g['t_push'][k], g['t_noise'][k] if noisy else None, g['t_last_two'][k], g['t_last_esc'][k], g['t_vis'][k])
+        E.close()
+
+
+def check_engine_episodes(lib_path, model):
+    """The 4 scripted golden episodes through ll_sepmc_step_scripted: observations, ray and visibility end points, flag hand-over,
+    first-contact-wins bookkeeping, rewards, termination, info and the two-robot push schedule, step by step."""
+    from lifelike_agility_and_play_amd import sepmc_capi
+    g = load_golden()
+    for e in range(len(g['e_n'])):
+        n = int(g['e_n'][e])
+        noisy = bool(g['e_noise_on'][e])
+        cfg = env_config(g['e_elements'][e], noisy, g['e_max_steps'][e])
+        E = make_engine(cfg, 1, lib_path)
+        # the oracle runs alongside only to cut the reference's draw log into per-call pieces
+        orc = make_oracle(g, model, g['e_elements'][e], noisy, g['e_prev_orn'][e], g['e_max_steps'][e])
+        log = g['e_draws'][e][:g['e_n_draws'][e]]
+        draws = SO.LoggedDraws(log)
+        drill = [0]
+        kw = dict(rays=lambda r, f, t: drill_rays(drill[0], r), vis=lambda s, f, t: vis_blocked(drill[0], s))
+        orc.reset(draws, contacts=lambda: [], **kw)
+        _reset_engine(E, g, log[:draws.i], g['e_prev_orn'][e])
+        np.testing.assert_allclose(E.obs()[0], g['e_reset_obs'][e], rtol=0, atol=OBS_TOL)
+        np.testing.assert_allclose(E.state()[0], g['e_init_state'][e], atol=2e-6)
+        vis_rows = g['e_vis'][e][:g['e_n_vis'][e]]
+
+        def check_rays(d):
+            f, t, _, _ = E.rays()
+            np.testing.assert_allclose(f[0], g['e_ray_from'][e][d], atol=OBS_TOL)
+            np.testing.assert_allclose(t[0], g['e_ray_to'][e][d], atol=OBS_TOL)
+            v = E.vis()[0]
+            for w in vis_rows[vis_rows[:, 0] == d]:                         # every segment the reference asked about
+                s = int(w[1])
+                assert v[s][7] > 0.5
+                np.testing.assert_allclose(v[s][:6], w[2:8], atol=OBS_TOL)
+                assert bool(v[s][6] > 0.5) == bool(w[8])
+        check_rays(0)
+        for t in range(n):
+            drill[0] = t + 1
+            i0 = draws.i
+            st = [g['e_state'][e][0][t], g['e_state'][e][1][t]]
+            orc.step([g['e_action'][e][0][t], g['e_action'][e][1][t]], draws, lambda k, tgt, f: st if k == orc.n_sub - 1 else None,
+                     contacts=lambda: contacts_of(g['e_contacts'][e][t]), **kw)
+            u = draws_to_uniforms(log[i0:draws.i])
+            cl = np.full((sepmc_capi.LLS_MAX_CONTACTS, 4), -9, np.int32)
+            rows = contacts_of(g['e_contacts'][e][t])
+            if rows:
+                cl[:len(rows)] = rows
+            hit, frac, vis = script_of(t + 1)
+            E.step_scripted(np.array([g['e_action'][e][0][t], g['e_action'][e][1][t]]), np.array(st), hit, frac, vis, cl, draws=u[None] if len(u) else None)
+            obs = E.obs()[0].astype(np.float64)
+            if t < N_FULL:
+                np.testing.assert_allclose(obs, g['e_obs_full'][e][t], rtol=0, atol=OBS_TOL)
+                check_rays(t + 1)
+            for r in range(2):
+                np.testing.assert_allclose(core_of(obs[r]), g['e_obs_core'][e][t][r], rtol=0, atol=OBS_TOL)
+                np.testing.assert_allclose(percep_checks(obs[r]), g['e_obs_checks'][e][t][r], rtol=1e-5, atol=2e-3)
+            rew, done, why = E.reward_done()
+            np.testing.assert_allclose(rew[0], g['e_reward'][e][t], atol=REW_TOL)
+            assert bool(done[0]) == bool(g['e_done'][e][t]), (e, t)
+            ep = E.episode()
+            np.testing.assert_allclose([ep['flag_x'][0], ep['flag_y'][0], ep['flag_z'][0]], g['e_flag'][e][t + 1], atol=1e-6)
+            assert bool(ep['with_flag0'][0] > 0.5) == bool(g['e_with_flag'][e][t + 1]) and bool(ep['switch'][0] > 0.5) == bool(g['e_switch'][e][t])
+            assert [bool(ep['visible0'][0] > 0.5), bool(ep['visible1'][0] > 0.5)] == [bool(x) for x in g['e_visible'][e][t + 1]], (e, t)
+            np.testing.assert_allclose(E.info()[0], g['e_info'][e][t], atol=2e-5)
+            pt = E.push_trace()[0]                                        # [robot][substep][4]
+            for r in range(2):
+                assert [bool(x > 0.5) for x in pt[r][:, 0]] == [bool(x) for x in g['e_force_on'][e][t][:, r]], (e, t, r)
+                np.testing.assert_allclose(pt[r][:, 1:4], g['e_force'][e][t][:, r], atol=5e-5)
+        assert done[0] and draws.exhausted()
+        if e == 0:
+            assert why[0] == sepmc_capi.DONE_CATCH
+        E.close()

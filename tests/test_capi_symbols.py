@@ -57,3 +57,16 @@ def test_policy_header_binding_and_library_agree():
     for name in declared:
         assert hasattr(lib, name), name
     assert pmc_policy_hip.pack_weights().size == pmc_policy_hip.LLP_N_FLOATS == 358647
+
+
+def test_sepmc_header_binding_and_library_agree():
+    """include/llenv_sepmc.h (the two-robot chase-tag env) == sepmc_capi._SIGS == what libllenv.so exports."""
+    from lifelike_agility_and_play_amd import sepmc_capi
+    text = open(os.path.join(ROOT, 'include', 'llenv_sepmc.h')).read()
+    declared = sorted(set(re.findall(r'\b(ll_sepmc_[a-z0-9_]+)\s*\(', text)))
+    assert declared == sepmc_capi.EXPORTED_SYMBOLS
+    import __graft_entry__ as g
+    g.build_hip()
+    lib = sepmc_capi.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
