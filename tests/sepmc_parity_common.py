@@ -285,3 +285,109 @@ def check_engine_episodes(lib_path, model):
         if e == 0:
             assert why[0] == sepmc_capi.DONE_CATCH
         E.close()
+
+
+# ------------------------------------------------------------------------------------------------ free-running checks
+ALL_ELEMENTS = (1, 1, 1)
+
+
+def boxes_with_flag(E, a):
+    rows, n = E.boxes()
+    ep = E.episode()
+    st = [[0.0, *rows[a][b][:3], *rows[a][b][3:6], 0.0] for b in range(n[a])]
+    st.append(list(SO.flag_box([ep['flag_x'][a], ep['flag_y'][a], ep['flag_z'][a]])))
+    return np.array(st, dtype=np.float64)
+
+
+def check_free_running(lib_path, n_arenas=8, steps=120, seed=3):
+    """Real physics, rays and contacts: invariants between the two robots' views, analytic rays and visibility segments against
+    the oracle's cast_rays on the engine's own arena, episodes ending and restarting."""
+    E = make_engine(env_config(ALL_ELEMENTS), n_arenas, lib_path, auto_reset=1, seed=seed)
+    E.reset()
+    ends = 0
+    for t in range(steps):
+        E.fill_random_actions(np.exp(-2.0))
+        E.step()
+        if t % 20 == 19 or t == steps - 1:
+            obs = E.obs().astype(np.float64)
+            assert np.isfinite(obs).all()
+            rew, done, why = E.reward_done()
+            assert np.all(np.abs(rew[:, 0] + rew[:, 1]) < 1e-6)                                  # zero sum
+            np.testing.assert_allclose(obs[:, 0, 913 + 35:913 + 39], obs[:, 1, 913 + 35:913 + 39], atol=0)      # the same flag
+            np.testing.assert_allclose(obs[:, 0, 913 + 49], obs[:, 1, 913 + 50], atol=0)          # with_flag rows mirror each other
+            np.testing.assert_allclose(obs[:, 0, 913 + 21:913 + 24], obs[:, 1, 913:913 + 3], atol=0)            # my oppo_pos is its position
+            np.testing.assert_allclose(obs[:, 1, 913 + 21:913 + 24], obs[:, 0, 913:913 + 3], atol=0)
+            f, tt, hit, frac = E.rays()
+            vis = E.vis()
+            same = tot = 0
+            for a in range(min(n_arenas, 3)):
+                if done[a]:
+                    continue                      # the rays of a re-seeded arena saw the new arena; episode() reports it too, but keep it simple
+                bx = boxes_with_flag(E, a)
+                ep = E.episode()
+                if ep['switch'][a] > 0.5:
+                    continue                      # the flag moved after the rays were cast
+                for r in range(2):
+                    h2, f2 = SO.cast_rays(f[a][r], tt[a][r], bx)
+                    same += int((h2 == hit[a][r]).sum()); tot += len(h2)
+                    both = h2 & hit[a][r]
+                    np.testing.assert_allclose(frac[a][r][both], f2[both], atol=3e-4)
+                asked = vis[a][:, 7] > 0.5
+                hb, _ = SO.cast_rays(vis[a][asked, 0:3], vis[a][asked, 3:6], bx)
+                assert (hb == (vis[a][asked, 6] > 0.5)).mean() > 0.9
+            if tot:
+                assert same / tot > 0.995, same / tot
+        ends = E.counters()['episodes']
+    assert ends > 0                                 # random actions make robot 0 fall within the run
+    st = E.state()
+    assert np.isfinite(st).all() and np.all(np.abs(st[:, :, 0:2]) < 2.6)                             # nobody left through a wall
+    out = dict(episodes=ends)
+    E.close()
+    return out
+
+
+def check_flag_handover_physical(lib_path):
+    """The robot that may take the flag is put with a thigh onto it: the engine's own contact test hands the flag over (reward
+    +-1, a new flag position), and a robot that already holds it does not trigger anything."""
+    E = make_engine(env_config((0, 0, 0)), 2, lib_path, auto_reset=0, seed=11)
+    E.reset()
+    ep = E.episode()
+    st = E.state().astype(np.float64)
+    flag0 = np.array([ep['flag_x'], ep['flag_y']]).T.copy()
+    wf0 = ep['with_flag0'].copy()
+    for a in range(2):
+        taker = 1 if wf0[a] > 0.5 else 0                       # CTG:579-581
+        who = taker if a == 0 else 1 - taker                   # arena 0: the taker touches; arena 1: the holder touches (nothing happens)
+        st[a, who, 0:2] = flag0[a] - np.array([0.195, -0.15])
+        st[a, who, 2] = 0.32
+        st[a, who, 3:7] = [0, 0, 0, 1]
+        st[a, 1 - who, 0:2] = -np.sign(flag0[a]) * 1.5       # the other one far away
+    E.set_state(st)
+    E.step_host(np.zeros((2, 2, 12)))
+    ep2 = E.episode()
+    rew, done, why = E.reward_done()
+    assert ep2['switch'][0] > 0.5 and ep2['with_flag0'][0] != wf0[0]
+    assert abs(ep2['flag_x'][0] - flag0[0][0]) + abs(ep2['flag_y'][0] - flag0[0][1]) > 1e-3
+    taker = 1 if wf0[0] > 0.5 else 0
+    assert rew[0][taker] == 1.0 and rew[0][1 - taker] == -1.0
+    assert ep2['switch'][1] < 0.5 and ep2['with_flag0'][1] == wf0[1] and rew[1][0] == 0.0
+    E.close()
+
+
+def check_free_running_big(lib_path, n_arenas, steps):
+    E = make_engine(env_config(ALL_ELEMENTS), n_arenas, lib_path, auto_reset=1, seed=5)
+    E.reset()
+    for t in range(steps):
+        E.fill_random_actions(np.exp(-2.0))
+        E.step()
+    obs = E.obs().astype(np.float64)
+    rew, done, why = E.reward_done()
+    st = E.state()
+    assert np.isfinite(obs).all() and np.isfinite(st).all()
+    assert np.all(np.abs(rew[:, 0] + rew[:, 1]) < 1e-6)
+    np.testing.assert_allclose(obs[:, 0, 913 + 35:913 + 39], obs[:, 1, 913 + 35:913 + 39], atol=0)
+    np.testing.assert_allclose(obs[:, 0, 913 + 21:913 + 24], obs[:, 1, 913:913 + 3], atol=0)
+    c = E.counters()
+    assert c['episodes'] > 0 and c['nonfinite'] == 0
+    E.close()
+    return c

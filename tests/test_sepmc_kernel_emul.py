@@ -25,3 +25,12 @@ def test_reset_cases_against_reference_goldens(emul_lib):
 
 def test_scripted_episodes_against_reference_goldens(emul_lib, model_blob):
     SC.check_engine_episodes(emul_lib, SO.BlobModel(model_blob))
+
+
+def test_free_running_invariants(emul_lib):
+    out = SC.check_free_running(emul_lib, n_arenas=4, steps=80)
+    print(out)
+
+
+def test_flag_handover_by_physical_contact(emul_lib):
+    SC.check_flag_handover_physical(emul_lib)
