@@ -75,12 +75,14 @@ def main():
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--workload', choices=['pmc', 'epmc'], default='pmc',
-                    help="pmc = BASELINE config 2 (the contract line); epmc = config 4 (PlayGroundEnv, DESIGN.md 8), same JSON shape")
+    ap.add_argument('--workload', choices=['pmc', 'epmc', 'sepmc'], default='pmc',
+                    help="pmc = BASELINE config 2 (the contract line); epmc = config 4 (PlayGroundEnv, DESIGN.md 8), sepmc = config 5 (ChaseTagGameEnv, 2048 arenas x 2 robots, DESIGN.md 8b), same JSON shape")
     ap.add_argument('--element', type=int, default=1, help='epmc only: env_randomize_config element_id (0 joystick, 1 hurdles, 2 holes, 3 cubes)')
     args = ap.parse_args()
     if args.workload == 'epmc':
         return main_epmc(args)
+    if args.workload == 'sepmc':
+        return main_sepmc(args)
 
     import torch
     import torch.distributed as dist
@@ -259,6 +261,74 @@ def main_epmc(args):
                          'kernel': 'epmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
                          'algorithmic_bytes_per_env_step': EPMC_ALGO_BYTES_PER_ENV_STEP,
                          'note': 'bound by single-wave instruction issue and per-(ray, box) LDS latency, not HBM; see DESIGN.md 8'}}), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def sepmc_env_config():
+    """train_scripts/example_sepmc_train.sh:93-117 (BASELINE config 5: no arena elements)."""
+    return {'arena_id': 'CTG', 'render': False, 'control_freq': 50.0, 'prop_type': list(PMC_PROP_TYPE), 'kp': 50.0, 'kd': 0.5, 'max_tau': 16, 'max_steps': 1000,
+            'obs_randomization': {},
+            'env_randomize_config': {'friction_range': [0.4, 3.0],
+                                     'disturb_force_config': {'start_time': 0.5, 'interval_time': 1.0, 'duration_time': 0.2, 'horizontal_force': [0, 50], 'vertical_force': [0, 10]}},
+            'element_config': {'rand_cube': False, 'hurdle': False, 'hole': False}}
+
+
+SEPMC_ALGO_BYTES_PER_ROBOT_STEP = 37 * 4 * 2 + 965 * 4 + 135 * 4 + 12 * 4 + 40 * 4 * 2 + 13 * 8 * 4 + 16   # state r/w, obs w, history r, action, scalars r/w, boxes r, reward/done
+
+
+def main_sepmc(args):
+    """Same measurement for the SEPMC env (not the driver's contract line): robot-steps/s of envs_per_gpu / 2 chase-tag arenas per GPU."""
+    import torch
+    import torch.distributed as dist
+    from lifelike_agility_and_play_amd import sepmc_capi, urdf_model
+    world = int(os.environ.get('WORLD_SIZE', '1')); rank = int(os.environ.get('RANK', '0')); local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(os.environ.get('LL_BENCH_BACKEND', 'nccl'), rank=rank, world_size=world)
+    n_arenas = args.envs_per_gpu // 2                              # 4096 robots = the 2048 arenas of BASELINE config 5
+    cfg = sepmc_capi.make_sepmc_config(n_arenas, sepmc_env_config(), auto_reset=1, seed=1234 + rank, device=local_rank)
+    eng = sepmc_capi.SepmcEngine(cfg, urdf_model.default_model_blob())
+    eng.reset()
+
+    def one_step():
+        eng.fill_random_actions(SIGMA)
+        eng.step()
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    eng.sync(); torch.cuda.synchronize()
+    eng.enable_kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    eng.sync(); torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_n = eng.kernel_time_ms()
+    if world > 1:
+        tt = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        achieved = 2 * n_arenas * SEPMC_ALGO_BYTES_PER_ROBOT_STEP / (k_ms * 1e-3) / 1e9
+        print(json.dumps({
+            'metric': 'robot-steps/sec (whole node), SEPMC chase-tag env, random policy', 'value': world * 2 * n_arenas * args.steps / elapsed, 'unit': 'robot-steps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'SEPMC ChaseTagGameEnv (BASELINE config 5), %d arenas x 2 robots per MI355X, 2 x 778 perception rays + 21 visibility rays per '
+                                   'arena-step, two-robot push schedule, robot-robot contact, random-policy actions N(0, e^-2), auto-reset' % n_arenas,
+                       'arenas_per_gpu': n_arenas, 'episodes_finished_rank0': eng.counters()['episodes']},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'kernel': 'sepmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
+                         'algorithmic_bytes_per_robot_step': SEPMC_ALGO_BYTES_PER_ROBOT_STEP,
+                         'note': 'bound by single-wave instruction issue, not HBM; see DESIGN.md 8b'}}), flush=True)
     eng.close()
     if world > 1:
         dist.destroy_process_group()

@@ -478,7 +478,7 @@ struct Epmc {
     if (counter % cmd_freq == 0) ep[EP_TARGET_SPD] = d.uniform(E.spd_lo, E.spd_hi);   // PGE:312-313
 
     typename K::SubstepExtra ex;
-    ex.want_touch = false; ex.flag_shape = -1;
+    ex.want_touch = false; ex.flag_shape = -1; ex.pair_active = false; ex.pair_me = 0;
     ex.mu_foot = ep[EP_FRICTION] * E.plane_friction;
     // terrain within reach of the robot's contact candidates during this control step: boxes whose footprint, grown by 0.9 m
     // (leg reach 0.45 m + the distance covered in 20 ms + margin), contains the base; kept in the row's LDS scratch

@@ -136,6 +136,7 @@ struct GpuLanes {
   // higher lanes, lane i receives lane (i - n) mod 16)
   static LL_D F from_prev_leg(F x) { return LL_DPP_MOV(x, 0x124); }
   static LL_D F from_leg2(F x) { return LL_DPP_MOV(x, 0x128); }
+  static LL_D F from_next_leg(F x) { return LL_DPP_MOV(x, 0x12C); }   // row_ror:12: the same sub-lane of leg (leg + 1) % 4
   // value of x held by the same lane of the NEIGHBOURING row (row ^ 1 of the wave): the other robot of a SEPMC arena.
   // gfx950 v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second.
   LL_D F peer(F x) const {

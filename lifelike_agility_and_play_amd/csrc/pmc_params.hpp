@@ -30,7 +30,8 @@ enum LegConst {
   LC_SHBOX = 114,     // 12 box on the shank link
   LC_FOOTSPH = 126,   // 4  foot sphere on the shank link: c(3) r
   LC_CAPS = 130,      // 14 self-collision capsules: thigh a(3) b(3) in the thigh frame, shank a(3) b(3) in the shank frame, r_thigh, r_shank
-  LC_COUNT = 144
+  LC_TRUNKCAP = 144,  // 7  robot-robot collision (SEPMC): trunk capsule (leg & 1) of the two that stand for the body box: a(3) b(3) in F0, r
+  LC_COUNT = 151
 };
 
 // ---- contact candidate table: candc[(jj * CF_WORDS + field) * 16 + leg * 4 + sub], 7 candidates per (leg, sub) --------------

@@ -300,6 +300,12 @@ struct Pmc {
     bool want_touch;
     int flag_shape;       // index into shapes, -1: none
     mutable float touch_static, touch_flag;
+    // PAIR builds (SEPMC): the other robot of the arena lives in the neighbouring row; pair_active = the two are close enough to
+    // touch during this control step (the same value in both rows), pair_me = 0 / 1.  touch_robot (with want_touch): one of my leg /
+    // wheel links -- a thigh capsule, or a shank capsule away from its foot end -- is within the margin of the other robot
+    bool pair_active;
+    int pair_me;
+    mutable float touch_robot;
   };
   // Signed distance of point E to record s (box united with its edge rods) and the outward normal there.  Inside a box the
   // face of least penetration gives both; near an edge outside, max(q) under-estimates the distance, which only makes a
@@ -335,6 +341,10 @@ struct Pmc {
   }
   // closest points of the segments p1-q1 and p2-q2 (Ericson 5.1.9; same branches as the oracle's seg_seg)
   static LL_HD void seg_seg(const L& ln, const V3l& p1, const V3l& q1, const V3l& p2, const V3l& q2, V3l& c1, V3l& c2) {
+    F s, t;
+    seg_seg_st(ln, p1, q1, p2, q2, c1, c2, s, t);
+  }
+  static LL_HD void seg_seg_st(const L& ln, const V3l& p1, const V3l& q1, const V3l& p2, const V3l& q2, V3l& c1, V3l& c2, F& s, F& t) {
     const F zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f);
     V3l d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
     F a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2);
@@ -342,9 +352,9 @@ struct Pmc {
     F s0 = lm::sel(den > 1e-9f, lm::min_(lm::max_((b * f - c * e) / lm::max_(den, ln.lane_f(1e-9f)), zero), one), zero);
     F t0 = (b * s0 + f) / e;
     B lt = t0 < 0.0f, gt = t0 > 1.0f;
-    F t = lm::sel(lt, zero, lm::sel(gt, one, t0));
+    t = lm::sel(lt, zero, lm::sel(gt, one, t0));
     F s_alt = lm::min_(lm::max_(lm::sel(lt, zero - c, b - c) / a, zero), one);
-    F s = lm::sel(lm::or_(lt, gt), s_alt, s0);
+    s = lm::sel(lm::or_(lt, gt), s_alt, s0);
     c1 = p1 + scale(d1, s);
     c2 = p2 + scale(d2, t);
   }
@@ -358,6 +368,21 @@ struct Pmc {
   static LL_HD void self_turn(SelfRow& rw, float* dx, F* dq) {
     float w = rw.c + L::qsum(rw.jt[0] * dq[0] + rw.jt[1] * dq[1] + rw.jt[2] * dq[2]);
     for (int i = 0; i < 6; i++) w += rw.gt[i] * dx[i];
+    float nl = rw.lam - w * rw.inv;
+    if (nl < 0.0f) nl = 0.0f;
+    const float d = nl - rw.lam;
+    rw.lam = nl;
+    for (int j = 0; j < 3; j++) dq[j] = dq[j] + rw.jt[j] * d;
+    for (int i = 0; i < 6; i++) dx[i] += rw.gt[i] * d;
+  }
+
+  // robot-robot row (SEPMC): the same frictionless turn, with the other robot's share of the row velocity fetched from its row; both
+  // rows add the two shares in the same order (robot 0's first), so both apply the same multiplier
+  static LL_HD void pair_turn(const L& ln, SelfRow& rw, float* dx, F* dq, int me) {
+    float mine = L::qsum(rw.jt[0] * dq[0] + rw.jt[1] * dq[1] + rw.jt[2] * dq[2]);
+    for (int i = 0; i < 6; i++) mine += rw.gt[i] * dx[i];
+    const float theirs = ln.peer_u(mine);
+    const float w = rw.c + ((me == 0) ? mine + theirs : theirs + mine);
     float nl = rw.lam - w * rw.inv;
     if (nl < 0.0f) nl = 0.0f;
     const float d = nl - rw.lam;
@@ -384,7 +409,8 @@ struct Pmc {
     substep_impl<false>(ln, P, bs, q, qd, tgt, env, sidx, ex);
   }
   // TERRAIN: contact candidates are also tested against ex->shapes, and a contact's normal is that of the shape it touches
-  template <bool TERRAIN>
+  // PAIR: contacts with the other robot of a SEPMC arena (the neighbouring row) are found and solved too
+  template <bool TERRAIN, bool PAIR = false>
   static LL_HD void substep_impl(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env, int sidx, const SubstepExtra* ex) {
 #define PMC_TSS(k) do { if (sidx == 5) PMC_TS(k); } while (0)
     const float* legc = P.legc;
@@ -862,6 +888,178 @@ struct Pmc {
         }
       }
     }
+    // --- robot-robot contact (SEPMC): each robot is ten capsules -- thigh and shank-with-foot of every leg as in the
+    //     self-collision test, and two for the trunk.  Both rows evaluate all 100 pairs with robot 0's capsule as the first segment, on
+    //     bit-identical inputs (world end points computed once and copied across), so both find the same two deepest contacts.
+    SelfRow pr[2];
+    bool any_pair = false;
+    int n_pair_w = 0;
+    if (PAIR) {
+      pr[0].inv = pr[1].inv = 0.0f; pr[0].lam = pr[1].lam = 0.0f; pr[0].c = pr[1].c = 0.0f;
+      for (int i = 0; i < 3; i++) pr[0].jt[i] = pr[1].jt[i] = zero;
+      for (int i = 0; i < 6; i++) pr[0].gt[i] = pr[1].gt[i] = 0.0f;
+      if (ex->want_touch) ex->touch_robot = 0.0f;
+      if (L::any(ln.lane_f(ex->pair_active ? 1.0f : 0.0f) > 0.5f)) {
+        const int me = ex->pair_me;
+        const B act = ln.lane_f(ex->pair_active ? 1.0f : 0.0f) > 0.5f, i_am_0 = ln.lane_f(me == 0 ? 1.0f : 0.0f) > 0.5f;
+        // my capsules in world coordinates: [0] thigh, [1] shank, [2] the trunk capsule this leg holds
+        V3l wa[3], wb[3];
+        F wr[3];
+        {
+          V3l ab[3] = {k.p2 + mul(k.R2, ld3c(ln, legc, LC_CAPS)), k.p3 + mul(k.R3, ld3c(ln, legc, LC_CAPS + 6)), ld3c(ln, legc, LC_TRUNKCAP)};
+          V3l bb[3] = {k.p2 + mul(k.R2, ld3c(ln, legc, LC_CAPS + 3)), k.p3 + mul(k.R3, ld3c(ln, legc, LC_CAPS + 9)), ld3c(ln, legc, LC_TRUNKCAP + 3)};
+          for (int c = 0; c < 3; c++) {
+            V3l x = mul(R, ab[c]), y = mul(R, bb[c]);
+            wa[c] = mk3<F>(x.x + bs.p.x, x.y + bs.p.y, x.z + bs.p.z);
+            wb[c] = mk3<F>(y.x + bs.p.x, y.y + bs.p.y, y.z + bs.p.z);
+          }
+          wr[0] = ln.legc(legc, LC_CAPS + 12); wr[1] = ln.legc(legc, LC_CAPS + 13); wr[2] = ln.legc(legc, LC_TRUNKCAP + 6);
+        }
+        V3l oa[3], ob[3];                                    // the other robot's, same lane
+        for (int c = 0; c < 3; c++) {
+          oa[c] = mk3<F>(ln.peer(wa[c].x), ln.peer(wa[c].y), ln.peer(wa[c].z));
+          ob[c] = mk3<F>(ln.peer(wb[c].x), ln.peer(wb[c].y), ln.peer(wb[c].z));
+        }
+        const B s_odd = lm::odd_(ln.sub()), s_hi = lm::bit1_(ln.sub()), g_odd = lm::odd_(ln.leg());
+        const F subf = L::i2f(ln.sub()), legf = ln.legf();
+        const F lo_bit = lm::sel(s_odd, one, zero), hi_bit = lm::sel(s_hi, one, zero);
+        // per-lane two best (depth, pair id) with point and normal
+        F bd[2] = {far_, far_}, bid[2] = {far_, far_};
+        V3l bP[2], bN[2];
+        bP[0] = bP[1] = bN[0] = bN[1] = mk3<F>(zero, zero, zero);
+        F tch = one;
+        for (int pass = 0; pass < 7; pass++) {
+          V3l ma, mb, ta, tb;                                // my capsule, their capsule
+          F mr, tr, mi, ti;                                  // radii and capsule indices (0..7 legs, 8..9 trunk)
+          B pass_ok = act;
+          if (pass < 4) {                                    // my leg capsule (sub bit 0) x their leg (leg + pass) capsule (sub bit 1)
+            ma = mk3<F>(lm::sel(s_odd, wa[1].x, wa[0].x), lm::sel(s_odd, wa[1].y, wa[0].y), lm::sel(s_odd, wa[1].z, wa[0].z));
+            mb = mk3<F>(lm::sel(s_odd, wb[1].x, wb[0].x), lm::sel(s_odd, wb[1].y, wb[0].y), lm::sel(s_odd, wb[1].z, wb[0].z));
+            mr = lm::sel(s_odd, wr[1], wr[0]);
+            mi = legf * 2.0f + lo_bit;
+            V3l ra[2], rb[2];
+            for (int c = 0; c < 2; c++) {
+              if (pass == 0) { ra[c] = oa[c]; rb[c] = ob[c]; }
+              else if (pass == 1) { ra[c] = mk3<F>(L::from_next_leg(oa[c].x), L::from_next_leg(oa[c].y), L::from_next_leg(oa[c].z)); rb[c] = mk3<F>(L::from_next_leg(ob[c].x), L::from_next_leg(ob[c].y), L::from_next_leg(ob[c].z)); }
+              else if (pass == 2) { ra[c] = mk3<F>(L::from_leg2(oa[c].x), L::from_leg2(oa[c].y), L::from_leg2(oa[c].z)); rb[c] = mk3<F>(L::from_leg2(ob[c].x), L::from_leg2(ob[c].y), L::from_leg2(ob[c].z)); }
+              else { ra[c] = mk3<F>(L::from_prev_leg(oa[c].x), L::from_prev_leg(oa[c].y), L::from_prev_leg(oa[c].z)); rb[c] = mk3<F>(L::from_prev_leg(ob[c].x), L::from_prev_leg(ob[c].y), L::from_prev_leg(ob[c].z)); }
+            }
+            ta = mk3<F>(lm::sel(s_hi, ra[1].x, ra[0].x), lm::sel(s_hi, ra[1].y, ra[0].y), lm::sel(s_hi, ra[1].z, ra[0].z));
+            tb = mk3<F>(lm::sel(s_hi, rb[1].x, rb[0].x), lm::sel(s_hi, rb[1].y, rb[0].y), lm::sel(s_hi, rb[1].z, rb[0].z));
+            tr = lm::sel(s_hi, wr[1], wr[0]);                 // (same model: their radii are mine)
+            F tl = legf + (float)pass;
+            tl = lm::sel(tl > 3.5f, tl - 4.0f, tl);
+            ti = tl * 2.0f + hi_bit;
+          } else if (pass == 4) {                            // my trunk capsule (sub bit 1) x their leg `leg` capsule (sub bit 0)
+            B own_t = lm::or_(lm::and_(s_hi, g_odd), lm::and_(lm::not_(s_hi), lm::not_(g_odd)));     // the capsule this leg holds is the wanted one
+            V3l na = mk3<F>(L::from_next_leg(wa[2].x), L::from_next_leg(wa[2].y), L::from_next_leg(wa[2].z)), nb_ = mk3<F>(L::from_next_leg(wb[2].x), L::from_next_leg(wb[2].y), L::from_next_leg(wb[2].z));
+            ma = mk3<F>(lm::sel(own_t, wa[2].x, na.x), lm::sel(own_t, wa[2].y, na.y), lm::sel(own_t, wa[2].z, na.z));
+            mb = mk3<F>(lm::sel(own_t, wb[2].x, nb_.x), lm::sel(own_t, wb[2].y, nb_.y), lm::sel(own_t, wb[2].z, nb_.z));
+            mr = wr[2]; mi = hi_bit + 8.0f;
+            ta = mk3<F>(lm::sel(s_odd, oa[1].x, oa[0].x), lm::sel(s_odd, oa[1].y, oa[0].y), lm::sel(s_odd, oa[1].z, oa[0].z));
+            tb = mk3<F>(lm::sel(s_odd, ob[1].x, ob[0].x), lm::sel(s_odd, ob[1].y, ob[0].y), lm::sel(s_odd, ob[1].z, ob[0].z));
+            tr = lm::sel(s_odd, wr[1], wr[0]); ti = legf * 2.0f + lo_bit;
+          } else if (pass == 5) {                            // my leg capsule (sub bit 0) x their trunk capsule (sub bit 1)
+            B own_t = lm::or_(lm::and_(s_hi, g_odd), lm::and_(lm::not_(s_hi), lm::not_(g_odd)));
+            V3l na = mk3<F>(L::from_next_leg(oa[2].x), L::from_next_leg(oa[2].y), L::from_next_leg(oa[2].z)), nb_ = mk3<F>(L::from_next_leg(ob[2].x), L::from_next_leg(ob[2].y), L::from_next_leg(ob[2].z));
+            ta = mk3<F>(lm::sel(own_t, oa[2].x, na.x), lm::sel(own_t, oa[2].y, na.y), lm::sel(own_t, oa[2].z, na.z));
+            tb = mk3<F>(lm::sel(own_t, ob[2].x, nb_.x), lm::sel(own_t, ob[2].y, nb_.y), lm::sel(own_t, ob[2].z, nb_.z));
+            tr = wr[2]; ti = hi_bit + 8.0f;
+            ma = mk3<F>(lm::sel(s_odd, wa[1].x, wa[0].x), lm::sel(s_odd, wa[1].y, wa[0].y), lm::sel(s_odd, wa[1].z, wa[0].z));
+            mb = mk3<F>(lm::sel(s_odd, wb[1].x, wb[0].x), lm::sel(s_odd, wb[1].y, wb[0].y), lm::sel(s_odd, wb[1].z, wb[0].z));
+            mr = lm::sel(s_odd, wr[1], wr[0]); mi = legf * 2.0f + lo_bit;
+          } else {                                           // trunk x trunk, on the lanes of leg 0: mine (sub bit 0) x theirs (sub bit 1)
+            V3l nma = mk3<F>(L::from_next_leg(wa[2].x), L::from_next_leg(wa[2].y), L::from_next_leg(wa[2].z)), nmb = mk3<F>(L::from_next_leg(wb[2].x), L::from_next_leg(wb[2].y), L::from_next_leg(wb[2].z));
+            V3l nta = mk3<F>(L::from_next_leg(oa[2].x), L::from_next_leg(oa[2].y), L::from_next_leg(oa[2].z)), ntb = mk3<F>(L::from_next_leg(ob[2].x), L::from_next_leg(ob[2].y), L::from_next_leg(ob[2].z));
+            ma = mk3<F>(lm::sel(s_odd, nma.x, wa[2].x), lm::sel(s_odd, nma.y, wa[2].y), lm::sel(s_odd, nma.z, wa[2].z));
+            mb = mk3<F>(lm::sel(s_odd, nmb.x, wb[2].x), lm::sel(s_odd, nmb.y, wb[2].y), lm::sel(s_odd, nmb.z, wb[2].z));
+            ta = mk3<F>(lm::sel(s_hi, nta.x, oa[2].x), lm::sel(s_hi, nta.y, oa[2].y), lm::sel(s_hi, nta.z, oa[2].z));
+            tb = mk3<F>(lm::sel(s_hi, ntb.x, ob[2].x), lm::sel(s_hi, ntb.y, ob[2].y), lm::sel(s_hi, ntb.z, ob[2].z));
+            mr = wr[2]; tr = wr[2]; mi = lo_bit + 8.0f; ti = hi_bit + 8.0f;
+            pass_ok = lm::and_(pass_ok, legf < 0.5f);
+          }
+          // canonical order: robot 0's capsule is the first segment
+          V3l a1 = mk3<F>(lm::sel(i_am_0, ma.x, ta.x), lm::sel(i_am_0, ma.y, ta.y), lm::sel(i_am_0, ma.z, ta.z)), b1 = mk3<F>(lm::sel(i_am_0, mb.x, tb.x), lm::sel(i_am_0, mb.y, tb.y), lm::sel(i_am_0, mb.z, tb.z));
+          V3l a2 = mk3<F>(lm::sel(i_am_0, ta.x, ma.x), lm::sel(i_am_0, ta.y, ma.y), lm::sel(i_am_0, ta.z, ma.z)), b2 = mk3<F>(lm::sel(i_am_0, tb.x, mb.x), lm::sel(i_am_0, tb.y, mb.y), lm::sel(i_am_0, tb.z, mb.z));
+          F r1 = lm::sel(i_am_0, mr, tr), r2 = lm::sel(i_am_0, tr, mr);
+          F id = lm::sel(i_am_0, mi * 10.0f + ti, ti * 10.0f + mi);
+          V3l c1, c2;
+          F ps, pt;
+          seg_seg_st(ln, a1, b1, a2, b2, c1, c2, ps, pt);
+          V3l dd = c1 - c2;                                  // from robot 1's capsule to robot 0's
+          F len = lm::sqrt_(dot(dd, dd));
+          V3l nn_ = scale(dd, one / lm::max_(len, ln.lane_f(1e-9f)));
+          V3l pp = scale((c1 - scale(nn_, r1)) + (c2 + scale(nn_, r2)), ln.lane_f(0.5f));
+          F dep = len - r1 - r2;
+          B valid = lm::and_(pass_ok, lm::and_(dep < P.margin_dist, len > 1e-9f));
+          // my side of it: a leg / wheel link unless it is the foot end of a shank capsule
+          F my_par = lm::sel(i_am_0, ps, pt);
+          B my_body = lm::and_(mi < 7.5f, lm::not_(lm::and_(lm::abs_(mi - lm::rint_(mi * 0.5f) * 2.0f) > 0.5f, my_par > 0.9f)));
+          tch = lm::sel(lm::and_(valid, my_body), zero, tch);
+          F d = lm::sel(valid, dep, far_);
+          B beat0 = lm::or_(d < bd[0], lm::and_(lm::and_(d <= bd[0], d < 1.0e29f), id < bid[0]));
+          B beat1 = lm::and_(lm::not_(beat0), lm::or_(d < bd[1], lm::and_(lm::and_(d <= bd[1], d < 1.0e29f), id < bid[1])));
+          // shift down, then insert
+          bd[1] = lm::sel(beat0, bd[0], lm::sel(beat1, d, bd[1])); bid[1] = lm::sel(beat0, bid[0], lm::sel(beat1, id, bid[1]));
+          bP[1] = mk3<F>(lm::sel(beat0, bP[0].x, lm::sel(beat1, pp.x, bP[1].x)), lm::sel(beat0, bP[0].y, lm::sel(beat1, pp.y, bP[1].y)), lm::sel(beat0, bP[0].z, lm::sel(beat1, pp.z, bP[1].z)));
+          bN[1] = mk3<F>(lm::sel(beat0, bN[0].x, lm::sel(beat1, nn_.x, bN[1].x)), lm::sel(beat0, bN[0].y, lm::sel(beat1, nn_.y, bN[1].y)), lm::sel(beat0, bN[0].z, lm::sel(beat1, nn_.z, bN[1].z)));
+          bd[0] = lm::sel(beat0, d, bd[0]); bid[0] = lm::sel(beat0, id, bid[0]);
+          bP[0] = mk3<F>(lm::sel(beat0, pp.x, bP[0].x), lm::sel(beat0, pp.y, bP[0].y), lm::sel(beat0, pp.z, bP[0].z));
+          bN[0] = mk3<F>(lm::sel(beat0, nn_.x, bN[0].x), lm::sel(beat0, nn_.y, bN[0].y), lm::sel(beat0, nn_.z, bN[0].z));
+        }
+        if (ex->want_touch) ex->touch_robot = L::rmin(tch) < 0.5f ? 1.0f : 0.0f;
+        any_pair = L::any(bd[0] < 1.0e29f);
+        if (any_pair) {
+          LL_UNROLL
+          for (int slot = 0; slot < 2; slot++) {
+            if (slot == 1 && !L::any(bd[0] < 1.0e29f)) break;
+            n_pair_w = slot + 1;
+            const float dmin = L::rmin(bd[0]);
+            B at = bd[0] <= ln.lane_f(dmin);
+            const float imin = L::rmin(lm::sel(at, bid[0], ln.lane_f(1.0e9f)));
+            const bool have = dmin < 1.0e29f;
+            B win = lm::and_(at, lm::abs_(bid[0] - imin) < 0.5f);
+            // several lanes may hold the same pair (never: each pair is evaluated by exactly one lane of a row)
+            F w6[6] = {lm::sel(win, bP[0].x, zero), lm::sel(win, bP[0].y, zero), lm::sel(win, bP[0].z, zero), lm::sel(win, bN[0].x, zero), lm::sel(win, bN[0].y, zero), lm::sel(win, bN[0].z, zero)};
+            float u6[6];
+            L::rsum6(w6, u6);
+            // the winner lane promotes its second best
+            bd[0] = lm::sel(win, bd[1], bd[0]); bid[0] = lm::sel(win, bid[1], bid[0]);
+            bP[0] = mk3<F>(lm::sel(win, bP[1].x, bP[0].x), lm::sel(win, bP[1].y, bP[0].y), lm::sel(win, bP[1].z, bP[0].z));
+            bN[0] = mk3<F>(lm::sel(win, bN[1].x, bN[0].x), lm::sel(win, bN[1].y, bN[0].y), lm::sel(win, bN[1].z, bN[0].z));
+            bd[1] = lm::sel(win, far_, bd[1]);
+            const int pid = have ? (int)(imin + 0.5f) : 0, ia = pid / 10, ib = pid - 10 * ia;
+            const int ic = me == 0 ? ia : ib;                          // my capsule: 0..7 leg (leg = ic >> 1, thigh / shank), 8..9 trunk
+            const float sg = me == 0 ? 1.0f : -1.0f;                   // the normal points from robot 1 to robot 0
+            // into my base frame
+            const V3<float> pw = mk3<float>(u6[0] - bs.p.x, u6[1] - bs.p.y, u6[2] - bs.p.z), nw = mk3<float>(u6[3] * sg, u6[4] * sg, u6[5] * sg);
+            const V3<float> pb_ = mulT(R, pw), nb_ = mulT(R, nw);
+            V3l Pb = cvt3<F>(pb_), nb = cvt3<F>(nb_);
+            B mine = lm::and_(ln.is_leg(ic >> 1), ln.lane_f(ic < 8 ? 1.0f : 0.0f) > 0.5f);
+            F on3 = ln.lane_f((ic & 1) ? 1.0f : 0.0f);
+            V3l a1v = mk3<F>(one, zero, zero);
+            V3l e1 = cross(a1v, Pb - k.p1), e2 = cross(k.a2, Pb - k.p2), e3 = scale(cross(k.a2, Pb - k.p3), on3);
+            SelfRow& rw = pr[slot];
+            rw.jt[0] = lm::sel(mine, dot(nb, e1), zero); rw.jt[1] = lm::sel(mine, dot(nb, e2), zero); rw.jt[2] = lm::sel(mine, dot(nb, e3), zero);
+            const V3<float> pxu = cross(pb_, nb_);
+            float vrow = L::qsum(rw.jt[0] * qs[0] + rw.jt[1] * qs[1] + rw.jt[2] * qs[2]) + pxu.x * xi[0] + pxu.y * xi[1] + pxu.z * xi[2] + nb_.x * xi[3] + nb_.y * xi[4] + nb_.z * xi[5];
+            lm_fwd(lf, rw.jt);
+            SV<F> yj = scale(lf.y1, rw.jt[0]) + scale(lf.y2, rw.jt[1]) + scale(lf.y3, rw.jt[2]);
+            F g6[6] = {zero - yj.a.x, zero - yj.a.y, zero - yj.a.z, zero - yj.l.x, zero - yj.l.y, zero - yj.l.z};
+            L::qsum6(g6, rw.gt);
+            rw.gt[0] += pxu.x; rw.gt[1] += pxu.y; rw.gt[2] += pxu.z; rw.gt[3] += nb_.x; rw.gt[4] += nb_.y; rw.gt[5] += nb_.z;
+            fwd6(Sb, Sd, rw.gt);
+            float nn = L::qsum(rw.jt[0] * rw.jt[0] + rw.jt[1] * rw.jt[1] + rw.jt[2] * rw.jt[2]);
+            for (int i = 0; i < 6; i++) nn += rw.gt[i] * rw.gt[i];
+            const float vo = ln.peer_u(vrow), no = ln.peer_u(nn);
+            rw.c = ((me == 0) ? vrow + vo : vo + vrow) + ((dmin > 0.0f) ? dmin * inv_dt : dmin * (P.erp * inv_dt));
+            rw.inv = have ? 1.0f / ((me == 0) ? nn + no : no + nn) : 0.0f;
+            rw.lam = 0.0f;
+            if (!have) { for (int i = 0; i < 3; i++) rw.jt[i] = zero; for (int i = 0; i < 6; i++) rw.gt[i] = 0.0f; rw.c = 0.0f; }
+          }
+        }
+      }
+    }
     PMC_TSS(26);
 #if defined(PMC_ABLATION)
     if (PMC_ABL(16) && ln.is_lane(0)) P.counters[4 + (long)env * PMC_TS_SLOTS + 28] += (unsigned long long)(any_self ? 1 : 0);
@@ -889,6 +1087,12 @@ struct Pmc {
       if (any_self) {                                                        // then the self-collision rows, one after the other
         self_turn(sr[0], dx, dq);
         if (n_self_w > 1) self_turn(sr[1], dx, dq);
+      }
+      if (PAIR) {
+        if (any_pair) {                                                      // last, the rows shared with the other robot
+          pair_turn(ln, pr[0], dx, dq, ex->pair_me);
+          if (n_pair_w > 1) pair_turn(ln, pr[1], dx, dq, ex->pair_me);
+        }
       }
     }
 

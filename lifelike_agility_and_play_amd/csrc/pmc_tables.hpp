@@ -98,6 +98,20 @@ static inline std::string pmc_build_tables(const double* blob, int blob_len, std
     L(LC_CAPS + 12, l) = (float)(tb.size[1] > tb.size[2] ? tb.size[1] : tb.size[2]);
     L(LC_CAPS + 13, l) = (float)(0.5 * ((sb.size[1] > sb.size[2] ? sb.size[1] : sb.size[2]) + ft.size[0]));
   }
+  // robot-robot collision (SEPMC): the body box as two capsules along its long axis, radius = its half height,
+  // side by side so that they span its width; legs 0, 2 hold the first, legs 1, 3 the second
+  {
+    PmcPrimView bb = pmc_prim(blob + LLM_OFF_BASE_PRIMS);
+    const double r = bb.size[2], hx = bb.size[0] - r, oy = bb.size[1] - r;
+    for (int l = 0; l < 4; l++) {
+      const double sy = (l & 1) ? -oy : oy;
+      for (int c = 0; c < 3; c++) {
+        L(LC_TRUNKCAP + 0 + c, l) = (float)(bb.pos[c] + hx * bb.rot[3 * c] + sy * bb.rot[3 * c + 1]);
+        L(LC_TRUNKCAP + 3 + c, l) = (float)(bb.pos[c] - hx * bb.rot[3 * c] + sy * bb.rot[3 * c + 1]);
+      }
+      L(LC_TRUNKCAP + 6, l) = (float)r;
+    }
+  }
   // base
   double m = blob[LLM_OFF_BASE_MASS];
   const double* c = blob + LLM_OFF_BASE_COM;

@@ -64,6 +64,7 @@ struct SepmcEngine {
       E.ray_trace = base.template dalloc<float>(N * EPMC_N_RAYS * 8);      // diagnostics / parity only
       S.vis_trace = base.template dalloc<float>(N * 16 * 8);
     }
+    S.robot_contacts = 1;
     S.rand_cube = c.rand_cube ? 1 : 0; S.hurdle = c.hurdle ? 1 : 0; S.hole = c.hole ? 1 : 0;
     S.cos_visible = (float)cos(c.visible_angle); S.control_spd = (float)c.control_spd;
     S.sp = base.template dalloc<float>(N * SEPMC_SP_STRIDE);

@@ -45,6 +45,7 @@ struct SepmcParams {
   EpmcParams e;         // the fields the two envs share: max_steps, push schedule, friction / force / noise ranges, init_state, per-row boxes,
                         // push_trace, ray_trace and the scripted-state / scripted-ray / scripted-draw hooks (all indexed by robot row)
   int32_t rand_cube, hurdle, hole, scr_on;
+  int32_t robot_contacts, pad0;           // 0: the robots pass through each other (diagnostics)
   float cos_visible, control_spd;         // control_spd < 0: the episode's draw (CTG:264, :361)
   float* sp;                              // [rows][SEPMC_SP_STRIDE]
   float* info;                            // [rows][4] avg_spd0, avg_spd1, max_spd0, max_spd1 (CTG:404-409)
@@ -362,7 +363,12 @@ struct Sepmc {
                    (uint32_t)sp[SP_EPISODE], 0x57e9d3u};
     typename K::SubstepExtra ex;
     ex.mu_foot = sp[SP_FRICTION] * E.plane_friction;
-    ex.want_touch = false; ex.flag_shape = -1; ex.touch_static = ex.touch_flag = 0.0f;
+    ex.want_touch = false; ex.flag_shape = -1; ex.touch_static = ex.touch_flag = ex.touch_robot = 0.0f;
+    {   // can the two robots meet during this control step?  (reach 0.55 m each + what 20 ms of motion adds)
+      const float ddx = ln.peer_u(bs.p.x) - bs.p.x, ddy = ln.peer_u(bs.p.y) - bs.p.y, ddz = ln.peer_u(bs.p.z) - bs.p.z;
+      ex.pair_active = !E.scr_state && S.robot_contacts && (ddx * ddx + ddy * ddy + ddz * ddz < 1.5f * 1.5f);
+      ex.pair_me = me;
+    }
     const int nb = (int)sp[SP_N_BOXES];
     float* allb = E.boxes + (long)row * EPMC_MAX_BOXES * EPMC_BOX_WORDS;
     {   // boxes within reach of this robot during the control step (epmc_step.hpp), the flag among them
@@ -405,7 +411,7 @@ struct Sepmc {
         for (int i = 0; i < 3; i++) ptrace[s * 4 + 1 + i] = ex.has_push ? ex.push[i] : 0.0f;
       }
       ex.want_touch = s == P.n_sub - 1;
-      if (!E.scr_state) K::template substep_impl<true>(ln, P, bs, q, qd, tgt, row, s, &ex);
+      if (!E.scr_state) K::template substep_impl<true, true>(ln, P, bs, q, qd, tgt, row, s, &ex);
     }
     if (E.scr_state) {   // parity hook: the caller plays PyBullet
       const float* ss = E.scr_state + (long)row * 37;
@@ -418,7 +424,7 @@ struct Sepmc {
     F fin = q[0] + q[1] + q[2] + qd[0] + qd[1] + qd[2];
     float chk = L::qsum(fin) + bs.p.x + bs.p.y + bs.p.z + bs.q.x + bs.q.y + bs.q.z + bs.q.w + bs.v.x + bs.v.y + bs.v.z + bs.w.x + bs.w.y + bs.w.z;
     const float my_bad = !(fabsf(chk) < 1e30f) ? 1.0f : 0.0f;
-    const float my_code = ex.touch_static * 1.0f + ex.touch_flag * 2.0f + my_bad * 8.0f;
+    const float my_code = ex.touch_static * 1.0f + ex.touch_flag * 2.0f + ex.touch_robot * 4.0f + my_bad * 8.0f;
     Peer o = exchange(ln, P, bs, q, my_code);
     const bool bad = my_bad > 0.5f || ((int)o.code & 8);
     const float code0 = me == 0 ? my_code : o.code, code1 = me == 0 ? o.code : my_code;

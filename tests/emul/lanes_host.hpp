@@ -141,6 +141,7 @@ struct HostLanes {
     }
   }
   static F from_prev_leg(const F& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = x.v[(i + 12) & 15]; return r; }
+  static F from_next_leg(const F& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = x.v[(i + 4) & 15]; return r; }
   static F from_leg2(const F& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = x.v[(i + 8) & 15]; return r; }
   static float rmin(const F& x) { float m = x.v[0]; for (int i = 1; i < EW; i++) m = fminf(m, x.v[i]); return m; }
   static bool any(const B& m) { for (int i = 0; i < EW; i++) if (m.v[i]) return true; return false; }

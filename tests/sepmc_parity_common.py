@@ -391,3 +391,42 @@ def check_free_running_big(lib_path, n_arenas, steps):
     assert c['episodes'] > 0 and c['nonfinite'] == 0
     E.close()
     return c
+
+
+def check_robot_robot_contact(lib_path):
+    """This build's robot-robot contact (capsule pairs between the two rows of an arena).  Arena 0: robot 0 is dropped onto robot 1
+    and is carried by it instead of falling through.  Arena 1: robot 0 walks its front legs into robot 1's hind legs -- a catch
+    (CTG:442-450) with +-1 on top of the reward.  Arena 2: far apart, nothing happens."""
+    from lifelike_agility_and_play_amd import sepmc_capi
+    E = make_engine(env_config((0, 0, 0)), 3, lib_path, auto_reset=0, seed=21)
+    E.reset()
+    st = E.state().astype(np.float64)
+    wf0 = E.episode()['with_flag0'].copy()
+    for a in range(3):
+        for r in range(2):
+            st[a, r, 3:7] = [0, 0, 0, 1]
+            st[a, r, 7:13] = 0.0
+    st[0, 1, 0:3] = [1.0, 1.0, 0.31]; st[0, 0, 0:3] = [1.0, 1.0, 0.58]
+    st[1, 1, 0:3] = [0.0, 1.0, 0.31]; st[1, 0, 0:3] = [-0.40, 1.0, 0.31]
+    st[2, 1, 0:3] = [1.5, -1.5, 0.31]; st[2, 0, 0:3] = [-1.5, -1.5, 0.31]
+    # keep the flag out of the way of all three
+    E.set_state(st)
+    zero = np.zeros((3, 2, 12))
+    E.step_host(zero)
+    rew, done, why = E.reward_done()
+    assert done[1] and (why[1] & sepmc_capi.DONE_CATCH), why
+    want = 1.0 if wf0[1] > 0.5 else -1.0
+    assert abs(rew[1][0] - want) < 1e-6 and abs(rew[1][1] + want) < 1e-6, rew[1]
+    assert not done[2] and rew[2][0] == 0.0
+    zs = []
+    for t in range(40):
+        E.step_host(zero)
+        s = E.state()
+        assert np.isfinite(s).all()
+        zs.append(s[0, 0, 2] - s[0, 1, 2])
+    # robot 1 carries robot 0: its legs give way under the double load (alone it keeps standing at 0.3 m), and robot 0 stays above it
+    # (without the contact rows it would drop through and stand at the same height)
+    assert min(zs) > 0.04 and E.state()[0, 1, 2] < 0.2, (zs[-5:], E.state()[0, :, 2])
+    assert abs(E.state()[2, 0, 0] + 1.5) < 0.2          # the far pair stayed where it was
+    E.close()
+    return dict(stack_gap=float(zs[-1]))

@@ -25,3 +25,7 @@ def test_free_running_invariants_gpu():
 
 def test_flag_handover_by_physical_contact_gpu():
     SC.check_flag_handover_physical(None)
+
+
+def test_robot_robot_contact_gpu():
+    print(SC.check_robot_robot_contact(None))

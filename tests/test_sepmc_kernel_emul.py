@@ -34,3 +34,7 @@ def test_free_running_invariants(emul_lib):
 
 def test_flag_handover_by_physical_contact(emul_lib):
     SC.check_flag_handover_physical(emul_lib)
+
+
+def test_robot_robot_contact(emul_lib):
+    print(SC.check_robot_robot_contact(emul_lib))
