@@ -19,9 +19,12 @@
 #define EPMC_MAX_BOXES 40
 #define EPMC_MAX_DRAWS 64
 #define EPMC_BOX_WORDS 8
-#define EPMC_RAY_NEAR 10      // boxes the height and front rays test from registers
 #define EPMC_MAX_NEAR 8       // boxes within reach of the robot's contact candidates during one control step
 #define EPMC_EP_STRIDE 40
+#define EPMC_LIST_A 320         // row-scratch words: the near list (height + front rays) after the staged box records, then the fan's list
+#define EPMC_LIST_A_MAX 12
+#define EPMC_LIST_B (EPMC_LIST_A + EPMC_LIST_A_MAX * EPMC_BOX_WORDS)
+#define EPMC_LIST_B_MAX 16
 
 // per-env scalar row (EpmcParams::ep)
 enum EpmcEpField {
@@ -247,93 +250,191 @@ struct Epmc {
       }
     }
   }
-  // the three percep arrays straight into the obs row; lanes share the rays out
+  // sin / cos of a moderate angle (|x| < ~1e3): the scalar twin of Pmc::sincos_joint (Cody-Waite to [-pi/4, pi/4] + minimax polynomials)
+  static LL_HD void sincos_f(float x, float* s, float* c) {
+    const float kf = rintf(x * 0.63661977236758134f);
+    float r = x - kf * 1.5707962512969971f;
+    r = r - kf * 7.5497894158615964e-08f;
+    const float r2 = r * r;
+    const float sp = r + r * r2 * (-0.16666654611f + r2 * (0.0083321608736f + r2 * (-0.00019515295891f)));
+    const float cp = 1.0f + r2 * (-0.5f + r2 * (0.041666645683f + r2 * (-0.0013887316255f + r2 * 0.000024433157117f)));
+    const int k = (int)kf;
+    const float ss = (k & 1) ? cp : sp, cs = (k & 1) ? sp : cp;
+    *s = (k & 2) ? -ss : ss;
+    *c = ((k + 1) & 2) ? -cs : cs;
+  }
+  // a box record as two 16-byte reads (one LDS instruction each), fetched one box ahead of its use so that the read latency hides
+  // behind the previous box's arithmetic -- a wave has nothing else to switch to
+  struct alignas(16) F4 { float x, y, z, w; };
+  struct BoxRec { F4 a, c; };                              // a = x0 x1 y0 y1, c = z0 z1 - -
+  static LL_HD BoxRec load_box(const float* p) {
+    BoxRec b;
+    b.a = *reinterpret_cast<const F4*>(p);
+    b.c = *reinterpret_cast<const F4*>(p + 4);
+    return b;
+  }
+  // one axis of the slab test of origin o, direction d (inv = 1/d, anything if d == 0) against [lo, hi]: narrows [te, tl]
+  static LL_HD void slab_axis(float lo, float hi, float o, float d, float inv, float& te, float& tl) {
+    const float t1 = (lo - o) * inv, t2 = (hi - o) * inv;
+    const bool par = d == 0.0f, inside = (o >= lo) & (o <= hi);
+    const float a = par ? (inside ? -3.0e38f : 3.0e38f) : fminf(t1, t2);
+    const float b = par ? (inside ? 3.0e38f : -3.0e38f) : fmaxf(t1, t2);
+    te = fmaxf(te, a);
+    tl = fminf(tl, b);
+  }
+  // The three percep arrays straight into the obs row; lanes share the rays out.  `boxes` = the env's n_boxes records staged at
+  // the start of the row scratch.  Each family is a dense, branch-light loop: lane 0 first compacts the boxes a family can meet --
+  // within 3.6 m of the base for the height grid (reach 1.35 m) and the front rays (3.4 m); for the horizontal fan, whose rays are
+  // exactly level (PGE:30-38), the boxes whose height range contains the base height, within 20.1 m -- into two lists behind the
+  // staged records; a ray then walks its family's list with one 32-byte LDS read per box and no per-ray set-up beyond its origin
+  // (the front rays share one direction, the fan one origin; the fan's directions come from one sin/cos per lane and eight exact
+  // 45-degree turns).
   static LL_HD void observe_rays(const L& ln, const StepParams& P, const EpmcParams& E, int env, const float* pos, const M3<float>& R, float yaw,
                                  const float* noise, const float* boxes, int n_boxes, float* percep) {
-    // boxes within reach of the rays around the base: 3.6 m covers the height grid (1.35 m) and the front rays (3.4 m), 20.1 m
-    // the horizontal fan -- whose rays are exactly level (PGE:30-38), so only boxes whose height range contains the base height
-    // can be met.  Evaluated once per env.  The near set (up to EPMC_RAY_NEAR boxes) is then held in registers: a height or
-    // front ray tests it without a memory access; the horizontal fan walks its set in LDS.
-    unsigned long long near = 0ull, far = 0ull;
+    if (PMC_ABL(32)) return;                                                     // ablation build only: no rays
+    if (E.scr_ray_hit) {                                                         // parity hook: the caller plays rayTestBatch
+      for (int r = ln.ray_first(); r < EPMC_N_RAYS; r += ln.ray_stride()) {
+        float f[3], t[3];
+        ray_ends(r, pos, R, yaw, f, t);
+        const bool hit = E.scr_ray_hit[(long)env * EPMC_N_RAYS + r] != 0;
+        const float frac = E.scr_ray_frac[(long)env * EPMC_N_RAYS + r];
+        emit_ray(E, env, r, f, t, hit, frac, noise, percep);
+      }
+      return;
+    }
+    // --- the two compact lists (lane 0 writes, the row reads after the sync) ---
+    float* listA = ln.row_scratch() + EPMC_LIST_A;
+    float* listB = ln.row_scratch() + EPMC_LIST_B;
+    int nA = 0, nB = 0;
     for (int b = 0; b < n_boxes; b++) {
       const float* bx = boxes + b * EPMC_BOX_WORDS;
-      if (bx[1] >= pos[0] - 3.6f && bx[0] <= pos[0] + 3.6f && bx[3] >= pos[1] - 3.6f && bx[2] <= pos[1] + 3.6f) near |= 1ull << b;
-      if (bx[1] >= pos[0] - 20.1f && bx[0] <= pos[0] + 20.1f && bx[3] >= pos[1] - 20.1f && bx[2] <= pos[1] + 20.1f && bx[4] <= pos[2] && bx[5] >= pos[2])
-        far |= 1ull << b;
-    }
-    float nb[EPMC_RAY_NEAR][6];
-    int n_near = 0;
-    {
-      unsigned long long m = near;
-      for (int k = 0; k < EPMC_RAY_NEAR; k++) {
-        const bool have = m != 0ull;
-        const int b = have ? __builtin_ctzll(m) : 0;
-        if (have) m &= m - 1;
-        const float* bx = boxes + b * EPMC_BOX_WORDS;
-        for (int i = 0; i < 6; i++) nb[k][i] = have ? bx[i] : ((i & 1) ? -3.0e38f : 3.0e38f);     // an empty slot is an empty box
-        n_near += have ? 1 : 0;
+      const bool near = bx[1] >= pos[0] - 3.6f && bx[0] <= pos[0] + 3.6f && bx[3] >= pos[1] - 3.6f && bx[2] <= pos[1] + 3.6f;
+      const bool fan = bx[1] >= pos[0] - 20.1f && bx[0] <= pos[0] + 20.1f && bx[3] >= pos[1] - 20.1f && bx[2] <= pos[1] + 20.1f && bx[4] <= pos[2] && bx[5] >= pos[2];
+      if (near) {
+        if (nA < EPMC_LIST_A_MAX && ln.lane0()) for (int i = 0; i < EPMC_BOX_WORDS; i++) listA[nA * EPMC_BOX_WORDS + i] = bx[i];
+        nA++;
       }
-      near = m;                                                                 // whatever did not fit stays on the LDS path
-    }
-    int kmax = 0;                                                               // slots in use by any env of the wave (wave-uniform loop bound)
-    for (int k = 0; k < EPMC_RAY_NEAR; k++)
-      if (L::any(ln.lane_f(n_near > k ? 1.0f : 0.0f) > 0.5f)) kmax = k + 1;
-    if (PMC_ABL(32)) return;                                                     // ablation build only: no rays
-    for (int r = ln.ray_first(); r < EPMC_N_RAYS; r += ln.ray_stride()) {
-      if (PMC_ABL(64) && r >= EPMC_N_HEIGHT) break;                              // ablation: height rays only
-      if (PMC_ABL(128) && (r < EPMC_N_HEIGHT || r >= EPMC_N_HEIGHT + EPMC_N_HORIZ)) continue;   // ablation: horizontal fan only
-      float f[3], t[3];
-      ray_ends(r, pos, R, yaw, f, t);
-      bool hit;
-      float frac;
-      if (E.scr_ray_hit) {
-        hit = E.scr_ray_hit[(long)env * EPMC_N_RAYS + r] != 0;
-        frac = E.scr_ray_frac[(long)env * EPMC_N_RAYS + r];
-      } else if (r >= EPMC_N_HEIGHT && r < EPMC_N_HEIGHT + EPMC_N_HORIZ) {
-        frac = cast(f, t, boxes, far, &hit);
-      } else {
-        float best = cast(f, t, boxes, near, &hit);                              // plane + overflow boxes (normally none)
-        if (!hit) best = 3.0e38f;
-        if (r < EPMC_N_HEIGHT) {                                                 // straight down from z = 10: the highest top under (x, y)
-          float top = -3.0e38f;
-          LL_UNROLL
-          for (int k = 0; k < EPMC_RAY_NEAR; k++) {
-            if (k >= kmax) break;
-            if (f[0] >= nb[k][0] && f[0] <= nb[k][1] && f[1] >= nb[k][2] && f[1] <= nb[k][3]) top = fmaxf(top, nb[k][5]);
-          }
-          if (top > -1.0e38f) best = fminf(best, (10.0f - top) * 0.05f);
-        } else {
-          const float d[3] = {t[0] - f[0], t[1] - f[1], t[2] - f[2]};
-          float inv[3];
-          for (int a = 0; a < 3; a++) inv[a] = d[a] != 0.0f ? 1.0f / d[a] : 0.0f;
-          LL_UNROLL
-          for (int k = 0; k < EPMC_RAY_NEAR; k++) {
-            if (k >= kmax) break;
-            best = fminf(best, slab(f, d, inv, nb[k]));
-          }
-        }
-        hit = best < 2.0f;
-        frac = hit ? best : 1.0f;
+      if (fan) {
+        if (nB < EPMC_LIST_B_MAX && ln.lane0()) for (int i = 0; i < EPMC_BOX_WORDS; i++) listB[nB * EPMC_BOX_WORDS + i] = bx[i];
+        nB++;
       }
+    }
+    ln.row_sync();
+    const float* LA = nA <= EPMC_LIST_A_MAX ? listA : boxes;                     // a list that does not fit: walk all boxes (the tests are exact anyway)
+    const float* LB = nB <= EPMC_LIST_B_MAX ? listB : boxes;
+    const int cA = nA <= EPMC_LIST_A_MAX ? nA : n_boxes, cB = nB <= EPMC_LIST_B_MAX ? nB : n_boxes;
+    // --- height grid (PGE:431-447): straight down from z = 10 to -10: the highest top under (x, y), or the plane ---
+    if (!PMC_ABL(128))
+    for (int r = ln.ray_first(); r < EPMC_N_HEIGHT; r += ln.ray_stride()) {
+      float gx, gy;
+      grid_point(r, -1.2f, 1.2f, -0.6f, 0.6f, &gx, &gy);
+      const float x = R.m[0] * gx + R.m[1] * gy + pos[0], y = R.m[3] * gx + R.m[4] * gy + pos[1];
+      float top = 0.0f;
+      BoxRec nx = load_box(LA);
+      for (int b = 0; b < cA; b++) {
+        const BoxRec bx = nx;
+        nx = load_box(LA + (b + 1) * EPMC_BOX_WORDS);                             // (one record past the list is readable scratch)
+        const bool in = (x >= bx.a.x) & (x <= bx.a.y) & (y >= bx.a.z) & (y <= bx.a.w);
+        top = in ? fmaxf(top, bx.c.y) : top;
+      }
+      const float frac = (10.0f - top) * 0.05f;
+      float v = 10.0f + frac * -20.0f;                                          // PGE:442 hit height
+      if (E.noise_on[3]) v = (v > 0.01f && v < 0.6f) ? v + noise[3] : 0.0f;      // PGE:443-446
+      percep[r] = v;
       if (E.ray_trace) {
         float* tr = E.ray_trace + ((long)env * EPMC_N_RAYS + r) * 8;
-        tr[0] = f[0]; tr[1] = f[1]; tr[2] = f[2]; tr[3] = t[0]; tr[4] = t[1]; tr[5] = t[2]; tr[6] = hit ? 1.0f : 0.0f; tr[7] = frac;
+        tr[0] = x; tr[1] = y; tr[2] = 10.0f; tr[3] = x; tr[4] = y; tr[5] = -10.0f; tr[6] = 1.0f; tr[7] = frac;
       }
-      const float hx = hit ? f[0] + frac * (t[0] - f[0]) : 0.0f, hy = hit ? f[1] + frac * (t[1] - f[1]) : 0.0f, hz = hit ? f[2] + frac * (t[2] - f[2]) : 0.0f;
-      float v;
-      if (r < EPMC_N_HEIGHT) {                                                  // PGE:442-446 hit height; a miss reports (0,0,0)
-        v = hz;
-        if (E.noise_on[3]) v = (v > 0.01f && v < 0.6f) ? v + noise[3] : 0.0f;
-      } else if (r < EPMC_N_HEIGHT + EPMC_N_HORIZ) {                            // PGE:399, :49-50: a miss measures |(0,0,0) - origin|
-        const float dx = hx - f[0], dy = hy - f[1], dz = hz - f[2];
-        v = sqrtf(dx * dx + dy * dy + dz * dz);
-      } else {                                                                  // PGE:425-427: a miss counts as the far end
-        const float px = hit ? hx : t[0], py = hit ? hy : t[1], pz = hit ? hz : t[2];
-        const float dx = px - f[0], dy = py - f[1], dz = pz - f[2];
-        v = sqrtf(dx * dx + dy * dy + dz * dz);
-      }
-      percep[r] = v;
     }
+    if (PMC_ABL(64)) return;                                                     // ablation: height rays only
+    // --- horizontal fan (PGE:30-38, :399): 128 level rays of 20 m from the base position; a miss measures |(0,0,0) - origin| ---
+    {
+      float sy, cy;
+      sincos_f(yaw, &sy, &cy);
+      const float miss = sqrtf(pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2]);
+      for (int k = ln.ray_first(); k < EPMC_N_HORIZ; k += ln.ray_stride()) {
+        float sk, ck;
+        sincos_f(6.283185307179586f * (float)k * (1.0f / 128.0f), &sk, &ck);
+        const float dx = 20.0f * (cy * ck - sy * sk), dy = 20.0f * (sy * ck + cy * sk);
+        const float ix = dx != 0.0f ? 1.0f / dx : 0.0f, iy = dy != 0.0f ? 1.0f / dy : 0.0f;
+        float best = 3.0e38f;
+        BoxRec nx = load_box(LB);
+        for (int b = 0; b < cB; b++) {
+          const BoxRec bx = nx;
+          nx = load_box(LB + (b + 1) * EPMC_BOX_WORDS);
+          float te = -3.0e38f, tl = 3.0e38f;
+          slab_axis(bx.a.x, bx.a.y, pos[0], dx, ix, te, tl);
+          slab_axis(bx.a.z, bx.a.w, pos[1], dy, iy, te, tl);
+          const bool ok = (pos[2] >= bx.c.x) & (pos[2] <= bx.c.y) & (te <= tl) & (te >= 0.0f) & (te <= 1.0f);
+          best = ok ? fminf(best, te) : best;
+        }
+        const bool hit = best < 2.0f;
+        const int r = EPMC_N_HEIGHT + k;
+        percep[r] = hit ? best * 20.0f : miss;
+        if (E.ray_trace) {
+          float* tr = E.ray_trace + ((long)env * EPMC_N_RAYS + r) * 8;
+          tr[0] = pos[0]; tr[1] = pos[1]; tr[2] = pos[2]; tr[3] = pos[0] + dx; tr[4] = pos[1] + dy; tr[5] = pos[2]; tr[6] = hit ? 1.0f : 0.0f; tr[7] = hit ? best : 1.0f;
+        }
+      }
+    }
+    if (PMC_ABL(128)) return;                                                    // ablation: height rays and the fan only
+    // --- front rays (PGE:405-427): from (0, gy, gz) to (3, gy, gz) in the base frame; a miss counts as the far end ---
+    {
+      const float d[3] = {3.0f * R.m[0], 3.0f * R.m[3], 3.0f * R.m[6]};
+      float inv[3];
+      for (int a = 0; a < 3; a++) inv[a] = d[a] != 0.0f ? 1.0f / d[a] : 0.0f;
+      for (int i = ln.ray_first(); i < EPMC_N_FRONT; i += ln.ray_stride()) {
+        float gy, gz;
+        grid_point(i, -0.25f, 0.25f, -0.3f, 0.1f, &gy, &gz);
+        float o[3];
+        for (int a = 0; a < 3; a++) o[a] = R.m[3 * a + 1] * gy + R.m[3 * a + 2] * gz + pos[a];
+        float best = 3.0e38f;
+        if (d[2] < 0.0f) {
+          const float tz = -o[2] * inv[2];
+          if (tz >= 0.0f && tz <= 1.0f) best = tz;
+        }
+        BoxRec nx = load_box(LA);
+        for (int b = 0; b < cA; b++) {
+          const BoxRec bx = nx;
+          nx = load_box(LA + (b + 1) * EPMC_BOX_WORDS);
+          float te = -3.0e38f, tl = 3.0e38f;
+          slab_axis(bx.a.x, bx.a.y, o[0], d[0], inv[0], te, tl);
+          slab_axis(bx.a.z, bx.a.w, o[1], d[1], inv[1], te, tl);
+          slab_axis(bx.c.x, bx.c.y, o[2], d[2], inv[2], te, tl);
+          const bool ok = (te <= tl) & (te >= 0.0f) & (te <= 1.0f);
+          best = ok ? fminf(best, te) : best;
+        }
+        const bool hit = best < 2.0f;
+        const int r = EPMC_N_HEIGHT + EPMC_N_HORIZ + i;
+        percep[r] = hit ? best * 3.0f : 3.0f;
+        if (E.ray_trace) {
+          float* tr = E.ray_trace + ((long)env * EPMC_N_RAYS + r) * 8;
+          for (int a = 0; a < 3; a++) { tr[a] = o[a]; tr[3 + a] = o[a] + d[a]; }
+          tr[6] = hit ? 1.0f : 0.0f; tr[7] = hit ? best : 1.0f;
+        }
+      }
+    }
+  }
+  // what the env makes of one ray's answer (PGE:395-447), for the scripted path
+  static LL_HD void emit_ray(const EpmcParams& E, int env, int r, const float* f, const float* t, bool hit, float frac, const float* noise, float* percep) {
+    if (E.ray_trace) {
+      float* tr = E.ray_trace + ((long)env * EPMC_N_RAYS + r) * 8;
+      tr[0] = f[0]; tr[1] = f[1]; tr[2] = f[2]; tr[3] = t[0]; tr[4] = t[1]; tr[5] = t[2]; tr[6] = hit ? 1.0f : 0.0f; tr[7] = frac;
+    }
+    const float hx = hit ? f[0] + frac * (t[0] - f[0]) : 0.0f, hy = hit ? f[1] + frac * (t[1] - f[1]) : 0.0f, hz = hit ? f[2] + frac * (t[2] - f[2]) : 0.0f;
+    float v;
+    if (r < EPMC_N_HEIGHT) {                                                  // PGE:442-446 hit height; a miss reports (0,0,0)
+      v = hz;
+      if (E.noise_on[3]) v = (v > 0.01f && v < 0.6f) ? v + noise[3] : 0.0f;
+    } else if (r < EPMC_N_HEIGHT + EPMC_N_HORIZ) {                            // PGE:399, :49-50: a miss measures |(0,0,0) - origin|
+      const float dx = hx - f[0], dy = hy - f[1], dz = hz - f[2];
+      v = sqrtf(dx * dx + dy * dy + dz * dz);
+    } else {                                                                  // PGE:425-427: a miss counts as the far end
+      const float px = hit ? hx : t[0], py = hit ? hy : t[1], pz = hit ? hz : t[2];
+      const float dx = px - f[0], dy = py - f[1], dz = pz - f[2];
+      v = sqrtf(dx * dx + dy * dy + dz * dz);
+    }
+    percep[r] = v;
   }
 
   // ------------------------------------------------------------------------------------------------------------

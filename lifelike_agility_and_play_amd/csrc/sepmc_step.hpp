@@ -16,7 +16,7 @@
 #define SEPMC_SP_STRIDE 40
 #define SEPMC_MAX_CONTACTS 8     // scripted getContactPoints records per arena
 #define SEPMC_N_VIS 21           // visibility rays per arena: base to base, then head of robot i to the 10 convex points of the other
-#define SEPMC_VIS_SCRATCH 256    // word of the row scratch where the visibility end points go (after the staged boxes)
+#define SEPMC_VIS_SCRATCH 544    // word of the row scratch where the visibility end points go (after the staged boxes and the ray lists)
 
 enum SepmcField {
   SP_FLAG = 0,          // 3 flag position (CTG:231-236)
