@@ -366,7 +366,7 @@ struct Sepmc {
     ex.want_touch = false; ex.flag_shape = -1; ex.touch_static = ex.touch_flag = ex.touch_robot = 0.0f;
     {   // can the two robots meet during this control step?  (reach 0.55 m each + what 20 ms of motion adds)
       const float ddx = ln.peer_u(bs.p.x) - bs.p.x, ddy = ln.peer_u(bs.p.y) - bs.p.y, ddz = ln.peer_u(bs.p.z) - bs.p.z;
-      ex.pair_active = !E.scr_state && S.robot_contacts && (ddx * ddx + ddy * ddy + ddz * ddz < 1.5f * 1.5f);
+      ex.pair_active = !E.scr_state && S.robot_contacts && !PMC_ABL(2048) && (ddx * ddx + ddy * ddy + ddz * ddz < 1.5f * 1.5f);
       ex.pair_me = me;
     }
     const int nb = (int)sp[SP_N_BOXES];
@@ -386,7 +386,7 @@ struct Sepmc {
       }
       ln.row_sync();
       ex.shapes = near;
-      ex.n_shapes = (E.terrain_contacts && !E.scr_state) ? (n_near < EPMC_MAX_NEAR ? n_near : EPMC_MAX_NEAR) : 0;
+      ex.n_shapes = (E.terrain_contacts && !E.scr_state && !PMC_ABL(4096)) ? (n_near < EPMC_MAX_NEAR ? n_near : EPMC_MAX_NEAR) : 0;
       ex.box_mu_scale = E.box_friction / E.plane_friction;
     }
     float* ptrace = E.push_trace + (long)row * P.n_sub * 4;
@@ -483,7 +483,7 @@ struct Sepmc {
     if (reason) {
       if (me == 0) K::count_add(ln, P.counters + 1);
       if (bad && me == 0) K::count_add(ln, P.counters + 2);
-      if (P.auto_reset) {
+      if (P.auto_reset && !PMC_ABL(8192)) {
         const uint32_t episode = (uint32_t)sp[SP_EPISODE] + 1u;
         sp[SP_EPISODE] = (float)episode;
         EpmcDraws dr = {nullptr, 0, 0, P.seed, (uint32_t)arena, episode, 0x5e9a1du};

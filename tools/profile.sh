@@ -26,6 +26,9 @@ fi
 python bench.py --workload epmc --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/epmc_bench.log 2>$OUT/epmc_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/epmc_stats -- python bench.py --workload epmc --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2>&1
 python tools/sweep_epmc.py "4096:0,4096:1,4096:2,4096:3,16384:1,65536:1" > $OUT/epmc_sweep.txt 2>&1
+python bench.py --workload sepmc --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/sepmc_bench.log 2>$OUT/sepmc_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sepmc_stats -- python bench.py --workload sepmc --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2>&1
+python tools/sweep_sepmc.py "2048:0,2048:1,8192:0,32768:0,32768:1" > $OUT/sepmc_sweep.txt 2>&1
 (python tools/rollout_policy.py 4096 300 hip; python tools/rollout_policy.py 65536 200 hip; python tools/rollout_policy.py 4096 300 torch) > $OUT/policy_rollout.txt 2>&1
 find $OUT -name "*.csv" -size +20M -delete
 tail -c 600 $OUT/bench.log

@@ -17,12 +17,13 @@ def one(pattern):
 
 
 shutil.copy(one('stats/**/*kernel_stats.csv'), os.path.join(dst, '%s_kernel_stats.csv' % tag))
-for name in ('bench.log', 'sweep.txt', 'timeline.txt', 'ablation.txt', 'epmc_bench.log', 'epmc_sweep.txt', 'policy_rollout.txt'):
+for name in ('bench.log', 'sweep.txt', 'timeline.txt', 'ablation.txt', 'epmc_bench.log', 'epmc_sweep.txt', 'sepmc_bench.log', 'sepmc_sweep.txt', 'policy_rollout.txt'):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, '%s_%s' % (tag, name.replace('bench.log', 'bench_n1.log'))))
-if glob.glob(os.path.join(src, 'epmc_stats/**/*kernel_stats.csv'), recursive=True):
-    shutil.copy(one('epmc_stats/**/*kernel_stats.csv'), os.path.join(dst, '%s_epmc_kernel_stats.csv' % tag))
+for fam in ('epmc', 'sepmc'):
+    if glob.glob(os.path.join(src, fam + '_stats/**/*kernel_stats.csv'), recursive=True):
+        shutil.copy(one(fam + '_stats/**/*kernel_stats.csv'), os.path.join(dst, '%s_%s_kernel_stats.csv' % (tag, fam)))
 
 counters, meta = {}, {}
 for sub in ('pmc_sq', 'pmc_fetch', 'pmc_write'):
