@@ -225,6 +225,18 @@ class OracleBatch(object):
         assert rc == 0
         return s, nc.value, lam
 
+    def substep_pair(self, state0, state1, tau0, tau1, mu_foot, shapes0, shapes1, box_mu_scale, push0=None, push1=None):
+        """One substep of the two robots of a SEPMC arena (sepmc parity tests).  Returns (state0, state1, shared rows [n][8])."""
+        s0, s1 = f64(state0).copy(), f64(state1).copy()
+        sh = [f64(np.asarray(x).reshape(-1, 8)) if len(x) else np.zeros((0, 8)) for x in (shapes0, shapes1)]
+        pu = [None if x is None else f64(x) for x in (push0, push1)]
+        rows = np.zeros((2, 8))
+        n = lib().orc_substep_pair(self.h, _p(s0), _p(s1), _p(f64(tau0)), _p(f64(tau1)), C.c_double(mu_foot), C.c_int(len(sh[0])), _p(sh[0]) if len(sh[0]) else None,
+                                   C.c_int(len(sh[1])), _p(sh[1]) if len(sh[1]) else None, C.c_double(box_mu_scale), _p(pu[0]) if pu[0] is not None else None,
+                                   _p(pu[1]) if pu[1] is not None else None, _p(rows))
+        assert n >= 0
+        return s0, s1, rows[:n]
+
     def momentum(self, state):
         out = np.zeros(6); lib().orc_momentum(self.h, _p(f64(state)), _p(out)); return out
 

@@ -792,9 +792,32 @@ int orc_substep_model(const OModel* M, double dt, int n_iter, double mu_foot, do
 }
 /* T (nullable): EPMC terrain; push (nullable): PR:72-77 applyExternalForce(linkIndex 0, LINK_FRAME) -- a force in the FR hip link's
  * frame at that link's centre of mass */
-static int substep_terrain(const OModel* M, double dt, int n_iter, double mu_foot, double* state, const double* tau_in, OSubstepDiag* diag,
-                           const OTerrain* T, const double* push) {
+/* Everything one robot brings to the solve: kinematics, the velocities after the unconstrained update, its rows in the order of the
+ * spec, M^-1 J^T.  The projected Gauss-Seidel then runs in velocity form (nu carries the impulses applied so far):
+ * w = J nu + bias, lambda' = clamp(lambda - w / (J M^-1 J^T)), nu += M^-1 J^T (lambda' - lambda) -- the same iteration as the
+ * A-matrix form, and the form in which rows shared between two robots (SEPMC) are natural. */
+typedef struct {
   OKin K;
+  double nu[NDOF];
+  int nr, no, nc;
+  double J[MAXROWS][NDOF], MiJt[MAXROWS][NDOF], Minv[NDOF][NDOF];
+  double bias[MAXROWS], lo[MAXROWS], hi[MAXROWS], lam[MAXROWS], mu_row[MAXROWS], dinv[MAXROWS];
+  int fric_of[MAXROWS], order[MAXROWS], lim_row[12], con_row[4][KC];
+  int con_leg[MAXC], con_slot[MAXC];
+} ORows;
+
+static int assemble_rows(const OModel* M, double dt, double mu_foot, const double* state, const double* tau_in, OSubstepDiag* diag,
+                         const OTerrain* T, const double* push, ORows* W) {
+#define K (W->K)
+#define nu (W->nu)
+#define J (W->J)
+#define bias (W->bias)
+#define lo (W->lo)
+#define hi (W->hi)
+#define fric_of (W->fric_of)
+#define mu_row (W->mu_row)
+#define lim_row (W->lim_row)
+#define con_row (W->con_row)
   double fext[NB][6], acc[NDOF], tau[12];
   kinematics(M, state, NULL, &K);
   external_forces(M, &K, fext);
@@ -808,7 +831,7 @@ static int substep_terrain(const OModel* M, double dt, int n_iter, double mu_foo
   if (diag) memcpy(diag->acc_free, acc, sizeof acc);
 
   /* velocities after the unconstrained update, generalized body-frame coordinates nu = [w_b, v_b, qd] */
-  double nu[NDOF], wxv[3];
+  double wxv[3];
   v3cross(K.v[0], K.v[0] + 3, wxv);
   for (int i = 0; i < 3; i++) {
     nu[i] = K.v[0][i] + dt * acc[i];
@@ -820,14 +843,12 @@ static int substep_terrain(const OModel* M, double dt, int n_iter, double mu_foo
   /* ---- constraint rows --------------------------------------------------------------------------- */
   OContact C[MAXC];
   int nc = find_contacts(M, &K, mu_foot, LLM_LINK_FRICTION * LLM_PLANE_FRICTION, T, C);
-  static _Thread_local double J[MAXROWS][NDOF], MiJt[MAXROWS][NDOF], A[MAXROWS][MAXROWS];
-  double bias[MAXROWS], lo[MAXROWS], hi[MAXROWS], lam[MAXROWS];
-  int fric_of[MAXROWS]; double mu_row[MAXROWS];
   int nr = 0;
+  W->nc = nc;
+  for (int c = 0; c < nc; c++) { W->con_leg[c] = C[c].leg; W->con_slot[c] = C[c].slot; }
   /* joint limits: one unilateral row per joint toward its nearer limit (URDF <limit>, Bullet
    * btMultiBodyJointLimitConstraint).  A row can only ever act if its free approach speed s*qd* + bias is small,
    * so rows with s*qd* + bias >= LLM_LIMIT_GATE are left out of the solve (DESIGN.md "joint limits"). */
-  int lim_row[12];
   for (int i = 0; i < 12; i++) {
     double dl = state[13 + i] - M->qlo[i], dh = M->qhi[i] - state[13 + i];
     double d = dl <= dh ? dl : dh, sgn = dl <= dh ? 1.0 : -1.0;
@@ -842,7 +863,6 @@ static int substep_terrain(const OModel* M, double dt, int n_iter, double mu_foo
     nr++;
   }
   /* contacts: normal + two friction rows, directions n=+z, t1=(0,-1,0), t2=(1,0,0) (btPlaneSpace1 of +z) */
-  int con_row[4][KC];
   for (int l = 0; l < 4; l++) for (int k = 0; k < KC; k++) con_row[l][k] = -1;
   for (int c = 0; c < nc; c++) {
     int b = C[c].body;
@@ -916,68 +936,71 @@ static int substep_terrain(const OModel* M, double dt, int n_iter, double mu_foo
   }
   /* M^-1 J^T by unit responses of the ABA at zero velocity */
   {
-    static _Thread_local double Minv[NDOF][NDOF];
     double zero12[12] = {0};
     for (int d = 0; d < NDOF; d++) {
       double fe[NB][6], t12[12] = {0}, col[NDOF];
       memset(fe, 0, sizeof fe);
       if (d < 6) fe[0][d] = 1.0; else t12[d - 6] = 1.0;
       if (aba(M, &K, zero12, t12, fe, 0, col, col + 6)) return -1;
-      for (int i = 0; i < NDOF; i++) Minv[i][d] = col[i];
+      for (int i = 0; i < NDOF; i++) W->Minv[i][d] = col[i];
     }
-    for (int r = 0; r < nr; r++)
+    for (int r = 0; r < nr; r++) {
+      double dd = 0;
       for (int i = 0; i < NDOF; i++) {
         double s = 0;
-        for (int k = 0; k < NDOF; k++) s += Minv[i][k] * J[r][k];
-        MiJt[r][i] = s;
+        for (int k = 0; k < NDOF; k++) s += W->Minv[i][k] * J[r][k];
+        W->MiJt[r][i] = s;
       }
-    for (int r = 0; r < nr; r++)
-      for (int s2 = 0; s2 < nr; s2++) {
-        double s = 0;
-        for (int k = 0; k < NDOF; k++) s += J[r][k] * MiJt[s2][k];
-        A[r][s2] = s;
-      }
+      for (int k = 0; k < NDOF; k++) dd += J[r][k] * W->MiJt[r][k];
+      W->dinv[r] = 1.0 / dd;
+      W->lam[r] = 0;
+    }
   }
-  /* projected Gauss-Seidel, LR:261 numSolverIterations (10).  Row order of the spec: the limit rows
-   * (joint, leg), then all normal rows (slot, leg), all t1 rows, all t2 rows. */
-  int order[MAXROWS], no = 0;
+  /* Row order of the spec: the limit rows (joint, leg), then all normal rows (slot, leg), all t1 rows, all t2 rows,
+   * then the self-collision rows. */
+  int no = 0;
   for (int j = 0; j < 3; j++)
     for (int l = 0; l < 4; l++)
-      if (lim_row[3 * l + j] >= 0) order[no++] = lim_row[3 * l + j];
+      if (lim_row[3 * l + j] >= 0) W->order[no++] = lim_row[3 * l + j];
   for (int r = 0; r < 3; r++)
     for (int k = 0; k < KC; k++)
       for (int l = 0; l < 4; l++)
-        if (con_row[l][k] >= 0) order[no++] = con_row[l][k] + r;
-  for (int c = 0; c < ns; c++) order[no++] = self_row[c];      /* then the self-collision rows */
-  double v0[MAXROWS];
-  for (int r = 0; r < nr; r++) {
-    double s = 0;
-    for (int k = 0; k < NDOF; k++) s += J[r][k] * nu[k];
-    v0[r] = s; lam[r] = 0;
-  }
-  for (int it = 0; it < n_iter; it++) {
-    for (int oi = 0; oi < no; oi++) {
-      int r = order[oi];
-      double w = v0[r] + bias[r];
-      for (int s2 = 0; s2 < nr; s2++) w += A[r][s2] * lam[s2];
-      double l_new = lam[r] - w / A[r][r];
-      double l_lo = lo[r], l_hi = hi[r];
-      if (fric_of[r] >= 0) { l_hi = mu_row[r] * lam[fric_of[r]]; l_lo = -l_hi; }
-      if (l_new < l_lo) l_new = l_lo;
-      if (l_new > l_hi) l_new = l_hi;
-      lam[r] = l_new;
-    }
-  }
-  for (int r = 0; r < nr; r++)
-    for (int k = 0; k < NDOF; k++) nu[k] += MiJt[r][k] * lam[r];
-  if (diag) {   /* fixed layout for the tests: [12 limit rows (0 when gated out)] [3 rows per contact, contact order] */
-    diag->n_contacts = nc; diag->n_rows = 12 + 3 * nc;
-    memset(diag->lambda, 0, sizeof diag->lambda);
-    for (int i = 0; i < 12; i++) if (lim_row[i] >= 0) diag->lambda[i] = lam[lim_row[i]];
-    for (int c = 0; c < nc; c++)
-      for (int r = 0; r < 3; r++) diag->lambda[12 + 3 * c + r] = lam[con_row[C[c].leg][C[c].slot] + r];
-  }
+        if (con_row[l][k] >= 0) W->order[no++] = con_row[l][k] + r;
+  for (int c = 0; c < ns; c++) W->order[no++] = self_row[c];
+  W->nr = nr; W->no = no;
+  return 0;
+#undef K
+#undef nu
+#undef J
+#undef bias
+#undef lo
+#undef hi
+#undef fric_of
+#undef mu_row
+#undef lim_row
+#undef con_row
+}
 
+/* one Gauss-Seidel sweep over a robot's own rows (LR:261 numSolverIterations sweeps per substep) */
+static void sweep_rows(ORows* W) {
+  for (int oi = 0; oi < W->no; oi++) {
+    const int r = W->order[oi];
+    double w = W->bias[r];
+    for (int k = 0; k < NDOF; k++) w += W->J[r][k] * W->nu[k];
+    double l_new = W->lam[r] - w * W->dinv[r];
+    double l_lo = W->lo[r], l_hi = W->hi[r];
+    if (W->fric_of[r] >= 0) { l_hi = W->mu_row[r] * W->lam[W->fric_of[r]]; l_lo = -l_hi; }
+    if (l_new < l_lo) l_new = l_lo;
+    if (l_new > l_hi) l_new = l_hi;
+    const double d = l_new - W->lam[r];
+    W->lam[r] = l_new;
+    for (int k = 0; k < NDOF; k++) W->nu[k] += W->MiJt[r][k] * d;
+  }
+}
+
+static void integrate_state(const ORows* W, double dt, double* state) {
+  const double* nu = W->nu;
+#define K (W->K)
   /* ---- integrate positions with the NEW velocities (semi-implicit Euler) -------------------------- */
   double vw[3], ww[3];
   m3v(K.Rw[0], nu, ww);
@@ -989,7 +1012,132 @@ static int substep_terrain(const OModel* M, double dt, int n_iter, double mu_foo
   q_mul(dq, qn, qo);
   q_normalize(qo, state + 3);
   for (int i = 0; i < 12; i++) { state[25 + i] = nu[6 + i]; state[13 + i] += dt * nu[6 + i]; }
+#undef K
+}
+
+
+static int substep_terrain(const OModel* M, double dt, int n_iter, double mu_foot, double* state, const double* tau_in, OSubstepDiag* diag,
+                           const OTerrain* T, const double* push) {
+  static _Thread_local ORows W;
+  if (assemble_rows(M, dt, mu_foot, state, tau_in, diag, T, push, &W)) return -1;
+  for (int it = 0; it < n_iter; it++) sweep_rows(&W);
+  if (diag) {   /* fixed layout for the tests: [12 limit rows (0 when gated out)] [3 rows per contact, contact order] */
+    diag->n_contacts = W.nc; diag->n_rows = 12 + 3 * W.nc;
+    memset(diag->lambda, 0, sizeof diag->lambda);
+    for (int i = 0; i < 12; i++) if (W.lim_row[i] >= 0) diag->lambda[i] = W.lam[W.lim_row[i]];
+    for (int c = 0; c < W.nc; c++)
+      for (int r = 0; r < 3; r++) diag->lambda[12 + 3 * c + r] = W.lam[W.con_row[W.con_leg[c]][W.con_slot[c]] + r];
+  }
+  integrate_state(&W, dt, state);
   return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* SEPMC: two robots in one world (CTG:383-388).  Spec of this build (unpinned): each robot is ten capsules -- thigh and */
+/* shank-with-foot per leg (as for self-collision) and two along the trunk box, radius its half height, side by side; the two       */
+/* deepest of the 100 pairs within the contact margin (ties: lower pair id = 10 * capsule of robot 0 + capsule of robot 1) give one */
+/* frictionless row each, solved after both robots' own rows in every iteration.                                                 */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct { int body[2]; double P[3], n[3], depth; int id; } OPair;
+static void pair_capsule(const OModel* M, const OKin* K, int idx, double* a, double* b, double* r, int* body) {
+  if (idx < 8) { capsule(M, K, idx >> 1, idx & 1, a, b, r, body); return; }
+  const OPrim* bb = &M->base_prims[0];
+  const double rr = bb->size[2], hx = bb->size[0] - rr, oy = (idx == 8 ? 1.0 : -1.0) * (bb->size[1] - rr);
+  double la[3], lb[3], t[3];
+  for (int i = 0; i < 3; i++) {
+    la[i] = bb->pos[i] + hx * bb->rot[3 * i] + oy * bb->rot[3 * i + 1];
+    lb[i] = bb->pos[i] - hx * bb->rot[3 * i] + oy * bb->rot[3 * i + 1];
+  }
+  *r = rr; *body = 0;
+  m3v(K->Rw[0], la, t); for (int i = 0; i < 3; i++) a[i] = K->pw[0][i] + t[i];
+  m3v(K->Rw[0], lb, t); for (int i = 0; i < 3; i++) b[i] = K->pw[0][i] + t[i];
+}
+static int find_pair_contacts(const OModel* M, const OKin* K0, const OKin* K1, OPair* out) {
+  static _Thread_local OPair cand[100];
+  int nc = 0;
+  for (int ia = 0; ia < 10; ia++)
+    for (int ib = 0; ib < 10; ib++) {
+      double a1[3], b1[3], a2[3], b2[3], r1, r2, c1[3], c2[3], d[3];
+      int bA, bB;
+      pair_capsule(M, K0, ia, a1, b1, &r1, &bA);
+      pair_capsule(M, K1, ib, a2, b2, &r2, &bB);
+      seg_seg(a1, b1, a2, b2, c1, c2);
+      for (int i = 0; i < 3; i++) d[i] = c1[i] - c2[i];
+      double len = sqrt(v3dot(d, d));
+      if (len < 1e-9) continue;
+      OPair* o = &cand[nc++];
+      o->body[0] = bA; o->body[1] = bB; o->depth = len - r1 - r2; o->id = ia * 10 + ib;
+      for (int i = 0; i < 3; i++) { o->n[i] = d[i] / len; o->P[i] = 0.5 * ((c1[i] - r1 * o->n[i]) + (c2[i] + r2 * o->n[i])); }
+    }
+  int n = 0, taken[100] = {0};
+  for (int s = 0; s < 2; s++) {
+    int best = -1;
+    for (int i = 0; i < nc; i++)
+      if (!taken[i] && cand[i].depth < LLM_CONTACT_MARGIN && (best < 0 || cand[i].depth < cand[best].depth)) best = i;
+    if (best < 0) break;
+    taken[best] = 1;
+    out[n++] = cand[best];
+  }
+  return n;
+}
+/* states[2][37], taus[2][12], pushes[2] (nullable entries), one terrain for both; returns the number of shared rows */
+int orc_substep_pair_model(const OModel* M, double dt, int n_iter, const double* mu_foot2, double* state0, double* state1, const double* tau0,
+                           const double* tau1, const OTerrain* T0, const OTerrain* T1, const double* push0, const double* push1, double* pair_rows) {
+  static _Thread_local ORows W[2];
+  double* st[2] = {state0, state1};
+  if (assemble_rows(M, dt, mu_foot2[0], state0, tau0, NULL, T0, push0, &W[0])) return -1;
+  if (assemble_rows(M, dt, mu_foot2[1], state1, tau1, NULL, T1, push1, &W[1])) return -1;
+  OPair PC[2];
+  const int np = find_pair_contacts(M, &W[0].K, &W[1].K, PC);
+  double Jp[2][2][NDOF], MJ[2][2][NDOF], dinv[2], bias[2], lam[2] = {0, 0};
+  for (int c = 0; c < np; c++) {
+    double dd = 0;
+    for (int side = 0; side < 2; side++) {
+      const OKin* K = &W[side].K;
+      const int b = PC[c].body[side];
+      double d3[3], ploc[3];
+      for (int i = 0; i < 3; i++) d3[i] = PC[c].P[i] - K->pw[b][i];
+      m3tv(K->Rw[b], d3, ploc);
+      for (int d = 0; d < NDOF; d++) {
+        double e[NDOF], t[3], vl[3], vw[3];
+        memset(e, 0, sizeof e);
+        e[d] = 1.0;
+        OKin Kd;
+        kinematics(M, st[side], e, &Kd);
+        v3cross(Kd.v[b], ploc, t);
+        for (int i = 0; i < 3; i++) vl[i] = Kd.v[b][3 + i] + t[i];
+        m3v(K->Rw[b], vl, vw);
+        Jp[c][side][d] = (side ? -1.0 : 1.0) * v3dot(PC[c].n, vw);       /* n points from robot 1 to robot 0 */
+      }
+      for (int i = 0; i < NDOF; i++) {
+        double s = 0;
+        for (int k = 0; k < NDOF; k++) s += W[side].Minv[i][k] * Jp[c][side][k];
+        MJ[c][side][i] = s;
+      }
+      for (int k = 0; k < NDOF; k++) dd += Jp[c][side][k] * MJ[c][side][k];
+    }
+    dinv[c] = 1.0 / dd;
+    bias[c] = PC[c].depth > 0 ? PC[c].depth / dt : LLM_ERP * PC[c].depth / dt;
+    if (pair_rows) { for (int i = 0; i < 3; i++) { pair_rows[8 * c + i] = PC[c].P[i]; pair_rows[8 * c + 3 + i] = PC[c].n[i]; } pair_rows[8 * c + 6] = PC[c].depth; pair_rows[8 * c + 7] = PC[c].id; }
+  }
+  for (int it = 0; it < n_iter; it++) {
+    sweep_rows(&W[0]);
+    sweep_rows(&W[1]);
+    for (int c = 0; c < np; c++) {
+      double w = bias[c];
+      for (int side = 0; side < 2; side++)
+        for (int k = 0; k < NDOF; k++) w += Jp[c][side][k] * W[side].nu[k];
+      double l_new = lam[c] - w * dinv[c];
+      if (l_new < 0) l_new = 0;
+      const double d = l_new - lam[c];
+      lam[c] = l_new;
+      for (int side = 0; side < 2; side++)
+        for (int k = 0; k < NDOF; k++) W[side].nu[k] += MJ[c][side][k] * d;
+    }
+  }
+  integrate_state(&W[0], dt, state0);
+  integrate_state(&W[1], dt, state1);
+  return np;
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -1239,6 +1387,16 @@ int orc_substep_terrain(const OBatch* B, double* state, const double* tau, doubl
 }
 
 /* tests: the self-collision candidates of a state: up to 2 rows [depth, pair index, P(3), n(3)]; returns how many */
+/* SEPMC: one substep of two robots in one world; shapes0 / shapes1 = the terrain records within reach of each (the flag among them);
+ * pair_rows8 (nullable): [2][8] = P 3, n 3 (from robot 1 to robot 0), depth, pair id of the shared rows.  Returns their number. */
+int orc_substep_pair(const OBatch* B, double* state0, double* state1, const double* tau0, const double* tau1, double mu_foot, int n_shapes0,
+                     const double* shapes0, int n_shapes1, const double* shapes1, double box_mu_scale, const double* push0, const double* push1,
+                     double* pair_rows8) {
+  OTerrain T0 = {n_shapes0, shapes0, box_mu_scale}, T1 = {n_shapes1, shapes1, box_mu_scale};
+  const double mu2[2] = {mu_foot, mu_foot};
+  return orc_substep_pair_model(&B->model, B->dt, B->cfg.solver_iterations, mu2, state0, state1, tau0, tau1, n_shapes0 > 0 ? &T0 : NULL,
+                                n_shapes1 > 0 ? &T1 : NULL, push0, push1, pair_rows8);
+}
 int orc_self_contacts(const OBatch* B, const double* state, double* rows8) {
   OKin K;
   kinematics(&B->model, state, NULL, &K);

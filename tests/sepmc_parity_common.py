@@ -430,3 +430,78 @@ def check_robot_robot_contact(lib_path):
     assert abs(E.state()[2, 0, 0] + 1.5) < 0.2          # the far pair stayed where it was
     E.close()
     return dict(stack_gap=float(zs[-1]))
+
+
+def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5):
+    """Two robots within reach of each other (side by side, nose to tail, one partly above the other), random joint states and
+    velocities, the push active: one control step of real physics, engine (float32, two rows exchanging registers) vs the float64
+    oracle's two-robot substep (orc_substep_pair: explicit Jacobians, M^-1 by unit responses) given the same arena records,
+    friction and push forces.  The two share the spec (capsules, pair order, row order) and nothing else."""
+    from conftest import make_oracle_batch
+    from oracle import oracle as orc
+    from lifelike_agility_and_play_amd import mocap, urdf_model
+    from parity_common import quat_align
+    cfg = env_config((1, 0, 0))
+    cfg['env_randomize_config']['disturb_force_config'] = {'start_time': 0.0, 'interval_time': 1.0, 'duration_time': 0.5, 'horizontal_force': [10, 50], 'vertical_force': [0, 10]}
+    E = make_engine(cfg, n_arenas, lib_path, seed=seed)
+    E.reset()
+    rng = np.random.default_rng(seed)
+    st = E.state().astype(np.float64)
+    from scipy.spatial.transform import Rotation as R
+    for a in range(n_arenas):
+        c = rng.uniform(-1.2, 1.2, 2)
+        ang = rng.uniform(0, 2 * np.pi)
+        dist = rng.uniform(0.18, 0.62)
+        off = 0.5 * dist * np.array([np.cos(ang), np.sin(ang)])
+        for r in range(2):
+            st[a, r, 0:2] = c + (off if r == 0 else -off)
+            st[a, r, 2] = rng.uniform(0.27, 0.33) + (0.12 if (a % 4 == 3 and r == 0) else 0.0)
+            st[a, r, 3:7] = R.from_euler('xyz', [rng.normal() * 0.1, rng.normal() * 0.1, rng.uniform(0, 2 * np.pi)]).as_quat()
+            st[a, r, 7:13] = rng.normal(size=6) * 0.3
+            st[a, r, 13:25] += rng.normal(size=12) * 0.15
+            st[a, r, 25:37] = rng.normal(size=12)
+    E.set_state(st)
+    st32 = E.state().astype(np.float64)
+    act = (rng.normal(size=(n_arenas, 2, 12)) * 0.135).astype(np.float32)
+    ep = E.episode()
+    rows, cnt = E.boxes()
+    E.step_host(act)
+    es = E.state().astype(np.float64)
+    tr = E.push_trace().astype(np.float64)
+    B = make_oracle_batch(orc, urdf_model.default_model_blob(), mocap.load_mocap('', 0.02), n_envs=1, kd=0.5, max_tau=16.0)
+    out = dict(config=[], vel=[], n_rows=0, n_felt=0)
+    for a in range(n_arenas):
+        rec = np.array([[rows[a][b][0] - rows[a][b][3], rows[a][b][0] + rows[a][b][3], rows[a][b][1] - rows[a][b][4], rows[a][b][1] + rows[a][b][4],
+                         rows[a][b][2] - rows[a][b][5], rows[a][b][2] + rows[a][b][5], 0.0, 0.0] for b in range(cnt[a])], dtype=np.float64).reshape(-1, 8)
+        fl = np.array([ep['flag_x'][a], ep['flag_y'][a], ep['flag_z'][a]], dtype=np.float64)
+        rec = np.vstack([rec, [[fl[0] - 0.05, fl[0] + 0.05, fl[1] - 0.05, fl[1] + 0.05, fl[2] - 0.25, fl[2] + 0.25, 0.0, 0.0]]]).astype(np.float32).astype(np.float64)
+        near, s, s_free = [], [], []
+        for r in range(2):
+            p = st32[a, r, 0:3]
+            near.append(rec[(p[0] >= rec[:, 0] - 0.9) & (p[0] <= rec[:, 1] + 0.9) & (p[1] >= rec[:, 2] - 0.9) & (p[1] <= rec[:, 3] + 0.9) & (p[2] <= rec[:, 5] + 0.9)][:8])
+            s.append(st32[a, r].copy()); s_free.append(st32[a, r].copy())
+        tgt = [np.clip(s[r][13:25] + act[a, r].astype(np.float64), -3.0, 3.0) for r in range(2)]
+        mu = float(np.float32(ep['friction'][a]) * np.float32(0.9))
+        nrows = 0
+        for k in range(10):
+            tau = [np.clip(50.0 * (tgt[r] - s[r][13:25]) - 0.5 * s[r][25:37], -16.0, 16.0) for r in range(2)]
+            push = [tr[a, r, k, 1:4] if tr[a, r, k, 0] > 0.5 else None for r in range(2)]
+            s[0], s[1], pr = B.substep_pair(s[0], s[1], tau[0], tau[1], mu, near[0], near[1], 0.5 / 0.9, push[0], push[1])
+            nrows += len(pr)
+            for r in range(2):                                   # the same step with the other robot ignored
+                tf = np.clip(50.0 * (tgt[r] - s_free[r][13:25]) - 0.5 * s_free[r][25:37], -16.0, 16.0)
+                s_free[r], _, _ = B.substep_terrain(s_free[r], tf, mu, near[r], 0.5 / 0.9, push[r])
+        out['n_rows'] += 1 if nrows else 0
+        if max(np.abs(s[r] - s_free[r]).max() for r in range(2)) > 1e-3:
+            out['n_felt'] += 1
+        for r in range(2):
+            err = np.abs(quat_align(es[a, r], s[r]) - s[r])
+            out['config'].append(max(err[0:7].max(), err[13:25].max()))
+            out['vel'].append(max(err[7:13].max(), err[25:37].max()) / (1.0 + np.abs(s[r][25:37]).max()))
+    E.close()
+    c, v = np.array(out['config']), np.array(out['vel'])
+    assert out['n_rows'] >= n_arenas // 2 and out['n_felt'] >= n_arenas // 3, (out['n_rows'], out['n_felt'])
+    assert np.median(c) < 1e-4 and np.median(v) < 1e-3, (np.median(c), np.median(v))
+    assert (c < 5e-3).mean() > 0.9 and (v < 5e-2).mean() > 0.9, (np.sort(c)[-6:], np.sort(v)[-6:])   # a near-tie between two capsule pairs may fall either way in float32
+    return dict(config_median=float(np.median(c)), config_max=float(c.max()), vel_median=float(np.median(v)), vel_max=float(v.max()), arenas_with_rows=out['n_rows'],
+                arenas_felt=out['n_felt'])

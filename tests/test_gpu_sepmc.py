@@ -29,3 +29,7 @@ def test_flag_handover_by_physical_contact_gpu():
 
 def test_robot_robot_contact_gpu():
     print(SC.check_robot_robot_contact(None))
+
+
+def test_pair_physics_against_oracle_gpu():
+    print(SC.check_pair_physics_against_oracle(None, n_arenas=64, seed=9))

@@ -38,3 +38,7 @@ def test_flag_handover_by_physical_contact(emul_lib):
 
 def test_robot_robot_contact(emul_lib):
     print(SC.check_robot_robot_contact(emul_lib))
+
+
+def test_pair_physics_against_oracle(emul_lib):
+    print(SC.check_pair_physics_against_oracle(emul_lib))
