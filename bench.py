@@ -94,17 +94,24 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
+    tc = torch.cuda.is_available()      # torch is plumbing (streams, RCCL): a single-GPU run goes on without it if only torch fails to see the device
+    if not tc and world > 1:
+        raise SystemExit('bench.py --gpus > 1 needs torch.cuda for the RCCL gather')
     # test hooks (a 1-GPU box cannot host two RCCL ranks): LL_BENCH_BACKEND=gloo LL_BENCH_ONE_DEVICE=1 runs the N>1
     # control flow with every rank on device 0 and the gather staged through host memory
     backend = os.environ.get('LL_BENCH_BACKEND', 'nccl')
     if os.environ.get('LL_BENCH_ONE_DEVICE'):
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    if tc:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def dev_sync():
+        eng.sync()
+        if tc:
+            torch.cuda.synchronize()
 
     n = args.envs_per_gpu
     blob = urdf_model.default_model_blob()
@@ -112,8 +119,9 @@ def main():
     cfg = capi.make_config(n, control_freq=50.0, sim_freq=500.0, kp=50.0, kd=0.5, max_tau=18.0,
                            reward_weights=PMC_REWARD_WEIGHTS, prop_type=PMC_PROP_TYPE, prioritized_sample_factor=3.0,
                            auto_reset=1, seed=1234 + rank, device=local_rank)
-    eng = capi.Engine(cfg, blob, table)
-    stream = gather.bind_torch_stream(eng)             # step kernels, torch ops and the RCCL gather are ordered on one stream
+    eng = capi.Engine(cfg, blob, table)                # (raises LL_ENODEV without a HIP device: there is no CPU path)
+    if tc:
+        gather.bind_torch_stream(eng)                  # step kernels, torch ops and the RCCL gather are ordered on one stream
     eng.reset()
     traj = gather.TrajectoryBuffer(eng, UNROLL) if world > 1 else None
 
@@ -131,17 +139,17 @@ def main():
         traj.wait()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    dev_sync()
     eng.enable_kernel_timing(True)
     t0 = time.perf_counter()
     for t in range(args.steps):
         one_step(t)
     if traj is not None:
         traj.wait()                                          # an in-flight gather belongs to the timed region
-    torch.cuda.synchronize()
+    dev_sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    dev_sync()
     elapsed = time.perf_counter() - t0
     k_ms, k_n = eng.kernel_time_ms()
     eng.enable_kernel_timing(False)
@@ -150,6 +158,24 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     counters = eng.counters()
+    triad = None
+    if rank == 0 and world == 1 and tc:
+        # the nominal HBM figure next to a device triad measured on this box (a = b + s * c on 3 x 1 GiB, torch's own kernel:
+        # a calibration of the denominator, not part of the product)
+        try:
+            nel = 1 << 28
+            b_ = torch.ones(nel, device='cuda', dtype=torch.float32); c_ = torch.ones(nel, device='cuda', dtype=torch.float32); a_ = torch.empty_like(b_)
+            for _ in range(3):
+                torch.add(b_, c_, alpha=1.5, out=a_)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                torch.add(b_, c_, alpha=1.5, out=a_)
+            e1.record(); torch.cuda.synchronize()
+            triad = 10 * 3 * nel * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del a_, b_, c_
+        except Exception:                # noqa: BLE001
+            triad = None
 
     if rank == 0:
         total_env_steps = world * n * args.steps
@@ -181,9 +207,10 @@ def main():
             'config': {'workload': 'PMC tracking env, %d parallel envs per MI355X, flat terrain, full mocap_data clip set '
                                    '(62 clips), random-policy actions N(0, e^-2), auto-reset%s' % (n, ', RCCL trajectory gather to rank 0 every %d steps' % UNROLL if world > 1 else ''),
                        'envs_per_gpu': n, 'substeps_per_step': 10, 'solver_iterations': 10,
-                       'episodes_finished_rank0': counters['episodes'], 'nonfinite_resets_rank0': counters['nonfinite']},
+                       'episodes_finished_rank0': counters['episodes'], 'nonfinite_resets_rank0': counters['nonfinite'],
+                       'mean_episode_length_steps_rank0': (counters['env_steps'] / counters['episodes']) if counters['episodes'] else None},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': (achieved / HBM_PEAK_GBPS) if achieved else None, 'traffic': traffic,
+                         'frac': (achieved / HBM_PEAK_GBPS) if achieved else None, 'traffic': traffic, 'peak_measured_triad': triad,
                          'traffic_source': 'profiles/traffic.json (bytes per launch, FETCH_SIZE + WRITE_SIZE, uncorrected; see DESIGN.md 5.1)',
                          'kernel': 'pmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
                          'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP, 'single_wave_issue': issue,
@@ -217,9 +244,11 @@ def main_epmc(args):
     import torch.distributed as dist
     from lifelike_agility_and_play_amd import epmc_capi, urdf_model
     world = int(os.environ.get('WORLD_SIZE', '1')); rank = int(os.environ.get('RANK', '0')); local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
-    torch.cuda.set_device(local_rank)
+    tc = torch.cuda.is_available()
+    if not tc and world > 1:
+        raise SystemExit('bench.py --gpus > 1 needs torch.cuda')
+    if tc:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(os.environ.get('LL_BENCH_BACKEND', 'nccl'), rank=rank, world_size=world)
@@ -235,12 +264,16 @@ def main_epmc(args):
         one_step()
     if world > 1:
         dist.barrier()
-    eng.sync(); torch.cuda.synchronize()
+    eng.sync()
+    if tc:
+        torch.cuda.synchronize()
     eng.enable_kernel_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-    eng.sync(); torch.cuda.synchronize()
+    eng.sync()
+    if tc:
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -284,9 +317,11 @@ def main_sepmc(args):
     import torch.distributed as dist
     from lifelike_agility_and_play_amd import sepmc_capi, urdf_model
     world = int(os.environ.get('WORLD_SIZE', '1')); rank = int(os.environ.get('RANK', '0')); local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
-    torch.cuda.set_device(local_rank)
+    tc = torch.cuda.is_available()
+    if not tc and world > 1:
+        raise SystemExit('bench.py --gpus > 1 needs torch.cuda')
+    if tc:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(os.environ.get('LL_BENCH_BACKEND', 'nccl'), rank=rank, world_size=world)
@@ -302,12 +337,16 @@ def main_sepmc(args):
         one_step()
     if world > 1:
         dist.barrier()
-    eng.sync(); torch.cuda.synchronize()
+    eng.sync()
+    if tc:
+        torch.cuda.synchronize()
     eng.enable_kernel_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-    eng.sync(); torch.cuda.synchronize()
+    eng.sync()
+    if tc:
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0

@@ -98,9 +98,9 @@ int ll_sepmc_get_reward_done(ll_sepmc_engine* e, float* h_reward /*[n_arenas][2]
 int ll_sepmc_get_state(ll_sepmc_engine* e, float* h_state37 /*[n_arenas][2][37]*/);
 int ll_sepmc_set_state(ll_sepmc_engine* e, const float* h_state37);
 /* per arena: flag 3, with_flag[0], foot friction, episodic_fix_spd, counter, push force 3, noise 4, last_two_rob_pos_diff_len,
- * last_esc_flag_pos_diff_len, switch_flag_at_this_frame, oppo_visible 2, who-touches of robot 0 and of the possible flag taker
- * (LLS_BODY_*, -1 none) -> 20 floats */
-int ll_sepmc_get_episode(ll_sepmc_engine* e, float* h_rows20);
+ * last_esc_flag_pos_diff_len, switch_flag_at_this_frame, oppo_visible 2, who-touches (_detect_body_contact, CTG:426-440) of robot 0 and
+ * of the robot that could take the flag (LLS_BODY_*, -1 none) -> 21 floats */
+int ll_sepmc_get_episode(ll_sepmc_engine* e, float* h_rows21);
 /* avg_spd0, avg_spd1, max_spd0, max_spd1 of the last step (CTG:404-409) */
 int ll_sepmc_get_info(ll_sepmc_engine* e, float* h_rows4);
 /* the arena's boxes in creation order (walls, cubes, hurdle, bar): rows [x, y, z, hx, hy, hz]; h_count [n_arenas] */

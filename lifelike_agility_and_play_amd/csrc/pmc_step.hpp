@@ -760,7 +760,7 @@ struct Pmc {
         }
       }
       F depth_c = my_depth;
-      F bias = lm::sel(depth_c > 0.0f, depth_c * inv_dt, depth_c * (P.erp * inv_dt));
+      F bias = lm::sel(depth_c > 0.0f, depth_c * inv_dt, lm::max_(depth_c * (P.erp * inv_dt), ln.lane_f(-(float)LLM_MAX_DEPEN_SPEED)));
       // joint j moves the point iff the point's link is at or below joint j: link >= j+1
       F on1 = lm::sel(link > 0.5f, one, zero), on2 = lm::sel(link > 1.5f, one, zero), on3 = lm::sel(link > 2.5f, one, zero);
       V3l rr1 = Pb - k.p1, rr2 = Pb - k.p2, rr3 = Pb - k.p3;
@@ -881,7 +881,7 @@ struct Pmc {
           fwd6(Sb, Sd, rw.gt);
           float nn = L::qsum(rw.jt[0] * rw.jt[0] + rw.jt[1] * rw.jt[1] + rw.jt[2] * rw.jt[2]);
           for (int i = 0; i < 6; i++) nn += rw.gt[i] * rw.gt[i];
-          rw.c = vrow + ((dmin > 0.0f) ? dmin * inv_dt : dmin * (P.erp * inv_dt));
+          rw.c = vrow + ((dmin > 0.0f) ? dmin * inv_dt : fmaxf(dmin * (P.erp * inv_dt), -(float)LLM_MAX_DEPEN_SPEED));
           rw.inv = have ? 1.0f / nn : 0.0f;
           rw.lam = 0.0f;
           if (!have) { for (int i = 0; i < 3; i++) rw.jt[i] = zero; for (int i = 0; i < 6; i++) rw.gt[i] = 0.0f; rw.c = 0.0f; }
@@ -1052,7 +1052,7 @@ struct Pmc {
             float nn = L::qsum(rw.jt[0] * rw.jt[0] + rw.jt[1] * rw.jt[1] + rw.jt[2] * rw.jt[2]);
             for (int i = 0; i < 6; i++) nn += rw.gt[i] * rw.gt[i];
             const float vo = ln.peer_u(vrow), no = ln.peer_u(nn);
-            rw.c = ((me == 0) ? vrow + vo : vo + vrow) + ((dmin > 0.0f) ? dmin * inv_dt : dmin * (P.erp * inv_dt));
+            rw.c = ((me == 0) ? vrow + vo : vo + vrow) + ((dmin > 0.0f) ? dmin * inv_dt : fmaxf(dmin * (P.erp * inv_dt), -(float)LLM_MAX_DEPEN_SPEED));
             rw.inv = have ? 1.0f / ((me == 0) ? nn + no : no + nn) : 0.0f;
             rw.lam = 0.0f;
             if (!have) { for (int i = 0; i < 3; i++) rw.jt[i] = zero; for (int i = 0; i < 6; i++) rw.gt[i] = 0.0f; rw.c = 0.0f; }

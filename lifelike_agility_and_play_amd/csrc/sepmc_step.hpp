@@ -16,6 +16,7 @@
 #define SEPMC_SP_STRIDE 40
 #define SEPMC_MAX_CONTACTS 8     // scripted getContactPoints records per arena
 #define SEPMC_N_VIS 21           // visibility rays per arena: base to base, then head of robot i to the 10 convex points of the other
+#define SEPMC_WALL_SOLID 1.0f     // metres the arena walls extend outwards for the contact tests (the rays see their true 1 cm)
 #define SEPMC_VIS_SCRATCH 544    // word of the row scratch where the visibility end points go (after the staged boxes and the ray lists)
 
 enum SepmcField {
@@ -378,7 +379,12 @@ struct Sepmc {
         const float* bx = allb + b * EPMC_BOX_WORDS;
         if (bs.p.x >= bx[0] - 0.9f && bs.p.x <= bx[1] + 0.9f && bs.p.y >= bx[2] - 0.9f && bs.p.y <= bx[3] + 0.9f && bs.p.z <= bx[5] + 0.9f) {
           if (n_near < EPMC_MAX_NEAR) {
-            if (ln.lane0()) for (int i = 0; i < EPMC_BOX_WORDS; i++) near[n_near * EPMC_BOX_WORDS + i] = bx[i];
+            if (ln.lane0()) {
+              for (int i = 0; i < EPMC_BOX_WORDS; i++) near[n_near * EPMC_BOX_WORDS + i] = bx[i];
+              // for contacts the four arena walls (boxes 0..3, BS4:897-902: 1 cm thick) are solid outwards: a point pressed more than
+              // half-way into a thin box would otherwise be pushed out of its far side
+              if (b < 4) near[n_near * EPMC_BOX_WORDS + (b == 0 ? 3 : (b == 1 ? 2 : (b == 2 ? 1 : 0)))] += (b == 0 || b == 2) ? SEPMC_WALL_SOLID : -SEPMC_WALL_SOLID;
+            }
             if (b == nb) ex.flag_shape = n_near;
           }
           n_near++;

@@ -114,7 +114,7 @@ def load_library(path=None):
 
 _ptr = capi._ptr
 EP_FIELDS = ('flag_x', 'flag_y', 'flag_z', 'with_flag0', 'friction', 'fix_spd', 'counter', 'push_fx', 'push_fy', 'push_fz', 'pos_x_bias', 'pos_y_bias', 'yaw_bias',
-             'pos_z_bias', 'last_two_rob_pos_diff_len', 'last_esc_flag_pos_diff_len', 'switch', 'visible0', 'visible1', 'who0')
+             'pos_z_bias', 'last_two_rob_pos_diff_len', 'last_esc_flag_pos_diff_len', 'switch', 'visible0', 'visible1', 'who0', 'who_taker')
 
 
 class SepmcEngine(object):
@@ -209,7 +209,7 @@ class SepmcEngine(object):
         self._chk(self.lib.ll_sepmc_set_state(self.h, _ptr(s)))
 
     def episode(self):
-        e = np.empty((self.n_arenas, 20), dtype=np.float32)
+        e = np.empty((self.n_arenas, 21), dtype=np.float32)
         self._chk(self.lib.ll_sepmc_get_episode(self.h, _ptr(e)))
         return {k: e[:, i] for i, k in enumerate(EP_FIELDS)}
 

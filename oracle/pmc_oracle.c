@@ -898,7 +898,7 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
         J[nr][d] = v3dot(dirs[r], vw);
       }
       if (r == 0) {
-        bias[nr] = C[c].depth > 0 ? C[c].depth / dt : LLM_ERP * C[c].depth / dt;
+        bias[nr] = C[c].depth > 0 ? C[c].depth / dt : fmax(LLM_ERP * C[c].depth / dt, -LLM_MAX_DEPEN_SPEED);
         lo[nr] = 0; hi[nr] = INFINITY; fric_of[nr] = -1; mu_row[nr] = 0;
       } else {
         bias[nr] = 0; lo[nr] = 0; hi[nr] = 0; fric_of[nr] = nr - r; mu_row[nr] = C[c].mu;
@@ -930,7 +930,7 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
       }
       J[nr][d] = rel;
     }
-    bias[nr] = SC[c].depth > 0 ? SC[c].depth / dt : LLM_ERP * SC[c].depth / dt;
+    bias[nr] = SC[c].depth > 0 ? SC[c].depth / dt : fmax(LLM_ERP * SC[c].depth / dt, -LLM_MAX_DEPEN_SPEED);
     lo[nr] = 0; hi[nr] = INFINITY; fric_of[nr] = -1; mu_row[nr] = 0;
     nr++;
   }
@@ -1117,7 +1117,7 @@ int orc_substep_pair_model(const OModel* M, double dt, int n_iter, const double*
       for (int k = 0; k < NDOF; k++) dd += Jp[c][side][k] * MJ[c][side][k];
     }
     dinv[c] = 1.0 / dd;
-    bias[c] = PC[c].depth > 0 ? PC[c].depth / dt : LLM_ERP * PC[c].depth / dt;
+    bias[c] = PC[c].depth > 0 ? PC[c].depth / dt : fmax(LLM_ERP * PC[c].depth / dt, -LLM_MAX_DEPEN_SPEED);
     if (pair_rows) { for (int i = 0; i < 3; i++) { pair_rows[8 * c + i] = PC[c].P[i]; pair_rows[8 * c + 3 + i] = PC[c].n[i]; } pair_rows[8 * c + 6] = PC[c].depth; pair_rows[8 * c + 7] = PC[c].id; }
   }
   for (int it = 0; it < n_iter; it++) {

@@ -359,18 +359,21 @@ def check_flag_handover_physical(lib_path):
         taker = 1 if wf0[a] > 0.5 else 0                       # CTG:579-581
         who = taker if a == 0 else 1 - taker                   # arena 0: the taker touches; arena 1: the holder touches (nothing happens)
         st[a, who, 0:2] = flag0[a] - np.array([0.195, -0.15])
-        st[a, who, 2] = 0.32
+        st[a, who, 2] = 0.36                                   # the standing height of the start pose
         st[a, who, 3:7] = [0, 0, 0, 1]
         st[a, 1 - who, 0:2] = -np.sign(flag0[a]) * 1.5       # the other one far away
     E.set_state(st)
-    E.step_host(np.zeros((2, 2, 12)))
-    ep2 = E.episode()
-    rew, done, why = E.reward_done()
-    assert ep2['switch'][0] > 0.5 and ep2['with_flag0'][0] != wf0[0]
+    for t in range(3):               # (in the first step a shank end within 2 cm of the ground may be listed before the flag: CTG:426-440)
+        E.step_host(np.zeros((2, 2, 12)))
+        ep2 = E.episode()
+        rew, done, why = E.reward_done()
+        assert ep2['switch'][1] < 0.5 and ep2['with_flag0'][1] == wf0[1] and rew[1][0] == 0.0        # the holder touching it: nothing
+        if ep2['switch'][0] > 0.5:
+            break
+    assert ep2['switch'][0] > 0.5 and ep2['with_flag0'][0] != wf0[0] and ep2['who_taker'][0] == 2
     assert abs(ep2['flag_x'][0] - flag0[0][0]) + abs(ep2['flag_y'][0] - flag0[0][1]) > 1e-3
     taker = 1 if wf0[0] > 0.5 else 0
     assert rew[0][taker] == 1.0 and rew[0][1 - taker] == -1.0
-    assert ep2['switch'][1] < 0.5 and ep2['with_flag0'][1] == wf0[1] and rew[1][0] == 0.0
     E.close()
 
 
@@ -406,9 +409,9 @@ def check_robot_robot_contact(lib_path):
         for r in range(2):
             st[a, r, 3:7] = [0, 0, 0, 1]
             st[a, r, 7:13] = 0.0
-    st[0, 1, 0:3] = [1.0, 1.0, 0.31]; st[0, 0, 0:3] = [1.0, 1.0, 0.58]
-    st[1, 1, 0:3] = [0.0, 1.0, 0.31]; st[1, 0, 0:3] = [-0.40, 1.0, 0.31]
-    st[2, 1, 0:3] = [1.5, -1.5, 0.31]; st[2, 0, 0:3] = [-1.5, -1.5, 0.31]
+    st[0, 1, 0:3] = [1.0, 1.0, 0.36]; st[0, 0, 0:3] = [1.0, 1.0, 0.63]       # (0.36 = the standing height of the start pose)
+    st[1, 1, 0:3] = [0.0, 1.0, 0.36]; st[1, 0, 0:3] = [-0.40, 1.0, 0.36]
+    st[2, 1, 0:3] = [1.5, -1.5, 0.36]; st[2, 0, 0:3] = [-1.5, -1.5, 0.36]
     # keep the flag out of the way of all three
     E.set_state(st)
     zero = np.zeros((3, 2, 12))
@@ -455,7 +458,7 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5):
         off = 0.5 * dist * np.array([np.cos(ang), np.sin(ang)])
         for r in range(2):
             st[a, r, 0:2] = c + (off if r == 0 else -off)
-            st[a, r, 2] = rng.uniform(0.27, 0.33) + (0.12 if (a % 4 == 3 and r == 0) else 0.0)
+            st[a, r, 2] = rng.uniform(0.31, 0.37) + (0.12 if (a % 4 == 3 and r == 0) else 0.0)
             st[a, r, 3:7] = R.from_euler('xyz', [rng.normal() * 0.1, rng.normal() * 0.1, rng.uniform(0, 2 * np.pi)]).as_quat()
             st[a, r, 7:13] = rng.normal(size=6) * 0.3
             st[a, r, 13:25] += rng.normal(size=12) * 0.15
@@ -475,6 +478,8 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5):
                          rows[a][b][2] - rows[a][b][5], rows[a][b][2] + rows[a][b][5], 0.0, 0.0] for b in range(cnt[a])], dtype=np.float64).reshape(-1, 8)
         fl = np.array([ep['flag_x'][a], ep['flag_y'][a], ep['flag_z'][a]], dtype=np.float64)
         rec = np.vstack([rec, [[fl[0] - 0.05, fl[0] + 0.05, fl[1] - 0.05, fl[1] + 0.05, fl[2] - 0.25, fl[2] + 0.25, 0.0, 0.0]]]).astype(np.float32).astype(np.float64)
+        rec[0, 3] += 1.0; rec[1, 2] -= 1.0; rec[2, 1] += 1.0; rec[3, 0] -= 1.0        # the walls are solid outwards for contacts (SEPMC_WALL_SOLID)
+        rec = rec.astype(np.float32).astype(np.float64)
         near, s, s_free = [], [], []
         for r in range(2):
             p = st32[a, r, 0:3]

@@ -8,12 +8,21 @@ from test_env_api import check_single_env_contract, pmc_config
 pytestmark = pytest.mark.gpu
 
 
+def torch_cuda():
+    """torch is plumbing here (device tensors over the engine's buffers).  On some boxes torch's bundled HIP runtime does not find
+    the device although the engine (system HIP) does: those tests are then skipped with this message, the engine-only tests still run."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('torch.cuda is not available on this box (the HIP engine itself is: see the other gpu tests)')
+    return torch
+
+
 def test_single_env_contract_gpu(golden):
     check_single_env_contract(golden, None)
 
 
 def test_batched_env_zero_copy_torch(golden):
-    import torch
+    torch = torch_cuda()
     from lifelike_agility_and_play_amd import gather
     env = lla.create_tracking_game(**pmc_config(num_envs=256, seed=9))
     with pytest.raises(ValueError):
@@ -32,7 +41,7 @@ def test_batched_env_zero_copy_torch(golden):
 
 
 def test_trajectory_ring_gpu(model_blob, mocap_table):
-    import torch
+    torch_cuda()
     import parity_common as pc
     from lifelike_agility_and_play_amd import gather
 
@@ -45,7 +54,7 @@ def test_trained_policy_on_device_closed_loop(model_blob, mocap_table):
     """The trained reference policy evaluated with torch on the engine's own device buffers (zero copies) agrees with its NumPy
     statement, and drives 1024 environments closed-loop on the GPU with a high tracking reward."""
     import os
-    import torch
+    torch = torch_cuda()
     from conftest import GOLDEN_DIR, PMC_PROP_TYPE, PMC_REWARD_WEIGHTS
     from lifelike_agility_and_play_amd import capi, gather
     from lifelike_agility_and_play_amd.pmc_policy import PmcPolicy
@@ -74,7 +83,7 @@ def test_fused_mfma_policy_kernel(model_blob, mocap_table):
     codes agree (a near-tie between two codes may fall either way in float32 -- allowed for < 0.5 % of envs), the actions of
     agreeing envs match, and the closed loop on the device tracks the clips."""
     import os
-    import torch
+    torch = torch_cuda()
     from conftest import GOLDEN_DIR, PMC_PROP_TYPE, PMC_REWARD_WEIGHTS
     from lifelike_agility_and_play_amd import capi, gather
     from lifelike_agility_and_play_amd.pmc_policy import PmcPolicy

@@ -1,0 +1,55 @@
+"""Long free runs of the three engines on the GPU: nothing non-finite, nobody through a wall, episodes keep ending and restarting.
+    python tools/soak.py [pmc_steps] [epmc_steps] [sepmc_steps]        -> one line per engine"""
+import math, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+from lifelike_agility_and_play_amd import capi, epmc_capi, sepmc_capi, mocap, urdf_model
+sys.argv += ['20000', '5000', '5000'][len(sys.argv) - 1:]
+blob = urdf_model.default_model_blob()
+SIG = math.exp(-2)
+
+t0 = time.perf_counter()
+from bench import PMC_PROP_TYPE, PMC_REWARD_WEIGHTS   # noqa: E402
+cfg = capi.make_config(4096, control_freq=50.0, kd=0.5, prop_type=PMC_PROP_TYPE, prioritized_sample_factor=3.0, reward_weights=PMC_REWARD_WEIGHTS, auto_reset=1, seed=77)
+E = capi.Engine(cfg, blob, mocap.load_mocap('', 0.02))
+E.reset()
+n = int(sys.argv[1])
+for t in range(n):
+    E.step_random(SIG)
+o, s, c = E.obs(), E.state(), E.counters()
+assert np.isfinite(o).all() and np.isfinite(s).all()
+print('pmc   %6d steps x 4096 envs: %d episodes (mean length %.1f steps), %d non-finite resets, max |q| %.2f, %.1f s' % (n, c['episodes'], c['env_steps'] / max(1, c['episodes']), c['nonfinite'],
+      np.abs(s[:, 13:25]).max(), time.perf_counter() - t0))
+E.close()
+
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+from env_configs import epmc_env_config, sepmc_env_config   # noqa: E402
+
+t0 = time.perf_counter()
+E = epmc_capi.EpmcEngine(epmc_capi.make_epmc_config(4096, epmc_env_config(3), auto_reset=1, seed=78), blob)
+E.reset()
+n = int(sys.argv[2])
+for t in range(n):
+    E.fill_random_actions(SIG); E.step()
+o, s, c = E.obs(), E.state(), E.counters()
+assert np.isfinite(o).all() and np.isfinite(s).all()
+print('epmc  %6d steps x 4096 envs (cubes): %d episodes, %d non-finite resets, x range [%.1f, %.1f], %.1f s' % (n, c['episodes'], c['nonfinite'], s[:, 0].min(), s[:, 0].max(), time.perf_counter() - t0))
+E.close()
+
+t0 = time.perf_counter()
+E = sepmc_capi.SepmcEngine(sepmc_capi.make_sepmc_config(2048, sepmc_env_config(1), auto_reset=1, seed=79), blob)
+E.reset()
+n = int(sys.argv[3])
+why_hist = np.zeros(32, int)
+for t in range(n):
+    E.fill_random_actions(SIG); E.step()
+    if t % 50 == 0:
+        _, d, w = E.reward_done()
+        why_hist += np.bincount(w[d], minlength=32)
+o, s, c = E.obs(), E.state(), E.counters()
+fin = np.isfinite(o).all() and np.isfinite(s).all()
+out = np.argwhere(np.abs(s[:, :, 0:2]).max(axis=2) >= 2.7)
+print('sepmc finite', fin, 'robots outside the walls:', len(out), [(int(a), int(r), s[a, r, 0:3].round(2).tolist()) for a, r in out[:6]])
+print('sepmc %6d steps x 2048 arenas (all elements): %d episodes, %d non-finite resets, max |xy| %.2f, sampled end reasons fall %d time %d catch %d, %.1f s' % (
+    n, c['episodes'], c['nonfinite'], np.abs(s[:, :, 0:2]).max(), why_hist[1::2].sum(), (why_hist[[2, 3, 6, 7, 10, 11]]).sum(), why_hist[8:16].sum(), time.perf_counter() - t0))
+E.close()

@@ -4,14 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import numpy as np
 from lifelike_agility_and_play_amd import epmc_capi, urdf_model
 
-def env_config(element_id):
-    return {'arena_id': 'Playground', 'render': False, 'control_freq': 50.0,
-            'prop_type': ['joint_pos', 'joint_vel', 'root_ang_vel_loc', 'root_lin_vel_loc', 'e_g'],
-            'kp': 50.0, 'kd': 0.5, 'max_tau': 16, 'max_steps': 1000, 'obs_randomization': {},
-            'env_randomize_config': {'element_id': element_id, 'height_range': [0.0, 0.0], 'friction_range': [0.4, 3.0],
-                                     'disturb_force_config': {'start_time': 0.5, 'interval_time': 1.0, 'duration_time': 0.2, 'horizontal_force': [0, 50], 'vertical_force': [0, 10]},
-                                     'cmd_vary_freq_range': [9999, 10000], 'target_spd_range': [0.5, 3.0], 'auxiliary_radius': 0.02,
-                                     'hole_config': {'min_gap_height': 0.25, 'max_gap_height': 0.25}}}
+from env_configs import epmc_env_config as env_config  # noqa: E402
 blob = urdf_model.default_model_blob()
 for item in sys.argv[1].split(','):
     n, el = [int(x) for x in item.split(':')]

@@ -5,15 +5,7 @@ import numpy as np
 from lifelike_agility_and_play_amd import sepmc_capi, urdf_model
 
 
-def env_config(elements):
-    return {'arena_id': 'CTG', 'render': False, 'control_freq': 50.0,
-            'prop_type': ['joint_pos', 'joint_vel', 'root_ang_vel_loc', 'root_lin_vel_loc', 'e_g'],
-            'kp': 50.0, 'kd': 0.5, 'max_tau': 16, 'max_steps': 1000, 'obs_randomization': {},
-            'env_randomize_config': {'friction_range': [0.4, 3.0],
-                                     'disturb_force_config': {'start_time': 0.5, 'interval_time': 1.0, 'duration_time': 0.2, 'horizontal_force': [0, 50], 'vertical_force': [0, 10]}},
-            'element_config': {'rand_cube': bool(elements), 'hurdle': bool(elements), 'hole': bool(elements)}}
-
-
+from env_configs import sepmc_env_config as env_config  # noqa: E402
 blob = urdf_model.default_model_blob()
 for item in sys.argv[1].split(','):
     n, el = [int(x) for x in item.split(':')]
