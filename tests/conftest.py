@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:                # torch bundles its own copy of the HIP runtime under the same SONAME as the system one libllenv.so links: whichever is
+    import torch    # noqa: F401  loaded first serves the process.  Load torch's first, the order bench.py has (and every full-suite run had)
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -36,7 +36,9 @@ def test_batched_env_zero_copy_torch(golden):
     np.testing.assert_array_equal(t['obs'].cpu().numpy(), env.engine.obs())          # torch sees the engine's buffer
     r, d, _ = env.engine.reward_done()
     np.testing.assert_array_equal(t['reward'].cpu().numpy(), r)
-    np.testing.assert_allclose(t['obs'][:, 123:135].cpu().numpy(), act.cpu().numpy(), rtol=1e-6)   # newest action in prop_a
+    live = ~np.asarray(d, dtype=bool)                                                 # (an env that ended in this step was re-seeded: its history is zeros)
+    assert live.mean() > 0.9
+    np.testing.assert_allclose(t['obs'][:, 123:135].cpu().numpy()[live], act.cpu().numpy()[live], rtol=1e-6)   # newest action in prop_a
     env.close()
 
 
