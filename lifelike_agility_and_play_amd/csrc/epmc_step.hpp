@@ -263,16 +263,8 @@ struct Epmc {
     *s = (k & 2) ? -ss : ss;
     *c = ((k + 1) & 2) ? -cs : cs;
   }
-  // a box record as two 16-byte reads (one LDS instruction each), fetched one box ahead of its use so that the read latency hides
-  // behind the previous box's arithmetic -- a wave has nothing else to switch to
-  struct alignas(16) F4 { float x, y, z, w; };
-  struct BoxRec { F4 a, c; };                              // a = x0 x1 y0 y1, c = z0 z1 - -
-  static LL_HD BoxRec load_box(const float* p) {
-    BoxRec b;
-    b.a = *reinterpret_cast<const F4*>(p);
-    b.c = *reinterpret_cast<const F4*>(p + 4);
-    return b;
-  }
+  // (box records are read with load_box, pmc_math.hpp: a = x0 x1 y0 y1, c = z0 z1 - -, one box ahead of their use so that the read
+  // latency hides behind the previous box's arithmetic -- a wave has nothing else to switch to)
   // one axis of the slab test of origin o, direction d (inv = 1/d, anything if d == 0) against [lo, hi]: narrows [te, tl]
   static LL_HD void slab_axis(float lo, float hi, float o, float d, float inv, float& te, float& tl) {
     const float t1 = (lo - o) * inv, t2 = (hi - o) * inv;

@@ -3,6 +3,16 @@
 #pragma once
 #include "lanes.hpp"
 
+// an 8-float record (terrain box: x0 x1 y0 y1 | z0 z1 rod r) as two 16-byte reads -- one LDS / global instruction each
+struct alignas(16) F4 { float x, y, z, w; };
+struct BoxRec { F4 a, c; };
+LL_HD BoxRec load_box(const float* p) {
+  BoxRec b;
+  b.a = *reinterpret_cast<const F4*>(p);
+  b.c = *reinterpret_cast<const F4*>(p + 4);
+  return b;
+}
+
 template <class T>
 struct V3 {
   T x, y, z;

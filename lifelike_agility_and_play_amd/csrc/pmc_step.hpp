@@ -313,9 +313,10 @@ struct Pmc {
   template <class T>
   static LL_HD void shape_sdf(const L& ln, const float* s, const V3<T>& E, T& d, V3<T>& n, T& is_box) {
     const T zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f), neg = ln.lane_f(-1.0f);
-    T ax0 = ln.lane_f(s[0]) - E.x, ax1 = E.x - ln.lane_f(s[1]);
-    T ay0 = ln.lane_f(s[2]) - E.y, ay1 = E.y - ln.lane_f(s[3]);
-    T az0 = ln.lane_f(s[4]) - E.z, az1 = E.z - ln.lane_f(s[5]);
+    const BoxRec rec = load_box(s);                                  // two 16-byte reads instead of eight scalar ones
+    T ax0 = ln.lane_f(rec.a.x) - E.x, ax1 = E.x - ln.lane_f(rec.a.y);
+    T ay0 = ln.lane_f(rec.a.z) - E.y, ay1 = E.y - ln.lane_f(rec.a.w);
+    T az0 = ln.lane_f(rec.c.x) - E.z, az1 = E.z - ln.lane_f(rec.c.y);
     T qx = lm::max_(ax0, ax1), qy = lm::max_(ay0, ay1), qz = lm::max_(az0, az1);
     T sx = lm::sel(ax1 > ax0, one, neg), sy = lm::sel(ay1 > ay0, one, neg), sz = lm::sel(az1 > az0, one, neg);
     d = qx; n = mk3<T>(sx, zero, zero);
@@ -324,11 +325,11 @@ struct Pmc {
     B bz = qz > d;
     d = lm::sel(bz, qz, d); n = mk3<T>(lm::sel(bz, zero, n.x), lm::sel(bz, zero, n.y), lm::sel(bz, sz, zero));
     is_box = one;
-    if (s[6] != 0.0f) {
-      const float ze = s[6] > 0.0f ? s[5] : s[4], rr = s[7];
+    if (rec.c.z != 0.0f) {
+      const float ze = rec.c.z > 0.0f ? rec.c.y : rec.c.x, rr = rec.c.w;
       B iny = lm::and_(qy <= 0.0f, one > zero);
       for (int e = 0; e < 2; e++) {
-        T dx = E.x - ln.lane_f(s[e]), dz = E.z - ln.lane_f(ze);
+        T dx = E.x - ln.lane_f(e == 0 ? rec.a.x : rec.a.y), dz = E.z - ln.lane_f(ze);
         T len = lm::sqrt_(dx * dx + dz * dz);
         T dr = len - rr;
         B better = lm::and_(iny, lm::and_(dr < d, len > 1e-6f));

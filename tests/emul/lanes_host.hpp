@@ -105,7 +105,7 @@ struct HostLanes {
   int ray_stride() const { return 1; }
   void row_sync() const {}
   const float* stage_row(const float* g, int) const { return g; }
-  mutable float scratch_[608];
+  alignas(16) mutable float scratch_[608];
   float* row_scratch() const { return scratch_; }
   void prepare_turn_masks() const {}
   I leg() const { iN r; for (int i = 0; i < EW; i++) r.v[i] = i >> 2; return r; }
