@@ -38,7 +38,7 @@ enum LegConst {
 //   a candidate is a point of a link:  P = A - r * n(ez_link),  n = unit(ez - (ez.ax) ax)  (fb if degenerate)
 //   sphere: A = centre, ax = 0;  box vertex: A = vertex, r = 0;  cylinder cap: A = cap centre, ax = axis
 enum CandField { CF_A = 0, CF_AX = 3, CF_FB = 6, CF_R = 9, CF_LINK = 10, CF_KIND = 11, CF_WORDS = 12 };
-#define CAND_PER_SUB 7
+#define CAND_PER_SUB 8   // 7 on flat ground (PMC); the eighth, a sphere on the link's axis, only matters against terrain (TERRAIN builds)
 #define CAND_TABLE_WORDS (CAND_PER_SUB * CF_WORDS)
 
 // ---- base constant table (quad-uniform) ----------------------------------------------------------------

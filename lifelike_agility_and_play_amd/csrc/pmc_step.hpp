@@ -590,11 +590,12 @@ struct Pmc {
         tgp[2] = mk3<F>(lm::sel(sub_0, k.p3.x, zero), lm::sel(sub_0, k.p3.y, zero), lm::sel(sub_0, k.p3.z, zero));
       }
     }
-    F depth[7];
+    constexpr int NC = TERRAIN ? 8 : 7;                       // candidates per sub-lane: the eighth (mid-link sphere) only meets terrain
+    F depth[NC];
     const bool want_touch = TERRAIN && ex && ex->want_touch;
     F tch_st = one, tch_fl = one;                             // 0 once a body link touches a static / the flag
-    for (int jj = 0; jj < 7; jj++) {
-      const int g = jj < 4 ? 0 : (jj < 6 ? 1 : 2);
+    for (int jj = 0; jj < NC; jj++) {
+      const int g = jj < 4 ? 0 : (jj < 6 ? 1 : (jj < 7 ? 2 : 0));   // (candidate 7 sits on group A's link)
       V3l A = mk3<F>(ln.candc(jj * CF_WORDS + CF_A), ln.candc(jj * CF_WORDS + CF_A + 1), ln.candc(jj * CF_WORDS + CF_A + 2));
       V3l ax = mk3<F>(ln.candc(jj * CF_WORDS + CF_AX), ln.candc(jj * CF_WORDS + CF_AX + 1), ln.candc(jj * CF_WORDS + CF_AX + 2));
       F r = ln.candc(jj * CF_WORDS + CF_R), link = ln.candc(jj * CF_WORDS + CF_LINK);
@@ -637,7 +638,7 @@ struct Pmc {
     F my_depth = far_, my_sub = zero, my_jj = zero;
     for (int s = 0; s < PMC_K; s++) {
       F m = depth[0], am = zero;
-      for (int jj = 1; jj < 7; jj++) {
+      for (int jj = 1; jj < NC; jj++) {
         B lt = depth[jj] < m;
         m = lm::sel(lt, depth[jj], m);
         am = lm::sel(lt, ln.lane_f((float)jj), am);
@@ -647,7 +648,7 @@ struct Pmc {
       F wsub = L::submin(code);                             // lowest sub-lane holding the minimum (4 = none)
       B winner = lm::and_(code <= wsub, code < 3.5f);
       F wjj = L::subsum(lm::sel(winner, am, zero));
-      for (int jj = 0; jj < 7; jj++) depth[jj] = lm::sel(lm::and_(winner, lm::abs_(am - (float)jj) < 0.5f), far_, depth[jj]);
+      for (int jj = 0; jj < NC; jj++) depth[jj] = lm::sel(lm::and_(winner, lm::abs_(am - (float)jj) < 0.5f), far_, depth[jj]);
       B owner = ln.is_sub(s);
       my_depth = lm::sel(owner, lm::sel(wsub < 3.5f, mq, far_), my_depth);
       my_sub = lm::sel(owner, wsub, my_sub);
@@ -656,7 +657,7 @@ struct Pmc {
     // store the kept candidates in candidate-index order (near-ties in depth must not reorder the solve): each slot lane
     // ranks its candidate among the leg's four and picks up the one whose rank equals its slot
     {
-      F idx = lm::sel(my_depth < 1.0e29f, my_sub * 7.0f + my_jj, ln.lane_f(1000.0f) + L::i2f(ln.sub()));
+      F idx = lm::sel(my_depth < 1.0e29f, my_sub * 8.0f + my_jj, ln.lane_f(1000.0f) + L::i2f(ln.sub()));
       F i0 = L::template subbcast<0>(idx), i1 = L::template subbcast<1>(idx), i2 = L::template subbcast<2>(idx), i3 = L::template subbcast<3>(idx);
       F rank = lm::sel(i0 < idx, one, zero) + lm::sel(i1 < idx, one, zero) + lm::sel(i2 < idx, one, zero) + lm::sel(i3 < idx, one, zero);
       F me = L::i2f(ln.sub());

@@ -192,6 +192,25 @@ static inline std::string pmc_build_cand_table(const double* blob, std::vector<f
       const double z3[3] = {0, 0, 0};
       pmc_put_cand(t, L0 + 3, 6, z3, nullptr, nullptr, 0.0, -1, 0);
     }
+    // candidate 7 (terrain only): a sphere of the capsule radius at 1/3 and 2/3 of the shank axis (subs 0, 1) and of the
+    // thigh axis (subs 2, 3) -- what meets a hurdle or step edge between the end points of a link
+    {
+      double d[3], len = 0, sa[3], sbv[3], ta[3], tb2[3];
+      for (int c = 0; c < 3; c++) { d[c] = lp[6].pos[c] - lp[5].pos[c]; len += d[c] * d[c]; }
+      len = sqrt(len);
+      for (int c = 0; c < 3; c++) {
+        sa[c] = lp[5].pos[c] - lp[5].size[0] * d[c] / len; sbv[c] = lp[6].pos[c];
+        ta[c] = lp[1].pos[c] + lp[1].size[0] * lp[1].rot[3 * c]; tb2[c] = lp[1].pos[c] - lp[1].size[0] * lp[1].rot[3 * c];
+      }
+      const double rs = 0.5 * ((lp[5].size[1] > lp[5].size[2] ? lp[5].size[1] : lp[5].size[2]) + lp[6].size[0]);
+      const double rt = lp[1].size[1] > lp[1].size[2] ? lp[1].size[1] : lp[1].size[2];
+      for (int sub = 0; sub < 4; sub++) {
+        const double f = (sub & 1) ? 2.0 / 3.0 : 1.0 / 3.0;
+        double A2[3];
+        for (int c = 0; c < 3; c++) A2[c] = sub < 2 ? sa[c] + f * (sbv[c] - sa[c]) : ta[c] + f * (tb2[c] - ta[c]);
+        pmc_put_cand(t, L0 + sub, 7, A2, nullptr, nullptr, sub < 2 ? rs : rt, sub < 2 ? 3 : 2, 0);
+      }
+    }
   }
   return "";
 }

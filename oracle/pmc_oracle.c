@@ -646,30 +646,40 @@ static void cand_point(const OPrim* p, const double* Rw, const double* pw, int w
   c->valid = 1;
 }
 
+static void capsule(const OModel* M, const OKin* K, int leg, int which, double* a, double* b, double* r, int* body);
 static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double mu_link, const OTerrain* T, OContact* out) {
   int n = 0;
   for (int l = 0; l < 4; l++) {
-    OCand c[28];
+    OCand c[32];      /* index = 8 * sub + jj as in the kernel's table; jj = 7 (the mid-link spheres) exists only with terrain */
     memset(c, 0, sizeof c);
     int hip = 1 + 3 * l, thigh = 2 + 3 * l, shank = 3 + 3 * l, k = 0;
     const OPrim* lp = M->leg_prims[l];   /* 0 hip cyl | 1 thigh box, 2 thigh cyl 0, 3 thigh cyl 1, 4 wheel | 5 shank box, 6 foot */
 #define CAND(prim, body_, which, mu_) do { cand_point(prim, K->Rw[body_], K->pw[body_], which, &c[k]); c[k].body = body_; c[k].mu = mu_; k++; } while (0)
+#define MID(which_, f_) do { if (T) { double a_[3], b_[3], r_; int bd_; capsule(M, K, l, which_, a_, b_, &r_, &bd_); \
+      for (int i = 0; i < 3; i++) { c[k].P[i] = a_[i] + (f_) * (b_[i] - a_[i]); } \
+      c[k].P[2] -= r_; c[k].depth = c[k].P[2]; c[k].rs = r_; \
+      c[k].n[0] = 0; c[k].n[1] = 0; c[k].n[2] = 1; c[k].valid = 1; c[k].body = bd_; c[k].mu = mu_link; } k++; } while (0)
     CAND(&lp[6], shank, 0, mu_foot);                                        /*  0      foot                         */
     for (int v = 0; v < 3; v++) CAND(&lp[5], shank, v, mu_link);             /*  1-3    shank box v0..v2             */
     for (int s2 = 0; s2 < 2; s2++) CAND(&lp[4], thigh, s2, mu_link);         /*  4,5    wheel caps                   */
     CAND(&lp[5], shank, 3, mu_link);                                        /*  6      shank box v3                 */
+    MID(1, 1.0 / 3.0);                                                      /*  7      shank axis 1/3 (terrain)     */
     for (int v = 4; v < 8; v++) CAND(&lp[5], shank, v, mu_link);             /*  7-10   shank box v4..v7             */
     for (int s2 = 0; s2 < 2; s2++) CAND(&lp[2], thigh, s2, mu_link);         /*  11,12  thigh cylinder 0 caps        */
     CAND(&M->base_prims[0], 0, l, mu_link);                                 /*  13     body box vertex (leg, z-)    */
+    MID(1, 2.0 / 3.0);                                                      /*         shank axis 2/3 (terrain)     */
     for (int v = 0; v < 4; v++) CAND(&lp[1], thigh, v, mu_link);             /*  14-17  thigh box v0..v3             */
     for (int s2 = 0; s2 < 2; s2++) CAND(&lp[3], thigh, s2, mu_link);         /*  18,19  thigh cylinder 1 caps        */
     CAND(&M->base_prims[0], 0, l + 4, mu_link);                             /*  20     body box vertex (leg, z+)    */
+    MID(0, 1.0 / 3.0);                                                      /*         thigh axis 1/3 (terrain)     */
     for (int v = 4; v < 8; v++) CAND(&lp[1], thigh, v, mu_link);             /*  21-24  thigh box v4..v7             */
     for (int s2 = 0; s2 < 2; s2++) CAND(&lp[0], hip, s2, mu_link);           /*  25,26  hip cylinder caps            */
     if (l == 0 || l == 2) CAND(&M->base_prims[l == 0 ? 1 : 2], 0, 0, mu_link); else k++;   /* 27 handle sphere (legs 0, 2) */
+    MID(0, 2.0 / 3.0);                                                      /*         thigh axis 2/3 (terrain)     */
 #undef CAND
+#undef MID
     if (T)                                   /* the nearest surface decides depth, normal and friction partner */
-      for (int i = 0; i < 28; i++) {
+      for (int i = 0; i < 32; i++) {
         if (!c[i].valid) continue;
         double E[3] = {c[i].P[0], c[i].P[1], c[i].P[2] + c[i].rs};
         for (int si = 0; si < T->n; si++) {
@@ -678,17 +688,17 @@ static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double 
           if (d < c[i].depth) { c[i].depth = d; memcpy(c[i].n, nn, 24); c[i].valid = isb ? 2 : 3; }   /* valid: 1 plane, 2 box, 3 edge cylinder */
         }
       }
-    int taken[28] = {0}, nsel = 0;
+    int taken[32] = {0}, nsel = 0;
     for (int s = 0; s < KC; s++) {          /* the KC deepest (ties: lower index) ... */
       int best = -1;
-      for (int i = 0; i < 28; i++)
+      for (int i = 0; i < 32; i++)
         if (c[i].valid && !taken[i] && c[i].depth < LLM_CONTACT_MARGIN && (best < 0 || c[i].depth < c[best].depth)) best = i;
       if (best < 0) break;
       taken[best] = 1;
       nsel++;
     }
     int slot = 0;
-    for (int i = 0; i < 28; i++) {          /* ... stored in candidate-index order, so near-ties in depth cannot reorder the solve */
+    for (int i = 0; i < 32; i++) {          /* ... stored in candidate-index order, so near-ties in depth cannot reorder the solve */
       if (!taken[i]) continue;
       out[n].body = c[i].body; memcpy(out[n].P, c[i].P, 24); out[n].depth = c[i].depth;
       out[n].mu = c[i].mu * (c[i].valid == 2 && T ? T->box_mu_scale : 1.0);

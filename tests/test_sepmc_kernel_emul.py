@@ -42,3 +42,23 @@ def test_robot_robot_contact(emul_lib):
 
 def test_pair_physics_against_oracle(emul_lib):
     print(SC.check_pair_physics_against_oracle(emul_lib))
+
+
+def test_reset_of_a_subset_of_arenas(emul_lib):
+    """ll_sepmc_reset(arena_ids): only the listed arenas are re-seeded (new arena, roles, flag, poses, zeroed history); the
+    others keep their state, episode scalars and observations bit for bit."""
+    E = SC.make_engine(SC.env_config((1, 1, 0)), 5, emul_lib, auto_reset=0, seed=17)
+    E.reset()
+    for t in range(3):
+        E.step_host(np.full((5, 2, 12), 0.05, np.float32))
+    s0, o0, b0, ep0 = E.state().copy(), E.obs().copy(), E.boxes()[0].copy(), {k: v.copy() for k, v in E.episode().items()}
+    E.reset(arena_ids=[1, 3])
+    s1, o1, b1, ep1 = E.state(), E.obs(), E.boxes()[0], E.episode()
+    keep, redo = [0, 2, 4], [1, 3]
+    np.testing.assert_array_equal(s1[keep], s0[keep]); np.testing.assert_array_equal(o1[keep], o0[keep]); np.testing.assert_array_equal(b1[keep], b0[keep])
+    for k in ('flag_x', 'counter', 'friction', 'with_flag0'):
+        np.testing.assert_array_equal(ep1[k][keep], ep0[k][keep])
+    assert np.all(ep1['counter'][redo] == 0) and np.all(ep1['flag_x'][redo] != ep0['flag_x'][redo]) and np.all(s1[redo][:, :, 2] == 0.5)
+    assert np.all(o1[redo][:, :, 99:135] == 0.0)                                   # action history of a fresh episode
+    assert not np.array_equal(b1[redo], b0[redo])                                  # new cubes
+    E.close()
