@@ -46,7 +46,7 @@
 #define LLM_LINK_FRICTION 0.5          /* Bullet default lateralFriction of every non-foot link */
 #define LLM_CONTACT_MARGIN 0.02        /* Bullet contact breaking threshold */
 #define LLM_ERP 0.2                    /* PyBullet default erp / contactERP */
-#define LLM_MAX_DEPEN_SPEED 2.0        /* m/s: cap on the penetration-recovery part of a contact row's bias (a body that starts inside an
+#define LLM_MAX_DEPEN_SPEED 0.5        /* m/s: cap on the penetration-recovery part of a contact row's bias (a body that starts inside an
                                           obstacle -- SEPMC spawns at random -- is pushed out gently instead of being shot out) */
 #define LLM_LINK_DAMPING 0.04          /* btMultiBody default linear & angular damping (quirk Q12) */
 #define LLM_MAX_CONTACTS_PER_LEG 4     /* contact slots per leg lane */

@@ -237,6 +237,14 @@ class OracleBatch(object):
         assert n >= 0
         return s0, s1, rows[:n]
 
+    def touch(self, state0, state1, shapes0, flag0, shapes1, flag1):
+        """SEPMC contact classes of both robots: [[static, flag, robot] of robot 0, ... of robot 1]; flag* = index of the flag in shapes* (-1 none)."""
+        sh = [f64(np.asarray(x).reshape(-1, 8)) if len(x) else np.zeros((0, 8)) for x in (shapes0, shapes1)]
+        out = np.zeros(6, dtype=np.int32)
+        lib().orc_touch(self.h, _p(f64(state0)), _p(f64(state1)), C.c_int(len(sh[0])), _p(sh[0]) if len(sh[0]) else None, C.c_int(flag0), C.c_int(len(sh[1])),
+                        _p(sh[1]) if len(sh[1]) else None, C.c_int(flag1), _p(out))
+        return out.reshape(2, 3)
+
     def momentum(self, state):
         out = np.zeros(6); lib().orc_momentum(self.h, _p(f64(state)), _p(out)); return out
 

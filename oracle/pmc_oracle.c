@@ -647,37 +647,41 @@ static void cand_point(const OPrim* p, const double* Rw, const double* pw, int w
 }
 
 static void capsule(const OModel* M, const OKin* K, int leg, int which, double* a, double* b, double* r, int* body);
+/* the 32 candidate points of leg l, index = 8 * sub + jj as in the kernel's table; jj = 7 (the mid-link spheres) exists only with terrain */
+static void enum_cands(const OModel* M, const OKin* K, int l, double mu_foot, double mu_link, const OTerrain* T, OCand* c) {
+  memset(c, 0, 32 * sizeof(OCand));
+  int hip = 1 + 3 * l, thigh = 2 + 3 * l, shank = 3 + 3 * l, k = 0;
+  const OPrim* lp = M->leg_prims[l];   /* 0 hip cyl | 1 thigh box, 2 thigh cyl 0, 3 thigh cyl 1, 4 wheel | 5 shank box, 6 foot */
+#define CAND(prim, body_, which, mu_) do { cand_point(prim, K->Rw[body_], K->pw[body_], which, &c[k]); c[k].body = body_; c[k].mu = mu_; k++; } while (0)
+#define MID(which_, f_) do { if (T) { double a_[3], b_[3], r_; int bd_; capsule(M, K, l, which_, a_, b_, &r_, &bd_); \
+    for (int i = 0; i < 3; i++) { c[k].P[i] = a_[i] + (f_) * (b_[i] - a_[i]); } \
+    c[k].P[2] -= r_; c[k].depth = c[k].P[2]; c[k].rs = r_; \
+    c[k].n[0] = 0; c[k].n[1] = 0; c[k].n[2] = 1; c[k].valid = 1; c[k].body = bd_; c[k].mu = mu_link; } k++; } while (0)
+  CAND(&lp[6], shank, 0, mu_foot);                                        /*  0      foot                         */
+  for (int v = 0; v < 3; v++) CAND(&lp[5], shank, v, mu_link);             /*  1-3    shank box v0..v2             */
+  for (int s2 = 0; s2 < 2; s2++) CAND(&lp[4], thigh, s2, mu_link);         /*  4,5    wheel caps                   */
+  CAND(&lp[5], shank, 3, mu_link);                                        /*  6      shank box v3                 */
+  MID(1, 1.0 / 3.0);                                                      /*  7      shank axis 1/3 (terrain)     */
+  for (int v = 4; v < 8; v++) CAND(&lp[5], shank, v, mu_link);             /*  7-10   shank box v4..v7             */
+  for (int s2 = 0; s2 < 2; s2++) CAND(&lp[2], thigh, s2, mu_link);         /*  11,12  thigh cylinder 0 caps        */
+  CAND(&M->base_prims[0], 0, l, mu_link);                                 /*  13     body box vertex (leg, z-)    */
+  MID(1, 2.0 / 3.0);                                                      /*         shank axis 2/3 (terrain)     */
+  for (int v = 0; v < 4; v++) CAND(&lp[1], thigh, v, mu_link);             /*  14-17  thigh box v0..v3             */
+  for (int s2 = 0; s2 < 2; s2++) CAND(&lp[3], thigh, s2, mu_link);         /*  18,19  thigh cylinder 1 caps        */
+  CAND(&M->base_prims[0], 0, l + 4, mu_link);                             /*  20     body box vertex (leg, z+)    */
+  MID(0, 1.0 / 3.0);                                                      /*         thigh axis 1/3 (terrain)     */
+  for (int v = 4; v < 8; v++) CAND(&lp[1], thigh, v, mu_link);             /*  21-24  thigh box v4..v7             */
+  for (int s2 = 0; s2 < 2; s2++) CAND(&lp[0], hip, s2, mu_link);           /*  25,26  hip cylinder caps            */
+  if (l == 0 || l == 2) CAND(&M->base_prims[l == 0 ? 1 : 2], 0, 0, mu_link); else k++;   /* 27 handle sphere (legs 0, 2) */
+  MID(0, 2.0 / 3.0);                                                      /*         thigh axis 2/3 (terrain)     */
+#undef CAND
+#undef MID
+}
 static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double mu_link, const OTerrain* T, OContact* out) {
   int n = 0;
   for (int l = 0; l < 4; l++) {
-    OCand c[32];      /* index = 8 * sub + jj as in the kernel's table; jj = 7 (the mid-link spheres) exists only with terrain */
-    memset(c, 0, sizeof c);
-    int hip = 1 + 3 * l, thigh = 2 + 3 * l, shank = 3 + 3 * l, k = 0;
-    const OPrim* lp = M->leg_prims[l];   /* 0 hip cyl | 1 thigh box, 2 thigh cyl 0, 3 thigh cyl 1, 4 wheel | 5 shank box, 6 foot */
-#define CAND(prim, body_, which, mu_) do { cand_point(prim, K->Rw[body_], K->pw[body_], which, &c[k]); c[k].body = body_; c[k].mu = mu_; k++; } while (0)
-#define MID(which_, f_) do { if (T) { double a_[3], b_[3], r_; int bd_; capsule(M, K, l, which_, a_, b_, &r_, &bd_); \
-      for (int i = 0; i < 3; i++) { c[k].P[i] = a_[i] + (f_) * (b_[i] - a_[i]); } \
-      c[k].P[2] -= r_; c[k].depth = c[k].P[2]; c[k].rs = r_; \
-      c[k].n[0] = 0; c[k].n[1] = 0; c[k].n[2] = 1; c[k].valid = 1; c[k].body = bd_; c[k].mu = mu_link; } k++; } while (0)
-    CAND(&lp[6], shank, 0, mu_foot);                                        /*  0      foot                         */
-    for (int v = 0; v < 3; v++) CAND(&lp[5], shank, v, mu_link);             /*  1-3    shank box v0..v2             */
-    for (int s2 = 0; s2 < 2; s2++) CAND(&lp[4], thigh, s2, mu_link);         /*  4,5    wheel caps                   */
-    CAND(&lp[5], shank, 3, mu_link);                                        /*  6      shank box v3                 */
-    MID(1, 1.0 / 3.0);                                                      /*  7      shank axis 1/3 (terrain)     */
-    for (int v = 4; v < 8; v++) CAND(&lp[5], shank, v, mu_link);             /*  7-10   shank box v4..v7             */
-    for (int s2 = 0; s2 < 2; s2++) CAND(&lp[2], thigh, s2, mu_link);         /*  11,12  thigh cylinder 0 caps        */
-    CAND(&M->base_prims[0], 0, l, mu_link);                                 /*  13     body box vertex (leg, z-)    */
-    MID(1, 2.0 / 3.0);                                                      /*         shank axis 2/3 (terrain)     */
-    for (int v = 0; v < 4; v++) CAND(&lp[1], thigh, v, mu_link);             /*  14-17  thigh box v0..v3             */
-    for (int s2 = 0; s2 < 2; s2++) CAND(&lp[3], thigh, s2, mu_link);         /*  18,19  thigh cylinder 1 caps        */
-    CAND(&M->base_prims[0], 0, l + 4, mu_link);                             /*  20     body box vertex (leg, z+)    */
-    MID(0, 1.0 / 3.0);                                                      /*         thigh axis 1/3 (terrain)     */
-    for (int v = 4; v < 8; v++) CAND(&lp[1], thigh, v, mu_link);             /*  21-24  thigh box v4..v7             */
-    for (int s2 = 0; s2 < 2; s2++) CAND(&lp[0], hip, s2, mu_link);           /*  25,26  hip cylinder caps            */
-    if (l == 0 || l == 2) CAND(&M->base_prims[l == 0 ? 1 : 2], 0, 0, mu_link); else k++;   /* 27 handle sphere (legs 0, 2) */
-    MID(0, 2.0 / 3.0);                                                      /*         thigh axis 2/3 (terrain)     */
-#undef CAND
-#undef MID
+    OCand c[32];
+    enum_cands(M, K, l, mu_foot, mu_link, T, c);
     if (T)                                   /* the nearest surface decides depth, normal and friction partner */
       for (int i = 0; i < 32; i++) {
         if (!c[i].valid) continue;
@@ -1090,6 +1094,55 @@ static int find_pair_contacts(const OModel* M, const OKin* K0, const OKin* K1, O
   }
   return n;
 }
+/* SEPMC contact bookkeeping, this build's spec: does a leg / wheel link of the robot -- any candidate point below the
+ * trunk except the foot sphere (index 0 of every leg) -- have a contact point with the plane or a box other than `flag` / with the flag? */
+static void touch_classes(const OModel* M, const OKin* K, const OTerrain* T, int flag, int* t_static, int* t_flag) {
+  *t_static = 0; *t_flag = 0;
+  for (int l = 0; l < 4; l++) {
+    OCand c[32];
+    enum_cands(M, K, l, 0.0, 0.0, T, c);
+    for (int i = 0; i < 32; i++) {
+      if (!c[i].valid || c[i].body == 0 || i == 0) continue;
+      if (c[i].P[2] < LLM_CONTACT_MARGIN) *t_static = 1;
+      const double E[3] = {c[i].P[0], c[i].P[1], c[i].P[2] + c[i].rs};
+      for (int si = 0; T && si < T->n; si++) {
+        double nn[3]; int isb;
+        if (shape_sdf(T->rec + 8 * si, E, nn, &isb) - c[i].rs < LLM_CONTACT_MARGIN) { if (si == flag) *t_flag = 1; else *t_static = 1; }
+      }
+    }
+  }
+}
+/* ... and with the other robot: a thigh capsule, or a shank capsule away from its foot end (closest-point parameter <= 0.9) */
+static void pair_touch(const OModel* M, const OKin* K0, const OKin* K1, int* touch0, int* touch1) {
+  *touch0 = 0; *touch1 = 0;
+  for (int ia = 0; ia < 10; ia++)
+    for (int ib = 0; ib < 10; ib++) {
+      double a1[3], b1[3], a2[3], b2[3], r1, r2, c1[3], c2[3], d[3], u[3], w[3];
+      int bA, bB;
+      pair_capsule(M, K0, ia, a1, b1, &r1, &bA);
+      pair_capsule(M, K1, ib, a2, b2, &r2, &bB);
+      seg_seg(a1, b1, a2, b2, c1, c2);
+      for (int i = 0; i < 3; i++) d[i] = c1[i] - c2[i];
+      const double len = sqrt(v3dot(d, d));
+      if (len < 1e-9 || len - r1 - r2 >= LLM_CONTACT_MARGIN) continue;
+      for (int i = 0; i < 3; i++) { u[i] = c1[i] - a1[i]; w[i] = b1[i] - a1[i]; }
+      const double s0 = sqrt(v3dot(u, u) / v3dot(w, w));
+      for (int i = 0; i < 3; i++) { u[i] = c2[i] - a2[i]; w[i] = b2[i] - a2[i]; }
+      const double s1 = sqrt(v3dot(u, u) / v3dot(w, w));
+      if (ia < 8 && !((ia & 1) && s0 > 0.9)) *touch0 = 1;
+      if (ib < 8 && !((ib & 1) && s1 > 0.9)) *touch1 = 1;
+    }
+}
+int orc_touch_model(const OModel* M, const double* state0, const double* state1, const OTerrain* T0, int flag0, const OTerrain* T1, int flag1, int32_t* out6) {
+  OKin K0, K1;
+  kinematics(M, state0, NULL, &K0);
+  kinematics(M, state1, NULL, &K1);
+  int a, b;
+  touch_classes(M, &K0, T0, flag0, &a, &b); out6[0] = a; out6[1] = b;
+  touch_classes(M, &K1, T1, flag1, &a, &b); out6[3] = a; out6[4] = b;
+  pair_touch(M, &K0, &K1, &a, &b); out6[2] = a; out6[5] = b;
+  return 0;
+}
 /* states[2][37], taus[2][12], pushes[2] (nullable entries), one terrain for both; returns the number of shared rows */
 int orc_substep_pair_model(const OModel* M, double dt, int n_iter, const double* mu_foot2, double* state0, double* state1, const double* tau0,
                            const double* tau1, const OTerrain* T0, const OTerrain* T1, const double* push0, const double* push1, double* pair_rows) {
@@ -1406,6 +1459,12 @@ int orc_substep_pair(const OBatch* B, double* state0, double* state1, const doub
   const double mu2[2] = {mu_foot, mu_foot};
   return orc_substep_pair_model(&B->model, B->dt, B->cfg.solver_iterations, mu2, state0, state1, tau0, tau1, n_shapes0 > 0 ? &T0 : NULL,
                                 n_shapes1 > 0 ? &T1 : NULL, push0, push1, pair_rows8);
+}
+/* SEPMC: the contact classes of both robots in the given configuration: out6 = robot 0 {static, flag, robot}, robot 1 {static, flag, robot} */
+int orc_touch(const OBatch* B, const double* state0, const double* state1, int n_shapes0, const double* shapes0, int flag0, int n_shapes1,
+              const double* shapes1, int flag1, int32_t* out6) {
+  OTerrain T0 = {n_shapes0, shapes0, 1.0}, T1 = {n_shapes1, shapes1, 1.0};
+  return orc_touch_model(&B->model, state0, state1, n_shapes0 > 0 ? &T0 : NULL, flag0, n_shapes1 > 0 ? &T1 : NULL, flag1, out6);
 }
 int orc_self_contacts(const OBatch* B, const double* state, double* rows8) {
   OKin K;

@@ -458,7 +458,7 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5):
         off = 0.5 * dist * np.array([np.cos(ang), np.sin(ang)])
         for r in range(2):
             st[a, r, 0:2] = c + (off if r == 0 else -off)
-            st[a, r, 2] = rng.uniform(0.31, 0.37) + (0.12 if (a % 4 == 3 and r == 0) else 0.0)
+            st[a, r, 2] = rng.uniform(0.35, 0.41) + (0.12 if (a % 4 == 3 and r == 0) else 0.0)      # (standing height of the start pose: 0.356)
             st[a, r, 3:7] = R.from_euler('xyz', [rng.normal() * 0.1, rng.normal() * 0.1, rng.uniform(0, 2 * np.pi)]).as_quat()
             st[a, r, 7:13] = rng.normal(size=6) * 0.3
             st[a, r, 13:25] += rng.normal(size=12) * 0.15
@@ -472,7 +472,8 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5):
     es = E.state().astype(np.float64)
     tr = E.push_trace().astype(np.float64)
     B = make_oracle_batch(orc, urdf_model.default_model_blob(), mocap.load_mocap('', 0.02), n_envs=1, kd=0.5, max_tau=16.0)
-    out = dict(config=[], vel=[], n_rows=0, n_felt=0)
+    out = dict(config=[], vel=[], n_rows=0, n_felt=0, who=[])
+    ep_after = E.episode()
     for a in range(n_arenas):
         rec = np.array([[rows[a][b][0] - rows[a][b][3], rows[a][b][0] + rows[a][b][3], rows[a][b][1] - rows[a][b][4], rows[a][b][1] + rows[a][b][4],
                          rows[a][b][2] - rows[a][b][5], rows[a][b][2] + rows[a][b][5], 0.0, 0.0] for b in range(cnt[a])], dtype=np.float64).reshape(-1, 8)
@@ -480,10 +481,11 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5):
         rec = np.vstack([rec, [[fl[0] - 0.05, fl[0] + 0.05, fl[1] - 0.05, fl[1] + 0.05, fl[2] - 0.25, fl[2] + 0.25, 0.0, 0.0]]]).astype(np.float32).astype(np.float64)
         rec[0, 3] += 1.0; rec[1, 2] -= 1.0; rec[2, 1] += 1.0; rec[3, 0] -= 1.0        # the walls are solid outwards for contacts (SEPMC_WALL_SOLID)
         rec = rec.astype(np.float32).astype(np.float64)
-        near, s, s_free = [], [], []
+        near, s, s_free, flag_at = [], [], [], []
         for r in range(2):
             p = st32[a, r, 0:3]
-            near.append(rec[(p[0] >= rec[:, 0] - 0.9) & (p[0] <= rec[:, 1] + 0.9) & (p[1] >= rec[:, 2] - 0.9) & (p[1] <= rec[:, 3] + 0.9) & (p[2] <= rec[:, 5] + 0.9)][:8])
+            sel = np.nonzero((p[0] >= rec[:, 0] - 0.9) & (p[0] <= rec[:, 1] + 0.9) & (p[1] >= rec[:, 2] - 0.9) & (p[1] <= rec[:, 3] + 0.9) & (p[2] <= rec[:, 5] + 0.9))[0][:8]
+            near.append(rec[sel]); flag_at.append(int(np.nonzero(sel == len(rec) - 1)[0][0]) if (len(rec) - 1) in sel else -1)
             s.append(st32[a, r].copy()); s_free.append(st32[a, r].copy())
         tgt = [np.clip(s[r][13:25] + act[a, r].astype(np.float64), -3.0, 3.0) for r in range(2)]
         mu = float(np.float32(ep['friction'][a]) * np.float32(0.9))
@@ -491,6 +493,11 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5):
         for k in range(10):
             tau = [np.clip(50.0 * (tgt[r] - s[r][13:25]) - 0.5 * s[r][25:37], -16.0, 16.0) for r in range(2)]
             push = [tr[a, r, k, 1:4] if tr[a, r, k, 0] > 0.5 else None for r in range(2)]
+            if k == 9:                          # the contact list the env reads is that of the last substep's collision detection (CTG:426-450)
+                tc = B.touch(s[0], s[1], near[0], flag_at[0], near[1], flag_at[1])
+                who = [1 if tc[r][0] else (2 if tc[r][1] else ((4 - r) if tc[r][2] else -1)) for r in range(2)]
+                taker = 1 if ep['with_flag0'][a] > 0.5 else 0
+                out['who'].append((int(ep_after['who0'][a]) == who[0], int(ep_after['who_taker'][a]) == who[taker], who[0], who[taker]))
             s[0], s[1], pr = B.substep_pair(s[0], s[1], tau[0], tau[1], mu, near[0], near[1], 0.5 / 0.9, push[0], push[1])
             nrows += len(pr)
             for r in range(2):                                   # the same step with the other robot ignored
@@ -508,5 +515,8 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5):
     assert out['n_rows'] >= n_arenas // 2 and out['n_felt'] >= n_arenas // 3, (out['n_rows'], out['n_felt'])
     assert np.median(c) < 1e-4 and np.median(v) < 1e-3, (np.median(c), np.median(v))
     assert (c < 5e-3).mean() > 0.9 and (v < 5e-2).mean() > 0.9, (np.sort(c)[-6:], np.sort(v)[-6:])   # a near-tie between two capsule pairs may fall either way in float32
-    return dict(config_median=float(np.median(c)), config_max=float(c.max()), vel_median=float(np.median(v)), vel_max=float(v.max()), arenas_with_rows=out['n_rows'],
+    w = np.array(out['who'])
+    # who-touches-whom from this build's contact classes (the env's real, unscripted bookkeeping path) against the oracle's restatement
+    assert w[:, 0].mean() > 0.9 and w[:, 1].mean() > 0.9 and (w[:, 2] == 4).sum() >= 3 and (w[:, 2] == 1).sum() >= 1, (w[:, 0].mean(), w[:, 1].mean(), w[:, 2].tolist())
+    return dict(who0_agree=float(w[:, 0].mean()), who_taker_agree=float(w[:, 1].mean()), who0_hist=np.bincount(w[:, 2] + 1, minlength=6).tolist(), config_median=float(np.median(c)), config_max=float(c.max()), vel_median=float(np.median(v)), vel_max=float(v.max()), arenas_with_rows=out['n_rows'],
                 arenas_felt=out['n_felt'])
