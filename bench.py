@@ -238,6 +238,26 @@ def epmc_env_config(element_id):
                                      'hole_config': {'min_gap_height': 0.25, 'max_gap_height': 0.25}}}
 
 
+def cpu_baseline_env(kind, env_config, budget_s=10.0):
+    """The EPMC / SEPMC oracles put together as a CPU env (oracle/free_run.py: NumPy env logic + analytic rays + the float64 C physics), random
+    policy, one core, a bounded sample.  A port (the checker), not the product and not a tuned CPU engine."""
+    import numpy as np
+    from oracle import oracle as orc, free_run as FR
+    from lifelike_agility_and_play_amd import epmc_capi, mocap, urdf_model
+    orc.build()
+    blob, table, init = urdf_model.default_model_blob(), mocap.load_mocap('', 1.0 / 50.0), epmc_capi.default_init_state()
+    rng = np.random.default_rng(0)
+    if kind == 'epmc':
+        run = FR.EpmcFreeRun(env_config, blob, table, init, seed=1)
+        steps, secs, eps = FR.time_random_policy(run, budget_s, 12, rng)
+        return {'value': steps / secs, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+                'sample': '%d env-steps (%d episodes) of one PlayGround env in %.1f s: oracle/epmc_oracle.py (NumPy) + oracle/pmc_oracle.c physics, random policy' % (steps, eps, secs)}
+    run = FR.SepmcFreeRun(env_config, blob, table, init, seed=1)
+    steps, secs, eps = FR.time_random_policy(run, budget_s, [12, 12], rng)
+    return {'value': 2 * steps / secs, 'unit': 'robot-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d arena-steps (%d episodes) of one chase-tag arena in %.1f s: oracle/sepmc_oracle.py (NumPy) + oracle/pmc_oracle.c two-robot physics, random policy' % (steps, eps, secs)}
+
+
 def main_epmc(args):
     """Same measurement for the EPMC env (not the driver's contract line): env-steps/s of 4096 PlayGround envs per GPU."""
     import torch
@@ -284,7 +304,8 @@ def main_epmc(args):
         elapsed = float(tt.item())
     if rank == 0:
         achieved = n * EPMC_ALGO_BYTES_PER_ENV_STEP / (k_ms * 1e-3) / 1e9
-        print(json.dumps({
+        extra = {'cpu_baseline': cpu_baseline_env('epmc', epmc_env_config(args.element))} if (world == 1 and not args.no_cpu_baseline) else {}
+        print(json.dumps({**extra, **{
             'metric': 'env-steps/sec (whole node), EPMC PlayGround env, random policy', 'value': world * n * args.steps / elapsed, 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -293,7 +314,7 @@ def main_epmc(args):
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
                          'kernel': 'epmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
                          'algorithmic_bytes_per_env_step': EPMC_ALGO_BYTES_PER_ENV_STEP,
-                         'note': 'bound by single-wave instruction issue and per-(ray, box) LDS latency, not HBM; see DESIGN.md 8'}}), flush=True)
+                         'note': 'bound by single-wave instruction issue, not HBM; see DESIGN.md 8'}}}), flush=True)
     eng.close()
     if world > 1:
         dist.destroy_process_group()
@@ -357,7 +378,8 @@ def main_sepmc(args):
         elapsed = float(tt.item())
     if rank == 0:
         achieved = 2 * n_arenas * SEPMC_ALGO_BYTES_PER_ROBOT_STEP / (k_ms * 1e-3) / 1e9
-        print(json.dumps({
+        extra = {'cpu_baseline': cpu_baseline_env('sepmc', sepmc_env_config())} if (world == 1 and not args.no_cpu_baseline) else {}
+        print(json.dumps({**extra, **{
             'metric': 'robot-steps/sec (whole node), SEPMC chase-tag env, random policy', 'value': world * 2 * n_arenas * args.steps / elapsed, 'unit': 'robot-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -367,7 +389,7 @@ def main_sepmc(args):
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
                          'kernel': 'sepmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
                          'algorithmic_bytes_per_robot_step': SEPMC_ALGO_BYTES_PER_ROBOT_STEP,
-                         'note': 'bound by single-wave instruction issue, not HBM; see DESIGN.md 8b'}}), flush=True)
+                         'note': 'bound by single-wave instruction issue, not HBM; see DESIGN.md 8b'}}}), flush=True)
     eng.close()
     if world > 1:
         dist.destroy_process_group()
