@@ -148,3 +148,31 @@ def time_random_policy(runner, budget_s, n_act, rng, max_steps=10 ** 9):
             episodes += 1
             runner.reset()
     return steps, time.perf_counter() - t0, episodes
+
+
+class SharedDraws(object):
+    """Uniforms in [0, 1) rounded to float32, recorded in order, mapped to values exactly as the engines map them (epmc_step.hpp EpmcDraws):
+    the oracle env draws from this object, the recorded uniforms are then handed to the engine (ll_*_reset h_draws, ll_*_set_step_draws),
+    so both sides see the same random numbers."""
+
+    def __init__(self, seed=0):
+        self.g = np.random.default_rng(seed)
+        self.rec = []
+
+    def _u(self):
+        u = float(np.float32(self.g.random() * 0.999))
+        self.rec.append(u)
+        return u
+
+    def uniform(self, a, b):
+        return a + (b - a) * self._u()
+
+    def randint(self, a, b):
+        return a + min(int((b - a) * self._u()), b - a - 1)
+
+    def rand(self):
+        return self._u()
+
+    def take(self):
+        out, self.rec = self.rec, []
+        return out

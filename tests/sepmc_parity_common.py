@@ -520,3 +520,67 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5):
     assert w[:, 0].mean() > 0.9 and w[:, 1].mean() > 0.9 and (w[:, 2] == 4).sum() >= 3 and (w[:, 2] == 1).sum() >= 1, (w[:, 0].mean(), w[:, 1].mean(), w[:, 2].tolist())
     return dict(who0_agree=float(w[:, 0].mean()), who_taker_agree=float(w[:, 1].mean()), who0_hist=np.bincount(w[:, 2] + 1, minlength=6).tolist(), config_median=float(np.median(c)), config_max=float(c.max()), vel_median=float(np.median(v)), vel_max=float(v.max()), arenas_with_rows=out['n_rows'],
                 arenas_felt=out['n_felt'])
+
+
+def check_free_running_against_oracle_env(lib_path, n_steps=4):
+    """End to end, nothing scripted: the engine and the oracles assembled into a CPU chase-tag env (oracle/free_run.py: NumPy env logic,
+    analytic rays and visibility segments on the real arena, the two-robot C physics, the oracle's contact classes) start from the same
+    uniforms, get the same actions and are compared after every control step: both observations, both states, flag, roles, rewards, done."""
+    from oracle import free_run as FR
+    from lifelike_agility_and_play_amd import mocap, urdf_model, epmc_capi, sepmc_capi
+    from parity_common import quat_align
+    blob, table, init = urdf_model.default_model_blob(), mocap.load_mocap('', 0.02), epmc_capi.default_init_state()
+    worst = dict(state=0.0, percep_same=1.0)
+    for elements in ((0, 0, 0), (1, 1, 1)):
+        cfg = env_config(elements)
+        cfg['env_randomize_config']['disturb_force_config'] = {'start_time': 0.0, 'interval_time': 1.0, 'duration_time': 0.5, 'horizontal_force': [10, 50], 'vertical_force': [0, 10]}
+        n = 3
+        E = make_engine(cfg, n, lib_path, seed=1)
+        runs = [FR.SepmcFreeRun(cfg, blob, table, init, seed=0) for _ in range(n)]
+        U = np.full((n, sepmc_capi.LLS_MAX_DRAWS), 0.5, np.float32)
+        obs_o = []
+        for i, r in enumerate(runs):
+            r.draws = FR.SharedDraws(10 * sum(elements) + i)
+            obs_o.append(r.reset())
+            u = r.draws.take()
+            assert len(u) <= sepmc_capi.LLS_MAX_DRAWS
+            U[i, :len(u)] = u
+        E.reset(draws=U)
+        rng = np.random.default_rng(sum(elements))
+
+        def compare(t, obs_o, rew_o=None, done_o=None):
+            obs_e, st_e, ep = E.obs().astype(np.float64), E.state().astype(np.float64), E.episode()
+            tol = 1e-5 * 3.0 ** t
+            for i, r in enumerate(runs):
+                np.testing.assert_allclose([ep['flag_x'][i], ep['flag_y'][i]], r.env.target_pos[:2], atol=1e-6)
+                assert bool(ep['with_flag0'][i] > 0.5) == r.env.with_flag[0]
+                for k in range(2):
+                    err = np.abs(quat_align(st_e[i][k], r.env.states[k]) - r.env.states[k])
+                    worst['state'] = max(worst['state'], err[:7].max() / tol)
+                    assert err[:7].max() < tol and err[13:25].max() < 5 * tol, (elements, i, k, t, err[:7].max(), err[13:25].max())
+                    pe, po = obs_e[i][k][135:913], np.asarray(obs_o[i][k])[135:913]
+                    same = np.abs(pe - po) < 2e-3 + 20 * tol
+                    worst['percep_same'] = min(worst['percep_same'], same.mean())
+                    assert same.mean() > 0.97, (elements, i, k, t, same.mean())
+                    np.testing.assert_allclose(obs_e[i][k][913:], np.asarray(obs_o[i][k])[913:], atol=2e-3 + 20 * tol)      # percept_vec .. control_spd
+            if rew_o is not None:
+                rew_e, done_e, _ = E.reward_done()
+                for i in range(n):
+                    assert bool(done_e[i]) == bool(done_o[i]), (elements, i, t)
+                    np.testing.assert_allclose(rew_e[i], rew_o[i], atol=1e-6)
+        compare(0, obs_o)
+        for t in range(n_steps):
+            act = (rng.normal(size=(n, 2, 12)) * 0.135).astype(np.float32)
+            outs = [r.step([act[i][0].astype(np.float64), act[i][1].astype(np.float64)]) for i, r in enumerate(runs)]
+            used = [r.draws.take() for r in runs]
+            k = max(1, max(len(u) for u in used))
+            D = np.full((n, k), 0.5, np.float32)
+            for i, u in enumerate(used):
+                D[i, :len(u)] = u
+            E.set_step_draws(D)
+            E.step_host(act)
+            compare(t + 1, [o[0] for o in outs], [o[1] for o in outs], [o[2] for o in outs])
+            if any(o[2] for o in outs):
+                break
+        E.close()
+    return worst

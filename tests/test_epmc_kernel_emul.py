@@ -36,3 +36,7 @@ def test_free_running_invariants(emul_lib):
 def test_terrain_physics_against_oracle(emul_lib):
     out = ec.check_terrain_physics_against_oracle(emul_lib)
     assert out['n_terrain'] >= 10
+
+
+def test_free_running_against_the_oracle_env(emul_lib):
+    print(ec.check_free_running_against_oracle_env(emul_lib))

@@ -31,3 +31,7 @@ def test_env_api_contract_gpu():
 def test_terrain_physics_against_oracle():
     out = ec.check_terrain_physics_against_oracle(None, n_envs=48)
     assert out['n_terrain'] >= 30 and out['n_felt'] >= 20
+
+
+def test_free_running_against_the_oracle_env_gpu():
+    print(ec.check_free_running_against_oracle_env(None))

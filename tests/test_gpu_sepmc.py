@@ -33,3 +33,7 @@ def test_robot_robot_contact_gpu():
 
 def test_pair_physics_against_oracle_gpu():
     print(SC.check_pair_physics_against_oracle(None, n_arenas=64, seed=9))
+
+
+def test_free_running_against_the_oracle_env_gpu():
+    print(SC.check_free_running_against_oracle_env(None))

@@ -62,3 +62,7 @@ def test_reset_of_a_subset_of_arenas(emul_lib):
     assert np.all(o1[redo][:, :, 99:135] == 0.0)                                   # action history of a fresh episode
     assert not np.array_equal(b1[redo], b0[redo])                                  # new cubes
     E.close()
+
+
+def test_free_running_against_the_oracle_env(emul_lib):
+    print(SC.check_free_running_against_oracle_env(emul_lib))
