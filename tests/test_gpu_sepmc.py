@@ -17,7 +17,7 @@ def test_scripted_episodes_against_reference_goldens_gpu(model_blob):
 
 
 def test_free_running_invariants_gpu():
-    out = SC.check_free_running(None, n_arenas=200, steps=200)        # 400 rows: partial last wave, ray traces on
+    out = SC.check_free_running(None, n_arenas=201, steps=200)        # 402 rows: a partial last wave (two of four rows), ray traces on
     print(out)
     out = SC.check_free_running_big(None, n_arenas=3000, steps=60)    # occupancy-2 build
     print(out)
