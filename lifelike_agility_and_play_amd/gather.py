@@ -43,13 +43,23 @@ def bind_torch_stream(engine, stream=None):
     return s
 
 
+def use_engine_stream(engine):
+    """The other direction of bind_torch_stream, for engines without a set_stream entry (EPMC, SEPMC): torch's current stream becomes
+    the engine's own stream, so torch ops on the engine's buffers are ordered with its kernels."""
+    s = torch.cuda.ExternalStream(int(engine.device_ptrs().stream))
+    torch.cuda.set_stream(s)
+    return s
+
+
 def engine_tensors(engine):
-    """torch views of the engine's output/action buffers (no copies)."""
+    """torch views of the engine's output/action buffers (no copies).  n_envs counts robot rows for the SEPMC engine ([arena][robot])."""
     p = engine.device_ptrs()
     n, od = p.n_envs, p.obs_dim
-    return dict(obs=device_tensor(p.obs, (n, od)), reward=device_tensor(p.reward, (n,)),
-                done=device_tensor(p.done, (n,), torch.uint8), actions=device_tensor(p.actions, (n, 12)),
-                terminal_obs=device_tensor(p.terminal_obs, (n, od)))
+    out = dict(obs=device_tensor(p.obs, (n, od)), reward=device_tensor(p.reward, (n,)),
+               done=device_tensor(p.done, (n,), torch.uint8), actions=device_tensor(p.actions, (n, 12)))
+    if p.terminal_obs:
+        out['terminal_obs'] = device_tensor(p.terminal_obs, (n, od))
+    return out
 
 
 def pack_rows(obs, actions, reward, done, out):

@@ -246,6 +246,12 @@ class SepmcEngine(object):
         self._chk(self.lib.ll_sepmc_get_counters(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(arena_steps=a.value, episodes=b.value, nonfinite=c.value)
 
+    def device_ptrs(self):
+        """Device addresses of obs / reward / done / actions and the engine's stream (gather.engine_tensors, gather.use_engine_stream)."""
+        p = capi.LLDevicePtrs()
+        self._chk(self.lib.ll_sepmc_device_ptrs(self.h, C.byref(p)))
+        return p
+
     def enable_kernel_timing(self, on=True):
         self._chk(self.lib.ll_sepmc_enable_kernel_timing(self.h, 1 if on else 0))
 

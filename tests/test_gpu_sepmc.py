@@ -37,3 +37,25 @@ def test_pair_physics_against_oracle_gpu():
 
 def test_free_running_against_the_oracle_env_gpu():
     print(SC.check_free_running_against_oracle_env(None))
+
+
+def test_zero_copy_torch_views_gpu():
+    """torch tensors over the SEPMC engine's own obs / action buffers on the engine's stream: a device-side policy needs no copies."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('torch.cuda is not available on this box')
+    from lifelike_agility_and_play_amd import gather
+    E = SC.make_engine(SC.env_config((1, 0, 0)), 64, None, auto_reset=1, seed=2)
+    gather.use_engine_stream(E)
+    T = gather.engine_tensors(E)
+    E.reset()
+    assert T['obs'].shape == (128, 965) and T['actions'].shape == (128, 12)
+    for t in range(3):
+        T['actions'].copy_(torch.randn((128, 12), device='cuda') * 0.1)
+        a = T['actions'].clone()
+        E.step()
+        torch.cuda.current_stream().synchronize()
+    np.testing.assert_array_equal(T['obs'].cpu().numpy().reshape(64, 2, 965), E.obs())
+    live = ~np.repeat(E.reward_done()[1], 2)
+    np.testing.assert_allclose(T['obs'][:, 123:135].cpu().numpy()[live], a.cpu().numpy()[live], rtol=1e-6)      # the newest action frame of prop_a
+    E.close()
