@@ -522,7 +522,7 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5):
                 arenas_felt=out['n_felt'])
 
 
-def check_free_running_against_oracle_env(lib_path, n_steps=4):
+def check_free_running_against_oracle_env(lib_path, n_steps=4, prop_type=None, element_sets=((0, 0, 0), (1, 1, 1))):
     """End to end, nothing scripted: the engine and the oracles assembled into a CPU chase-tag env (oracle/free_run.py: NumPy env logic,
     analytic rays and visibility segments on the real arena, the two-robot C physics, the oracle's contact classes) start from the same
     uniforms, get the same actions and are compared after every control step: both observations, both states, flag, roles, rewards, done."""
@@ -531,8 +531,11 @@ def check_free_running_against_oracle_env(lib_path, n_steps=4):
     from parity_common import quat_align
     blob, table, init = urdf_model.default_model_blob(), mocap.load_mocap('', 0.02), epmc_capi.default_init_state()
     worst = dict(state=0.0, percep_same=1.0)
-    for elements in ((0, 0, 0), (1, 1, 1)):
+    for elements in element_sets:
         cfg = env_config(elements)
+        if prop_type is not None:
+            cfg['prop_type'] = list(prop_type)
+        P3 = 3 * sum({'joint_pos': 12, 'joint_vel': 12, 'root_lin_vel_loc': 3, 'root_ang_vel_loc': 3, 'e_g': 3}[k] for k in cfg['prop_type']) + 36   # prop | prop_a
         cfg['env_randomize_config']['disturb_force_config'] = {'start_time': 0.0, 'interval_time': 1.0, 'duration_time': 0.5, 'horizontal_force': [10, 50], 'vertical_force': [0, 10]}
         n = 3
         E = make_engine(cfg, n, lib_path, seed=1)
@@ -558,11 +561,13 @@ def check_free_running_against_oracle_env(lib_path, n_steps=4):
                     err = np.abs(quat_align(st_e[i][k], r.env.states[k]) - r.env.states[k])
                     worst['state'] = max(worst['state'], err[:7].max() / tol)
                     assert err[:7].max() < tol and err[13:25].max() < 5 * tol, (elements, i, k, t, err[:7].max(), err[13:25].max())
-                    pe, po = obs_e[i][k][135:913], np.asarray(obs_o[i][k])[135:913]
+                    assert obs_e[i][k].shape == np.asarray(obs_o[i][k]).shape == (P3 + 830,)
+                    np.testing.assert_allclose(obs_e[i][k][:P3], np.asarray(obs_o[i][k])[:P3], atol=2e-3 + 500 * tol)              # prop (joint rates up to 30 rad/s), prop_a
+                    pe, po = obs_e[i][k][P3:P3 + 778], np.asarray(obs_o[i][k])[P3:P3 + 778]
                     same = np.abs(pe - po) < 2e-3 + 20 * tol
                     worst['percep_same'] = min(worst['percep_same'], same.mean())
                     assert same.mean() > 0.97, (elements, i, k, t, same.mean())
-                    np.testing.assert_allclose(obs_e[i][k][913:], np.asarray(obs_o[i][k])[913:], atol=2e-3 + 20 * tol)      # percept_vec .. control_spd
+                    np.testing.assert_allclose(obs_e[i][k][P3 + 778:], np.asarray(obs_o[i][k])[P3 + 778:], atol=2e-3 + 20 * tol)      # percept_vec .. control_spd
             if rew_o is not None:
                 rew_e, done_e, _ = E.reward_done()
                 for i in range(n):

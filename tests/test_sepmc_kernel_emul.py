@@ -66,3 +66,8 @@ def test_reset_of_a_subset_of_arenas(emul_lib):
 
 def test_free_running_against_the_oracle_env(emul_lib):
     print(SC.check_free_running_against_oracle_env(emul_lib))
+
+
+def test_free_running_with_another_prop_type(emul_lib):
+    """A shorter prop (CTG:90-104: any list of the five keys, in the given order) moves every later observation block."""
+    print(SC.check_free_running_against_oracle_env(emul_lib, n_steps=3, prop_type=['e_g', 'joint_pos'], element_sets=((1, 0, 1),)))
