@@ -80,12 +80,18 @@ struct EpmcDraws {
   int n_scr, used;
   uint64_t seed;
   uint32_t env, episode, salt;
+  uint32_t blk[4];          // the four words of Philox block used / 4 (one evaluation serves four consecutive draws)
+  int have = -1;            // index of the block held in blk, -1: none
   LL_HD float u01() {
     const int i = used++;
     if (scr) return i < n_scr ? scr[i] : 0.5f;
-    uint32_t r[4];
-    philox4x32(env, episode, (uint32_t)i, salt, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    return (float)(r[0] >> 8) * (1.0f / 16777216.0f);
+    if ((i >> 2) != have) {
+      have = i >> 2;
+      philox4x32(env, episode, (uint32_t)have, salt, (uint32_t)seed, (uint32_t)(seed >> 32), blk);
+    }
+    const int k = i & 3;
+    const uint32_t w = k == 0 ? blk[0] : (k == 1 ? blk[1] : (k == 2 ? blk[2] : blk[3]));
+    return (float)(w >> 8) * (1.0f / 16777216.0f);
   }
   LL_HD float uniform(float a, float b) { return a + (b - a) * u01(); }
   LL_HD int randint(int a, int b) {                      // np.random.randint(a, b): a .. b-1
