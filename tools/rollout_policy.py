@@ -25,13 +25,16 @@ for _ in range(20):
 racc.zero_(); dacc.zero_()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(steps):
+c0 = E.counters()['episodes']
+SAMPLE = 10                                  # the reward statistic reads every tenth step (two extra launches per sample); episodes come from the engine's counter
+for t in range(steps):
     act()
     E.step()
-    racc.add_(T['reward']); dacc.add_(T['done'])
+    if t % SAMPLE == 0:
+        racc.add_(T['reward'])
 torch.cuda.synchronize()
-rsum, dsum = racc.sum(), dacc.sum()
 dt = time.perf_counter() - t0
+rsum, dsum = racc.sum() * (steps / len(range(0, steps, SAMPLE))), E.counters()['episodes'] - c0
 print('trained policy (%s%s), %d envs: %.3f ms/step -> %.2f M env-steps/s; mean tracking reward %.3f, episodes ended %d (%.4f per env-step)'
       % (kind, '', n, dt / steps * 1e3, n * steps / dt / 1e6, float(rsum) / (n * steps), int(dsum), float(dsum) / (n * steps)))
 if kind == 'hip':
