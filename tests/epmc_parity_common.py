@@ -285,7 +285,7 @@ def check_terrain_physics_against_oracle(lib_path, n_envs=16, seed=11):
     return out
 
 
-def check_free_running_against_oracle_env(lib_path, n_steps=4):
+def check_free_running_against_oracle_env(lib_path, n_steps=4, elements=(1, 3, 0), aux=0.02, obs_rand=None):
     """End to end, nothing scripted: the engine and the oracles assembled into a CPU env (oracle/free_run.py) start from the same uniforms,
     get the same actions and are compared after every control step -- terrain, rays on the real boxes, ten substeps of terrain physics with the
     push, rewards, termination.  Contact dynamics amplify float32 rounding, so the bars widen with the step index."""
@@ -293,8 +293,8 @@ def check_free_running_against_oracle_env(lib_path, n_steps=4):
     from lifelike_agility_and_play_amd import mocap
     blob, table, init = urdf_model.default_model_blob(), mocap.load_mocap('', 0.02), epmc_capi.default_init_state()
     worst = dict(state=0.0, percep_same=1.0, reward=0.0)
-    for element in (1, 3, 0):
-        cfg = env_config(element, cmd_range=(3, 5))
+    for element in elements:
+        cfg = env_config(element, aux=aux, obs_rand=obs_rand, cmd_range=(3, 5))
         cfg['env_randomize_config']['disturb_force_config'] = {'start_time': 0.0, 'interval_time': 1.0, 'duration_time': 0.5, 'horizontal_force': [10, 50], 'vertical_force': [0, 10]}
         n = 3
         E = make_engine(cfg, n, lib_path, seed=1)

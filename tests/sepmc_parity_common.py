@@ -522,7 +522,7 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5):
                 arenas_felt=out['n_felt'])
 
 
-def check_free_running_against_oracle_env(lib_path, n_steps=4, prop_type=None, element_sets=((0, 0, 0), (1, 1, 1))):
+def check_free_running_against_oracle_env(lib_path, n_steps=4, prop_type=None, element_sets=((0, 0, 0), (1, 1, 1)), noisy=False):
     """End to end, nothing scripted: the engine and the oracles assembled into a CPU chase-tag env (oracle/free_run.py: NumPy env logic,
     analytic rays and visibility segments on the real arena, the two-robot C physics, the oracle's contact classes) start from the same
     uniforms, get the same actions and are compared after every control step: both observations, both states, flag, roles, rewards, done."""
@@ -532,7 +532,7 @@ def check_free_running_against_oracle_env(lib_path, n_steps=4, prop_type=None, e
     blob, table, init = urdf_model.default_model_blob(), mocap.load_mocap('', 0.02), epmc_capi.default_init_state()
     worst = dict(state=0.0, percep_same=1.0)
     for elements in element_sets:
-        cfg = env_config(elements)
+        cfg = env_config(elements, noisy)
         if prop_type is not None:
             cfg['prop_type'] = list(prop_type)
         P3 = 3 * sum({'joint_pos': 12, 'joint_vel': 12, 'root_lin_vel_loc': 3, 'root_ang_vel_loc': 3, 'e_g': 3}[k] for k in cfg['prop_type']) + 36   # prop | prop_a

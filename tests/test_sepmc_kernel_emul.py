@@ -71,3 +71,7 @@ def test_free_running_against_the_oracle_env(emul_lib):
 def test_free_running_with_another_prop_type(emul_lib):
     """A shorter prop (CTG:90-104: any list of the five keys, in the given order) moves every later observation block."""
     print(SC.check_free_running_against_oracle_env(emul_lib, n_steps=3, prop_type=['e_g', 'joint_pos'], element_sets=((1, 0, 1),)))
+
+
+def test_free_running_with_observation_noise(emul_lib):
+    print(SC.check_free_running_against_oracle_env(emul_lib, n_steps=3, element_sets=((0, 1, 0),), noisy=True))
