@@ -1,5 +1,5 @@
 """ctypes binding of include/llenv_policy.h: the trained PMC policy as ONE fused MFMA kernel inside libllenv.so, evaluated
-straight on an engine's device buffers.  `pmc_policy.PmcPolicy` (NumPy) and `pmc_policy_torch.TorchPmcPolicy` (library GEMMs)
+straight on an engine's device buffers.  `oracle/pmc_policy.py` (NumPy) and `pmc_policy_torch.TorchPmcPolicy` (library GEMMs)
 state the same forward pass."""
 import ctypes as C
 import os

@@ -2,7 +2,7 @@
 on the engine's obs buffer and into its action buffer (zero copies): the caller-side neighbour of the hot path.
 
 Plain library GEMMs (torch.matmul -> hipBLASLt / rocBLAS) -- seven small matrix products per step, all MFMA work; a fused
-hand-written kernel is a later step.  `pmc_policy.PmcPolicy` is the NumPy statement of the same forward pass."""
+hand-written kernel is a later step.  `oracle/pmc_policy.py` is the NumPy statement of the same forward pass."""
 import os
 
 import numpy as np

@@ -1,4 +1,6 @@
-"""NumPy forward pass of the reference's trained PMC policy (networks/legged_robot/pmc_net/pmc_net.py:117-178, :99-114):
+"""TEST INFRASTRUCTURE ONLY (never imported by the product; the product's policy is the fused HIP kernel, pmc_policy_hip.py).
+
+NumPy forward pass of the reference's trained PMC policy (networks/legged_robot/pmc_net/pmc_net.py:117-178, :99-114):
 running-mean/std normalisation clipped to +-5, VQ encoder 207->256->256->32, nearest code of a (32, 256) codebook,
 low-level controller  [relu(prop 135->64) | relu(z 32->32)] -> 256 -> 256 -> 12  (mean action).
 

@@ -59,7 +59,7 @@ def test_trained_policy_on_device_closed_loop(model_blob, mocap_table):
     torch = torch_cuda()
     from conftest import GOLDEN_DIR, PMC_PROP_TYPE, PMC_REWARD_WEIGHTS
     from lifelike_agility_and_play_amd import capi, gather
-    from lifelike_agility_and_play_amd.pmc_policy import PmcPolicy
+    from oracle.pmc_policy import PmcPolicy
     from lifelike_agility_and_play_amd.pmc_policy_torch import TorchPmcPolicy
     n = 1024
     cfg = capi.make_config(n, control_freq=50.0, kd=0.5, reward_weights=PMC_REWARD_WEIGHTS, prop_type=PMC_PROP_TYPE, prioritized_sample_factor=3.0,
@@ -88,7 +88,7 @@ def test_fused_mfma_policy_kernel(model_blob, mocap_table):
     torch = torch_cuda()
     from conftest import GOLDEN_DIR, PMC_PROP_TYPE, PMC_REWARD_WEIGHTS
     from lifelike_agility_and_play_amd import capi, gather
-    from lifelike_agility_and_play_amd.pmc_policy import PmcPolicy
+    from oracle.pmc_policy import PmcPolicy
     from lifelike_agility_and_play_amd.pmc_policy_hip import HipPmcPolicy
     for n in (1000, 4096):                                            # 1000: a partial last workgroup
         cfg = capi.make_config(n, control_freq=50.0, kd=0.5, reward_weights=PMC_REWARD_WEIGHTS, prop_type=PMC_PROP_TYPE, prioritized_sample_factor=3.0,
