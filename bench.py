@@ -71,8 +71,8 @@ def cpu_baseline(blob, table, budget_s=8.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=300)
-    ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=200)
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', choices=['pmc', 'epmc', 'sepmc'], default='pmc',
