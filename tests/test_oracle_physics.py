@@ -159,3 +159,31 @@ def test_fk_feet_matches_numpy(golden, orc, model_blob, mocap_table):
                 pos = pos + rot.apply(jo[i])
                 rot = rot * R.from_rotvec(ax[i] * s[13 + i])
             np.testing.assert_allclose(feet[l], pos + rot.apply(fp[l]), atol=1e-12)
+
+
+def test_two_robots_exchange_momentum(golden, orc, frictionless_blob, mocap_table):
+    """The oracle's two-robot substep (SEPMC): two robots colliding in mid-air, no damping, zero torque -- what one loses the other
+    gains: the total linear momentum changes by gravity alone, the z component of the total angular momentum not at all, while each
+    robot's own momentum changes by much more (the shared rows act)."""
+    orc.set_link_damping(0.0)
+    try:
+        B = make_oracle_batch(orc, frictionless_blob, mocap_table, sim_freq=10000.0, control_freq=1000.0)     # (small dt: the first-order
+        s0, s1 = standing_state(golden, z=3.0), standing_state(golden, z=3.0)                                      #  integrator's own drift is O(dt))
+        s0[0:3] = [0.0, 0.0, 3.0]; s1[0:3] = [0.30, 0.05, 3.02]                      # trunks 30 cm apart: legs and trunks interleave
+        s0[7:10] = [0.8, 0.0, 0.0]; s1[7:10] = [-0.8, 0.1, 0.0]                      # closing at 1.6 m/s
+        P0 = B.momentum(s0) + B.momentum(s1)
+        p0a = B.momentum(s0)
+        mass, dt, n = 13.000210501828224, 1.0e-4, 200
+        rows = 0
+        for _ in range(n):
+            s0, s1, pr = B.substep_pair(s0, s1, np.zeros(12), np.zeros(12), 0.45, np.zeros((0, 8)), np.zeros((0, 8)), 0.5 / 0.9)
+            rows += len(pr)
+        P1 = B.momentum(s0) + B.momentum(s1)
+        p1a = B.momentum(s0)
+        assert rows >= n // 2                                                         # the pair was in contact most of the time
+        assert np.abs((p1a - p0a)[:2]).max() > 0.5                                    # robot 0 was pushed (13 kg: > 4 cm/s)
+        np.testing.assert_allclose(P1[:2], P0[:2], atol=2e-3)                         # the pair as a whole was not
+        assert abs((P1[2] - P0[2]) + 2 * mass * 9.80665 * dt * n) < 2e-3
+        assert abs(P1[5] - P0[5]) < 5e-3                                              # Lz of the pair about the world origin
+    finally:
+        orc.set_link_damping(um_default_damping())
