@@ -254,3 +254,7 @@ class OracleBatch(object):
 
 def set_link_damping(k):
     lib().orc_set_link_damping(C.c_double(k))
+
+
+def set_self_collision(on):
+    lib().orc_set_self_collision(C.c_int(1 if on else 0))

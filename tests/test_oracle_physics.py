@@ -187,3 +187,33 @@ def test_two_robots_exchange_momentum(golden, orc, frictionless_blob, mocap_tabl
         assert abs(P1[5] - P0[5]) < 5e-3                                              # Lz of the pair about the world origin
     finally:
         orc.set_link_damping(um_default_damping())
+
+
+def test_self_collision_is_internal(golden, orc, frictionless_blob, mocap_table):
+    """Self-collision rows push two legs of the same robot apart: the joint velocities end up different from a run with the rows
+    switched off, the robot's total momentum does not (beyond gravity and the integrator's O(dt) drift)."""
+    orc.set_link_damping(0.0)
+    try:
+        B = make_oracle_batch(orc, frictionless_blob, mocap_table, sim_freq=10000.0, control_freq=1000.0)
+        s_init = standing_state(golden, z=3.0)
+        q = s_init[13:25]
+        q[0], q[3] = 0.65, -0.6                                   # the front hips rolled towards each other: the front legs cross
+        q[1], q[2], q[4], q[5] = -0.3, 0.6, -0.45, 0.9
+        s_init[25:37] = 0.0; s_init[25] = -2.0; s_init[28] = 2.0   # and closing further
+        mass, dt, n = 13.000210501828224, 1.0e-4, 100
+        P0 = B.momentum(s_init)
+        out = {}
+        for on in (1, 0):
+            orc.set_self_collision(on)
+            s = s_init.copy()
+            for _ in range(n):
+                s, nc, lam, acc = B.substep(s, np.zeros(12))
+                assert nc == 0
+            out[on] = s
+            P1 = B.momentum(s)
+            np.testing.assert_allclose(P1[:2], P0[:2], atol=1e-3)
+            assert abs((P1[2] - P0[2]) + mass * 9.80665 * dt * n) < 1e-3
+        assert np.abs(out[1][25:31] - out[0][25:31]).max() > 0.5          # the rows acted on the front legs' joints
+    finally:
+        orc.set_self_collision(1)
+        orc.set_link_damping(um_default_damping())
