@@ -217,3 +217,27 @@ def test_self_collision_is_internal(golden, orc, frictionless_blob, mocap_table)
     finally:
         orc.set_self_collision(1)
         orc.set_link_damping(um_default_damping())
+
+
+def test_standing_on_a_box_and_against_a_wall(golden, orc, model_blob, mocap_table):
+    """Terrain contact of the oracle (EPMC / SEPMC spec): a robot holding its pose on a 25 cm box stands 25 cm higher than on the
+    ground; one pushed sideways against a wall is stopped by it (the nearest-surface normal is the wall's, not +z)."""
+    B = make_oracle_batch(orc, model_blob, mocap_table)
+    hold = standing_state(golden)[13:25].copy()
+
+    def settle(s, shapes, n=400, fx=0.0):
+        for _ in range(n):
+            tau = np.clip(50.0 * (hold - s[13:25]) - 0.5 * s[25:37], -18.0, 18.0)
+            push = np.array([fx, 0.0, 0.0]) if fx else None
+            s, nc, lam = B.substep_terrain(s, tau, 0.45, shapes, 1.0, push)      # (box as grippy as the plane, so that only the geometry differs)
+        return s
+    ground = settle(standing_state(golden, z=0.40), np.zeros((0, 8)))
+    box = np.array([[-1.0, 1.0, -1.0, 1.0, 0.0, 0.25, 0.0, 0.0]])
+    raised = settle(standing_state(golden, z=0.65), box)
+    assert abs((raised[2] - ground[2]) - 0.25) < 5e-3, (ground[2], raised[2])
+    assert abs(B.fk_feet(raised)[:, 2].min() - 0.275) < 6e-3                          # the foot spheres (r = 2.5 cm) rest on the box top
+    wall = np.array([[0.45, 0.55, -2.0, 2.0, 0.0, 2.0, 0.0, 0.0]])                     # 10 cm thick, its face 45 cm ahead of the base
+    free = settle(standing_state(golden, z=ground[2]), np.zeros((0, 8)), n=400, fx=120.0)
+    held = settle(standing_state(golden, z=ground[2]), wall, n=400, fx=120.0)
+    assert free[0] > 0.3 and held[0] < free[0] - 0.1, (free[0], held[0])              # 120 N on the FR hip link drags it forwards; the wall stops it
+    assert B.fk_feet(held)[:, 0].max() < 0.45 + 0.03                                   # no foot beyond the wall's face
