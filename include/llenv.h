@@ -157,6 +157,18 @@ int ll_step(ll_engine* e, const float* d_actions);
  */
 int ll_step_scripted(ll_engine* e, const float* d_actions, const float* h_state, const float* h_feet);
 
+/*
+ * Parity probe for LeggedRobot.apply_action (LR:119-148) and the target of PLE:199-200: the torques the reference hands to
+ * setJointMotorControlArray(TORQUE_CONTROL, forces=...) before every stepSimulation, computed on the device by the very
+ * functions the step kernel calls (pmc_step.hpp pd_target / pd_torque).
+ *   h_rows [n][36] = joint_pos 12 | joint_vel 12 | x 12   (reference joint order FR1..3, FL1..3, HR1..3, HL1..3)
+ *   mode 0: x = tgt_joint_pos as passed to apply_action (clipped to +-3 rad there, LR:126-127)
+ *   mode 1: x = the policy action of a control step (target = joint_pos + action, PLE:199-200)
+ *   h_tau  [n][12]  kp (target - q) + kd (0 - qd), clipped to +-max_tau (LR:137-141)
+ * Synchronous.  Golden: tests/golden/pmc_config_golden.npz (G8).
+ */
+int ll_probe_pd_torque(ll_engine* e, const float* h_rows, int n, int mode, float* h_tau);
+
 /* Synthetic random policy a ~ N(0, sigma^2) per joint (sigma = exp(-2)), generated on
  * device by Philox keyed on (seed, env, step) into the engine's action buffer. */
 int ll_fill_random_actions(ll_engine* e, float sigma);

@@ -19,6 +19,8 @@ PLE_DEFAULT_REWARD_WEIGHTS = {'joint_pos': 0.6, 'joint_vel': 0.05, 'end_effector
                               'root_vel': 0.1}                                                       # PLE:359-363
 
 DONE_FALL, DONE_CLIP_END, DONE_DIVERGED, DONE_COLLISION, DONE_NONFINITE = 1, 2, 4, 8, 16
+LL_DONE_FALL, LL_DONE_CLIP_END, LL_DONE_DIVERGED, LL_DONE_COLLISION, LL_DONE_NONFINITE = 1, 2, 4, 8, 16      # include/llenv.h:65-69
+LL_OK, LL_EINVAL, LL_ENOMEM, LL_EHIP, LL_ESTATE, LL_ENODEV = 0, -1, -2, -3, -4, -5                           # include/llenv.h:57-62
 
 
 class LLConfig(C.Structure):
@@ -81,6 +83,7 @@ _SIGS = {
     'll_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'll_step': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_step_scripted': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'll_probe_pd_torque': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'll_fill_random_actions': (C.c_int, [C.c_void_p, C.c_float]),
     'll_step_random': (C.c_int, [C.c_void_p, C.c_float]),
     'll_sync': (C.c_int, [C.c_void_p]),
@@ -192,6 +195,14 @@ class Engine(object):
         f = np.ascontiguousarray(feet, dtype=np.float32).reshape(self.n_envs, 24) if feet is not None else None
         self._chk(self.lib.ll_set_actions(self.h, _ptr(a)))
         self._chk(self.lib.ll_step_scripted(self.h, None, _ptr(s), _ptr(f)))
+
+    def probe_pd_torque(self, q, qd, x, mode=0):
+        """Parity probe (ll_probe_pd_torque): the PD torques of LR:137-141 for rows of joint_pos, joint_vel and a target (mode 0) or action (mode 1)."""
+        rows = np.ascontiguousarray(np.concatenate([np.asarray(q), np.asarray(qd), np.asarray(x)], axis=1), dtype=np.float32)
+        assert rows.shape[1] == 36
+        tau = np.empty((len(rows), 12), dtype=np.float32)
+        self._chk(self.lib.ll_probe_pd_torque(self.h, _ptr(rows), len(rows), int(mode), _ptr(tau)))
+        return tau
 
     def fill_random_actions(self, sigma):
         self._chk(self.lib.ll_fill_random_actions(self.h, float(sigma)))

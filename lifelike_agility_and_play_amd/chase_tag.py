@@ -73,6 +73,9 @@ class _ReferenceDraws(object):
         self.n_sub = int((1.0 / env_config.get('control_freq', 25.0)) / epmc_capi.TIME_STEP)
         self.u = []
         np.random.uniform(*self.rc['friction_range'])                          # CTG:61: the constructor's own friction draw
+        self.max_tau = env_config.get('max_tau', 18.0)
+        vals = [float(np.random.uniform(*self.max_tau)) if isinstance(self.max_tau, list) else self.max_tau for _ in range(2)]   # LR:244, one per robot
+        self.max_tau_value = vals[0]                                           # (the engine has one torque limit per arena: robot 0's)
 
     def _uniform(self, a, b):
         v = np.random.uniform(a, b)
@@ -107,6 +110,8 @@ class _ReferenceDraws(object):
             self.count = -self.push.get('start_time', 0.) // epmc_capi.TIME_STEP
             self.interval = self.push.get('interval_time', 5.) // epmc_capi.TIME_STEP
             self.duration = self.push.get('duration_time', 0.5) // epmc_capi.TIME_STEP
+        if isinstance(self.max_tau, list):                                     # CTG:285-287: one draw per robot into an attribute the torque
+            np.random.uniform(*self.max_tau); np.random.uniform(*self.max_tau)  # clip never reads; the global stream moves on
         drawn = {}
         for k in self.obs_rand:                                                # CTG:207-210, in the dict's own order ...
             n0 = len(self.u)
@@ -144,11 +149,11 @@ class ChaseTagGame(object):
     """ChaseTagGameEnv: one arena, two robots, reference semantics (no auto-reset)."""
 
     def __init__(self, env_config):
-        self._engine = _build_engine(env_config, 1, auto_reset=0)
+        self._draws = _ReferenceDraws(env_config)                                 # the constructor's draws, in the reference's order
+        self._engine = _build_engine(dict(env_config, max_tau=self._draws.max_tau_value), 1, auto_reset=0)
         obs, act, self._prop = _spaces(env_config['prop_type'])
         self.n_max = 2
         self.observation_space, self.action_space = Tuple([obs] * 2), Tuple([act] * 2)    # CTG:125, :128-135
-        self._draws = _ReferenceDraws(env_config)
 
     def _obs(self):
         o = self._engine.obs()[0].astype(np.float64)

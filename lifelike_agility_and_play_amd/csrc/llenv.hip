@@ -196,6 +196,15 @@ __global__ __launch_bounds__(PMC_WAVE) void pmc_reset_kernel(StepParams P, const
   P.done_reason[env] = 0;
 }
 
+__global__ __launch_bounds__(PMC_WAVE) void pmc_probe_pd_kernel(StepParams P, const float* in, float* out, int n, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int i = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
+  GpuLanes ln(lds);
+  ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
+  if (i >= n) return;
+  K::probe_pd(ln, P, in + (long)i * 36, out + (long)i * 12, mode);
+}
+
 __global__ void pmc_actions_kernel(StepParams P, float* actions, float sigma) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= P.n_envs * 3) return;
@@ -209,6 +218,7 @@ struct HipBackend {
   int simds = 1024;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
   size_t ev_used = 0;
+  static constexpr size_t kMaxTimedLaunches = 16384;   // event pairs kept between two ll_kernel_time_ms() polls
 
   explicit HipBackend(int dev) : device(dev) {
     int n = 0;
@@ -254,6 +264,7 @@ struct HipBackend {
   static size_t lds_bytes_epmc() { return lds_bytes() + (size_t)PMC_ENVS_PER_WAVE * PMC_ROW_SCRATCH * sizeof(float); }
   std::pair<hipEvent_t, hipEvent_t>* timing_begin() {
     if (!timing) return nullptr;
+    if (ev_used == kMaxTimedLaunches) return nullptr;   // un-polled timing does not grow without bound: later launches go untimed
     if (ev_used == evs.size()) {
       hipEvent_t a, b;
       HIPCHK(hipEventCreate(&a));
@@ -307,6 +318,11 @@ struct HipBackend {
     use();
     const int blocks = (n + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     hipLaunchKernelGGL(pmc_reset_kernel, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P, ids, n, clip, t0);
+    HIPCHK(hipGetLastError());
+  }
+  void launch_probe_pd(const StepParams& P, const float* in, float* out, int n, int mode) {
+    use();
+    hipLaunchKernelGGL(pmc_probe_pd_kernel, dim3((n + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE), dim3(PMC_WAVE), lds_bytes(), stream, P, in, out, n, mode);
     HIPCHK(hipGetLastError());
   }
   void launch_actions(const StepParams& P, float* actions, float sigma) {

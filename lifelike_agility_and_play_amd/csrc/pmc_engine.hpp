@@ -146,10 +146,16 @@ struct PmcEngine {
     need(true, false);
     const int N = P.n_envs;
     if (!env_ids) n = N;
-    if (n <= 0 || n > N) throw PmcError(LL_EINVAL, "bad env count in ll_reset");
+    if (n < 0 || n > N) throw PmcError(LL_EINVAL, "bad env count in ll_reset");
+    if (P.set_obstacle && !have_obstacles) throw PmcError(LL_ESTATE, "set_obstacle needs ll_load_obstacles");
+    if (n == 0) return;                                  // `reset(env_ids=where(done))` on a step that finished nobody
     if (env_ids) {
-      for (int i = 0; i < n; i++)
+      std::vector<char> seen(N, 0);                      // two rows for one env would race on its state and episode counter
+      for (int i = 0; i < n; i++) {
         if (env_ids[i] < 0 || env_ids[i] >= N) throw PmcError(LL_EINVAL, "env id out of range");
+        if (seen[env_ids[i]]) throw PmcError(LL_EINVAL, "env id listed twice in ll_reset");
+        seen[env_ids[i]] = 1;
+      }
       bk.h2d(d_reset_ids, env_ids, n * 4);
     }
     if (clip) {
@@ -158,17 +164,15 @@ struct PmcEngine {
       bk.h2d(d_reset_clip, clip, n * 4);
     }
     if (t0) {
+      // A start time is only meaningful inside the clip it belongs to, and the first observation looks frame_rate + 2 rows
+      // ahead of it (ML:75-86): the admissible range is the reference's own sampling range (ML:50-51).
+      if (!clip) throw PmcError(LL_EINVAL, "ll_reset: explicit start times need explicit clip indices");
       for (int i = 0; i < n; i++) {
-        if (clip) {
-          double dur = P.frame_step * (h_clip_len[clip[i]] - 2);
-          if (!(t0[i] >= 0) || t0[i] > dur) throw PmcError(LL_EINVAL, "start time outside the clip");
-        } else if (!(t0[i] >= 0)) {
-          throw PmcError(LL_EINVAL, "negative start time");
-        }
+        const double tmax = P.frame_step * (double)(h_clip_len[clip[i]] - P.margin - 1);
+        if (!(t0[i] >= 0) || t0[i] > tmax) throw PmcError(LL_EINVAL, "start time outside the clip's sampling range (ML:50)");
       }
       bk.h2d(d_reset_t0, t0, n * 8);
     }
-    if (P.set_obstacle && !have_obstacles) throw PmcError(LL_ESTATE, "set_obstacle needs ll_load_obstacles");
     bk.launch_reset(P, env_ids ? d_reset_ids : nullptr, n, clip ? d_reset_clip : nullptr, t0 ? d_reset_t0 : nullptr);
     have_reset = true;
   }
@@ -210,6 +214,19 @@ struct PmcEngine {
     Q.traj_slot = traj_unroll ? (int)(P.step_count % (uint64_t)traj_unroll) : 0;
     bk.launch_step(Q);
     P.step_count += 1;
+  }
+  // parity probe for golden G8 (the torques the reference hands to PyBullet): runs the step kernel's own pd_target / pd_torque
+  void probe_pd_torque(const float* h_rows, int n, int mode, float* h_tau) {
+    if (n <= 0) throw PmcError(LL_EINVAL, "bad row count");
+    float* d_in = (float*)bk.alloc((size_t)n * 36 * 4);
+    float* d_out = (float*)bk.alloc((size_t)n * 12 * 4);
+    try {
+      bk.h2d(d_in, h_rows, (size_t)n * 36 * 4);
+      bk.launch_probe_pd(P, d_in, d_out, n, mode);
+      bk.sync();
+      bk.d2h(h_tau, d_out, (size_t)n * 12 * 4);
+    } catch (...) { bk.release(d_in); bk.release(d_out); throw; }
+    bk.release(d_in); bk.release(d_out);
   }
   // keep the last `unroll` transitions of every env in HBM, in the layout the learner rank gathers
   void enable_trajectory(int unroll) {

@@ -405,6 +405,28 @@ struct Pmc {
     rs = lm::sel(dot(ax, ax) < 0.5f, r, zero);
     Ew = mk3<F>(Pw.x + bs.p.x, Pw.y + bs.p.y, Pw.z + bs.p.z + rs);
   }
+  // LR:137-141: tau = kp (target - q) + kd (0 - qd), clipped to +-max_tau -- the `forces=` the reference hands to
+  // setJointMotorControlArray(TORQUE_CONTROL) before every stepSimulation (golden G8; ll_probe_pd_torque runs exactly this)
+  static LL_HD void pd_torque(const L& ln, const StepParams& P, const F* q, const F* qd, const F* tgt, F* tau) {
+    for (int j = 0; j < 3; j++) {
+      F t = (tgt[j] - q[j]) * P.kp + (ln.lane_f(0.0f) - qd[j]) * P.kd;
+      tau[j] = lm::min_(lm::max_(t, ln.lane_f(-P.max_tau)), ln.lane_f(P.max_tau));
+    }
+  }
+  // the target of a control step: joint angles at its start + the policy's action (PLE:199-200), clipped to +-3 rad (LR:126-127)
+  static LL_HD void pd_target(const L& ln, const F* q, const F* act, F* tgt) {
+    for (int j = 0; j < 3; j++) tgt[j] = lm::min_(lm::max_(q[j] + act[j], ln.lane_f(-3.0f)), ln.lane_f(3.0f));
+  }
+  // parity probe (golden G8): rows of [q 12 | qd 12 | x 12] -> tau 12; x is a target (mode 0: LeggedRobot.apply_action's
+  // argument, clipped here as LR:126-127 does) or an action (mode 1: PLE:199-200 forms the target from it)
+  static LL_HD void probe_pd(const L& ln, const StepParams& P, const float* in, float* out, int mode) {
+    F q[3], qd[3], x[3], tgt[3], tau[3];
+    for (int j = 0; j < 3; j++) { q[j] = ln.ldl(in, j, 3); qd[j] = ln.ldl(in, 12 + j, 3); x[j] = ln.ldl(in, 24 + j, 3); }
+    if (mode == 1) pd_target(ln, q, x, tgt);
+    else for (int j = 0; j < 3; j++) tgt[j] = lm::min_(lm::max_(x[j], ln.lane_f(-3.0f)), ln.lane_f(3.0f));
+    pd_torque(ln, P, q, qd, tgt, tau);
+    for (int j = 0; j < 3; j++) ln.stl(out, j, 3, tau[j]);
+  }
   static LL_HD void substep(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env = 0, int sidx = -1,
                             const SubstepExtra* ex = nullptr) {
     substep_impl<false>(ln, P, bs, q, qd, tgt, env, sidx, ex);
@@ -426,11 +448,8 @@ struct Pmc {
 
     // --- PD torque with clip (LR:126-141) + URDF joint damping --------------------------------------------
     F tau[3];
-    for (int j = 0; j < 3; j++) {
-      F t = (tgt[j] - q[j]) * P.kp + (ln.lane_f(0.0f) - qd[j]) * P.kd;
-      t = lm::min_(lm::max_(t, ln.lane_f(-P.max_tau)), ln.lane_f(P.max_tau));
-      tau[j] = t - ln.legc(legc, LC_JDAMP + j) * qd[j];
-    }
+    pd_torque(ln, P, q, qd, tgt, tau);
+    for (int j = 0; j < 3; j++) tau[j] = tau[j] - ln.legc(legc, LC_JDAMP + j) * qd[j];
 
     // --- leg kinematics, velocities -------------------------------------------------------------------------
     LegKin k = leg_fk(ln, legc, q[0], q[1], q[2]);
@@ -1381,11 +1400,8 @@ struct Pmc {
     PMC_TS(0);
     if (PMC_ABL(8)) return;
     load_state(ln, P.state, N, env, bs, q, qd);
-    for (int j = 0; j < 3; j++) {
-      act[j] = act_in[j];
-      F t = q[j] + act[j];                                                   // PLE:199-200
-      tgt[j] = lm::min_(lm::max_(t, ln.lane_f(-3.0f)), ln.lane_f(3.0f));     // LR:126-127
-    }
+    for (int j = 0; j < 3; j++) act[j] = act_in[j];
+    pd_target(ln, q, act, tgt);                                              // PLE:199-200, LR:126-127
     double t = P.time[env], t_loc = t;
     const int clip = P.clip[env];
     const int clen = P.clip_len[clip];

@@ -52,8 +52,10 @@ def _build_engine(env_config, num_envs, auto_reset):
         warnings.warn('render / video_path are ignored: the batched engine has no GUI (PLE:58-60 is PyBullet-only)')
     if not isinstance(prop_type, list):
         raise TypeError("Expected 'prop_type' to be a list.")                # PLE:113
-    if isinstance(max_tau, (list, tuple)):                                  # LR:244 draws once at construction;
-        max_tau = float(np.random.uniform(*max_tau))                        # the per-episode redraw of PLE:153 is a no-op (quirk Q1)
+    if isinstance(max_tau, tuple):                                          # the reference only understands a list (LR:244): a tuple
+        raise ValueError('operands could not be broadcast together: max_tau must be a scalar or a [lo, hi] list (LR:244-245)')   # reaches np.ones_like(...) * tuple
+    if isinstance(max_tau, list):                                           # LR:244 draws once at construction; the per-episode redraw
+        max_tau = float(np.random.uniform(*max_tau))                        # of PLE:153 never reaches the torque clip (quirk Q1)
     policy_step = 1.0 / control_freq
     table = mocap.load_mocap(data_path, policy_step)
     urdf_path = env_config.get('urdf_path', None)
@@ -84,6 +86,7 @@ class TrackingGame(object):
     """PrimitiveLevelEnv wrapped in SingleAgentWrapper (CPE:6-18), one robot, reference semantics."""
 
     def __init__(self, env_config):
+        self._max_tau_cfg = env_config.get('max_tau', 18.0)                 # PLE:47 keeps the configured value, list or scalar
         self._engine, self._table, self._prop_type = _build_engine(env_config, 1, auto_reset=0)
         obs_space, act_space = _spaces(self._prop_type)
         self.observation_space = Tuple([obs_space])                         # CPE:9
@@ -104,6 +107,8 @@ class TrackingGame(object):
         return _split_obs(row.astype(np.float64), self._prop_size)          # the reference returns float64 arrays
 
     def reset(self, **kwargs):                                              # CPE:12-14 (kwargs accepted and dropped)
+        if isinstance(self._max_tau_cfg, list):                             # PLE:153: the redraw lands in an attribute apply_action never
+            np.random.uniform(*self._max_tau_cfg)                           # reads (quirk Q1), but the global stream moves on -- so does ours
         prob = self._engine.sampling_table()[0]
         n = self._table.n_clips
         clip = int(np.random.choice(range(n), p=prob))                      # ML:60

@@ -96,6 +96,7 @@ class TrajectoryBuffer(object):
 
     def __init__(self, engine, unroll, host_memory=False):
         ptr, w = engine.enable_trajectory(2 * unroll)
+        self.engine = engine
         self.unroll = unroll
         mk = host_tensor if host_memory else device_tensor
         self.buf = mk(ptr, (2 * unroll, engine.n_envs, w))
@@ -116,6 +117,13 @@ class TrajectoryBuffer(object):
         """Start gathering unroll k (the half the last `unroll` steps wrote); the previous gather must have finished."""
         self.wait()
         local = self.half(k)
+        if local.is_cuda:
+            # the collective (and the .cpu() staging of the gloo test path) is ordered against torch's CURRENT stream only: the step
+            # kernels that wrote this half must be on that very stream, or the gather reads rows that are still being written
+            es, ts = int(self.engine.device_ptrs().stream or 0), int(torch.cuda.current_stream().cuda_stream)
+            if es != ts:
+                raise RuntimeError('TrajectoryBuffer.gather_async: the engine launches on stream %#x but torch\'s current stream is %#x; '
+                                   'call gather.bind_torch_stream(engine) first' % (es, ts))
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         if local.is_cuda and dist.get_backend(group) == 'gloo':      # test configuration only: gloo gathers host tensors
             local = local.cpu()

@@ -70,6 +70,8 @@ class _ReferenceDraws(object):
         self.n_sub = int((1.0 / env_config.get('control_freq', 50.0)) / epmc_capi.TIME_STEP)
         self.u = []
         np.random.uniform(*self.rc['friction_range'])                          # PGE:92: the constructor's own friction draw
+        self.max_tau = env_config.get('max_tau', 16.0)
+        self.max_tau_value = float(np.random.uniform(*self.max_tau)) if isinstance(self.max_tau, list) else self.max_tau   # LR:244, right after it
 
     def _uniform(self, a, b):
         v = np.random.uniform(a, b)
@@ -116,6 +118,8 @@ class _ReferenceDraws(object):
                         self._uniform(-3.0, 3.0)
         cr = self.rc.get('cmd_vary_freq_range', [25, 200])
         self.cmd_freq = self._randint(*cr)                                     # PGE:223
+        if isinstance(self.max_tau, list):                                     # PGE:236: lands in an attribute the torque clip never reads,
+            np.random.uniform(*self.max_tau)                                   # but the global stream moves on
         drawn = {}
         for k in self.obs_rand:                                                # PGE:176-179, in the dict's own order ...
             n0 = len(self.u)
@@ -148,11 +152,11 @@ class PlaygroundGame(object):
     """PlayGroundEnv behind SingleAgentWrapper, one robot, reference semantics (no auto-reset)."""
 
     def __init__(self, env_config):
-        self._engine = _build_engine(env_config, 1, auto_reset=0)
+        self._draws = _ReferenceDraws(env_config)                                 # the constructor's draws, in the reference's order
+        self._engine = _build_engine(dict(env_config, max_tau=self._draws.max_tau_value), 1, auto_reset=0)
         obs, act, self._prop = _spaces(env_config['prop_type'])
         self.observation_space, self.action_space = Tuple([obs]), Tuple([act])    # CPE:9-10
         self.env = self
-        self._draws = _ReferenceDraws(env_config)
 
     def _obs(self):
         return _split(self._engine.obs()[0].astype(np.float64), self._prop)

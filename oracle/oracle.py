@@ -46,9 +46,32 @@ def make_config(n_envs=1, control_freq=50.0, sim_freq=500.0, kp=50.0, kd=0.5, ma
     return cfg
 
 
+def _cpu_key():
+    """What -march=native means on this host: the library is rebuilt when the snapshot lands on a different CPU (the GPU box)."""
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('flags'):
+                    import hashlib
+                    return hashlib.sha1(line.encode()).hexdigest()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def build(force=False):
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, 'pmc_oracle.c')):
-        subprocess.check_call(['make', '-C', HERE, '-s'] + (['-B'] if force else []))
+    """make (-O3 -march=native, OpenMP); serialised by a file lock so that concurrent test processes do not race on the .so."""
+    import fcntl
+    os.makedirs(os.path.join(HERE, '_build'), exist_ok=True)
+    stamp = os.path.join(HERE, '_build', '.cpu')
+    with open(os.path.join(HERE, '_build', '.lock'), 'w') as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        key = _cpu_key()
+        old = open(stamp).read() if os.path.exists(stamp) else ''
+        subprocess.check_call(['make', '-C', HERE, '-s'] + (['-B'] if (force or old != key) else []))
+        if old != key:
+            with open(stamp, 'w') as f:
+                f.write(key)
     return LIB
 
 
@@ -77,6 +100,13 @@ def f64(a):
 
 
 # ---- stateless pieces -------------------------------------------------------------------------
+def pd_torque(kp, kd, max_tau, q, qd, tgt_joint_pos):
+    """LR:119-148 (orc_pd_torque): the torques apply_action hands to PyBullet, for one robot."""
+    out = np.zeros(12)
+    lib().orc_pd_torque(C.c_double(kp), C.c_double(kd), C.c_double(max_tau), _p(f64(q)), _p(f64(qd)), _p(f64(tgt_joint_pos)), _p(out))
+    return out
+
+
 def mocap_locate(t, frame_step):
     fid, frac = C.c_int32(), C.c_double()
     lib().orc_mocap_locate(C.c_double(t), C.c_double(frame_step), C.byref(fid), C.byref(frac))

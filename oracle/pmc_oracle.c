@@ -1381,6 +1381,20 @@ int orc_reset_env(OBatch* B, int env, int clip, double t0, double* obs_out) {
 /* upper bound of the start-time window of a clip, ML:50 */
 double orc_motion_duration(const OBatch* B, int clip) { return B->frame_step * (B->clip_len[clip] - B->margin - 1); }
 
+/* LeggedRobot.apply_action, LR:119-148 (noise=None): the `forces=` handed to setJointMotorControlArray(TORQUE_CONTROL).
+ * Pinned by golden G8 (tests/golden/pmc_config_golden.npz) at 1e-12. */
+void orc_pd_torque(double kp, double kd, double max_tau, const double* q, const double* qd, const double* tgt_joint_pos, double* tau) {
+  for (int i = 0; i < 12; i++) {
+    double tgt = tgt_joint_pos[i];
+    if (tgt > 3.0) tgt = 3.0;                                             /* LR:126-127 np.clip(+-3) */
+    if (tgt < -3.0) tgt = -3.0;
+    double t = kp * (tgt - q[i]) + kd * (0.0 - qd[i]);                    /* LR:139 (tgt_joint_vel = 0, LR:128) */
+    if (t > max_tau) t = max_tau;                                         /* LR:140 clip_value */
+    if (t < -max_tau) t = -max_tau;
+    tau[i] = t;
+  }
+}
+
 /*
  * PLE:195-245 for one env.  scripted_dyn / feet_* (nullable) replace the physics result / FK, which is
  * how the golden harness (fake BulletClient) drove the reference.
@@ -1390,19 +1404,10 @@ int orc_step_env(OBatch* B, int env, const double* action, const double* scripte
   OEnv* e = &B->envs[env];
   e->ep_steps += 1;                                                       /* PLE:197 */
   double tgt[12], tau[12];
-  for (int i = 0; i < 12; i++) {
-    tgt[i] = e->state[13 + i] + action[i];                                /* PLE:199-200 */
-    if (tgt[i] > 3.0) tgt[i] = 3.0;                                       /* LR:126-127 */
-    if (tgt[i] < -3.0) tgt[i] = -3.0;
-  }
+  for (int i = 0; i < 12; i++) tgt[i] = e->state[13 + i] + action[i];     /* PLE:199-200 (clipped inside apply_action, LR:126-127) */
   int bad = 0;
   for (int s = 0; s < B->n_sub; s++) {                                    /* PLE:202 */
-    for (int i = 0; i < 12; i++) {                                        /* LR:137-141 */
-      double t = B->cfg.kp * (tgt[i] - e->state[13 + i]) + B->cfg.kd * (0.0 - e->state[25 + i]);
-      if (t > B->cfg.max_tau) t = B->cfg.max_tau;
-      if (t < -B->cfg.max_tau) t = -B->cfg.max_tau;
-      tau[i] = t;
-    }
+    orc_pd_torque(B->cfg.kp, B->cfg.kd, B->cfg.max_tau, e->state + 13, e->state + 25, tgt, tau);   /* LR:137-141 */
     if (!scripted_dyn)
       if (orc_substep_model(&B->model, B->dt, B->cfg.solver_iterations, B->mu_foot, e->state, tau, NULL)) bad = 1;   /* PLE:206 */
     orc_mocap_locate(e->time, B->frame_step, &e->frame_id, &e->frac);      /* PLE:208 (time BEFORE the increment, quirk Q2) */

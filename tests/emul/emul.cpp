@@ -49,6 +49,10 @@ struct HostBackend {
       P.done_reason[env] = 0;
     }
   }
+  void launch_probe_pd(const StepParams& P, const float* in, float* out, int n, int mode) {
+    HostLanes ln(P.candc);
+    for (int i = 0; i < n; i++) K::probe_pd(ln, P, in + (long)i * 36, out + (long)i * 12, mode);
+  }
   void launch_actions(const StepParams& P, float* actions, float sigma) {
     for (int gid = 0; gid < P.n_envs * 3; gid++) {
       uint32_t r[4];

@@ -428,3 +428,84 @@ def check_self_collision_parity(golden, orc, model_blob, table, lib_path, n_envs
     assert np.median(cfg_err) < 1e-4 and cfg_err.max() < 5e-3, cfg_err
     assert np.median(vel_err) < 1e-3 and vel_err.max() < 5e-2, vel_err
     return dict(config=cfg_err, vel=vel_err, stopped=stopped)
+
+
+def check_nonfinite_guard(model_blob, table, lib_path):
+    """A NaN / Inf that reaches an env's state ("NaN guard + counter") ends that episode with LL_DONE_NONFINITE, counts once
+    per env, zeroes its reward, re-seeds it -- and leaves every other env, including the three that share its wavefront, bit-for-bit
+    what they are in a twin engine that was never poisoned."""
+    n = 8                                                   # two wavefronts of four envs
+    A = make_engine(model_blob, table, n, lib_path, auto_reset=1, seed=9)
+    B = make_engine(model_blob, table, n, lib_path, auto_reset=1, seed=9)
+    A.reset(); B.reset()
+    rng = np.random.default_rng(1)
+    for t in range(3):
+        a = (rng.normal(size=(n, 12)) * SIGMA).astype(np.float32)
+        A.step_host(a); B.step_host(a)
+    assert np.array_equal(A.state(), B.state()) and A.counters()['nonfinite'] == 0
+    s = A.state()
+    s[2, 13 + 4] = np.nan                                   # a joint angle of env 2 (wave 0)
+    s[5, 7] = np.inf                                        # a base velocity of env 5 (wave 1)
+    A.set_state(s)
+    a = (rng.normal(size=(n, 12)) * SIGMA).astype(np.float32)
+    ep0 = A.counters()['episodes']
+    A.step_host(a); B.step_host(a)
+    r, d, why = A.reward_done()
+    rb, db, whyb = B.reward_done()
+    bad, good = np.array([2, 5]), np.array([0, 1, 3, 4, 6, 7])
+    assert d[bad].all() and ((why[bad] & capi.LL_DONE_NONFINITE) != 0).all() and (r[bad] == 0.0).all()
+    c = A.counters()
+    assert c['nonfinite'] == 2 and c['episodes'] - ep0 == 2 + int(db[good].sum())
+    sa, oa = A.state(), A.obs()
+    assert np.isfinite(sa).all() and np.isfinite(oa).all() and np.isfinite(A.ref_state()).all()      # re-seeded from the clip table
+    info = A.episode_info()
+    assert (info['steps'][bad] == 0).all() and (info['reward_sum'][bad] == 0.0).all()
+    np.testing.assert_array_equal(sa[bad], A.ref_state()[bad])                                        # PLE:162-163
+    assert np.array_equal(sa[good], B.state()[good]) and np.array_equal(oa[good], B.obs()[good])      # neighbours untouched
+    assert np.array_equal(r[good], rb[good]) and np.array_equal(why[good], whyb[good])
+    # the run goes on as if nothing had happened
+    for t in range(3):
+        A.step_random(SIGMA)
+    assert np.isfinite(A.state()).all() and A.counters()['nonfinite'] == 2
+    A.close(); B.close()
+    # without auto-reset the env is flagged and stays the caller's to reset; the poison does not spread
+    E = make_engine(model_blob, table, 4, lib_path, auto_reset=0, seed=2)
+    E.reset()
+    s = E.state(); s[1, 0] = np.nan; E.set_state(s)
+    E.step_host(np.zeros((4, 12), np.float32))
+    r, d, why = E.reward_done()
+    assert d[1] and (why[1] & capi.LL_DONE_NONFINITE) and r[1] == 0.0 and E.counters()['nonfinite'] == 1
+    assert np.isfinite(E.state()[[0, 2, 3]]).all() and np.isfinite(r).all()
+    E.reset(env_ids=[1])
+    E.step_host(np.zeros((4, 12), np.float32))
+    assert np.isfinite(E.state()).all() and E.counters()['nonfinite'] == 1
+    E.close()
+
+
+def check_reset_argument_handling(model_blob, table, lib_path):
+    """ll_reset's argument contract: an empty id list is a no-op, repeated ids and start times outside the reference's sampling range
+    (ML:50-51) are rejected, start times need their clip."""
+    E = make_engine(model_blob, table, 6, lib_path, auto_reset=0, seed=4)
+    E.reset()
+    before = (E.obs(), E.state(), E.episode_info())
+    E.reset(env_ids=np.zeros(0, np.int32))                                   # `reset(env_ids=np.where(done)[0])` when nobody finished
+    assert np.array_equal(E.obs(), before[0]) and np.array_equal(E.state(), before[1])
+    for bad in (dict(env_ids=[1, 1]), dict(env_ids=[0, 3, 0]), dict(env_ids=[6]), dict(env_ids=[-1])):
+        try:
+            E.reset(**bad)
+            raise AssertionError('accepted %r' % (bad,))
+        except capi.LLError as e:
+            assert e.code == capi.LL_EINVAL
+    c = 7
+    tmax = table.frame_step * (int(table.clip_len[c]) - table.margin - 1)     # ML:50
+    E.reset(env_ids=[2], clip=[c], t0=[tmax])                                 # the last admissible start: futures stay inside the clip
+    assert np.isfinite(E.obs()[2]).all()
+    for bad in (dict(env_ids=[2], clip=[c], t0=[tmax + 1e-6]), dict(env_ids=[2], clip=[c], t0=[-1e-9]), dict(env_ids=[2], clip=[c], t0=[float('nan')]),
+                dict(env_ids=[2], t0=[0.5]), dict(env_ids=[2], clip=[table.n_clips], t0=[0.0])):
+        try:
+            E.reset(**bad)
+            raise AssertionError('accepted %r' % (bad,))
+        except capi.LLError as e:
+            assert e.code == capi.LL_EINVAL
+    assert np.array_equal(E.state()[[0, 1, 3, 4, 5]], before[1][[0, 1, 3, 4, 5]])
+    E.close()

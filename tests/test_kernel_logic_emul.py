@@ -63,3 +63,11 @@ def test_auto_reset_equals_manual_reset(model_blob, mocap_table, emul_lib):
 def test_self_collision_parity(golden, orc, model_blob, mocap_table, emul_lib):
     out = pc.check_self_collision_parity(golden, orc, model_blob, mocap_table, emul_lib)
     assert out['stopped'] >= 8
+
+
+def test_nonfinite_guard(model_blob, mocap_table, emul_lib):
+    pc.check_nonfinite_guard(model_blob, mocap_table, emul_lib)
+
+
+def test_reset_argument_handling(model_blob, mocap_table, emul_lib):
+    pc.check_reset_argument_handling(model_blob, mocap_table, emul_lib)
