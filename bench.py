@@ -36,16 +36,39 @@ PMC_REWARD_WEIGHTS = {'joint_pos': 0.3, 'joint_vel': 0.05, 'end_effector': 0.1, 
 PMC_PROP_TYPE = ['joint_pos', 'joint_vel', 'root_ang_vel_loc', 'root_lin_vel_loc', 'e_g']
 
 
+def effective_cores():
+    """Host threads this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container can see 256
+    hardware threads and be allowed 8 cores' worth of time: 256 OpenMP threads then only take turns)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()[:2]                      # cgroup v2
+        if q != 'max':
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())              # cgroup v1
+            p = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    eff = n if quota is None else max(1, min(n, int(math.ceil(quota))))
+    return eff, n, quota
+
+
 def cpu_baseline(blob, table, budget_s=8.0):
-    """The oracle (a port, not the product) on a bounded sample of the same workload, random policy: first on one core,
-    then on every core of this host (OpenMP over the independent envs).  The all-cores figure is the reported value."""
+    """The oracle (a port, not the product; -O3 -march=native, OpenMP over envs) on bounded samples of the same workload, random policy:
+    BASELINE config 1 as SURVEY 8d specifies it (ONE env, the walk clip alone, one thread), then config 2's mix (all clips) on one core
+    and on every core this process may use.  The all-cores figure is the reported value."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from oracle import oracle as orc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    from lifelike_agility_and_play_amd import mocap
+    cores, visible, quota = effective_cores()
 
-    def run(n, threads, budget):
+    def run(n, threads, budget, tab):
         cfg = orc.make_config(n_envs=n, reward_weights=PMC_REWARD_WEIGHTS, prop_type=PMC_PROP_TYPE, prioritized_sample_factor=3.0)
-        B = orc.OracleBatch(cfg, blob, table)
+        B = orc.OracleBatch(cfg, blob, tab)
         rng = np.random.default_rng(0)
 
         def reseed(i):
@@ -53,19 +76,28 @@ def cpu_baseline(blob, table, budget_s=8.0):
             B.reset_env(i, c, float(rng.uniform(0, 1) * B.motion_duration(c)))
         for i in range(n):
             reseed(i)
-        steps, t0 = 0, time.time()
-        while time.time() - t0 < budget:
+        steps, eps, spent = 0, 0, 0.0                          # only the oracle's own time is counted (the Python glue between steps is not)
+        while spent < budget:
             a = rng.normal(size=(n, 12)) * SIGMA
+            t0 = time.perf_counter()
             _, _, d = B.step_all_mt(a, threads) if threads > 1 else B.step_all(a)
+            spent += time.perf_counter() - t0
             steps += n
             for i in np.where(d)[0]:
-                reseed(int(i))
-        return steps, time.time() - t0
-    s1, t1 = run(64, 1, budget_s)
-    sn, tn = run(max(64, 8 * cores), cores, budget_s) if cores > 1 else (s1, t1)
+                reseed(int(i)); eps += 1
+        return steps, spent, eps
+    walk = mocap.load_mocap('dog_quad_walkrun_001_ret.txt', 1.0 / 50.0)
+    s0, t0, e0 = run(1, 1, budget_s / 2, walk)                  # config 1
+    s1, t1, _ = run(64, 1, budget_s, table)
+    sn, tn, _ = run(max(64, 16 * cores), cores, budget_s, table) if cores > 1 else (s1, t1, 0)
     return {'value': sn / tn, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port', 'one_core_value': s1 / t1,
+            'config1': {'value': s0 / t0, 'unit': 'env-steps/s', 'cores': 1,
+                        'sample': '%d env-steps (%d episodes) of ONE env on dog_quad_walkrun_001_ret.txt alone, one thread, %.1f s' % (s0, e0, t0)},
+            'host': {'threads_visible': visible, 'cgroup_cpu_quota': quota, 'threads_used': cores},
+            'reference_cap': 'the reference env itself sleeps to real time: 50 env-steps/s per env (PLE:241-244)',
             'sample': '%d env-steps on %d threads (%d envs) + %d env-steps on 1 thread (64 envs), all clips, random policy, %.0f s + %.0f s '
-                      'of the float64 oracle (oracle/pmc_oracle.c, OpenMP over envs)' % (sn, cores, max(64, 8 * cores), s1, tn, t1)}
+                      'of the float64 oracle (oracle/pmc_oracle.c, -O3 -march=native, OpenMP over envs; Python glue between steps not timed)'
+                      % (sn, cores, max(64, 16 * cores), s1, tn, t1)}
 
 
 def main():

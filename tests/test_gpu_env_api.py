@@ -117,3 +117,25 @@ def test_fused_mfma_policy_kernel(model_blob, mocap_table):
             rsum += float(T['reward'].mean())
         assert rsum / 120 > 0.8, rsum / 120
         pol.close(); E.close()
+
+
+def test_config1_single_walk_clip_through_the_hip_library(golden):
+    """BASELINE config 1 as SURVEY 8d specifies it -- ONE robot, data_path = dog_quad_walkrun_001_ret.txt alone, env_config of
+    test_primitive_level_env.py:25-38 -- through the product library: the seeded reset reproduces the reference's (K4: t0 and the
+    first observation), and a whole episode runs to the end of the clip's tracking envelope."""
+    env = lla.create_tracking_game(**pmc_config(data_path='dog_quad_walkrun_001_ret.txt'))
+    assert env.env._table.n_clips == 1 and int(env.env._table.clip_len[0]) == 1147
+    np.random.seed(123)
+    (o,) = env.reset()
+    assert env.env.sampled_data_idx == 0 and abs(env.env.time - float(golden['k4_t0'])) < 1e-12
+    np.testing.assert_allclose(np.concatenate([o['prop'], o['prop_a'], o['future']]), golden['k4_obs'], rtol=1e-5, atol=1e-5)
+    rng = np.random.default_rng(0)
+    n, rs = 0, 0.0
+    for t in range(600):
+        (o,), (r,), d, info = env.step([rng.normal(size=12) * float(np.exp(-2.0))])
+        assert np.isfinite(r) and 0.0 <= r <= 1.0 + 1e-6 and all(np.isfinite(v).all() for v in o.values())
+        n += 1; rs += r
+        if d:
+            break
+    assert d and n >= 2                                                     # random actions: falls, diverges or reaches the clip end
+    env.close()
