@@ -209,22 +209,26 @@ struct GpuLanes {
   static LL_D void fmac_rbcast_settled(F& acc, F x, F k);
   // returns x after two wait states, so that following DPP reads of the result are hazard free
   static LL_D F settle(F x) { asm volatile("s_nop 1" : "+v"(x)); return x; }
-  // g[L] = sum_i x[i] * rbcast<L>(x[i]) for L = 0..15: ONE block of 96 v_fmac_f32 with a DPP source.  The six inputs are not
-  // written inside the block, so after the leading wait states no DPP read-after-write hazard can occur.
-  static LL_D void gram16(const F* x, F* g) {
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f, g5 = 0.f, g6 = 0.f, g7 = 0.f, g8 = 0.f, g9 = 0.f, g10 = 0.f, g11 = 0.f, g12 = 0.f,
-          g13 = 0.f, g14 = 0.f, g15 = 0.f;
-#define LL_G1(O, L_, X) "v_fmac_f32_dpp " O ", " X ", " X " row_newbcast:" #L_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-#define LL_G6(O, L_) LL_G1(O, L_, "%16") LL_G1(O, L_, "%17") LL_G1(O, L_, "%18") LL_G1(O, L_, "%19") LL_G1(O, L_, "%20") LL_G1(O, L_, "%21")
-    asm("s_nop 1\n\t" LL_G6("%0", 0) LL_G6("%1", 1) LL_G6("%2", 2) LL_G6("%3", 3) LL_G6("%4", 4) LL_G6("%5", 5) LL_G6("%6", 6) LL_G6("%7", 7)
-        LL_G6("%8", 8) LL_G6("%9", 9) LL_G6("%10", 10) LL_G6("%11", 11) LL_G6("%12", 12) LL_G6("%13", 13) LL_G6("%14", 14) LL_G6("%15", 15)
-        : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4), "+v"(g5), "+v"(g6), "+v"(g7), "+v"(g8), "+v"(g9), "+v"(g10), "+v"(g11), "+v"(g12),
-          "+v"(g13), "+v"(g14), "+v"(g15)
-        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]));
+  // g[4t + S_] += sum_i y[i] * (x[i] of lane 4t + S_), t = 0..3: the Gram scalars of a row against the four rows of turn block S_,
+  // 24 v_fmac_f32 with a DPP row-broadcast source.  x and y are not written inside the block, so after the leading wait states no
+  // DPP read-after-write hazard can occur.
+  template <int S_>
+  static LL_D void gram4(const F* x, const F* y, F* g) {
+    float g0 = g[S_], g1 = g[4 + S_], g2 = g[8 + S_], g3 = g[12 + S_];
+#define LL_G1(O, L_, X, Y) "v_fmac_f32_dpp " O ", " X ", " Y " row_newbcast:" L_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define LL_G6(O, L_) LL_G1(O, L_, "%4", "%10") LL_G1(O, L_, "%5", "%11") LL_G1(O, L_, "%6", "%12") LL_G1(O, L_, "%7", "%13") LL_G1(O, L_, "%8", "%14") LL_G1(O, L_, "%9", "%15")
+#define LL_G24(A_, B_, C_, D_)                                                                                                             \
+    asm("s_nop 1\n\t" LL_G6("%0", A_) LL_G6("%1", B_) LL_G6("%2", C_) LL_G6("%3", D_)                                                   \
+        : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3)                                                                                       \
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]))
+    if (S_ == 0) LL_G24("0", "4", "8", "12");
+    else if (S_ == 1) LL_G24("1", "5", "9", "13");
+    else if (S_ == 2) LL_G24("2", "6", "10", "14");
+    else LL_G24("3", "7", "11", "15");
+#undef LL_G24
 #undef LL_G6
 #undef LL_G1
-    g[0] = g0; g[1] = g1; g[2] = g2; g[3] = g3; g[4] = g4; g[5] = g5; g[6] = g6; g[7] = g7;
-    g[8] = g8; g[9] = g9; g[10] = g10; g[11] = g11; g[12] = g12; g[13] = g13; g[14] = g14; g[15] = g15;
+    g[S_] = g0; g[4 + S_] = g1; g[8 + S_] = g2; g[12 + S_] = g3;
   }
   // Four Gauss-Seidel turns (lanes S, 4+S, 8+S, 12+S) as one block: v_med3 (clamp the pending increment), v_cndmask (the lane
   // whose turn it is keeps its increment; masks m0..m3 are the lane masks of the four turns), one wait state, v_fmac with a
@@ -244,6 +248,101 @@ struct GpuLanes {
     else              asm(LL_T1("%5", "%9", "3") LL_T1("%6", "%10", "7") LL_T1("%7", "%11", "11") LL_T1("%8", "%12", "15") : "+v"(u), "+v"(dl), "=&v"(d) : "v"(lo), "v"(hi), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
 #undef LL_T1
   }
+  // Eight Gauss-Seidel turns as ONE block (H_ = 0: lanes 0,4,8,12, 1,5,9,13;  H_ = 1: lanes 2,6,10,14, 3,7,11,15): between two
+  // separate asm statements the compiler puts a wait state of its own.
+  template <int H_>
+  LL_D void turns8(F& u, F& dl, F lo, F hi, const F* nk) const {
+    constexpr int A = 2 * H_, B = 2 * H_ + 1;
+    const unsigned long long m0 = tm_[A], m1 = tm_[4 + A], m2 = tm_[8 + A], m3 = tm_[12 + A], m4 = tm_[B], m5 = tm_[4 + B], m6 = tm_[8 + B], m7 = tm_[12 + B];
+    float d;
+#define LL_T1(K, M, L_)                                                                          \
+    "v_med3_f32 %2, %0, %3, %4\n\t"                                                            \
+    "v_cndmask_b32_e64 %1, %1, %2, " M "\n\t"                                                  \
+    "s_nop 0\n\t"                                                                              \
+    "v_fmac_f32_dpp %0, %2, " K " row_newbcast:" L_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    if (H_ == 0)
+      asm(LL_T1("%5", "%13", "0") LL_T1("%6", "%14", "4") LL_T1("%7", "%15", "8") LL_T1("%8", "%16", "12")
+          LL_T1("%9", "%17", "1") LL_T1("%10", "%18", "5") LL_T1("%11", "%19", "9") LL_T1("%12", "%20", "13")
+          : "+v"(u), "+v"(dl), "=&v"(d)
+          : "v"(lo), "v"(hi), "v"(nk[0]), "v"(nk[4]), "v"(nk[8]), "v"(nk[12]), "v"(nk[1]), "v"(nk[5]), "v"(nk[9]), "v"(nk[13]),
+            "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4), "s"(m5), "s"(m6), "s"(m7));
+    else
+      asm(LL_T1("%5", "%13", "2") LL_T1("%6", "%14", "6") LL_T1("%7", "%15", "10") LL_T1("%8", "%16", "14")
+          LL_T1("%9", "%17", "3") LL_T1("%10", "%18", "7") LL_T1("%11", "%19", "11") LL_T1("%12", "%20", "15")
+          : "+v"(u), "+v"(dl), "=&v"(d)
+          : "v"(lo), "v"(hi), "v"(nk[2]), "v"(nk[6]), "v"(nk[10]), "v"(nk[14]), "v"(nk[3]), "v"(nk[7]), "v"(nk[11]), "v"(nk[15]),
+            "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4), "s"(m5), "s"(m6), "s"(m7));
+#undef LL_T1
+  }
+
+  // ---- the solver's velocity state, scattered over the sub-lanes (pmc_step.hpp gs_round) ------------------------------------------
+  // Per env the projected Gauss-Seidel sweep carries the whitened base twist dx[6] and, per leg, the whitened joint rates dq[3].
+  // They live in THREE registers:   VA: lane (leg, s) holds dx[s]      VB: dx[4 + (s & 1)]      VJ: dq_leg[s] (s = 3: zero)
+  // and a row keeps its nine coefficients pre-permuted for its own lane (row_permute in pmc_step.hpp):
+  //   ca[k] = gt[s ^ k],   cb[k] = gt[4 + ((s ^ k) & 1)],   cj[k] = jt[s ^ k] (index 3: zero)          k = 0..3 / 0..1 / 0..3
+  // vel_dot:    c + gt . dx + jt . dq = c + sum_k ca[k] * VA[s ^ k] + ...: ten multiply-adds, seven of them with a quad_perm source;
+  //             the three plain ones come first, so a register written just before the call has settled when DPP reads it.
+  LL_D static F vel_dot(F c, const F* ca, const F* cb, const F* cj, F VA, F VB, F VJ) {
+    float w;
+#define LL_Q(X) " quad_perm:" X " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm("v_fma_f32 %0, %1, %11, %14\n\t"
+        "v_fmac_f32_e32 %0, %5, %12\n\t"
+        "v_fmac_f32_e32 %0, %7, %13\n\t"
+        "v_fmac_f32_dpp %0, %11, %2" LL_Q("[1,0,3,2]")
+        "v_fmac_f32_dpp %0, %11, %3" LL_Q("[2,3,0,1]")
+        "v_fmac_f32_dpp %0, %11, %4" LL_Q("[3,2,1,0]")
+        "v_fmac_f32_dpp %0, %12, %6" LL_Q("[1,0,3,2]")
+        "v_fmac_f32_dpp %0, %13, %8" LL_Q("[1,0,3,2]")
+        "v_fmac_f32_dpp %0, %13, %9" LL_Q("[2,3,0,1]")
+        "v_fmac_f32_dpp %0, %13, %10" LL_Q("[3,2,1,0]")
+        : "=&v"(w)
+        : "v"(ca[0]), "v"(ca[1]), "v"(ca[2]), "v"(ca[3]), "v"(cb[0]), "v"(cb[1]), "v"(cj[0]), "v"(cj[1]), "v"(cj[2]), "v"(cj[3]), "v"(VA), "v"(VB),
+          "v"(VJ), "v"(c));
+    return w;
+  }
+  // vel_commit: every lane has committed the multiplier increment dl of its row;  dx += sum over the 16 lanes of gt * dl,
+  // dq += sum over the leg's 4 lanes of jt * dl.  A transpose-reduce: because lane s multiplies dl with the coefficient of value
+  // s ^ k, "own product + partner's product" lands value s in lane s after two quad exchanges -- 4 multiplies and 3 adds reduce four
+  // values over a quad (an all-reduce takes 4 and 8), and the result is already laid out as VA / VB / VJ.  25 instructions; every
+  // DPP read is at least three instructions behind its producer, so the block has no wait states.
+  LL_D static void vel_commit(F dl, const F* ca, const F* cb, const F* cj, F& VA, F& VB, F& VJ) {
+    float p0, p1, p2, p3, q0, q1, j0, j1, j2, j3;
+#define LL_R(X) " " X " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm("v_mul_f32_e32 %3, %13, %23\n\t"
+        "v_mul_f32_e32 %4, %14, %23\n\t"
+        "v_mul_f32_e32 %5, %15, %23\n\t"
+        "v_mul_f32_e32 %6, %16, %23\n\t"
+        "v_mul_f32_e32 %7, %17, %23\n\t"
+        "v_mul_f32_e32 %8, %18, %23\n\t"
+        "v_mul_f32_e32 %9, %19, %23\n\t"
+        "v_mul_f32_e32 %10, %20, %23\n\t"
+        "v_mul_f32_e32 %11, %21, %23\n\t"
+        "v_mul_f32_e32 %12, %22, %23\n\t"
+        "v_add_f32_dpp %3, %4, %3" LL_R("quad_perm:[1,0,3,2]")
+        "v_add_f32_dpp %5, %6, %5" LL_R("quad_perm:[1,0,3,2]")
+        "v_add_f32_dpp %7, %8, %7" LL_R("quad_perm:[1,0,3,2]")
+        "v_add_f32_dpp %9, %10, %9" LL_R("quad_perm:[1,0,3,2]")
+        "v_add_f32_dpp %11, %12, %11" LL_R("quad_perm:[1,0,3,2]")
+        "v_add_f32_dpp %3, %5, %3" LL_R("quad_perm:[2,3,0,1]")
+        "v_add_f32_dpp %7, %7, %7" LL_R("quad_perm:[2,3,0,1]")
+        "v_add_f32_dpp %9, %11, %9" LL_R("quad_perm:[2,3,0,1]")
+        "v_add_f32_dpp %3, %3, %3" LL_R("row_ror:4")
+        "v_add_f32_dpp %7, %7, %7" LL_R("row_ror:4")
+        "v_add_f32_e32 %2, %2, %9\n\t"
+        "v_add_f32_dpp %3, %3, %3" LL_R("row_ror:8")
+        "v_add_f32_dpp %7, %7, %7" LL_R("row_ror:8")
+        "v_add_f32_e32 %0, %0, %3\n\t"
+        "v_add_f32_e32 %1, %1, %7"
+        : "+v"(VA), "+v"(VB), "+v"(VJ), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(q0), "=&v"(q1), "=&v"(j0), "=&v"(j1), "=&v"(j2), "=&v"(j3)
+        : "v"(ca[0]), "v"(ca[1]), "v"(ca[2]), "v"(ca[3]), "v"(cb[0]), "v"(cb[1]), "v"(cj[0]), "v"(cj[1]), "v"(cj[2]), "v"(cj[3]), "v"(dl));
+#undef LL_R
+#undef LL_Q
+  }
+  // what the scattered registers hold, for the code after the sweep: dx[i] (env-uniform), dq[j] (leg-uniform)
+  template <int I_>
+  static LL_D float vel_dx(F VA, F VB) { return I_ < 4 ? LL_DPP_MOV(VA, 0x150 + (I_ & 3)) : LL_DPP_MOV(VB, 0x150 + (I_ & 1)); }
+  template <int J_>
+  static LL_D F vel_dq(F VJ) { return LL_DPP_MOV(VJ, J_ | (J_ << 2) | (J_ << 4) | (J_ << 6)); }
   // the sixteen turn masks (lane t of every row), made opaque so they stay resident in SGPR pairs across the solver loop
   // instead of being rebuilt from a 32-bit half before every turn
   LL_D void prepare_turn_masks() const {

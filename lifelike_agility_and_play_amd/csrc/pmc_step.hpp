@@ -228,21 +228,41 @@ struct Pmc {
   // held in registers in whitened coordinates together with the Gram scalars against the 16 rows of the same round
   // ---------------------------------------------------------------------------------------------------
   struct Row {
-    F gt[6], jt[3], c, inv, lam;
-    F nk[16];      // -(gt . gt_L + [same leg] jt . jt_L) * inv   for L = lane of the env row
+    F ca[4], cb[2], cj[4];   // the row's nine coefficients gt[6], jt[3], permuted for its lane (lanes.hpp "scattered velocity state")
+    F c, inv, lam;
+    F nk[16];                // -(gt . gt_L + [same leg] jt . jt_L) * inv   for L = lane of the env row
   };
-  static LL_HD void finish_row(const L& ln, Row& r) {
+  // x[s ^ k] for k = 0..3 in the lane of sub-lane s (x[3] may be a constant zero): two conditional swaps instead of four 4-way selects
+  static LL_HD void permute4(const L& ln, const F& x0, const F& x1, const F& x2, const F& x3, F* c) {
+    B odd = lm::odd_(ln.sub()), hi = lm::bit1_(ln.sub());
+    F a01 = lm::sel(odd, x1, x0), a10 = lm::sel(odd, x0, x1), a23 = lm::sel(odd, x3, x2), a32 = lm::sel(odd, x2, x3);
+    c[0] = lm::sel(hi, a23, a01); c[1] = lm::sel(hi, a32, a10); c[2] = lm::sel(hi, a01, a23); c[3] = lm::sel(hi, a10, a32);
+  }
+  // Gram scalars of the row against the 16 rows of its round, and the lane-permuted coefficients.  LIMIT: sub-lane 3 holds no row,
+  // so the four turns of lanes 3, 7, 11, 15 do not exist and their scalars are not formed.
+  template <bool LIMIT>
+  static LL_HD void finish_row(const L& ln, Row& r, const F* gt, const F* jt) {
+    F zero = ln.lane_f(0.0f);
+    F ninv = zero - r.inv;
+    F yg[6], yj[3];
+    for (int i = 0; i < 6; i++) yg[i] = gt[i] * ninv;
+    for (int i = 0; i < 3; i++) yj[i] = jt[i] * ninv;
     F nj[4];
-    nj[0] = r.jt[0] * L::template subbcast<0>(r.jt[0]) + r.jt[1] * L::template subbcast<0>(r.jt[1]) + r.jt[2] * L::template subbcast<0>(r.jt[2]);
-    nj[1] = r.jt[0] * L::template subbcast<1>(r.jt[0]) + r.jt[1] * L::template subbcast<1>(r.jt[1]) + r.jt[2] * L::template subbcast<1>(r.jt[2]);
-    nj[2] = r.jt[0] * L::template subbcast<2>(r.jt[0]) + r.jt[1] * L::template subbcast<2>(r.jt[1]) + r.jt[2] * L::template subbcast<2>(r.jt[2]);
-    nj[3] = r.jt[0] * L::template subbcast<3>(r.jt[0]) + r.jt[1] * L::template subbcast<3>(r.jt[1]) + r.jt[2] * L::template subbcast<3>(r.jt[2]);
-    F g[16];
-    L::gram16(r.gt, g);                                    // g[L] = gt . gt_L for the 16 rows of the round
-    F ninv = ln.lane_f(0.0f) - r.inv;
+    nj[0] = yj[0] * L::template subbcast<0>(jt[0]) + yj[1] * L::template subbcast<0>(jt[1]) + yj[2] * L::template subbcast<0>(jt[2]);
+    nj[1] = yj[0] * L::template subbcast<1>(jt[0]) + yj[1] * L::template subbcast<1>(jt[1]) + yj[2] * L::template subbcast<1>(jt[2]);
+    nj[2] = yj[0] * L::template subbcast<2>(jt[0]) + yj[1] * L::template subbcast<2>(jt[1]) + yj[2] * L::template subbcast<2>(jt[2]);
+    if (!LIMIT) nj[3] = yj[0] * L::template subbcast<3>(jt[0]) + yj[1] * L::template subbcast<3>(jt[1]) + yj[2] * L::template subbcast<3>(jt[2]);
     for (int L_ = 0; L_ < 16; L_++)
-      r.nk[L_] = (g[L_] + lm::sel(ln.is_leg(L_ >> 2), nj[L_ & 3], ln.lane_f(0.0f))) * ninv;
-    r.lam = ln.lane_f(0.0f);
+      if (!(LIMIT && (L_ & 3) == 3)) r.nk[L_] = lm::sel(ln.is_leg(L_ >> 2), nj[L_ & 3], zero);      // the rows of the own leg also meet in the joints
+    L::template gram4<0>(gt, yg, r.nk);                          // nk[L] += sum_i yg[i] * gt_L[i]
+    L::template gram4<1>(gt, yg, r.nk);
+    L::template gram4<2>(gt, yg, r.nk);
+    if (!LIMIT) L::template gram4<3>(gt, yg, r.nk);
+    r.lam = zero;
+    permute4(ln, gt[0], gt[1], gt[2], gt[3], r.ca);
+    B odd = lm::odd_(ln.sub());
+    r.cb[0] = lm::sel(odd, gt[5], gt[4]); r.cb[1] = lm::sel(odd, gt[4], gt[5]);
+    permute4(ln, jt[0], jt[1], jt[2], zero, r.cj);
   }
   template <int K_>
   static LL_HD void pick_rank(const L& ln, const F& rank, const F& me, const F& d, const F& sb, const F& jj, F& nd, F& ns, F& nj) {
@@ -251,32 +271,24 @@ struct Pmc {
     ns = lm::sel(take, L::template subbcast<K_>(sb), ns);
     nj = lm::sel(take, L::template subbcast<K_>(jj), nj);
   }
-  // one Gauss-Seidel round over the 16 rows of a kind; any4[s] = some lane of the wave has a live row in slot s
-  static LL_HD void gs_round(const L& ln, Row& r, const F& lo, const F& hi, const bool* any4, float* dx, F* dq) {
+  // One Gauss-Seidel round over the 16 rows of a kind.  The velocity the rows act on -- whitened base twist dx, whitened joint
+  // rates dq -- is carried in the three scattered registers VA, VB, VJ (lanes.hpp): the round reads it with ten multiply-adds
+  // (vel_dot), takes its sixteen turns, and folds the committed increments back with a 25-instruction transpose-reduce (vel_commit).
+  // A turn: the lane whose turn it is commits clamp(u) -- every lane's pending increment then moves by nk[L] * d_L.  All turns run
+  // unconditionally: a lane without a live row has inv = 0 and commits exactly zero.  (Skipping the 4-turn blocks no env of the wave
+  // occupies was measured slower: each wave-uniform test costs more issue slots than the 16 instructions it occasionally saves.)
+  template <bool LIMIT>
+  static LL_HD void gs_round(const L& ln, Row& r, const F& lo, const F& hi, F& VA, F& VB, F& VJ) {
     F zero = ln.lane_f(0.0f);
-    F cq = r.c + r.jt[0] * dq[0] + r.jt[1] * dq[1] + r.jt[2] * dq[2];
-    F s0 = r.gt[0] * dx[0] + r.gt[1] * dx[1], s1 = r.gt[2] * dx[2] + r.gt[3] * dx[3], s2 = r.gt[4] * dx[4] + r.gt[5] * dx[5];
-    F u = (zero - ((s0 + s1) + (s2 + cq))) * r.inv;       // unclamped increment; admissible interval [lo - lam, hi - lam]
+    F w = L::vel_dot(r.c, r.ca, r.cb, r.cj, VA, VB, VJ);
+    F u = (zero - w) * r.inv;                             // unclamped increment; admissible interval [lo - lam, hi - lam]
     F lo_d = lo - r.lam, hi_d = hi - r.lam;
     F dl = zero;
-    // a turn: the lane whose turn it is commits clamp(u) -- every lane's pending increment then moves by nk[L] * d_L
-    // all sixteen turns, unconditionally: a lane without a live row has inv = 0 and commits exactly zero.  (Skipping the 4-turn
-    // blocks no env of the wave occupies was measured slower: the contact blocks are all live anyway, and each wave-uniform
-    // test costs more issue slots in branch bubbles and mask bookkeeping than the 16 instructions it occasionally saves.)
-    (void)any4;
-    ln.template turns4<0>(u, dl, lo_d, hi_d, r.nk[0], r.nk[4], r.nk[8], r.nk[12]);
-    ln.template turns4<1>(u, dl, lo_d, hi_d, r.nk[1], r.nk[5], r.nk[9], r.nk[13]);
-    ln.template turns4<2>(u, dl, lo_d, hi_d, r.nk[2], r.nk[6], r.nk[10], r.nk[14]);
-    ln.template turns4<3>(u, dl, lo_d, hi_d, r.nk[3], r.nk[7], r.nk[11], r.nk[15]);
+    ln.template turns8<0>(u, dl, lo_d, hi_d, r.nk);
+    if (LIMIT) ln.template turns4<2>(u, dl, lo_d, hi_d, r.nk[2], r.nk[6], r.nk[10], r.nk[14]);
+    else ln.template turns8<1>(u, dl, lo_d, hi_d, r.nk);
     r.lam = r.lam + dl;
-    F pj[3] = {r.jt[0] * dl, r.jt[1] * dl, r.jt[2] * dl}, sj[3];
-    L::subsum3(pj, sj);                                   // the slots of a leg share its joint velocities
-    for (int i = 0; i < 3; i++) dq[i] = dq[i] + sj[i];
-    F pg[6];
-    float sg[6];
-    for (int i = 0; i < 6; i++) pg[i] = r.gt[i] * dl;
-    L::rsum6(pg, sg);                                     // every row moves the base twist
-    for (int i = 0; i < 6; i++) dx[i] += sg[i];
+    L::vel_commit(dl, r.ca, r.cb, r.cj, VA, VB, VJ);
   }
 
   // ---------------------------------------------------------------------------------------------------
@@ -359,37 +371,49 @@ struct Pmc {
     c1 = p1 + scale(d1, s);
     c2 = p2 + scale(d2, t);
   }
-  // self-collision row: frictionless, between a point on leg `own` and the same point on leg `other`
+  // self-collision row: frictionless, between a point on leg `own` and the same point on leg `other`.  Its base part
+  // gt[6] is env-uniform, its joint part jt[3] per leg; packed against the scattered velocity registers: a 16-lane sum of
+  // sa * VA + sb * VB + sj * VJ is gt . dx + sum over legs jt . dq  (VA repeats dx[0..3] in four legs, VB dx[4..5] eight times)
   struct SelfRow {
-    F jt[3];
-    float gt[6];
+    F sa, sb, sj;      // gt[sub] / 4,  gt[4 + (sub & 1)] / 8,  jt[sub] (sub 3: 0)
     float c, inv, lam;
   };
-
-  static LL_HD void self_turn(SelfRow& rw, float* dx, F* dq) {
-    float w = rw.c + L::qsum(rw.jt[0] * dq[0] + rw.jt[1] * dq[1] + rw.jt[2] * dq[2]);
-    for (int i = 0; i < 6; i++) w += rw.gt[i] * dx[i];
-    float nl = rw.lam - w * rw.inv;
-    if (nl < 0.0f) nl = 0.0f;
+  static LL_HD void self_row_clear(const L& ln, SelfRow& rw) {
+    rw.sa = rw.sb = rw.sj = ln.lane_f(0.0f);
+    rw.c = rw.inv = rw.lam = 0.0f;
+  }
+  static LL_HD void self_row_pack(const L& ln, const F* jt, const float* gt, SelfRow& rw) {
+    B s0 = ln.is_sub(0), s1 = ln.is_sub(1), s2 = ln.is_sub(2), odd = lm::odd_(ln.sub());
+    rw.sa = lm::sel(s0, ln.lane_f(0.25f * gt[0]), lm::sel(s1, ln.lane_f(0.25f * gt[1]), lm::sel(s2, ln.lane_f(0.25f * gt[2]), ln.lane_f(0.25f * gt[3]))));
+    rw.sb = lm::sel(odd, ln.lane_f(0.125f * gt[5]), ln.lane_f(0.125f * gt[4]));
+    rw.sj = lm::sel(s0, jt[0], lm::sel(s1, jt[1], lm::sel(s2, jt[2], ln.lane_f(0.0f))));
+  }
+  static LL_HD float self_row_velocity(const SelfRow& rw, const F& VA, const F& VB, const F& VJ) {
+    return L::qsum(L::subsum(rw.sa * VA + rw.sb * VB + rw.sj * VJ));
+  }
+  static LL_HD void self_row_apply(const L& ln, const SelfRow& rw, float d, F& VA, F& VB, F& VJ) {
+    VA = VA + rw.sa * ln.lane_f(4.0f * d);
+    VB = VB + rw.sb * ln.lane_f(8.0f * d);
+    VJ = VJ + rw.sj * ln.lane_f(d);
+  }
+  static LL_HD void self_turn(const L& ln, SelfRow& rw, F& VA, F& VB, F& VJ) {
+    const float w = rw.c + self_row_velocity(rw, VA, VB, VJ);
+    const float nl = fmaxf(rw.lam - w * rw.inv, 0.0f);
     const float d = nl - rw.lam;
     rw.lam = nl;
-    for (int j = 0; j < 3; j++) dq[j] = dq[j] + rw.jt[j] * d;
-    for (int i = 0; i < 6; i++) dx[i] += rw.gt[i] * d;
+    self_row_apply(ln, rw, d, VA, VB, VJ);
   }
 
   // robot-robot row (SEPMC): the same frictionless turn, with the other robot's share of the row velocity fetched from its row; both
   // rows add the two shares in the same order (robot 0's first), so both apply the same multiplier
-  static LL_HD void pair_turn(const L& ln, SelfRow& rw, float* dx, F* dq, int me) {
-    float mine = L::qsum(rw.jt[0] * dq[0] + rw.jt[1] * dq[1] + rw.jt[2] * dq[2]);
-    for (int i = 0; i < 6; i++) mine += rw.gt[i] * dx[i];
+  static LL_HD void pair_turn(const L& ln, SelfRow& rw, F& VA, F& VB, F& VJ, int me) {
+    const float mine = self_row_velocity(rw, VA, VB, VJ);
     const float theirs = ln.peer_u(mine);
     const float w = rw.c + ((me == 0) ? mine + theirs : theirs + mine);
-    float nl = rw.lam - w * rw.inv;
-    if (nl < 0.0f) nl = 0.0f;
+    const float nl = fmaxf(rw.lam - w * rw.inv, 0.0f);
     const float d = nl - rw.lam;
     rw.lam = nl;
-    for (int j = 0; j < 3; j++) dq[j] = dq[j] + rw.jt[j] * d;
-    for (int i = 0; i < 6; i++) dx[i] += rw.gt[i] * d;
+    self_row_apply(ln, rw, d, VA, VB, VJ);
   }
 
   // Where a candidate is tested against the terrain: its lowest point (the point the plane test uses), in world coordinates;
@@ -404,6 +428,26 @@ struct Pmc {
     V3l Pw = mul(R, Pb);
     rs = lm::sel(dot(ax, ax) < 0.5f, r, zero);
     Ew = mk3<F>(Pw.x + bs.p.x, Pw.y + bs.p.y, Pw.z + bs.p.z + rs);
+  }
+  // one row of a contact at point Pb (F0) along direction uu: joint part through the lever arms d1..d3, base part [Pb x uu; uu],
+  // both whitened; c = its free velocity (+ bias for the normal row)
+  static LL_HD void contact_row(const L& ln, Row& rw, const V3l& uu, const V3l& Pb, const V3l& d1, const V3l& d2, const V3l& d3, const LegFactor& lf,
+                                const float* Sb, const float* Sd, const float* xi, const F* qs, const F& bias, const B& cvalid) {
+    F gt[6], jt[3];
+    jt[0] = dot(uu, d1); jt[1] = dot(uu, d2); jt[2] = dot(uu, d3);
+    V3l pxu = cross(Pb, uu);
+    // free row velocity J_b xi + J_l qd*
+    F vrow = pxu.x * xi[0] + pxu.y * xi[1] + pxu.z * xi[2] + uu.x * xi[3] + uu.y * xi[4] + uu.z * xi[5] + jt[0] * qs[0] + jt[1] * qs[1] + jt[2] * qs[2];
+    lm_fwd(lf, jt);
+    SV<F> yj = scale(lf.y1, jt[0]) + scale(lf.y2, jt[1]) + scale(lf.y3, jt[2]);
+    gt[0] = pxu.x - yj.a.x; gt[1] = pxu.y - yj.a.y; gt[2] = pxu.z - yj.a.z;
+    gt[3] = uu.x - yj.l.x; gt[4] = uu.y - yj.l.y; gt[5] = uu.z - yj.l.z;
+    fwd6(Sb, Sd, gt);
+    F nn = jt[0] * jt[0] + jt[1] * jt[1] + jt[2] * jt[2];
+    for (int i = 0; i < 6; i++) nn = nn + gt[i] * gt[i];
+    rw.c = vrow + bias;
+    rw.inv = lm::sel(cvalid, ln.lane_f(1.0f) / nn, ln.lane_f(0.0f));
+    finish_row<false>(ln, rw, gt, jt);
   }
   // LR:137-141: tau = kp (target - q) + kd (0 - qd), clipped to +-max_tau -- the `forces=` the reference hands to
   // setJointMotorControlArray(TORQUE_CONTROL) before every stepSimulation (golden G8; ll_probe_pd_torque runs exactly this)
@@ -705,21 +749,22 @@ struct Pmc {
       F dlo = qj - qlo, dhi = qhi - qj;
       B lower = dlo <= dhi;
       F d = lm::sel(lower, dlo, dhi), sg = lm::sel(lower, one, zero - one);
-      rl.jt[0] = lm::sel(sub_0, sg, zero);
-      rl.jt[1] = lm::sel(lm::and_(sub_lt2, lm::not_(sub_0)), sg, zero);
-      rl.jt[2] = lm::sel(lm::and_(sub_lt3, lm::not_(sub_lt2)), sg, zero);
-      lm_fwd(lf, rl.jt);
-      SV<F> g6 = scale(scale(lf.y1, rl.jt[0]) + scale(lf.y2, rl.jt[1]) + scale(lf.y3, rl.jt[2]), zero - one);
-      sv_to6(g6, rl.gt);
-      fwd6(Sb, Sd, rl.gt);
-      F nn = rl.jt[0] * rl.jt[0] + rl.jt[1] * rl.jt[1] + rl.jt[2] * rl.jt[2];
-      for (int i = 0; i < 6; i++) nn = nn + rl.gt[i] * rl.gt[i];
+      F ljt[3], lgt[6];
+      ljt[0] = lm::sel(sub_0, sg, zero);
+      ljt[1] = lm::sel(lm::and_(sub_lt2, lm::not_(sub_0)), sg, zero);
+      ljt[2] = lm::sel(lm::and_(sub_lt3, lm::not_(sub_lt2)), sg, zero);
+      lm_fwd(lf, ljt);
+      SV<F> g6 = scale(scale(lf.y1, ljt[0]) + scale(lf.y2, ljt[1]) + scale(lf.y3, ljt[2]), zero - one);
+      sv_to6(g6, lgt);
+      fwd6(Sb, Sd, lgt);
+      F nn = ljt[0] * ljt[0] + ljt[1] * ljt[1] + ljt[2] * ljt[2];
+      for (int i = 0; i < 6; i++) nn = nn + lgt[i] * lgt[i];
       rl.c = sg * qsj + lm::sel(d > 0.0f, d * inv_dt, d * (P.erp * inv_dt));
       B lvalid = lm::and_(lm::and_(has, rl.c < P.limit_gate), ln.lane_f(PMC_ABL(2) ? 0.0f : 1.0f) > 0.5f);     // rows that cannot act this substep stay out of the solve
       rl.inv = lm::sel(lvalid, one / nn, zero);
       any_l[0] = L::any(lm::and_(lvalid, ln.is_sub(0))); any_l[1] = L::any(lm::and_(lvalid, ln.is_sub(1)));
       any_l[2] = L::any(lm::and_(lvalid, ln.is_sub(2)));
-      if (any_l[0] || any_l[1] || any_l[2]) finish_row(ln, rl);
+      if (any_l[0] || any_l[1] || any_l[2]) finish_row<true>(ln, rl, lgt, ljt);
     }
     PMC_TSS(25);
     if (any_contact) {
@@ -788,33 +833,16 @@ struct Pmc {
       V3l a1v = mk3<F>(one, zero, zero);
       V3l d1 = scale(cross(a1v, rr1), on1), d2 = scale(cross(k.a2, rr2), on2), d3 = scale(cross(k.a2, rr3), on3);
       // rows n = +z, t1 = -y, t2 = +x (world), expressed in F0
-      for (int r_ = 0; r_ < 3; r_++) {
-        Row& rw = (r_ == 0) ? rn : (r_ == 1 ? r1 : r2);
-        V3l uu = (r_ == 0) ? un : (r_ == 1 ? ut1 : ut2);
-        rw.jt[0] = dot(uu, d1); rw.jt[1] = dot(uu, d2); rw.jt[2] = dot(uu, d3);
-        V3l pxu = cross(Pb, uu);
-        // free row velocity J_b xi + J_l qd*
-        F vrow = pxu.x * xi[0] + pxu.y * xi[1] + pxu.z * xi[2] + uu.x * xi[3] + uu.y * xi[4] + uu.z * xi[5] + rw.jt[0] * qs[0] + rw.jt[1] * qs[1] + rw.jt[2] * qs[2];
-        lm_fwd(lf, rw.jt);
-        SV<F> yj = scale(lf.y1, rw.jt[0]) + scale(lf.y2, rw.jt[1]) + scale(lf.y3, rw.jt[2]);
-        rw.gt[0] = pxu.x - yj.a.x; rw.gt[1] = pxu.y - yj.a.y; rw.gt[2] = pxu.z - yj.a.z;
-        rw.gt[3] = uu.x - yj.l.x; rw.gt[4] = uu.y - yj.l.y; rw.gt[5] = uu.z - yj.l.z;
-        fwd6(Sb, Sd, rw.gt);
-        F nn = rw.jt[0] * rw.jt[0] + rw.jt[1] * rw.jt[1] + rw.jt[2] * rw.jt[2];
-        for (int i = 0; i < 6; i++) nn = nn + rw.gt[i] * rw.gt[i];
-        rw.c = (r_ == 0) ? vrow + bias : vrow;
-        rw.inv = lm::sel(cvalid, one / nn, zero);
-        finish_row(ln, rw);
-      }
+      contact_row(ln, rn, un, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, bias, cvalid);
+      contact_row(ln, r1, ut1, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid);
+      contact_row(ln, r2, ut2, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid);
     }
 
     // --- self-collision (LR:212-217: links of different legs): each leg is two capsules, the closest pairs within the
     //     margin give up to two frictionless rows.  Lane (leg g, sub s) tests capsule (s & 2 ? shank : thigh) of its own leg against
     //     capsule (s & 1 ? shank : thigh) of the previous leg, and -- legs 0 and 1 only -- of the leg two away: 24 pairs in two passes.
     SelfRow sr[2];
-    sr[0].inv = sr[1].inv = 0.0f; sr[0].lam = sr[1].lam = 0.0f; sr[0].c = sr[1].c = 0.0f;
-    for (int i = 0; i < 3; i++) sr[0].jt[i] = sr[1].jt[i] = zero;
-    for (int i = 0; i < 6; i++) sr[0].gt[i] = sr[1].gt[i] = 0.0f;
+    self_row_clear(ln, sr[0]); self_row_clear(ln, sr[1]);
     bool any_self = false;
     int n_self_w = 0;                   // self-collision slots in use by some env of the wave
     if (P.self_collision > 0.5f && !PMC_ABL(512)) {                                 // (ablation 512: no self-collision at all)
@@ -893,19 +921,22 @@ struct Pmc {
           V3l a1v = mk3<F>(one, zero, zero);
           V3l e1 = cross(a1v, Pb - k.p1), e2 = cross(k.a2, Pb - k.p2), e3 = scale(cross(k.a2, Pb - k.p3), on3);
           SelfRow& rw = sr[slot];
-          rw.jt[0] = sgn * dot(nb, e1); rw.jt[1] = sgn * dot(nb, e2); rw.jt[2] = sgn * dot(nb, e3);
-          float vrow = L::qsum(rw.jt[0] * qs[0] + rw.jt[1] * qs[1] + rw.jt[2] * qs[2]);      // the base moves both points alike: no base part
-          lm_fwd(lf, rw.jt);
-          SV<F> yj = scale(lf.y1, rw.jt[0]) + scale(lf.y2, rw.jt[1]) + scale(lf.y3, rw.jt[2]);
+          F sjt[3];
+          float sgt[6];
+          sjt[0] = sgn * dot(nb, e1); sjt[1] = sgn * dot(nb, e2); sjt[2] = sgn * dot(nb, e3);
+          float vrow = L::qsum(sjt[0] * qs[0] + sjt[1] * qs[1] + sjt[2] * qs[2]);      // the base moves both points alike: no base part
+          lm_fwd(lf, sjt);
+          SV<F> yj = scale(lf.y1, sjt[0]) + scale(lf.y2, sjt[1]) + scale(lf.y3, sjt[2]);
           F g6[6] = {zero - yj.a.x, zero - yj.a.y, zero - yj.a.z, zero - yj.l.x, zero - yj.l.y, zero - yj.l.z};
-          L::qsum6(g6, rw.gt);
-          fwd6(Sb, Sd, rw.gt);
-          float nn = L::qsum(rw.jt[0] * rw.jt[0] + rw.jt[1] * rw.jt[1] + rw.jt[2] * rw.jt[2]);
-          for (int i = 0; i < 6; i++) nn += rw.gt[i] * rw.gt[i];
+          L::qsum6(g6, sgt);
+          fwd6(Sb, Sd, sgt);
+          float nn = L::qsum(sjt[0] * sjt[0] + sjt[1] * sjt[1] + sjt[2] * sjt[2]);
+          for (int i = 0; i < 6; i++) nn += sgt[i] * sgt[i];
+          self_row_pack(ln, sjt, sgt, rw);
           rw.c = vrow + ((dmin > 0.0f) ? dmin * inv_dt : fmaxf(dmin * (P.erp * inv_dt), -(float)LLM_MAX_DEPEN_SPEED));
           rw.inv = have ? 1.0f / nn : 0.0f;
           rw.lam = 0.0f;
-          if (!have) { for (int i = 0; i < 3; i++) rw.jt[i] = zero; for (int i = 0; i < 6; i++) rw.gt[i] = 0.0f; rw.c = 0.0f; }
+          if (!have) self_row_clear(ln, rw);
         }
       }
     }
@@ -916,9 +947,7 @@ struct Pmc {
     bool any_pair = false;
     int n_pair_w = 0;
     if (PAIR) {
-      pr[0].inv = pr[1].inv = 0.0f; pr[0].lam = pr[1].lam = 0.0f; pr[0].c = pr[1].c = 0.0f;
-      for (int i = 0; i < 3; i++) pr[0].jt[i] = pr[1].jt[i] = zero;
-      for (int i = 0; i < 6; i++) pr[0].gt[i] = pr[1].gt[i] = 0.0f;
+      self_row_clear(ln, pr[0]); self_row_clear(ln, pr[1]);
       if (ex->want_touch) ex->touch_robot = 0.0f;
       if (L::any(ln.lane_f(ex->pair_active ? 1.0f : 0.0f) > 0.5f)) {
         const int me = ex->pair_me;
@@ -1061,22 +1090,25 @@ struct Pmc {
             V3l a1v = mk3<F>(one, zero, zero);
             V3l e1 = cross(a1v, Pb - k.p1), e2 = cross(k.a2, Pb - k.p2), e3 = scale(cross(k.a2, Pb - k.p3), on3);
             SelfRow& rw = pr[slot];
-            rw.jt[0] = lm::sel(mine, dot(nb, e1), zero); rw.jt[1] = lm::sel(mine, dot(nb, e2), zero); rw.jt[2] = lm::sel(mine, dot(nb, e3), zero);
+            F sjt[3];
+            float sgt[6];
+            sjt[0] = lm::sel(mine, dot(nb, e1), zero); sjt[1] = lm::sel(mine, dot(nb, e2), zero); sjt[2] = lm::sel(mine, dot(nb, e3), zero);
             const V3<float> pxu = cross(pb_, nb_);
-            float vrow = L::qsum(rw.jt[0] * qs[0] + rw.jt[1] * qs[1] + rw.jt[2] * qs[2]) + pxu.x * xi[0] + pxu.y * xi[1] + pxu.z * xi[2] + nb_.x * xi[3] + nb_.y * xi[4] + nb_.z * xi[5];
-            lm_fwd(lf, rw.jt);
-            SV<F> yj = scale(lf.y1, rw.jt[0]) + scale(lf.y2, rw.jt[1]) + scale(lf.y3, rw.jt[2]);
+            float vrow = L::qsum(sjt[0] * qs[0] + sjt[1] * qs[1] + sjt[2] * qs[2]) + pxu.x * xi[0] + pxu.y * xi[1] + pxu.z * xi[2] + nb_.x * xi[3] + nb_.y * xi[4] + nb_.z * xi[5];
+            lm_fwd(lf, sjt);
+            SV<F> yj = scale(lf.y1, sjt[0]) + scale(lf.y2, sjt[1]) + scale(lf.y3, sjt[2]);
             F g6[6] = {zero - yj.a.x, zero - yj.a.y, zero - yj.a.z, zero - yj.l.x, zero - yj.l.y, zero - yj.l.z};
-            L::qsum6(g6, rw.gt);
-            rw.gt[0] += pxu.x; rw.gt[1] += pxu.y; rw.gt[2] += pxu.z; rw.gt[3] += nb_.x; rw.gt[4] += nb_.y; rw.gt[5] += nb_.z;
-            fwd6(Sb, Sd, rw.gt);
-            float nn = L::qsum(rw.jt[0] * rw.jt[0] + rw.jt[1] * rw.jt[1] + rw.jt[2] * rw.jt[2]);
-            for (int i = 0; i < 6; i++) nn += rw.gt[i] * rw.gt[i];
+            L::qsum6(g6, sgt);
+            sgt[0] += pxu.x; sgt[1] += pxu.y; sgt[2] += pxu.z; sgt[3] += nb_.x; sgt[4] += nb_.y; sgt[5] += nb_.z;
+            fwd6(Sb, Sd, sgt);
+            float nn = L::qsum(sjt[0] * sjt[0] + sjt[1] * sjt[1] + sjt[2] * sjt[2]);
+            for (int i = 0; i < 6; i++) nn += sgt[i] * sgt[i];
+            self_row_pack(ln, sjt, sgt, rw);
             const float vo = ln.peer_u(vrow), no = ln.peer_u(nn);
             rw.c = ((me == 0) ? vrow + vo : vo + vrow) + ((dmin > 0.0f) ? dmin * inv_dt : fmaxf(dmin * (P.erp * inv_dt), -(float)LLM_MAX_DEPEN_SPEED));
             rw.inv = have ? 1.0f / ((me == 0) ? nn + no : no + nn) : 0.0f;
             rw.lam = 0.0f;
-            if (!have) { for (int i = 0; i < 3; i++) rw.jt[i] = zero; for (int i = 0; i < 6; i++) rw.gt[i] = 0.0f; rw.c = 0.0f; }
+            if (!have) self_row_clear(ln, rw);
           }
         }
       }
@@ -1091,34 +1123,36 @@ struct Pmc {
 #endif
     // --- projected Gauss-Seidel in whitened coordinates, rows in registers ------------------------------------------------------
     // Order of the spec: limit rows (joint, leg), then normal rows (slot, leg), t1 rows, t2 rows.
-    float dx[6] = {0, 0, 0, 0, 0, 0};      // env-uniform:  sum gt * lambda
-    F dq[3] = {zero, zero, zero};          // leg-uniform:  sum jt * lambda
+    F VA = zero, VB = zero, VJ = zero;     // sum gt * lambda (env-uniform dx[6]) and sum jt * lambda (leg-uniform dq[3]), scattered over the sub-lanes
     const F big = ln.lane_f(3.0e38f);
     const bool any_limit = any_l[0] || any_l[1] || any_l[2];
     ln.prepare_turn_masks();
     LL_NOUNROLL
     for (int it = 0; it < P.n_iter; it++) {
-      if (any_limit) gs_round(ln, rl, zero, big, any_l, dx, dq);
+      if (any_limit) gs_round<true>(ln, rl, zero, big, VA, VB, VJ);
       if (any_contact) {
-        gs_round(ln, rn, zero, big, any_c, dx, dq);
+        gs_round<false>(ln, rn, zero, big, VA, VB, VJ);
         F hi = mu * rn.lam;
-        gs_round(ln, r1, zero - hi, hi, any_c, dx, dq);
-        gs_round(ln, r2, zero - hi, hi, any_c, dx, dq);
+        gs_round<false>(ln, r1, zero - hi, hi, VA, VB, VJ);
+        gs_round<false>(ln, r2, zero - hi, hi, VA, VB, VJ);
       }
       if (any_self) {                                                        // then the self-collision rows, one after the other
-        self_turn(sr[0], dx, dq);
-        if (n_self_w > 1) self_turn(sr[1], dx, dq);
+        self_turn(ln, sr[0], VA, VB, VJ);
+        if (n_self_w > 1) self_turn(ln, sr[1], VA, VB, VJ);
       }
       if (PAIR) {
         if (any_pair) {                                                      // last, the rows shared with the other robot
-          pair_turn(ln, pr[0], dx, dq, ex->pair_me);
-          if (n_pair_w > 1) pair_turn(ln, pr[1], dx, dq, ex->pair_me);
+          pair_turn(ln, pr[0], VA, VB, VJ, ex->pair_me);
+          if (n_pair_w > 1) pair_turn(ln, pr[1], VA, VB, VJ, ex->pair_me);
         }
       }
     }
 
     PMC_TSS(27);
     // back to velocities: d(xi) = Lb^-T dx ; d(qd) = Lm^-T (dq - Y^T d(xi))
+    float dx[6] = {L::template vel_dx<0>(VA, VB), L::template vel_dx<1>(VA, VB), L::template vel_dx<2>(VA, VB),
+                   L::template vel_dx<3>(VA, VB), L::template vel_dx<4>(VA, VB), L::template vel_dx<5>(VA, VB)};
+    F dq[3] = {L::template vel_dq<0>(VJ), L::template vel_dq<1>(VJ), L::template vel_dq<2>(VJ)};
     bwd6(Sb, Sd, dx);
     SV<float> dxi;
     dxi.a = mk3<float>(dx[0], dx[1], dx[2]); dxi.l = mk3<float>(dx[3], dx[4], dx[5]);

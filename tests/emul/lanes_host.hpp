@@ -128,8 +128,11 @@ struct HostLanes {
   template <int L_> static void fmac_rbcast(F& acc, const F& x, const F& k) { for (int i = 0; i < EW; i++) acc.v[i] = acc.v[i] + x.v[L_] * k.v[i]; }
   template <int L_> static void fmac_rbcast_settled(F& acc, const F& x, const F& k) { fmac_rbcast<L_>(acc, x, k); }
   static F settle(const F& x) { return x; }
-  static void gram16(const F* x, F* g) {
-    for (int L_ = 0; L_ < 16; L_++) { fN a(0.0f); for (int i = 0; i < 6; i++) for (int l = 0; l < EW; l++) a.v[l] = a.v[l] + x[i].v[l] * x[i].v[L_]; g[L_] = a; }
+  template <int S_> static void gram4(const F* x, const F* y, F* g) {
+    for (int t = 0; t < 4; t++) {
+      const int L_ = 4 * t + S_;
+      for (int i = 0; i < 6; i++) for (int l = 0; l < EW; l++) g[L_].v[l] = g[L_].v[l] + x[i].v[L_] * y[i].v[l];
+    }
   }
   template <int S_> static void turns4(F& u, F& dl, const F& lo, const F& hi, const F& k0, const F& k1, const F& k2, const F& k3) {
     const F* ks[4] = {&k0, &k1, &k2, &k3};
@@ -140,6 +143,41 @@ struct HostLanes {
       for (int l = 0; l < EW; l++) u.v[l] = u.v[l] + d.v[L_] * ks[t]->v[l];
     }
   }
+  template <int H_> static void turns8(F& u, F& dl, const F& lo, const F& hi, const F* nk) {
+    const int order[2][8] = {{0, 4, 8, 12, 1, 5, 9, 13}, {2, 6, 10, 14, 3, 7, 11, 15}};
+    for (int t = 0; t < 8; t++) {
+      const int L_ = order[H_][t];
+      fN d = lm::med3_(u, lo, hi);
+      dl.v[L_] = d.v[L_];
+      for (int l = 0; l < EW; l++) u.v[l] = u.v[l] + d.v[L_] * nk[L_].v[l];
+    }
+  }
+  // the solver's scattered velocity state (lanes.hpp): VA[l] = dx[l & 3], VB[l] = dx[4 + (l & 1)], VJ[l] = dq_leg[l & 3];
+  // ca[k][l] = gt[(l & 3) ^ k], cb[k][l] = gt[4 + (((l & 3) ^ k) & 1)], cj[k][l] = jt[(l & 3) ^ k]
+  static F vel_dot(const F& c, const F* ca, const F* cb, const F* cj, const F& VA, const F& VB, const F& VJ) {
+    fN w;
+    for (int l = 0; l < EW; l++) {
+      float a = ca[0].v[l] * VA.v[l] + c.v[l];
+      a += cb[0].v[l] * VB.v[l];
+      a += cj[0].v[l] * VJ.v[l];
+      for (int k = 1; k < 4; k++) a += ca[k].v[l] * VA.v[l ^ k];
+      a += cb[1].v[l] * VB.v[l ^ 1];
+      for (int k = 1; k < 4; k++) a += cj[k].v[l] * VJ.v[l ^ k];
+      w.v[l] = a;
+    }
+    return w;
+  }
+  static void vel_commit(const F& dl, const F* ca, const F* cb, const F* cj, F& VA, F& VB, F& VJ) {
+    float tA[4] = {0, 0, 0, 0}, tB[2] = {0, 0}, tJ[4][4] = {{0}};
+    for (int l = 0; l < EW; l++) {
+      const int s = l & 3;
+      for (int k = 0; k < 4; k++) { tA[s ^ k] += ca[k].v[l] * dl.v[l]; tJ[l >> 2][s ^ k] += cj[k].v[l] * dl.v[l]; }
+      for (int k = 0; k < 2; k++) tB[(s ^ k) & 1] += cb[k].v[l] * dl.v[l];
+    }
+    for (int l = 0; l < EW; l++) { VA.v[l] += tA[l & 3]; VB.v[l] += tB[l & 1]; VJ.v[l] += tJ[l >> 2][l & 3]; }
+  }
+  template <int I_> static float vel_dx(const F& VA, const F& VB) { return I_ < 4 ? VA.v[I_ & 3] : VB.v[I_ & 1]; }
+  template <int J_> static F vel_dq(const F& VJ) { fN r; for (int i = 0; i < EW; i++) r.v[i] = VJ.v[(i & ~3) | J_]; return r; }
   static F from_prev_leg(const F& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = x.v[(i + 12) & 15]; return r; }
   static F from_next_leg(const F& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = x.v[(i + 4) & 15]; return r; }
   static F from_leg2(const F& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = x.v[(i + 8) & 15]; return r; }
