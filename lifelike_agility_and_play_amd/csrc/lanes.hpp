@@ -357,6 +357,7 @@ struct GpuLanes {
   // ---- constants -------------------------------------------------------------------------------------------------
   LL_D F legc(const float*, int field) const { return lds_[cbase_ + field * 4]; }
   LL_D F candc(int word) const { return lds_[tbase_ + word * PMC_ROW]; }                           // own (leg, sub) column
+  LL_D float basec(const float* bc, int i) const { return bc[i]; }                                // env-uniform base constants
   LL_D F candc_of(I sub2, I word) const { return lds_[tbase_ - sub_ + sub2 + word * PMC_ROW]; }    // column of another sub-lane of the leg
   // lane pick for 3-vectors: leg 0 -> x, 1 -> y, 2,3 -> z
   LL_D F pick3(float x, float y, float z) const { return leg_ == 0 ? x : (leg_ == 1 ? y : z); }
@@ -390,16 +391,34 @@ struct GpuLanes {
 // every substep.  For the occupancy-1 build only: with one wavefront per SIMD nothing hides an LDS round trip (measured:
 // a quarter of the kernel's cycles sat in s_waitcnt on constant reads), while 256 AGPRs lie idle as spill space -- the
 // register allocator parks the table there and a use costs one v_accvgpr_read instead of a ds_read plus its latency.
-template <int N_LEG_FIELDS>
+template <int N_LEG_FIELDS, int PIN_CANDS = 0, int N_BASE = 0>
 struct GpuLanesPinned : GpuLanes {
   float lc_[N_LEG_FIELDS];
+  // PIN_CANDS > 0 (the PMC step kernel, which has the registers to spare): the fields of the lane's first PIN_CANDS contact candidates
+  // that the per-substep candidate loop reads (A, ax, r, link: 8 of the 12 words) and the base constants are held too.  Measured
+  // before: 40 s_waitcnt lgkmcnt per substep, each a few instructions behind its ds_read -- an LDS round trip nobody hides.
+  float cc_[PIN_CANDS > 0 ? PIN_CANDS * 8 : 1];
+  float bcr_[N_BASE > 0 ? N_BASE : 1];
   LL_D GpuLanesPinned(float* lds) : GpuLanes(lds) {}
-  LL_D void stage_consts(const float* legc, int n_leg_fields, const float* candc, int n_cand_words) {
+  LL_D void stage_consts(const float* legc, int n_leg_fields, const float* candc, int n_cand_words, const float* basec = nullptr) {
     GpuLanes::stage_consts(legc, n_leg_fields, candc, n_cand_words);
     LL_UNROLL
     for (int i = 0; i < N_LEG_FIELDS; i++) lc_[i] = lds_[i * 4 + leg_];
+    LL_UNROLL
+    for (int j = 0; j < PIN_CANDS; j++) {
+      LL_UNROLL
+      for (int f = 0; f < 8; f++) cc_[j * 8 + f] = lds_[tbase_ + (j * 12 + (f < 6 ? f : f + 3)) * PMC_ROW];
+    }
+    LL_UNROLL
+    for (int i = 0; i < N_BASE; i++) bcr_[i] = basec[i];
   }
   LL_D F legc(const float*, int field) const { return lc_[field]; }
+  LL_D F candc(int word) const {
+    const int j = word / 12, f = word % 12;
+    if (j < PIN_CANDS && (f < 6 || f == 9 || f == 10)) return cc_[j * 8 + (f < 6 ? f : f - 3)];
+    return lds_[tbase_ + word * PMC_ROW];
+  }
+  LL_D float basec(const float* bc, int i) const { return N_BASE > 0 ? bcr_[i] : bc[i]; }
 };
 
 #define LL_FMAC_RBCAST(L_)                                                                                               \

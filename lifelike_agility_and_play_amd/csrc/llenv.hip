@@ -27,7 +27,11 @@
   } while (0)
 
 typedef Pmc<GpuLanes> K;
-typedef GpuLanesPinned<LC_COUNT> GpuLanes1;
+typedef GpuLanesPinned<LC_COUNT> GpuLanes1;                   // EPMC / SEPMC at one wave per SIMD: the per-leg table in registers
+#ifndef LL_PIN_PMC
+#define LL_PIN_PMC 1
+#endif
+typedef GpuLanesPinned<LC_COUNT, LL_PIN_PMC ? 7 : 0, LL_PIN_PMC ? BC_COUNT : 0> GpuLanesPmc1;  // PMC at one wave per SIMD: candidate fields and base constants too
 
 // PLE:235-240 for the batch, by one wavefront: fold the statistics published by finished episodes into the per-clip table
 // (lane = clip, 64 per pass), then rebuild p ~ (1 - avg_reward_sum)^factor and its inclusive CDF.  Called by the last
@@ -93,9 +97,10 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int row = threadIdx.x >> 4;                                         // one env = one 16-lane DPP row
   const int env = blockIdx.x * PMC_ENVS_PER_WAVE + row;
-  typedef typename std::conditional<OCC == 1, GpuLanes1, GpuLanes>::type Lanes;
+  typedef typename std::conditional<OCC == 1, GpuLanesPmc1, GpuLanes>::type Lanes;
   Lanes ln(lds);
-  ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);           // all 64 lanes copy, also those without an env
+  if constexpr (OCC == 1) ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS, P.basec);   // all 64 lanes copy, also those without an env
+  else ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
   if (env < P.n_envs) {
     float act[3];
     if (P.action_sigma > 0.0f) {

@@ -557,10 +557,10 @@ struct Pmc {
       F cin[12] = {Ic1.m, Ic1.h.x, Ic1.h.y, Ic1.h.z, Ic1.io.xx, Ic1.io.xy, Ic1.io.xz, Ic1.io.yy, Ic1.io.yz, Ic1.io.zz, zero, zero};
       float cs[12];
       L::qsum6(cin, cs); L::qsum6(cin + 6, cs + 6);
-      float m = bc[BC_MASS] + cs[0];
-      float hx = bc[BC_H + 0] + cs[1], hy = bc[BC_H + 1] + cs[2], hz = bc[BC_H + 2] + cs[3];
-      float ixx = bc[BC_IO + 0] + cs[4], ixy = bc[BC_IO + 1] + cs[5], ixz = bc[BC_IO + 2] + cs[6];
-      float iyy = bc[BC_IO + 3] + cs[7], iyz = bc[BC_IO + 4] + cs[8], izz = bc[BC_IO + 5] + cs[9];
+      float m = ln.basec(bc, BC_MASS) + cs[0];
+      float hx = ln.basec(bc, BC_H + 0) + cs[1], hy = ln.basec(bc, BC_H + 1) + cs[2], hz = ln.basec(bc, BC_H + 2) + cs[3];
+      float ixx = ln.basec(bc, BC_IO + 0) + cs[4], ixy = ln.basec(bc, BC_IO + 1) + cs[5], ixz = ln.basec(bc, BC_IO + 2) + cs[6];
+      float iyy = ln.basec(bc, BC_IO + 3) + cs[7], iyz = ln.basec(bc, BC_IO + 4) + cs[8], izz = ln.basec(bc, BC_IO + 5) + cs[9];
       // [[Io, hx],[-hx, m]] with hx = skew(h): rows 3..5 x cols 0..2 hold -skew(h) = [[0,hz,-hy],[-hz,0,hx],[hy,-hx,0]]
       Sb[0] = ixx;
       Sb[1] = ixy; Sb[2] = iyy;
@@ -587,12 +587,12 @@ struct Pmc {
     float xb[6];
     {
       RI<float> I0;
-      I0.m = bc[BC_MASS];
-      I0.h = mk3<float>(bc[BC_H], bc[BC_H + 1], bc[BC_H + 2]);
-      I0.io.xx = bc[BC_IO]; I0.io.xy = bc[BC_IO + 1]; I0.io.xz = bc[BC_IO + 2]; I0.io.yy = bc[BC_IO + 3]; I0.io.yz = bc[BC_IO + 4]; I0.io.zz = bc[BC_IO + 5];
+      I0.m = ln.basec(bc, BC_MASS);
+      I0.h = mk3<float>(ln.basec(bc, BC_H), ln.basec(bc, BC_H + 1), ln.basec(bc, BC_H + 2));
+      I0.io.xx = ln.basec(bc, BC_IO); I0.io.xy = ln.basec(bc, BC_IO + 1); I0.io.xz = ln.basec(bc, BC_IO + 2); I0.io.yy = ln.basec(bc, BC_IO + 3); I0.io.yz = ln.basec(bc, BC_IO + 4); I0.io.zz = ln.basec(bc, BC_IO + 5);
       S3<float> ic0;
-      ic0.xx = bc[BC_ICOM]; ic0.xy = bc[BC_ICOM + 1]; ic0.xz = bc[BC_ICOM + 2]; ic0.yy = bc[BC_ICOM + 3]; ic0.yz = bc[BC_ICOM + 4]; ic0.zz = bc[BC_ICOM + 5];
-      V3u com0 = mk3<float>(bc[BC_COM], bc[BC_COM + 1], bc[BC_COM + 2]);
+      ic0.xx = ln.basec(bc, BC_ICOM); ic0.xy = ln.basec(bc, BC_ICOM + 1); ic0.xz = ln.basec(bc, BC_ICOM + 2); ic0.yy = ln.basec(bc, BC_ICOM + 3); ic0.yz = ln.basec(bc, BC_ICOM + 4); ic0.zz = ln.basec(bc, BC_ICOM + 5);
+      V3u com0 = mk3<float>(ln.basec(bc, BC_COM), ln.basec(bc, BC_COM + 1), ln.basec(bc, BC_COM + 2));
       SV<float> f0 = crf(v0, apply(I0, v0)) + scale(damping_force<float>(v0, com0, ic0, I0.m, P.link_damping), -1.0f);
       F fz[6] = {f123.a.x + z.a.x, f123.a.y + z.a.y, f123.a.z + z.a.z, f123.l.x + z.l.x, f123.l.y + z.l.y, f123.l.z + z.l.z};
       float fs[6];

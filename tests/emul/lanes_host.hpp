@@ -184,6 +184,7 @@ struct HostLanes {
   static float rmin(const F& x) { float m = x.v[0]; for (int i = 1; i < EW; i++) m = fminf(m, x.v[i]); return m; }
   static bool any(const B& m) { for (int i = 0; i < EW; i++) if (m.v[i]) return true; return false; }
   F legc(const float* tbl, int field) const { fN r; for (int i = 0; i < EW; i++) r.v[i] = tbl[field * 4 + (i >> 2)]; return r; }
+  float basec(const float* bc, int i) const { return bc[i]; }
   F candc(int word) const { fN r; for (int i = 0; i < EW; i++) r.v[i] = candc_[word * 16 + i]; return r; }
   F candc_of(const I& sub2, const I& word) const { fN r; for (int i = 0; i < EW; i++) r.v[i] = candc_[word.v[i] * 16 + (i & ~3) + sub2.v[i]]; return r; }
   F pick3(float x, float y, float z) const { fN r; for (int i = 0; i < EW; i++) r.v[i] = (i >> 2) == 0 ? x : ((i >> 2) == 1 ? y : z); return r; }
