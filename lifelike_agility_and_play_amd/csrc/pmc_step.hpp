@@ -1596,8 +1596,10 @@ struct Pmc {
     PMC_TS(6);
     // --- observation (PLE:227), state, ghost, feet, bookkeeping ---
     obs_emit(ln, P, row, fill, oin, bs, R, oq, oqd, oact);
+    PMC_TS(8);
     store_state(ln, P.state, N, env, bs, oq, oqd);
     store_state(ln, P.kin, N, env, gb, gjp, gjv);
+    PMC_TS(9);
     for (int c = 0; c < 3; c++) {
       ln.stl(P.feet, (long)c * N + env, 3L * N, (c == 0) ? fd.x : (c == 1 ? fd.y : fd.z));
       ln.stl(P.feet, (long)(12 + c) * N + env, 3L * N, (c == 0) ? fk.x : (c == 1 ? fk.y : fk.z));

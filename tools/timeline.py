@@ -14,7 +14,7 @@ cfg = capi.make_config(n, control_freq=50.0, sim_freq=500.0, kd=0.5, reward_weig
 E = capi.Engine(cfg, blob, table, lib_path=os.environ['LL_LIB'])
 fn = E.lib.ll_debug_timestamps; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p]
 E.reset()
-NAMES = {0: 'entry', 1: 'state loaded', 2: 'mocap gathered', 3: 'reward', 4: 'termination', 5: 'trajectory row', 6: 'episode end/re-seed', 7: 'obs + stores (end)'}
+NAMES = {8: 'obs row written', 9: 'state + ghost stored', 0: 'entry', 1: 'state loaded', 2: 'mocap gathered', 3: 'reward', 4: 'termination', 5: 'trajectory row', 6: 'episode end/re-seed', 7: 'obs + stores (end)'}
 for k in range(10):
     NAMES[10 + k] = 'substep %d' % k
 for k, nm in zip(range(21, 28), ['kinematics+inertias', 'base S factor', 'free accelerations', 'candidates+selection', 'limit rows', 'contact rows', 'PGS']):
@@ -32,7 +32,7 @@ for it in range(60):
     t = ts.astype(np.float64) * 0.01          # us (100 MHz)
     t0 = t[:, 0].min()
     acc.append((t - t0, np.asarray(done).astype(bool)))
-order = [0, 1] + list(range(10, 15)) + list(range(21, 28)) + list(range(15, 20)) + [2, 3, 4, 5, 6, 7]
+order = [0, 1] + list(range(10, 15)) + list(range(21, 28)) + list(range(15, 20)) + [2, 3, 4, 5, 6, 8, 9, 7]
 print('n_envs %d: stamps relative to the first wave entry, us; mean over 20 steps of [mean | max over envs], split by reset' % n)
 print('%-18s %8s %8s | %8s %8s (resetting envs)' % ('mark', 'mean', 'max', 'mean', 'max'))
 for k in order:
