@@ -31,6 +31,7 @@ SIGMA = math.exp(-2.0)
 ALGO_BYTES_PER_ENV_STEP = 2552          # SURVEY.md 8(d) / DESIGN.md "algorithmic bytes"
 HBM_PEAK_GBPS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s spec
 UNROLL = 128                            # example_pmc_train.sh:145 unroll_length
+GAMMA, LAMBDA = 0.95, 0.95              # example_pmc_train.sh:21-22
 
 PMC_REWARD_WEIGHTS = {'joint_pos': 0.3, 'joint_vel': 0.05, 'end_effector': 0.1, 'root_pose': 0.5, 'root_vel': 0.05}
 PMC_PROP_TYPE = ['joint_pos', 'joint_vel', 'root_ang_vel_loc', 'root_lin_vel_loc', 'e_g']
@@ -162,8 +163,10 @@ def main():
     def one_step(_):
         eng.step_random(SIGMA)                             # ONE launch: draws a ~ N(0, sigma^2) on device and steps
         n_done[0] += 1
-        if traj is not None and n_done[0] % UNROLL == 0:   # the step kernel itself records the rows (ll_enable_trajectory);
-            traj.gather_async(n_done[0] // UNROLL - 1, 0)  # the gather of this unroll overlaps with the next unroll's steps
+        if traj is not None and n_done[0] % UNROLL == 0:   # the step kernel itself records the rows (ll_enable_unrolls);
+            k = n_done[0] // UNROLL - 1
+            traj.finish(k, GAMMA, LAMBDA)                  # TD(lambda) returns of the finished unroll (one small kernel, same stream)
+            traj.gather_async(k, 0)                        # the gather of this unroll overlaps with the next unroll's steps
 
     for t in range(args.warmup):
         one_step(t)
@@ -185,11 +188,24 @@ def main():
     elapsed = time.perf_counter() - t0
     k_ms, k_n = eng.kernel_time_ms()
     eng.enable_kernel_timing(False)
+    gather_check = None
     if world > 1:
         tt = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        if os.environ.get('LL_BENCH_VERIFY') and traj.n_gathered > 0:
+            # what rank 0 received for the last gathered unroll == what each rank's engine holds in that block (float64 checksums + probes)
+            k_last = traj.n_gathered - 1
+            mine = traj.half(k_last).double().cpu()
+            sig = [float(mine.sum()), float(mine.abs().sum()), float(mine[0, 0, 0]), float(mine[-1, -1, -1]), float(mine[n // 2, UNROLL // 2, 207])]
+            sigs = [None] * world
+            dist.all_gather_object(sigs, sig)
+            if rank == 0:
+                got = [o.double().cpu() for o in traj.last]
+                got_sig = [[float(g.sum()), float(g.abs().sum()), float(g[0, 0, 0]), float(g[-1, -1, -1]), float(g[n // 2, UNROLL // 2, 207])] for g in got]
+                gather_check = 'ok' if got_sig == sigs and len({tuple(x) for x in sigs}) == world else 'MISMATCH %r vs %r' % (got_sig, sigs)
     counters = eng.counters()
+    ep_hist = [int(x) for x in eng.episode_histogram()]
     triad = None
     if rank == 0 and world == 1 and tc:
         # the nominal HBM figure next to a device triad measured on this box (a = b + s * c on 3 x 1 GiB, torch's own kernel:
@@ -240,7 +256,9 @@ def main():
                                    '(62 clips), random-policy actions N(0, e^-2), auto-reset%s' % (n, ', RCCL trajectory gather to rank 0 every %d steps' % UNROLL if world > 1 else ''),
                        'envs_per_gpu': n, 'substeps_per_step': 10, 'solver_iterations': 10,
                        'episodes_finished_rank0': counters['episodes'], 'nonfinite_resets_rank0': counters['nonfinite'],
-                       'mean_episode_length_steps_rank0': (counters['env_steps'] / counters['episodes']) if counters['episodes'] else None},
+                       'mean_episode_length_steps_rank0': (counters['env_steps'] / counters['episodes']) if counters['episodes'] else None,
+                       'episode_length_histogram_rank0': {'bucket_lower_edges_steps': [1 << b for b in range(16)], 'episodes': ep_hist},
+                       **({'unrolls_gathered': traj.n_gathered, 'unroll_row_floats': int(traj.buf.shape[-1]), 'gather_check': gather_check} if traj is not None else {})},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBPS) if achieved else None, 'traffic': traffic, 'peak_measured_triad': triad,
                          'traffic_source': 'profiles/traffic.json (bytes per launch, FETCH_SIZE + WRITE_SIZE, uncorrected; see DESIGN.md 5.1)',

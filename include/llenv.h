@@ -169,6 +169,14 @@ int ll_step_scripted(ll_engine* e, const float* d_actions, const float* h_state,
  */
 int ll_probe_pd_torque(ll_engine* e, const float* h_rows, int n, int mode, float* h_tau);
 
+/*
+ * Deviation study: move one constant of the physics spec that is this build's own choice (ids LLM_SPEC_* in
+ * llenv_model.h: limit-row gate, depenetration cap, per-link damping, deepest-K, leg-leg rows on/off, their margin and count, ERP,
+ * contact margin).  Takes effect from the next step.  The shipped defaults are the spec; nothing in the product calls this.
+ */
+int ll_set_spec_param(ll_engine* e, int id, double value);
+int ll_get_spec_param(ll_engine* e, int id, double* value);
+
 /* Synthetic random policy a ~ N(0, sigma^2) per joint (sigma = exp(-2)), generated on
  * device by Philox keyed on (seed, env, step) into the engine's action buffer. */
 int ll_fill_random_actions(ll_engine* e, float sigma);
@@ -200,11 +208,33 @@ typedef struct ll_device_ptrs_t {
 } ll_device_ptrs_t;
 int ll_device_ptrs(ll_engine* e, ll_device_ptrs_t* out);
 
-/* Trajectory ring for the learner hand-off (replaces the actor's unroll buffer, learning/actors/distill_actor.py:84-176):
- * from now on every ll_step also writes, into slot (step index mod unroll) of a device buffer [unroll][n_envs][row_floats],
- * the row  obs_t[obs_dim] | action_t[12] | reward_t | done_t  of the transition it computes (obs_t = the observation the
- * action was chosen on).  Returns the device buffer (owned by the engine) and row_floats = obs_dim + 14. */
-int ll_enable_trajectory(ll_engine* e, int unroll, float** d_buffer, int* row_floats);
+/*
+ * Unroll buffers for the learner hand-off: replace the actor's unroll list and its
+ * structure -> flatten -> concatenate packing, learning/actors/distill_actor.py:118-162.  From now on every ll_step also writes the
+ * transition it computes into a device buffer [n_buffers][n_envs][unroll_length][row_floats]: step s goes to time step
+ * s % unroll_length of block (s / unroll_length) % n_buffers, so ONE ENV'S UNROLL IS CONTIGUOUS and -- read as float32 -- is the
+ * `unroll_np` the reference pushes for that env (golden: tests/golden/unroll_golden.npz).  A row is one flattened time step:
+ *     X    future[72] | prop[3 * prop_dim] | prop_a[36]    the observation the action was chosen on; the observation dict's keys
+ *                                                         in sorted order, as the flatten of the (absent) tleague data structure
+ *                                                         walks them [assumption stated in tests/golden/gen_unroll_golden.py]
+ *     A    action[12]
+ *     neglogp, R, V                                        the learner's remaining inputs (pmc_net.py:61-96: X, A, neglogp, R, V):
+ *                                                         neglogp and V as found in the engine's ll_pg_ptrs buffers when the step
+ *                                                         ran (written there by ll_policy_act_pg; zero if nobody did), R by
+ *                                                         ll_finish_unroll
+ *     r, 1 - done                                          what ll_finish_unroll computes R from
+ * row_floats = obs_dim + 17.  The buffer is owned by the engine.
+ */
+int ll_enable_unrolls(ll_engine* e, int unroll_length, int n_buffers, float** d_base, int* row_floats);
+/* Device buffers [n_envs] in which a policy leaves -log p(a|obs) and V(obs) for the actions it wrote into the action buffer. */
+int ll_pg_ptrs(ll_engine* e, float** d_neglogp, float** d_value);
+/*
+ * TD(lambda) returns of block `buffer` (what the actor of a PPO learner computes before it pushes an unroll; gamma, lam:
+ * example_pmc_train.sh:21-22): delta_t = r_t + gamma V_{t+1} m_t - V_t, A_t = delta_t + gamma lam m_t A_{t+1}, R_t = A_t + V_t with
+ * m_t = 1 - done_t and V_T = d_bootstrap_value[env] (NULL: the engine's value buffer, i.e. the policy's estimate for the
+ * observation that follows the block).  Asynchronous on the engine's stream.
+ */
+int ll_finish_unroll(ll_engine* e, int buffer, float gamma, float lam, const float* d_bootstrap_value);
 
 /* Host copies (synchronise the stream first). */
 int ll_get_obs(ll_engine* e, float* h_obs /*[n_envs][obs_dim]*/);
@@ -228,6 +258,9 @@ int ll_get_feet(ll_engine* e, float* h_feet_dyn /*[n_envs][4][3]*/, float* h_fee
 
 /* Counters for bench/diagnostics: total env-steps executed, episodes finished, non-finite resets. */
 int ll_get_counters(ll_engine* e, uint64_t* steps, uint64_t* episodes, uint64_t* nonfinite);
+/* Finished episodes by length since creation: counts16[b] = episodes of 2^b .. 2^(b+1) - 1 control steps (b = 15: and longer); SURVEY 8d asks
+ * for it next to the throughput so that the reset frequency of a benchmark is visible. */
+int ll_get_episode_histogram(ll_engine* e, uint64_t* counts16);
 
 /* Average device time (ms) of the step kernel over the launches since the last call, measured with
  * HIP events on the engine's own stream (bench.py roofline leg); also returns the launch count. */

@@ -55,4 +55,20 @@
                                            speeds up to 5 m/s per 2 ms substep; the capsules themselves are 35 mm thick */
 #define LLM_MAX_SELF 2                  /* self-collision rows per robot */
 
+/* ---- spec overrides for the deviation study (DESIGN.md 4 "known deviations"): ids of ll_set_spec_param / orc_set_spec_param.
+ * Every constant above that is this build's own choice rather than something the reference states can be moved at run time, in the
+ * engine and in the oracle alike, so that its effect on the trained reference policy can be measured (tools/deviation_table.py). */
+#define LLM_SPEC_LIMIT_GATE 0            /* rad/s   default LLM_LIMIT_GATE; 1e30 = every limit row enters the solve */
+#define LLM_SPEC_MAX_DEPEN_SPEED 1       /* m/s     default LLM_MAX_DEPEN_SPEED; 1e30 = uncapped ERP push-out */
+#define LLM_SPEC_LINK_DAMPING 2          /* 1/s     default LLM_LINK_DAMPING */
+#define LLM_SPEC_MAX_CONTACTS_PER_LEG 3  /* 1..4    default LLM_MAX_CONTACTS_PER_LEG (the deepest-K rule) */
+#define LLM_SPEC_SELF_COLLISION 4        /* 0 / 1   leg-leg capsule rows on / off */
+#define LLM_SPEC_SELF_MARGIN 5           /* m       default LLM_SELF_MARGIN */
+#define LLM_SPEC_MAX_SELF 6              /* 0..2    default LLM_MAX_SELF */
+#define LLM_SPEC_ERP 7                   /*         default LLM_ERP */
+#define LLM_SPEC_CONTACT_MARGIN 8        /* m       default LLM_CONTACT_MARGIN */
+#define LLM_SPEC_SELF_FRICTION 9         /* mu of two tangential rows per leg-leg contact; default 0 (frictionless).  ORACLE ONLY */
+#define LLM_SPEC_WARM_START 10           /* factor applied to the previous substep's multipliers of persisting rows; default 0 = none.  ORACLE ONLY */
+#define LLM_SPEC_COUNT 11
+
 #endif

@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 #define LLP_N_ARRAYS 28      /* the model's arrays in the order of the reference's checkpoint (tools/extract_policy.py) */
-#define LLP_N_FLOATS 358647  /* their total size: rms 135+135+72+72, vf head (unused), encoder, codebook, llc, decoder, logstd */
+#define LLP_N_FLOATS 358647  /* their total size: rms 135+135+72+72, vf head, encoder, codebook, llc, decoder, logstd */
 #define LLP_OBS_DIM 207
 #define LLP_ACT_DIM 12
 
@@ -34,6 +34,18 @@ int ll_policy_destroy(ll_policy* p);
 /* mean action of every env: d_obs [n_envs][207] -> d_actions [n_envs][12]; d_code (nullable) [n_envs] int32 receives the index
  * of the chosen code.  Asynchronous on hip_stream (NULL: the default stream). */
 int ll_policy_act(ll_policy* p, const float* d_obs, float* d_actions, int32_t* d_code, int n_envs, void* hip_stream);
+/*
+ * The same forward pass as the ACTOR of a policy-gradient learner needs it (learner inputs pmc_net.py:61-96):
+ *   sample != 0   a ~ DiagGaussian(mean, exp(logstd)) (pmc_net.py:109-113) drawn with Philox4x32-10 keyed on (seed; env, step)
+ *                 -- the same (seed, step) gives the same actions -- instead of the mean action;
+ *   d_neglogp     (nullable) [n_envs]  -log p(a | obs) of the emitted action, DiagGaussianPd.neglogp:
+ *                 0.5 sum ((a - mean) / std)^2 + 6 log(2 pi) + sum logstd;
+ *   d_value       (nullable) [n_envs]  the value head tanh(207 -> 256) -> tanh(256) -> 1 (pmc_net.py:141-146), arrays w04..w09.
+ * Written next to the actions, typically into the engine's own buffers (ll_pg_ptrs), from where the step kernel copies them into
+ * the unroll it records (ll_enable_unrolls).
+ */
+int ll_policy_act_pg(ll_policy* p, const float* d_obs, float* d_actions, int32_t* d_code, float* d_neglogp, float* d_value, int n_envs, uint64_t seed,
+                     uint64_t step, int sample, void* hip_stream);
 /* HIP-event time of the ll_policy_act launches since the last call (like ll_kernel_time_ms). */
 int ll_policy_enable_timing(ll_policy* p, int on);
 int ll_policy_time_ms(ll_policy* p, double* avg_ms, int* n_launches);

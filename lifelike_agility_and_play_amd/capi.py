@@ -19,6 +19,8 @@ PLE_DEFAULT_REWARD_WEIGHTS = {'joint_pos': 0.6, 'joint_vel': 0.05, 'end_effector
                               'root_vel': 0.1}                                                       # PLE:359-363
 
 DONE_FALL, DONE_CLIP_END, DONE_DIVERGED, DONE_COLLISION, DONE_NONFINITE = 1, 2, 4, 8, 16
+SPEC_IDS = dict(limit_gate=0, max_depen_speed=1, link_damping=2, max_contacts_per_leg=3, self_collision=4, self_margin=5, max_self=6,
+                erp=7, contact_margin=8, self_friction=9, warm_start=10)                                       # include/llenv_model.h LLM_SPEC_*
 LL_DONE_FALL, LL_DONE_CLIP_END, LL_DONE_DIVERGED, LL_DONE_COLLISION, LL_DONE_NONFINITE = 1, 2, 4, 8, 16      # include/llenv.h:65-69
 LL_OK, LL_EINVAL, LL_ENOMEM, LL_EHIP, LL_ESTATE, LL_ENODEV = 0, -1, -2, -3, -4, -5                           # include/llenv.h:57-62
 
@@ -84,11 +86,15 @@ _SIGS = {
     'll_step': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_step_scripted': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'll_probe_pd_torque': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'll_set_spec_param': (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    'll_get_spec_param': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     'll_fill_random_actions': (C.c_int, [C.c_void_p, C.c_float]),
     'll_step_random': (C.c_int, [C.c_void_p, C.c_float]),
     'll_sync': (C.c_int, [C.c_void_p]),
     'll_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
-    'll_enable_trajectory': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    'll_enable_unrolls': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    'll_pg_ptrs': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    'll_finish_unroll': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     'll_device_ptrs': (C.c_int, [C.c_void_p, C.POINTER(LLDevicePtrs)]),
     'll_get_obs': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_get_terminal_obs': (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -102,6 +108,7 @@ _SIGS = {
     'll_set_sampling_table': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_get_feet': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'll_get_counters': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'll_get_episode_histogram': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_kernel_time_ms': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'll_enable_kernel_timing': (C.c_int, [C.c_void_p, C.c_int]),
 }
@@ -204,6 +211,16 @@ class Engine(object):
         self._chk(self.lib.ll_probe_pd_torque(self.h, _ptr(rows), len(rows), int(mode), _ptr(tau)))
         return tau
 
+    def set_spec(self, **kw):
+        """Deviation study (ll_set_spec_param): e.g. set_spec(limit_gate=1e30, max_contacts_per_leg=2)."""
+        for k, v in kw.items():
+            self._chk(self.lib.ll_set_spec_param(self.h, SPEC_IDS[k], float(v)))
+
+    def get_spec(self, key):
+        v = C.c_double()
+        self._chk(self.lib.ll_get_spec_param(self.h, SPEC_IDS[key], C.byref(v)))
+        return v.value
+
     def fill_random_actions(self, sigma):
         self._chk(self.lib.ll_fill_random_actions(self.h, float(sigma)))
 
@@ -221,11 +238,20 @@ class Engine(object):
             raise ValueError('the legacy default stream (handle 0) cannot be shared; pass a torch.cuda.Stream handle, or None for the private stream')
         self._chk(self.lib.ll_set_stream(self.h, C.c_void_p(int(stream_handle)) if stream_handle is not None else None))
 
-    def enable_trajectory(self, unroll):
-        """-> (device address, row_floats) of the [unroll][n_envs][row_floats] ring written by every step"""
+    def enable_unrolls(self, unroll_length, n_buffers=2):
+        """-> (device address, row_floats) of the [n_buffers][n_envs][unroll_length][row_floats] unroll buffers every step writes into"""
         buf, w = C.c_void_p(), C.c_int()
-        self._chk(self.lib.ll_enable_trajectory(self.h, int(unroll), C.byref(buf), C.byref(w)))
+        self._chk(self.lib.ll_enable_unrolls(self.h, int(unroll_length), int(n_buffers), C.byref(buf), C.byref(w)))
         return buf.value, w.value
+
+    def pg_ptrs(self):
+        """-> device addresses of the [n_envs] neglogp and value buffers a policy fills next to the action buffer"""
+        a, b = C.c_void_p(), C.c_void_p()
+        self._chk(self.lib.ll_pg_ptrs(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def finish_unroll(self, buffer, gamma, lam, d_bootstrap_value=None):
+        self._chk(self.lib.ll_finish_unroll(self.h, int(buffer), float(gamma), float(lam), C.c_void_p(int(d_bootstrap_value)) if d_bootstrap_value else None))
 
     def device_ptrs(self):
         p = LLDevicePtrs()
@@ -290,6 +316,12 @@ class Engine(object):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._chk(self.lib.ll_get_counters(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(env_steps=a.value, episodes=b.value, nonfinite=c.value)
+
+    def episode_histogram(self):
+        """finished episodes by length: counts[b] = episodes of 2^b .. 2^(b+1) - 1 control steps (b = 15: and longer)"""
+        c = np.zeros(16, dtype=np.uint64)
+        self._chk(self.lib.ll_get_episode_histogram(self.h, _ptr(c)))
+        return c
 
     def enable_kernel_timing(self, on=True):
         self._chk(self.lib.ll_enable_kernel_timing(self.h, int(on)))

@@ -373,6 +373,8 @@ struct GpuLanes {
   // (the index is clamped rather than the load predicated: a predicated load is a branch, and a wait, per chunk; n >= 1)
   LL_D F ld16(const float* src, int i0, int n) const { const int i = i0 + lane16_; const float v = src[i < n ? i : n - 1]; return i < n ? v : 0.0f; }
   LL_D void st16(float* dst, int i0, int n, F v) const { const int i = i0 + lane16_; if (i < n) dst[i] = v; }
+  // the same with the row rotated: element i goes to i + (n - split) if i < split, else to i - split  (obs row prop | prop_a | future -> future | prop | prop_a)
+  LL_D void st16_rot(float* dst, int i0, int n, int split, F v) const { const int i = i0 + lane16_; if (i < n) dst[i < split ? i + (n - split) : i - split] = v; }
   // number of entries of the non-decreasing table p[0..n) that are <= u: sixteen entries per round trip, row-summed
   LL_D int count_le16(const double* p, int n, double u) const {
     float c = 0.0f;

@@ -210,6 +210,22 @@ __global__ __launch_bounds__(PMC_WAVE) void pmc_probe_pd_kernel(StepParams P, co
   K::probe_pd(ln, P, in + (long)i * 36, out + (long)i * 12, mode);
 }
 
+// ll_finish_unroll: one thread per env walks its unroll backwards (rows are [obs_dim | A 12 | neglogp | R | V | r | 1 - done])
+__global__ void pmc_gae_kernel(float* block, int n_envs, int unroll, int W, int od, float gamma, float lam, const float* bootstrap) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n_envs) return;
+  float* rows = block + (size_t)env * unroll * W;
+  float adv = 0.0f, vnext = bootstrap[env];
+  for (int t = unroll - 1; t >= 0; t--) {
+    float* r = rows + (size_t)t * W + od;
+    const float V = r[14], m = r[16];
+    const float delta = r[15] + gamma * vnext * m - V;
+    adv = delta + gamma * lam * m * adv;
+    r[13] = adv + V;
+    vnext = V;
+  }
+}
+
 __global__ void pmc_actions_kernel(StepParams P, float* actions, float sigma) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= P.n_envs * 3) return;
@@ -328,6 +344,11 @@ struct HipBackend {
   void launch_probe_pd(const StepParams& P, const float* in, float* out, int n, int mode) {
     use();
     hipLaunchKernelGGL(pmc_probe_pd_kernel, dim3((n + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE), dim3(PMC_WAVE), lds_bytes(), stream, P, in, out, n, mode);
+    HIPCHK(hipGetLastError());
+  }
+  void launch_gae(float* block, int n_envs, int unroll, int W, int od, float gamma, float lam, const float* bootstrap) {
+    use();
+    hipLaunchKernelGGL(pmc_gae_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, stream, block, n_envs, unroll, W, od, gamma, lam, bootstrap);
     HIPCHK(hipGetLastError());
   }
   void launch_actions(const StepParams& P, float* actions, float sigma) {

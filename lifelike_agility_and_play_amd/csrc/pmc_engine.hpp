@@ -23,8 +23,9 @@ struct PmcEngine {
   // table state (device, float64)
   double *d_avg_reward = nullptr, *d_avg_len = nullptr, *d_prob = nullptr, *d_cdf = nullptr;
   float* d_actions = nullptr;       // engine-owned action buffer
-  float* d_traj = nullptr;          // optional trajectory ring [unroll][n_envs][obs_dim + 14]
-  int traj_unroll = 0;
+  float* d_traj = nullptr;          // optional unroll buffers [n_buffers][n_envs][unroll][obs_dim + LL_UNROLL_EXTRA]
+  int traj_unroll = 0, traj_buffers = 0;
+  float *d_neglogp = nullptr, *d_value = nullptr;   // [n_envs] policy outputs that accompany the actions (ll_pg_ptrs)
   int32_t* d_reset_ids = nullptr;   // scratch for ll_reset
   int32_t* d_reset_clip = nullptr;
   double* d_reset_t0 = nullptr;
@@ -64,8 +65,10 @@ struct PmcEngine {
     P.obs = dalloc<float>(N * P.obs_dim); P.term_obs = dalloc<float>(N * P.obs_dim);
     P.reward = dalloc<float>(N); P.done = dalloc<uint8_t>(N); P.done_reason = dalloc<uint8_t>(N);
     d_actions = dalloc<float>(N * 12);
+    d_neglogp = dalloc<float>(N); d_value = dalloc<float>(N);
     P.actions = d_actions;
     P.counters = dalloc<unsigned long long>(4 + (size_t)PMC_TS_SLOTS * N);
+    P.ep_hist = dalloc<unsigned long long>(16);
     P.block_ticket = dalloc<unsigned int>(2);
     P.actions_out = d_actions;
     d_reset_ids = dalloc<int32_t>(N); d_reset_clip = dalloc<int32_t>(N); d_reset_t0 = dalloc<double>(N);
@@ -186,8 +189,7 @@ struct PmcEngine {
     StepParams Q = P;
     Q.actions = d_act ? d_act : d_actions;
     Q.action_sigma = sigma;
-    Q.traj = d_traj;
-    Q.traj_slot = traj_unroll ? (int)(P.step_count % (uint64_t)traj_unroll) : 0;
+    set_unroll_slot(Q);
     bk.launch_step(Q);
     P.step_count += 1;
   }
@@ -210,8 +212,7 @@ struct PmcEngine {
     Q.actions = d_act ? d_act : d_actions;
     Q.scripted_state = d_script_state;
     Q.scripted_feet = h_feet ? d_script_feet : nullptr;
-    Q.traj = d_traj;
-    Q.traj_slot = traj_unroll ? (int)(P.step_count % (uint64_t)traj_unroll) : 0;
+    set_unroll_slot(Q);
     bk.launch_step(Q);
     P.step_count += 1;
   }
@@ -228,12 +229,30 @@ struct PmcEngine {
     } catch (...) { bk.release(d_in); bk.release(d_out); throw; }
     bk.release(d_in); bk.release(d_out);
   }
-  // keep the last `unroll` transitions of every env in HBM, in the layout the learner rank gathers
-  void enable_trajectory(int unroll) {
-    if (unroll <= 0) throw PmcError(LL_EINVAL, "unroll must be positive");
-    if (d_traj) throw PmcError(LL_ESTATE, "trajectory ring already enabled");
-    d_traj = dalloc<float>((size_t)unroll * P.n_envs * (P.obs_dim + 14));
-    traj_unroll = unroll;
+  // record every env's transitions as unrolls in HBM, in the layout the learner consumes: n_buffers blocks of
+  // [n_envs][unroll][row]; step s writes time step s % unroll of block (s / unroll) % n_buffers, so a finished block can be handed
+  // off (RCCL gather) while the next one fills.
+  void enable_unrolls(int unroll, int n_buffers) {
+    if (unroll <= 0 || n_buffers <= 0) throw PmcError(LL_EINVAL, "unroll length and buffer count must be positive");
+    if (d_traj) throw PmcError(LL_ESTATE, "unroll buffers already enabled");
+    d_traj = dalloc<float>((size_t)n_buffers * P.n_envs * unroll * (P.obs_dim + LL_UNROLL_EXTRA));
+    traj_unroll = unroll; traj_buffers = n_buffers;
+  }
+  void set_unroll_slot(StepParams& Q) const {
+    Q.traj = d_traj;
+    Q.traj_unroll = traj_unroll;
+    Q.traj_slot = traj_unroll ? (int)(P.step_count % (uint64_t)traj_unroll) : 0;
+    Q.traj_buf = traj_unroll ? (int)((P.step_count / (uint64_t)traj_unroll) % (uint64_t)traj_buffers) : 0;
+    Q.neglogp = d_neglogp; Q.value = d_value;
+  }
+  // TD(lambda) returns of one finished block (the actor-side post-processing of a PPO learner's data: R = GAE advantage + V):
+  //   delta_t = r_t + gamma V_{t+1} m_t - V_t,  A_t = delta_t + gamma lam m_t A_{t+1},  R_t = A_t + V_t,  m_t = 1 - done_t,
+  // V_T = bootstrap[env] (the value of the observation after the block's last step; masked when that step ended the episode)
+  void finish_unroll(int buffer, float gamma, float lam, const float* d_bootstrap) {
+    if (!d_traj) throw PmcError(LL_ESTATE, "ll_enable_unrolls must be called first");
+    if (buffer < 0 || buffer >= traj_buffers) throw PmcError(LL_EINVAL, "buffer index out of range");
+    bk.launch_gae(d_traj + (size_t)buffer * P.n_envs * traj_unroll * (P.obs_dim + LL_UNROLL_EXTRA), P.n_envs, traj_unroll, P.obs_dim + LL_UNROLL_EXTRA,
+                  P.obs_dim, gamma, lam, d_bootstrap ? d_bootstrap : d_value);
   }
   void fill_random_actions(float sigma) {
     need(true, false);

@@ -2,6 +2,7 @@
 #pragma once
 #include <stdint.h>
 
+#define LL_UNROLL_EXTRA 17   // floats of an unroll row after the observation: A 12, neglogp, R, V, r, 1 - done
 #define PMC_K 4            // contact slots per leg lane (== LLM_MAX_CONTACTS_PER_LEG)
 #define PMC_WAVE 64
 #define PMC_ENVS_PER_WAVE 4     // one env = one 16-lane DPP row
@@ -75,7 +76,9 @@ struct StepParams {
   float mu_foot, mu_link, gravity, link_damping;
   float erp, margin_dist, limit_gate, self_collision;   // self_collision: 1 = links of different legs collide (LR:212-217)
   float rw[5];              // normalised reward weights (PLE:365-370)
-  float pad4;
+  float max_depen;          // cap on the penetration-recovery speed of a contact row (LLM_MAX_DEPEN_SPEED)
+  float self_margin, pad4;  // leg-leg capsule rows start within this distance (LLM_SELF_MARGIN)
+  int32_t max_contacts, max_self;   // deepest-K per leg (LLM_MAX_CONTACTS_PER_LEG), self-collision rows per robot (LLM_MAX_SELF)
   double dt_d, frame_step, policy_step, sample_factor;
   uint64_t seed;
   uint64_t step_count;      // control steps executed so far (salts the Philox stream)
@@ -99,8 +102,13 @@ struct StepParams {
   // parity hook (ll_step_scripted): physics result and foot positions supplied by the caller, rows [n_envs][37] / [n_envs][24]
   const float* scripted_state;
   const float* scripted_feet;
-  float* traj;              // optional [unroll][n_envs][obs_dim + 14] trajectory ring: obs_t | action_t | reward_t | done_t
-  int32_t traj_slot, traj_pad;
+  // optional unroll buffers for the learner hand-off (ll_enable_unrolls): [n_buffers][n_envs][unroll][obs_dim + LL_UNROLL_EXTRA], one
+  // env's unroll contiguous and its time step laid out the way the reference's actor flattens it (distill_actor.py:118-162):
+  //   X: future 72 | prop | prop_a 36   (the observation dict's keys in sorted order)   | A 12 | neglogp | R | V | r | 1 - done
+  float* traj;
+  int32_t traj_slot, traj_buf, traj_unroll, traj_pad;
+  const float* neglogp;     // [n_envs] what the policy reported for the actions being applied (ll_pg_ptrs), copied into the unroll
+  const float* value;       // [n_envs]
   // mocap
   const double* frames;     // [total][19]
   const int32_t* clip_off;
@@ -123,6 +131,7 @@ struct StepParams {
   unsigned long long* pending_reward;  // [n_clips] packed (env+1)<<32 | float bits of reward_sum/max_steps
   unsigned long long* pending_len;     // [n_clips] packed (env+1)<<32 | float bits of avg_episode_len
   unsigned long long* counters;        // [4] env-steps, episodes, non-finite resets, -
+  unsigned long long* ep_hist;         // [16] finished episodes by length: bucket b counts lengths in [2^b, 2^(b+1)) control steps (the last: and longer)
   // constants
   const float* legc;        // [LC_COUNT][4]
   const float* candc;       // [CAND_TABLE_WORDS][16]

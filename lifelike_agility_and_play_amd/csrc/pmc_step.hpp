@@ -700,6 +700,7 @@ struct Pmc {
     // the leg keeps its 4 deepest candidates, slot s = s-th deepest: four rounds of (local min, quad min, claim)
     F my_depth = far_, my_sub = zero, my_jj = zero;
     for (int s = 0; s < PMC_K; s++) {
+      if (s >= P.max_contacts) break;                       // (spec override LLM_SPEC_MAX_CONTACTS_PER_LEG; 4 unless a deviation study says otherwise)
       F m = depth[0], am = zero;
       for (int jj = 1; jj < NC; jj++) {
         B lt = depth[jj] < m;
@@ -826,7 +827,7 @@ struct Pmc {
         }
       }
       F depth_c = my_depth;
-      F bias = lm::sel(depth_c > 0.0f, depth_c * inv_dt, lm::max_(depth_c * (P.erp * inv_dt), ln.lane_f(-(float)LLM_MAX_DEPEN_SPEED)));
+      F bias = lm::sel(depth_c > 0.0f, depth_c * inv_dt, lm::max_(depth_c * (P.erp * inv_dt), ln.lane_f(-P.max_depen)));
       // joint j moves the point iff the point's link is at or below joint j: link >= j+1
       F on1 = lm::sel(link > 0.5f, one, zero), on2 = lm::sel(link > 1.5f, one, zero), on3 = lm::sel(link > 2.5f, one, zero);
       V3l rr1 = Pb - k.p1, rr2 = Pb - k.p2, rr3 = Pb - k.p3;
@@ -884,14 +885,15 @@ struct Pmc {
         F lp = (pass == 0) ? lm::sel(legf < 0.5f, ln.lane_f(3.0f), legf - one) : legf + ln.lane_f(4.0f);
         F sp = (pass == 0) ? subf : lm::sel(own_s, one, zero) + lm::sel(oth_s, ln.lane_f(2.0f), zero);
         cpair[pass] = lp * 4.0f + sp;
-        B valid = lm::and_(dep < (float)LLM_SELF_MARGIN, len > 1e-9f);
+        B valid = lm::and_(dep < P.self_margin, len > 1e-9f);
         if (pass == 1) valid = lm::and_(valid, legf < 1.5f);                    // pairs {0,2} and {1,3}, once each
         cd[pass] = lm::sel(valid, dep, far_);
       }
-      any_self = L::any(lm::min_(cd[0], cd[1]) < 1.0e29f) && !PMC_ABL(256);          // (ablation 256: detection only)
+      any_self = L::any(lm::min_(cd[0], cd[1]) < 1.0e29f) && !PMC_ABL(256) && P.max_self > 0;          // (ablation 256: detection only)
       if (any_self) {
         LL_UNROLL
         for (int slot = 0; slot < 2; slot++) {
+          if (slot >= P.max_self) break;                                             // (spec override LLM_SPEC_MAX_SELF)
           if (slot == 1 && !L::any(lm::min_(cd[0], cd[1]) < 1.0e29f)) break;        // nobody in the wave has a second one
           n_self_w = slot + 1;
           F dlane = lm::min_(cd[0], cd[1]);
@@ -933,7 +935,7 @@ struct Pmc {
           float nn = L::qsum(sjt[0] * sjt[0] + sjt[1] * sjt[1] + sjt[2] * sjt[2]);
           for (int i = 0; i < 6; i++) nn += sgt[i] * sgt[i];
           self_row_pack(ln, sjt, sgt, rw);
-          rw.c = vrow + ((dmin > 0.0f) ? dmin * inv_dt : fmaxf(dmin * (P.erp * inv_dt), -(float)LLM_MAX_DEPEN_SPEED));
+          rw.c = vrow + ((dmin > 0.0f) ? dmin * inv_dt : fmaxf(dmin * (P.erp * inv_dt), -P.max_depen));
           rw.inv = have ? 1.0f / nn : 0.0f;
           rw.lam = 0.0f;
           if (!have) self_row_clear(ln, rw);
@@ -1105,7 +1107,7 @@ struct Pmc {
             for (int i = 0; i < 6; i++) nn += sgt[i] * sgt[i];
             self_row_pack(ln, sjt, sgt, rw);
             const float vo = ln.peer_u(vrow), no = ln.peer_u(nn);
-            rw.c = ((me == 0) ? vrow + vo : vo + vrow) + ((dmin > 0.0f) ? dmin * inv_dt : fmaxf(dmin * (P.erp * inv_dt), -(float)LLM_MAX_DEPEN_SPEED));
+            rw.c = ((me == 0) ? vrow + vo : vo + vrow) + ((dmin > 0.0f) ? dmin * inv_dt : fmaxf(dmin * (P.erp * inv_dt), -P.max_depen));
             rw.inv = have ? 1.0f / ((me == 0) ? nn + no : no + nn) : 0.0f;
             rw.lam = 0.0f;
             if (!have) self_row_clear(ln, rw);
@@ -1462,9 +1464,12 @@ struct Pmc {
     ObsIn oin = obs_gather(ln, P, row, false, rows, fid, frac);
     constexpr int TRAJ_CHUNKS = 13;                                          // obs_dim <= 207
     F told[TRAJ_CHUNKS];
+    float t_neglogp = 0.0f, t_value = 0.0f;
     if (P.traj) {
       LL_UNROLL
       for (int c = 0; c < TRAJ_CHUNKS; c++) told[c] = ln.ld16(row, 16 * c, P.obs_dim);
+      if (P.neglogp) t_neglogp = P.neglogp[env];
+      if (P.value) t_value = P.value[env];
     }
     const int steps = P.ep_steps[env] + 1;                                    // PLE:197
     const float rsum0 = P.reward_sum[env];
@@ -1536,16 +1541,20 @@ struct Pmc {
     const float rsum = rsum0 + reward;                                        // PLE:231
 
     PMC_TS(4);
-    // --- trajectory row for the learner: the observation the policy acted on, its action, the reward
-    //     and done flag of this transition; written before the obs row is replaced ---
+    // --- this transition's row of the env's unroll (distill_actor.py:118-162): the observation the policy acted on
+    //     in the learner's flatten order (future first: dict keys sorted), its action, neglogp and value as the policy reported
+    //     them, the reward and the not-done mask; R is filled in by ll_finish_unroll.  Written before the obs row is replaced. ---
     if (P.traj) {
-      const int W = P.obs_dim + 14;
-      float* tr = P.traj + ((long)P.traj_slot * N + env) * W;
+      const int W = P.obs_dim + LL_UNROLL_EXTRA, od = P.obs_dim;
+      float* tr = P.traj + ((((long)P.traj_buf * N + env) * P.traj_unroll) + P.traj_slot) * W;
       LL_UNROLL
-      for (int c = 0; c < TRAJ_CHUNKS; c++) ln.st16(tr, 16 * c, P.obs_dim, told[c]);
-      for (int j = 0; j < 3; j++) ln.stl(tr, P.obs_dim + j, 3, act[j]);
-      tr[P.obs_dim + 12] = reward;
-      tr[P.obs_dim + 13] = reason ? 1.0f : 0.0f;
+      for (int c = 0; c < TRAJ_CHUNKS; c++) ln.st16_rot(tr, 16 * c, od, od - 72, told[c]);
+      for (int j = 0; j < 3; j++) ln.stl(tr, od + j, 3, act[j]);
+      tr[od + 12] = t_neglogp;
+      tr[od + 13] = 0.0f;
+      tr[od + 14] = t_value;
+      tr[od + 15] = reward;
+      tr[od + 16] = reason ? 0.0f : 1.0f;
     }
 
     PMC_TS(5);
@@ -1564,6 +1573,11 @@ struct Pmc {
       publish_max(ln, P.pending_len + clip, tag | (unsigned long long)f2u(avg_l));
       count_add(ln, P.counters + 1);
       if (bad) count_add(ln, P.counters + 2);
+      {
+        int b = 0;
+        for (int s2 = steps; s2 > 1 && b < 15; s2 >>= 1) b++;                 // floor(log2(steps)), capped
+        count_add(ln, P.ep_hist + b);
+      }
       if (ar) {
         // auto-reset inside the step (PLE:150-171 + ML:48-63): the env continues from a freshly sampled (clip, t0); only what
         // differs from a running env is done here -- the pose and the four future sites are re-read at the new place, and

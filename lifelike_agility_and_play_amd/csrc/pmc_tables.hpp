@@ -239,6 +239,8 @@ static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
   P.margin_dist = (float)LLM_CONTACT_MARGIN;
   P.limit_gate = (float)LLM_LIMIT_GATE;
   P.self_collision = 1.0f;
+  P.max_depen = (float)LLM_MAX_DEPEN_SPEED; P.self_margin = (float)LLM_SELF_MARGIN;
+  P.max_contacts = LLM_MAX_CONTACTS_PER_LEG; P.max_self = LLM_MAX_SELF;
   double sw = 0;
   for (int i = 0; i < 5; i++) sw += cfg.reward_weights[i];               // PLE:365
   if (!(sw > 0)) return "reward_weights must sum to a positive number";
@@ -270,4 +272,44 @@ static inline void pmc_fill_mocap(StepParams& P, int n_clips, double frame_step)
   P.frame_step = frame_step;
   P.frame_rate = (int)(1.0 / frame_step);
   P.margin = (int)ceil(P.policy_step / frame_step) + P.frame_rate + 2;
+}
+
+// ll_set_spec_param / ll_get_spec_param (include/llenv_model.h LLM_SPEC_*): the constants of the physics spec that are this build's own
+// choice, movable at run time for the deviation study.  Returns "" or a message.
+inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
+  switch (id) {
+    case LLM_SPEC_LIMIT_GATE: P.limit_gate = (float)v; break;
+    case LLM_SPEC_MAX_DEPEN_SPEED: P.max_depen = (float)v; break;
+    case LLM_SPEC_LINK_DAMPING: P.link_damping = (float)v; break;
+    case LLM_SPEC_MAX_CONTACTS_PER_LEG:
+      if (!(v >= 1 && v <= LLM_MAX_CONTACTS_PER_LEG)) return "max contacts per leg must be 1..4";
+      P.max_contacts = (int)v; break;
+    case LLM_SPEC_SELF_COLLISION: P.self_collision = v > 0.5 ? 1.0f : 0.0f; break;
+    case LLM_SPEC_SELF_MARGIN: P.self_margin = (float)v; break;
+    case LLM_SPEC_MAX_SELF:
+      if (!(v >= 0 && v <= LLM_MAX_SELF)) return "self-collision rows per robot must be 0..2";
+      P.max_self = (int)v; break;
+    case LLM_SPEC_ERP: P.erp = (float)v; break;
+    case LLM_SPEC_CONTACT_MARGIN: P.margin_dist = (float)v; break;
+    case LLM_SPEC_SELF_FRICTION:
+    case LLM_SPEC_WARM_START:
+      if (v != 0.0) return "this switch exists in the oracle only (tools/deviation_table.py reports what it is worth)";
+      break;
+    default: return "unknown spec parameter id";
+  }
+  return "";
+}
+inline double pmc_get_spec_param(const StepParams& P, int id) {
+  switch (id) {
+    case LLM_SPEC_LIMIT_GATE: return P.limit_gate;
+    case LLM_SPEC_MAX_DEPEN_SPEED: return P.max_depen;
+    case LLM_SPEC_LINK_DAMPING: return P.link_damping;
+    case LLM_SPEC_MAX_CONTACTS_PER_LEG: return P.max_contacts;
+    case LLM_SPEC_SELF_COLLISION: return P.self_collision;
+    case LLM_SPEC_SELF_MARGIN: return P.self_margin;
+    case LLM_SPEC_MAX_SELF: return P.max_self;
+    case LLM_SPEC_ERP: return P.erp;
+    case LLM_SPEC_CONTACT_MARGIN: return P.margin_dist;
+    default: return 0.0;
+  }
 }

@@ -5,9 +5,11 @@ ZeroMQ (learning/actors/distill_actor.py:84-176, push at :167).  Here each GPU r
 ring in HBM and, once per unroll, the rows are gathered to the learner rank with one RCCL collective
 (torch.distributed backend "nccl" IS RCCL on ROCm).  Envs never communicate per step.
 
-Row layout (float32): obs[obs_dim] | action[12] | reward | done   (222 floats for the PMC obs of 207).
+Row layout (float32, include/llenv.h ll_enable_unrolls): one flattened time step of the learner's data structure,
+future[72] | prop | prop_a[36] | action[12] | neglogp | R | V | r | 1 - done   (224 floats for the PMC obs of 207), one env's
+unroll contiguous: a rank's block [n_envs][unroll][224] is n_envs of the `unroll_np` arrays the reference pushes.
 xGMI is point-to-point: a gather into rank 0 arrives over 7 different links, so it is per-link bound
-(~153 GB/s per peer): 4096 envs x 128 steps x 888 B = 466 MB per rank per unroll ~ 3 ms, once per 128 steps.
+(~153 GB/s per peer): 4096 envs x 128 steps x 896 B = 470 MB per rank per unroll ~ 3 ms, once per 128 steps.
 """
 import numpy as np
 import torch
@@ -86,27 +88,49 @@ def gather_unroll(local, dst=0, group=None):
     return None
 
 
-class TrajectoryBuffer(object):
-    """The engine's own trajectory ring ([slots][n_envs][obs|action|reward|done], written inside the step kernel) as a torch
-    tensor, plus the hand-off to the learner rank.
+def flatten_unroll(obs_dicts, actions):
+    """The reference's wire format for one env's unroll, host-side statement (distill_actor.py:159-162 over a data structure whose
+    flatten walks the observation dict in sorted key order): time-major, per time step  future | prop | prop_a | action.
+    Pinned by tests/golden/unroll_golden.npz; the device rows written by the step kernel start with exactly these floats."""
+    return np.concatenate([np.concatenate([np.asarray(o[k]).reshape(-1) for k in sorted(o)] + [np.asarray(a).reshape(-1)]) for o, a in zip(obs_dicts, actions)])
 
-    The ring holds TWO unrolls: while the steps of unroll k+1 fill one half, the gather of unroll k (the other half) is in
-    flight on RCCL's own stream (``async_op``), so the collective overlaps with simulation instead of stalling it.  xGMI is
-    point-to-point, so rank 0 receives over 7 different links at once."""
+
+UNROLL_FIELDS = ('X', 'A', 'neglogp', 'R', 'V', 'r', 'mask')
+
+
+def split_row(rows, obs_dim):
+    """views of an unroll block [..., obs_dim + 17]: the learner's inputs X, A, neglogp, R, V (pmc_net.py:61-96) and r, mask = 1 - done"""
+    od = obs_dim
+    return dict(X=rows[..., :od], A=rows[..., od:od + 12], neglogp=rows[..., od + 12], R=rows[..., od + 13], V=rows[..., od + 14],
+                r=rows[..., od + 15], mask=rows[..., od + 16])
+
+
+class TrajectoryBuffer(object):
+    """The engine's own unroll buffers ([2][n_envs][unroll][row], written inside the step kernel) as a torch tensor, plus the
+    hand-off to the learner rank.
+
+    TWO blocks: while the steps of unroll k+1 fill one, the gather of unroll k (the other) is in flight on RCCL's own stream
+    (``async_op``), so the collective overlaps with simulation instead of stalling it.  xGMI is point-to-point, so rank 0
+    receives over 7 different links at once."""
 
     def __init__(self, engine, unroll, host_memory=False):
-        ptr, w = engine.enable_trajectory(2 * unroll)
+        ptr, w = engine.enable_unrolls(unroll, 2)
         self.engine = engine
         self.unroll = unroll
         mk = host_tensor if host_memory else device_tensor
-        self.buf = mk(ptr, (2 * unroll, engine.n_envs, w))
+        self.buf = mk(ptr, (2, engine.n_envs, unroll, w))
         self.outs = None
         self.work = None
         self.last = None
         self.n_gathered = 0
 
     def half(self, k):
-        return self.buf[(k % 2) * self.unroll:(k % 2 + 1) * self.unroll]
+        return self.buf[k % 2]
+
+    def finish(self, k, gamma=0.95, lam=0.95):
+        """TD(lambda) returns of unroll k (ll_finish_unroll), bootstrapped from the engine's value buffer: call it after the policy
+        has evaluated the observation that follows the unroll and before gathering."""
+        self.engine.finish_unroll(k % 2, gamma, lam)
 
     def wait(self):
         if self.work is not None:
@@ -114,12 +138,12 @@ class TrajectoryBuffer(object):
             self.work = None
 
     def gather_async(self, k, dst=0, group=None):
-        """Start gathering unroll k (the half the last `unroll` steps wrote); the previous gather must have finished."""
+        """Start gathering unroll k (the block the last `unroll` steps wrote); the previous gather must have finished."""
         self.wait()
         local = self.half(k)
         if local.is_cuda:
             # the collective (and the .cpu() staging of the gloo test path) is ordered against torch's CURRENT stream only: the step
-            # kernels that wrote this half must be on that very stream, or the gather reads rows that are still being written
+            # kernels that wrote this block must be on that very stream, or the gather reads rows that are still being written
             es, ts = int(self.engine.device_ptrs().stream or 0), int(torch.cuda.current_stream().cuda_stream)
             if es != ts:
                 raise RuntimeError('TrajectoryBuffer.gather_async: the engine launches on stream %#x but torch\'s current stream is %#x; '

@@ -15,6 +15,7 @@ _SIGS = {
     'll_policy_create': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     'll_policy_destroy': (C.c_int, [C.c_void_p]),
     'll_policy_act': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'll_policy_act_pg': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]),
     'll_policy_enable_timing': (C.c_int, [C.c_void_p, C.c_int]),
     'll_policy_time_ms': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
@@ -58,6 +59,15 @@ class HipPmcPolicy(object):
         """obs buffer of `engine` -> its action buffer, queued on the engine's stream (then engine.step() applies it)."""
         p = engine.device_ptrs()
         self.act_ptr(p.obs, p.actions, p.n_envs, p.stream, d_code)
+
+    def act_pg(self, engine, seed, step, sample=True, d_code=None):
+        """The actor's forward pass (ll_policy_act_pg): a ~ pi(.|obs) into the engine's action buffer, -log p(a|obs) and V(obs) into its
+        ll_pg_ptrs buffers -- from where the next engine.step() copies them into the unroll it records."""
+        p = engine.device_ptrs()
+        nl, v = engine.pg_ptrs()
+        self._chk(self.lib.ll_policy_act_pg(self.h, C.c_void_p(int(p.obs)), C.c_void_p(int(p.actions)), C.c_void_p(int(d_code)) if d_code else None,
+                                            C.c_void_p(int(nl)), C.c_void_p(int(v)), int(p.n_envs), int(seed), int(step), 1 if sample else 0,
+                                            C.c_void_p(int(p.stream)) if p.stream else None))
 
     def enable_timing(self, on=True):
         self._chk(self.lib.ll_policy_enable_timing(self.h, 1 if on else 0))

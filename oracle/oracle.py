@@ -99,6 +99,21 @@ def f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+# ---- spec overrides (include/llenv_model.h LLM_SPEC_*; deviation study) ------------------------
+SPEC_IDS = dict(limit_gate=0, max_depen_speed=1, link_damping=2, max_contacts_per_leg=3, self_collision=4, self_margin=5, max_self=6,
+                erp=7, contact_margin=8, self_friction=9, warm_start=10)
+
+
+def set_spec(**kw):
+    for k, v in kw.items():
+        if lib().orc_set_spec_param(C.c_int(SPEC_IDS[k]), C.c_double(float(v))) != 0:
+            raise ValueError('bad spec override %s=%r' % (k, v))
+
+
+def reset_spec():
+    lib().orc_reset_spec()
+
+
 # ---- stateless pieces -------------------------------------------------------------------------
 def pd_torque(kp, kd, max_tau, q, qd, tgt_joint_pos):
     """LR:119-148 (orc_pd_torque): the torques apply_action hands to PyBullet, for one robot."""

@@ -35,7 +35,7 @@
 #define NDOF 18
 #define KC LLM_MAX_CONTACTS_PER_LEG
 #define MAXC (4 * KC)
-#define MAXROWS (12 + 3 * MAXC + 2)   /* limits + contacts (n, t1, t2) + self-collision rows */
+#define MAXROWS (12 + 3 * MAXC + 3 * LLM_MAX_SELF)   /* limits + contacts (n, t1, t2) + self-collision rows (n, and t1, t2 when LLM_SPEC_SELF_FRICTION > 0) */
 
 /* ------------------------------------------------------------------------------------------------ */
 /* small linear algebra                                                                             */
@@ -546,10 +546,27 @@ static int aba(const OModel* M, const OKin* K, const double* qd, const double* t
 }
 
 /* gravity + Bullet's per-link velocity damping as external spatial forces (body coords) */
-static double g_link_damping = LLM_LINK_DAMPING;
-static int g_self_collision = 1;
-void orc_set_self_collision(int on) { g_self_collision = on; } /* tests: compare with / without */
-void orc_set_link_damping(double k) { g_link_damping = k; } /* tests: 0 makes free flight conservative */
+/* Spec overrides (include/llenv_model.h LLM_SPEC_*): process-wide, defaults = the constants of that header.  The engine has the same
+ * switches (ll_set_spec_param); tools/deviation_table.py moves them in both to measure what each of this build's own choices is worth. */
+static double g_spec[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
+                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0};
+int orc_set_spec_param(int id, double v) {
+  if (id < 0 || id >= LLM_SPEC_COUNT) return -1;
+  if (id == LLM_SPEC_MAX_CONTACTS_PER_LEG && !(v >= 1 && v <= LLM_MAX_CONTACTS_PER_LEG)) return -1;
+  if (id == LLM_SPEC_MAX_SELF && !(v >= 0 && v <= LLM_MAX_SELF)) return -1;
+  g_spec[id] = v;
+  return 0;
+}
+double orc_get_spec_param(int id) { return (id >= 0 && id < LLM_SPEC_COUNT) ? g_spec[id] : NAN; }
+void orc_reset_spec(void) {
+  const double d[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
+                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0};
+  memcpy(g_spec, d, sizeof d);
+}
+#define g_link_damping (g_spec[LLM_SPEC_LINK_DAMPING])
+#define g_self_collision (g_spec[LLM_SPEC_SELF_COLLISION] > 0.5)
+void orc_set_self_collision(int on) { g_spec[LLM_SPEC_SELF_COLLISION] = on ? 1.0 : 0.0; } /* tests: compare with / without */
+void orc_set_link_damping(double k) { g_spec[LLM_SPEC_LINK_DAMPING] = k; } /* tests: 0 makes free flight conservative */
 static void external_forces(const OModel* M, const OKin* K, double (*fext)[6]) {
   const double k1 = g_link_damping, k2 = g_link_damping;
   for (int b = 0; b < NB; b++) {
@@ -587,6 +604,7 @@ typedef struct {
   double depth;   /* signed distance to the plane z=0 (negative = penetrating) */
   double mu;
   int leg, slot;
+  int cand;       /* index of the candidate within the leg's fixed enumeration (identity across substeps: the warm-start key) */
   double n[3];    /* unit normal of the surface it touches (plane: +z), world */
 } OContact;
 
@@ -693,10 +711,11 @@ static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double 
         }
       }
     int taken[32] = {0}, nsel = 0;
-    for (int s = 0; s < KC; s++) {          /* the KC deepest (ties: lower index) ... */
+    const int kc = (int)g_spec[LLM_SPEC_MAX_CONTACTS_PER_LEG];
+    for (int s = 0; s < kc; s++) {          /* the KC deepest (ties: lower index) ... */
       int best = -1;
       for (int i = 0; i < 32; i++)
-        if (c[i].valid && !taken[i] && c[i].depth < LLM_CONTACT_MARGIN && (best < 0 || c[i].depth < c[best].depth)) best = i;
+        if (c[i].valid && !taken[i] && c[i].depth < g_spec[LLM_SPEC_CONTACT_MARGIN] && (best < 0 || c[i].depth < c[best].depth)) best = i;
       if (best < 0) break;
       taken[best] = 1;
       nsel++;
@@ -707,7 +726,7 @@ static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double 
       out[n].body = c[i].body; memcpy(out[n].P, c[i].P, 24); out[n].depth = c[i].depth;
       out[n].mu = c[i].mu * (c[i].valid == 2 && T ? T->box_mu_scale : 1.0);
       memcpy(out[n].n, c[i].n, 24);
-      out[n].leg = l; out[n].slot = slot++;
+      out[n].leg = l; out[n].slot = slot++; out[n].cand = i;
       n++;
     }
     (void)nsel;
@@ -778,10 +797,10 @@ static int find_self_contacts(const OModel* M, const OKin* K, OSelf* out) {
       for (int i = 0; i < 3; i++) { o->n[i] = d[i] / len; o->P[i] = 0.5 * ((c1[i] - r1 * o->n[i]) + (c2[i] + r2 * o->n[i])); }
     }
   int n = 0, taken[24] = {0};
-  for (int s = 0; s < MAX_SELF; s++) {
+  for (int s = 0; s < (int)g_spec[LLM_SPEC_MAX_SELF]; s++) {
     int best = -1;
     for (int i = 0; i < nc; i++)
-      if (!taken[i] && cand[i].depth < LLM_SELF_MARGIN && (best < 0 || cand[i].depth < cand[best].depth)) best = i;
+      if (!taken[i] && cand[i].depth < g_spec[LLM_SPEC_SELF_MARGIN] && (best < 0 || cand[i].depth < cand[best].depth)) best = i;
     if (best < 0) break;
     taken[best] = 1;
     out[n++] = cand[best];
@@ -817,7 +836,8 @@ typedef struct {
   double J[MAXROWS][NDOF], MiJt[MAXROWS][NDOF], Minv[NDOF][NDOF];
   double bias[MAXROWS], lo[MAXROWS], hi[MAXROWS], lam[MAXROWS], mu_row[MAXROWS], dinv[MAXROWS];
   int fric_of[MAXROWS], order[MAXROWS], lim_row[12], con_row[4][KC];
-  int con_leg[MAXC], con_slot[MAXC];
+  int con_leg[MAXC], con_slot[MAXC], con_cand[MAXC];
+  int ns, self_pair[LLM_MAX_SELF], self_row[LLM_MAX_SELF], self_rows;
 } ORows;
 
 static int assemble_rows(const OModel* M, double dt, double mu_foot, const double* state, const double* tau_in, OSubstepDiag* diag,
@@ -866,9 +886,9 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
   for (int i = 0; i < 12; i++) {
     double dl = state[13 + i] - M->qlo[i], dh = M->qhi[i] - state[13 + i];
     double d = dl <= dh ? dl : dh, sgn = dl <= dh ? 1.0 : -1.0;
-    double bz = d > 0 ? d / dt : LLM_ERP * d / dt;
+    double bz = d > 0 ? d / dt : g_spec[LLM_SPEC_ERP] * d / dt;
     lim_row[i] = -1;
-    if (!(sgn * nu[6 + i] + bz < LLM_LIMIT_GATE)) continue;
+    if (!(sgn * nu[6 + i] + bz < g_spec[LLM_SPEC_LIMIT_GATE])) continue;
     memset(J[nr], 0, sizeof J[nr]);
     J[nr][6 + i] = sgn;
     bias[nr] = bz;
@@ -912,7 +932,7 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
         J[nr][d] = v3dot(dirs[r], vw);
       }
       if (r == 0) {
-        bias[nr] = C[c].depth > 0 ? C[c].depth / dt : fmax(LLM_ERP * C[c].depth / dt, -LLM_MAX_DEPEN_SPEED);
+        bias[nr] = C[c].depth > 0 ? C[c].depth / dt : fmax(g_spec[LLM_SPEC_ERP] * C[c].depth / dt, -g_spec[LLM_SPEC_MAX_DEPEN_SPEED]);
         lo[nr] = 0; hi[nr] = INFINITY; fric_of[nr] = -1; mu_row[nr] = 0;
       } else {
         bias[nr] = 0; lo[nr] = 0; hi[nr] = 0; fric_of[nr] = nr - r; mu_row[nr] = C[c].mu;
@@ -920,33 +940,58 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
       nr++;
     }
   }
-  /* self-collision rows: n . (v_A(P) - v_B(P)) >= -depth/dt, no friction */
+  /* self-collision rows: n . (v_A(P) - v_B(P)) >= -depth/dt; frictionless in the spec, with LLM_SPEC_SELF_FRICTION = mu > 0 (deviation
+   * study) followed by two tangential rows along btPlaneSpace1(n) bounded by mu times the normal multiplier */
   OSelf SC[MAX_SELF];
   int ns = g_self_collision ? find_self_contacts(M, &K, SC) : 0, self_row[MAX_SELF];
+  const double mu_self = g_spec[LLM_SPEC_SELF_FRICTION];
+  const int self_rows = mu_self > 0 ? 3 : 1;
+  W->ns = ns;
   for (int c = 0; c < ns; c++) {
     self_row[c] = nr;
-    for (int d = 0; d < NDOF; d++) {
-      double e[NDOF];
-      memset(e, 0, sizeof e);
-      e[d] = 1.0;
-      OKin Kd;
-      kinematics(M, state, e, &Kd);
-      double rel = 0;
-      for (int side = 0; side < 2; side++) {
-        int b = side ? SC[c].bodyB : SC[c].bodyA;
-        double d3[3], ploc[3], t[3], vl[3], vw[3];
-        for (int i = 0; i < 3; i++) d3[i] = SC[c].P[i] - K.pw[b][i];
-        m3tv(K.Rw[b], d3, ploc);
-        v3cross(Kd.v[b], ploc, t);
-        for (int i = 0; i < 3; i++) vl[i] = Kd.v[b][3 + i] + t[i];
-        m3v(K.Rw[b], vl, vw);
-        rel += (side ? -1.0 : 1.0) * v3dot(SC[c].n, vw);
+    W->self_pair[c] = SC[c].pair;
+    double dirs[3][3];
+    {
+      const double* nn = SC[c].n;
+      memcpy(dirs[0], nn, 24);
+      if (fabs(nn[2]) > 0.7071067811865475) {
+        double a = nn[1] * nn[1] + nn[2] * nn[2], kk = 1.0 / sqrt(a);
+        dirs[1][0] = 0; dirs[1][1] = -nn[2] * kk; dirs[1][2] = nn[1] * kk;
+        dirs[2][0] = a * kk; dirs[2][1] = -nn[0] * dirs[1][2]; dirs[2][2] = nn[0] * dirs[1][1];
+      } else {
+        double a = nn[0] * nn[0] + nn[1] * nn[1], kk = 1.0 / sqrt(a);
+        dirs[1][0] = -nn[1] * kk; dirs[1][1] = nn[0] * kk; dirs[1][2] = 0;
+        dirs[2][0] = -nn[2] * dirs[1][1]; dirs[2][1] = nn[2] * dirs[1][0]; dirs[2][2] = a * kk;
       }
-      J[nr][d] = rel;
     }
-    bias[nr] = SC[c].depth > 0 ? SC[c].depth / dt : fmax(LLM_ERP * SC[c].depth / dt, -LLM_MAX_DEPEN_SPEED);
-    lo[nr] = 0; hi[nr] = INFINITY; fric_of[nr] = -1; mu_row[nr] = 0;
-    nr++;
+    for (int r = 0; r < self_rows; r++) {
+      for (int d = 0; d < NDOF; d++) {
+        double e[NDOF];
+        memset(e, 0, sizeof e);
+        e[d] = 1.0;
+        OKin Kd;
+        kinematics(M, state, e, &Kd);
+        double rel = 0;
+        for (int side = 0; side < 2; side++) {
+          int b = side ? SC[c].bodyB : SC[c].bodyA;
+          double d3[3], ploc[3], t[3], vl[3], vw[3];
+          for (int i = 0; i < 3; i++) d3[i] = SC[c].P[i] - K.pw[b][i];
+          m3tv(K.Rw[b], d3, ploc);
+          v3cross(Kd.v[b], ploc, t);
+          for (int i = 0; i < 3; i++) vl[i] = Kd.v[b][3 + i] + t[i];
+          m3v(K.Rw[b], vl, vw);
+          rel += (side ? -1.0 : 1.0) * v3dot(dirs[r], vw);
+        }
+        J[nr][d] = rel;
+      }
+      if (r == 0) {
+        bias[nr] = SC[c].depth > 0 ? SC[c].depth / dt : fmax(g_spec[LLM_SPEC_ERP] * SC[c].depth / dt, -g_spec[LLM_SPEC_MAX_DEPEN_SPEED]);
+        lo[nr] = 0; hi[nr] = INFINITY; fric_of[nr] = -1; mu_row[nr] = 0;
+      } else {
+        bias[nr] = 0; lo[nr] = 0; hi[nr] = 0; fric_of[nr] = nr - r; mu_row[nr] = mu_self;
+      }
+      nr++;
+    }
   }
   /* M^-1 J^T by unit responses of the ABA at zero velocity */
   {
@@ -980,8 +1025,12 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
     for (int k = 0; k < KC; k++)
       for (int l = 0; l < 4; l++)
         if (con_row[l][k] >= 0) W->order[no++] = con_row[l][k] + r;
-  for (int c = 0; c < ns; c++) W->order[no++] = self_row[c];
+  for (int c = 0; c < ns; c++)
+    for (int r = 0; r < self_rows; r++) W->order[no++] = self_row[c] + r;
   W->nr = nr; W->no = no;
+  for (int c = 0; c < nc; c++) W->con_cand[c] = C[c].cand;
+  for (int c = 0; c < ns; c++) W->self_row[c] = self_row[c];
+  W->self_rows = self_rows;
   return 0;
 #undef K
 #undef nu
@@ -1030,11 +1079,38 @@ static void integrate_state(const ORows* W, double dt, double* state) {
 }
 
 
+/* Warm starting (LLM_SPEC_WARM_START = factor > 0; deviation study only -- the spec, like btMultiBodyConstraintSolver for multibody
+ * contacts as far as this author recalls its source, starts every substep from zero multipliers): the multipliers a robot's rows
+ * ended the previous substep with, keyed by what persists -- joint, (leg, candidate index), capsule pair. */
+typedef struct { double lim[12], con[4][32][3], self[24][3]; } OWarm;
+static _Thread_local OWarm* tl_warm = NULL;   /* set by orc_step_env around its substeps; NULL for the stateless entry points */
+static void warm_apply(ORows* W, const OWarm* c, double f) {
+  for (int r = 0; r < W->nr; r++) W->lam[r] = 0;
+  for (int i = 0; i < 12; i++) if (W->lim_row[i] >= 0) W->lam[W->lim_row[i]] = f * c->lim[i];
+  for (int k = 0; k < W->nc; k++)
+    for (int r = 0; r < 3; r++) W->lam[W->con_row[W->con_leg[k]][W->con_slot[k]] + r] = f * c->con[W->con_leg[k]][W->con_cand[k]][r];
+  for (int k = 0; k < W->ns; k++)
+    for (int r = 0; r < W->self_rows; r++) W->lam[W->self_row[k] + r] = f * c->self[W->self_pair[k]][r];
+  for (int r = 0; r < W->nr; r++)
+    if (W->lam[r] != 0)
+      for (int k = 0; k < NDOF; k++) W->nu[k] += W->MiJt[r][k] * W->lam[r];
+}
+static void warm_store(const ORows* W, OWarm* c) {
+  memset(c, 0, sizeof *c);
+  for (int i = 0; i < 12; i++) if (W->lim_row[i] >= 0) c->lim[i] = W->lam[W->lim_row[i]];
+  for (int k = 0; k < W->nc; k++)
+    for (int r = 0; r < 3; r++) c->con[W->con_leg[k]][W->con_cand[k]][r] = W->lam[W->con_row[W->con_leg[k]][W->con_slot[k]] + r];
+  for (int k = 0; k < W->ns; k++)
+    for (int r = 0; r < W->self_rows; r++) c->self[W->self_pair[k]][r] = W->lam[W->self_row[k] + r];
+}
+
 static int substep_terrain(const OModel* M, double dt, int n_iter, double mu_foot, double* state, const double* tau_in, OSubstepDiag* diag,
                            const OTerrain* T, const double* push) {
   static _Thread_local ORows W;
   if (assemble_rows(M, dt, mu_foot, state, tau_in, diag, T, push, &W)) return -1;
+  if (tl_warm && g_spec[LLM_SPEC_WARM_START] > 0) warm_apply(&W, tl_warm, g_spec[LLM_SPEC_WARM_START]);
   for (int it = 0; it < n_iter; it++) sweep_rows(&W);
+  if (tl_warm) warm_store(&W, tl_warm);
   if (diag) {   /* fixed layout for the tests: [12 limit rows (0 when gated out)] [3 rows per contact, contact order] */
     diag->n_contacts = W.nc; diag->n_rows = 12 + 3 * W.nc;
     memset(diag->lambda, 0, sizeof diag->lambda);
@@ -1211,6 +1287,7 @@ typedef struct {
   double hist_prop[LL_STACK][LL_PROP_FRAME_MAX], hist_act[LL_STACK][12];
   int hist_n, clip, frame_id, ep_steps, done_reason, ob_id;
   double feet_dyn[12], feet_kin[12];
+  OWarm warm;     /* multipliers of the previous substep (only read when LLM_SPEC_WARM_START > 0) */
 } OEnv;
 
 typedef struct {
@@ -1373,6 +1450,7 @@ int orc_reset_env(OBatch* B, int env, int clip, double t0, double* obs_out) {
   orc_mocap_locate(t0, B->frame_step, &e->frame_id, &e->frac);                              /* ML:52-53 */
   orc_mocap_interp(clip_row(B, clip, e->frame_id), clip_row(B, clip, e->frame_id + 1), e->frac, B->frame_step, e->kin);
   memcpy(e->state, e->kin, sizeof e->kin);                                                  /* PLE:162-163 */
+  memset(&e->warm, 0, sizeof e->warm);
   double zero[12] = {0};
   prepare_obs(B, e, zero, obs_out);                                                         /* PLE:168-170 */
   return 0;
@@ -1408,8 +1486,11 @@ int orc_step_env(OBatch* B, int env, const double* action, const double* scripte
   int bad = 0;
   for (int s = 0; s < B->n_sub; s++) {                                    /* PLE:202 */
     orc_pd_torque(B->cfg.kp, B->cfg.kd, B->cfg.max_tau, e->state + 13, e->state + 25, tgt, tau);   /* LR:137-141 */
-    if (!scripted_dyn)
+    if (!scripted_dyn) {
+      tl_warm = &e->warm;
       if (orc_substep_model(&B->model, B->dt, B->cfg.solver_iterations, B->mu_foot, e->state, tau, NULL)) bad = 1;   /* PLE:206 */
+      tl_warm = NULL;
+    }
     orc_mocap_locate(e->time, B->frame_step, &e->frame_id, &e->frac);      /* PLE:208 (time BEFORE the increment, quirk Q2) */
     e->time += B->dt;                                                      /* PLE:210 */
   }

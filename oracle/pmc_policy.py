@@ -30,3 +30,15 @@ class PmcPolicy(object):
         s = np.concatenate([relu(prop_rms @ w[17] + w[18]), relu(q @ w[19] + w[20])], axis=1)     # llc pmc_net.py:99-108
         h = relu(relu(s @ w[21] + w[22]) @ w[23] + w[24])
         return h @ w[25] + w[26]                                         # decoder mean
+
+    def value(self, obs):
+        """vf head (pmc_net.py:141-146): tanh(207 -> 256) -> tanh(256) -> 1 on the normalised observation"""
+        w = self.w
+        prop, future = obs[:, :135], obs[:, 135:]
+        ob = np.concatenate([np.clip((prop - w[0]) / (w[1] + 1e-8), -5.0, 5.0), np.clip((future - w[2]) / (w[3] + 1e-8), -5.0, 5.0)], axis=1)
+        return (np.tanh(np.tanh(ob @ w[4] + w[5]) @ w[6] + w[7]) @ w[8] + w[9])[:, 0]
+
+    def neglogp(self, obs, a):
+        """DiagGaussianPd.neglogp of action a under the policy's head (mean = act(obs), logstd = w27; pmc_net.py:109-113)"""
+        logstd = self.w[27].reshape(1, 12)
+        return 0.5 * (((a - self.act(obs)) / np.exp(logstd)) ** 2).sum(1) + 0.5 * np.log(2.0 * np.pi) * 12 + logstd.sum()

@@ -53,6 +53,20 @@ struct HostBackend {
     HostLanes ln(P.candc);
     for (int i = 0; i < n; i++) K::probe_pd(ln, P, in + (long)i * 36, out + (long)i * 12, mode);
   }
+  void launch_gae(float* block, int n_envs, int unroll, int W, int od, float gamma, float lam, const float* bootstrap) {
+    for (int env = 0; env < n_envs; env++) {
+      float* rows = block + (size_t)env * unroll * W;
+      float adv = 0.0f, vnext = bootstrap[env];
+      for (int t = unroll - 1; t >= 0; t--) {
+        float* r = rows + (size_t)t * W + od;
+        const float V = r[14], m = r[16];
+        const float delta = r[15] + gamma * vnext * m - V;
+        adv = delta + gamma * lam * m * adv;
+        r[13] = adv + V;
+        vnext = V;
+      }
+    }
+  }
   void launch_actions(const StepParams& P, float* actions, float sigma) {
     for (int gid = 0; gid < P.n_envs * 3; gid++) {
       uint32_t r[4];

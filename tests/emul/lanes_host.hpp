@@ -194,6 +194,7 @@ struct HostLanes {
   void copy16(float* dst, const float* src, int i0, int n) const { for (int i = i0; i < i0 + EW && i < n; i++) dst[i] = src[i]; }
   F ld16(const float* src, int i0, int n) const { fN r; for (int i = 0; i < EW; i++) r.v[i] = (i0 + i < n) ? src[i0 + i] : 0.0f; return r; }
   void st16(float* dst, int i0, int n, const F& v) const { for (int i = 0; i < EW; i++) if (i0 + i < n) dst[i0 + i] = v.v[i]; }
+  void st16_rot(float* dst, int i0, int n, int split, const F& v) const { for (int k = 0; k < EW; k++) { const int i = i0 + k; if (i < n) dst[i < split ? i + (n - split) : i - split] = v.v[k]; } }
   int count_le16(const double* p, int n, double u) const { int c = 0; for (int i = 0; i < n; i++) c += (p[i] <= u) ? 1 : 0; return c; }
   D lddl(const double* p, long base, long stride) const { dN r; for (int i = 0; i < EW; i++) r.v[i] = p[base + stride * (i >> 2)]; return r; }
   static F d2f(const D& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = (float)x.v[i]; return r; }

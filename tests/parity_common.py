@@ -213,29 +213,80 @@ def check_trained_policy_tracks(lib_path, n_envs=16, n_steps=200, seed=7):
     return dict(mean_reward=mean_r, tracked=ok.mean(), steps=steps, why=why)
 
 
-def check_trajectory_ring(model_blob, table, lib_path, read_ring):
-    """ll_enable_trajectory: every step writes  obs_t | action_t | reward_t | done_t  into slot (step mod unroll).
-    read_ring(address, shape) -> numpy copy of the ring (host memory for the emulation library, device memory on a GPU)."""
+def check_trajectory_ring(model_blob, table, lib_path, read_ring, write_dev=None):
+    """ll_enable_unrolls: every step writes its transition into time step (s mod unroll) of block ((s div unroll) mod 2) of the
+    env's unroll -- X in the learner's flatten order (future | prop | prop_a), A, neglogp, R, V, r, 1 - done -- and ll_finish_unroll
+    fills R with the TD(lambda) returns.  read_ring(address, shape) -> numpy copy (host memory for the emulation library, device
+    memory on a GPU); write_dev(address, array) -> stores float32 values at a device address (policy outputs), or None."""
+    import os
+    from conftest import GOLDEN_DIR
+    from lifelike_agility_and_play_amd import gather
     n, unroll = 24, 4
     E = make_engine(model_blob, table, n, lib_path, auto_reset=1, seed=5)
     E.reset()
-    ptr, w = E.enable_trajectory(unroll)
-    assert w == E.obs_dim + 14
+    ptr, w = E.enable_unrolls(unroll, 2)
+    od = E.obs_dim
+    assert w == od + 17
+    p_nl, p_v = E.pg_ptrs()
     rng = np.random.default_rng(0)
     prev_obs = E.obs()
-    for t in range(7):
+    hist = []
+    for t in range(11):
         act = (rng.normal(size=(n, 12)) * 0.5).astype(np.float32)
+        nl, v = rng.uniform(5, 15, n).astype(np.float32), rng.uniform(0, 10, n).astype(np.float32)
+        if write_dev is not None:
+            E.sync(); write_dev(p_nl, nl); write_dev(p_v, v)
+        else:
+            nl[:] = 0; v[:] = 0
         E.step_host(act)
         r, d, _ = E.reward_done()
         E.sync()
-        ring = read_ring(ptr, (unroll, n, w))
-        row = ring[t % unroll]
-        np.testing.assert_array_equal(row[:, :E.obs_dim], prev_obs)           # the observation the action was chosen on
-        np.testing.assert_array_equal(row[:, E.obs_dim:E.obs_dim + 12], act)
-        np.testing.assert_array_equal(row[:, E.obs_dim + 12], r)
-        np.testing.assert_array_equal(row[:, E.obs_dim + 13], d.astype(np.float32))
+        ring = read_ring(ptr, (2, n, unroll, w))
+        row = ring[(t // unroll) % 2][:, t % unroll]
+        f = gather.split_row(row, od)
+        np.testing.assert_array_equal(f['X'][:, :72], prev_obs[:, od - 72:])            # future first (dict keys sorted)
+        np.testing.assert_array_equal(f['X'][:, 72:], prev_obs[:, :od - 72])            # then prop | prop_a: the observation the action was chosen on
+        np.testing.assert_array_equal(f['A'], act)
+        np.testing.assert_array_equal(f['neglogp'], nl); np.testing.assert_array_equal(f['V'], v)
+        np.testing.assert_array_equal(f['r'], r)
+        np.testing.assert_array_equal(f['mask'], 1.0 - d.astype(np.float32))
+        hist.append((prev_obs.copy(), act, r.copy(), d.copy(), v.copy()))
         prev_obs = E.obs()
+        if t % unroll == unroll - 1:
+            # one env's unroll is contiguous and starts, per time step, with the reference's flattened [X_t, A_t] (distill_actor.py:159-162)
+            blk = ring[(t // unroll) % 2]
+            for e in (0, n - 1):
+                steps = hist[-unroll:]
+                obs_d = [dict(prop=h[0][e, :od - 108], prop_a=h[0][e, od - 108:od - 72], future=h[0][e, od - 72:]) for h in steps]
+                ref = gather.flatten_unroll(obs_d, [h[1][e] for h in steps]).reshape(unroll, od + 12)
+                np.testing.assert_array_equal(blk[e][:, :od + 12], ref.astype(np.float32))
+            # TD(lambda) returns against a NumPy statement of the recursion
+            gamma, lam = 0.95, 0.9
+            boot = rng.uniform(0, 10, n).astype(np.float32)
+            if write_dev is not None:
+                write_dev(p_v, boot)
+            else:
+                boot[:] = 0
+            E.finish_unroll((t // unroll) % 2, gamma, lam)
+            E.sync()
+            blk = read_ring(ptr, (2, n, unroll, w))[(t // unroll) % 2]
+            f = gather.split_row(blk, od)
+            adv, vnext, R = np.zeros(n), boot.astype(np.float64), np.zeros((n, unroll))
+            for k in range(unroll - 1, -1, -1):
+                delta = f['r'][:, k] + gamma * vnext * f['mask'][:, k] - f['V'][:, k]
+                adv = delta + gamma * lam * f['mask'][:, k] * adv
+                R[:, k] = adv + f['V'][:, k]
+                vnext = f['V'][:, k].astype(np.float64)
+            np.testing.assert_allclose(f['R'], R, rtol=1e-5, atol=1e-5)
     E.close()
+    # the flatten itself is the reference's: golden generated by running distill_actor._push_data_to_learner
+    g = np.load(os.path.join(GOLDEN_DIR, 'unroll_golden.npz'))
+    T = int(g['unroll_length'])
+    for k in range(len(g['unroll_np'])):
+        sl = slice(k * T, (k + 1) * T)
+        obs_d = [dict(prop=p, prop_a=a, future=f) for p, a, f in zip(g['obs_prop'][sl], g['obs_prop_a'][sl], g['obs_future'][sl])]
+        np.testing.assert_array_equal(gather.flatten_unroll(obs_d, g['action'][sl]), g['unroll_np'][k])
+    assert list(g['shapes']) == [72, 99, 36, 12]
 
 
 def check_obstacle_variant(golden, orc, model_blob, table, lib_path, n_envs=24, n_steps=60, seed=2):

@@ -112,4 +112,4 @@ def test_async_ring_gather_two_ranks():
     assert n_g == 2
     np.testing.assert_array_equal(a0, b0)                   # rank 0's own block
     np.testing.assert_array_equal(a1, b1)                   # rank 1's block == rank 1's engine recomputed on rank 0
-    assert a0.shape == (3, 6, 221) and np.abs(a0 - a1).max() > 0
+    assert a0.shape == (6, 3, 224) and np.abs(a0 - a1).max() > 0      # [n_envs][unroll][row]: every env's unroll contiguous

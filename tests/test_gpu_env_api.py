@@ -49,7 +49,12 @@ def test_trajectory_ring_gpu(model_blob, mocap_table):
 
     def read_ring(addr, shape):
         return gather.device_tensor(addr, shape).cpu().numpy()
-    pc.check_trajectory_ring(model_blob, mocap_table, None, read_ring)
+
+    def write_dev(addr, arr):
+        import torch
+        gather.device_tensor(addr, arr.shape).copy_(torch.from_numpy(arr))
+        torch.cuda.synchronize()
+    pc.check_trajectory_ring(model_blob, mocap_table, None, read_ring, write_dev)
 
 
 def test_trained_policy_on_device_closed_loop(model_blob, mocap_table):
@@ -139,3 +144,65 @@ def test_config1_single_walk_clip_through_the_hip_library(golden):
             break
     assert d and n >= 2                                                     # random actions: falls, diverges or reaches the clip end
     env.close()
+
+
+def test_policy_gradient_actor_outputs(model_blob, mocap_table):
+    """ll_policy_act_pg: sampled actions, their neglogp and the value head against the NumPy statement of the network; the same
+    (seed, step) reproduces the draw; and a rollout with it leaves complete learner rows (X, A, neglogp, R, V) in the unroll."""
+    import os
+    torch = torch_cuda()
+    from conftest import GOLDEN_DIR, PMC_PROP_TYPE, PMC_REWARD_WEIGHTS
+    from lifelike_agility_and_play_amd import capi, gather
+    from oracle.pmc_policy import PmcPolicy
+    from lifelike_agility_and_play_amd.pmc_policy_hip import HipPmcPolicy
+    n, unroll = 1000, 8
+    cfg = capi.make_config(n, control_freq=50.0, kd=0.5, reward_weights=PMC_REWARD_WEIGHTS, prop_type=PMC_PROP_TYPE, prioritized_sample_factor=3.0,
+                           auto_reset=1, seed=4)
+    E = capi.Engine(cfg, model_blob, mocap_table)
+    gather.bind_torch_stream(E)
+    T = gather.engine_tensors(E)
+    nl_p, v_p = E.pg_ptrs()
+    NL, V = gather.device_tensor(nl_p, (n,)), gather.device_tensor(v_p, (n,))
+    pol, ref = HipPmcPolicy(), PmcPolicy(os.path.join(GOLDEN_DIR, 'pmc_policy.npz'))
+    tb = gather.TrajectoryBuffer(E, unroll)
+    E.reset()
+    code = torch.zeros(n, dtype=torch.int32, device='cuda')
+    pol.act_pg(E, seed=77, step=0, sample=True, d_code=code.data_ptr())
+    torch.cuda.synchronize()
+    obs = E.obs().astype(np.float64)
+    a, nl, v = T['actions'].cpu().numpy().astype(np.float64), NL.cpu().numpy(), V.cpu().numpy()
+    np.testing.assert_allclose(v, ref.value(obs), rtol=2e-4, atol=2e-4)
+    mean, std = ref.act(obs), np.exp(ref.w[27].reshape(1, 12))
+    w = ref.w                                                             # envs whose nearest code is a near-tie may pick the other one in float32
+    prop = np.clip((obs[:, :135] - w[0]) / (w[1] + 1e-8), -5, 5); fut = np.clip((obs[:, 135:] - w[2]) / (w[3] + 1e-8), -5, 5)
+    h = np.maximum(np.maximum(np.concatenate([prop, fut], 1) @ w[10] + w[11], 0) @ w[12] + w[13], 0)
+    ze = h @ w[14] + w[15]
+    same = code.cpu().numpy() == np.argmax(-((ze ** 2).sum(1, keepdims=True) - 2 * ze @ w[16] + (w[16] ** 2).sum(0, keepdims=True)), 1)
+    assert same.mean() > 0.99
+    eps = ((a - mean) / std)[same]
+    assert abs(eps.mean()) < 0.03 and abs(eps.std() - 1.0) < 0.03 and np.abs(eps).max() < 6.0      # standard normal draws
+    np.testing.assert_allclose(nl[same], ref.neglogp(obs, a)[same], rtol=2e-3, atol=2e-3)
+    pol.act_pg(E, seed=77, step=0, sample=True); torch.cuda.synchronize()
+    np.testing.assert_array_equal(T['actions'].cpu().numpy(), a.astype(np.float32))                 # same (seed, step): same draw
+    pol.act_pg(E, seed=77, step=1, sample=True); torch.cuda.synchronize()
+    assert np.abs(T['actions'].cpu().numpy() - a).max() > 0.05
+    pol.act_pg(E, seed=77, step=0, sample=False); torch.cuda.synchronize()
+    np.testing.assert_allclose(T['actions'].cpu().numpy()[same], mean[same], rtol=2e-4, atol=2e-4)  # the mean action, neglogp at the mode
+    np.testing.assert_allclose(NL.cpu().numpy(), 0.5 * np.log(2 * np.pi) * 12 + ref.w[27].sum(), rtol=1e-5)
+    # a rollout: policy -> step, the TD(lambda) returns when a block is complete; rows carry what the policy reported
+    E.reset()
+    for s in range(2 * unroll + 1):
+        pol.act_pg(E, seed=5, step=s, sample=True)
+        if s and s % unroll == 0:
+            tb.finish(s // unroll - 1, gamma=0.95, lam=0.95)            # bootstrapped from V(obs_s), which the call above just wrote
+        nl_s, v_s, a_s = NL.clone(), V.clone(), T['actions'].clone()
+        E.step()
+        if s % unroll == 3:
+            torch.cuda.synchronize()
+            f = gather.split_row(tb.half(s // unroll)[:, s % unroll], E.obs_dim)
+            assert torch.equal(f['neglogp'], nl_s) and torch.equal(f['V'], v_s) and torch.equal(f['A'], a_s)
+    torch.cuda.synchronize()
+    f = gather.split_row(tb.half(0).cpu().numpy(), E.obs_dim)
+    assert np.isfinite(f['R']).all() and (f['R'] != 0).all() and (np.abs(f['R'] - f['V']) < 20).all()
+    assert (f['neglogp'] > 0).all() or (f['neglogp'] < 0).any()           # filled, not the zero of "no policy attached"
+    pol.close(); E.close()

@@ -44,7 +44,10 @@ def test_trajectory_ring(model_blob, mocap_table, emul_lib):
     def read_ring(addr, shape):
         n = int(np.prod(shape))
         return np.ctypeslib.as_array((ctypes.c_float * n).from_address(addr)).reshape(shape).copy()
-    pc.check_trajectory_ring(model_blob, mocap_table, emul_lib, read_ring)
+
+    def write_dev(addr, arr):
+        np.ctypeslib.as_array((ctypes.c_float * arr.size).from_address(addr))[:] = arr.ravel()
+    pc.check_trajectory_ring(model_blob, mocap_table, emul_lib, read_ring, write_dev)
 
 
 def test_obstacle_variant(golden, orc, model_blob, mocap_table, emul_lib):

@@ -1,0 +1,152 @@
+"""What each of this build's own physics choices is worth (DESIGN.md 4 "known deviations"), measured with the strongest Bullet-facing
+evidence available here: the reference's TRAINED PMC policy (trained against PyBullet) driving our simulator closed-loop.
+
+For every variant of the spec -- one constant moved, everything else as shipped -- N episodes are started at uniformly random
+(clip, start time), run until they end or reach the horizon, and scored:
+    reward     mean tracking reward per env-step
+    tracked    fraction of episodes that reach the end of their clip or are still tracking at the horizon (not fallen / diverged)
+    length     mean episode length in control steps
+Two simulators run the same protocol: the float32 HIP engine (--engine, needs a GPU; 4096 episodes) and the float64 oracle
+(--oracle, CPU, OpenMP; the only one that has the warm-start and self-friction switches).
+
+    gpurun -- 'python tools/deviation_table.py --engine --oracle --episodes 1024 > gpurun_out/dev/table.md'
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np  # noqa: E402
+
+RW = {'joint_pos': 0.3, 'joint_vel': 0.05, 'end_effector': 0.1, 'root_pose': 0.5, 'root_vel': 0.05}
+PT = ['joint_pos', 'joint_vel', 'root_ang_vel_loc', 'root_lin_vel_loc', 'e_g']
+HORIZON = 500            # control steps = 10 s
+
+# (label, overrides, what it stands for)
+VARIANTS = [
+    ('spec (as shipped)', {}, ''),
+    ('limit gate off', dict(limit_gate=1e30), 'every joint-limit row enters the solve (LLM_LIMIT_GATE 20 rad/s -> inf)'),
+    ('limit gate 5 rad/s', dict(limit_gate=5.0), ''),
+    ('depenetration cap off', dict(max_depen_speed=1e30), 'ERP push-out uncapped (LLM_MAX_DEPEN_SPEED 0.5 m/s -> inf), Bullet\'s behaviour'),
+    ('deepest-2 per leg', dict(max_contacts_per_leg=2), 'LLM_MAX_CONTACTS_PER_LEG 4 -> 2'),
+    ('deepest-1 per leg', dict(max_contacts_per_leg=1), ''),
+    ('no link damping', dict(link_damping=0.0), 'btMultiBody linear/angular damping 0.04 -> 0'),
+    ('link damping x2', dict(link_damping=0.08), ''),
+    ('no self-collision', dict(self_collision=0), 'leg-leg capsule rows off'),
+    ('one self row', dict(max_self=1), 'LLM_MAX_SELF 2 -> 1'),
+    ('self margin 0.02', dict(self_margin=0.02), 'LLM_SELF_MARGIN 0.01 -> 0.02 (Bullet\'s contact breaking threshold)'),
+    ('ERP 0.1', dict(erp=0.1), ''),
+    ('contact margin 0.01', dict(contact_margin=0.01), 'speculative rows start at 1 cm instead of 2 cm'),
+    ('self friction 0.25', dict(self_friction=0.25), 'ORACLE ONLY: two tangential rows per leg-leg contact, mu = 0.5 x 0.5'),
+    ('warm start 0.85', dict(warm_start=0.85), 'ORACLE ONLY: multipliers of persisting rows carried over x 0.85'),
+]
+ORACLE_ONLY = ('self_friction', 'warm_start')
+
+
+def starts(table, n, seed):
+    rng = np.random.default_rng(seed)
+    clip = rng.integers(0, table.n_clips, n)
+    dur = table.frame_step * (np.asarray(table.clip_len)[clip] - table.margin - 1)
+    return clip.astype(np.int32), rng.uniform(0, 1, n) * dur
+
+
+def score(rsum, steps, why, alive):
+    from lifelike_agility_and_play_amd import capi
+    ok = alive | (why == capi.DONE_CLIP_END)
+    return dict(reward=float(rsum.sum() / steps.sum()), tracked=float(ok.mean()), length=float(steps.mean()),
+                fell=float(((why & capi.DONE_FALL) != 0).mean()), diverged=float(((why & capi.DONE_DIVERGED) != 0).mean()))
+
+
+def run_engine(pol, blob, table, n, over, seed):
+    from lifelike_agility_and_play_amd import capi
+    cfg = capi.make_config(n, control_freq=50.0, kd=0.5, reward_weights=RW, prop_type=PT, prioritized_sample_factor=3.0, auto_reset=0, seed=seed)
+    E = capi.Engine(cfg, blob, table)
+    E.set_spec(**over)
+    clip, t0 = starts(table, n, seed)
+    E.reset(clip=clip, t0=t0)
+    alive = np.ones(n, bool); steps = np.zeros(n, int); rsum = np.zeros(n); why = np.zeros(n, int)
+    for t in range(HORIZON):
+        E.step_host(pol.act(E.obs().astype(np.float64)))
+        r, d, w = E.reward_done()
+        rsum += np.where(alive, r, 0.0); steps += alive
+        newly = alive & d
+        why[newly] = w[newly]
+        alive &= ~d
+        if not alive.any():
+            break
+    E.close()
+    return score(rsum, steps, why, alive)
+
+
+def run_oracle(pol, blob, table, n, over, seed, threads):
+    from oracle import oracle as orc
+    orc.reset_spec()
+    orc.set_spec(**over)
+    cfg = orc.make_config(n_envs=n, reward_weights=RW, prop_type=PT, prioritized_sample_factor=3.0)
+    B = orc.OracleBatch(cfg, blob, table)
+    clip, t0 = starts(table, n, seed)
+    obs = np.zeros((n, 207))
+    for i in range(n):
+        obs[i] = B.reset_env(i, int(clip[i]), float(t0[i]))
+    alive = np.ones(n, bool); steps = np.zeros(n, int); rsum = np.zeros(n); why = np.zeros(n, int)
+    for t in range(HORIZON):
+        a = pol.act(obs)
+        a[~alive] = 0.0
+        obs, r, d = B.step_all_mt(a, threads)
+        rsum += np.where(alive, r, 0.0); steps += alive
+        newly = alive & d.astype(bool)
+        for i in np.where(newly)[0]:
+            why[i] = B.episode_info(int(i))['done_reason']
+            obs[i] = B.reset_env(int(i), int(clip[i]), float(t0[i]))     # a finished env idles inside its clip; its further steps are not scored
+        alive &= ~d.astype(bool)
+        if not alive.any():
+            break
+    orc.reset_spec()
+    return score(rsum, steps, why, alive)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--engine', action='store_true'); ap.add_argument('--oracle', action='store_true')
+    ap.add_argument('--episodes', type=int, default=1024, help='episodes per variant on the oracle')
+    ap.add_argument('--engine-episodes', type=int, default=4096)
+    ap.add_argument('--only', default='')
+    ap.add_argument('--oracle-all', action='store_true', help='run every variant on the oracle too (default: the baseline and the oracle-only switches)')
+    args = ap.parse_args()
+    from lifelike_agility_and_play_amd import mocap, urdf_model
+    from oracle.pmc_policy import PmcPolicy
+    import bench
+    pol = PmcPolicy(os.path.join(ROOT, 'tests', 'golden', 'pmc_policy.npz'))
+    blob, table = urdf_model.default_model_blob(), mocap.load_mocap('', 0.02)
+    threads = bench.effective_cores()[0]
+    print('# Deviation study: the trained reference policy in our simulator, one spec constant moved at a time')
+    print()
+    print('Protocol: episodes started at uniformly random (clip, t0) over all 62 clips, horizon %d control steps; engine = float32 HIP kernel, '
+          '%d episodes per variant; oracle = float64 CPU restatement, %d episodes per variant (%d threads).  tools/deviation_table.py.' %
+          (HORIZON, args.engine_episodes, args.episodes, threads))
+    print()
+    print('| variant | engine reward | engine tracked | engine length | oracle reward | oracle tracked | oracle length | note |')
+    print('|---|---|---|---|---|---|---|---|')
+    for label, over, note in VARIANTS:
+        if args.only and args.only not in label:
+            continue
+        cells = []
+        if args.engine and not any(k in over for k in ORACLE_ONLY):
+            t = time.time(); e = run_engine(pol, blob, table, args.engine_episodes, over, 11)
+            cells += ['%.4f' % e['reward'], '%.3f' % e['tracked'], '%.1f' % e['length']]
+        else:
+            cells += ['-', '-', '-']
+        if args.oracle and (args.oracle_all or not over or any(k in over for k in ORACLE_ONLY)):
+            o = run_oracle(pol, blob, table, args.episodes, over, 11, threads)
+            cells += ['%.4f' % o['reward'], '%.3f' % o['tracked'], '%.1f' % o['length']]
+        else:
+            cells += ['-', '-', '-']
+        print('| %s | %s | %s |' % (label, ' | '.join(cells), note), flush=True)
+
+
+if __name__ == '__main__':
+    main()
