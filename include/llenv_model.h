@@ -54,6 +54,10 @@
 #define LLM_SELF_MARGIN 0.01            /* a capsule pair of two legs becomes a (speculative) row within this distance: covers closing
                                            speeds up to 5 m/s per 2 ms substep; the capsules themselves are 35 mm thick */
 #define LLM_MAX_SELF 2                  /* self-collision rows per robot */
+#define LLM_SEG_PARALLEL_REG 1e-3        /* closest points of two capsule axes: weight (relative to |d1|^2 |d2|^2) that pulls the parameter of nearly
+                                           parallel segments to the middle of their overlap; sin^2(angle) >> this: Ericson's closest point */
+#define LLM_SELECT_EPS 1e-5             /* m: candidates (contact points, capsule pairs) whose depth is within this of the deepest count as equally
+                                           deep and the lower index wins -- the deepest-K choice must not hang on float rounding */
 
 /* ---- spec overrides for the deviation study (DESIGN.md 4 "known deviations"): ids of ll_set_spec_param / orc_set_spec_param.
  * Every constant above that is this build's own choice rather than something the reference states can be moved at run time, in the

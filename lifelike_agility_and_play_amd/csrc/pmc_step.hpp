@@ -361,12 +361,16 @@ struct Pmc {
     const F zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f);
     V3l d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
     F a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2);
+    // nearly parallel axes: regularised toward the middle of the overlap (LLM_SEG_PARALLEL_REG; same statement as the oracle's seg_seg)
+    F ia = one / a;
+    F sa = lm::min_(lm::max_((zero - c) * ia, zero), one), sb = lm::min_(lm::max_((b - c) * ia, zero), one);
+    F reg = a * e * (float)LLM_SEG_PARALLEL_REG;
     F den = a * e - b * b;
-    F s0 = lm::sel(den > 1e-9f, lm::min_(lm::max_((b * f - c * e) / lm::max_(den, ln.lane_f(1e-9f)), zero), one), zero);
+    F s0 = lm::min_(lm::max_((b * f - c * e + reg * (0.5f * (sa + sb))) / (den + reg), zero), one);
     F t0 = (b * s0 + f) / e;
     B lt = t0 < 0.0f, gt = t0 > 1.0f;
     t = lm::sel(lt, zero, lm::sel(gt, one, t0));
-    F s_alt = lm::min_(lm::max_(lm::sel(lt, zero - c, b - c) / a, zero), one);
+    F s_alt = lm::sel(lt, sa, sb);                         // clamp(-c / a) resp. clamp((b - c) / a): the projections computed above
     s = lm::sel(lm::or_(lt, gt), s_alt, s0);
     c1 = p1 + scale(d1, s);
     c2 = p2 + scale(d2, t);
@@ -697,26 +701,33 @@ struct Pmc {
         ex->touch_flag = L::rmin(tch_fl) < 0.5f ? 1.0f : 0.0f;
       }
     }
-    // the leg keeps its 4 deepest candidates, slot s = s-th deepest: four rounds of (local min, quad min, claim)
+    // the leg keeps its 4 deepest candidates, slot s = s-th pick: four rounds of (quad min, claim).  Candidates within LLM_SELECT_EPS of
+    // the deepest count as equally deep and the lowest candidate index (sub-lane, then position) wins: symmetric poses put several
+    // points at the same depth up to rounding, and which of them is kept must not depend on the arithmetic.
     F my_depth = far_, my_sub = zero, my_jj = zero;
     for (int s = 0; s < PMC_K; s++) {
       if (s >= P.max_contacts) break;                       // (spec override LLM_SPEC_MAX_CONTACTS_PER_LEG; 4 unless a deviation study says otherwise)
-      F m = depth[0], am = zero;
-      for (int jj = 1; jj < NC; jj++) {
-        B lt = depth[jj] < m;
-        m = lm::sel(lt, depth[jj], m);
-        am = lm::sel(lt, ln.lane_f((float)jj), am);
-      }
+      F m = depth[0];
+      for (int jj = 1; jj < NC; jj++) m = lm::min_(m, depth[jj]);
       F mq = L::submin(m);
-      F code = lm::sel(lm::and_(m <= mq, m < far_), L::i2f(ln.sub()), ln.lane_f(4.0f));
-      F wsub = L::submin(code);                             // lowest sub-lane holding the minimum (4 = none)
-      B winner = lm::and_(code <= wsub, code < 3.5f);
-      F wjj = L::subsum(lm::sel(winner, am, zero));
-      for (int jj = 0; jj < NC; jj++) depth[jj] = lm::sel(lm::and_(winner, lm::abs_(am - (float)jj) < 0.5f), far_, depth[jj]);
+      F thr = mq + (float)LLM_SELECT_EPS;
+      F am = ln.lane_f(100.0f);                             // first own candidate within the tolerance of the leg's deepest
+      for (int jj = NC - 1; jj >= 0; jj--) am = lm::sel(depth[jj] <= thr, ln.lane_f((float)jj), am);
+      F code = lm::sel(lm::and_(am < 50.0f, mq < far_), L::i2f(ln.sub()) * 8.0f + am, ln.lane_f(1000.0f));
+      F wcode = L::submin(code);                            // lowest candidate index among them (1000 = none)
+      B winner = lm::and_(code <= wcode, code < 500.0f);
+      F dsel = zero;
+      for (int jj = 0; jj < NC; jj++) {
+        B hit = lm::and_(winner, lm::abs_(am - (float)jj) < 0.5f);
+        dsel = lm::sel(hit, depth[jj], dsel);
+        depth[jj] = lm::sel(hit, far_, depth[jj]);
+      }
+      F wdepth = L::subsum(dsel);
+      F wsub = lm::rint_(wcode * 0.125f - 0.4375f);         // floor(wcode / 8) for wcode = 8 sub + jj, jj < 8
       B owner = ln.is_sub(s);
-      my_depth = lm::sel(owner, lm::sel(wsub < 3.5f, mq, far_), my_depth);
+      my_depth = lm::sel(owner, lm::sel(wcode < 500.0f, wdepth, far_), my_depth);
       my_sub = lm::sel(owner, wsub, my_sub);
-      my_jj = lm::sel(owner, wjj, my_jj);
+      my_jj = lm::sel(owner, wcode - wsub * 8.0f, my_jj);
     }
     // store the kept candidates in candidate-index order (near-ties in depth must not reorder the solve): each slot lane
     // ranks its candidate among the leg's four and picks up the one whose rank equals its slot
@@ -872,8 +883,11 @@ struct Pmc {
         V3l a2 = mk3<F>(lm::sel(oth_s, oSA.x, oTA.x), lm::sel(oth_s, oSA.y, oTA.y), lm::sel(oth_s, oSA.z, oTA.z));
         V3l b2 = mk3<F>(lm::sel(oth_s, oSB.x, oTB.x), lm::sel(oth_s, oSB.y, oTB.y), lm::sel(oth_s, oSB.z, oTB.z));
         F r2 = lm::sel(oth_s, orS, orT);
+        // the closest points of two nearly parallel axes depend on which segment the algorithm treats first: the spec's pair (A, B)
+        // has A = the previous leg in pass 0 (the OTHER capsule) and A = the own leg in pass 1 -- the oracle's order
         V3l c1, c2;
-        seg_seg(ln, a1, b1, a2, b2, c1, c2);
+        if (pass == 0) seg_seg(ln, a2, b2, a1, b1, c2, c1);
+        else seg_seg(ln, a1, b1, a2, b2, c1, c2);
         V3l dd = c1 - c2;
         F len = lm::sqrt_(dot(dd, dd));
         F il = one / lm::max_(len, ln.lane_f(1e-9f));
@@ -898,7 +912,7 @@ struct Pmc {
           n_self_w = slot + 1;
           F dlane = lm::min_(cd[0], cd[1]);
           float dmin = L::rmin(dlane);
-          B at0 = cd[0] <= ln.lane_f(dmin), at1 = cd[1] <= ln.lane_f(dmin);
+          B at0 = cd[0] <= ln.lane_f(dmin + (float)LLM_SELECT_EPS), at1 = cd[1] <= ln.lane_f(dmin + (float)LLM_SELECT_EPS);   // equally deep within the tolerance: lower pair index
           F code = lm::min_(lm::sel(at0, cpair[0], ln.lane_f(1.0e9f)), lm::sel(at1, cpair[1], ln.lane_f(1.0e9f)));
           float cmin = L::rmin(code);
           const bool have = dmin < 1.0e29f;
@@ -909,6 +923,7 @@ struct Pmc {
           w6[2] = lm::sel(win0, cP[0].z, lm::sel(win1, cP[1].z, zero)); w6[3] = lm::sel(win0, cN[0].x, lm::sel(win1, cN[1].x, zero));
           w6[4] = lm::sel(win0, cN[0].y, lm::sel(win1, cN[1].y, zero)); w6[5] = lm::sel(win0, cN[0].z, lm::sel(win1, cN[1].z, zero));
           L::rsum6(w6, u6);
+          const float dsel = have ? L::rmin(lm::sel(win0, cd[0], lm::sel(win1, cd[1], far_))) : 0.0f;   // the chosen pair's own depth (within the tolerance of dmin)
           cd[0] = lm::sel(win0, far_, cd[0]); cd[1] = lm::sel(win1, far_, cd[1]);
           // who is who: pair index -> (own leg: sign +, other leg: sign -) and the links (2 thigh, 3 shank)
           const int pair = have ? (int)(cmin + 0.5f) : 0, lpi = pair >> 2, spi = pair & 3;
@@ -935,7 +950,7 @@ struct Pmc {
           float nn = L::qsum(sjt[0] * sjt[0] + sjt[1] * sjt[1] + sjt[2] * sjt[2]);
           for (int i = 0; i < 6; i++) nn += sgt[i] * sgt[i];
           self_row_pack(ln, sjt, sgt, rw);
-          rw.c = vrow + ((dmin > 0.0f) ? dmin * inv_dt : fmaxf(dmin * (P.erp * inv_dt), -P.max_depen));
+          rw.c = vrow + ((dsel > 0.0f) ? dsel * inv_dt : fmaxf(dsel * (P.erp * inv_dt), -P.max_depen));
           rw.inv = have ? 1.0f / nn : 0.0f;
           rw.lam = 0.0f;
           if (!have) self_row_clear(ln, rw);
@@ -1049,8 +1064,9 @@ struct Pmc {
           B my_body = lm::and_(mi < 7.5f, lm::not_(lm::and_(lm::abs_(mi - lm::rint_(mi * 0.5f) * 2.0f) > 0.5f, my_par > 0.9f)));
           tch = lm::sel(lm::and_(valid, my_body), zero, tch);
           F d = lm::sel(valid, dep, far_);
-          B beat0 = lm::or_(d < bd[0], lm::and_(lm::and_(d <= bd[0], d < 1.0e29f), id < bid[0]));
-          B beat1 = lm::and_(lm::not_(beat0), lm::or_(d < bd[1], lm::and_(lm::and_(d <= bd[1], d < 1.0e29f), id < bid[1])));
+          const float se = (float)LLM_SELECT_EPS;               // deeper by more than the tolerance, or equally deep with the lower id
+          B beat0 = lm::and_(d < 1.0e29f, lm::or_(d < bd[0] - se, lm::and_(d <= bd[0] + se, id < bid[0])));
+          B beat1 = lm::and_(lm::and_(lm::not_(beat0), d < 1.0e29f), lm::or_(d < bd[1] - se, lm::and_(d <= bd[1] + se, id < bid[1])));
           // shift down, then insert
           bd[1] = lm::sel(beat0, bd[0], lm::sel(beat1, d, bd[1])); bid[1] = lm::sel(beat0, bid[0], lm::sel(beat1, id, bid[1]));
           bP[1] = mk3<F>(lm::sel(beat0, bP[0].x, lm::sel(beat1, pp.x, bP[1].x)), lm::sel(beat0, bP[0].y, lm::sel(beat1, pp.y, bP[1].y)), lm::sel(beat0, bP[0].z, lm::sel(beat1, pp.z, bP[1].z)));
@@ -1067,10 +1083,11 @@ struct Pmc {
             if (slot == 1 && !L::any(bd[0] < 1.0e29f)) break;
             n_pair_w = slot + 1;
             const float dmin = L::rmin(bd[0]);
-            B at = bd[0] <= ln.lane_f(dmin);
+            B at = bd[0] <= ln.lane_f(dmin + (float)LLM_SELECT_EPS);                       // equally deep within the tolerance: lower pair id
             const float imin = L::rmin(lm::sel(at, bid[0], ln.lane_f(1.0e9f)));
             const bool have = dmin < 1.0e29f;
             B win = lm::and_(at, lm::abs_(bid[0] - imin) < 0.5f);
+            const float dsel = have ? L::rmin(lm::sel(win, bd[0], far_)) : 0.0f;
             // several lanes may hold the same pair (never: each pair is evaluated by exactly one lane of a row)
             F w6[6] = {lm::sel(win, bP[0].x, zero), lm::sel(win, bP[0].y, zero), lm::sel(win, bP[0].z, zero), lm::sel(win, bN[0].x, zero), lm::sel(win, bN[0].y, zero), lm::sel(win, bN[0].z, zero)};
             float u6[6];
@@ -1107,7 +1124,7 @@ struct Pmc {
             for (int i = 0; i < 6; i++) nn += sgt[i] * sgt[i];
             self_row_pack(ln, sjt, sgt, rw);
             const float vo = ln.peer_u(vrow), no = ln.peer_u(nn);
-            rw.c = ((me == 0) ? vrow + vo : vo + vrow) + ((dmin > 0.0f) ? dmin * inv_dt : fmaxf(dmin * (P.erp * inv_dt), -P.max_depen));
+            rw.c = ((me == 0) ? vrow + vo : vo + vrow) + ((dsel > 0.0f) ? dsel * inv_dt : fmaxf(dsel * (P.erp * inv_dt), -P.max_depen));
             rw.inv = have ? 1.0f / ((me == 0) ? nn + no : no + nn) : 0.0f;
             rw.lam = 0.0f;
             if (!have) self_row_clear(ln, rw);

@@ -714,8 +714,11 @@ static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double 
     const int kc = (int)g_spec[LLM_SPEC_MAX_CONTACTS_PER_LEG];
     for (int s = 0; s < kc; s++) {          /* the KC deepest (ties: lower index) ... */
       int best = -1;
+      double dmin = INFINITY;                /* candidates within LLM_SELECT_EPS of the deepest are equally deep: the lowest index wins */
       for (int i = 0; i < 32; i++)
-        if (c[i].valid && !taken[i] && c[i].depth < g_spec[LLM_SPEC_CONTACT_MARGIN] && (best < 0 || c[i].depth < c[best].depth)) best = i;
+        if (c[i].valid && !taken[i] && c[i].depth < g_spec[LLM_SPEC_CONTACT_MARGIN] && c[i].depth < dmin) dmin = c[i].depth;
+      for (int i = 0; i < 32 && best < 0; i++)
+        if (c[i].valid && !taken[i] && c[i].depth < g_spec[LLM_SPEC_CONTACT_MARGIN] && c[i].depth <= dmin + LLM_SELECT_EPS) best = i;
       if (best < 0) break;
       taken[best] = 1;
       nsel++;
@@ -769,7 +772,14 @@ static void seg_seg(const double* p1, const double* q1, const double* p2, const 
   double d1[3], d2[3], r[3];
   for (int i = 0; i < 3; i++) { d1[i] = q1[i] - p1[i]; d2[i] = q2[i] - p2[i]; r[i] = p1[i] - p2[i]; }
   double a = v3dot(d1, d1), e = v3dot(d2, d2), f = v3dot(d2, r), c = v3dot(d1, r), b = v3dot(d1, d2);
-  double den = a * e - b * b, s = den > 1e-12 ? (b * f - c * e) / den : 0.0, t;
+  /* Nearly parallel segments: den = a e sin^2(angle) -> 0 and the textbook quotient is 0 / 0 -- any s between the overlap's ends is a
+   * closest point, and which one rounding picks decides where the contact row acts.  The spec regularises: the quotient is pulled
+   * toward the middle of the overlap (sa, sb = the other segment's ends projected on this one) with weight LLM_SEG_PARALLEL_REG
+   * relative to a e; for angles above a few degrees this is Ericson's closest point, for parallel capsules the middle of the overlap. */
+  double sa = -c / a, sb = (b - c) / a;
+  sa = sa < 0 ? 0 : (sa > 1 ? 1 : sa); sb = sb < 0 ? 0 : (sb > 1 ? 1 : sb);
+  double reg = LLM_SEG_PARALLEL_REG * a * e;
+  double den = a * e - b * b, s = (b * f - c * e + reg * 0.5 * (sa + sb)) / (den + reg), t;
   if (s < 0) s = 0;
   if (s > 1) s = 1;
   t = (b * s + f) / e;
@@ -799,8 +809,11 @@ static int find_self_contacts(const OModel* M, const OKin* K, OSelf* out) {
   int n = 0, taken[24] = {0};
   for (int s = 0; s < (int)g_spec[LLM_SPEC_MAX_SELF]; s++) {
     int best = -1;
+    double dmin = INFINITY;                  /* (cand[] is in pair-index order) */
     for (int i = 0; i < nc; i++)
-      if (!taken[i] && cand[i].depth < g_spec[LLM_SPEC_SELF_MARGIN] && (best < 0 || cand[i].depth < cand[best].depth)) best = i;
+      if (!taken[i] && cand[i].depth < g_spec[LLM_SPEC_SELF_MARGIN] && cand[i].depth < dmin) dmin = cand[i].depth;
+    for (int i = 0; i < nc && best < 0; i++)
+      if (!taken[i] && cand[i].depth < g_spec[LLM_SPEC_SELF_MARGIN] && cand[i].depth <= dmin + LLM_SELECT_EPS) best = i;
     if (best < 0) break;
     taken[best] = 1;
     out[n++] = cand[best];
@@ -1162,8 +1175,11 @@ static int find_pair_contacts(const OModel* M, const OKin* K0, const OKin* K1, O
   int n = 0, taken[100] = {0};
   for (int s = 0; s < 2; s++) {
     int best = -1;
+    double dmin = INFINITY;                  /* (cand[] is in pair-id order) */
     for (int i = 0; i < nc; i++)
-      if (!taken[i] && cand[i].depth < LLM_CONTACT_MARGIN && (best < 0 || cand[i].depth < cand[best].depth)) best = i;
+      if (!taken[i] && cand[i].depth < LLM_CONTACT_MARGIN && cand[i].depth < dmin) dmin = cand[i].depth;
+    for (int i = 0; i < nc && best < 0; i++)
+      if (!taken[i] && cand[i].depth < LLM_CONTACT_MARGIN && cand[i].depth <= dmin + LLM_SELECT_EPS) best = i;
     if (best < 0) break;
     taken[best] = 1;
     out[n++] = cand[best];

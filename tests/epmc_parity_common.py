@@ -278,10 +278,10 @@ def check_terrain_physics_against_oracle(lib_path, n_envs=16, seed=11):
         E.close()
     c, v = np.array(out['config']), np.array(out['vel'])
     assert out['n_terrain'] >= 10 and out.get('n_felt', 0) >= 8, (out['n_terrain'], out.get('n_felt', 0))
-    # (the 4th-deepest candidate of a leg may be a near-tie between two points, which float32 and float64 can break differently; checked on
-    # the one outlier of the 96 GPU cases: the float64 oracle's own result moves by 6e-2 when that start state is perturbed by 1e-7)
-    assert np.median(c) < 1e-4 and (c < 5e-3).mean() >= 0.95, np.sort(c)[-5:]
-    assert np.median(v) < 1e-3 and (v < 5e-2).mean() >= 0.95, np.sort(v)[-5:]
+    # every case within the bars of flat-ground motion: candidates whose depths tie up to rounding are chosen by index in both
+    # implementations (LLM_SELECT_EPS), so the deepest-4 rule no longer hangs on the arithmetic
+    assert c.max() < 1e-4, np.sort(c)[-5:]
+    assert v.max() < 1e-3, np.sort(v)[-5:]
     return out
 
 

@@ -4,11 +4,10 @@ with reference-generated goldens on identical inputs.
 
 Tolerances (float32 engine vs float64 reference/oracle), as stated in BASELINE.md §5:
   * non-physics math (mocap, obs, reward, flags): 1e-5
-  * physics: one control step (10 substeps, contacts included): state error <= 1e-4 for the configuration
+  * physics: one control step (10 substeps, contacts included): EVERY sample's state error <= 1e-4 for the configuration
     (base position, quaternion, joint angles) and, for velocities -- joint rates reach 35 rad/s on links that weigh
-    170 g, so an absolute 1e-4 is below float32 resolution of the accelerations involved -- 1e-4 RELATIVE to
-    (1 + largest joint rate of that env) at the 99th percentile, with a hard cap of 20x on the worst sample
-    (a contact that switches on in one arithmetic and not in the other).
+    170 g, so an absolute 1e-4 is below float32 resolution of the accelerations involved -- <= 1e-3 RELATIVE to
+    (1 + largest joint rate of that env), with at most 1 % of the samples above 1e-4.
 """
 import numpy as np
 
@@ -117,16 +116,16 @@ def run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed
 def check_single_step_parity(golden, orc, model_blob, table, lib_path, n_envs=32, n_steps=12, seed=7):
     st = run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True)
     assert len(st['config']) > n_envs * n_steps * 0.5
+    # EVERY sample: configuration within 1e-4, velocities within 1e-3 of (1 + the env's largest joint rate); and at most 1 % of the env-steps
+    # above 1e-4 in velocity (float32 rounding through a contact that switches on or off inside the step; 0.4 % measured)
     assert st['config'].max() < PHYS_STEP_TOL, np.percentile(st['config'], [50, 90, 99, 100])
-    # a step in which a self-collision row is active is looser (closest points of nearly parallel capsules are ill-conditioned
-    # in float32: 1e-4 .. 5e-4 measured): at most 2.5 % of the env-steps may exceed the bar, none the 20x bound
     v = np.asarray(st['vel']).reshape(-1)
-    assert (v > PHYS_STEP_TOL).sum() <= max(1, len(v) // 40), np.percentile(v, [50, 90, 99, 100])
-    assert st['vel'].max() < 20 * PHYS_STEP_TOL, st['vel'].max()
+    assert (v > PHYS_STEP_TOL).sum() <= max(1, len(v) // 100), np.percentile(v, [50, 90, 99, 100])
+    assert st['vel'].max() < 10 * PHYS_STEP_TOL, st['vel'].max()
     assert st['obs'].max() < PHYS_STEP_TOL, np.percentile(st['obs'], [50, 90, 99, 100])
     ov = np.asarray(st['obs_vel']).reshape(-1)
-    assert (ov > PHYS_STEP_TOL).sum() <= max(1, len(ov) // 40), np.percentile(ov, [50, 90, 99, 100])
-    assert st['obs_vel'].max() < 20 * PHYS_STEP_TOL
+    assert (ov > PHYS_STEP_TOL).sum() <= max(1, len(ov) // 100), np.percentile(ov, [50, 90, 99, 100])
+    assert st['obs_vel'].max() < 10 * PHYS_STEP_TOL
     assert st['reward'].max() < PHYS_STEP_TOL
     assert st['feet'].max() < PHYS_STEP_TOL
     assert st['done_mismatch'] <= max(1, st['done'] // 10)
@@ -173,10 +172,9 @@ def check_contact_rich_parity(golden, orc, model_blob, table, lib_path, n_envs=1
     E.close()
     out = {k: np.array(v) for k, v in out.items()}
     assert np.isfinite(es).all()
-    # a penetrating start makes a stiff, many-contact solve: parity is looser than in free motion, but the two
-    # arithmetics must still tell the same story
-    assert np.median(out['config']) < 1e-4 and out['config'].max() < 5e-3, out['config']
-    assert np.median(out['vel']) < 1e-3 and out['vel'].max() < 5e-2, out['vel']
+    # a penetrating start makes a stiff, many-contact solve; every sample still within the bars of free motion (measured: 1e-6 / 1.3e-5)
+    assert out['config'].max() < 1e-4, out['config']
+    assert out['vel'].max() < 1e-3, out['vel']
     return out
 
 
@@ -476,8 +474,8 @@ def check_self_collision_parity(golden, orc, model_blob, table, lib_path, n_envs
     E.close()
     cfg_err, vel_err = np.array(cfg_err), np.array(vel_err)
     assert stopped >= n_envs // 2, stopped
-    assert np.median(cfg_err) < 1e-4 and cfg_err.max() < 5e-3, cfg_err
-    assert np.median(vel_err) < 1e-3 and vel_err.max() < 5e-2, vel_err
+    assert cfg_err.max() < 1e-4, cfg_err              # every sample (measured: 8e-7 / 2.5e-5 -- since the closest-point routine takes the pair's
+    assert vel_err.max() < 1e-3, vel_err              # segments in the spec's order (A first) in both implementations and is regularised for parallel axes)
     return dict(config=cfg_err, vel=vel_err, stopped=stopped)
 
 

@@ -513,8 +513,7 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5):
     E.close()
     c, v = np.array(out['config']), np.array(out['vel'])
     assert out['n_rows'] >= n_arenas // 2 and out['n_felt'] >= n_arenas // 3, (out['n_rows'], out['n_felt'])
-    assert np.median(c) < 1e-4 and np.median(v) < 1e-3, (np.median(c), np.median(v))
-    assert (c < 5e-3).mean() > 0.9 and (v < 5e-2).mean() > 0.9, (np.sort(c)[-6:], np.sort(v)[-6:])   # a near-tie between two capsule pairs may fall either way in float32
+    assert c.max() < 1e-4 and v.max() < 1e-3, (np.sort(c)[-6:], np.sort(v)[-6:])     # every robot of every arena (measured: 4e-6 / 2e-5)
     w = np.array(out['who'])
     # who-touches-whom from this build's contact classes (the env's real, unscripted bookkeeping path) against the oracle's restatement
     assert w[:, 0].mean() > 0.9 and w[:, 1].mean() > 0.9 and (w[:, 2] == 4).sum() >= 3 and (w[:, 2] == 1).sum() >= 1, (w[:, 0].mean(), w[:, 1].mean(), w[:, 2].tolist())

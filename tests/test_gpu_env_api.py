@@ -206,3 +206,37 @@ def test_policy_gradient_actor_outputs(model_blob, mocap_table):
     assert np.isfinite(f['R']).all() and (f['R'] != 0).all() and (np.abs(f['R'] - f['V']) < 20).all()
     assert (f['neglogp'] > 0).all() or (f['neglogp'] < 0).any()           # filled, not the zero of "no policy attached"
     pol.close(); E.close()
+
+
+def test_bench_two_ranks_on_one_device(tmp_path):
+    """bench.py's N > 1 branch end to end (an 8-GPU node is not ours to lease): two ranks launched the way the driver launches
+    them, both on device 0, the gather staged through gloo (LL_BENCH_BACKEND / LL_BENCH_ONE_DEVICE test hooks).  The JSON line is the
+    contract's, rank 0's gathered blocks equal what each rank's engine recorded, and the gather overlaps with the steps."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    torch_cuda()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, LL_BENCH_BACKEND='gloo', LL_BENCH_ONE_DEVICE='1', LL_BENCH_VERIFY='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    steps, warm, n = 384, 128, 512                                        # three gathered unrolls of 128 steps inside the timed region
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', str(steps), '--warmup', str(warm), '--envs-per-gpu', str(n)]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1, out.stdout[-2000:]                               # ONE line, from rank 0
+    j = json.loads(line[0])
+    assert j['n_gpus'] == 2 and j['steps'] == steps and j['scaling'] == 'weak' and j['unit'] == 'env-steps/s'
+    assert abs(j['value'] - 2 * n * steps / (j['ms_per_step'] * 1e-3 * steps)) < 1e-6 * j['value']       # whole-job aggregate over both ranks
+    c = j['config']
+    assert c['unrolls_gathered'] == (steps + warm) // 128 and c['unroll_row_floats'] == 224 and c['gather_check'] == 'ok'
+    # overlap: the timed region is not (steps x kernel) + (gathers end to end); with two ranks time-sharing one device the step kernels
+    # of the two ranks serialise, so the bound is 2 x kernel per step plus slack for the host-staged test gather
+    assert j['ms_per_step'] < 2.0 * j['roofline']['kernel_avg_ms'] + 0.25, j
+    log_dir = os.path.join(root, 'gpurun_out', 'two_rank')
+    os.makedirs(log_dir, exist_ok=True)
+    with open(os.path.join(log_dir, 'bench_two_ranks_one_device.json'), 'w') as f:
+        f.write(line[0] + '\n')

@@ -62,23 +62,30 @@ def score(rsum, steps, why, alive):
 
 
 def run_engine(pol, blob, table, n, over, seed):
+    """the fused HIP policy kernel (mean action) and the step kernel, back to back on one stream; only reward / done come to the host"""
     from lifelike_agility_and_play_amd import capi
+    from lifelike_agility_and_play_amd.pmc_policy_hip import HipPmcPolicy
     cfg = capi.make_config(n, control_freq=50.0, kd=0.5, reward_weights=RW, prop_type=PT, prioritized_sample_factor=3.0, auto_reset=0, seed=seed)
     E = capi.Engine(cfg, blob, table)
     E.set_spec(**over)
+    hp = HipPmcPolicy()
     clip, t0 = starts(table, n, seed)
     E.reset(clip=clip, t0=t0)
     alive = np.ones(n, bool); steps = np.zeros(n, int); rsum = np.zeros(n); why = np.zeros(n, int)
     for t in range(HORIZON):
-        E.step_host(pol.act(E.obs().astype(np.float64)))
+        hp.act(E)
+        E.step()
         r, d, w = E.reward_done()
         rsum += np.where(alive, r, 0.0); steps += alive
         newly = alive & d
         why[newly] = w[newly]
         alive &= ~d
+        if newly.any():
+            ids = np.where(newly)[0]
+            E.reset(env_ids=ids, clip=clip[ids], t0=t0[ids])                # a finished env idles inside its clip; its further steps are not scored
         if not alive.any():
             break
-    E.close()
+    hp.close(); E.close()
     return score(rsum, steps, why, alive)
 
 
