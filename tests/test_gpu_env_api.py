@@ -191,7 +191,7 @@ def test_policy_gradient_actor_outputs(model_blob, mocap_table):
     np.testing.assert_allclose(NL.cpu().numpy(), 0.5 * np.log(2 * np.pi) * 12 + ref.w[27].sum(), rtol=1e-5)
     # a rollout: policy -> step, the TD(lambda) returns when a block is complete; rows carry what the policy reported
     E.reset()
-    for s in range(2 * unroll + 1):
+    for s in range(2 * unroll):                                          # (step 2 * unroll would start overwriting block 0)
         pol.act_pg(E, seed=5, step=s, sample=True)
         if s and s % unroll == 0:
             tb.finish(s // unroll - 1, gamma=0.95, lam=0.95)            # bootstrapped from V(obs_s), which the call above just wrote
@@ -201,10 +201,15 @@ def test_policy_gradient_actor_outputs(model_blob, mocap_table):
             torch.cuda.synchronize()
             f = gather.split_row(tb.half(s // unroll)[:, s % unroll], E.obs_dim)
             assert torch.equal(f['neglogp'], nl_s) and torch.equal(f['V'], v_s) and torch.equal(f['A'], a_s)
+    pol.act_pg(E, seed=5, step=2 * unroll, sample=True)                   # V of the observation after block 1 ...
+    tb.finish(1, gamma=0.95, lam=0.95)                                     # ... bootstraps its returns
     torch.cuda.synchronize()
+    for blk in (0, 1):
+        f = gather.split_row(tb.half(blk).cpu().numpy(), E.obs_dim)
+        assert np.isfinite(f['R']).all() and (f['R'] != 0).all() and (np.abs(f['R'] - f['V']) < 20).all()
+        assert (f['neglogp'] != 0).all() and (f['V'] != 0).all()           # filled by the policy, not the zero of "no policy attached"
     f = gather.split_row(tb.half(0).cpu().numpy(), E.obs_dim)
     assert np.isfinite(f['R']).all() and (f['R'] != 0).all() and (np.abs(f['R'] - f['V']) < 20).all()
-    assert (f['neglogp'] > 0).all() or (f['neglogp'] < 0).any()           # filled, not the zero of "no policy attached"
     pol.close(); E.close()
 
 
