@@ -67,8 +67,12 @@ LL_HD bool eq_(int a, int b) { return a == b; }
 // DPP helpers.  ctrl encodings (gfx9 DPP16): quad_perm 0x00-0xFF, row_shr:n 0x110+n, row_ror:n 0x120+n, row_newbcast:n 0x150+n.
 #define LL_DPP_MOV(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (x)), (ctrl), 0xf, 0xf, true))
 
+typedef float ll_f2 __attribute__((ext_vector_type(2)));   // two floats in an aligned register pair: the operand of v_pk_*_f32
+
 struct GpuLanes {
   using F = float;
+  using F2 = ll_f2;
+  static LL_D F2 pair(F a, F b) { F2 r; r.x = a; r.y = b; return r; }
   using I = int;
   using D = double;
   using B = bool;
@@ -233,10 +237,11 @@ struct GpuLanes {
   // Four Gauss-Seidel turns (lanes S, 4+S, 8+S, 12+S) as one block: v_med3 (clamp the pending increment), v_cndmask (the lane
   // whose turn it is keeps its increment; masks m0..m3 are the lane masks of the four turns), one wait state, v_fmac with a
   // DPP row broadcast (every lane's pending increment moves by nk * d).  4 issue slots per turn.
-  template <int S_>
+  template <int S_, bool NEG_LO = false>   // NEG_LO: the lower bound is -lo (a unilateral row passes its multiplier and saves the subtraction)
   LL_D void turns4(F& u, F& dl, F lo, F hi, F k0, F k1, F k2, F k3) const {
     const unsigned long long m0 = tm_[S_], m1 = tm_[4 + S_], m2 = tm_[8 + S_], m3 = tm_[12 + S_];
     float d;
+    if (NEG_LO) lo = -lo;
 #define LL_T1(K, M, L_)                                                                          \
     "v_med3_f32 %2, %0, %3, %4\n\t"                                                            \
     "v_cndmask_b32_e64 %1, %1, %2, " M "\n\t"                                                  \
@@ -250,28 +255,27 @@ struct GpuLanes {
   }
   // Eight Gauss-Seidel turns as ONE block (H_ = 0: lanes 0,4,8,12, 1,5,9,13;  H_ = 1: lanes 2,6,10,14, 3,7,11,15): between two
   // separate asm statements the compiler puts a wait state of its own.
-  template <int H_>
+  template <int H_, bool NEG_LO = false>   // NEG_LO: the lower bound is -lo, taken with the instruction's own source negation
   LL_D void turns8(F& u, F& dl, F lo, F hi, const F* nk) const {
     constexpr int A = 2 * H_, B = 2 * H_ + 1;
     const unsigned long long m0 = tm_[A], m1 = tm_[4 + A], m2 = tm_[8 + A], m3 = tm_[12 + A], m4 = tm_[B], m5 = tm_[4 + B], m6 = tm_[8 + B], m7 = tm_[12 + B];
     float d;
-#define LL_T1(K, M, L_)                                                                          \
-    "v_med3_f32 %2, %0, %3, %4\n\t"                                                            \
+#define LL_T1(LO, K, M, L_)                                                                      \
+    "v_med3_f32 %2, %0, " LO ", %4\n\t"                                                        \
     "v_cndmask_b32_e64 %1, %1, %2, " M "\n\t"                                                  \
     "s_nop 0\n\t"                                                                              \
     "v_fmac_f32_dpp %0, %2, " K " row_newbcast:" L_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-    if (H_ == 0)
-      asm(LL_T1("%5", "%13", "0") LL_T1("%6", "%14", "4") LL_T1("%7", "%15", "8") LL_T1("%8", "%16", "12")
-          LL_T1("%9", "%17", "1") LL_T1("%10", "%18", "5") LL_T1("%11", "%19", "9") LL_T1("%12", "%20", "13")
-          : "+v"(u), "+v"(dl), "=&v"(d)
-          : "v"(lo), "v"(hi), "v"(nk[0]), "v"(nk[4]), "v"(nk[8]), "v"(nk[12]), "v"(nk[1]), "v"(nk[5]), "v"(nk[9]), "v"(nk[13]),
-            "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4), "s"(m5), "s"(m6), "s"(m7));
-    else
-      asm(LL_T1("%5", "%13", "2") LL_T1("%6", "%14", "6") LL_T1("%7", "%15", "10") LL_T1("%8", "%16", "14")
-          LL_T1("%9", "%17", "3") LL_T1("%10", "%18", "7") LL_T1("%11", "%19", "11") LL_T1("%12", "%20", "15")
-          : "+v"(u), "+v"(dl), "=&v"(d)
-          : "v"(lo), "v"(hi), "v"(nk[2]), "v"(nk[6]), "v"(nk[10]), "v"(nk[14]), "v"(nk[3]), "v"(nk[7]), "v"(nk[11]), "v"(nk[15]),
-            "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4), "s"(m5), "s"(m6), "s"(m7));
+#define LL_T8(LO, L0, L1, L2, L3, L4, L5, L6, L7)                                                                                        \
+      asm(LL_T1(LO, "%5", "%13", L0) LL_T1(LO, "%6", "%14", L1) LL_T1(LO, "%7", "%15", L2) LL_T1(LO, "%8", "%16", L3)                    \
+          LL_T1(LO, "%9", "%17", L4) LL_T1(LO, "%10", "%18", L5) LL_T1(LO, "%11", "%19", L6) LL_T1(LO, "%12", "%20", L7)                 \
+          : "+v"(u), "+v"(dl), "=&v"(d)                                                                                                  \
+          : "v"(lo), "v"(hi), "v"(nk[A]), "v"(nk[4 + A]), "v"(nk[8 + A]), "v"(nk[12 + A]), "v"(nk[B]), "v"(nk[4 + B]), "v"(nk[8 + B]), "v"(nk[12 + B]), \
+            "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4), "s"(m5), "s"(m6), "s"(m7))
+    if (H_ == 0 && !NEG_LO) LL_T8("%3", "0", "4", "8", "12", "1", "5", "9", "13");
+    else if (H_ == 0) LL_T8("-%3", "0", "4", "8", "12", "1", "5", "9", "13");
+    else if (!NEG_LO) LL_T8("%3", "2", "6", "10", "14", "3", "7", "11", "15");
+    else LL_T8("-%3", "2", "6", "10", "14", "3", "7", "11", "15");
+#undef LL_T8
 #undef LL_T1
   }
 
@@ -282,7 +286,7 @@ struct GpuLanes {
   //   ca[k] = gt[s ^ k],   cb[k] = gt[4 + ((s ^ k) & 1)],   cj[k] = jt[s ^ k] (index 3: zero)          k = 0..3 / 0..1 / 0..3
   // vel_dot:    c + gt . dx + jt . dq = c + sum_k ca[k] * VA[s ^ k] + ...: ten multiply-adds, seven of them with a quad_perm source;
   //             the three plain ones come first, so a register written just before the call has settled when DPP reads it.
-  LL_D static F vel_dot(F c, const F* ca, const F* cb, const F* cj, F VA, F VB, F VJ) {
+  LL_D static F vel_dot(F c, F2 ca01, F2 ca23, F2 cb01, F2 cj01, F2 cj23, F VA, F VB, F VJ) {
     float w;
 #define LL_Q(X) " quad_perm:" X " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
     asm("v_fma_f32 %0, %1, %11, %14\n\t"
@@ -296,45 +300,41 @@ struct GpuLanes {
         "v_fmac_f32_dpp %0, %13, %9" LL_Q("[2,3,0,1]")
         "v_fmac_f32_dpp %0, %13, %10" LL_Q("[3,2,1,0]")
         : "=&v"(w)
-        : "v"(ca[0]), "v"(ca[1]), "v"(ca[2]), "v"(ca[3]), "v"(cb[0]), "v"(cb[1]), "v"(cj[0]), "v"(cj[1]), "v"(cj[2]), "v"(cj[3]), "v"(VA), "v"(VB),
+        : "v"(ca01.x), "v"(ca01.y), "v"(ca23.x), "v"(ca23.y), "v"(cb01.x), "v"(cb01.y), "v"(cj01.x), "v"(cj01.y), "v"(cj23.x), "v"(cj23.y), "v"(VA), "v"(VB),
           "v"(VJ), "v"(c));
     return w;
   }
   // vel_commit: every lane has committed the multiplier increment dl of its row;  dx += sum over the 16 lanes of gt * dl,
   // dq += sum over the leg's 4 lanes of jt * dl.  A transpose-reduce: because lane s multiplies dl with the coefficient of value
   // s ^ k, "own product + partner's product" lands value s in lane s after two quad exchanges -- 4 multiplies and 3 adds reduce four
-  // values over a quad (an all-reduce takes 4 and 8), and the result is already laid out as VA / VB / VJ.  25 instructions; every
-  // DPP read is at least three instructions behind its producer, so the block has no wait states.
-  LL_D static void vel_commit(F dl, const F* ca, const F* cb, const F* cj, F& VA, F& VB, F& VJ) {
-    float p0, p1, p2, p3, q0, q1, j0, j1, j2, j3;
+  // values over a quad (an all-reduce takes 4 and 8), and the result is already laid out as VA / VB / VJ.  The ten products are five
+  // v_pk_mul_f32 (the coefficients live in register pairs for this); 20 instructions; every DPP read is at least three instructions
+  // behind its producer, so the block has no wait states.
+  // (lam += dl rides along as the block's first instruction: with the s_nop behind it, the products -- computed by the compiler's own
+  //  v_pk_mul_f32 just before the block -- have settled when the first DPP read comes, wherever the scheduler put them)
+  LL_D static void vel_commit(F dl, F& lam, F2 ca01, F2 ca23, F2 cb01, F2 cj01, F2 cj23, F& VA, F& VB, F& VJ) {
+    const F2 P01 = ca01 * dl, P23 = ca23 * dl, Q01 = cb01 * dl, J01 = cj01 * dl, J23 = cj23 * dl;
+    float p0 = P01.x, p1 = P01.y, p2 = P23.x, p3 = P23.y, q0 = Q01.x, q1 = Q01.y, j0 = J01.x, j1 = J01.y, j2 = J23.x, j3 = J23.y;
 #define LL_R(X) " " X " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-    asm("v_mul_f32_e32 %3, %13, %23\n\t"
-        "v_mul_f32_e32 %4, %14, %23\n\t"
-        "v_mul_f32_e32 %5, %15, %23\n\t"
-        "v_mul_f32_e32 %6, %16, %23\n\t"
-        "v_mul_f32_e32 %7, %17, %23\n\t"
-        "v_mul_f32_e32 %8, %18, %23\n\t"
-        "v_mul_f32_e32 %9, %19, %23\n\t"
-        "v_mul_f32_e32 %10, %20, %23\n\t"
-        "v_mul_f32_e32 %11, %21, %23\n\t"
-        "v_mul_f32_e32 %12, %22, %23\n\t"
-        "v_add_f32_dpp %3, %4, %3" LL_R("quad_perm:[1,0,3,2]")
-        "v_add_f32_dpp %5, %6, %5" LL_R("quad_perm:[1,0,3,2]")
-        "v_add_f32_dpp %7, %8, %7" LL_R("quad_perm:[1,0,3,2]")
-        "v_add_f32_dpp %9, %10, %9" LL_R("quad_perm:[1,0,3,2]")
-        "v_add_f32_dpp %11, %12, %11" LL_R("quad_perm:[1,0,3,2]")
-        "v_add_f32_dpp %3, %5, %3" LL_R("quad_perm:[2,3,0,1]")
-        "v_add_f32_dpp %7, %7, %7" LL_R("quad_perm:[2,3,0,1]")
-        "v_add_f32_dpp %9, %11, %9" LL_R("quad_perm:[2,3,0,1]")
+    asm("v_add_f32_e32 %8, %8, %14\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %3, %9, %3" LL_R("quad_perm:[1,0,3,2]")
+        "v_add_f32_dpp %4, %10, %4" LL_R("quad_perm:[1,0,3,2]")
+        "v_add_f32_dpp %5, %11, %5" LL_R("quad_perm:[1,0,3,2]")
+        "v_add_f32_dpp %6, %12, %6" LL_R("quad_perm:[1,0,3,2]")
+        "v_add_f32_dpp %7, %13, %7" LL_R("quad_perm:[1,0,3,2]")
+        "v_add_f32_dpp %3, %4, %3" LL_R("quad_perm:[2,3,0,1]")
+        "v_add_f32_dpp %5, %5, %5" LL_R("quad_perm:[2,3,0,1]")
+        "v_add_f32_dpp %6, %7, %6" LL_R("quad_perm:[2,3,0,1]")
         "v_add_f32_dpp %3, %3, %3" LL_R("row_ror:4")
-        "v_add_f32_dpp %7, %7, %7" LL_R("row_ror:4")
-        "v_add_f32_e32 %2, %2, %9\n\t"
+        "v_add_f32_dpp %5, %5, %5" LL_R("row_ror:4")
+        "v_add_f32_e32 %2, %2, %6\n\t"
         "v_add_f32_dpp %3, %3, %3" LL_R("row_ror:8")
-        "v_add_f32_dpp %7, %7, %7" LL_R("row_ror:8")
+        "v_add_f32_dpp %5, %5, %5" LL_R("row_ror:8")
         "v_add_f32_e32 %0, %0, %3\n\t"
-        "v_add_f32_e32 %1, %1, %7"
-        : "+v"(VA), "+v"(VB), "+v"(VJ), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(q0), "=&v"(q1), "=&v"(j0), "=&v"(j1), "=&v"(j2), "=&v"(j3)
-        : "v"(ca[0]), "v"(ca[1]), "v"(ca[2]), "v"(ca[3]), "v"(cb[0]), "v"(cb[1]), "v"(cj[0]), "v"(cj[1]), "v"(cj[2]), "v"(cj[3]), "v"(dl));
+        "v_add_f32_e32 %1, %1, %5"
+        : "+v"(VA), "+v"(VB), "+v"(VJ), "+v"(p0), "+v"(p2), "+v"(q0), "+v"(j0), "+v"(j2), "+v"(lam)
+        : "v"(p1), "v"(p3), "v"(q1), "v"(j1), "v"(j3), "v"(dl));
 #undef LL_R
 #undef LL_Q
   }

@@ -66,6 +66,7 @@ struct Pmc {
   typedef typename L::B B;
   typedef typename L::I I;
   typedef typename L::D D;
+  typedef typename L::F2 F2;
   typedef V3<float> V3u;
   typedef V3<F> V3l;
 
@@ -228,7 +229,8 @@ struct Pmc {
   // held in registers in whitened coordinates together with the Gram scalars against the 16 rows of the same round
   // ---------------------------------------------------------------------------------------------------
   struct Row {
-    F ca[4], cb[2], cj[4];   // the row's nine coefficients gt[6], jt[3], permuted for its lane (lanes.hpp "scattered velocity state")
+    F2 ca01, ca23, cb01, cj01, cj23;   // the row's nine coefficients gt[6], jt[3], permuted for its lane (lanes.hpp "scattered velocity state"),
+                                       // in register pairs: ca[k] = gt[sub ^ k], cb[k] = gt[4 + ((sub ^ k) & 1)], cj[k] = jt[sub ^ k]
     F c, inv, lam;
     F nk[16];                // -(gt . gt_L + [same leg] jt . jt_L) * inv   for L = lane of the env row
   };
@@ -259,10 +261,13 @@ struct Pmc {
     L::template gram4<2>(gt, yg, r.nk);
     if (!LIMIT) L::template gram4<3>(gt, yg, r.nk);
     r.lam = zero;
-    permute4(ln, gt[0], gt[1], gt[2], gt[3], r.ca);
+    F t[4];
+    permute4(ln, gt[0], gt[1], gt[2], gt[3], t);
+    r.ca01 = L::pair(t[0], t[1]); r.ca23 = L::pair(t[2], t[3]);
     B odd = lm::odd_(ln.sub());
-    r.cb[0] = lm::sel(odd, gt[5], gt[4]); r.cb[1] = lm::sel(odd, gt[4], gt[5]);
-    permute4(ln, jt[0], jt[1], jt[2], zero, r.cj);
+    r.cb01 = L::pair(lm::sel(odd, gt[5], gt[4]), lm::sel(odd, gt[4], gt[5]));
+    permute4(ln, jt[0], jt[1], jt[2], zero, t);
+    r.cj01 = L::pair(t[0], t[1]); r.cj23 = L::pair(t[2], t[3]);
   }
   template <int K_>
   static LL_HD void pick_rank(const L& ln, const F& rank, const F& me, const F& d, const F& sb, const F& jj, F& nd, F& ns, F& nj) {
@@ -277,18 +282,19 @@ struct Pmc {
   // A turn: the lane whose turn it is commits clamp(u) -- every lane's pending increment then moves by nk[L] * d_L.  All turns run
   // unconditionally: a lane without a live row has inv = 0 and commits exactly zero.  (Skipping the 4-turn blocks no env of the wave
   // occupies was measured slower: each wave-uniform test costs more issue slots than the 16 instructions it occasionally saves.)
-  template <bool LIMIT>
-  static LL_HD void gs_round(const L& ln, Row& r, const F& lo, const F& hi, F& VA, F& VB, F& VJ) {
+  // UNILATERAL (limit and normal rows: 0 <= lambda): the admissible increment is [-lambda, inf) -- the turns take the multiplier with
+  // the instruction's source negation and `hi` (a huge constant) as it stands, no bound arithmetic; friction rows pass [-hi, hi].
+  template <bool LIMIT, bool UNILATERAL>
+  static LL_HD void gs_round(const L& ln, Row& r, const F& hi, F& VA, F& VB, F& VJ) {
     F zero = ln.lane_f(0.0f);
-    F w = L::vel_dot(r.c, r.ca, r.cb, r.cj, VA, VB, VJ);
+    F w = L::vel_dot(r.c, r.ca01, r.ca23, r.cb01, r.cj01, r.cj23, VA, VB, VJ);
     F u = (zero - w) * r.inv;                             // unclamped increment; admissible interval [lo - lam, hi - lam]
-    F lo_d = lo - r.lam, hi_d = hi - r.lam;
+    F lo_d = UNILATERAL ? r.lam : (zero - hi) - r.lam, hi_d = UNILATERAL ? hi : hi - r.lam;
     F dl = zero;
-    ln.template turns8<0>(u, dl, lo_d, hi_d, r.nk);
-    if (LIMIT) ln.template turns4<2>(u, dl, lo_d, hi_d, r.nk[2], r.nk[6], r.nk[10], r.nk[14]);
-    else ln.template turns8<1>(u, dl, lo_d, hi_d, r.nk);
-    r.lam = r.lam + dl;
-    L::vel_commit(dl, r.ca, r.cb, r.cj, VA, VB, VJ);
+    ln.template turns8<0, UNILATERAL>(u, dl, lo_d, hi_d, r.nk);
+    if (LIMIT) ln.template turns4<2, UNILATERAL>(u, dl, lo_d, hi_d, r.nk[2], r.nk[6], r.nk[10], r.nk[14]);
+    else ln.template turns8<1, UNILATERAL>(u, dl, lo_d, hi_d, r.nk);
+    L::vel_commit(dl, r.lam, r.ca01, r.ca23, r.cb01, r.cj01, r.cj23, VA, VB, VJ);      // (also lam += dl)
   }
 
   // ---------------------------------------------------------------------------------------------------
@@ -705,14 +711,19 @@ struct Pmc {
     // the deepest count as equally deep and the lowest candidate index (sub-lane, then position) wins: symmetric poses put several
     // points at the same depth up to rounding, and which of them is kept must not depend on the arithmetic.
     F my_depth = far_, my_sub = zero, my_jj = zero;
+    LL_UNROLL
     for (int s = 0; s < PMC_K; s++) {
       if (s >= P.max_contacts) break;                       // (spec override LLM_SPEC_MAX_CONTACTS_PER_LEG; 4 unless a deviation study says otherwise)
       F m = depth[0];
       for (int jj = 1; jj < NC; jj++) m = lm::min_(m, depth[jj]);
       F mq = L::submin(m);
       F thr = mq + (float)LLM_SELECT_EPS;
-      F am = ln.lane_f(100.0f);                             // first own candidate within the tolerance of the leg's deepest
-      for (int jj = NC - 1; jj >= 0; jj--) am = lm::sel(depth[jj] <= thr, ln.lane_f((float)jj), am);
+      // first own candidate within the tolerance of the leg's deepest: key = jj if depth <= thr, jj + 100 otherwise, as
+      // clamp(jj + (depth - thr) * 1e30, jj, jj + 100) -- a v_fma and a v_med3 per candidate instead of a compare feeding a select
+      // (which costs two wait states on gfx950); the smallest key is the answer
+      F nthr = thr * -1.0e30f;
+      F am = ln.lane_f(100.0f);
+      for (int jj = NC - 1; jj >= 0; jj--) am = lm::min_(am, lm::med3_(depth[jj] * 1.0e30f + (nthr + (float)jj), ln.lane_f((float)jj), ln.lane_f((float)jj + 100.0f)));
       F code = lm::sel(lm::and_(am < 50.0f, mq < far_), L::i2f(ln.sub()) * 8.0f + am, ln.lane_f(1000.0f));
       F wcode = L::submin(code);                            // lowest candidate index among them (1000 = none)
       B winner = lm::and_(code <= wcode, code < 500.0f);
@@ -1148,12 +1159,12 @@ struct Pmc {
     ln.prepare_turn_masks();
     LL_NOUNROLL
     for (int it = 0; it < P.n_iter; it++) {
-      if (any_limit) gs_round<true>(ln, rl, zero, big, VA, VB, VJ);
+      if (any_limit) gs_round<true, true>(ln, rl, big, VA, VB, VJ);
       if (any_contact) {
-        gs_round<false>(ln, rn, zero, big, VA, VB, VJ);
+        gs_round<false, true>(ln, rn, big, VA, VB, VJ);
         F hi = mu * rn.lam;
-        gs_round<false>(ln, r1, zero - hi, hi, VA, VB, VJ);
-        gs_round<false>(ln, r2, zero - hi, hi, VA, VB, VJ);
+        gs_round<false, false>(ln, r1, hi, VA, VB, VJ);
+        gs_round<false, false>(ln, r2, hi, VA, VB, VJ);
       }
       if (any_self) {                                                        // then the self-collision rows, one after the other
         self_turn(ln, sr[0], VA, VB, VJ);

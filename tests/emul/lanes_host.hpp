@@ -85,6 +85,8 @@ struct HostLanes {
   typedef iN I;
   typedef dN D;
   typedef bN B;
+  struct F2 { fN x, y; };
+  static F2 pair(const F& a, const F& b) { F2 r; r.x = a; r.y = b; return r; }
   const float* candc_;    // [words][16]
 
   PairLink* link_ = nullptr;
@@ -134,8 +136,9 @@ struct HostLanes {
       for (int i = 0; i < 6; i++) for (int l = 0; l < EW; l++) g[L_].v[l] = g[L_].v[l] + x[i].v[L_] * y[i].v[l];
     }
   }
-  template <int S_> static void turns4(F& u, F& dl, const F& lo, const F& hi, const F& k0, const F& k1, const F& k2, const F& k3) {
+  template <int S_, bool NEG_LO = false> static void turns4(F& u, F& dl, const F& lo_in, const F& hi, const F& k0, const F& k1, const F& k2, const F& k3) {
     const F* ks[4] = {&k0, &k1, &k2, &k3};
+    const fN lo = NEG_LO ? fN(0.0f) - lo_in : lo_in;
     for (int t = 0; t < 4; t++) {
       const int L_ = 4 * t + S_;
       fN d = lm::med3_(u, lo, hi);
@@ -143,7 +146,8 @@ struct HostLanes {
       for (int l = 0; l < EW; l++) u.v[l] = u.v[l] + d.v[L_] * ks[t]->v[l];
     }
   }
-  template <int H_> static void turns8(F& u, F& dl, const F& lo, const F& hi, const F* nk) {
+  template <int H_, bool NEG_LO = false> static void turns8(F& u, F& dl, const F& lo_in, const F& hi, const F* nk) {
+    const fN lo = NEG_LO ? fN(0.0f) - lo_in : lo_in;
     const int order[2][8] = {{0, 4, 8, 12, 1, 5, 9, 13}, {2, 6, 10, 14, 3, 7, 11, 15}};
     for (int t = 0; t < 8; t++) {
       const int L_ = order[H_][t];
@@ -154,25 +158,32 @@ struct HostLanes {
   }
   // the solver's scattered velocity state (lanes.hpp): VA[l] = dx[l & 3], VB[l] = dx[4 + (l & 1)], VJ[l] = dq_leg[l & 3];
   // ca[k][l] = gt[(l & 3) ^ k], cb[k][l] = gt[4 + (((l & 3) ^ k) & 1)], cj[k][l] = jt[(l & 3) ^ k]
-  static F vel_dot(const F& c, const F* ca, const F* cb, const F* cj, const F& VA, const F& VB, const F& VJ) {
+  static F vel_dot(const F& c, const F2& ca01, const F2& ca23, const F2& cb01, const F2& cj01, const F2& cj23, const F& VA, const F& VB, const F& VJ) {
+    const fN* ca[4] = {&ca01.x, &ca01.y, &ca23.x, &ca23.y};
+    const fN* cb[2] = {&cb01.x, &cb01.y};
+    const fN* cj[4] = {&cj01.x, &cj01.y, &cj23.x, &cj23.y};
     fN w;
     for (int l = 0; l < EW; l++) {
-      float a = ca[0].v[l] * VA.v[l] + c.v[l];
-      a += cb[0].v[l] * VB.v[l];
-      a += cj[0].v[l] * VJ.v[l];
-      for (int k = 1; k < 4; k++) a += ca[k].v[l] * VA.v[l ^ k];
-      a += cb[1].v[l] * VB.v[l ^ 1];
-      for (int k = 1; k < 4; k++) a += cj[k].v[l] * VJ.v[l ^ k];
+      float a = ca[0]->v[l] * VA.v[l] + c.v[l];
+      a += cb[0]->v[l] * VB.v[l];
+      a += cj[0]->v[l] * VJ.v[l];
+      for (int k = 1; k < 4; k++) a += ca[k]->v[l] * VA.v[l ^ k];
+      a += cb[1]->v[l] * VB.v[l ^ 1];
+      for (int k = 1; k < 4; k++) a += cj[k]->v[l] * VJ.v[l ^ k];
       w.v[l] = a;
     }
     return w;
   }
-  static void vel_commit(const F& dl, const F* ca, const F* cb, const F* cj, F& VA, F& VB, F& VJ) {
+  static void vel_commit(const F& dl, F& lam, const F2& ca01, const F2& ca23, const F2& cb01, const F2& cj01, const F2& cj23, F& VA, F& VB, F& VJ) {
+    const fN* ca[4] = {&ca01.x, &ca01.y, &ca23.x, &ca23.y};
+    const fN* cb[2] = {&cb01.x, &cb01.y};
+    const fN* cj[4] = {&cj01.x, &cj01.y, &cj23.x, &cj23.y};
     float tA[4] = {0, 0, 0, 0}, tB[2] = {0, 0}, tJ[4][4] = {{0}};
+    lam = lam + dl;
     for (int l = 0; l < EW; l++) {
       const int s = l & 3;
-      for (int k = 0; k < 4; k++) { tA[s ^ k] += ca[k].v[l] * dl.v[l]; tJ[l >> 2][s ^ k] += cj[k].v[l] * dl.v[l]; }
-      for (int k = 0; k < 2; k++) tB[(s ^ k) & 1] += cb[k].v[l] * dl.v[l];
+      for (int k = 0; k < 4; k++) { tA[s ^ k] += ca[k]->v[l] * dl.v[l]; tJ[l >> 2][s ^ k] += cj[k]->v[l] * dl.v[l]; }
+      for (int k = 0; k < 2; k++) tB[(s ^ k) & 1] += cb[k]->v[l] * dl.v[l];
     }
     for (int l = 0; l < EW; l++) { VA.v[l] += tA[l & 3]; VB.v[l] += tB[l & 1]; VJ.v[l] += tJ[l >> 2][l & 3]; }
   }
