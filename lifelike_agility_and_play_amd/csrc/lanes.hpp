@@ -48,6 +48,9 @@ LL_HD bool and_(bool a, bool b) { return a && b; }
 LL_HD bool or_(bool a, bool b) { return a || b; }
 LL_HD bool not_(bool a) { return !a; }
 LL_HD float rint_(float x) { return rintf(x); }
+LL_HD float atan2_(float y, float x) { return atan2f(y, x); }
+LL_HD float sin_(float x) { return sinf(x); }
+LL_HD float cos_(float x) { return cosf(x); }
 LL_HD float med3_(float x, float lo, float hi) {   // clamp for lo <= hi: one v_med3_f32 on the GPU
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_fmed3f(x, lo, hi);
@@ -367,6 +370,10 @@ struct GpuLanes {
   LL_D void stl(float* p, long base, long stride, F v) const { if (sub_ == 0) p[base + stride * leg_] = v; }
   LL_D void stl_if(B m, float* p, long base, long stride, F v) const { if (m && sub_ == 0) p[base + stride * leg_] = v; }
   LL_D D lddl(const double* p, long base, long stride) const { return p[base + stride * leg_]; }
+  // per-leg values / gathers: leg l of the row works on item l (the four future-goal sites of an observation)
+  LL_D I pick4i(int a, int b, int c, int d) const { return leg_ == 0 ? a : (leg_ == 1 ? b : (leg_ == 2 ? c : d)); }
+  LL_D D pick4d(double a, double b, double c, double d) const { return leg_ == 0 ? a : (leg_ == 1 ? b : (leg_ == 2 ? c : d)); }
+  LL_D D ldd_idx(const double* p, I idx) const { return p[idx]; }
   // cooperative copy of up to 16 consecutive floats: lane i moves element i0 + i (if below n)
   LL_D void copy16(float* dst, const float* src, int i0, int n) const { const int i = i0 + lane16_; if (i < n) dst[i] = src[i]; }
   // the two halves of copy16, so that a caller can issue every load of a row before its first store

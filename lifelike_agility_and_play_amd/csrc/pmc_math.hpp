@@ -246,6 +246,64 @@ LL_HD float axis_angle_scaled(const Q4& q, V3<float>* aa) {
   return angle;
 }
 
+// ---- the same quaternion helpers for lane-varying scalars (T = L::F): branch-free, both sides of a case evaluated and selected.
+//      The four future-goal sites of an observation are worked on by the four legs of the row at once (pmc_step.hpp obs_emit).
+template <class T>
+struct Q4T {
+  T x, y, z, w;
+};
+template <class P, class Q>
+LL_HD auto qmul_t(const P& p, const Q& q) -> Q4T<decltype(p.w * q.x)> {
+  Q4T<decltype(p.w * q.x)> r;
+  r.x = p.w * q.x + p.x * q.w + p.y * q.z - p.z * q.y;
+  r.y = p.w * q.y - p.x * q.z + p.y * q.w + p.z * q.x;
+  r.z = p.w * q.z + p.x * q.y - p.y * q.x + p.z * q.w;
+  r.w = p.w * q.w - p.x * q.x - p.y * q.y - p.z * q.z;
+  return r;
+}
+template <class T>
+LL_HD Q4T<T> qconj_t(const Q4T<T>& q, const T& zero) {
+  Q4T<T> r = {zero - q.x, zero - q.y, zero - q.z, q.w};
+  return r;
+}
+template <class T>
+LL_HD Q4T<T> qnormalize_t(const Q4T<T>& q) {
+  T n = lm::rsqrt_(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  Q4T<T> r = {q.x * n, q.y * n, q.z * n, q.w * n};
+  return r;
+}
+template <class T>
+LL_HD V3<T> rotvec_of_t(V3<T> v, T w, const T& zero) {       // rotvec_of for lane-varying arguments
+  auto neg = w < 0.0f;
+  v.x = lm::sel(neg, zero - v.x, v.x); v.y = lm::sel(neg, zero - v.y, v.y); v.z = lm::sel(neg, zero - v.z, v.z);
+  w = lm::sel(neg, zero - w, w);
+  T n = lm::sqrt_(v.x * v.x + v.y * v.y + v.z * v.z);
+  T angle = lm::atan2_(n, w) * 2.0f;
+  T a2 = angle * angle;
+  T s_small = a2 * (1.0f / 12.0f) + (a2 * a2) * (7.0f / 2880.0f) + 2.0f;
+  T s_big = angle / lm::sin_(angle * 0.5f);
+  T s = lm::sel(angle <= 1e-3f, s_small, s_big);
+  return mk3<T>(s * v.x, s * v.y, s * v.z);
+}
+template <class T>
+LL_HD Q4T<T> quat_of_rotvec_t(const V3<T>& rv) {
+  T angle = lm::sqrt_(rv.x * rv.x + rv.y * rv.y + rv.z * rv.z);
+  T a2 = angle * angle;
+  T s_small = (a2 * a2) * (1.0f / 3840.0f) - a2 * (1.0f / 48.0f) + 0.5f;
+  T s_big = lm::sin_(angle * 0.5f) / angle;
+  T s = lm::sel(angle <= 1e-3f, s_small, s_big);
+  Q4T<T> q = {s * rv.x, s * rv.y, s * rv.z, lm::cos_(angle * 0.5f)};
+  return q;
+}
+template <class T>
+LL_HD T axis_angle_scaled_t(const Q4T<T>& q, V3<T>* aa, const T& zero) {
+  V3<T> rv = rotvec_of_t(mk3<T>(q.x, q.y, q.z), q.w, zero);
+  T angle = lm::sqrt_(rv.x * rv.x + rv.y * rv.y + rv.z * rv.z);
+  T k = angle / (angle + 1e-8f);
+  *aa = mk3<T>(rv.x * k, rv.y * k, rv.z * k);
+  return angle;
+}
+
 // ---- Philox4x32-10 (counter-based RNG, quad-uniform) -------------------------------------------------------
 LL_HD void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
   for (int r = 0; r < 10; r++) {

@@ -1268,20 +1268,42 @@ struct Pmc {
   // before its first store because the compiler must assume the two alias.
   // ---------------------------------------------------------------------------------------------------
   static constexpr int OBS_HIST_CHUNKS = 5;   // 2 * prop_dim <= 66 floats, 16 per chunk
+  // The four future-goal sites (1/30, 1/15, 1/3, 1 s ahead; ML:75-86) are env-level work: four slerps and four relative rotations with
+  // their atan2 / sin / cos.  Leg l of the row takes site l -- the base-pose part of a site is gathered and computed lane-varying,
+  // one site's worth of instructions instead of four; only the reference joint angles stay per (site, leg).
+  struct FutBase {
+    V3l p;               // interpolated base position of this leg's site
+    Q4T<F> qc, dl;       // current-frame quaternion; next - current (formed in float64)
+    F ff;                // frame fraction
+  };
   struct ObsIn {
     F h[OBS_HIST_CHUNKS], ha[2];
-    RefRaw fut[4];
+    FutBase futb;
+    F fut_jp[4][3];      // reference joint angles of the lane's leg at the four sites
   };
   static LL_HD void obs_gather_futures(const L& ln, const StepParams& P, ObsIn& in, const double* clip_rows, int frame_id, double frac) {
     const double hz[4] = {1. / 30., 1. / 15., 1. / 3., 1.};                     // ML:75-86
+    int fidh[4];
+    double ffh[4];
     LL_UNROLL
     for (int h = 0; h < 4; h++) {
       double t = P.frame_step * frac + hz[h];
-      int fid = (int)floor(t / P.frame_step);
-      double ff = t / P.frame_step - fid;
-      const double* fc = clip_rows + (long)(frame_id + fid) * 19;
-      in.fut[h] = mocap_gather(ln, fc, fc + 19, ff, P.frame_step);
+      fidh[h] = (int)floor(t / P.frame_step);
+      ffh[h] = t / P.frame_step - fidh[h];
+      const double* fc = clip_rows + (long)(frame_id + fidh[h]) * 19;
+      for (int j = 0; j < 3; j++) {
+        D c = ln.lddl(fc, 7 + j, 3), n = ln.lddl(fc + 19, 7 + j, 3);
+        in.fut_jp[h][j] = L::d2f(c + (n - c) * ffh[h]);                          // ML:157
+      }
     }
+    const I idx = ln.pick4i((frame_id + fidh[0]) * 19, (frame_id + fidh[1]) * 19, (frame_id + fidh[2]) * 19, (frame_id + fidh[3]) * 19);
+    const D ffd = ln.pick4d(ffh[0], ffh[1], ffh[2], ffh[3]);
+    D c[7], n[7];
+    for (int i = 0; i < 7; i++) { c[i] = ln.ldd_idx(clip_rows, idx + i); n[i] = ln.ldd_idx(clip_rows, idx + (19 + i)); }
+    in.futb.p = mk3<F>(L::d2f(c[0] + ffd * (n[0] - c[0])), L::d2f(c[1] + ffd * (n[1] - c[1])), L::d2f(c[2] + ffd * (n[2] - c[2])));
+    in.futb.qc.x = L::d2f(c[3]); in.futb.qc.y = L::d2f(c[4]); in.futb.qc.z = L::d2f(c[5]); in.futb.qc.w = L::d2f(c[6]);
+    in.futb.dl.x = L::d2f(n[3] - c[3]); in.futb.dl.y = L::d2f(n[4] - c[4]); in.futb.dl.z = L::d2f(n[5] - c[5]); in.futb.dl.w = L::d2f(n[6] - c[6]);
+    in.futb.ff = L::d2f(ffd);
   }
   static LL_HD ObsIn obs_gather(const L& ln, const StepParams& P, const float* hist_row, bool fill, const double* clip_rows, int frame_id,
                                 double frac) {
@@ -1325,19 +1347,23 @@ struct Pmc {
                              const F* q, const F* qd, const F* act) {
     obs_emit_core(ln, P, row, fill, in, bs, R, q, qd, act);
     B lane3 = ln.legf() < 2.5f;
-    // --- future goals (ML:75-86 + PLE:299-317) ---
+    // --- future goals (ML:75-86 + PLE:299-317): leg l computes site l (see FutBase) and stores its six numbers ---
+    (void)lane3;
     long f0 = 3L * P.prop_dim + 36;
+    const F zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f);
     Q4 qbi = qconj(qnormalize(bs.q));
+    const FutBase& fb = in.futb;
+    Q4T<F> e = qmul_t(qconj_t(fb.qc, zero), fb.dl);                                 // qc^-1 qn = 1 + qc^-1 (qn - qc)
+    V3l rv = rotvec_of_t(mk3<F>(e.x, e.y, e.z), one + e.w, zero);                    // ML:127-134 (scipy Slerp)
+    Q4T<F> qf = qmul_t(fb.qc, quat_of_rotvec_t(mk3<F>(rv.x * fb.ff, rv.y * fb.ff, rv.z * fb.ff)));
+    V3l dp = mulT(R, mk3<F>(fb.p.x - bs.p.x, fb.p.y - bs.p.y, fb.p.z - bs.p.z));
+    V3l aa;
+    axis_angle_scaled_t(qmul_t(qbi, qnormalize_t(qf)), &aa, zero);
+    ln.stl(row, f0 + 0, 18, dp.x); ln.stl(row, f0 + 1, 18, dp.y); ln.stl(row, f0 + 2, 18, dp.z);
+    ln.stl(row, f0 + 3, 18, aa.x); ln.stl(row, f0 + 4, 18, aa.y); ln.stl(row, f0 + 5, 18, aa.z);
     LL_UNROLL
-    for (int h = 0; h < 4; h++) {
-      RefPose rp = mocap_finish(in.fut[h], P.frame_step, false);
-      V3u dp = mulT(R, mk3<float>(rp.p.x - bs.p.x, rp.p.y - bs.p.y, rp.p.z - bs.p.z));
-      V3u aa;
-      axis_angle_scaled(qmul(qbi, qnormalize(rp.q)), &aa);
-      ln.stl_if(lane3, row, f0 + 18 * h, 1, ln.pick3(dp.x, dp.y, dp.z));
-      ln.stl_if(lane3, row, f0 + 18 * h + 3, 1, ln.pick3(aa.x, aa.y, aa.z));
-      for (int j = 0; j < 3; j++) ln.stl(row, f0 + 18 * h + 6 + j, 3, rp.jp[j]);
-    }
+    for (int h = 0; h < 4; h++)
+      for (int j = 0; j < 3; j++) ln.stl(row, f0 + 18 * h + 6 + j, 3, in.fut_jp[h][j]);
   }
 
   // ---------------------------------------------------------------------------------------------------

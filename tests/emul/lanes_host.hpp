@@ -50,6 +50,8 @@ EMU_BIN_S(dN, double, +) EMU_BIN_S(dN, double, -) EMU_BIN_S(dN, double, *)
 namespace lm {
 #define EMU_UN(NAME, FN) inline fN NAME(const fN& a) { fN r; for (int i = 0; i < EW; i++) r.v[i] = FN(a.v[i]); return r; }
 EMU_UN(sqrt_, sqrtf) EMU_UN(abs_, fabsf) EMU_UN(rint_, rintf)
+inline fN atan2_(const fN& y, const fN& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = atan2f(y.v[i], x.v[i]); return r; }
+EMU_UN(sin_, sinf) EMU_UN(cos_, cosf)
 inline fN rsqrt_(const fN& a) { fN r; for (int i = 0; i < EW; i++) r.v[i] = 1.0f / sqrtf(a.v[i]); return r; }
 inline fN min_(const fN& a, const fN& b) { fN r; for (int i = 0; i < EW; i++) r.v[i] = fminf(a.v[i], b.v[i]); return r; }
 inline fN max_(const fN& a, const fN& b) { fN r; for (int i = 0; i < EW; i++) r.v[i] = fmaxf(a.v[i], b.v[i]); return r; }
@@ -207,6 +209,9 @@ struct HostLanes {
   void st16(float* dst, int i0, int n, const F& v) const { for (int i = 0; i < EW; i++) if (i0 + i < n) dst[i0 + i] = v.v[i]; }
   void st16_rot(float* dst, int i0, int n, int split, const F& v) const { for (int k = 0; k < EW; k++) { const int i = i0 + k; if (i < n) dst[i < split ? i + (n - split) : i - split] = v.v[k]; } }
   int count_le16(const double* p, int n, double u) const { int c = 0; for (int i = 0; i < n; i++) c += (p[i] <= u) ? 1 : 0; return c; }
+  I pick4i(int a, int b, int c, int d) const { const int v[4] = {a, b, c, d}; iN r; for (int i = 0; i < EW; i++) r.v[i] = v[i >> 2]; return r; }
+  D pick4d(double a, double b, double c, double d) const { const double v[4] = {a, b, c, d}; dN r; for (int i = 0; i < EW; i++) r.v[i] = v[i >> 2]; return r; }
+  D ldd_idx(const double* p, const I& idx) const { dN r; for (int i = 0; i < EW; i++) r.v[i] = p[idx.v[i]]; return r; }
   D lddl(const double* p, long base, long stride) const { dN r; for (int i = 0; i < EW; i++) r.v[i] = p[base + stride * (i >> 2)]; return r; }
   static F d2f(const D& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = (float)x.v[i]; return r; }
   static F i2f(const I& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = (float)x.v[i]; return r; }
