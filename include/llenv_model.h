@@ -56,6 +56,8 @@
 #define LLM_MAX_SELF 2                  /* self-collision rows per robot */
 #define LLM_SEG_PARALLEL_REG 1e-3        /* closest points of two capsule axes: weight (relative to |d1|^2 |d2|^2) that pulls the parameter of nearly
                                            parallel segments to the middle of their overlap; sin^2(angle) >> this: Ericson's closest point */
+#define LLM_OBSTACLE_REACH 1.2          /* m: the jump obstacle of PLE:182-193 takes part in the substeps of a control step that starts with the base
+                                           within this horizontal distance of the box centre (robot reach 0.45 m + half box length 0.5 m + slack) */
 #define LLM_SELECT_EPS 1e-5             /* m: candidates (contact points, capsule pairs) whose depth is within this of the deepest count as equally
                                            deep and the lower index wins -- the deepest-K choice must not hang on float rounding */
 

@@ -92,7 +92,8 @@ __device__ __forceinline__ float4 random_action_group(const StepParams& P, uint3
 
 // OCC = wavefronts per SIMD the register budget allows: 1 (512 registers, nothing spills to scratch) while the grid fits the
 // chip one wavefront per SIMD, 2 (256 registers) for larger batches, where a second resident wavefront hides issue stalls.
-template <int OCC>
+// OBST = the set_obstacle build (Pmc::step_env<true>): the jump obstacle takes part in the substeps as a static box.
+template <int OCC, bool OBST = false>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int row = threadIdx.x >> 4;                                         // one env = one 16-lane DPP row
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
     } else {
       for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
     }
-    Pmc<Lanes>::step_env(ln, P, env, act);
+    Pmc<Lanes>::template step_env<OBST>(ln, P, env, act);
   }
   // The last workgroup to get here folds this step's finished episodes into the sampling table.  The statistics travel by
   // device-scope atomics only (publish_max), so no cache write-back is needed -- a __threadfence() here would flush this
@@ -330,8 +331,13 @@ struct HipBackend {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin();
-    if (blocks <= simds) hipLaunchKernelGGL(pmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
-    else                 hipLaunchKernelGGL(pmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
+    if (P.set_obstacle) {
+      if (blocks <= simds) hipLaunchKernelGGL((pmc_step_kernel<1, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
+      else                 hipLaunchKernelGGL((pmc_step_kernel<2, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
+    } else {
+      if (blocks <= simds) hipLaunchKernelGGL(pmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
+      else                 hipLaunchKernelGGL(pmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
+    }
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->second, stream));
   }

@@ -324,7 +324,19 @@ struct Pmc {
     bool pair_active;
     int pair_me;
     mutable float touch_robot;
+    // the PMC jump obstacle (PLE:182-193): ONE shape whose record is given in a frame turned by yaw about z around (ycx, ycy)
+    bool yawed = false;
+    float ycx = 0.0f, ycy = 0.0f, ycs = 1.0f, ysn = 0.0f;
   };
+  // shape_sdf of record si at world point E, for terrain that may be yawed: distance, outward normal in WORLD coordinates
+  template <class T>
+  static LL_HD void terrain_sdf(const L& ln, const SubstepExtra* ex, int si, const V3<T>& E, T& d, V3<T>& n, T& is_box) {
+    if (!ex->yawed) { shape_sdf<T>(ln, ex->shapes + si * 8, E, d, n, is_box); return; }
+    const T dx = E.x - ex->ycx, dy = E.y - ex->ycy;
+    V3<T> El = mk3<T>(dx * ex->ycs + dy * ex->ysn, dy * ex->ycs - dx * ex->ysn, E.z), nl;
+    shape_sdf<T>(ln, ex->shapes + si * 8, El, d, nl, is_box);
+    n = mk3<T>(nl.x * ex->ycs - nl.y * ex->ysn, nl.x * ex->ysn + nl.y * ex->ycs, nl.z);
+  }
   // Signed distance of point E to record s (box united with its edge rods) and the outward normal there.  Inside a box the
   // face of least penetration gives both; near an edge outside, max(q) under-estimates the distance, which only makes a
   // speculative contact start a little early.
@@ -684,7 +696,7 @@ struct Pmc {
           for (int si = 0; si < n_shapes; si++) {
             F ds, isb;
             V3l ns;
-            shape_sdf<F>(ln, ex->shapes + si * 8, Ew, ds, ns, isb);
+            terrain_sdf<F>(ln, ex, si, Ew, ds, ns, isb);
             dpt = lm::min_(dpt, ds - rs);
             if (want_touch) {
               B isf = ln.lane_f(si == ex->flag_shape ? 1.0f : 0.0f) > 0.5f;
@@ -830,7 +842,7 @@ struct Pmc {
           for (int si = 0; si < n_shapes; si++) {
             F ds, isb;
             V3l ns;
-            shape_sdf<F>(ln, ex->shapes + si * 8, Ew, ds, ns, isb);
+            terrain_sdf<F>(ln, ex, si, Ew, ds, ns, isb);
             B win = (ds - rs) < best;
             best = lm::sel(win, ds - rs, best);
             nw = mk3<F>(lm::sel(win, ns.x, nw.x), lm::sel(win, ns.y, nw.y), lm::sel(win, ns.z, nw.z));
@@ -1432,10 +1444,12 @@ struct Pmc {
     const int oc = P.ob_cnt[clip];
     if (oc <= 0) return false;                                          // PLE:342 `self._obstacle is not None`
     const double* tab = P.ob_table + (long)P.ob_off[clip] * 4;
+    // getContactPoints (PLE:343) reports the contacts of the last stepSimulation -- the box where it stood during the substeps;
+    // _update_obstacle (PLE:229, :262-268) has already moved it on for the next step by then
     int ob = P.ob_id[env];
+    const float cx = (float)tab[ob * 4 + 0], cy = (float)tab[ob * 4 + 1], yaw = (float)tab[ob * 4 + 2];
     while (ob < oc - 1 && t > tab[ob * 4 + 3] + 0.5) ob++;              // PLE:264-265
     P.ob_id[env] = ob;
-    const float cx = (float)tab[ob * 4 + 0], cy = (float)tab[ob * 4 + 1], yaw = (float)tab[ob * 4 + 2];
     const float cyaw = cosf(yaw), syaw = sinf(yaw), hx = 0.025f, hy = 0.5f, hz = P.ob_half_height;   // PLE:184
     F zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f);
     B sub_lt2 = L::i2f(ln.sub()) < 1.5f, sub_lt3 = L::i2f(ln.sub()) < 2.5f, sub_0 = L::i2f(ln.sub()) < 0.5f;
@@ -1483,6 +1497,8 @@ struct Pmc {
   // the control step
   // ---------------------------------------------------------------------------------------------------
   // act_in: the env's actions, one register per joint of the lane's leg (read from P.actions or drawn by the caller)
+  // OBST (set_obstacle builds): the jump obstacle of the episode is a static box the robot collides with during the substeps
+  template <bool OBST = false>
   static LL_HD void step_env(const L& ln, const StepParams& P, int env, const F* act_in) {
     const int N = P.n_envs;
     Base bs;
@@ -1497,8 +1513,30 @@ struct Pmc {
     const int clen = P.clip_len[clip];
     const double* rows = P.frames + (long)P.clip_off[clip] * 19;
     PMC_TS(1);
+    SubstepExtra ex;
+    if (OBST) {
+      // PLE:182-193: 0.05 x 1.0 x 2h box (createMultiBody, mass 0, Bullet's default friction 0.5) at the pose the last reset /
+      // _update_obstacle gave it; it takes part in the substeps when the step starts with the base within LLM_OBSTACLE_REACH of it
+      ex.want_touch = false; ex.flag_shape = -1; ex.pair_active = false; ex.pair_me = 0; ex.has_push = false;
+      ex.mu_foot = P.mu_foot; ex.box_mu_scale = (float)(LLM_LINK_FRICTION / LLM_PLANE_FRICTION);
+      ex.n_shapes = 0; ex.shapes = ln.row_scratch();
+      const int oc = P.ob_cnt[clip];
+      if (oc > 0) {
+        const double* tab = P.ob_table + ((long)P.ob_off[clip] + P.ob_id[env]) * 4;
+        ex.ycx = (float)tab[0]; ex.ycy = (float)tab[1];
+        const float yaw = (float)tab[2], ddx = bs.p.x - ex.ycx, ddy = bs.p.y - ex.ycy;
+        ex.ycs = cosf(yaw); ex.ysn = sinf(yaw); ex.yawed = true;
+        if (ddx * ddx + ddy * ddy < (float)(LLM_OBSTACLE_REACH * LLM_OBSTACLE_REACH)) ex.n_shapes = 1;
+      }
+      float* rec = ln.row_scratch();
+      if (ln.lane0()) {
+        rec[0] = -0.025f; rec[1] = 0.025f; rec[2] = -0.5f; rec[3] = 0.5f; rec[4] = -P.ob_half_height; rec[5] = P.ob_half_height; rec[6] = 0.0f; rec[7] = 0.0f;
+      }
+      ln.row_sync();
+    }
     for (int s = 0; s < P.n_sub; s++) {                                      // PLE:202
-      substep(ln, P, bs, q, qd, tgt, env, s);                                // PLE:204-206
+      if (OBST) substep_impl<true>(ln, P, bs, q, qd, tgt, env, s, &ex);
+      else substep(ln, P, bs, q, qd, tgt, env, s);                           // PLE:204-206
       t_loc = t;                                                             // PLE:208 motion.step(time BEFORE the increment), quirk Q2
       t += P.dt_d;                                                           // PLE:210
     PMC_TS(10 + (s < 20 ? s : 20));

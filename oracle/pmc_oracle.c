@@ -611,7 +611,22 @@ typedef struct {
 /* EPMC terrain (epmc_step.hpp): axis-aligned boxes  x0 x1 y0 y1 z0 z1 rod r ; rod = +1 / -1 / 0: thin cylinders of
  * radius r along y on the two top / bottom x-edges.  Signed distance and outward normal of point E; same spec as the kernel's
  * shape_sdf (face of least penetration inside, max(q) outside). */
-typedef struct { int n; const double* rec; double box_mu_scale; } OTerrain;
+typedef struct {
+  int n; const double* rec; double box_mu_scale;
+  /* yawed != 0 (the PMC jump obstacle, PLE:182-193): the records are given in a frame turned by yaw about z around (cx, cy) */
+  int yawed; double cx, cy, cs, sn;
+} OTerrain;
+/* shape_sdf of record si at world point E for a terrain that may be yawed: distance, and the outward normal in WORLD coordinates */
+static double shape_sdf(const double* s, const double* E, double* n, int* is_box);
+static double terrain_sdf(const OTerrain* T, int si, const double* E, double* n, int* is_box) {
+  if (!T->yawed) return shape_sdf(T->rec + 8 * si, E, n, is_box);
+  const double dx = E[0] - T->cx, dy = E[1] - T->cy;
+  const double El[3] = {dx * T->cs + dy * T->sn, dy * T->cs - dx * T->sn, E[2]};
+  double nl[3];
+  const double d = shape_sdf(T->rec + 8 * si, El, nl, is_box);
+  n[0] = nl[0] * T->cs - nl[1] * T->sn; n[1] = nl[0] * T->sn + nl[1] * T->cs; n[2] = nl[2];
+  return d;
+}
 static double shape_sdf(const double* s, const double* E, double* n, int* is_box) {
   double a0[3] = {s[0] - E[0], s[2] - E[1], s[4] - E[2]}, a1[3] = {E[0] - s[1], E[1] - s[3], E[2] - s[5]};
   double q[3], sg[3];
@@ -706,7 +721,7 @@ static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double 
         double E[3] = {c[i].P[0], c[i].P[1], c[i].P[2] + c[i].rs};
         for (int si = 0; si < T->n; si++) {
           double nn[3]; int isb;
-          double d = shape_sdf(T->rec + 8 * si, E, nn, &isb) - c[i].rs;
+          double d = terrain_sdf(T, si, E, nn, &isb) - c[i].rs;
           if (d < c[i].depth) { c[i].depth = d; memcpy(c[i].n, nn, 24); c[i].valid = isb ? 2 : 3; }   /* valid: 1 plane, 2 box, 3 edge cylinder */
         }
       }
@@ -1199,7 +1214,7 @@ static void touch_classes(const OModel* M, const OKin* K, const OTerrain* T, int
       const double E[3] = {c[i].P[0], c[i].P[1], c[i].P[2] + c[i].rs};
       for (int si = 0; T && si < T->n; si++) {
         double nn[3]; int isb;
-        if (shape_sdf(T->rec + 8 * si, E, nn, &isb) - c[i].rs < LLM_CONTACT_MARGIN) { if (si == flag) *t_flag = 1; else *t_static = 1; }
+        if (terrain_sdf(T, si, E, nn, &isb) - c[i].rs < LLM_CONTACT_MARGIN) { if (si == flag) *t_flag = 1; else *t_static = 1; }
       }
     }
   }
@@ -1419,8 +1434,10 @@ static int obstacle_contact(OBatch* B, OEnv* e) {
   int oc = B->ob_cnt ? B->ob_cnt[e->clip] : 0;
   if (oc <= 0) return 0;
   const double* tab = B->ob_table + (size_t)B->ob_off[e->clip] * 4;
-  while (e->ob_id < oc - 1 && e->time > tab[e->ob_id * 4 + 3] + 0.5) e->ob_id++;          /* PLE:264-265 */
+  /* getContactPoints (PLE:343) reports the contacts of the last stepSimulation, i.e. with the box where it stood during the substeps;
+   * _update_obstacle (PLE:229, :262-268) has already moved it on for the next step by then */
   double cx = tab[e->ob_id * 4], cy = tab[e->ob_id * 4 + 1], yaw = tab[e->ob_id * 4 + 2], hz = B->cfg.obstacle_height;
+  while (e->ob_id < oc - 1 && e->time > tab[e->ob_id * 4 + 3] + 0.5) e->ob_id++;          /* PLE:264-265 */
   OKin K;
   kinematics(&B->model, e->state, NULL, &K);
   static const int links[LLM_N_LEG_PRIMS] = LLM_LEG_PRIM_LINKS;
@@ -1500,11 +1517,27 @@ int orc_step_env(OBatch* B, int env, const double* action, const double* scripte
   double tgt[12], tau[12];
   for (int i = 0; i < 12; i++) tgt[i] = e->state[13 + i] + action[i];     /* PLE:199-200 (clipped inside apply_action, LR:126-127) */
   int bad = 0;
+  /* PLE:182-193: the jump obstacle is a static body (createMultiBody, mass 0) the robot collides with: 0.05 x 1.0 x 2h box at the
+   * pose the last reset / _update_obstacle gave it, Bullet's default lateral friction 0.5 */
+  OTerrain OT;
+  double ob_rec[8];
+  const OTerrain* Tob = NULL;
+  if (B->cfg.set_obstacle && B->ob_cnt && B->ob_cnt[e->clip] > 0) {
+    const double* tab = B->ob_table + ((size_t)B->ob_off[e->clip] + e->ob_id) * 4;
+    const double dx = e->state[0] - tab[0], dy = e->state[1] - tab[1], hz = B->cfg.obstacle_height;
+    if (dx * dx + dy * dy < LLM_OBSTACLE_REACH * LLM_OBSTACLE_REACH) {
+      const double rec[8] = {-0.025, 0.025, -0.5, 0.5, -hz, hz, 0.0, 0.0};
+      memcpy(ob_rec, rec, sizeof rec);
+      OTerrain t = {1, ob_rec, LLM_LINK_FRICTION / LLM_PLANE_FRICTION, 1, tab[0], tab[1], cos(tab[2]), sin(tab[2])};
+      OT = t;
+      Tob = &OT;
+    }
+  }
   for (int s = 0; s < B->n_sub; s++) {                                    /* PLE:202 */
     orc_pd_torque(B->cfg.kp, B->cfg.kd, B->cfg.max_tau, e->state + 13, e->state + 25, tgt, tau);   /* LR:137-141 */
     if (!scripted_dyn) {
       tl_warm = &e->warm;
-      if (orc_substep_model(&B->model, B->dt, B->cfg.solver_iterations, B->mu_foot, e->state, tau, NULL)) bad = 1;   /* PLE:206 */
+      if (substep_terrain(&B->model, B->dt, B->cfg.solver_iterations, B->mu_foot, e->state, tau, NULL, Tob, NULL)) bad = 1;   /* PLE:206 */
       tl_warm = NULL;
     }
     orc_mocap_locate(e->time, B->frame_step, &e->frame_id, &e->frac);      /* PLE:208 (time BEFORE the increment, quirk Q2) */

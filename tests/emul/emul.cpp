@@ -30,7 +30,8 @@ struct HostBackend {
     for (int env = 0; env < P.n_envs; env++) {
       fN act[3];
       for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
-      K::step_env(ln, P, env, act);
+      if (P.set_obstacle) K::step_env<true>(ln, P, env, act);
+      else K::step_env<false>(ln, P, env, act);
     }
     pmc_finalize_table(P, P.avg_reward, P.avg_len, P.prob, P.cdf);
   }

@@ -308,6 +308,7 @@ def check_obstacle_variant(golden, orc, model_blob, table, lib_path, n_envs=24, 
         B.set_state(i, E.state()[i].astype(np.float64))
     alive = np.ones(n_envs, bool)
     n_coll = mism = 0
+    cfg_err, vel_err = [], []
     for t in range(n_steps):
         act = (rng.normal(size=(n_envs, 12)) * SIGMA).astype(np.float32)
         E.step_host(act)
@@ -318,6 +319,11 @@ def check_obstacle_variant(golden, orc, model_blob, table, lib_path, n_envs=24, 
                 continue
             _, _, od = B.step_env(i, act[i].astype(np.float64))
             oreason = B.episode_info(i)['done_reason']
+            # the box is a collision body during the substeps (PLE:182-193): the states after a step that touched it agree too
+            os_ = B.get_state(i)
+            err = np.abs(quat_align(es[i].astype(np.float64), os_) - os_)
+            cfg_err.append(max(err[0:7].max(), err[13:25].max()))
+            vel_err.append(max(err[7:13].max(), err[25:37].max()) / (1.0 + np.abs(os_[25:37]).max()))
             if bool(d[i]) != od or (od and (int(why[i]) & 8) != (oreason & 8)):
                 mism += 1
             if od or d[i]:
@@ -328,6 +334,7 @@ def check_obstacle_variant(golden, orc, model_blob, table, lib_path, n_envs=24, 
     E.close()
     assert n_coll >= 3, n_coll
     assert mism <= 1, mism
+    assert max(cfg_err) < 1e-4 and max(vel_err) < 1e-3, (max(cfg_err), max(vel_err))
     return n_coll
 
 

@@ -241,3 +241,41 @@ def test_standing_on_a_box_and_against_a_wall(golden, orc, model_blob, mocap_tab
     held = settle(standing_state(golden, z=ground[2]), wall, n=400, fx=120.0)
     assert free[0] > 0.3 and held[0] < free[0] - 0.1, (free[0], held[0])              # 120 N on the FR hip link drags it forwards; the wall stops it
     assert B.fk_feet(held)[:, 0].max() < 0.45 + 0.03                                   # no foot beyond the wall's face
+
+
+def test_jump_obstacle_is_a_solid_body(golden, orc, model_blob, mocap_table):
+    """set_obstacle (PLE:182-193): the box is a collision body, not only a termination test.  A robot following a jump clip into an
+    obstacle made too tall to clear is decelerated by it in the very step that reports COLLISION, and does not pass through it;
+    without the obstacle the same state flies on."""
+    cnt, tab = mocap_table.obstacles()
+    clip = int(np.where(cnt > 0)[0][0])
+    off = int(np.concatenate([[0], np.cumsum(cnt)])[clip])
+    cx, cy, yaw, t_peak = tab[off]
+    ux, uy = np.cos(yaw), np.sin(yaw)                                  # the box's thin direction (0.05 m), the way the clip jumps it
+    t0 = max(0.0, t_peak - 0.3)
+
+    def run(flag, n):
+        B = make_oracle_batch(orc, model_blob, mocap_table, set_obstacle=flag, obstacle_height=0.6)
+        B.reset_env(0, clip, t0)
+        out = []
+        for t in range(n):
+            _, _, d = B.step_env(0, np.zeros(12))
+            out.append(B.get_state(0))
+            if d:
+                return out, B.episode_info(0)['done_reason']
+        return out, 0
+    with_box, why = run(True, 40)
+    free, why_free = run(False, len(with_box))
+    sgn = np.sign((with_box[0][7] * ux + with_box[0][8] * uy))          # which way the clip crosses the box
+    along = lambda s: sgn * ((s[0] - cx) * ux + (s[1] - cy) * uy)
+    v_along = lambda s: sgn * (s[7] * ux + s[8] * uy)
+    assert why & 8, why                                               # PLE:343-346: touching the box ends the episode
+    assert not (why_free & 8)
+    k = len(with_box) - 1
+    assert len(free) == k + 1
+    np.testing.assert_allclose(with_box[max(k - 3, 0)][:3], free[max(k - 3, 0)][:3], atol=0.05)   # same flight until the touch ...
+    # ... then the box pushes back.  The episode ends with the step of the first touch, so the push is one control step's worth: the
+    # base loses speed towards the box and the touching leg's joints are knocked (free flight leaves them at ~1e-3 rad/s)
+    assert v_along(with_box[k]) < v_along(free[k]) - 0.01, (v_along(with_box[k]), v_along(free[k]))
+    assert np.abs(with_box[k][25:37] - free[k][25:37]).max() > 0.05
+    assert along(with_box[k]) < 0.0                                                               # the base is still on its own side
