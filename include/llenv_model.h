@@ -75,6 +75,7 @@
 #define LLM_SPEC_CONTACT_MARGIN 8        /* m       default LLM_CONTACT_MARGIN */
 #define LLM_SPEC_SELF_FRICTION 9         /* mu of two tangential rows per leg-leg contact; default 0 (frictionless).  ORACLE ONLY */
 #define LLM_SPEC_WARM_START 10           /* factor applied to the previous substep's multipliers of persisting rows; default 0 = none.  ORACLE ONLY */
-#define LLM_SPEC_COUNT 11
+#define LLM_SPEC_TRUNK_EDGES 11         /* 0 / 1   terrain edges under the body box are contact candidates; default 1.  ORACLE ONLY (a test instrument) */
+#define LLM_SPEC_COUNT 12
 
 #endif

@@ -338,8 +338,7 @@ struct Pmc {
     n = mk3<T>(nl.x * ex->ycs - nl.y * ex->ysn, nl.x * ex->ysn + nl.y * ex->ycs, nl.z);
   }
   // Signed distance of point E to record s (box united with its edge rods) and the outward normal there.  Inside a box the
-  // face of least penetration gives both; near an edge outside, max(q) under-estimates the distance, which only makes a
-  // speculative contact start a little early.
+  // face of least penetration gives both; outside, the nearest point of the box does.
   template <class T>
   static LL_HD void shape_sdf(const L& ln, const float* s, const V3<T>& E, T& d, V3<T>& n, T& is_box) {
     const T zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f), neg = ln.lane_f(-1.0f);
@@ -355,6 +354,15 @@ struct Pmc {
     B bz = qz > d;
     d = lm::sel(bz, qz, d); n = mk3<T>(lm::sel(bz, zero, n.x), lm::sel(bz, zero, n.y), lm::sel(bz, sz, zero));
     is_box = one;
+    {   // outside the box: Euclidean distance and the direction away from its nearest point (over a face the same as above; diagonally
+        // outside an edge or corner the rounded distance -- a sphere or a link's mid-span meets an edge with the normal through its centre)
+      T ox = lm::max_(qx, zero), oy = lm::max_(qy, zero), oz = lm::max_(qz, zero);
+      T e2 = ox * ox + oy * oy + oz * oz;
+      B outside = e2 > 0.0f;
+      T e = lm::sqrt_(e2), ie = one / lm::max_(e, ln.lane_f(1e-30f));
+      d = lm::sel(outside, e, d);
+      n = mk3<T>(lm::sel(outside, sx * ox * ie, n.x), lm::sel(outside, sy * oy * ie, n.y), lm::sel(outside, sz * oz * ie, n.z));
+    }
     if (rec.c.z != 0.0f) {
       const float ze = rec.c.z > 0.0f ? rec.c.y : rec.c.x, rr = rec.c.w;
       B iny = lm::and_(qy <= 0.0f, one > zero);
@@ -369,6 +377,86 @@ struct Pmc {
         is_box = lm::sel(better, zero, is_box);
       }
     }
+  }
+  // Reverse candidates (DESIGN.md 8 "edges under the trunk"; the oracle's reverse_edge states the rule): the robot's own candidates are
+  // vertices and spheres, blind to a step edge that crosses the flat of the body box between its corners.  Leg l tests top edge l of every
+  // terrain box (0: x = x0, 1: x = x1, 2: y = y0, 3: y = y1, at z = z1) against the body box in the box's frame: the edge is cut to the box
+  // grown by the margin; the middle of what is left names the face it runs along; the edge cut to the exact extents of the other two
+  // axes has two ends -- end `endf` (0 / 1) is this lane's candidate: depth = signed distance to the face's plane, point = the point of
+  // the terrain edge (returned in F0), normal = the face's inward normal (returned in world coordinates).  Deepest over the boxes.
+  static LL_HD void reverse_edge(const L& ln, const StepParams& P, const SubstepExtra* ex, const Base& bs, const M3<float>& R, const F& endf,
+                                 F& depth, V3l& Pb, V3l& nw) {
+    const F zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f), far_ = ln.lane_f(1.0e30f);
+    const float* bc = P.basec + BC_BOX;
+    float h[3], W[9];                           // half extents; rows of W: the box's unit axes in world coordinates
+    for (int a = 0; a < 3; a++) {
+      const float ux = bc[3 + 3 * a], uy = bc[4 + 3 * a], uz = bc[5 + 3 * a];
+      h[a] = sqrtf(ux * ux + uy * uy + uz * uz);
+      const float ih = 1.0f / h[a];
+      W[3 * a + 0] = (R.m[0] * ux + R.m[1] * uy + R.m[2] * uz) * ih;
+      W[3 * a + 1] = (R.m[3] * ux + R.m[4] * uy + R.m[5] * uz) * ih;
+      W[3 * a + 2] = (R.m[6] * ux + R.m[7] * uy + R.m[8] * uz) * ih;
+    }
+    const float cwx = bs.p.x + R.m[0] * bc[0] + R.m[1] * bc[1] + R.m[2] * bc[2], cwy = bs.p.y + R.m[3] * bc[0] + R.m[4] * bc[1] + R.m[5] * bc[2],
+                cwz = bs.p.z + R.m[6] * bc[0] + R.m[7] * bc[1] + R.m[8] * bc[2];
+    const float reach = sqrtf(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]) + P.margin_dist;
+    const B l0 = ln.is_leg(0), l1 = ln.is_leg(1), l2 = ln.is_leg(2), l3 = ln.is_leg(3), end1 = endf > 0.5f;
+    depth = far_;
+    V3l Pw = mk3<F>(zero, zero, zero);
+    nw = mk3<F>(zero, zero, one);
+    for (int si = 0; si < ex->n_shapes; si++) {
+      const BoxRec rec = load_box(ex->shapes + si * 8);
+      // (skipping boxes no env of the wave has its trunk near is an optimisation only: an edge point within the margin of the body box
+      //  is within `reach` of its centre)
+      float lx = cwx, ly = cwy;
+      if (ex->yawed) { const float dx = cwx - ex->ycx, dy = cwy - ex->ycy; lx = dx * ex->ycs + dy * ex->ysn; ly = dy * ex->ycs - dx * ex->ysn; }
+      const bool near = lx > rec.a.x - reach && lx < rec.a.y + reach && ly > rec.a.z - reach && ly < rec.a.w + reach && fabsf(cwz - rec.c.y) < reach;
+      if (!L::any(ln.lane_f(near ? 1.0f : 0.0f) > 0.5f)) continue;
+      F ax_ = lm::sel(l1, ln.lane_f(rec.a.y), ln.lane_f(rec.a.x)), ay_ = lm::sel(l3, ln.lane_f(rec.a.w), ln.lane_f(rec.a.z));
+      F bx_ = lm::sel(l0, ln.lane_f(rec.a.x), ln.lane_f(rec.a.y)), by_ = lm::sel(l2, ln.lane_f(rec.a.z), ln.lane_f(rec.a.w));
+      V3l aw = mk3<F>(ax_, ay_, ln.lane_f(rec.c.y)), bw = mk3<F>(bx_, by_, ln.lane_f(rec.c.y));
+      if (ex->yawed) {
+        aw = mk3<F>(ln.lane_f(ex->ycx) + ax_ * ex->ycs - ay_ * ex->ysn, ln.lane_f(ex->ycy) + ax_ * ex->ysn + ay_ * ex->ycs, aw.z);
+        bw = mk3<F>(ln.lane_f(ex->ycx) + bx_ * ex->ycs - by_ * ex->ysn, ln.lane_f(ex->ycy) + bx_ * ex->ysn + by_ * ex->ycs, bw.z);
+      }
+      V3l ra = mk3<F>(aw.x - cwx, aw.y - cwy, aw.z - cwz), dw = bw - aw;
+      F pa[3], dd[3], lo[3], hi[3];
+      F t0 = zero, t1 = one;
+      for (int i = 0; i < 3; i++) {
+        pa[i] = ra.x * W[3 * i] + ra.y * W[3 * i + 1] + ra.z * W[3 * i + 2];
+        dd[i] = dw.x * W[3 * i] + dw.y * W[3 * i + 1] + dw.z * W[3 * i + 2];
+        F inv = one / lm::sel(lm::abs_(dd[i]) < 1e-9f, ln.lane_f(1e-9f), dd[i]);
+        const float H = h[i] + P.margin_dist;
+        F ta = (ln.lane_f(-H) - pa[i]) * inv, tb = (ln.lane_f(H) - pa[i]) * inv;
+        t0 = lm::max_(t0, lm::min_(ta, tb)); t1 = lm::min_(t1, lm::max_(ta, tb));
+        F ea = (ln.lane_f(-h[i]) - pa[i]) * inv, eb = (ln.lane_f(h[i]) - pa[i]) * inv;
+        lo[i] = lm::min_(ea, eb); hi[i] = lm::max_(ea, eb);
+      }
+      F tm = (t0 + t1) * 0.5f;
+      F pm0 = pa[0] + tm * dd[0], pm1 = pa[1] + tm * dd[1], pm2 = pa[2] + tm * dd[2];
+      F q0 = lm::abs_(pm0) - h[0], q1 = lm::abs_(pm1) - h[1], q2 = lm::abs_(pm2) - h[2];
+      B is1 = q1 > q0;
+      F q = lm::sel(is1, q1, q0);
+      B is2 = q2 > q;
+      B a0 = lm::and_(lm::not_(is1), lm::not_(is2)), a1 = lm::and_(is1, lm::not_(is2));
+      F pmx = lm::sel(is2, pm2, lm::sel(is1, pm1, pm0));
+      F sg = lm::sel(pmx >= 0.0f, one, zero - one);
+      F u0 = lm::max_(zero, lm::sel(a0, lm::max_(lo[1], lo[2]), lm::sel(a1, lm::max_(lo[0], lo[2]), lm::max_(lo[0], lo[1]))));
+      F u1 = lm::min_(one, lm::sel(a0, lm::min_(hi[1], hi[2]), lm::sel(a1, lm::min_(hi[0], hi[2]), lm::min_(hi[0], hi[1]))));
+      B valid = lm::and_(t0 <= t1, u0 <= u1);
+      F u = lm::sel(end1, u1, u0);
+      F pax = lm::sel(is2, pa[2], lm::sel(is1, pa[1], pa[0])), dax = lm::sel(is2, dd[2], lm::sel(is1, dd[1], dd[0]));
+      F hax = lm::sel(is2, ln.lane_f(h[2]), lm::sel(is1, ln.lane_f(h[1]), ln.lane_f(h[0])));
+      F dep = sg * (pax + u * dax) - hax;
+      B better = lm::and_(valid, dep < depth);
+      depth = lm::sel(better, dep, depth);
+      Pw = mk3<F>(lm::sel(better, aw.x + u * dw.x, Pw.x), lm::sel(better, aw.y + u * dw.y, Pw.y), lm::sel(better, aw.z + u * dw.z, Pw.z));
+      F nsg = zero - sg;
+      nw = mk3<F>(lm::sel(better, nsg * lm::sel(is2, ln.lane_f(W[6]), lm::sel(is1, ln.lane_f(W[3]), ln.lane_f(W[0]))), nw.x),
+                  lm::sel(better, nsg * lm::sel(is2, ln.lane_f(W[7]), lm::sel(is1, ln.lane_f(W[4]), ln.lane_f(W[1]))), nw.y),
+                  lm::sel(better, nsg * lm::sel(is2, ln.lane_f(W[8]), lm::sel(is1, ln.lane_f(W[5]), ln.lane_f(W[2]))), nw.z));
+    }
+    Pb = mulT(R, mk3<F>(Pw.x - bs.p.x, Pw.y - bs.p.y, Pw.z - bs.p.z));
   }
   // closest points of the segments p1-q1 and p2-q2 (Ericson 5.1.9; same branches as the oracle's seg_seg)
   static LL_HD void seg_seg(const L& ln, const V3l& p1, const V3l& q1, const V3l& p2, const V3l& q2, V3l& c1, V3l& c2) {
@@ -675,11 +763,13 @@ struct Pmc {
         tgp[2] = mk3<F>(lm::sel(sub_0, k.p3.x, zero), lm::sel(sub_0, k.p3.y, zero), lm::sel(sub_0, k.p3.z, zero));
       }
     }
-    constexpr int NC = TERRAIN ? 8 : 7;                       // candidates per sub-lane: the eighth (mid-link sphere) only meets terrain
+    // candidates per sub-lane: the eighth (mid-link sphere) and the ninth (a terrain edge under the trunk, reverse_edge) only with terrain
+    constexpr int NT = TERRAIN ? 8 : 7, NC = TERRAIN ? 9 : 7;
+    constexpr float STRIDE = TERRAIN ? 16.0f : 8.0f;          // candidate index = STRIDE * sub + jj: the (sub, jj) order of the oracle's enumeration
     F depth[NC];
     const bool want_touch = TERRAIN && ex && ex->want_touch;
     F tch_st = one, tch_fl = one;                             // 0 once a body link touches a static / the flag
-    for (int jj = 0; jj < NC; jj++) {
+    for (int jj = 0; jj < NT; jj++) {
       const int g = jj < 4 ? 0 : (jj < 6 ? 1 : (jj < 7 ? 2 : 0));   // (candidate 7 sits on group A's link)
       V3l A = mk3<F>(ln.candc(jj * CF_WORDS + CF_A), ln.candc(jj * CF_WORDS + CF_A + 1), ln.candc(jj * CF_WORDS + CF_A + 2));
       V3l ax = mk3<F>(ln.candc(jj * CF_WORDS + CF_AX), ln.candc(jj * CF_WORDS + CF_AX + 1), ln.candc(jj * CF_WORDS + CF_AX + 2));
@@ -714,6 +804,13 @@ struct Pmc {
       depth[jj] = lm::sel(lm::and_(dpt < P.margin_dist, link > -0.5f), dpt, far_);
     }
     if (TERRAIN) {
+      depth[NC - 1] = far_;
+      if (terr) {                                             // sub-lanes 0, 1: the two ends of the leg's terrain edge under the body box
+        F rd;
+        V3l rP, rn;
+        reverse_edge(ln, P, ex, bs, R, L::i2f(ln.sub()), rd, rP, rn);
+        depth[NC - 1] = lm::sel(lm::and_(sub_lt2, rd < P.margin_dist), rd, far_);
+      }
       if (want_touch) {
         ex->touch_static = L::rmin(tch_st) < 0.5f ? 1.0f : 0.0f;
         ex->touch_flag = L::rmin(tch_fl) < 0.5f ? 1.0f : 0.0f;
@@ -736,7 +833,7 @@ struct Pmc {
       F nthr = thr * -1.0e30f;
       F am = ln.lane_f(100.0f);
       for (int jj = NC - 1; jj >= 0; jj--) am = lm::min_(am, lm::med3_(depth[jj] * 1.0e30f + (nthr + (float)jj), ln.lane_f((float)jj), ln.lane_f((float)jj + 100.0f)));
-      F code = lm::sel(lm::and_(am < 50.0f, mq < far_), L::i2f(ln.sub()) * 8.0f + am, ln.lane_f(1000.0f));
+      F code = lm::sel(lm::and_(am < 50.0f, mq < far_), L::i2f(ln.sub()) * STRIDE + am, ln.lane_f(1000.0f));
       F wcode = L::submin(code);                            // lowest candidate index among them (1000 = none)
       B winner = lm::and_(code <= wcode, code < 500.0f);
       F dsel = zero;
@@ -746,16 +843,16 @@ struct Pmc {
         depth[jj] = lm::sel(hit, far_, depth[jj]);
       }
       F wdepth = L::subsum(dsel);
-      F wsub = lm::rint_(wcode * 0.125f - 0.4375f);         // floor(wcode / 8) for wcode = 8 sub + jj, jj < 8
+      F wsub = lm::rint_(wcode * (1.0f / STRIDE) - (0.5f - 0.5f / STRIDE));   // floor(wcode / STRIDE) for wcode = STRIDE sub + jj, jj <= STRIDE / 2
       B owner = ln.is_sub(s);
       my_depth = lm::sel(owner, lm::sel(wcode < 500.0f, wdepth, far_), my_depth);
       my_sub = lm::sel(owner, wsub, my_sub);
-      my_jj = lm::sel(owner, wcode - wsub * 8.0f, my_jj);
+      my_jj = lm::sel(owner, wcode - wsub * STRIDE, my_jj);
     }
     // store the kept candidates in candidate-index order (near-ties in depth must not reorder the solve): each slot lane
     // ranks its candidate among the leg's four and picks up the one whose rank equals its slot
     {
-      F idx = lm::sel(my_depth < 1.0e29f, my_sub * 8.0f + my_jj, ln.lane_f(1000.0f) + L::i2f(ln.sub()));
+      F idx = lm::sel(my_depth < 1.0e29f, my_sub * STRIDE + my_jj, ln.lane_f(1000.0f) + L::i2f(ln.sub()));
       F i0 = L::template subbcast<0>(idx), i1 = L::template subbcast<1>(idx), i2 = L::template subbcast<2>(idx), i3 = L::template subbcast<3>(idx);
       F rank = lm::sel(i0 < idx, one, zero) + lm::sel(i1 < idx, one, zero) + lm::sel(i2 < idx, one, zero) + lm::sel(i3 < idx, one, zero);
       F me = L::i2f(ln.sub());
@@ -804,11 +901,15 @@ struct Pmc {
     PMC_TSS(25);
     if (any_contact) {
       // geometry of this lane's contact: candidate (my_sub, my_jj) of the leg, re-evaluated from the table
-      I wsub = L::f2i(my_sub), wbase = L::f2i(my_jj) * CF_WORDS;
+      // (a reverse candidate, jj = 8, has no table entry: it reads entry 7's and replaces what it needs below)
+      const B isrev = TERRAIN ? lm::and_(cvalid, my_jj > 7.5f) : (zero > one);
+      // (a slot without a candidate decodes the 'none' code to indices outside the table: clamped, its row is dead anyway)
+      I wsub = L::f2i(lm::min_(my_sub, ln.lane_f(3.0f))), wbase = L::f2i(lm::min_(my_jj, ln.lane_f(7.0f))) * CF_WORDS;
       V3l A = mk3<F>(ln.candc_of(wsub, wbase + CF_A), ln.candc_of(wsub, wbase + CF_A + 1), ln.candc_of(wsub, wbase + CF_A + 2));
       V3l ax = mk3<F>(ln.candc_of(wsub, wbase + CF_AX), ln.candc_of(wsub, wbase + CF_AX + 1), ln.candc_of(wsub, wbase + CF_AX + 2));
       V3l fb = mk3<F>(ln.candc_of(wsub, wbase + CF_FB), ln.candc_of(wsub, wbase + CF_FB + 1), ln.candc_of(wsub, wbase + CF_FB + 2));
       F r = ln.candc_of(wsub, wbase + CF_R), link = ln.candc_of(wsub, wbase + CF_LINK), kind = ln.candc_of(wsub, wbase + CF_KIND);
+      if (TERRAIN) link = lm::sel(isrev, zero, link);          // the body box
       mu = lm::sel(kind > 0.5f, ln.lane_f(ex ? ex->mu_foot : P.mu_foot), ln.lane_f(P.mu_link));
       B l1 = link < 1.5f, l2 = link < 2.5f, l0 = link < 0.5f;       // link: 0 base, 1 hip, 2 thigh, 3 shank
       V3l ezk = mk3<F>(lm::sel(l0, ez.x, lm::sel(l1, ez1.x, lm::sel(l2, ez2.x, ez3.x))), lm::sel(l0, ez.y, lm::sel(l1, ez1.y, lm::sel(l2, ez2.y, ez3.y))),
@@ -848,6 +949,15 @@ struct Pmc {
             nw = mk3<F>(lm::sel(win, ns.x, nw.x), lm::sel(win, ns.y, nw.y), lm::sel(win, ns.z, nw.z));
             scale_mu = lm::sel(win, lm::sel(isb > 0.5f, ln.lane_f(ex->box_mu_scale), one), scale_mu);
           }
+          if (L::any(isrev)) {                                  // the terrain edge's point and the body box face's normal instead
+            F rd;
+            V3l rP, rn;
+            reverse_edge(ln, P, ex, bs, R, my_sub, rd, rP, rn);
+            Pb = mk3<F>(lm::sel(isrev, rP.x, Pb.x), lm::sel(isrev, rP.y, Pb.y), lm::sel(isrev, rP.z, Pb.z));
+            nw = mk3<F>(lm::sel(isrev, rn.x, nw.x), lm::sel(isrev, rn.y, nw.y), lm::sel(isrev, rn.z, nw.z));
+            scale_mu = lm::sel(isrev, ln.lane_f(ex->box_mu_scale), scale_mu);
+            rs = lm::sel(isrev, zero, rs);
+          }
           mu = mu * scale_mu;
           // btPlaneSpace1(n): two tangents; for n = +z they are -y and +x, the directions of the flat-ground rows
           B steep = lm::abs_(nw.z) > 0.7071067811865475f;
@@ -858,6 +968,7 @@ struct Pmc {
           V3l t1w = mk3<F>(lm::sel(steep, p_s.x, p_f.x), lm::sel(steep, p_s.y, p_f.y), lm::sel(steep, p_s.z, p_f.z));
           V3l t2w = mk3<F>(lm::sel(steep, q_s.x, q_f.x), lm::sel(steep, q_s.y, q_f.y), lm::sel(steep, q_s.z, q_f.z));
           un = mulT(R, nw); ut1 = mulT(R, t1w); ut2 = mulT(R, t2w);
+          Pb = Pb + scale(ez - un, rs);                         // a sphere touches where the surface's normal leaves it, not at its lowest point
         }
       }
       F depth_c = my_depth;

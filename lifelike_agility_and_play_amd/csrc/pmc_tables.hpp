@@ -295,6 +295,9 @@ inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
     case LLM_SPEC_WARM_START:
       if (v != 0.0) return "this switch exists in the oracle only (tools/deviation_table.py reports what it is worth)";
       break;
+    case LLM_SPEC_TRUNK_EDGES:
+      if (v != 1.0) return "this switch exists in the oracle only (a test instrument)";
+      break;
     default: return "unknown spec parameter id";
   }
   return "";
@@ -310,6 +313,7 @@ inline double pmc_get_spec_param(const StepParams& P, int id) {
     case LLM_SPEC_MAX_SELF: return P.max_self;
     case LLM_SPEC_ERP: return P.erp;
     case LLM_SPEC_CONTACT_MARGIN: return P.margin_dist;
+    case LLM_SPEC_TRUNK_EDGES: return 1.0;
     default: return 0.0;
   }
 }

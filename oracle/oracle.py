@@ -101,7 +101,7 @@ def f64(a):
 
 # ---- spec overrides (include/llenv_model.h LLM_SPEC_*; deviation study) ------------------------
 SPEC_IDS = dict(limit_gate=0, max_depen_speed=1, link_damping=2, max_contacts_per_leg=3, self_collision=4, self_margin=5, max_self=6,
-                erp=7, contact_margin=8, self_friction=9, warm_start=10)
+                erp=7, contact_margin=8, self_friction=9, warm_start=10, trunk_edges=11)
 
 
 def set_spec(**kw):

@@ -549,7 +549,7 @@ static int aba(const OModel* M, const OKin* K, const double* qd, const double* t
 /* Spec overrides (include/llenv_model.h LLM_SPEC_*): process-wide, defaults = the constants of that header.  The engine has the same
  * switches (ll_set_spec_param); tools/deviation_table.py moves them in both to measure what each of this build's own choices is worth. */
 static double g_spec[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0};
+                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0};
 int orc_set_spec_param(int id, double v) {
   if (id < 0 || id >= LLM_SPEC_COUNT) return -1;
   if (id == LLM_SPEC_MAX_CONTACTS_PER_LEG && !(v >= 1 && v <= LLM_MAX_CONTACTS_PER_LEG)) return -1;
@@ -560,7 +560,7 @@ int orc_set_spec_param(int id, double v) {
 double orc_get_spec_param(int id) { return (id >= 0 && id < LLM_SPEC_COUNT) ? g_spec[id] : NAN; }
 void orc_reset_spec(void) {
   const double d[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0};
+                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0};
   memcpy(g_spec, d, sizeof d);
 }
 #define g_link_damping (g_spec[LLM_SPEC_LINK_DAMPING])
@@ -636,6 +636,16 @@ static double shape_sdf(const double* s, const double* E, double* n, int* is_box
   if (q[2] > d) { d = q[2]; ax = 2; }
   n[0] = n[1] = n[2] = 0; n[ax] = sg[ax];
   *is_box = 1;
+  /* outside the box: the Euclidean distance to it and the direction away from its nearest point -- over a face the same as above,
+   * diagonally outside an edge or a corner the rounded distance, so that a sphere or a link's mid-span meets an edge with the
+   * normal pointing from the edge to its centre */
+  {
+    const double o0 = q[0] > 0 ? q[0] : 0, o1 = q[1] > 0 ? q[1] : 0, o2 = q[2] > 0 ? q[2] : 0, e2 = o0 * o0 + o1 * o1 + o2 * o2;
+    if (e2 > 0.0) {
+      const double e = sqrt(e2);
+      d = e; n[0] = sg[0] * o0 / e; n[1] = sg[1] * o1 / e; n[2] = sg[2] * o2 / e;
+    }
+  }
   if (s[6] != 0.0) {
     double ze = s[6] > 0 ? s[5] : s[4];
     for (int e = 0; e < 2; e++) {
@@ -652,6 +662,7 @@ static double shape_sdf(const double* s, const double* E, double* n, int* is_box
  * and keeps the KC candidates of smallest depth below the margin (ties: lower index); the kept ones fill the slots in
  * candidate-index order.  (The index order is the one of the kernel's table, pmc_tables.hpp pmc_build_cand_table.) */
 typedef struct { double P[3], depth, mu, rs, n[3]; int body, valid; } OCand;   /* rs: radius when the primitive is a sphere (tested at its centre) */
+#define NCAND 36   /* per leg: index = 9 * sub + jj; jj = 7 (mid-link spheres) and jj = 8 (terrain edges under the trunk) exist only with terrain */
 
 static void cand_point(const OPrim* p, const double* Rw, const double* pw, int which, OCand* c) {
   double ctr[3], t[3], Rp[9];
@@ -680,9 +691,9 @@ static void cand_point(const OPrim* p, const double* Rw, const double* pw, int w
 }
 
 static void capsule(const OModel* M, const OKin* K, int leg, int which, double* a, double* b, double* r, int* body);
-/* the 32 candidate points of leg l, index = 8 * sub + jj as in the kernel's table; jj = 7 (the mid-link spheres) exists only with terrain */
+/* the candidate points of leg l, index = 9 * sub + jj in the (sub, jj) order of the kernel's table; jj = 8 is left invalid here (reverse_edge) */
 static void enum_cands(const OModel* M, const OKin* K, int l, double mu_foot, double mu_link, const OTerrain* T, OCand* c) {
-  memset(c, 0, 32 * sizeof(OCand));
+  memset(c, 0, NCAND * sizeof(OCand));
   int hip = 1 + 3 * l, thigh = 2 + 3 * l, shank = 3 + 3 * l, k = 0;
   const OPrim* lp = M->leg_prims[l];   /* 0 hip cyl | 1 thigh box, 2 thigh cyl 0, 3 thigh cyl 1, 4 wheel | 5 shank box, 6 foot */
 #define CAND(prim, body_, which, mu_) do { cand_point(prim, K->Rw[body_], K->pw[body_], which, &c[k]); c[k].body = body_; c[k].mu = mu_; k++; } while (0)
@@ -695,51 +706,124 @@ static void enum_cands(const OModel* M, const OKin* K, int l, double mu_foot, do
   for (int s2 = 0; s2 < 2; s2++) CAND(&lp[4], thigh, s2, mu_link);         /*  4,5    wheel caps                   */
   CAND(&lp[5], shank, 3, mu_link);                                        /*  6      shank box v3                 */
   MID(1, 1.0 / 3.0);                                                      /*  7      shank axis 1/3 (terrain)     */
+  k++;                                                                    /*         (jj = 8: reverse_edge)       */
   for (int v = 4; v < 8; v++) CAND(&lp[5], shank, v, mu_link);             /*  7-10   shank box v4..v7             */
   for (int s2 = 0; s2 < 2; s2++) CAND(&lp[2], thigh, s2, mu_link);         /*  11,12  thigh cylinder 0 caps        */
   CAND(&M->base_prims[0], 0, l, mu_link);                                 /*  13     body box vertex (leg, z-)    */
   MID(1, 2.0 / 3.0);                                                      /*         shank axis 2/3 (terrain)     */
+  k++;                                                                    /*         (jj = 8: reverse_edge)       */
   for (int v = 0; v < 4; v++) CAND(&lp[1], thigh, v, mu_link);             /*  14-17  thigh box v0..v3             */
   for (int s2 = 0; s2 < 2; s2++) CAND(&lp[3], thigh, s2, mu_link);         /*  18,19  thigh cylinder 1 caps        */
   CAND(&M->base_prims[0], 0, l + 4, mu_link);                             /*  20     body box vertex (leg, z+)    */
   MID(0, 1.0 / 3.0);                                                      /*         thigh axis 1/3 (terrain)     */
+  k++;                                                                    /*         (jj = 8: reverse_edge)       */
   for (int v = 4; v < 8; v++) CAND(&lp[1], thigh, v, mu_link);             /*  21-24  thigh box v4..v7             */
   for (int s2 = 0; s2 < 2; s2++) CAND(&lp[0], hip, s2, mu_link);           /*  25,26  hip cylinder caps            */
   if (l == 0 || l == 2) CAND(&M->base_prims[l == 0 ? 1 : 2], 0, 0, mu_link); else k++;   /* 27 handle sphere (legs 0, 2) */
   MID(0, 2.0 / 3.0);                                                      /*         thigh axis 2/3 (terrain)     */
+  k++;                                                                    /*         (jj = 8: reverse_edge)       */
 #undef CAND
 #undef MID
+}
+/* Reverse candidates ("edges under the trunk"): the robot's own candidate points are vertices and spheres, which cannot see
+ * a step edge that crosses the flat of the body box between its corners.  So leg l also tests top edge l of every terrain box
+ *   l = 0: x = x0,  1: x = x1 (both along y),  2: y = y0,  3: y = y1 (both along x),  all at z = z1
+ * against the body box, in the box's own frame (half extents h):
+ *   1. the edge is cut to the box grown by the contact margin (nothing left: no candidate);
+ *   2. the middle of what is left names the face of the body box the edge runs along: the axis of largest |p_i| - h_i;
+ *   3. the edge is cut to the exact extents of the other two axes; the two ends of that piece are the candidates (sub-lanes 0 and 1 of
+ *      the leg, candidate jj = 8), each with depth = its signed distance to the face's plane, contact point = the point of the
+ *      terrain edge, normal = the face's inward normal (the way the body is pushed), friction partner = the terrain box.
+ * Over several boxes each candidate keeps the deepest.  Returns 0 / 1; P, n in world coordinates. */
+static int reverse_edge(const OModel* M, const OKin* K, const OTerrain* T, int l, int s, OCand* out) {
+  const OPrim* bx = &M->base_prims[0];
+  double Bt[9], cw[3], t[3];
+  m3m(K->Rw[0], bx->rot, Bt);
+  m3v(K->Rw[0], bx->pos, t);
+  for (int i = 0; i < 3; i++) cw[i] = K->pw[0][i] + t[i];
+  const double margin = g_spec[LLM_SPEC_CONTACT_MARGIN];
+  int found = 0;
+  for (int si = 0; si < T->n; si++) {
+    const double* r = T->rec + 8 * si;
+    double al[3] = {l == 1 ? r[1] : r[0], l == 3 ? r[3] : r[2], r[5]}, bl[3] = {l == 0 ? r[0] : r[1], l == 2 ? r[2] : r[3], r[5]};
+    double aw[3], bw[3], pa[3], d[3];
+    if (T->yawed) {
+      aw[0] = T->cx + al[0] * T->cs - al[1] * T->sn; aw[1] = T->cy + al[0] * T->sn + al[1] * T->cs; aw[2] = al[2];
+      bw[0] = T->cx + bl[0] * T->cs - bl[1] * T->sn; bw[1] = T->cy + bl[0] * T->sn + bl[1] * T->cs; bw[2] = bl[2];
+    } else { memcpy(aw, al, 24); memcpy(bw, bl, 24); }
+    for (int i = 0; i < 3; i++) {            /* into the body box's frame */
+      pa[i] = 0; d[i] = 0;
+      for (int k = 0; k < 3; k++) { pa[i] += Bt[3 * k + i] * (aw[k] - cw[k]); d[i] += Bt[3 * k + i] * (bw[k] - aw[k]); }
+    }
+    double lo[3], hi[3], t0 = 0, t1 = 1;
+    for (int i = 0; i < 3; i++) {
+      const double ds = fabs(d[i]) < 1e-9 ? 1e-9 : d[i], H = bx->size[i] + margin;
+      const double ta = (-H - pa[i]) / ds, tb = (H - pa[i]) / ds;
+      if ((ta < tb ? ta : tb) > t0) t0 = ta < tb ? ta : tb;
+      if ((ta < tb ? tb : ta) < t1) t1 = ta < tb ? tb : ta;
+      const double ea = (-bx->size[i] - pa[i]) / ds, eb = (bx->size[i] - pa[i]) / ds;
+      lo[i] = ea < eb ? ea : eb; hi[i] = ea < eb ? eb : ea;
+    }
+    if (t0 > t1) continue;
+    const double tm = 0.5 * (t0 + t1);
+    double q = -INFINITY, sg = 1; int ax = 0;
+    for (int i = 0; i < 3; i++) {
+      const double pm = pa[i] + tm * d[i], qi = fabs(pm) - bx->size[i];
+      if (qi > q) { q = qi; ax = i; sg = pm >= 0 ? 1.0 : -1.0; }
+    }
+    double u0 = 0, u1 = 1;
+    for (int i = 0; i < 3; i++) {
+      if (i == ax) continue;
+      if (lo[i] > u0) u0 = lo[i];
+      if (hi[i] < u1) u1 = hi[i];
+    }
+    if (u0 > u1) continue;
+    const double u = s ? u1 : u0;
+    double p[3];
+    for (int i = 0; i < 3; i++) p[i] = pa[i] + u * d[i];
+    const double depth = sg * p[ax] - bx->size[ax];
+    if (found && depth >= out->depth) continue;
+    found = 1;
+    out->depth = depth; out->rs = 0; out->body = 0; out->valid = 2;
+    for (int i = 0; i < 3; i++) { out->P[i] = aw[i] + u * (bw[i] - aw[i]); out->n[i] = -sg * Bt[3 * i + ax]; }
+  }
+  return found;
 }
 static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double mu_link, const OTerrain* T, OContact* out) {
   int n = 0;
   for (int l = 0; l < 4; l++) {
-    OCand c[32];
+    OCand c[NCAND];
     enum_cands(M, K, l, mu_foot, mu_link, T, c);
-    if (T)                                   /* the nearest surface decides depth, normal and friction partner */
-      for (int i = 0; i < 32; i++) {
+    if (T) {                                 /* the nearest surface decides depth, normal and friction partner */
+      for (int i = 0; i < NCAND; i++) {
         if (!c[i].valid) continue;
         double E[3] = {c[i].P[0], c[i].P[1], c[i].P[2] + c[i].rs};
         for (int si = 0; si < T->n; si++) {
           double nn[3]; int isb;
           double d = terrain_sdf(T, si, E, nn, &isb) - c[i].rs;
-          if (d < c[i].depth) { c[i].depth = d; memcpy(c[i].n, nn, 24); c[i].valid = isb ? 2 : 3; }   /* valid: 1 plane, 2 box, 3 edge cylinder */
+          if (d < c[i].depth) {              /* valid: 1 plane, 2 box, 3 edge cylinder */
+            c[i].depth = d; memcpy(c[i].n, nn, 24); c[i].valid = isb ? 2 : 3;
+            for (int k = 0; k < 3; k++) c[i].P[k] = E[k] - c[i].rs * nn[k];      /* a sphere touches where the surface's normal leaves it */
+          }
         }
       }
-    int taken[32] = {0}, nsel = 0;
+      for (int s = 0; s < 2 && g_spec[LLM_SPEC_TRUNK_EDGES] > 0.5; s++) { c[9 * s + 8].mu = mu_link; reverse_edge(M, K, T, l, s, &c[9 * s + 8]); }
+    }
+    int taken[NCAND] = {0}, nsel = 0;
     const int kc = (int)g_spec[LLM_SPEC_MAX_CONTACTS_PER_LEG];
     for (int s = 0; s < kc; s++) {          /* the KC deepest (ties: lower index) ... */
       int best = -1;
       double dmin = INFINITY;                /* candidates within LLM_SELECT_EPS of the deepest are equally deep: the lowest index wins */
-      for (int i = 0; i < 32; i++)
+      for (int i = 0; i < NCAND; i++)
         if (c[i].valid && !taken[i] && c[i].depth < g_spec[LLM_SPEC_CONTACT_MARGIN] && c[i].depth < dmin) dmin = c[i].depth;
-      for (int i = 0; i < 32 && best < 0; i++)
+      for (int i = 0; i < NCAND && best < 0; i++)
         if (c[i].valid && !taken[i] && c[i].depth < g_spec[LLM_SPEC_CONTACT_MARGIN] && c[i].depth <= dmin + LLM_SELECT_EPS) best = i;
       if (best < 0) break;
       taken[best] = 1;
       nsel++;
     }
     int slot = 0;
-    for (int i = 0; i < 32; i++) {          /* ... stored in candidate-index order, so near-ties in depth cannot reorder the solve */
+    for (int i = 0; i < NCAND; i++) {          /* ... stored in candidate-index order, so near-ties in depth cannot reorder the solve */
       if (!taken[i]) continue;
       out[n].body = c[i].body; memcpy(out[n].P, c[i].P, 24); out[n].depth = c[i].depth;
       out[n].mu = c[i].mu * (c[i].valid == 2 && T ? T->box_mu_scale : 1.0);
@@ -1110,7 +1194,7 @@ static void integrate_state(const ORows* W, double dt, double* state) {
 /* Warm starting (LLM_SPEC_WARM_START = factor > 0; deviation study only -- the spec, like btMultiBodyConstraintSolver for multibody
  * contacts as far as this author recalls its source, starts every substep from zero multipliers): the multipliers a robot's rows
  * ended the previous substep with, keyed by what persists -- joint, (leg, candidate index), capsule pair. */
-typedef struct { double lim[12], con[4][32][3], self[24][3]; } OWarm;
+typedef struct { double lim[12], con[4][NCAND][3], self[24][3]; } OWarm;
 static _Thread_local OWarm* tl_warm = NULL;   /* set by orc_step_env around its substeps; NULL for the stateless entry points */
 static void warm_apply(ORows* W, const OWarm* c, double f) {
   for (int r = 0; r < W->nr; r++) W->lam[r] = 0;
@@ -1206,9 +1290,9 @@ static int find_pair_contacts(const OModel* M, const OKin* K0, const OKin* K1, O
 static void touch_classes(const OModel* M, const OKin* K, const OTerrain* T, int flag, int* t_static, int* t_flag) {
   *t_static = 0; *t_flag = 0;
   for (int l = 0; l < 4; l++) {
-    OCand c[32];
+    OCand c[NCAND];
     enum_cands(M, K, l, 0.0, 0.0, T, c);
-    for (int i = 0; i < 32; i++) {
+    for (int i = 0; i < NCAND; i++) {
       if (!c[i].valid || c[i].body == 0 || i == 0) continue;
       if (c[i].P[2] < LLM_CONTACT_MARGIN) *t_static = 1;
       const double E[3] = {c[i].P[0], c[i].P[1], c[i].P[2] + c[i].rs};

@@ -285,6 +285,75 @@ def check_terrain_physics_against_oracle(lib_path, n_envs=16, seed=11):
     return out
 
 
+def check_trunk_on_edges_against_oracle(lib_path, n_envs=16, seed=5):
+    """DESIGN 8 "edges under the trunk" and the side point of a sphere on a wall: robots dropped belly-first across the edges of cube steps
+    and hurdles (legs folded back so that the trunk gets there first), one control step, engine vs oracle -- and against the oracle with the
+    reverse candidates switched off, to show that the cases are what they claim to be."""
+    from conftest import make_oracle_batch
+    from oracle import oracle as orc
+    from lifelike_agility_and_play_amd import mocap
+    from parity_common import quat_align
+    from scipy.spatial.transform import Rotation as Rot
+    out = dict(config=[], vel=[], n_edge_felt=0)
+    blob = urdf_model.default_model_blob()
+    box = blob[urdf_model.OFF_BASE_PRIMS:urdf_model.OFF_BASE_PRIMS + urdf_model.PRIM_STRIDE]
+    hz, cz = box[3], box[6]
+    for element in (3, 1):
+        cfg = env_config(element)
+        E = make_engine(cfg, n_envs, lib_path, seed=seed)
+        E.reset()
+        rows, cnt = E.statics()
+        rng = np.random.default_rng(seed)
+        st = E.state().astype(np.float64)
+        recs_all = [statics_to_records(rows[i, :cnt[i]].astype(np.float64)) for i in range(n_envs)]
+        for i in range(n_envs):
+            rec = recs_all[i]
+            cand = [b for b in rec[2:10] if b[4] < 0.01 and b[5] > 0.05]              # boxes standing on the ground
+            b = cand[rng.integers(0, len(cand))]
+            edge = b[0] if rng.uniform() < 0.5 else b[1]
+            st[i, 0] = edge + rng.uniform(-0.1, 0.1); st[i, 1] = rng.uniform(-0.1, 0.1)
+            st[i, 2] = b[5] + hz - cz + rng.uniform(-0.015, 0.012)                     # the belly within the margin of, or a little into, the top
+            st[i, 3:7] = Rot.from_euler('zyx', [rng.uniform(-0.5, 0.5), rng.uniform(-0.15, 0.15), rng.uniform(-0.1, 0.1)]).as_quat()
+            st[i, 7:13] = rng.normal(size=6) * 0.3; st[i, 9] -= 0.5
+            st[i, 13:25] = np.tile([0.0, 1.4, -2.4], 4) + rng.normal(size=12) * 0.05     # legs folded up and back
+            st[i, 25:37] = rng.normal(size=12) * 0.5
+        E.set_state(st)
+        st32 = E.state().astype(np.float64)
+        act = (rng.normal(size=(n_envs, 12)) * 0.05).astype(np.float32)
+        ep = E.episode()
+        E.step_host(act)
+        es = E.state().astype(np.float64)
+        tr = E.push_trace().astype(np.float64)
+        B = make_oracle_batch(orc, blob, mocap.load_mocap('', 0.02), n_envs=1, kd=0.5, max_tau=16.0)
+        for i in range(n_envs):
+            rec = recs_all[i]
+            p = st32[i, 0:3]
+            near = rec[(p[0] >= rec[:, 0] - 0.9) & (p[0] <= rec[:, 1] + 0.9) & (p[1] >= rec[:, 2] - 0.9) & (p[1] <= rec[:, 3] + 0.9) & (p[2] <= rec[:, 5] + 0.9)][:8]
+            res = {}
+            for edges in (1, 0):
+                orc.set_spec(trunk_edges=edges)
+                s = st32[i].copy()
+                tgt = np.clip(s[13:25] + act[i].astype(np.float64), -3.0, 3.0)
+                for k in range(10):
+                    tau = np.clip(50.0 * (tgt - s[13:25]) - 0.5 * s[25:37], -16.0, 16.0)
+                    push = tr[i, k, 1:4] if tr[i, k, 0] > 0.5 else None
+                    s, nc, lam = B.substep_terrain(s, tau, float(np.float32(ep['friction'][i]) * np.float32(0.9)), near, 0.5 / 0.9, push)
+                res[edges] = s
+            orc.reset_spec()
+            s = res[1]
+            if np.abs(res[1] - res[0]).max() > 1e-3:
+                out['n_edge_felt'] += 1
+            err = np.abs(quat_align(es[i], s) - s)
+            out['config'].append(max(err[0:7].max(), err[13:25].max()))
+            out['vel'].append(max(err[7:13].max(), err[25:37].max()) / (1.0 + np.abs(s[25:37]).max()))
+        E.close()
+    c, v = np.array(out['config']), np.array(out['vel'])
+    assert out['n_edge_felt'] >= 8, out['n_edge_felt']
+    assert c.max() < 1e-4, np.sort(c)[-5:]
+    assert v.max() < 1e-3, np.sort(v)[-5:]
+    return out
+
+
 def check_free_running_against_oracle_env(lib_path, n_steps=4, elements=(1, 3, 0), aux=0.02, obs_rand=None):
     """End to end, nothing scripted: the engine and the oracles assembled into a CPU env (oracle/free_run.py) start from the same uniforms,
     get the same actions and are compared after every control step -- terrain, rays on the real boxes, ten substeps of terrain physics with the

@@ -38,6 +38,11 @@ def test_terrain_physics_against_oracle(emul_lib):
     assert out['n_terrain'] >= 10
 
 
+def test_trunk_on_edges_against_oracle(emul_lib):
+    out = ec.check_trunk_on_edges_against_oracle(emul_lib)
+    print(out['n_edge_felt'], max(out['config']), max(out['vel']))
+
+
 def test_free_running_against_the_oracle_env(emul_lib):
     print(ec.check_free_running_against_oracle_env(emul_lib))
 

@@ -33,5 +33,10 @@ def test_terrain_physics_against_oracle():
     assert out['n_terrain'] >= 30 and out['n_felt'] >= 20
 
 
+def test_trunk_on_edges_against_oracle():
+    out = ec.check_trunk_on_edges_against_oracle(None, n_envs=48)
+    assert out['n_edge_felt'] >= 24
+
+
 def test_free_running_against_the_oracle_env_gpu():
     print(ec.check_free_running_against_oracle_env(None))

@@ -279,3 +279,30 @@ def test_jump_obstacle_is_a_solid_body(golden, orc, model_blob, mocap_table):
     assert v_along(with_box[k]) < v_along(free[k]) - 0.01, (v_along(with_box[k]), v_along(free[k]))
     assert np.abs(with_box[k][25:37] - free[k][25:37]).max() > 0.05
     assert along(with_box[k]) < 0.0                                                               # the base is still on its own side
+
+
+def test_belly_landing_on_edges_does_not_sink(golden, orc, model_blob, mocap_table):
+    """DESIGN 8 "edges under the trunk": the flat of the body box against terrain it overhangs.  (a) a pillar whose top is smaller than the
+    belly -- its corners are under the flat, no vertex of the robot is over it; (b) a thin wall crossed at right angles, and askew --
+    its top edges run under the belly from side to side.  In each case the robot, legs dangling, comes to rest with its belly on the top."""
+    B = make_oracle_batch(orc, model_blob, mocap_table)
+    hold = standing_state(golden)[13:25].copy()
+    box = model_blob[um.OFF_BASE_PRIMS:um.OFF_BASE_PRIMS + um.PRIM_STRIDE]
+    hz, cz = box[3], box[6]                                             # half thickness and centre height of the body box in the base frame
+    top = 0.6
+    cases = [('pillar', np.array([[-0.125, 0.125, -0.08, 0.08, 0.0, top, 0.0, 0.0]]), 0.0),
+             ('wall', np.array([[-0.05, 0.05, -1.0, 1.0, 0.0, top, 0.0, 0.0]]), 0.0),
+             ('wall, crossed at 0.2 rad', np.array([[-0.05, 0.05, -1.0, 1.0, 0.0, top, 0.0, 0.0]]), 0.2)]
+    for name, shapes, yaw in cases:
+        s = standing_state(golden, z=top + hz - cz + 0.03)
+        s[3:7] = [0, 0, np.sin(yaw / 2), np.cos(yaw / 2)]
+        ncs = []
+        for _ in range(600):
+            tau = np.clip(50.0 * (hold - s[13:25]) - 0.5 * s[25:37], -18.0, 18.0)
+            s, nc, lam = B.substep_terrain(s, tau, 0.45, shapes, 1.0, None)
+            ncs.append(nc)
+        belly = s[2] + cz - hz
+        assert abs(belly - top) < 4e-3, (name, belly)
+        assert np.abs(s[7:13]).max() < 0.05, (name, s[7:13])              # at rest
+        assert ncs[-1] >= 3, (name, ncs[-1])                              # a support polygon, not a point
+        assert B.fk_feet(s)[:, 2].min() > 0.1                             # the feet hang in the air: the belly carries the robot
