@@ -101,6 +101,23 @@ def cpu_baseline(blob, table, budget_s=8.0):
                       % (sn, cores, max(64, 16 * cores), s1, tn, t1)}
 
 
+def committed_counters(kernel, units):
+    """PMC counters cannot be read from inside this process: `traffic` (HBM bytes per launch, FETCH_SIZE + WRITE_SIZE) and the
+    issue-slot accounting of the dominant kernel come from the committed rocprofv3 --pmc passes of the same command at the same
+    batch (tools/profile.sh -> tools/profile_summarize.py -> profiles/traffic.json and the per-kernel counters file it names)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))[kernel]
+        if t['units_per_launch'] != units:
+            return None, None, None
+        c = json.load(open(os.path.join(ROOT, t['counters_file'])))
+        n_inst = c['SQ_INSTS_VALU'] + c['SQ_INSTS_SALU'] + c['SQ_INSTS_LDS']
+        issue = {'instructions_per_wave': n_inst / c['SQ_WAVES'], 'issue_slots_per_wave': c['SQ_WAVE_CYCLES'] / c['SQ_WAVES'], 'frac': n_inst / c['SQ_WAVE_CYCLES'],
+                 'source': t['counters_file'] + ' (rocprofv3 --pmc SQ_INSTS_*, SQ_WAVE_CYCLES in quad-cycles)'}
+        return t['traffic_bytes'], issue, 'profiles/traffic.json <- %s (bytes per launch, FETCH_SIZE + WRITE_SIZE, uncorrected; see DESIGN.md 5.1)' % t['counters_file']
+    except Exception:                    # noqa: BLE001
+        return None, None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -229,24 +246,7 @@ def main():
         total_env_steps = world * n * args.steps
         value = total_env_steps / elapsed
         achieved = (n * ALGO_BYTES_PER_ENV_STEP) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
-        traffic = None                       # PMC counters cannot be read from inside this process: the value comes from
-        tj = os.path.join(ROOT, 'profiles', 'traffic.json')   # the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        if os.path.exists(tj) and n == ENVS_PER_GPU:
-            try:
-                traffic = json.load(open(tj))['traffic_bytes']
-            except Exception:                # noqa: BLE001
-                traffic = None
-        issue = None                         # the binding limit: one instruction per wave per quad-cycle, one wave per SIMD
-        cj = os.path.join(ROOT, 'profiles', 'r01_pmc_step_kernel_counters.json')
-        if os.path.exists(cj) and n == ENVS_PER_GPU:
-            try:
-                c = json.load(open(cj))
-                issue = {'instructions_per_wave': (c['SQ_INSTS_VALU'] + c['SQ_INSTS_SALU'] + c['SQ_INSTS_LDS']) / c['SQ_WAVES'],
-                         'issue_slots_per_wave': c['SQ_WAVE_CYCLES'] / c['SQ_WAVES'],
-                         'frac': (c['SQ_INSTS_VALU'] + c['SQ_INSTS_SALU'] + c['SQ_INSTS_LDS']) / c['SQ_WAVE_CYCLES'],
-                         'source': 'profiles/r01_pmc_step_kernel_counters.json (rocprofv3 --pmc SQ_INSTS_*, SQ_WAVE_CYCLES in quad-cycles)'}
-            except Exception:                # noqa: BLE001
-                issue = None
+        traffic, issue, tsrc = committed_counters('pmc_step_kernel', n)
         out = {
             'metric': 'env-steps/sec (whole node), PMC tracking env, random policy',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -261,10 +261,10 @@ def main():
                        **({'unrolls_gathered': traj.n_gathered, 'unroll_row_floats': int(traj.buf.shape[-1]), 'gather_check': gather_check} if traj is not None else {})},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBPS) if achieved else None, 'traffic': traffic, 'peak_measured_triad': triad,
-                         'traffic_source': 'profiles/traffic.json (bytes per launch, FETCH_SIZE + WRITE_SIZE, uncorrected; see DESIGN.md 5.1)',
+                         'traffic_source': tsrc,
                          'kernel': 'pmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
                          'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP, 'single_wave_issue': issue,
-                         'note': 'bound by single-wave instruction issue, not HBM (about 1.5e5 instructions per wave per step vs 2.5 KB per env); see DESIGN.md 5.1'},
+                         'note': 'bound by single-wave instruction issue, not HBM (about 7.7e4 instructions per wave per step, four envs, vs 2.5 KB per env); see DESIGN.md 5.1'},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(blob, table)
@@ -354,6 +354,7 @@ def main_epmc(args):
         elapsed = float(tt.item())
     if rank == 0:
         achieved = n * EPMC_ALGO_BYTES_PER_ENV_STEP / (k_ms * 1e-3) / 1e9
+        traffic, issue, tsrc = committed_counters('epmc_step_kernel', n)
         extra = {'cpu_baseline': cpu_baseline_env('epmc', epmc_env_config(args.element))} if (world == 1 and not args.no_cpu_baseline) else {}
         print(json.dumps({**extra, **{
             'metric': 'env-steps/sec (whole node), EPMC PlayGround env, random policy', 'value': world * n * args.steps / elapsed, 'unit': 'env-steps/s',
@@ -361,7 +362,8 @@ def main_epmc(args):
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'EPMC PlayGround env (BASELINE config 4), %d envs per MI355X, element_id %d, 778 rays per env-step, push forces, '
                                    'random-policy actions N(0, e^-2), auto-reset' % (n, args.element), 'envs_per_gpu': n, 'episodes_finished_rank0': eng.counters()['episodes']},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                         'traffic_source': tsrc, 'single_wave_issue': issue,
                          'kernel': 'epmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
                          'algorithmic_bytes_per_env_step': EPMC_ALGO_BYTES_PER_ENV_STEP,
                          'note': 'bound by single-wave instruction issue, not HBM; see DESIGN.md 8'}}}), flush=True)
@@ -428,6 +430,7 @@ def main_sepmc(args):
         elapsed = float(tt.item())
     if rank == 0:
         achieved = 2 * n_arenas * SEPMC_ALGO_BYTES_PER_ROBOT_STEP / (k_ms * 1e-3) / 1e9
+        traffic, issue, tsrc = committed_counters('sepmc_step_kernel', 2 * n_arenas)
         extra = {'cpu_baseline': cpu_baseline_env('sepmc', sepmc_env_config())} if (world == 1 and not args.no_cpu_baseline) else {}
         print(json.dumps({**extra, **{
             'metric': 'robot-steps/sec (whole node), SEPMC chase-tag env, random policy', 'value': world * 2 * n_arenas * args.steps / elapsed, 'unit': 'robot-steps/s',
@@ -436,7 +439,8 @@ def main_sepmc(args):
             'config': {'workload': 'SEPMC ChaseTagGameEnv (BASELINE config 5), %d arenas x 2 robots per MI355X, 2 x 778 perception rays + 21 visibility rays per '
                                    'arena-step, two-robot push schedule, robot-robot contact, random-policy actions N(0, e^-2), auto-reset' % n_arenas,
                        'arenas_per_gpu': n_arenas, 'episodes_finished_rank0': eng.counters()['episodes']},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                         'traffic_source': tsrc, 'single_wave_issue': issue,
                          'kernel': 'sepmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
                          'algorithmic_bytes_per_robot_step': SEPMC_ALGO_BYTES_PER_ROBOT_STEP,
                          'note': 'bound by single-wave instruction issue, not HBM; see DESIGN.md 8b'}}}), flush=True)

@@ -76,6 +76,7 @@
 #define LLM_SPEC_SELF_FRICTION 9         /* mu of two tangential rows per leg-leg contact; default 0 (frictionless).  ORACLE ONLY */
 #define LLM_SPEC_WARM_START 10           /* factor applied to the previous substep's multipliers of persisting rows; default 0 = none.  ORACLE ONLY */
 #define LLM_SPEC_TRUNK_EDGES 11         /* 0 / 1   terrain edges under the body box are contact candidates; default 1.  ORACLE ONLY (a test instrument) */
-#define LLM_SPEC_COUNT 12
+#define LLM_SPEC_SELECT_EPS 12          /* m       default LLM_SELECT_EPS.  ORACLE ONLY (a test instrument: parity cases on the rule's discontinuity) */
+#define LLM_SPEC_COUNT 13
 
 #endif

@@ -298,6 +298,9 @@ inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
     case LLM_SPEC_TRUNK_EDGES:
       if (v != 1.0) return "this switch exists in the oracle only (a test instrument)";
       break;
+    case LLM_SPEC_SELECT_EPS:
+      if (v != LLM_SELECT_EPS) return "this switch exists in the oracle only (a test instrument)";
+      break;
     default: return "unknown spec parameter id";
   }
   return "";
@@ -314,6 +317,7 @@ inline double pmc_get_spec_param(const StepParams& P, int id) {
     case LLM_SPEC_ERP: return P.erp;
     case LLM_SPEC_CONTACT_MARGIN: return P.margin_dist;
     case LLM_SPEC_TRUNK_EDGES: return 1.0;
+    case LLM_SPEC_SELECT_EPS: return LLM_SELECT_EPS;
     default: return 0.0;
   }
 }

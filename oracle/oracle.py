@@ -101,7 +101,7 @@ def f64(a):
 
 # ---- spec overrides (include/llenv_model.h LLM_SPEC_*; deviation study) ------------------------
 SPEC_IDS = dict(limit_gate=0, max_depen_speed=1, link_damping=2, max_contacts_per_leg=3, self_collision=4, self_margin=5, max_self=6,
-                erp=7, contact_margin=8, self_friction=9, warm_start=10, trunk_edges=11)
+                erp=7, contact_margin=8, self_friction=9, warm_start=10, trunk_edges=11, select_eps=12)
 
 
 def set_spec(**kw):
@@ -269,6 +269,21 @@ class OracleBatch(object):
                                        _p(pu) if pu is not None else None, C.byref(nc), _p(lam))
         assert rc == 0
         return s, nc.value, lam
+
+    @staticmethod
+    def selection_margin(reset=True):
+        """How close the find_contacts calls of this thread since the last reset came to the deepest-K rule's discontinuity (a candidate's depth
+        crossing deepest + LLM_SELECT_EPS), in metres: parity tests set cases aside in which float32 rounding can flip the pick."""
+        f = lib().orc_selection_margin
+        f.restype = C.c_double
+        return float(f(C.c_int(1 if reset else 0)))
+
+    def list_contacts(self, state, mu_foot, shapes, box_mu_scale):
+        """The contacts kept in this configuration: rows [leg, candidate index (9 sub + jj), depth, P(3), n(3), mu, body] (tests)."""
+        out = np.zeros((16, 11))
+        sh = f64(np.asarray(shapes).reshape(-1, 8)) if len(shapes) else np.zeros((0, 8))
+        n = lib().orc_list_contacts(self.h, _p(f64(state)), C.c_double(mu_foot), C.c_int(len(sh)), _p(sh) if len(sh) else None, C.c_double(box_mu_scale), _p(out))
+        return out[:n]
 
     def substep_pair(self, state0, state1, tau0, tau1, mu_foot, shapes0, shapes1, box_mu_scale, push0=None, push1=None):
         """One substep of the two robots of a SEPMC arena (sepmc parity tests).  Returns (state0, state1, shared rows [n][8])."""

@@ -549,7 +549,7 @@ static int aba(const OModel* M, const OKin* K, const double* qd, const double* t
 /* Spec overrides (include/llenv_model.h LLM_SPEC_*): process-wide, defaults = the constants of that header.  The engine has the same
  * switches (ll_set_spec_param); tools/deviation_table.py moves them in both to measure what each of this build's own choices is worth. */
 static double g_spec[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0};
+                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS};
 int orc_set_spec_param(int id, double v) {
   if (id < 0 || id >= LLM_SPEC_COUNT) return -1;
   if (id == LLM_SPEC_MAX_CONTACTS_PER_LEG && !(v >= 1 && v <= LLM_MAX_CONTACTS_PER_LEG)) return -1;
@@ -560,7 +560,7 @@ int orc_set_spec_param(int id, double v) {
 double orc_get_spec_param(int id) { return (id >= 0 && id < LLM_SPEC_COUNT) ? g_spec[id] : NAN; }
 void orc_reset_spec(void) {
   const double d[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0};
+                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS};
   memcpy(g_spec, d, sizeof d);
 }
 #define g_link_damping (g_spec[LLM_SPEC_LINK_DAMPING])
@@ -789,6 +789,11 @@ static int reverse_edge(const OModel* M, const OKin* K, const OTerrain* T, int l
   }
   return found;
 }
+/* Diagnostic for the tests: how close the last find_contacts calls of this thread came to the one discontinuity of the deepest-K rule --
+ * a candidate's depth crossing (deepest of the round + LLM_SELECT_EPS), where the pick changes hands.  min over rounds and candidates of
+ * |depth - deepest - eps|; reset by orc_selection_margin(1). */
+static _Thread_local double tl_sel_margin = INFINITY;
+double orc_selection_margin(int reset) { const double m = tl_sel_margin; if (reset) tl_sel_margin = INFINITY; return m; }
 static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double mu_link, const OTerrain* T, OContact* out) {
   int n = 0;
   for (int l = 0; l < 4; l++) {
@@ -817,8 +822,11 @@ static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double 
       for (int i = 0; i < NCAND; i++)
         if (c[i].valid && !taken[i] && c[i].depth < g_spec[LLM_SPEC_CONTACT_MARGIN] && c[i].depth < dmin) dmin = c[i].depth;
       for (int i = 0; i < NCAND && best < 0; i++)
-        if (c[i].valid && !taken[i] && c[i].depth < g_spec[LLM_SPEC_CONTACT_MARGIN] && c[i].depth <= dmin + LLM_SELECT_EPS) best = i;
+        if (c[i].valid && !taken[i] && c[i].depth < g_spec[LLM_SPEC_CONTACT_MARGIN] && c[i].depth <= dmin + g_spec[LLM_SPEC_SELECT_EPS]) best = i;
       if (best < 0) break;
+      for (int i = 0; i < NCAND; i++)
+        if (c[i].valid && !taken[i] && c[i].depth < g_spec[LLM_SPEC_CONTACT_MARGIN] && fabs(c[i].depth - dmin - g_spec[LLM_SPEC_SELECT_EPS]) < tl_sel_margin)
+          tl_sel_margin = fabs(c[i].depth - dmin - g_spec[LLM_SPEC_SELECT_EPS]);
       taken[best] = 1;
       nsel++;
     }
@@ -912,7 +920,7 @@ static int find_self_contacts(const OModel* M, const OKin* K, OSelf* out) {
     for (int i = 0; i < nc; i++)
       if (!taken[i] && cand[i].depth < g_spec[LLM_SPEC_SELF_MARGIN] && cand[i].depth < dmin) dmin = cand[i].depth;
     for (int i = 0; i < nc && best < 0; i++)
-      if (!taken[i] && cand[i].depth < g_spec[LLM_SPEC_SELF_MARGIN] && cand[i].depth <= dmin + LLM_SELECT_EPS) best = i;
+      if (!taken[i] && cand[i].depth < g_spec[LLM_SPEC_SELF_MARGIN] && cand[i].depth <= dmin + g_spec[LLM_SPEC_SELECT_EPS]) best = i;
     if (best < 0) break;
     taken[best] = 1;
     out[n++] = cand[best];
@@ -1278,7 +1286,7 @@ static int find_pair_contacts(const OModel* M, const OKin* K0, const OKin* K1, O
     for (int i = 0; i < nc; i++)
       if (!taken[i] && cand[i].depth < LLM_CONTACT_MARGIN && cand[i].depth < dmin) dmin = cand[i].depth;
     for (int i = 0; i < nc && best < 0; i++)
-      if (!taken[i] && cand[i].depth < LLM_CONTACT_MARGIN && cand[i].depth <= dmin + LLM_SELECT_EPS) best = i;
+      if (!taken[i] && cand[i].depth < LLM_CONTACT_MARGIN && cand[i].depth <= dmin + g_spec[LLM_SPEC_SELECT_EPS]) best = i;
     if (best < 0) break;
     taken[best] = 1;
     out[n++] = cand[best];
@@ -1668,7 +1676,19 @@ int orc_substep_terrain(const OBatch* B, double* state, const double* tau, doubl
   return rc;
 }
 
-/* tests: the self-collision candidates of a state: up to 2 rows [depth, pair index, P(3), n(3)]; returns how many */
+/* tests: the contacts find_contacts keeps in the given configuration: rows [leg, candidate index 9 sub + jj, depth, P(3), n(3), mu, body]; returns how many */
+int orc_list_contacts(const OBatch* B, const double* state, double mu_foot, int n_shapes, const double* shapes, double box_mu_scale, double* out11) {
+  OTerrain T = {n_shapes, shapes, box_mu_scale};
+  OKin K;
+  OContact C[MAXC];
+  kinematics(&B->model, state, NULL, &K);
+  const int n = find_contacts(&B->model, &K, mu_foot, LLM_LINK_FRICTION * LLM_PLANE_FRICTION, n_shapes > 0 ? &T : NULL, C);
+  for (int i = 0; i < n; i++) {
+    double* o = out11 + 11 * i;
+    o[0] = C[i].leg; o[1] = C[i].cand; o[2] = C[i].depth; memcpy(o + 3, C[i].P, 24); memcpy(o + 6, C[i].n, 24); o[9] = C[i].mu; o[10] = C[i].body;
+  }
+  return n;
+}
 /* SEPMC: one substep of two robots in one world; shapes0 / shapes1 = the terrain records within reach of each (the flag among them);
  * pair_rows8 (nullable): [2][8] = P 3, n 3 (from robot 1 to robot 0), depth, pair id of the shared rows.  Returns their number. */
 int orc_substep_pair(const OBatch* B, double* state0, double* state1, const double* tau0, const double* tau1, double mu_foot, int n_shapes0,

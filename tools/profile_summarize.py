@@ -2,7 +2,7 @@
 
     python tools/profile_summarize.py r01
 """
-import csv, glob, json, os, shutil, sys
+import csv, glob, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 src, dst = os.path.join(ROOT, 'gpurun_out', tag), os.path.join(ROOT, 'profiles')
@@ -25,38 +25,74 @@ for fam in ('epmc', 'sepmc'):
     if glob.glob(os.path.join(src, fam + '_stats/**/*kernel_stats.csv'), recursive=True):
         shutil.copy(one(fam + '_stats/**/*kernel_stats.csv'), os.path.join(dst, '%s_%s_kernel_stats.csv' % (tag, fam)))
 
-counters, meta = {}, {}
-for sub in ('pmc_sq', 'pmc_fetch', 'pmc_write'):
-    acc, n = {}, {}
-    for row in csv.DictReader(open(one(sub + '/**/*counter_collection.csv'))):
-        if KERNEL not in row['Kernel_Name']:
+def static_info():
+    """registers / scratch of the compiled kernels (hipcc's own metadata; rocprofv3's VGPR_Count column only shows the architected
+    half of the unified register file and its LDS column only static LDS) and the dynamic LDS the launch asks for"""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import re
+    import isa_stats
+    out = {}
+    for name, lines in isa_stats.kernels(isa_stats.compile_asm('/tmp/isa_summarize')):
+        if '_step_kernel' not in name:
             continue
-        k = row['Counter_Name']
-        acc[k] = acc.get(k, 0.0) + float(row['Counter_Value']); n[k] = n.get(k, 0) + 1
-        meta = {'kernel_name': row['Kernel_Name'], 'VGPR': row['VGPR_Count'], 'AGPR': row['Accum_VGPR_Count'], 'SGPR': row['SGPR_Count'],
-                'LDS': row['LDS_Block_Size'], 'scratch': row['Scratch_Size'], 'grid': row['Grid_Size'], 'wg': row['Workgroup_Size']}
-    for k in acc:
-        counters[k] = acc[k] / n[k]
-bench = json.loads([l for l in open(os.path.join(src, 'bench.log')) if l.startswith('{')][-1])
-n_envs = bench['config']['envs_per_gpu']
-traffic = (counters['FETCH_SIZE'] + counters['WRITE_SIZE']) * 1024.0
-counters['_kernel'] = meta
-counters['_notes'] = {
-    'units': 'mean per launch of %s (%d envs, %d waves of 4 envs); SQ_*_CYCLES and SQ_ACTIVE/WAIT count quad-cycles summed over waves; '
-             'FETCH_SIZE / WRITE_SIZE in KB' % (KERNEL, n_envs, (n_envs + 3) // 4),
-    'traffic_bytes_uncorrected': traffic,
-    'traffic_note': 'MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads 1/2 of the bytes of a WIDE (16 B/lane) coalesced stream; this kernel '
-                    'issues 4- and 8-byte per-lane loads, for which the guide gives no calibration, so the raw sum is reported and the read '
-                    'side may be under-counted by up to 2x',
-    'algorithmic_bytes_per_launch': n_envs * bench['roofline']['algorithmic_bytes_per_env_step'],
-}
-json.dump(counters, open(os.path.join(dst, '%s_pmc_step_kernel_counters.json' % tag), 'w'), indent=1)
-json.dump({'kernel': KERNEL, 'n_envs': n_envs, 'fetch_kb': counters['FETCH_SIZE'], 'write_kb': counters['WRITE_SIZE'], 'traffic_bytes': traffic,
-           'source': 'profiles/%s_pmc_step_kernel_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/profile.sh)' % tag},
-          open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
-for row in csv.DictReader(open(os.path.join(dst, '%s_kernel_stats.csv' % tag))):
-    if KERNEL in row['Name']:
-        print('rocprofv3: %s  calls %s  avg %.1f us   | bench HIP events: %.1f us' % (row['Name'], row['Calls'], float(row['AverageNs']) / 1e3,
-                                                                                     bench['roofline']['kernel_avg_ms'] * 1e3))
-print('traffic %.2f MB per launch (algorithmic %.2f MB); value %.3g %s' % (traffic / 1e6, counters['_notes']['algorithmic_bytes_per_launch'] / 1e6,
-                                                                           bench['value'], bench['unit']))
+        m = {k: int(v) for k, v in re.findall(r'; (NumVgprs|NumAgprs|ScratchSize|Occupancy|codeLenInByte)[ =:]+(\d+)', '\n'.join(lines))}
+        out[name] = m
+    hdr = open(os.path.join(ROOT, 'lifelike_agility_and_play_amd', 'csrc', 'pmc_params.hpp')).read()
+    lc = int(re.search(r'LC_COUNT = (\d+)', hdr).group(1))
+    cps = int(re.search(r'#define CAND_PER_SUB (\d+)', hdr).group(1))
+    cfw = int(re.search(r'CF_WORDS = (\d+)', hdr).group(1))
+    scr = int(re.search(r'#define PMC_ROW_SCRATCH (\d+)', open(os.path.join(ROOT, 'lifelike_agility_and_play_amd', 'csrc', 'lanes.hpp')).read()).group(1))
+    lds = (lc * 4 + cps * cfw * 16 + 4 * 12) * 4
+    return out, {'pmc_step_kernel': lds, 'epmc_step_kernel': lds + 4 * scr * 4, 'sepmc_step_kernel': lds + 4 * scr * 4}
+
+
+STATIC, LDS_BYTES = static_info()
+traffic_all = {}
+for KERNEL, prefix, benchlog in (('pmc_step_kernel', '', 'bench.log'), ('epmc_step_kernel', 'epmc_', 'epmc_bench.log'), ('sepmc_step_kernel', 'sepmc_', 'sepmc_bench.log')):
+    counters, meta = {}, {}
+    if not glob.glob(os.path.join(src, prefix + 'pmc_sq/**/*counter_collection.csv'), recursive=True):
+        continue
+    for sub in ('pmc_sq', 'pmc_fetch', 'pmc_write'):
+        acc, n = {}, {}
+        for row in csv.DictReader(open(one(prefix + sub + '/**/*counter_collection.csv'))):
+            if not re.search(r'(^|[^a-z])' + KERNEL, row['Kernel_Name']):
+                continue
+            k = row['Counter_Name']
+            acc[k] = acc.get(k, 0.0) + float(row['Counter_Value']); n[k] = n.get(k, 0) + 1
+            meta = {'kernel_name': row['Kernel_Name'], 'grid': row['Grid_Size'], 'wg': row['Workgroup_Size'],
+                    'rocprofv3_columns': {'VGPR_Count': row['VGPR_Count'], 'Accum_VGPR_Count': row['Accum_VGPR_Count'], 'SGPR_Count': row['SGPR_Count'],
+                                          'LDS_Block_Size': row['LDS_Block_Size'], 'Scratch_Size': row['Scratch_Size']}}
+        for k in acc:
+            counters[k] = acc[k] / n[k]
+    bench = json.loads([l for l in open(os.path.join(src, benchlog)) if l.startswith('{')][-1])
+    occ = '1' if 'Li1E' in meta['kernel_name'] or '<1' in meta['kernel_name'] else '2'
+    st = [v for k, v in STATIC.items() if ('%d%s' % (len(KERNEL), KERNEL)) in k and ('ILi%s' % occ) in k and 'Lb1' not in k]
+    meta['compiled'] = dict(st[0], dynamic_lds_bytes=LDS_BYTES[KERNEL]) if st else None
+    traffic = (counters['FETCH_SIZE'] + counters['WRITE_SIZE']) * 1024.0
+    rl = bench['roofline']
+    algo_unit = rl.get('algorithmic_bytes_per_env_step', rl.get('algorithmic_bytes_per_robot_step'))
+    units = int(meta['grid']) // 64 * 4
+    counters['_kernel'] = meta
+    counters['_notes'] = {
+        'units': 'mean per launch of %s (%d env rows, %d waves of 4 rows); SQ_*_CYCLES and SQ_ACTIVE/WAIT count quad-cycles summed over waves; '
+                 'FETCH_SIZE / WRITE_SIZE in KB' % (KERNEL, units, units // 4),
+        'traffic_bytes_uncorrected': traffic,
+        'traffic_note': 'MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads 1/2 of the bytes of a WIDE (16 B/lane) coalesced stream; this kernel '
+                        'issues 4- and 8-byte per-lane loads, for which the guide gives no calibration, so the raw sum is reported and the read '
+                        'side may be under-counted by up to 2x',
+        'algorithmic_bytes_per_launch': units * algo_unit,
+        'instructions_per_wave': (counters['SQ_INSTS_VALU'] + counters['SQ_INSTS_SALU'] + counters['SQ_INSTS_LDS']) / counters['SQ_WAVES'],
+        'issue_slots_per_wave': counters['SQ_WAVE_CYCLES'] / counters['SQ_WAVES'],
+    }
+    json.dump(counters, open(os.path.join(dst, '%s_%s_counters.json' % (tag, KERNEL)), 'w'), indent=1)
+    traffic_all[KERNEL] = {'units_per_launch': units, 'fetch_kb': counters['FETCH_SIZE'], 'write_kb': counters['WRITE_SIZE'], 'traffic_bytes': traffic,
+                           'counters_file': 'profiles/%s_%s_counters.json' % (tag, KERNEL)}
+    statsf = os.path.join(dst, '%s_%skernel_stats.csv' % (tag, prefix))
+    for row in csv.DictReader(open(statsf)):
+        if re.search(r'(^|[^a-z])' + KERNEL, row['Name']):
+            print('rocprofv3: %s  calls %s  avg %.1f us   | bench HIP events: %.1f us' % (row['Name'], row['Calls'], float(row['AverageNs']) / 1e3, rl['kernel_avg_ms'] * 1e3))
+    print('  traffic %.2f MB per launch (algorithmic %.2f MB); %.0f instructions on %.0f issue slots per wave; value %.3g %s' % (
+        traffic / 1e6, counters['_notes']['algorithmic_bytes_per_launch'] / 1e6, counters['_notes']['instructions_per_wave'], counters['_notes']['issue_slots_per_wave'],
+        bench['value'], bench['unit']))
+traffic_all['source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/profile.sh %s), bytes per launch, uncorrected' % tag
+json.dump(traffic_all, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
