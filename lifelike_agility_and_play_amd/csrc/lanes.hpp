@@ -199,6 +199,47 @@ struct GpuLanes {
         : "+v"(q0), "+v"(q1), "+v"(q2));
     out[0] = q0; out[1] = q1; out[2] = q2;
   }
+  // ---- work split over the sub-lanes of a leg by LINK (pmc_step.hpp: sub-lane k < 3 owns link k + 1, sub-lane 3 a link of zero mass) ------
+  // suffix sums over the sub-lanes: x[k] <- x[k] + x[k+1] + x[k+2]  (sub-lane 3 must hold zero), N values at once with the DPP adds
+  // interleaved so that no DPP read follows its producer by less than two instructions
+#define LL_SUF(I_, P_) "v_add_f32_dpp %" #I_ ", %" #I_ ", %" #I_ " quad_perm:" P_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+  static LL_D void sufsum6(F* x) {
+    asm("s_nop 1\n\t"
+        LL_SUF(0, "[1,2,3,3]") LL_SUF(1, "[1,2,3,3]") LL_SUF(2, "[1,2,3,3]") LL_SUF(3, "[1,2,3,3]") LL_SUF(4, "[1,2,3,3]") LL_SUF(5, "[1,2,3,3]")
+        LL_SUF(0, "[2,3,3,3]") LL_SUF(1, "[2,3,3,3]") LL_SUF(2, "[2,3,3,3]") LL_SUF(3, "[2,3,3,3]") LL_SUF(4, "[2,3,3,3]") LL_SUF(5, "[2,3,3,3]")
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]));
+  }
+  static LL_D void sufsum4(F* x) {
+    asm("s_nop 1\n\t"
+        LL_SUF(0, "[1,2,3,3]") LL_SUF(1, "[1,2,3,3]") LL_SUF(2, "[1,2,3,3]") LL_SUF(3, "[1,2,3,3]")
+        LL_SUF(0, "[2,3,3,3]") LL_SUF(1, "[2,3,3,3]") LL_SUF(2, "[2,3,3,3]") LL_SUF(3, "[2,3,3,3]")
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+  }
+#undef LL_SUF
+  // out[i] = x[i] of sub-lane K of the own leg, six / three values at once (plain DPP moves; the leading wait states cover an x written
+  // just before the call)
+#define LL_BC(D_, S_, P_) "v_mov_b32_dpp %" #D_ ", %" #S_ " quad_perm:" P_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define LL_BC6(P_)                                                                                                       \
+    asm("s_nop 1\n\t" LL_BC(0, 6, P_) LL_BC(1, 7, P_) LL_BC(2, 8, P_) LL_BC(3, 9, P_) LL_BC(4, 10, P_) LL_BC(5, 11, P_)  \
+        : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5])                      \
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]))
+  template <int K_>
+  static LL_D void subbcast6(const F* x, F* out) {
+    if (K_ == 0) LL_BC6("[0,0,0,0]"); else if (K_ == 1) LL_BC6("[1,1,1,1]"); else if (K_ == 2) LL_BC6("[2,2,2,2]"); else LL_BC6("[3,3,3,3]");
+  }
+  // the lower triangle of a 3 x 3 matrix whose column k lives in sub-lane k as d[0..2] (row index): m11 m12 m22 m13 m23 m33 to every sub-lane
+  static LL_D void gather_tri3(const F* d, F* m) {
+    asm("s_nop 1\n\t" LL_BC(0, 6, "[0,0,0,0]") LL_BC(1, 6, "[1,1,1,1]") LL_BC(2, 7, "[1,1,1,1]") LL_BC(3, 6, "[2,2,2,2]") LL_BC(4, 7, "[2,2,2,2]") LL_BC(5, 8, "[2,2,2,2]")
+        : "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3]), "=&v"(m[4]), "=&v"(m[5])
+        : "v"(d[0]), "v"(d[1]), "v"(d[2]));
+  }
+  // x of sub-lane 0, 1, 2 of the own leg
+  static LL_D void spread3(F x, F* out) {
+    asm("s_nop 1\n\t" LL_BC(0, 3, "[0,0,0,0]") LL_BC(1, 3, "[1,1,1,1]") LL_BC(2, 3, "[2,2,2,2]")
+        : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]) : "v"(x));
+  }
+#undef LL_BC6
+#undef LL_BC
   // value of lane L of the row (env-uniform), of sub-lane K of the own leg (leg-uniform)
   template <int L_>
   static LL_D float rbcast(F x) { return LL_DPP_MOV(x, 0x150 + L_); }

@@ -142,6 +142,39 @@ struct Pmc {
     return mk3<F>(fw.x + p.x, fw.y + p.y, fw.z + p.z);
   }
 
+  // ---- link-level work is split over the sub-lanes of a leg: sub-lane k < 3 owns link k + 1 (hip, thigh, shank), sub-lane 3 a link of
+  // zero mass.  Its constants (mass, COM in the link frame, inertia about the COM) are picked once per kernel.
+  struct LinkC {
+    F m;
+    V3l com;
+    S3<F> ic;
+  };
+  static LL_HD LinkC own_link(const L& ln, const float* legc) {
+    const B s0 = ln.is_sub(0), s1 = ln.is_sub(1), s2 = ln.is_sub(2);
+    const F zero = ln.lane_f(0.0f);
+#define LL_PICK(F0, STRIDE) lm::sel(s0, ln.legc(legc, (F0)), lm::sel(s1, ln.legc(legc, (F0) + (STRIDE)), lm::sel(s2, ln.legc(legc, (F0) + 2 * (STRIDE)), zero)))
+    LinkC c;
+    c.m = LL_PICK(LC_M, 1);
+    c.com = mk3<F>(LL_PICK(LC_COM, 3), LL_PICK(LC_COM + 1, 3), LL_PICK(LC_COM + 2, 3));
+    c.ic.xx = LL_PICK(LC_IC, 6); c.ic.xy = LL_PICK(LC_IC + 1, 6); c.ic.xz = LL_PICK(LC_IC + 2, 6);
+    c.ic.yy = LL_PICK(LC_IC + 3, 6); c.ic.yz = LL_PICK(LC_IC + 4, 6); c.ic.zz = LL_PICK(LC_IC + 5, 6);
+#undef LL_PICK
+    return c;
+  }
+  // inertia of the lane's own link about the F0 origin, F0 axes (R, p: that link's frame)
+  static LL_HD RI<F> own_link_inertia(const LinkC& lk, const M3<F>& R, const V3l& p, V3l* com_out, S3<F>* icom_out) {
+    V3l c = p + mul(R, lk.com);
+    S3<F> ib = rot_sym(R, lk.ic);
+    RI<F> I;
+    I.m = lk.m;
+    I.h = scale(c, lk.m);
+    F cc = dot(c, c);
+    I.io.xx = ib.xx + lk.m * (cc - c.x * c.x); I.io.xy = ib.xy - lk.m * c.x * c.y; I.io.xz = ib.xz - lk.m * c.x * c.z;
+    I.io.yy = ib.yy + lk.m * (cc - c.y * c.y); I.io.yz = ib.yz - lk.m * c.y * c.z; I.io.zz = ib.zz + lk.m * (cc - c.z * c.z);
+    *com_out = c;
+    *icom_out = ib;
+    return I;
+  }
   // link inertia about the F0 origin, F0 axes
   static LL_HD RI<F> link_inertia(const L& ln, const float* legc, int k, const M3<F>& R, const V3l& p, V3l* com_out, S3<F>* icom_out) {
     F m = ln.legc(legc, LC_M + k);
@@ -583,12 +616,13 @@ struct Pmc {
   }
   static LL_HD void substep(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env = 0, int sidx = -1,
                             const SubstepExtra* ex = nullptr) {
-    substep_impl<false>(ln, P, bs, q, qd, tgt, env, sidx, ex);
+    substep_impl<false>(ln, P, bs, q, qd, tgt, env, sidx, ex, own_link(ln, P.legc));
   }
   // TERRAIN: contact candidates are also tested against ex->shapes, and a contact's normal is that of the shape it touches
   // PAIR: contacts with the other robot of a SEPMC arena (the neighbouring row) are found and solved too
   template <bool TERRAIN, bool PAIR = false>
-  static LL_HD void substep_impl(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env, int sidx, const SubstepExtra* ex) {
+  static LL_HD void substep_impl(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env, int sidx, const SubstepExtra* ex,
+                                 const LinkC& lk) {
 #define PMC_TSS(k) do { if (sidx == 5) PMC_TS(k); } while (0)
     const float* legc = P.legc;
     const float* bc = P.basec;
@@ -612,42 +646,70 @@ struct Pmc {
     S1.a = mk3<F>(one, zero, zero); S1.l = k.s1;
     S2.a = k.a2; S2.l = k.s2;
     S3v.a = k.a2; S3v.l = k.s3;
+    // Link-level work (inertia about the F0 origin, bias force, F = I^c S) is done ONCE per link: sub-lane k < 3 works on link k + 1
+    // (sub-lane 3 on a link of zero mass), composite quantities are suffix sums over the sub-lanes, and what every sub-lane needs
+    // afterwards (joint-space inertia, F1..F3, the leg's total bias force and inertia) is handed round with DPP moves.
+    const B sub_is0 = ln.is_sub(0), sub_is1 = ln.is_sub(1);
+    const F qd1m = lm::sel(sub_is0, zero, qd[1]), qd2m = lm::sel(lm::or_(sub_is0, sub_is1), zero, qd[2]);
     SV<F> vb = cvt6<F>(v0);
     SV<F> v1 = vb + scale(S1, qd[0]);
     SV<F> v2 = v1 + scale(S2, qd[1]);
-    SV<F> v3 = v2 + scale(S3v, qd[2]);
-    // velocity-product accelerations (frame falling with gravity, base acceleration zero)
-    SV<F> a1 = scale(crm(vb, S1), qd[0]);
-    SV<F> a2 = a1 + scale(crm(v1, S2), qd[1]);
-    SV<F> a3 = a2 + scale(crm(v2, S3v), qd[2]);
+    SV<F> vk = v1 + scale(S2, qd1m) + scale(S3v, qd2m);                      // velocity of the own link
+    // velocity-product acceleration of the own link (frame falling with gravity, base acceleration zero)
+    SV<F> ak = scale(crm(vb, S1), qd[0]) + scale(crm(v1, S2), qd1m) + scale(crm(v2, S3v), qd2m);
+    M3<F> Rk;
+    for (int i = 0; i < 9; i++) Rk.m[i] = lm::sel(sub_is0, k.R1.m[i], lm::sel(sub_is1, k.R2.m[i], k.R3.m[i]));
+    V3l pk = mk3<F>(lm::sel(sub_is0, k.p1.x, lm::sel(sub_is1, k.p2.x, k.p3.x)), lm::sel(sub_is0, k.p1.y, lm::sel(sub_is1, k.p2.y, k.p3.y)),
+                    lm::sel(sub_is0, k.p1.z, lm::sel(sub_is1, k.p2.z, k.p3.z)));
+    SV<F> Sk;                                                                 // motion axis of the own joint
+    Sk.a = mk3<F>(lm::sel(sub_is0, one, zero), lm::sel(sub_is0, zero, k.a2.y), lm::sel(sub_is0, zero, k.a2.z));
+    Sk.l = mk3<F>(lm::sel(sub_is0, k.s1.x, lm::sel(sub_is1, k.s2.x, k.s3.x)), lm::sel(sub_is0, k.s1.y, lm::sel(sub_is1, k.s2.y, k.s3.y)),
+                  lm::sel(sub_is0, k.s1.z, lm::sel(sub_is1, k.s2.z, k.s3.z)));
 
-    // --- link inertias, bias forces --------------------------------------------------------------------------
-    V3l c1, c2, c3;
-    S3<F> ic1, ic2, ic3;
-    RI<F> I1 = link_inertia(ln, legc, 0, k.R1, k.p1, &c1, &ic1);
-    RI<F> I2 = link_inertia(ln, legc, 1, k.R2, k.p2, &c2, &ic2);
-    RI<F> I3 = link_inertia(ln, legc, 2, k.R3, k.p3, &c3, &ic3);
-    SV<F> f3 = apply(I3, a3) + crf(v3, apply(I3, v3)) + scale(damping_force<F>(v3, c3, ic3, I3.m, P.link_damping), ln.lane_f(-1.0f));
-    SV<F> f2 = apply(I2, a2) + crf(v2, apply(I2, v2)) + scale(damping_force<F>(v2, c2, ic2, I2.m, P.link_damping), ln.lane_f(-1.0f));
-    SV<F> f1 = apply(I1, a1) + crf(v1, apply(I1, v1)) + scale(damping_force<F>(v1, c1, ic1, I1.m, P.link_damping), ln.lane_f(-1.0f));
-    if (ex && ex->has_push) {
-      V3l fb = scale(mul(k.R1, mk3<F>(ln.lane_f(ex->push[0]), ln.lane_f(ex->push[1]), ln.lane_f(ex->push[2]))), lm::sel(ln.is_leg(0), one, zero));
+    // --- own link: inertia, bias force ------------------------------------------------------------------------
+    V3l ck;
+    S3<F> ick;
+    RI<F> Ik = own_link_inertia(lk, Rk, pk, &ck, &ick);
+    SV<F> fk = apply(Ik, ak) + crf(vk, apply(Ik, vk)) + scale(damping_force<F>(vk, ck, ick, Ik.m, P.link_damping), ln.lane_f(-1.0f));
+    if (ex && ex->has_push) {                                                 // on the FR hip link: leg 0, sub-lane 0
+      V3l fb = scale(mul(Rk, mk3<F>(ln.lane_f(ex->push[0]), ln.lane_f(ex->push[1]), ln.lane_f(ex->push[2]))), lm::sel(lm::and_(ln.is_leg(0), sub_is0), one, zero));
       SV<F> fe;
-      fe.a = cross(c1, fb); fe.l = fb;
-      f1 = f1 + scale(fe, ln.lane_f(-1.0f));
+      fe.a = cross(ck, fb); fe.l = fb;
+      fk = fk + scale(fe, ln.lane_f(-1.0f));
     }
-    SV<F> f23 = f2 + f3;
-    SV<F> f123 = f1 + f23;
+    // force the joint of the own link carries = own + outboard links; the joint's share of it against the torque
+    F fs[6];
+    sv_to6(fk, fs);
+    L::sufsum6(fs);
+    SV<F> fsk;
+    fsk.a = mk3<F>(fs[0], fs[1], fs[2]); fsk.l = mk3<F>(fs[3], fs[4], fs[5]);
+    F tauk = lm::sel(sub_is0, tau[0], lm::sel(sub_is1, tau[1], tau[2]));
     F b[3];
-    b[0] = tau[0] - dot(S1, f123);
-    b[1] = tau[1] - dot(S2, f23);
-    b[2] = tau[2] - dot(S3v, f3);
+    L::spread3(tauk - dot(Sk, fsk), b);
+    F f123a[6];
+    L::template subbcast6<0>(fs, f123a);                                      // the leg's total, for the base
+    SV<F> f123;
+    f123.a = mk3<F>(f123a[0], f123a[1], f123a[2]); f123.l = mk3<F>(f123a[3], f123a[4], f123a[5]);
 
-    // --- composite inertias, joint-space inertia of the leg, coupling to the base ------------------------------
-    RI<F> Ic2 = add(I2, I3);
-    RI<F> Ic1 = add(I1, Ic2);
-    SV<F> F3 = apply(I3, S3v), F2 = apply(Ic2, S2), F1 = apply(Ic1, S1);
-    F m33 = dot(S3v, F3), m23 = dot(S2, F3), m13 = dot(S1, F3), m22 = dot(S2, F2), m12 = dot(S1, F2), m11 = dot(S1, F1);
+    // --- composite inertias (suffix sums), joint-space inertia of the leg, coupling to the base -----------------------
+    F ci[12] = {Ik.m, Ik.h.x, Ik.h.y, Ik.h.z, Ik.io.xx, Ik.io.xy, Ik.io.xz, Ik.io.yy, Ik.io.yz, Ik.io.zz, zero, zero};
+    L::sufsum6(ci); L::sufsum4(ci + 6);
+    RI<F> Ick;                                                                // I^c of the own joint: own link + outboard links
+    Ick.m = ci[0]; Ick.h = mk3<F>(ci[1], ci[2], ci[3]);
+    Ick.io.xx = ci[4]; Ick.io.xy = ci[5]; Ick.io.xz = ci[6]; Ick.io.yy = ci[7]; Ick.io.yz = ci[8]; Ick.io.zz = ci[9];
+    F cin[12];                                                                // I^c of the whole leg (sub-lane 0's), everywhere
+    L::template subbcast6<0>(ci, cin); L::template subbcast6<0>(ci + 6, cin + 6);
+    SV<F> Fk = apply(Ick, Sk);
+    F Fk6[6], F16[6], F26[6], F36[6];
+    sv_to6(Fk, Fk6);
+    L::template subbcast6<0>(Fk6, F16); L::template subbcast6<1>(Fk6, F26); L::template subbcast6<2>(Fk6, F36);
+    SV<F> F1, F2, F3;
+    F1.a = mk3<F>(F16[0], F16[1], F16[2]); F1.l = mk3<F>(F16[3], F16[4], F16[5]);
+    F2.a = mk3<F>(F26[0], F26[1], F26[2]); F2.l = mk3<F>(F26[3], F26[4], F26[5]);
+    F3.a = mk3<F>(F36[0], F36[1], F36[2]); F3.l = mk3<F>(F36[3], F36[4], F36[5]);
+    F dcol[3] = {dot(S1, Fk), dot(S2, Fk), dot(S3v, Fk)}, mt[6];              // column k of the joint-space inertia
+    L::gather_tri3(dcol, mt);
+    F m11 = mt[0], m12 = mt[1], m22 = mt[2], m13 = mt[3], m23 = mt[4], m33 = mt[5];
     LegFactor lf;
     lf.i11 = lm::rsqrt_(m11); lf.l11 = m11 * lf.i11;
     lf.l21 = m12 * lf.i11; lf.l31 = m13 * lf.i11;
@@ -664,7 +726,6 @@ struct Pmc {
     // --- base: S = I_base + sum I^c_leg - sum Y Y^T ; packed lower triangle, index order [wx wy wz vx vy vz] ----
     float Sb[21], Sd[6];
     {
-      F cin[12] = {Ic1.m, Ic1.h.x, Ic1.h.y, Ic1.h.z, Ic1.io.xx, Ic1.io.xy, Ic1.io.xz, Ic1.io.yy, Ic1.io.yz, Ic1.io.zz, zero, zero};
       float cs[12];
       L::qsum6(cin, cs); L::qsum6(cin + 6, cs + 6);
       float m = ln.basec(bc, BC_MASS) + cs[0];
@@ -1645,9 +1706,10 @@ struct Pmc {
       }
       ln.row_sync();
     }
+    const LinkC lk = own_link(ln, P.legc);
     for (int s = 0; s < P.n_sub; s++) {                                      // PLE:202
-      if (OBST) substep_impl<true>(ln, P, bs, q, qd, tgt, env, s, &ex);
-      else substep(ln, P, bs, q, qd, tgt, env, s);                           // PLE:204-206
+      if (OBST) substep_impl<true>(ln, P, bs, q, qd, tgt, env, s, &ex, lk);
+      else substep_impl<false>(ln, P, bs, q, qd, tgt, env, s, nullptr, lk);  // PLE:204-206
       t_loc = t;                                                             // PLE:208 motion.step(time BEFORE the increment), quirk Q2
       t += P.dt_d;                                                           // PLE:210
     PMC_TS(10 + (s < 20 ? s : 20));

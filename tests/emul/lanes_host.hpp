@@ -127,6 +127,21 @@ struct HostLanes {
   static void qsum6(const F* x, float* out) { for (int i = 0; i < 6; i++) out[i] = qsum(x[i]); }
   static void subsum3(const F* x, F* out) { for (int i = 0; i < 3; i++) out[i] = subsum(x[i]); }
   template <int L_> static float rbcast(const F& x) { return x.v[L_]; }
+  // work split over the sub-lanes by link (lanes.hpp): suffix sums over the sub-lanes (sub-lane 3 holds zero), broadcasts of a sub-lane's values
+  static void sufsum6(F* x) { for (int i = 0; i < 6; i++) sufsum1(x[i]); }
+  static void sufsum4(F* x) { for (int i = 0; i < 4; i++) sufsum1(x[i]); }
+  static void sufsum1(F& x) {
+    fN t, r;
+    static const int p1[4] = {1, 2, 3, 3}, p2[4] = {2, 3, 3, 3};
+    for (int i = 0; i < EW; i++) t.v[i] = x.v[(i & ~3) | p1[i & 3]] + x.v[i];
+    for (int i = 0; i < EW; i++) r.v[i] = t.v[(i & ~3) | p2[i & 3]] + t.v[i];
+    x = r;
+  }
+  template <int K_> static void subbcast6(const F* x, F* out) { for (int i = 0; i < 6; i++) out[i] = subbcast<K_>(x[i]); }
+  static void gather_tri3(const F* d, F* m) {
+    m[0] = subbcast<0>(d[0]); m[1] = subbcast<1>(d[0]); m[2] = subbcast<1>(d[1]); m[3] = subbcast<2>(d[0]); m[4] = subbcast<2>(d[1]); m[5] = subbcast<2>(d[2]);
+  }
+  static void spread3(const F& x, F* out) { out[0] = subbcast<0>(x); out[1] = subbcast<1>(x); out[2] = subbcast<2>(x); }
   template <int K_> static F subbcast(const F& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = x.v[(i & ~3) | K_]; return r; }
   template <int LEG_> static float bcast(const F& x) { return x.v[4 * LEG_]; }
   template <int L_> static void fmac_rbcast(F& acc, const F& x, const F& k) { for (int i = 0; i < EW; i++) acc.v[i] = acc.v[i] + x.v[L_] * k.v[i]; }

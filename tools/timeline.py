@@ -45,4 +45,21 @@ d = (occ[-1] - occ[0]) / (len(raw) - 1) / 10.0
 print('active 4-turn blocks per substep (wave level): contact %.2f of 4, limit %.2f of 3' % (d[:, 0].mean(), d[:, 1].mean()))
 print('substeps with a self-collision row somewhere in the wave: %.1f %%' % (100.0 * ((occ_s[-1] - occ_s[0]) / (len(raw) - 1) / 10.0).mean()))
 print('resets per step: %.1f' % np.mean([d.sum() for x, d in acc]))
+# what makes a wave slow: its duration (end stamp - entry stamp of its first env) against the number of its substeps that carried a
+# self-collision row and whether one of its envs re-seeded, least squares over all (step, wave) samples
+dur, nself, rese = [], [], []
+for i in range(1, len(raw)):
+    t = raw[i] * 0.01
+    w = (t[:, 7] - t[:, 0]).reshape(-1, 4).max(1)
+    dur.append(w); nself.append((raw[i][:, 28] - raw[i - 1][:, 28]).reshape(-1, 4).max(1)); rese.append(acc[i][1].reshape(-1, 4).any(1).astype(float))
+dur, nself, rese = np.concatenate(dur), np.concatenate(nself), np.concatenate(rese)
+A = np.stack([np.ones_like(dur), nself, rese], 1)
+coef, res, _, _ = np.linalg.lstsq(A, dur, rcond=None)
+print('wave duration (us): mean %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f' % (dur.mean(), *np.percentile(dur, [50, 90, 99]), dur.max()))
+print('  = %.1f + %.2f x (substeps with a self-collision row, mean %.1f, max %d) + %.1f x (re-seeding wave, %.1f %% of waves); residual sd %.1f' % (
+    coef[0], coef[1], nself.mean(), nself.max(), coef[2], 100 * rese.mean(), np.sqrt(np.mean((A @ coef - dur) ** 2))))
+for k in (0, 5, 10):
+    m = nself == k
+    if m.any():
+        print('  waves with %2d such substeps: %5.1f %% of waves, mean duration %.1f us' % (k, 100 * m.mean(), dur[m].mean()))
 E.close()
