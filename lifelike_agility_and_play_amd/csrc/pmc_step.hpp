@@ -108,10 +108,11 @@ struct Pmc {
 
   static LL_HD LegKin leg_fk(const L& ln, const float* legc, F q1, F q2, F q3) {
     LegKin k;
-    F c1, s1, c2, s2, c3, s3;
-    sincos_joint(ln, q1, &s1, &c1);
-    sincos_joint(ln, q2, &s2, &c2);
-    sincos_joint(ln, q2 + q3, &s3, &c3);
+    // one sine / cosine per sub-lane (hip angle, thigh angle, thigh + shank angle), handed round the leg's sub-lanes
+    F sk, ck, sv[3], cv[3];
+    sincos_joint(ln, lm::sel(ln.is_sub(0), q1, lm::sel(ln.is_sub(1), q2, q2 + q3)), &sk, &ck);
+    L::spread3(sk, sv); L::spread3(ck, cv);
+    F c1 = cv[0], s1 = sv[0], c2 = cv[1], s2 = sv[1], c3 = cv[2], s3 = sv[2];
     F zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f);
     // R1 = Rx(q1);  R2 = R1 * R(-y, q2);  R3 = R1 * R(-y, q2+q3)   (hip axis +x, thigh/shank axis -y)
     k.R1.m[0] = one; k.R1.m[1] = zero; k.R1.m[2] = zero;
