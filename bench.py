@@ -252,6 +252,8 @@ def main():
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'dtype_note': 'float32 state, dynamics and solver (SURVEY 8d counts FP32 bytes); float64 only where the reference\'s own float64 matters: '
+                          'the mocap time base and frame differences, the sampling table.  The reference computes in float64 (PyBullet)',
             'config': {'workload': 'PMC tracking env, %d parallel envs per MI355X, flat terrain, full mocap_data clip set '
                                    '(62 clips), random-policy actions N(0, e^-2), auto-reset%s' % (n, ', RCCL trajectory gather to rank 0 every %d steps' % UNROLL if world > 1 else ''),
                        'envs_per_gpu': n, 'substeps_per_step': 10, 'solver_iterations': 10,

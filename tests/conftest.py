@@ -14,6 +14,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
+POLICY_WEIGHTS = os.path.join(ROOT, 'lifelike_agility_and_play_amd', 'assets', 'pmc_policy.npz')   # the reference's trained PMC policy (tools/extract_policy.py)
 
 # test_primitive_level_env.py:18-38 / example_pmc_train.sh:67-79
 PMC_REWARD_WEIGHTS = {'joint_pos': 0.3, 'joint_vel': 0.05, 'end_effector': 0.1, 'root_pose': 0.5, 'root_vel': 0.05}

@@ -181,13 +181,13 @@ def check_contact_rich_parity(golden, orc, model_blob, table, lib_path, n_envs=1
 def check_trained_policy_tracks(lib_path, n_envs=16, n_steps=200, seed=7):
     """SURVEY.md 8f-3, the strongest available check on the UNPINNED physics: the reference's PMC policy
     (data/models/primitive_level.model, trained against PyBullet; weights extracted by tools/extract_policy.py into
-    tests/golden/pmc_policy.npz) drives our simulator closed-loop.  If our contact/articulated dynamics were not
+    lifelike_agility_and_play_amd/assets/pmc_policy.npz) drives our simulator closed-loop.  If our contact/articulated dynamics were not
     Bullet-like the policy would fall within a second; instead it tracks walk / run / jump / idle clips to the end."""
     import os
     import lifelike_agility_and_play_amd as lla
-    from conftest import GOLDEN_DIR
+    from conftest import GOLDEN_DIR, POLICY_WEIGHTS
     from oracle.pmc_policy import PmcPolicy
-    pol = PmcPolicy(os.path.join(GOLDEN_DIR, 'pmc_policy.npz'))
+    pol = PmcPolicy(POLICY_WEIGHTS)
     env = lla.create_tracking_game(arena_id='LeggedRobotTracking', data_path='', control_freq=50.0, prop_type=list(PMC_PROP_TYPE),
                                    prioritized_sample_factor=3.0, kp=50.0, kd=0.5, max_tau=18, reward_weights=dict(PMC_REWARD_WEIGHTS),
                                    num_envs=n_envs, seed=seed, auto_reset=False, lib_path=lib_path)

@@ -127,7 +127,7 @@ def main():
     from lifelike_agility_and_play_amd import mocap, urdf_model
     from oracle.pmc_policy import PmcPolicy
     import bench
-    pol = PmcPolicy(os.path.join(ROOT, 'tests', 'golden', 'pmc_policy.npz'))
+    pol = PmcPolicy(os.path.join(ROOT, 'lifelike_agility_and_play_amd', 'assets', 'pmc_policy.npz'))
     blob, table = urdf_model.default_model_blob(), mocap.load_mocap('', 0.02)
     threads = bench.effective_cores()[0]
     print('# Deviation study: the trained reference policy in our simulator, one spec constant moved at a time')

@@ -1,5 +1,5 @@
 """Extract the trained PMC policy weights (DATA: 28 float32 arrays) from the reference's pickle into
-tests/golden/pmc_policy.npz.  Build container only.  Used for the trained-policy sanity run:
+lifelike_agility_and_play_amd/assets/pmc_policy.npz.  Build container only.  Used for the trained-policy sanity run:
 the policy was trained against PyBullet, so if it tracks mocap clips in OUR simulator, our physics is Bullet-like."""
 import pickle
 import sys
@@ -31,7 +31,7 @@ class _U(pickle.Unpickler):
 
 if __name__ == '__main__':
     src = sys.argv[1] if len(sys.argv) > 1 else '/root/reference/data/models/primitive_level.model'
-    dst = sys.argv[2] if len(sys.argv) > 2 else 'tests/golden/pmc_policy.npz'
+    dst = sys.argv[2] if len(sys.argv) > 2 else 'lifelike_agility_and_play_amd/assets/pmc_policy.npz'
     m = _U(open(src, 'rb')).load().model
     assert len(m) == 28
     np.savez_compressed(dst, **{'w%02d' % i: np.asarray(a, dtype=np.float32) for i, a in enumerate(m)})
