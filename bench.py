@@ -245,7 +245,10 @@ def main():
     if rank == 0:
         total_env_steps = world * n * args.steps
         value = total_env_steps / elapsed
-        achieved = (n * ALGO_BYTES_PER_ENV_STEP) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+        # with the unroll recorded for the gather (N > 1) a step also writes its 224-float row (obs the policy acted on, action,
+        # neglogp, R, V, r, mask) -- stated and added to the algorithmic bytes
+        algo_bytes = ALGO_BYTES_PER_ENV_STEP + (4 * int(traj.buf.shape[-1]) if traj is not None else 0)
+        achieved = (n * algo_bytes) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
         traffic, issue, tsrc = committed_counters('pmc_step_kernel', n)
         out = {
             'metric': 'env-steps/sec (whole node), PMC tracking env, random policy',
@@ -265,7 +268,7 @@ def main():
                          'frac': (achieved / HBM_PEAK_GBPS) if achieved else None, 'traffic': traffic, 'peak_measured_triad': triad,
                          'traffic_source': tsrc,
                          'kernel': 'pmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
-                         'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP, 'single_wave_issue': issue,
+                         'algorithmic_bytes_per_env_step': algo_bytes, 'single_wave_issue': issue,
                          'note': 'bound by single-wave instruction issue, not HBM (about 7.7e4 instructions per wave per step, four envs, vs 2.5 KB per env); see DESIGN.md 5.1'},
         }
         if world == 1 and not args.no_cpu_baseline:
