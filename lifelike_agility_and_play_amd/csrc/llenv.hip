@@ -27,7 +27,16 @@
   } while (0)
 
 typedef Pmc<GpuLanes> K;
-typedef GpuLanesPinned<LC_COUNT> GpuLanes1;                   // EPMC / SEPMC at one wave per SIMD: the per-leg table in registers
+typedef GpuLanesPinned<LC_COUNT> GpuLanes1;                   // the per-leg table in registers (the PMC kernel's variant below pins more)
+// EPMC / SEPMC at one wave per SIMD read their tables from LDS: with terrain, rays and (SEPMC) pair rows on top of the substep the
+// registers are needed for the state -- pinned, the SEPMC kernel spilled 224 B per lane to scratch (45 MB of HBM traffic per launch
+// against 22.5 MB algorithmic); A/B on one box: SEPMC 0.326 -> 0.320 ms, EPMC 0.298 -> 0.296 ms
+#ifndef LL_PIN_EPMC
+#define LL_PIN_EPMC 0
+#endif
+#ifndef LL_PIN_SEPMC
+#define LL_PIN_SEPMC 0
+#endif
 #ifndef LL_PIN_PMC
 #define LL_PIN_PMC 1
 #endif
@@ -141,7 +150,7 @@ template <int OCC>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, EpmcParams E) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
-  typedef typename std::conditional<OCC == 1, GpuLanes1, GpuLanes>::type Lanes;
+  typedef typename std::conditional<OCC == 1 && LL_PIN_EPMC, GpuLanes1, GpuLanes>::type Lanes;
   Lanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
   if (env >= P.n_envs) return;
@@ -165,7 +174,7 @@ template <int OCC>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P, SepmcParams S) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int row = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
-  typedef typename std::conditional<OCC == 1, GpuLanes1, GpuLanes>::type Lanes;
+  typedef typename std::conditional<OCC == 1 && LL_PIN_SEPMC, GpuLanes1, GpuLanes>::type Lanes;
   Lanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
   if (row >= P.n_envs) return;
