@@ -600,7 +600,6 @@ struct Epmc {
       ex.box_mu_scale = E.box_friction / E.plane_friction;
     }
     float* ptrace = E.push_trace + (long)env * P.n_sub * 4;
-    const typename K::LinkC lk = K::own_link(ln, P.legc);
     for (int s = 0; s < P.n_sub; s++) {                                          // PGE:326-331
       ex.has_push = false;
       if (E.push_enabled) {                                                      // PR:56-86, counted in substeps
@@ -618,7 +617,7 @@ struct Epmc {
         ptrace[s * 4 + 0] = ex.has_push ? 1.0f : 0.0f;
         for (int i = 0; i < 3; i++) ptrace[s * 4 + 1 + i] = ex.has_push ? ex.push[i] : 0.0f;
       }
-      if (!E.scr_state) K::template substep_impl<true>(ln, P, bs, q, qd, tgt, env, s, &ex, lk);   // PGE:328-330
+      if (!E.scr_state) K::template substep_impl<true>(ln, P, bs, q, qd, tgt, env, s, &ex, nullptr);   // PGE:328-330
     }
     if (E.scr_state) {   // parity hook: the caller plays PyBullet
       const float* ss = E.scr_state + (long)env * 37;

@@ -88,6 +88,7 @@ struct GpuLanes {
   int row_scratch_;     // LDS word where the per-row scratch areas start
   mutable unsigned long long tm_[16];
 
+  static constexpr bool kHoldLink = false;   // pmc_step.hpp own_link: re-read the own-link constants every substep
   LL_D GpuLanes(float* lds) : leg_((threadIdx.x >> 2) & 3), sub_(threadIdx.x & 3), lane16_(threadIdx.x & 15), lds_(lds), cbase_(0), tbase_(0) {}
 
   // Stage the constant tables in LDS: legc [n_leg_fields][4] then candc [n_cand_words][16].  A constant then costs one
@@ -441,14 +442,16 @@ struct GpuLanes {
 // every substep.  For the occupancy-1 build only: with one wavefront per SIMD nothing hides an LDS round trip (measured:
 // a quarter of the kernel's cycles sat in s_waitcnt on constant reads), while 256 AGPRs lie idle as spill space -- the
 // register allocator parks the table there and a use costs one v_accvgpr_read instead of a ds_read plus its latency.
-template <int N_LEG_FIELDS, int PIN_CANDS = 0, int N_BASE = 0>
+template <int N_LEG_FIELDS, int PIN_CANDS = 0, int N_BASE = 0, int LKB = 0>   // LKB > 0: the ten own-link words at candidate-table word LKB are held too
 struct GpuLanesPinned : GpuLanes {
   float lc_[N_LEG_FIELDS];
+  float lkp_[LKB > 0 ? 10 : 1];
   // PIN_CANDS > 0 (the PMC step kernel, which has the registers to spare): the fields of the lane's first PIN_CANDS contact candidates
   // that the per-substep candidate loop reads (A, ax, r, link: 8 of the 12 words) and the base constants are held too.  Measured
   // before: 40 s_waitcnt lgkmcnt per substep, each a few instructions behind its ds_read -- an LDS round trip nobody hides.
   float cc_[PIN_CANDS > 0 ? PIN_CANDS * 8 : 1];
   float bcr_[N_BASE > 0 ? N_BASE : 1];
+  static constexpr bool kHoldLink = true;    // ... or hold them in registers across the substep loop (the occupancy-1 PMC kernel)
   LL_D GpuLanesPinned(float* lds) : GpuLanes(lds) {}
   LL_D void stage_consts(const float* legc, int n_leg_fields, const float* candc, int n_cand_words, const float* basec = nullptr) {
     GpuLanes::stage_consts(legc, n_leg_fields, candc, n_cand_words);
@@ -461,9 +464,14 @@ struct GpuLanesPinned : GpuLanes {
     }
     LL_UNROLL
     for (int i = 0; i < N_BASE; i++) bcr_[i] = basec[i];
+    if (LKB > 0) {
+      LL_UNROLL
+      for (int i = 0; i < 10; i++) lkp_[i] = lds_[tbase_ + (LKB + i) * PMC_ROW];
+    }
   }
   LL_D F legc(const float*, int field) const { return lc_[field]; }
   LL_D F candc(int word) const {
+    if (LKB > 0 && word >= LKB) return lkp_[word - LKB];
     const int j = word / 12, f = word % 12;
     if (j < PIN_CANDS && (f < 6 || f == 9 || f == 10)) return cc_[j * 8 + (f < 6 ? f : f - 3)];
     return lds_[tbase_ + word * PMC_ROW];

@@ -40,7 +40,7 @@ typedef GpuLanesPinned<LC_COUNT> GpuLanes1;                   // the per-leg tab
 #ifndef LL_PIN_PMC
 #define LL_PIN_PMC 1
 #endif
-typedef GpuLanesPinned<LC_COUNT, LL_PIN_PMC ? 7 : 0, LL_PIN_PMC ? BC_COUNT : 0> GpuLanesPmc1;  // PMC at one wave per SIMD: candidate fields and base constants too
+typedef GpuLanesPinned<LC_COUNT, LL_PIN_PMC ? 7 : 0, LL_PIN_PMC ? BC_COUNT : 0, LL_PIN_PMC ? LK_BASE : 0> GpuLanesPmc1;  // PMC at one wave per SIMD: candidate fields and base constants too
 
 // PLE:235-240 for the batch, by one wavefront: fold the statistics published by finished episodes into the per-clip table
 // (lane = clip, 64 per pass), then rebuild p ~ (1 - avg_reward_sum)^factor and its inclusive CDF.  Called by the last

@@ -40,7 +40,11 @@ enum LegConst {
 //   sphere: A = centre, ax = 0;  box vertex: A = vertex, r = 0;  cylinder cap: A = cap centre, ax = axis
 enum CandField { CF_A = 0, CF_AX = 3, CF_FB = 6, CF_R = 9, CF_LINK = 10, CF_KIND = 11, CF_WORDS = 12 };
 #define CAND_PER_SUB 8   // 7 on flat ground (PMC); the eighth, a sphere on the link's axis, only matters against terrain (TERRAIN builds)
-#define CAND_TABLE_WORDS (CAND_PER_SUB * CF_WORDS)
+// ... followed by LK_WORDS words per lane: the constants of the link the sub-lane owns in the dynamics (sub-lane k < 3: link k + 1 of the
+// leg -- mass, COM in the link frame, inertia about the COM xx xy xz yy yz zz; sub-lane 3: zeros)
+#define LK_BASE (CAND_PER_SUB * CF_WORDS)
+#define LK_WORDS 10
+#define CAND_TABLE_WORDS (CAND_PER_SUB * CF_WORDS + LK_WORDS)
 
 // ---- base constant table (quad-uniform) ----------------------------------------------------------------
 enum BaseConst {

@@ -144,13 +144,17 @@ struct Pmc {
   }
 
   // ---- link-level work is split over the sub-lanes of a leg: sub-lane k < 3 owns link k + 1 (hip, thigh, shank), sub-lane 3 a link of
-  // zero mass.  Its constants (mass, COM in the link frame, inertia about the COM) are picked once per kernel.
+  // zero mass.  Its constants (mass, COM in the link frame, inertia about the COM) are ten words of the lane's own column of the
+  // candidate table (pmc_params.hpp LK_BASE): registers in the occupancy-1 PMC build, LDS reads elsewhere.
   struct LinkC {
     F m;
     V3l com;
     S3<F> ic;
   };
-  static LL_HD LinkC own_link(const L& ln, const float* legc) {
+  // the same constants picked from the per-leg table by sub-lane: for callers that hold them in registers across the substep loop.
+  // Which of the two is faster is a matter of register pressure, measured per kernel (A/B on one box): the occupancy-1 PMC kernel and both
+  // SEPMC kernels are 1 - 7 % faster holding them, the occupancy-2 PMC and EPMC kernels 1 - 10 % faster re-reading the table every substep.
+  static LL_HD LinkC own_link_held(const L& ln, const float* legc) {
     const B s0 = ln.is_sub(0), s1 = ln.is_sub(1), s2 = ln.is_sub(2);
     const F zero = ln.lane_f(0.0f);
 #define LL_PICK(F0, STRIDE) lm::sel(s0, ln.legc(legc, (F0)), lm::sel(s1, ln.legc(legc, (F0) + (STRIDE)), lm::sel(s2, ln.legc(legc, (F0) + 2 * (STRIDE)), zero)))
@@ -160,6 +164,14 @@ struct Pmc {
     c.ic.xx = LL_PICK(LC_IC, 6); c.ic.xy = LL_PICK(LC_IC + 1, 6); c.ic.xz = LL_PICK(LC_IC + 2, 6);
     c.ic.yy = LL_PICK(LC_IC + 3, 6); c.ic.yz = LL_PICK(LC_IC + 4, 6); c.ic.zz = LL_PICK(LC_IC + 5, 6);
 #undef LL_PICK
+    return c;
+  }
+  static LL_HD LinkC own_link(const L& ln) {
+    LinkC c;
+    c.m = ln.candc(LK_BASE);
+    c.com = mk3<F>(ln.candc(LK_BASE + 1), ln.candc(LK_BASE + 2), ln.candc(LK_BASE + 3));
+    c.ic.xx = ln.candc(LK_BASE + 4); c.ic.xy = ln.candc(LK_BASE + 5); c.ic.xz = ln.candc(LK_BASE + 6);
+    c.ic.yy = ln.candc(LK_BASE + 7); c.ic.yz = ln.candc(LK_BASE + 8); c.ic.zz = ln.candc(LK_BASE + 9);
     return c;
   }
   // inertia of the lane's own link about the F0 origin, F0 axes (R, p: that link's frame)
@@ -617,13 +629,13 @@ struct Pmc {
   }
   static LL_HD void substep(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env = 0, int sidx = -1,
                             const SubstepExtra* ex = nullptr) {
-    substep_impl<false>(ln, P, bs, q, qd, tgt, env, sidx, ex, own_link(ln, P.legc));
+    substep_impl<false>(ln, P, bs, q, qd, tgt, env, sidx, ex, nullptr);
   }
   // TERRAIN: contact candidates are also tested against ex->shapes, and a contact's normal is that of the shape it touches
   // PAIR: contacts with the other robot of a SEPMC arena (the neighbouring row) are found and solved too
   template <bool TERRAIN, bool PAIR = false>
   static LL_HD void substep_impl(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env, int sidx, const SubstepExtra* ex,
-                                 const LinkC& lk) {
+                                 const LinkC* held) {   // held: the own-link constants if the caller keeps them in registers, or null
 #define PMC_TSS(k) do { if (sidx == 5) PMC_TS(k); } while (0)
     const float* legc = P.legc;
     const float* bc = P.basec;
@@ -670,6 +682,7 @@ struct Pmc {
     // --- own link: inertia, bias force ------------------------------------------------------------------------
     V3l ck;
     S3<F> ick;
+    const LinkC lk = held ? *held : own_link(ln);
     RI<F> Ik = own_link_inertia(lk, Rk, pk, &ck, &ick);
     SV<F> fk = apply(Ik, ak) + crf(vk, apply(Ik, vk)) + scale(damping_force<F>(vk, ck, ick, Ik.m, P.link_damping), ln.lane_f(-1.0f));
     if (ex && ex->has_push) {                                                 // on the FR hip link: leg 0, sub-lane 0
@@ -1707,10 +1720,12 @@ struct Pmc {
       }
       ln.row_sync();
     }
-    const LinkC lk = own_link(ln, P.legc);
+    LinkC lkh;
+    const LinkC* held = nullptr;
+    if (L::kHoldLink) { lkh = own_link_held(ln, P.legc); held = &lkh; }
     for (int s = 0; s < P.n_sub; s++) {                                      // PLE:202
-      if (OBST) substep_impl<true>(ln, P, bs, q, qd, tgt, env, s, &ex, lk);
-      else substep_impl<false>(ln, P, bs, q, qd, tgt, env, s, nullptr, lk);  // PLE:204-206
+      if (OBST) substep_impl<true>(ln, P, bs, q, qd, tgt, env, s, &ex, held);
+      else substep_impl<false>(ln, P, bs, q, qd, tgt, env, s, nullptr, held);   // PLE:204-206
       t_loc = t;                                                             // PLE:208 motion.step(time BEFORE the increment), quirk Q2
       t += P.dt_d;                                                           // PLE:210
     PMC_TS(10 + (s < 20 ? s : 20));

@@ -192,6 +192,14 @@ static inline std::string pmc_build_cand_table(const double* blob, std::vector<f
       const double z3[3] = {0, 0, 0};
       pmc_put_cand(t, L0 + 3, 6, z3, nullptr, nullptr, 0.0, -1, 0);
     }
+    // the link each sub-lane owns in the dynamics (pmc_step.hpp own_link): LK_WORDS constants per lane
+    for (int sub = 0; sub < 3; sub++) {
+      const int i = l * 3 + sub;
+      const double* I = blob + LLM_OFF_LINK_INERTIA + 9 * i;
+      const double v[LK_WORDS] = {blob[LLM_OFF_LINK_MASS + i], blob[LLM_OFF_LINK_COM + 3 * i], blob[LLM_OFF_LINK_COM + 3 * i + 1], blob[LLM_OFF_LINK_COM + 3 * i + 2],
+                                  I[0], I[1], I[2], I[4], I[5], I[8]};
+      for (int w = 0; w < LK_WORDS; w++) t[(LK_BASE + w) * 16 + L0 + sub] = (float)v[w];
+    }
     // candidate 7 (terrain only): a sphere of the capsule radius at 1/3 and 2/3 of the shank axis (subs 0, 1) and of the
     // thigh axis (subs 2, 3) -- what meets a hurdle or step edge between the end points of a link
     {

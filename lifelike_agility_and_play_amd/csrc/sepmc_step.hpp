@@ -396,7 +396,7 @@ struct Sepmc {
       ex.box_mu_scale = E.box_friction / E.plane_friction;
     }
     float* ptrace = E.push_trace + (long)row * P.n_sub * 4;
-    const typename K::LinkC lk = K::own_link(ln, P.legc);
+    const typename K::LinkC lkh = K::own_link_held(ln, P.legc);                    // (held in registers: faster in both SEPMC kernels)
     for (int s = 0; s < P.n_sub; s++) {                                          // CTG:383-388
       ex.has_push = false;
       if (E.push_enabled) {                                                      // PR:56-86, the legged_robots branch :78-86
@@ -418,7 +418,7 @@ struct Sepmc {
         for (int i = 0; i < 3; i++) ptrace[s * 4 + 1 + i] = ex.has_push ? ex.push[i] : 0.0f;
       }
       ex.want_touch = s == P.n_sub - 1;
-      if (!E.scr_state) K::template substep_impl<true, true>(ln, P, bs, q, qd, tgt, row, s, &ex, lk);
+      if (!E.scr_state) K::template substep_impl<true, true>(ln, P, bs, q, qd, tgt, row, s, &ex, &lkh);
     }
     if (E.scr_state) {   // parity hook: the caller plays PyBullet
       const float* ss = E.scr_state + (long)row * 37;

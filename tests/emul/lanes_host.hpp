@@ -83,6 +83,7 @@ struct PairLink {
 };
 
 struct HostLanes {
+  static constexpr bool kHoldLink = false;
   typedef fN F;
   typedef iN I;
   typedef dN D;
