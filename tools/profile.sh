@@ -24,7 +24,7 @@ if [ -f tools/_build/libllenv_abl.so ]; then
 fi
 # 5. the neighbours of the path: EPMC / SEPMC (bench line, kernel stats, the same PMC passes, sweeps) and the closed actor loop with the trained policy
 for W in epmc sepmc; do
-  python bench.py --workload $W --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/${W}_bench.log 2>$OUT/${W}_bench.err
+  python bench.py --workload $W > $OUT/${W}_bench.log 2>$OUT/${W}_bench.err      # the default run, CPU baseline leg included
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${W}_stats -- python bench.py --workload $W --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2>&1
   SW="python bench.py --workload $W --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline"
   rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/${W}_pmc_sq -- $SW > /dev/null 2>&1
