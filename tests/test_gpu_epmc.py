@@ -1,4 +1,5 @@
 """EPMC on the MI355X: the HIP library (through the C ABI of include/llenv_epmc.h) against the reference goldens and the oracle."""
+import numpy as np
 import pytest
 
 import epmc_parity_common as ec
@@ -40,3 +41,34 @@ def test_trunk_on_edges_against_oracle():
 
 def test_free_running_against_the_oracle_env_gpu():
     print(ec.check_free_running_against_oracle_env(None))
+
+
+def test_both_register_budgets_compute_the_same():
+    """epmc_step_kernel<1> (batches up to 4096 envs: what the oracle parity tests run) against epmc_step_kernel<2> (larger batches): same seed
+    -> same terrain, friction, pushes per env; every env, every step within the oracle bars, re-synchronised after each control step."""
+    from parity_common import quat_align
+    n_small, n_big = 64, 4096 + 128
+    cfg = ec.env_config(3)
+    cfg['env_randomize_config']['disturb_force_config'] = {'start_time': 0.0, 'interval_time': 1.0, 'duration_time': 0.5, 'horizontal_force': [10, 50], 'vertical_force': [0, 10]}
+    A = ec.make_engine(cfg, n_small, None, seed=9)
+    B = ec.make_engine(cfg, n_big, None, seed=9)
+    A.reset(); B.reset()
+    ra_, ca = A.statics(); rb_, cb = B.statics()
+    assert np.array_equal(ca, cb[:n_small]) and np.array_equal(ra_, rb_[:n_small])                 # the same terrain
+    assert np.array_equal(A.state(), B.state()[:n_small])
+    rng = np.random.default_rng(4)
+    worst_c = worst_v = 0.0
+    for t in range(30):
+        act = (rng.normal(size=(n_big, 12)) * 0.2).astype(np.float32)
+        A.step_host(act[:n_small]); B.step_host(act)
+        sa, sb_all = A.state().astype(np.float64), B.state()
+        sb = sb_all[:n_small].astype(np.float64)
+        err = np.abs(np.stack([quat_align(sb[i], sa[i]) for i in range(n_small)]) - sa)
+        worst_c = max(worst_c, err[:, 0:7].max(), err[:, 13:25].max())
+        worst_v = max(worst_v, (np.maximum(err[:, 7:13].max(1), err[:, 25:37].max(1)) / (1.0 + np.abs(sa[:, 25:37]).max(1))).max())
+        np.testing.assert_allclose(A.reward_done()[0], B.reward_done()[0][:n_small], atol=5e-5)
+        np.testing.assert_allclose(A.obs()[:, -778:], B.obs()[:n_small, -778:], atol=2e-3)         # the rays see the same terrain from (nearly) the same pose
+        sb_all[:n_small] = A.state()
+        B.set_state(sb_all)
+    assert worst_c < 1e-4 and worst_v < 1e-3, (worst_c, worst_v)
+    A.close(); B.close()

@@ -59,3 +59,33 @@ def test_zero_copy_torch_views_gpu():
     live = ~np.repeat(E.reward_done()[1], 2)
     np.testing.assert_allclose(T['obs'][:, 123:135].cpu().numpy()[live], a.cpu().numpy()[live], rtol=1e-6)      # the newest action frame of prop_a
     E.close()
+
+
+def test_both_register_budgets_compute_the_same_gpu():
+    """sepmc_step_kernel<1> (up to 2048 arenas: what the oracle parity tests run) against sepmc_step_kernel<2> (larger batches): same seed ->
+    same arena, spawn poses and pushes per arena; every robot, every step within the oracle bars, re-synchronised after each control step."""
+    from parity_common import quat_align
+    n_small, n_big = 32, 2048 + 64
+    cfg = SC.env_config(SC.ALL_ELEMENTS)
+    A = SC.make_engine(cfg, n_small, None, seed=6)
+    B = SC.make_engine(cfg, n_big, None, seed=6)
+    A.reset(); B.reset()
+    sa0, sb0 = A.state(), B.state()
+    rows = sa0.reshape(-1, 37).shape[0]
+    assert np.array_equal(sa0.reshape(-1, 37), sb0.reshape(-1, 37)[:rows])                          # the same spawn poses
+    rng = np.random.default_rng(8)
+    worst_c = worst_v = 0.0
+    for t in range(30):
+        act = (rng.normal(size=B.obs().shape[:-1] + (12,)) * 0.2).astype(np.float32)
+        A.step_host(act.reshape(-1, 12)[:rows].reshape(A.obs().shape[:-1] + (12,))); B.step_host(act)
+        sa = A.state().reshape(-1, 37).astype(np.float64)
+        sb_all = B.state()
+        sb = sb_all.reshape(-1, 37)[:rows].astype(np.float64)
+        err = np.abs(np.stack([quat_align(sb[i], sa[i]) for i in range(rows)]) - sa)
+        worst_c = max(worst_c, err[:, 0:7].max(), err[:, 13:25].max())
+        worst_v = max(worst_v, (np.maximum(err[:, 7:13].max(1), err[:, 25:37].max(1)) / (1.0 + np.abs(sa[:, 25:37]).max(1))).max())
+        flat = sb_all.reshape(-1, 37)
+        flat[:rows] = A.state().reshape(-1, 37)
+        B.set_state(flat.reshape(sb_all.shape))
+    assert worst_c < 1e-4 and worst_v < 1e-3, (worst_c, worst_v)
+    A.close(); B.close()
