@@ -42,7 +42,8 @@ def static_info():
     cps = int(re.search(r'#define CAND_PER_SUB (\d+)', hdr).group(1))
     cfw = int(re.search(r'CF_WORDS = (\d+)', hdr).group(1))
     scr = int(re.search(r'#define PMC_ROW_SCRATCH (\d+)', open(os.path.join(ROOT, 'lifelike_agility_and_play_amd', 'csrc', 'lanes.hpp')).read()).group(1))
-    lds = (lc * 4 + cps * cfw * 16 + 4 * 12) * 4
+    lkw = int(re.search(r'#define LK_WORDS (\d+)', hdr).group(1))
+    lds = (lc * 4 + (cps * cfw + lkw) * 16 + 4 * 12) * 4
     return out, {'pmc_step_kernel': lds, 'epmc_step_kernel': lds + 4 * scr * 4, 'sepmc_step_kernel': lds + 4 * scr * 4}
 
 
