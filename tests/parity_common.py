@@ -62,7 +62,7 @@ def check_reset_against_goldens(golden, model_blob, table, lib_path):
     E.close()
 
 
-def run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True, sigma=SIGMA):
+def run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True, sigma=SIGMA, policy=None):
     """Step engine and oracle side by side from golden (clip, t0) starts with the same random actions.
     With resync the oracle is re-seeded with the engine's float32 state after every control step, so every step
     is an independent single-control-step comparison."""
@@ -79,7 +79,10 @@ def run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed
     prev_obs = None
     alive = np.ones(n_envs, bool)
     for t in range(n_steps):
-        act = (rng.normal(size=(n_envs, 12)) * sigma).astype(np.float32)
+        if policy is None:
+            act = (rng.normal(size=(n_envs, 12)) * sigma).astype(np.float32)
+        else:                                # the trained policy's mean action on the engine's own observation: the tracking-gait regime
+            act = policy.act(E.obs().astype(np.float64)).astype(np.float32)
         E.step_host(act)
         eo, (er, ed, ew), es, ek = E.obs(), E.reward_done(), E.state(), E.ref_state()
         efd, efk = E.feet()
@@ -128,6 +131,23 @@ def check_single_step_parity(golden, orc, model_blob, table, lib_path, n_envs=32
     assert st['obs_vel'].max() < 10 * PHYS_STEP_TOL
     assert st['reward'].max() < PHYS_STEP_TOL
     assert st['feet'].max() < PHYS_STEP_TOL
+    assert st['done_mismatch'] <= max(1, st['done'] // 10)
+    return st
+
+
+def check_policy_driven_parity(golden, orc, model_blob, table, lib_path, n_envs=32, n_steps=40, seed=5):
+    """The same single-control-step comparison in the regime the env is built for: actions of the reference's trained policy (walking,
+    running, jumping gaits: feet make and break contact, little else touches), 40 steps per env, oracle re-synchronised after every step."""
+    from conftest import POLICY_WEIGHTS
+    from oracle.pmc_policy import PmcPolicy
+    st = run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True, policy=PmcPolicy(POLICY_WEIGHTS))
+    assert len(st['config']) > n_envs * n_steps * 0.7                                # the policy keeps most episodes alive
+    assert st['config'].max() < PHYS_STEP_TOL, np.percentile(st['config'], [50, 90, 99, 100])
+    v = np.asarray(st['vel']).reshape(-1)
+    # every sample within 1e-3 relative; a gait's joint rates are a few rad/s, so the same absolute error weighs more against (1 + max rate)
+    # than in the flailing runs: up to 3 % of the samples may exceed 1e-4 (measured: p99 = 1.0e-4, max 1.5e-4)
+    assert (v > PHYS_STEP_TOL).sum() <= max(1, 3 * len(v) // 100) and v.max() < 10 * PHYS_STEP_TOL, np.percentile(v, [50, 90, 99, 100])
+    assert st['reward'].max() < PHYS_STEP_TOL and st['feet'].max() < PHYS_STEP_TOL
     assert st['done_mismatch'] <= max(1, st['done'] // 10)
     return st
 

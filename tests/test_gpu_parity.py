@@ -35,6 +35,11 @@ def test_single_control_step_parity(golden, orc, model_blob, mocap_table):
     print('config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
 
 
+def test_policy_driven_parity(golden, orc, model_blob, mocap_table):
+    st = pc.check_policy_driven_parity(golden, orc, model_blob, mocap_table, None, n_envs=48)
+    print('policy-driven: config err 50/99/max', np.percentile(st['config'], [50, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 99, 100]))
+
+
 def test_partial_wave_and_odd_batch_sizes(golden, orc, model_blob, mocap_table):
     for n in (1, 5, 17):
         st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, None, n_envs=n, n_steps=3, seed=n)

@@ -29,6 +29,11 @@ def test_single_control_step_parity(golden, orc, model_blob, mocap_table, emul_l
     print('config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
 
 
+def test_policy_driven_parity(golden, orc, model_blob, mocap_table, emul_lib):
+    st = pc.check_policy_driven_parity(golden, orc, model_blob, mocap_table, emul_lib, n_envs=16)
+    print('policy-driven: config err 50/99/max', np.percentile(st['config'], [50, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 99, 100]))
+
+
 def test_contact_rich_parity(golden, orc, model_blob, mocap_table, emul_lib):
     out = pc.check_contact_rich_parity(golden, orc, model_blob, mocap_table, emul_lib)
     print('contact-rich: config err', np.percentile(out['config'], [50, 100]), 'vel', np.percentile(out['vel'], [50, 100]))
