@@ -35,6 +35,10 @@ def test_single_control_step_parity(golden, orc, model_blob, mocap_table):
     print('config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
 
 
+def test_free_running_episode_statistics(golden, orc, model_blob, mocap_table):
+    print(pc.check_rollout_statistics(golden, orc, model_blob, mocap_table, None, n_envs=512))
+
+
 def test_policy_driven_parity(golden, orc, model_blob, mocap_table):
     st = pc.check_policy_driven_parity(golden, orc, model_blob, mocap_table, None, n_envs=48)
     print('policy-driven: config err 50/99/max', np.percentile(st['config'], [50, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 99, 100]))

@@ -29,6 +29,10 @@ def test_single_control_step_parity(golden, orc, model_blob, mocap_table, emul_l
     print('config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
 
 
+def test_free_running_episode_statistics(golden, orc, model_blob, mocap_table, emul_lib):
+    print(pc.check_rollout_statistics(golden, orc, model_blob, mocap_table, emul_lib, n_envs=64))
+
+
 def test_policy_driven_parity(golden, orc, model_blob, mocap_table, emul_lib):
     st = pc.check_policy_driven_parity(golden, orc, model_blob, mocap_table, emul_lib, n_envs=16)
     print('policy-driven: config err 50/99/max', np.percentile(st['config'], [50, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 99, 100]))
