@@ -1,6 +1,7 @@
 """bench.py -- env-steps/sec of the PMC tracking-env hot path on N MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 300 --warmup 30
+    python bench.py --gpus N --steps K --warmup W          (no launcher: bench.py starts its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -32,6 +33,7 @@ SIGMA = math.exp(-2.0)
 ALGO_BYTES_PER_ENV_STEP = 2552          # SURVEY.md 8(d) / DESIGN.md "algorithmic bytes"
 HBM_PEAK_GBPS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s spec
 UNROLL = 128                            # example_pmc_train.sh:145 unroll_length
+STEPS_PER_LAUNCH = 32                   # control steps per launch of the random-policy loop (ll_step_random_n); divides UNROLL
 GAMMA, LAMBDA = 0.95, 0.95              # example_pmc_train.sh:21-22
 
 PMC_REWARD_WEIGHTS = {'joint_pos': 0.3, 'joint_vel': 0.05, 'end_effector': 0.1, 'root_pose': 0.5, 'root_vel': 0.05}
@@ -119,6 +121,22 @@ def committed_counters(kernel, units):
         return None, None, None
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command line, one per GPU, the way the driver's
+    explicit launch line does (torch.distributed.run, rendezvous on 127.0.0.1, a free port), and pass rank 0's ONE JSON line through."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('OMP_NUM_THREADS', '1')                  # what torchrun would set (with a warning) anyway
+    sys.stdout.flush()
+    rc = subprocess.call(cmd, env=env)                      # the ranks inherit stdout: rank 0 prints the line
+    if rc != 0:
+        raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -129,7 +147,15 @@ def main():
     ap.add_argument('--workload', choices=['pmc', 'epmc', 'sepmc'], default='pmc',
                     help="pmc = BASELINE config 2 (the contract line); epmc = config 4 (PlayGroundEnv, DESIGN.md 8), sepmc = config 5 (ChaseTagGameEnv, 2048 arenas x 2 robots, DESIGN.md 8b), same JSON shape")
     ap.add_argument('--element', type=int, default=1, help='epmc only: env_randomize_config element_id (0 joystick, 1 hurdles, 2 holes, 3 cubes)')
+    ap.add_argument('--steps-per-launch', type=int, default=STEPS_PER_LAUNCH,
+                    help='pmc: control steps per kernel launch (ll_step_random_n; the random policy needs nothing from the host between two '
+                         'steps).  1 = one launch per control step (ll_step_random).  Must divide the unroll length %d when N > 1' % UNROLL)
+    ap.add_argument('--gather-mode', choices=['async', 'blocking', 'none'], default='async',
+                    help='N > 1 only: async = the double-buffered gather overlapping the next unroll (the contract line); blocking = every '
+                         'gather is waited for before the next step (A/B leg: what the overlap buys); none = no gather (A/B leg: the steps alone)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args.gpus)
     if args.workload == 'epmc':
         return main_epmc(args)
     if args.workload == 'sepmc':
@@ -143,8 +169,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        raise SystemExit('bench.py --gpus %d inside a %d-rank launch' % (args.gpus, world))
     tc = torch.cuda.is_available()      # torch is plumbing (streams, RCCL): a single-GPU run goes on without it if only torch fails to see the device
     if not tc and world > 1:
         raise SystemExit('bench.py --gpus > 1 needs torch.cuda for the RCCL gather')
@@ -155,9 +180,16 @@ def main():
         local_rank = 0
     if tc:
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    # LL_BENCH_FORCE_GATHER=1 (test hook): the N > 1 control flow -- process group, unroll recording, gather, MAX over ranks -- with a
+    # ONE-rank communicator, so that RCCL itself (backend "nccl") executes on a 1-GPU box
+    multi = world > 1 or bool(os.environ.get('LL_BENCH_FORCE_GATHER'))
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        if 'MASTER_PORT' not in os.environ:
+            import socket
+            s_ = socket.socket(); s_.bind(('127.0.0.1', 0)); os.environ['MASTER_PORT'] = str(s_.getsockname()[1]); s_.close()
+        kw = {'device_id': torch.device('cuda', local_rank)} if backend == 'nccl' else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     def dev_sync():
         eng.sync()
@@ -174,43 +206,63 @@ def main():
     if tc:
         gather.bind_torch_stream(eng)                  # step kernels, torch ops and the RCCL gather are ordered on one stream
     eng.reset()
-    traj = gather.TrajectoryBuffer(eng, UNROLL) if world > 1 else None
+    traj = gather.TrajectoryBuffer(eng, UNROLL, mode=args.gather_mode) if multi else None
+    if traj is not None:
+        traj.prepare(0)                                    # rank 0's world x 470 MB receive buffers exist before anything is timed
 
     n_done = [0]                                           # control steps executed so far == the engine's step index
+    spl = max(1, args.steps_per_launch)
+    if traj is not None and UNROLL % spl:
+        raise SystemExit('--steps-per-launch must divide the unroll length %d' % UNROLL)
 
-    def one_step(_):
-        eng.step_random(SIGMA)                             # ONE launch: draws a ~ N(0, sigma^2) on device and steps
-        n_done[0] += 1
-        if traj is not None and n_done[0] % UNROLL == 0:   # the step kernel itself records the rows (ll_enable_unrolls);
-            k = n_done[0] // UNROLL - 1
-            traj.finish(k, GAMMA, LAMBDA)                  # TD(lambda) returns of the finished unroll (one small kernel, same stream)
-            traj.gather_async(k, 0)                        # the gather of this unroll overlaps with the next unroll's steps
+    def run_steps(count):
+        """`count` control steps of the random-policy loop: launches of up to `spl` steps each (ll_step_random_n draws a ~ N(0, sigma^2)
+        on device and steps, `spl` times per launch), cut at unroll boundaries, where the finished unroll is handed to the gather."""
+        left = count
+        while left > 0:
+            k = min(spl, left, UNROLL - n_done[0] % UNROLL) if traj is not None else min(spl, left)
+            if k == 1:
+                eng.step_random(SIGMA)
+            else:
+                eng.step_random_n(SIGMA, k)
+            n_done[0] += k
+            left -= k
+            if traj is not None and n_done[0] % UNROLL == 0:   # the step kernel itself records the rows (ll_enable_unrolls);
+                u = n_done[0] // UNROLL - 1
+                traj.finish(u, GAMMA, LAMBDA)                  # TD(lambda) returns of the finished unroll (one small kernel, same stream)
+                if args.gather_mode != 'none':
+                    traj.gather_async(u, 0)                    # the gather of this unroll overlaps with the next unroll's steps
 
-    for t in range(args.warmup):
-        one_step(t)
+    run_steps(args.warmup)
     if traj is not None:
         traj.wait()
-    if world > 1:
+        traj.stall_ms(); traj.host_stall_s = 0.0             # stall accounting covers the timed region only
+    if multi:
         dist.barrier()
     dev_sync()
     eng.enable_kernel_timing(True)
     t0 = time.perf_counter()
-    for t in range(args.steps):
-        one_step(t)
+    run_steps(args.steps)
     if traj is not None:
         traj.wait()                                          # an in-flight gather belongs to the timed region
     dev_sync()
-    if world > 1:
+    if multi:
         dist.barrier()
     dev_sync()
     elapsed = time.perf_counter() - t0
-    k_ms, k_n = eng.kernel_time_ms()
+    k_launch_ms, k_n, k_steps = eng.kernel_time_stats()      # HIP events on the launch stream: average per launch, launches, control steps
+    k_ms = k_launch_ms * k_n / k_steps if k_steps else 0.0     # ... per control step
     eng.enable_kernel_timing(False)
     gather_check = None
-    if world > 1:
-        tt = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+    gather_stats = None
+    if multi:
+        # how long the step kernels stood still behind a gather (events around the stream-side wait) and how long the host was blocked,
+        # inside the timed region; MAX over ranks like the elapsed time
+        tt = torch.tensor([elapsed, traj.stall_ms(), traj.host_stall_s * 1e3], device='cuda', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = float(tt[0].item())
+        gather_stats = {'mode': args.gather_mode, 'backend': backend, 'stream_stall_ms_total': float(tt[1].item()), 'host_blocked_ms_total': float(tt[2].item()),
+                        'bytes_per_rank_per_unroll': int(traj.buf[0].numel() * 4)}
         if os.environ.get('LL_BENCH_VERIFY') and traj.n_gathered > 0:
             # what rank 0 received for the last gathered unroll == what each rank's engine holds in that block (float64 checksums + probes)
             k_last = traj.n_gathered - 1
@@ -259,16 +311,22 @@ def main():
             'dtype_note': 'float32 state, dynamics and solver (SURVEY 8d counts FP32 bytes); float64 only where the reference\'s own float64 matters: '
                           'the mocap time base and frame differences, the sampling table.  The reference computes in float64 (PyBullet)',
             'config': {'workload': 'PMC tracking env, %d parallel envs per MI355X, flat terrain, full mocap_data clip set '
-                                   '(62 clips), random-policy actions N(0, e^-2), auto-reset%s' % (n, ', RCCL trajectory gather to rank 0 every %d steps' % UNROLL if world > 1 else ''),
+                                   '(62 clips), random-policy actions N(0, e^-2), auto-reset%s' % (n, ', RCCL trajectory gather to rank 0 every %d steps' % UNROLL if multi else ''),
                        'envs_per_gpu': n, 'substeps_per_step': 10, 'solver_iterations': 10,
+                       'steps_per_launch': spl,
+                       'steps_per_launch_note': 'the timed region runs ll_step_random_n: %d control steps of the random-policy loop per kernel launch '
+                                                '(every step is complete: physics, mocap, obs, reward, termination, re-seed, unroll row); '
+                                                '--steps-per-launch 1 is one launch per control step' % spl,
                        'episodes_finished_rank0': counters['episodes'], 'nonfinite_resets_rank0': counters['nonfinite'],
                        'mean_episode_length_steps_rank0': (counters['env_steps'] / counters['episodes']) if counters['episodes'] else None,
                        'episode_length_histogram_rank0': {'bucket_lower_edges_steps': [1 << b for b in range(16)], 'episodes': ep_hist},
-                       **({'unrolls_gathered': traj.n_gathered, 'unroll_row_floats': int(traj.buf.shape[-1]), 'gather_check': gather_check} if traj is not None else {})},
+                       **({'unrolls_gathered': traj.n_gathered, 'unroll_row_floats': int(traj.buf.shape[-1]), 'gather_check': gather_check,
+                           'gather': gather_stats} if traj is not None else {})},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBPS) if achieved else None, 'traffic': traffic, 'peak_measured_triad': triad,
                          'traffic_source': tsrc,
                          'kernel': 'pmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
+                         'kernel_avg_launch_ms': k_launch_ms, 'control_steps_per_launch': (k_steps / k_n) if k_n else None,
                          'algorithmic_bytes_per_env_step': algo_bytes, 'single_wave_issue': issue,
                          'note': 'bound by single-wave instruction issue, not HBM (about 7.7e4 instructions per wave per step, four envs, vs 2.5 KB per env); see DESIGN.md 5.1'},
         }
@@ -276,7 +334,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(blob, table)
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LL_ABI_VERSION 1
+#define LL_ABI_VERSION 2   /* 2: ll_enable_trajectory -> ll_enable_unrolls (round 2); ll_step_random_n, ll_unroll_position, ll_pg_mark_current, ll_kernel_time_stats */
 
 /* per-env sizes (PLE:101-124) */
 #define LL_N_JOINTS 12
@@ -124,8 +124,10 @@ int ll_load_mocap_f64(ll_engine* e, const double* h_frames, const int32_t* h_cli
  * Jump obstacles (only used when ll_config.set_obstacle != 0): replaces utils/obstacle.py:6-33 as consumed at
  * PLE:173-193 (_create_obstacle) and PLE:262-268 (_update_obstacle).  h_count[n_clips] obstacles per clip,
  * h_table[sum(count)][4] = x, y, yaw, peak time (float64).  The box is 0.05 x 1.0 x 2*obstacle_height, centred on the
- * ground (PLE:184-193).  The engine uses it for the termination test of PLE:341-346 only (any robot shape within the
- * contact distance of the box ends the episode); see DESIGN.md for the missing physical response.
+ * ground (PLE:184-193, createMultiBody with mass 0).  The box is a collision body during the substeps of a set_obstacle engine
+ * (pmc_step_kernel<OCC, true>: the robot is decelerated by it in the very step that touches it) and the termination test of
+ * PLE:341-346: any robot shape within the contact distance of the box, where it stood during the substeps, ends the episode
+ * (LL_DONE_COLLISION).  DESIGN.md 4 "Jump obstacle".
  */
 int ll_load_obstacles(ll_engine* e, const int32_t* h_count, const double* h_table, int n_clips);
 
@@ -185,6 +187,17 @@ int ll_fill_random_actions(ll_engine* e, float sigma);
  * Philox stream itself, records the actions in the engine's action buffer and applies them.  Stands for the reference
  * actor's random-policy loop (`env.step(np.random.randn(12) * sigma)`, learning/actors: SURVEY 8d). */
 int ll_step_random(ll_engine* e, float sigma);
+/*
+ * n_steps iterations of that loop -- `for _ in range(n_steps): env.step(np.random.randn(12) * sigma)` for every env -- as ONE launch.
+ * The random policy needs nothing from the host between two steps, so every wavefront walks its own environments through the n_steps
+ * control steps without waiting for the others: no launch gap, and a slow step of one wavefront (self-collision rows, a re-seed) is
+ * not a slow step of the whole chip.  Same Philox streams, same per-step outputs in the unroll buffers (ll_enable_unrolls) as n_steps
+ * calls of ll_step_random; the obs / reward / done buffers hold the LAST step's values.  One difference, stated: the prioritized
+ * sampling table (PLE:235-240) is folded once per launch, by its last workgroup, in the order one actor would have seen the episodes
+ * end (later step first, then higher env) -- episodes that re-seed inside the launch sample from the table as it stood when the launch
+ * began.  With prioritized_sample_factor = 0 (uniform sampling) the result is bit-identical to n_steps single-step calls.
+ */
+int ll_step_random_n(ll_engine* e, float sigma, int n_steps);
 
 /* Block until all queued work on the engine's stream has finished. */
 int ll_sync(ll_engine* e);
@@ -224,15 +237,26 @@ int ll_device_ptrs(ll_engine* e, ll_device_ptrs_t* out);
  *                                                         ll_finish_unroll
  *     r, 1 - done                                          what ll_finish_unroll computes R from
  * row_floats = obs_dim + 17.  The buffer is owned by the engine.
+ * Unroll 0 starts with the first control step AFTER this call (whatever ran before: warm-up, scripted steps, an earlier phase); unroll k
+ * lives in block k % n_buffers and is complete when ll_unroll_position reports unroll_index = k + 1, time_step = 0.
  */
 int ll_enable_unrolls(ll_engine* e, int unroll_length, int n_buffers, float** d_base, int* row_floats);
+/* Where the NEXT control step writes: the index of its unroll (counted from ll_enable_unrolls) and its time step inside it. */
+int ll_unroll_position(ll_engine* e, int64_t* unroll_index, int* time_step);
 /* Device buffers [n_envs] in which a policy leaves -log p(a|obs) and V(obs) for the actions it wrote into the action buffer. */
 int ll_pg_ptrs(ll_engine* e, float** d_neglogp, float** d_value);
+/* Tell the engine that those buffers now hold the policy's outputs for the CURRENT observation (the one the next ll_step acts on).
+ * A caller that fills them (ll_policy_act_pg on the engine's stream) calls this right after; ll_finish_unroll uses the stamp to refuse a
+ * stale bootstrap value. */
+int ll_pg_mark_current(ll_engine* e);
 /*
  * TD(lambda) returns of block `buffer` (what the actor of a PPO learner computes before it pushes an unroll; gamma, lam:
  * example_pmc_train.sh:21-22): delta_t = r_t + gamma V_{t+1} m_t - V_t, A_t = delta_t + gamma lam m_t A_{t+1}, R_t = A_t + V_t with
  * m_t = 1 - done_t and V_T = d_bootstrap_value[env] (NULL: the engine's value buffer, i.e. the policy's estimate for the
- * observation that follows the block).  Asynchronous on the engine's stream.
+ * observation that follows the block).  Call order with NULL: step the block's last step, evaluate the policy on the NEW observation
+ * (ll_policy_act_pg + ll_pg_mark_current), then ll_finish_unroll -- right after the step the value buffer still holds V(obs_{T-1}).
+ * Once ll_pg_mark_current has ever been called, a NULL bootstrap whose stamp is not the current step fails with LL_ESTATE (a buffer nobody
+ * ever marked holds zeros: the random-policy benchmark).  Asynchronous on the engine's stream.
  */
 int ll_finish_unroll(ll_engine* e, int buffer, float gamma, float lam, const float* d_bootstrap_value);
 
@@ -265,6 +289,8 @@ int ll_get_episode_histogram(ll_engine* e, uint64_t* counts16);
 /* Average device time (ms) of the step kernel over the launches since the last call, measured with
  * HIP events on the engine's own stream (bench.py roofline leg); also returns the launch count. */
 int ll_kernel_time_ms(ll_engine* e, double* avg_ms, int* n_launches);
+/* The same, plus the number of control steps those launches executed (ll_step_random_n launches run several). */
+int ll_kernel_time_stats(ll_engine* e, double* avg_launch_ms, int* n_launches, int64_t* n_control_steps);
 int ll_enable_kernel_timing(ll_engine* e, int on);
 
 #ifdef __cplusplus

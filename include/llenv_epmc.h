@@ -35,7 +35,7 @@ extern "C" {
 #define LLE_DONE_NONFINITE 16
 
 typedef struct ll_epmc_config {
-  int32_t abi_version; /* 1 */
+  int32_t abi_version; /* LL_ABI_VERSION (llenv.h) */
   int32_t n_envs;
   int32_t device;
   int32_t auto_reset;      /* 1: a finished env is re-seeded inside the step kernel; 0: reference semantics */

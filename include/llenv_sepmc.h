@@ -41,7 +41,7 @@ extern "C" {
 #define LLS_BODY_ROBOT1 4
 
 typedef struct ll_sepmc_config {
-  int32_t abi_version; /* 1 */
+  int32_t abi_version; /* LL_ABI_VERSION (llenv.h) */
   int32_t n_arenas;
   int32_t device;
   int32_t auto_reset;

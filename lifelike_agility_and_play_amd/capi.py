@@ -55,7 +55,7 @@ def make_config(n_envs, control_freq=25.0, sim_freq=500.0, kp=50.0, kd=1.0, max_
     if not isinstance(prop_type, (list, tuple)):
         raise TypeError("Expected 'prop_type' to be a list.")                     # PLE:113
     cfg = LLConfig()
-    cfg.abi_version = 1
+    cfg.abi_version = LL_ABI_VERSION
     cfg.n_envs, cfg.device, cfg.auto_reset = int(n_envs), int(device), int(auto_reset)
     cfg.control_freq, cfg.sim_freq, cfg.kp, cfg.kd = float(control_freq), float(sim_freq), float(kp), float(kd)
     cfg.max_tau, cfg.foot_lateral_friction = float(max_tau), float(foot_lateral_friction)
@@ -74,6 +74,8 @@ def make_config(n_envs, control_freq=25.0, sim_freq=500.0, kp=50.0, kd=1.0, max_
     return cfg
 
 
+LL_ABI_VERSION = 2          # include/llenv.h; checked against the library in load_library
+
 _SIGS = {
     'll_last_error': (C.c_char_p, []),
     'll_abi_version': (C.c_int, []),
@@ -91,10 +93,13 @@ _SIGS = {
     'll_get_spec_param': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     'll_fill_random_actions': (C.c_int, [C.c_void_p, C.c_float]),
     'll_step_random': (C.c_int, [C.c_void_p, C.c_float]),
+    'll_step_random_n': (C.c_int, [C.c_void_p, C.c_float, C.c_int]),
     'll_sync': (C.c_int, [C.c_void_p]),
     'll_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_enable_unrolls': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     'll_pg_ptrs': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    'll_pg_mark_current': (C.c_int, [C.c_void_p]),
+    'll_unroll_position': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     'll_finish_unroll': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     'll_device_ptrs': (C.c_int, [C.c_void_p, C.POINTER(LLDevicePtrs)]),
     'll_get_obs': (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -112,6 +117,7 @@ _SIGS = {
     'll_get_episode_histogram': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_kernel_time_ms': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'll_enable_kernel_timing': (C.c_int, [C.c_void_p, C.c_int]),
+    'll_kernel_time_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
 }
 EXPORTED_SYMBOLS = sorted(_SIGS)
 
@@ -128,6 +134,8 @@ def load_library(path=None):
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)           # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, args
+        if lib.ll_abi_version() != LL_ABI_VERSION:
+            raise ImportError('%s speaks ABI version %d, this binding %d: rebuild the library (__graft_entry__.build())' % (path, lib.ll_abi_version(), LL_ABI_VERSION))
         _libs[path] = lib
     return _libs[path]
 
@@ -229,6 +237,10 @@ class Engine(object):
         """fill_random_actions(sigma) + step() as one kernel launch."""
         self._chk(self.lib.ll_step_random(self.h, float(sigma)))
 
+    def step_random_n(self, sigma, n_steps):
+        """n_steps iterations of the random-policy loop in ONE launch (ll_step_random_n)."""
+        self._chk(self.lib.ll_step_random_n(self.h, float(sigma), int(n_steps)))
+
     def sync(self):
         self._chk(self.lib.ll_sync(self.h))
 
@@ -250,6 +262,16 @@ class Engine(object):
         a, b = C.c_void_p(), C.c_void_p()
         self._chk(self.lib.ll_pg_ptrs(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def pg_mark_current(self):
+        """the pg buffers now hold the policy's outputs for the current observation (ll_pg_mark_current)"""
+        self._chk(self.lib.ll_pg_mark_current(self.h))
+
+    def unroll_position(self):
+        """-> (index of the unroll the next step writes into, its time step there)"""
+        k, t = C.c_int64(), C.c_int()
+        self._chk(self.lib.ll_unroll_position(self.h, C.byref(k), C.byref(t)))
+        return k.value, t.value
 
     def finish_unroll(self, buffer, gamma, lam, d_bootstrap_value=None):
         self._chk(self.lib.ll_finish_unroll(self.h, int(buffer), float(gamma), float(lam), C.c_void_p(int(d_bootstrap_value)) if d_bootstrap_value else None))
@@ -331,3 +353,9 @@ class Engine(object):
         ms, n = C.c_double(), C.c_int()
         self._chk(self.lib.ll_kernel_time_ms(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def kernel_time_stats(self):
+        """-> (average ms per launch, launches, control steps those launches ran)"""
+        ms, n, st = C.c_double(), C.c_int(), C.c_int64()
+        self._chk(self.lib.ll_kernel_time_stats(self.h, C.byref(ms), C.byref(n), C.byref(st)))
+        return ms.value, n.value, st.value

@@ -34,7 +34,7 @@ struct EpmcEngine {
   }
 
   EpmcEngine(const ll_epmc_config& c, const double* blob, int blob_len, const double* init37) : base(base_config(c), blob, blob_len), cfg(c) {
-    if (c.abi_version != 1) throw PmcError(LL_EINVAL, "ll_epmc_config.abi_version mismatch");
+    if (c.abi_version != LL_ABI_VERSION) throw PmcError(LL_EINVAL, "ll_epmc_config.abi_version mismatch");
     if (c.element_id < 0 || c.element_id > 3) throw PmcError(LL_EINVAL, "Unknown element id.");                 // BSE:249-250
     if (c.max_steps <= 0 || c.cmd_vary_freq_range[0] <= 0 || c.cmd_vary_freq_range[1] <= c.cmd_vary_freq_range[0])
       throw PmcError(LL_EINVAL, "bad max_steps / cmd_vary_freq_range");

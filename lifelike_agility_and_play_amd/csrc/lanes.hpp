@@ -105,6 +105,9 @@ struct GpuLanes {
   }
   // make the table offsets opaque again so the compiler re-reads constants per substep instead of hoisting them all
   LL_D void refresh_consts() const { asm volatile("" : "+v"(cbase_), "+v"(tbase_)); }
+  // top of a control step inside a multi-step launch: nothing computed from the tables in one step may be carried to the next in
+  // registers (the compiler would hoist every step-invariant value out of the step loop and spill the state instead)
+  LL_D void new_step() { asm volatile("" : "+v"(cbase_), "+v"(tbase_), "+v"(leg_), "+v"(sub_), "+v"(lane16_) : : "memory"); }
 
   LL_D I leg() const { return leg_; }
   LL_D I sub() const { return sub_; }

@@ -87,9 +87,10 @@ __device__ __forceinline__ void table_fold_wave(const StepParams& P) {
 }
 
 // The synthetic random policy a ~ N(0, sigma^2): Philox4x32-10 keyed on (seed; group of four actions, step) + Box-Muller.
-__device__ __forceinline__ float4 random_action_group(const StepParams& P, uint32_t gid, float sigma) {
+__device__ __forceinline__ float4 random_action_group(const StepParams& P, uint32_t gid, float sigma, int sl = 0) {
   uint32_t r[4];
-  philox4x32(gid, (uint32_t)P.step_count, (uint32_t)(P.step_count >> 32), 0xAC710u, (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r);
+  const uint64_t step = P.step_count + (uint64_t)sl;
+  philox4x32(gid, (uint32_t)step, (uint32_t)(step >> 32), 0xAC710u, (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r);
   const float k = 2.3283064365386963e-10f;   // 2^-32
   float u1 = fminf(((float)r[0] + 1.0f) * k, 1.0f), u2 = (float)r[1] * k, u3 = fminf(((float)r[2] + 1.0f) * k, 1.0f), u4 = (float)r[3] * k;
   float m1 = sqrtf(-2.0f * logf(u1)), m2 = sqrtf(-2.0f * logf(u3));
@@ -106,29 +107,38 @@ template <int OCC, bool OBST = false>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int row = threadIdx.x >> 4;                                         // one env = one 16-lane DPP row
-  const int env = blockIdx.x * PMC_ENVS_PER_WAVE + row;
+  const int env0 = blockIdx.x * PMC_ENVS_PER_WAVE + row;
   typedef typename std::conditional<OCC == 1, GpuLanesPmc1, GpuLanes>::type Lanes;
   Lanes ln(lds);
   if constexpr (OCC == 1) ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS, P.basec);   // all 64 lanes copy, also those without an env
   else ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
-  if (env < P.n_envs) {
-    float act[3];
-    if (P.action_sigma > 0.0f) {
-      // lanes 0..2 of the row draw the env's three groups of four actions, record them, and hand them to the leg lanes via LDS
-      float* stash = lds + LC_COUNT * 4 + CAND_TABLE_WORDS * PMC_ROW + row * 12;
-      const int l16 = threadIdx.x & 15;
-      const uint32_t g = (uint32_t)(l16 < 3 ? l16 : 0);
-      const float4 o = random_action_group(P, (uint32_t)env * 3u + g, P.action_sigma);
-      if (l16 < 3) {
-        reinterpret_cast<float4*>(P.actions_out)[(long)env * 3 + l16] = o;
-        reinterpret_cast<float4*>(stash)[l16] = o;
+  // ll_step_random_n: n_steps control steps back to back.  A wave walks its four envs through them on its own -- no other wave is waited
+  // for, so a slow step of one wave (leg-leg rows, a re-seed) is not a slow step of the whole chip -- and between two steps it only has
+  // to see its own stores (state, obs row, bookkeeping: workgroup-scope fence = wait for the wave's outstanding memory operations).
+  for (int sl = 0; sl < P.n_steps; sl++) {
+    if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    ln.new_step();
+    int env = env0;
+    asm volatile("" : "+v"(env));      // ... and no address of the step's ~150 loads and stores either (they all derive from env)
+    if (env < P.n_envs) {
+      float act[3];
+      if (P.action_sigma > 0.0f) {
+        // lanes 0..2 of the row draw the env's three groups of four actions, record them, and hand them to the leg lanes via LDS
+        float* stash = lds + LC_COUNT * 4 + CAND_TABLE_WORDS * PMC_ROW + row * 12;
+        const int l16 = threadIdx.x & 15;
+        const uint32_t g = (uint32_t)(l16 < 3 ? l16 : 0);
+        const float4 o = random_action_group(P, (uint32_t)env * 3u + g, P.action_sigma, sl);
+        if (l16 < 3) {
+          reinterpret_cast<float4*>(P.actions_out)[(long)env * 3 + l16] = o;
+          reinterpret_cast<float4*>(stash)[l16] = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the row's LDS writes have landed (one wave)
+        for (int j = 0; j < 3; j++) act[j] = stash[ln.leg() * 3 + j];
+      } else {
+        for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the row's LDS writes have landed (one wave)
-      for (int j = 0; j < 3; j++) act[j] = stash[ln.leg() * 3 + j];
-    } else {
-      for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
+      Pmc<Lanes>::template step_env<OBST>(ln, P, env, act, sl);
     }
-    Pmc<Lanes>::template step_env<OBST>(ln, P, env, act);
   }
   // The last workgroup to get here folds this step's finished episodes into the sampling table.  The statistics travel by
   // device-scope atomics only (publish_max), so no cache write-back is needed -- a __threadfence() here would flush this
@@ -248,6 +258,7 @@ struct HipBackend {
   bool timing = false;
   int simds = 1024;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+  std::vector<int> ev_steps;                             // control steps of each timed launch (ll_step_random_n: more than one)
   size_t ev_used = 0;
   static constexpr size_t kMaxTimedLaunches = 16384;   // event pairs kept between two ll_kernel_time_ms() polls
 
@@ -293,7 +304,7 @@ struct HipBackend {
 
   static size_t lds_bytes() { return ((size_t)LC_COUNT * 4 + (size_t)CAND_TABLE_WORDS * PMC_ROW + PMC_ENVS_PER_WAVE * 12) * sizeof(float); }
   static size_t lds_bytes_epmc() { return lds_bytes() + (size_t)PMC_ENVS_PER_WAVE * PMC_ROW_SCRATCH * sizeof(float); }
-  std::pair<hipEvent_t, hipEvent_t>* timing_begin() {
+  std::pair<hipEvent_t, hipEvent_t>* timing_begin(int n_steps = 1) {
     if (!timing) return nullptr;
     if (ev_used == kMaxTimedLaunches) return nullptr;   // un-polled timing does not grow without bound: later launches go untimed
     if (ev_used == evs.size()) {
@@ -301,7 +312,9 @@ struct HipBackend {
       HIPCHK(hipEventCreate(&a));
       HIPCHK(hipEventCreate(&b));
       evs.push_back(std::make_pair(a, b));
+      ev_steps.push_back(1);
     }
+    ev_steps[ev_used] = n_steps;
     std::pair<hipEvent_t, hipEvent_t>* ev = &evs[ev_used++];
     HIPCHK(hipEventRecord(ev->first, stream));
     return ev;
@@ -339,7 +352,7 @@ struct HipBackend {
   void launch_step(const StepParams& P) {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
-    std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin();
+    std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
     if (P.set_obstacle) {
       if (blocks <= simds) hipLaunchKernelGGL((pmc_step_kernel<1, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
       else                 hipLaunchKernelGGL((pmc_step_kernel<2, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
@@ -373,16 +386,19 @@ struct HipBackend {
     HIPCHK(hipGetLastError());
   }
   void enable_timing(bool on) { timing = on; }
-  void collect_timing(double* avg_ms, int* n) {
+  void collect_timing(double* avg_ms, int* n, long long* n_steps = nullptr) {
     sync();
     double tot = 0;
+    long long steps = 0;
     for (size_t i = 0; i < ev_used; i++) {
       float ms = 0;
       HIPCHK(hipEventElapsedTime(&ms, evs[i].first, evs[i].second));
       tot += ms;
+      steps += ev_steps[i];
     }
     *n = (int)ev_used;
     *avg_ms = ev_used ? tot / ev_used : 0.0;
+    if (n_steps) *n_steps = steps;
     ev_used = 0;
   }
 };

@@ -184,18 +184,27 @@ struct PmcEngine {
   // One launch: the step kernel folds the statistics of the episodes it finishes into the sampling table itself (its last
   // workgroup does, PLE:235-240), and with sigma > 0 it also draws the actions a ~ N(0, sigma^2) it then applies -- the same
   // Philox stream as fill_random_actions(), so step_random(s) == fill_random_actions(s); step(nullptr).
-  void step(const float* d_act, float sigma = 0.0f) {
+  void step(const float* d_act, float sigma = 0.0f, int n_steps = 1) {
     need(true, true);
     StepParams Q = P;
     Q.actions = d_act ? d_act : d_actions;
     Q.action_sigma = sigma;
+    Q.n_steps = n_steps;
     set_unroll_slot(Q);
     bk.launch_step(Q);
-    P.step_count += 1;
+    P.step_count += (uint64_t)n_steps;
   }
   void step_random(float sigma) {
     if (!(sigma > 0.0f)) throw PmcError(LL_EINVAL, "sigma must be positive");
     step(nullptr, sigma);
+  }
+  // n_steps control steps of the random-policy loop in ONE launch: every wave walks its envs through the steps on its own, nothing
+  // waits for the slowest wave of a step and there is no launch gap.  The sampling table is folded once, by the launch's last workgroup.
+  void step_random_n(float sigma, int n_steps) {
+    if (!(sigma > 0.0f)) throw PmcError(LL_EINVAL, "sigma must be positive");
+    if (n_steps <= 0) throw PmcError(LL_EINVAL, "n_steps must be positive");
+    if ((uint64_t)n_steps * ((uint64_t)P.n_envs + 1) >= (1ull << 32)) throw PmcError(LL_EINVAL, "n_steps x n_envs too large for the episode-order tag");
+    step(nullptr, sigma, n_steps);
   }
   // parity hook: one control step whose physics result (and optionally foot positions) is supplied by the caller -- the
   // fake-BulletClient protocol of tests/golden/gen_golden.py -- so that everything around the physics can be compared with
@@ -237,20 +246,39 @@ struct PmcEngine {
     if (d_traj) throw PmcError(LL_ESTATE, "unroll buffers already enabled");
     d_traj = dalloc<float>((size_t)n_buffers * P.n_envs * unroll * (P.obs_dim + LL_UNROLL_EXTRA));
     traj_unroll = unroll; traj_buffers = n_buffers;
+    traj_base = P.step_count;       // unroll 0 starts with the NEXT control step, whatever ran before (warm-up, a previous learner phase)
+  }
+  uint64_t traj_base = 0;
+  // index of the unroll the next control step writes into, and its time step there; unroll k lives in block k % n_buffers
+  void unroll_position(int64_t* unroll_index, int* slot) const {
+    if (!d_traj) throw PmcError(LL_ESTATE, "ll_enable_unrolls must be called first");
+    const uint64_t rel = P.step_count - traj_base;
+    *unroll_index = (int64_t)(rel / (uint64_t)traj_unroll);
+    *slot = (int)(rel % (uint64_t)traj_unroll);
   }
   void set_unroll_slot(StepParams& Q) const {
+    const uint64_t rel = P.step_count - traj_base;
     Q.traj = d_traj;
     Q.traj_unroll = traj_unroll;
-    Q.traj_slot = traj_unroll ? (int)(P.step_count % (uint64_t)traj_unroll) : 0;
-    Q.traj_buf = traj_unroll ? (int)((P.step_count / (uint64_t)traj_unroll) % (uint64_t)traj_buffers) : 0;
+    Q.traj_nbuf = traj_buffers;
+    Q.traj_slot = traj_unroll ? (int)(rel % (uint64_t)traj_unroll) : 0;
+    Q.traj_buf = traj_unroll ? (int)((rel / (uint64_t)traj_unroll) % (uint64_t)traj_buffers) : 0;
     Q.neglogp = d_neglogp; Q.value = d_value;
   }
   // TD(lambda) returns of one finished block (the actor-side post-processing of a PPO learner's data: R = GAE advantage + V):
   //   delta_t = r_t + gamma V_{t+1} m_t - V_t,  A_t = delta_t + gamma lam m_t A_{t+1},  R_t = A_t + V_t,  m_t = 1 - done_t,
   // V_T = bootstrap[env] (the value of the observation after the block's last step; masked when that step ended the episode)
+  // the control step whose observation the value buffer was last written for by ll_policy_act_pg (~0: never -- the buffer holds zeros)
+  uint64_t value_step = ~0ull;
   void finish_unroll(int buffer, float gamma, float lam, const float* d_bootstrap) {
     if (!d_traj) throw PmcError(LL_ESTATE, "ll_enable_unrolls must be called first");
     if (buffer < 0 || buffer >= traj_buffers) throw PmcError(LL_EINVAL, "buffer index out of range");
+    // V_T must be the value of the observation AFTER the block's last step.  Right after that step the engine's value buffer still holds
+    // V(obs_{T-1}), the estimate that went with the action just applied: a policy-gradient actor has to evaluate the new observation
+    // (ll_policy_act_pg) before it closes the unroll, or hand the bootstrap values over explicitly.
+    if (!d_bootstrap && value_step != ~0ull && value_step != P.step_count)
+      throw PmcError(LL_ESTATE, "ll_finish_unroll: the value buffer was written for an earlier observation; call ll_policy_act_pg on the "
+                                "observation that follows the unroll first, or pass d_bootstrap_value");
     bk.launch_gae(d_traj + (size_t)buffer * P.n_envs * traj_unroll * (P.obs_dim + LL_UNROLL_EXTRA), P.n_envs, traj_unroll, P.obs_dim + LL_UNROLL_EXTRA,
                   P.obs_dim, gamma, lam, d_bootstrap ? d_bootstrap : d_value);
   }

@@ -110,7 +110,7 @@ struct StepParams {
   // env's unroll contiguous and its time step laid out the way the reference's actor flattens it (distill_actor.py:118-162):
   //   X: future 72 | prop | prop_a 36   (the observation dict's keys in sorted order)   | A 12 | neglogp | R | V | r | 1 - done
   float* traj;
-  int32_t traj_slot, traj_buf, traj_unroll, traj_pad;
+  int32_t traj_slot, traj_buf, traj_unroll, traj_nbuf;   // slot / block of the launch's FIRST control step; a launch of n_steps walks on from there
   const float* neglogp;     // [n_envs] what the policy reported for the actions being applied (ll_pg_ptrs), copied into the unroll
   const float* value;       // [n_envs]
   // mocap
@@ -124,7 +124,8 @@ struct StepParams {
   double* avg_len;          // [n_clips] avg_episode_len
   unsigned int* block_ticket;   // workgroups of the running step kernel that have finished; the last one folds the table
   float* actions_out;       // where a step that draws its own actions (action_sigma > 0) records them, [n_envs][12]
-  float action_sigma, pad5;
+  float action_sigma;
+  int32_t n_steps;           // control steps per launch (ll_step_random_n); 1 everywhere else
   // jump obstacles (set_obstacle): per clip offset/count into ob_table[total][4] = x, y, yaw, peak time
   const int32_t* ob_off;
   const int32_t* ob_cnt;

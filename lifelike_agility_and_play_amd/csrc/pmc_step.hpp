@@ -1684,8 +1684,9 @@ struct Pmc {
   // ---------------------------------------------------------------------------------------------------
   // act_in: the env's actions, one register per joint of the lane's leg (read from P.actions or drawn by the caller)
   // OBST (set_obstacle builds): the jump obstacle of the episode is a static box the robot collides with during the substeps
+  // sl: index of this control step inside its launch (ll_step_random_n runs n_steps of them back to back; 0 otherwise)
   template <bool OBST = false>
-  static LL_HD void step_env(const L& ln, const StepParams& P, int env, const F* act_in) {
+  static LL_HD void step_env(const L& ln, const StepParams& P, int env, const F* act_in, int sl = 0) {
     const int N = P.n_envs;
     Base bs;
     F q[3], qd[3], act[3], tgt[3];
@@ -1827,7 +1828,9 @@ struct Pmc {
     //     them, the reward and the not-done mask; R is filled in by ll_finish_unroll.  Written before the obs row is replaced. ---
     if (P.traj) {
       const int W = P.obs_dim + LL_UNROLL_EXTRA, od = P.obs_dim;
-      float* tr = P.traj + ((((long)P.traj_buf * N + env) * P.traj_unroll) + P.traj_slot) * W;
+      int tslot = P.traj_slot + sl, tbuf = P.traj_buf;                        // the launch's first step writes (traj_buf, traj_slot)
+      while (tslot >= P.traj_unroll) { tslot -= P.traj_unroll; tbuf = (tbuf + 1 == P.traj_nbuf) ? 0 : tbuf + 1; }
+      float* tr = P.traj + ((((long)tbuf * N + env) * P.traj_unroll) + tslot) * W;
       LL_UNROLL
       for (int c = 0; c < TRAJ_CHUNKS; c++) ln.st16_rot(tr, 16 * c, od, od - 72, told[c]);
       for (int j = 0; j < 3; j++) ln.stl(tr, od + j, 3, act[j]);
@@ -1849,7 +1852,8 @@ struct Pmc {
     if (reason) {
       float avg_r = (float)((double)rsum / max_steps), avg_l = (float)((double)steps / (max_steps + 1.0));
       if (bad) avg_r = 0.0f;
-      unsigned long long tag = ((unsigned long long)(env + 1)) << 32;
+      // (inside a multi-step launch the later step wins, then the higher env: the order in which one actor would have seen them)
+      unsigned long long tag = ((unsigned long long)((unsigned)sl * (unsigned)(N + 1) + (unsigned)(env + 1))) << 32;
       publish_max(ln, P.pending_reward + clip, tag | (unsigned long long)f2u(avg_r));
       publish_max(ln, P.pending_len + clip, tag | (unsigned long long)f2u(avg_l));
       count_add(ln, P.counters + 1);

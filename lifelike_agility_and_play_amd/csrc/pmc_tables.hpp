@@ -229,6 +229,7 @@ static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
   if (cfg.n_envs <= 0) return "n_envs must be positive";
   if (!(cfg.control_freq > 0) || !(cfg.sim_freq > 0)) return "control_freq and sim_freq must be positive";
   memset(&P, 0, sizeof P);
+  P.n_steps = 1;
   P.n_envs = cfg.n_envs;
   P.policy_step = 1.0 / cfg.control_freq;                 // PLE:47
   P.dt_d = 1.0 / cfg.sim_freq;                            // PLE:49

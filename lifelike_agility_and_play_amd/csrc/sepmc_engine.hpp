@@ -34,7 +34,7 @@ struct SepmcEngine {
   }
 
   SepmcEngine(const ll_sepmc_config& c, const double* blob, int blob_len, const double* init37) : base(base_config(c), blob, blob_len), cfg(c) {
-    if (c.abi_version != 1) throw PmcError(LL_EINVAL, "ll_sepmc_config.abi_version mismatch");
+    if (c.abi_version != LL_ABI_VERSION) throw PmcError(LL_EINVAL, "ll_sepmc_config.abi_version mismatch");
     if (c.n_arenas <= 0 || c.max_steps <= 0) throw PmcError(LL_EINVAL, "bad n_arenas / max_steps");
     if (c.push_enabled && (c.push_interval_step <= 0 || c.push_duration_step > c.push_interval_step))
       throw PmcError(LL_EINVAL, "push schedule: duration_time <= interval_time required (PR:34)");

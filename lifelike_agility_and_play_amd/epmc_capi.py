@@ -34,7 +34,7 @@ def make_epmc_config(n_envs, env_config, auto_reset=0, seed=0, device=0, solver_
         raise TypeError("Expected 'prop_type' to be a list.")                       # PGE:122
     rc = env_config['env_randomize_config'] if 'env_randomize_config' in env_config else None
     cfg = LLEpmcConfig()
-    cfg.abi_version, cfg.n_envs, cfg.device, cfg.auto_reset = 1, int(n_envs), int(device), int(auto_reset)
+    cfg.abi_version, cfg.n_envs, cfg.device, cfg.auto_reset = capi.LL_ABI_VERSION, int(n_envs), int(device), int(auto_reset)
     cfg.control_freq = float(env_config.get('control_freq', 50.0))
     cfg.kp, cfg.kd = float(env_config.get('kp', 50.0)), float(env_config.get('kd', 1.0))
     max_tau = env_config.get('max_tau', 16.0)

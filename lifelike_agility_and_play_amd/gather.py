@@ -111,21 +111,46 @@ class TrajectoryBuffer(object):
 
     TWO blocks: while the steps of unroll k+1 fill one, the gather of unroll k (the other) is in flight on RCCL's own stream
     (``async_op``), so the collective overlaps with simulation instead of stalling it.  xGMI is point-to-point, so rank 0
-    receives over 7 different links at once."""
+    receives over 7 different links at once.
 
-    def __init__(self, engine, unroll, host_memory=False):
+    What the overlap costs is measured, not assumed: every ``wait()`` brackets the point where the engine's stream has to wait for the
+    collective with two events (``stall_ms()``: how long the step kernels actually stood still behind a gather) and counts the host time
+    spent blocked.  ``mode='blocking'`` (bench.py --gather-mode blocking) waits for every gather before the next step is launched: the
+    A/B leg that shows what the double buffer buys."""
+
+    def __init__(self, engine, unroll, host_memory=False, mode='async'):
         ptr, w = engine.enable_unrolls(unroll, 2)
         self.engine = engine
         self.unroll = unroll
+        self.mode = mode
         mk = host_tensor if host_memory else device_tensor
         self.buf = mk(ptr, (2, engine.n_envs, unroll, w))
         self.outs = None
         self.work = None
         self.last = None
         self.n_gathered = 0
+        self._stall_events = []           # (before, after) event pairs around stream-side waits
+        self.host_stall_s = 0.0           # host time spent blocked in wait()
+        self._stage = None                # gloo test path: pinned staging buffers, side stream, worker thread
+        self._thread = None
 
     def half(self, k):
         return self.buf[k % 2]
+
+    def prepare(self, dst=0, group=None):
+        """Allocate everything a gather needs BEFORE a timed region: rank `dst`'s world x block receive buffers (8 x 470 MB at
+        BASELINE config 3) and, in the gloo test configuration, the pinned staging blocks.  Idempotent."""
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        staged = self.buf.is_cuda and dist.get_backend(group) == 'gloo'
+        like = self.buf[0]
+        if staged and self._stage is None:
+            self._stage = dict(host=[torch.empty(like.shape, dtype=like.dtype, pin_memory=True) for _ in range(2)],
+                               stream=torch.cuda.Stream(), ev=[torch.cuda.Event(), torch.cuda.Event()])
+        if rank == dst and self.outs is None:
+            dev = torch.device('cpu') if staged else like.device
+            self.outs = [torch.empty(like.shape, dtype=like.dtype, device=dev) for _ in range(world)]
+            for o in self.outs:
+                o.zero_()                                   # touch the pages now, not inside the first timed gather
 
     def finish(self, k, gamma=0.95, lam=0.95):
         """TD(lambda) returns of unroll k (ll_finish_unroll), bootstrapped from the engine's value buffer: call it after the policy
@@ -133,29 +158,74 @@ class TrajectoryBuffer(object):
         self.engine.finish_unroll(k % 2, gamma, lam)
 
     def wait(self):
+        import time
+        if self._thread is not None:                        # gloo test path: the staged gather runs in a helper thread
+            t0 = time.perf_counter()
+            self._thread.join()
+            self.host_stall_s += time.perf_counter() - t0
+            self._thread = None
         if self.work is not None:
-            self.work.wait()
+            t0 = time.perf_counter()
+            if self.buf.is_cuda:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                self.work.wait()                            # RCCL: the current stream waits for the collective's stream; the host does not
+                b.record()
+                self._stall_events.append((a, b))
+            else:
+                self.work.wait()
+            self.host_stall_s += time.perf_counter() - t0
             self.work = None
+
+    def stall_ms(self):
+        """Total time the engine's stream stood still in wait() behind a gather since the last call (device side, by events)."""
+        tot = 0.0
+        for a, b in self._stall_events:
+            b.synchronize()
+            tot += a.elapsed_time(b)
+        self._stall_events = []
+        return tot
 
     def gather_async(self, k, dst=0, group=None):
         """Start gathering unroll k (the block the last `unroll` steps wrote); the previous gather must have finished."""
         self.wait()
         local = self.half(k)
         if local.is_cuda:
-            # the collective (and the .cpu() staging of the gloo test path) is ordered against torch's CURRENT stream only: the step
+            # the collective (and the staging copy of the gloo test path) is ordered against torch's CURRENT stream only: the step
             # kernels that wrote this block must be on that very stream, or the gather reads rows that are still being written
             es, ts = int(self.engine.device_ptrs().stream or 0), int(torch.cuda.current_stream().cuda_stream)
             if es != ts:
                 raise RuntimeError('TrajectoryBuffer.gather_async: the engine launches on stream %#x but torch\'s current stream is %#x; '
                                    'call gather.bind_torch_stream(engine) first' % (es, ts))
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        if local.is_cuda and dist.get_backend(group) == 'gloo':      # test configuration only: gloo gathers host tensors
-            local = local.cpu()
-        if rank == dst:
-            if self.outs is None or self.outs[0].device != local.device:
-                self.outs = [torch.empty_like(local) for _ in range(world)]
+        self.prepare(dst, group)
+        if local.is_cuda and dist.get_backend(group) == 'gloo':
+            # Test configuration only (a 1-GPU box cannot host two RCCL ranks): gloo gathers host tensors.  The block is copied to pinned
+            # memory on a side stream behind the step kernels that wrote it, and a helper thread hands it to gloo once the copy has landed,
+            # so that -- as with RCCL -- neither the host nor the engine's stream waits for the gather until the next one is due.
+            import threading
+            st = self._stage
+            host, ev = st['host'][k % 2], st['ev'][k % 2]
+            st['stream'].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st['stream']):
+                host.copy_(local, non_blocking=True)
+                ev.record()
+            outs = self.outs if rank == dst else None
+
+            def run():
+                ev.synchronize()
+                dist.gather(host, gather_list=outs, dst=dst, group=group)
+            self._thread = threading.Thread(target=run)
+            self._thread.start()
+            if rank == dst:
+                self.last = self.outs
+        elif rank == dst:
             self.work = dist.gather(local, gather_list=self.outs, dst=dst, group=group, async_op=True)
             self.last = self.outs
         else:
             self.work = dist.gather(local, gather_list=None, dst=dst, group=group, async_op=True)
         self.n_gathered += 1
+        if self.mode == 'blocking':                         # A/B leg: nothing is launched until the gather has finished
+            self.wait()
+            if local.is_cuda:
+                torch.cuda.current_stream().synchronize()

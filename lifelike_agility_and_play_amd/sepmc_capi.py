@@ -30,7 +30,7 @@ def make_sepmc_config(n_arenas, env_config, auto_reset=0, seed=0, device=0, solv
     rc = env_config.get('env_randomize_config', {})
     el = env_config.get('element_config', {}) or {}
     cfg = LLSepmcConfig()
-    cfg.abi_version, cfg.n_arenas, cfg.device, cfg.auto_reset = 1, int(n_arenas), int(device), int(auto_reset)
+    cfg.abi_version, cfg.n_arenas, cfg.device, cfg.auto_reset = capi.LL_ABI_VERSION, int(n_arenas), int(device), int(auto_reset)
     cfg.control_freq = float(env_config.get('control_freq', 25.0))
     cfg.kp, cfg.kd = float(env_config.get('kp', 50.0)), float(env_config.get('kd', 1.0))
     max_tau = env_config.get('max_tau', 18.0)

@@ -29,7 +29,7 @@ def make_config(n_envs=1, control_freq=50.0, sim_freq=500.0, kp=50.0, kd=0.5, ma
                 reward_weights=None, prop_type=None, prioritized_sample_factor=3.0, auto_reset=0, seed=0, device=0,
                 set_obstacle=False, obstacle_height=0.0, solver_iterations=10):
     cfg = LLConfig()
-    cfg.abi_version = 1
+    cfg.abi_version = 2          # include/llenv.h LL_ABI_VERSION
     cfg.n_envs, cfg.device, cfg.auto_reset = n_envs, device, auto_reset
     cfg.control_freq, cfg.sim_freq, cfg.kp, cfg.kd, cfg.max_tau = control_freq, sim_freq, kp, kd, max_tau
     cfg.foot_lateral_friction = foot_lateral_friction

@@ -26,12 +26,18 @@ struct HostBackend {
   void sync() {}
   void launch_step(const StepParams& P) {
     HostLanes ln(P.candc);
-    if (P.action_sigma > 0.0f) launch_actions(P, P.actions_out, P.action_sigma);
-    for (int env = 0; env < P.n_envs; env++) {
-      fN act[3];
-      for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
-      if (P.set_obstacle) K::step_env<true>(ln, P, env, act);
-      else K::step_env<false>(ln, P, env, act);
+    for (int sl = 0; sl < P.n_steps; sl++) {               // ll_step_random_n: the table is folded once per launch
+      if (P.action_sigma > 0.0f) {
+        StepParams Q = P;
+        Q.step_count = P.step_count + (uint64_t)sl;
+        launch_actions(Q, P.actions_out, P.action_sigma);
+      }
+      for (int env = 0; env < P.n_envs; env++) {
+        fN act[3];
+        for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
+        if (P.set_obstacle) K::step_env<true>(ln, P, env, act, sl);
+        else K::step_env<false>(ln, P, env, act, sl);
+      }
     }
     pmc_finalize_table(P, P.avg_reward, P.avg_len, P.prob, P.cdf);
   }
@@ -120,7 +126,7 @@ struct HostBackend {
     });
   }
   void enable_timing(bool) {}
-  void collect_timing(double* avg_ms, int* n) { *avg_ms = 0; *n = 0; }
+  void collect_timing(double* avg_ms, int* n, long long* steps = nullptr) { *avg_ms = 0; *n = 0; if (steps) *steps = 0; }
 };
 
 typedef PmcEngine<HostBackend> ENGINE;

@@ -353,6 +353,56 @@ def check_trajectory_ring(model_blob, table, lib_path, read_ring, write_dev=None
     assert list(g['shapes']) == [72, 99, 36, 12]
 
 
+def check_multi_step_launch(model_blob, table, lib_path, read_ring, sizes=(24,), k=7, n_launches=5):
+    """ll_step_random_n(sigma, k) == k x ll_step_random(sigma), bit for bit -- state, ghost, observation, reward, done reasons, bookkeeping,
+    counters, episode histogram, the recorded actions and every row of the unroll buffers -- in the two settings in which the one stated
+    difference (the sampling table is folded once per launch) cannot show: uniform sampling with auto-reset (factor 0: the table never
+    changes what is drawn), and prioritized sampling without auto-reset (nobody draws; the table the launch leaves behind must then
+    equal the step-by-step one: later step wins, then the higher env).  With both on, the counters and invariants still hold."""
+    unroll = 4
+    for n in sizes:
+        for kw in (dict(auto_reset=1, prioritized_sample_factor=0.0), dict(auto_reset=0, prioritized_sample_factor=3.0)):
+            A = make_engine(model_blob, table, n, lib_path, seed=31, **kw)
+            B = make_engine(model_blob, table, n, lib_path, seed=31, **kw)
+            A.reset(); B.reset()
+            for _ in range(3):                                       # unrolls start wherever they are enabled (not at step 0)
+                A.step_random(SIGMA); B.step_random(SIGMA)
+            pa, w = A.enable_unrolls(unroll, 2); pb, _ = B.enable_unrolls(unroll, 2)
+            assert A.unroll_position() == (0, 0)
+            for L in range(n_launches):
+                for _ in range(k):
+                    A.step_random(SIGMA)
+                B.step_random_n(SIGMA, k)
+                A.sync(); B.sync()
+                assert A.unroll_position() == B.unroll_position() == divmod((L + 1) * k, unroll)
+                for x, y in ((A.state(), B.state()), (A.ref_state(), B.ref_state()), (A.obs(), B.obs()), (A.feet()[0], B.feet()[0])):
+                    np.testing.assert_array_equal(x, y)
+                ra, rb = A.reward_done(), B.reward_done()
+                np.testing.assert_array_equal(ra[0], rb[0]); np.testing.assert_array_equal(ra[2], rb[2])
+                ia, ib = A.episode_info(), B.episode_info()
+                for key in ia:
+                    np.testing.assert_array_equal(ia[key], ib[key])
+                assert A.counters() == B.counters()
+                np.testing.assert_array_equal(A.episode_histogram(), B.episode_histogram())
+                np.testing.assert_array_equal(read_ring(pa, (2, n, unroll, w)), read_ring(pb, (2, n, unroll, w)))
+                for x, y in zip(A.sampling_table(), B.sampling_table()):
+                    np.testing.assert_array_equal(x, y)
+            assert A.counters()['episodes'] > 0
+            A.close(); B.close()
+        # both on: the launch-granular table.  Same number of env-steps, everything finite, episodes keep ending and re-seeding
+        C = make_engine(model_blob, table, n, lib_path, seed=32, auto_reset=1, prioritized_sample_factor=3.0)
+        C.reset()
+        for _ in range(n_launches):
+            C.step_random_n(SIGMA, 4 * k)
+        c = C.counters()
+        assert c['env_steps'] == n * n_launches * 4 * k and c['episodes'] > 0 and c['nonfinite'] == 0
+        p, avg, _ = C.sampling_table()
+        assert np.isfinite(C.state()).all() and abs(p.sum() - 1.0) < 1e-9 and (avg != 0).any()
+        with np.testing.assert_raises(capi.LLError):
+            C.step_random_n(SIGMA, 0)
+        C.close()
+
+
 def check_obstacle_variant(golden, orc, model_blob, table, lib_path, n_envs=24, n_steps=60, seed=2):
     """set_obstacle=True (PLE:173-193, :262-268, :341-346): engine vs oracle on the jump clips, random policy.  The robot does
     not clear the box, so episodes must end with the COLLISION bit in both, at the same step."""

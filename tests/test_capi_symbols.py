@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.load_library()                 # resolves every name in capi._SIGS or raises
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.ll_abi_version() == 1
+    assert lib.ll_abi_version() == capi.LL_ABI_VERSION == 2
     assert lib.ll_model_blob_len() == 788
 
 

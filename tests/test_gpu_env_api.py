@@ -213,35 +213,92 @@ def test_policy_gradient_actor_outputs(model_blob, mocap_table):
     pol.close(); E.close()
 
 
-def test_bench_two_ranks_on_one_device(tmp_path):
-    """bench.py's N > 1 branch end to end (an 8-GPU node is not ours to lease): two ranks launched the way the driver launches
-    them, both on device 0, the gather staged through gloo (LL_BENCH_BACKEND / LL_BENCH_ONE_DEVICE test hooks).  The JSON line is the
-    contract's, rank 0's gathered blocks equal what each rank's engine recorded, and the gather overlaps with the steps."""
+def _run_bench(extra_args, extra_env, timeout=900):
+    """`python bench.py ...` exactly as the driver types it (no launcher in front), with the one-device test hooks in the environment."""
     import json
     import os
-    import socket
     import subprocess
     import sys
-    torch_cuda()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, LL_BENCH_BACKEND='gloo', LL_BENCH_ONE_DEVICE='1', LL_BENCH_VERIFY='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    steps, warm, n = 384, 128, 512                                        # three gathered unrolls of 128 steps inside the timed region
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
-           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', str(steps), '--warmup', str(warm), '--envs-per-gpu', str(n)]
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py')] + [str(a) for a in extra_args]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(line) == 1, out.stdout[-2000:]                               # ONE line, from rank 0
-    j = json.loads(line[0])
+    return json.loads(line[0]), line[0], root
+
+
+ONE_DEVICE = {'LL_BENCH_BACKEND': 'gloo', 'LL_BENCH_ONE_DEVICE': '1'}
+
+
+def test_bench_two_ranks_on_one_device(tmp_path):
+    """bench.py's N > 1 branch end to end (an 8-GPU node is not ours to lease): `python bench.py --gpus 2` -- no launcher, the
+    command starts its own two ranks -- both on device 0, the gather staged through gloo (LL_BENCH_BACKEND / LL_BENCH_ONE_DEVICE test hooks).
+    The JSON line is the contract's and rank 0's gathered blocks equal what each rank's engine recorded."""
+    import os
+    torch_cuda()
+    steps, warm, n = 384, 128, 512                                        # three gathered unrolls of 128 steps inside the timed region
+    j, raw, root = _run_bench(['--gpus', 2, '--steps', steps, '--warmup', warm, '--envs-per-gpu', n], dict(ONE_DEVICE, LL_BENCH_VERIFY='1'))
     assert j['n_gpus'] == 2 and j['steps'] == steps and j['scaling'] == 'weak' and j['unit'] == 'env-steps/s'
     assert abs(j['value'] - 2 * n * steps / (j['ms_per_step'] * 1e-3 * steps)) < 1e-6 * j['value']       # whole-job aggregate over both ranks
     c = j['config']
     assert c['unrolls_gathered'] == (steps + warm) // 128 and c['unroll_row_floats'] == 224 and c['gather_check'] == 'ok'
-    # overlap: the timed region is not (steps x kernel) + (gathers end to end); with two ranks time-sharing one device the step kernels
-    # of the two ranks serialise, so the bound is 2 x kernel per step plus slack for the host-staged test gather
+    assert c['gather']['mode'] == 'async' and c['gather']['bytes_per_rank_per_unroll'] == n * 128 * 224 * 4
+    # with two ranks time-sharing one device the step kernels of the two ranks serialise at worst: 2 x kernel per step plus launch slack
     assert j['ms_per_step'] < 2.0 * j['roofline']['kernel_avg_ms'] + 0.25, j
     log_dir = os.path.join(root, 'gpurun_out', 'two_rank')
     os.makedirs(log_dir, exist_ok=True)
     with open(os.path.join(log_dir, 'bench_two_ranks_one_device.json'), 'w') as f:
-        f.write(line[0] + '\n')
+        f.write(raw + '\n')
+
+
+def test_gather_overlaps_with_the_next_unroll():
+    """An overlap measurement that can fail: the same two-rank run three times -- without the gather (the steps alone), with every gather
+    waited for before the next step is launched (--gather-mode blocking), and as shipped (async, double-buffered).  Blocking costs the
+    gather's own duration G on top of the steps; the async run must win back most of min(G, steps): what a gather hidden behind the next
+    unroll's simulation can save at all."""
+    import os
+    torch_cuda()
+    steps, warm, n = 512, 128, 1024
+    args = ['--gpus', 2, '--steps', steps, '--warmup', warm, '--envs-per-gpu', n]
+    t = {}
+    lines = []
+    for mode in ('none', 'blocking', 'async', 'none', 'blocking', 'async'):      # two rounds, best of each (box noise only ever adds time)
+        j, raw, root = _run_bench(args + ['--gather-mode', mode], ONE_DEVICE)
+        t[mode] = min(t.get(mode, 1e9), j['ms_per_step'])
+        lines.append(raw)
+    G = t['blocking'] - t['none']                                             # per step: what an un-hidden gather costs
+    saved = t['blocking'] - t['async']
+    hideable = min(G, t['none'])
+    log_dir = os.path.join(root, 'gpurun_out', 'two_rank')
+    os.makedirs(log_dir, exist_ok=True)
+    with open(os.path.join(log_dir, 'gather_overlap.txt'), 'w') as f:
+        f.write('ms per step, 2 ranks x %d envs on one device, gloo-staged gather (best of 2): none %.4f  blocking %.4f  async %.4f\n'
+                'gather cost un-hidden G = %.4f, hideable min(G, steps) = %.4f, saved by the double buffer = %.4f (%.0f %%)\n'
+                % (n, t['none'], t['blocking'], t['async'], G, hideable, saved, 100.0 * saved / max(hideable, 1e-9)))
+        f.write('\n'.join(lines) + '\n')
+    assert G > 0.02 * t['none'], ('the gather is too cheap to measure here', t)
+    assert saved >= 0.8 * hideable, t
+    assert t['async'] <= 1.15 * max(t['none'], G), t                          # and the async run is close to max(steps, gather)
+
+
+def test_bench_rccl_one_rank_communicator():
+    """RCCL itself on this box: bench.py's N > 1 control flow (process group, unroll recording, TD(lambda), dist.gather with async_op on
+    the engine's own device blocks, MAX over ranks) with backend "nccl" (= RCCL) and a ONE-rank communicator (LL_BENCH_FORCE_GATHER) --
+    a 1-GPU box cannot host two RCCL ranks, but every call the 8-rank run makes is made, against the real library, on the real stream."""
+    torch_cuda()
+    steps, warm, n = 256, 128, 4096
+    j, raw, root = _run_bench(['--gpus', 1, '--steps', steps, '--warmup', warm, '--envs-per-gpu', n, '--no-cpu-baseline'],
+                              {'LL_BENCH_FORCE_GATHER': '1', 'LL_BENCH_VERIFY': '1'})
+    c = j['config']
+    assert j['n_gpus'] == 1 and c['unrolls_gathered'] == 3 and c['gather']['backend'] == 'nccl' and c['gather_check'] == 'ok'
+    # one rank: the "gather" is a device-to-device copy of 470 MB on RCCL's stream; the steps must not stand still behind it
+    assert c['gather']['stream_stall_ms_total'] < 0.2 * j['ms_per_step'] * steps, j
+    import os
+    log_dir = os.path.join(root, 'gpurun_out', 'two_rank')
+    os.makedirs(log_dir, exist_ok=True)
+    with open(os.path.join(log_dir, 'bench_rccl_one_rank.json'), 'w') as f:
+        f.write(raw + '\n')

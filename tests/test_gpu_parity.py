@@ -14,7 +14,7 @@ def test_library_is_the_hip_build(model_blob, mocap_table):
     object and no emulation entry point, is mapped into this process next to the HIP runtime, and launches on a real stream."""
     import os
     lib = capi.load_library()
-    assert lib.ll_abi_version() == 1
+    assert lib.ll_abi_version() == 2
     assert lib._name == capi.DEFAULT_LIB and os.path.basename(os.path.dirname(lib._name)) == 'csrc'
     assert not hasattr(lib, 'emu_substep')                                  # tests/emul/emul.cpp only
     blob = open(lib._name, 'rb').read()
@@ -131,6 +131,18 @@ def test_step_random_is_fill_then_step(model_blob, mocap_table):
         assert all(np.array_equal(x, y) for x, y in zip(ta, tb))
         assert A.counters() == B.counters() and A.counters()['episodes'] > 0
         A.close(); B.close()
+
+
+def test_multi_step_launch(model_blob, mocap_table):
+    """ll_step_random_n: k control steps in one launch == k launches, bit for bit (both kernel variants: 70 and 4200 envs)."""
+    from lifelike_agility_and_play_amd import gather
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('torch.cuda is not available on this box (needed to read the unroll buffers)')
+
+    def read_ring(addr, shape):
+        return gather.device_tensor(addr, shape).cpu().numpy()
+    pc.check_multi_step_launch(model_blob, mocap_table, None, read_ring, sizes=(70, 4200), k=9, n_launches=4)
 
 
 def test_contact_rich_parity(golden, orc, model_blob, mocap_table):

@@ -59,6 +59,15 @@ def test_trajectory_ring(model_blob, mocap_table, emul_lib):
     pc.check_trajectory_ring(model_blob, mocap_table, emul_lib, read_ring, write_dev)
 
 
+def test_multi_step_launch(model_blob, mocap_table, emul_lib):
+    import ctypes
+
+    def read_ring(addr, shape):
+        n = int(np.prod(shape))
+        return np.ctypeslib.as_array((ctypes.c_float * n).from_address(addr)).reshape(shape).copy()
+    pc.check_multi_step_launch(model_blob, mocap_table, emul_lib, read_ring)
+
+
 def test_obstacle_variant(golden, orc, model_blob, mocap_table, emul_lib):
     n = pc.check_obstacle_variant(golden, orc, model_blob, mocap_table, emul_lib)
     print('obstacle variant: %d episodes ended on the box' % n)
