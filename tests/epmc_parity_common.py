@@ -287,25 +287,30 @@ def assert_within_bars(out, cfg_bar=1e-4, vel_bar=1e-3, factor=4.0, max_ill=0.03
     assert (v < bar_v).all(), (np.sort(v)[-5:], cv[np.argsort(v)[-5:]])
 
 
-def check_terrain_physics_against_oracle(lib_path, n_envs=16, seed=11):
+def check_terrain_physics_against_oracle(lib_path, n_envs=16, seed=11, total_envs=None):
     """Robots standing on, straddling and pressed into cube steps and hurdles, with the push active: one control step of real
     physics, engine (float32) vs the float64 oracle given the same terrain records, friction and push forces.  The two share the
-    spec (shape_sdf, nearest-surface normal, btPlaneSpace1 tangents) and nothing else."""
+    spec (shape_sdf, nearest-surface normal, btPlaneSpace1 tangents) and nothing else.
+    total_envs: the engine runs that many envs (above 4096: the larger-batch kernel build) and the n_envs cases are spread over the first,
+    middle and last wavefronts of its grid."""
     from conftest import make_oracle_batch
     from oracle import oracle as orc
     from lifelike_agility_and_play_amd import mocap
     out = dict(config=[], vel=[], n_terrain=0)
+    N = total_envs or n_envs
+    third = n_envs // 3
+    idx = np.arange(n_envs) if not total_envs else np.concatenate([np.arange(third), N // 2 - 5 + np.arange(third), N - (n_envs - 2 * third) + np.arange(n_envs - 2 * third)])
     for element in (3, 1):
         cfg = env_config(element)
         cfg['env_randomize_config']['disturb_force_config'] = {'start_time': 0.0, 'interval_time': 1.0, 'duration_time': 0.5, 'horizontal_force': [10, 50], 'vertical_force': [0, 10]}
-        E = make_engine(cfg, n_envs, lib_path, seed=seed)
+        E = make_engine(cfg, N, lib_path, seed=seed)
         E.reset()
         rows, cnt = E.statics()
         rng = np.random.default_rng(seed)
         st = E.state().astype(np.float64)
-        recs_all = [statics_to_records(rows[i, :cnt[i]].astype(np.float64)) for i in range(n_envs)]
-        for i in range(n_envs):
-            rec = recs_all[i]
+        recs_all = [statics_to_records(rows[e, :cnt[e]].astype(np.float64)) for e in idx]
+        for k, i in enumerate(idx):
+            rec = recs_all[k]
             b = rec[2 + rng.integers(0, min(6, len(rec) - 2))]                      # one of the first obstacles (0, 1 are the walls)
             st[i, 0] = rng.uniform(b[0] - 0.35, b[1] + 0.35); st[i, 1] = rng.uniform(-0.1, 0.1)
             st[i, 2] = b[5] + rng.uniform(0.22, 0.33) if b[4] < 0.01 else rng.uniform(0.2, b[4] + 0.05)   # above a step / bar, or under a hanging bar
@@ -313,14 +318,14 @@ def check_terrain_physics_against_oracle(lib_path, n_envs=16, seed=11):
             st[i, 25:37] = rng.normal(size=12)
         E.set_state(st)
         st32 = E.state().astype(np.float64)
-        act = (rng.normal(size=(n_envs, 12)) * 0.135).astype(np.float32)
+        act = (rng.normal(size=(N, 12)) * 0.135).astype(np.float32)
         ep = E.episode()
         E.step_host(act)
         es = E.state().astype(np.float64)
         tr = E.push_trace().astype(np.float64)
         B = make_oracle_batch(orc, urdf_model.default_model_blob(), mocap.load_mocap('', 0.02), n_envs=1, kd=0.5, max_tau=16.0)
-        for i in range(n_envs):
-            rec = recs_all[i]
+        for k, i in enumerate(idx):
+            rec = recs_all[k]
             p = st32[i, 0:3]
             near = rec[(p[0] >= rec[:, 0] - 0.9) & (p[0] <= rec[:, 1] + 0.9) & (p[1] >= rec[:, 2] - 0.9) & (p[1] <= rec[:, 3] + 0.9) & (p[2] <= rec[:, 5] + 0.9)][:8]
             mu_i = float(np.float32(ep['friction'][i]) * np.float32(0.9))

@@ -62,25 +62,34 @@ def check_reset_against_goldens(golden, model_blob, table, lib_path):
     E.close()
 
 
-def run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True, sigma=SIGMA, policy=None):
+def run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True, sigma=SIGMA, policy=None, total_envs=None):
     """Step engine and oracle side by side from golden (clip, t0) starts with the same random actions.
     With resync the oracle is re-seeded with the engine's float32 state after every control step, so every step
-    is an independent single-control-step comparison."""
+    is an independent single-control-step comparison.
+    total_envs: the engine runs that many envs (the larger-batch kernel builds start above 4096) and the oracle follows n_envs of
+    them, spread over the first, middle and last wavefronts of the grid."""
     rng = np.random.default_rng(seed)
-    pick = rng.integers(0, len(golden['g2_clip']), n_envs)
+    N = total_envs or n_envs
+    if total_envs:
+        third = n_envs // 3
+        idx = np.concatenate([np.arange(third), N // 2 - 7 + np.arange(third), N - (n_envs - 2 * third) + np.arange(n_envs - 2 * third)])
+    else:
+        idx = np.arange(n_envs)
+    pick = rng.integers(0, len(golden['g2_clip']), N)
     clip, t0 = golden['g2_clip'][pick], golden['g2_t0'][pick]
-    E = make_engine(model_blob, table, n_envs, lib_path)
+    E = make_engine(model_blob, table, N, lib_path)
     B = make_oracle_batch(orc, model_blob, table, n_envs=n_envs)
     E.reset(clip=clip, t0=t0)
+    es0 = E.state()
     for i in range(n_envs):
-        B.reset_env(i, int(clip[i]), float(t0[i]))
-        B.set_state(i, E.state()[i].astype(np.float64))
+        B.reset_env(i, int(clip[idx[i]]), float(t0[idx[i]]))
+        B.set_state(i, es0[idx[i]].astype(np.float64))
     stats = dict(config=[], vel=[], obs=[], obs_vel=[], reward=[], feet=[], done_mismatch=0, done=0)
     prev_obs = None
     alive = np.ones(n_envs, bool)
     for t in range(n_steps):
         if policy is None:
-            act = (rng.normal(size=(n_envs, 12)) * sigma).astype(np.float32)
+            act = (rng.normal(size=(N, 12)) * sigma).astype(np.float32)
         else:                                # the trained policy's mean action on the engine's own observation: the tracking-gait regime
             act = policy.act(E.obs().astype(np.float64)).astype(np.float32)
         E.step_host(act)
@@ -89,35 +98,36 @@ def run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed
         for i in range(n_envs):
             if not alive[i]:
                 continue
-            oo, orr, od = B.step_env(i, act[i].astype(np.float64))
+            e = idx[i]
+            oo, orr, od = B.step_env(i, act[e].astype(np.float64))
             os_ = B.get_state(i)
-            err = np.abs(quat_align(es[i].astype(np.float64), os_) - os_)
+            err = np.abs(quat_align(es[e].astype(np.float64), os_) - os_)
             vscale = 1.0 + np.abs(os_[25:37]).max()
             stats['config'].append(max(err[0:7].max(), err[13:25].max()))
             stats['vel'].append(max(err[7:13].max(), err[25:37].max()) / vscale)
-            oe = np.abs(eo[i] - oo)
+            oe = np.abs(eo[e] - oo)
             # newest prop frame: joint_pos | joint_vel | ang_vel_loc | lin_vel_loc | e_g  (PMC_PROP_TYPE order)
             stats['obs'].append(max(oe[66:78].max(), oe[96:99].max(), oe[99:].max()))            # configuration-like entries
             stats['obs_vel'].append(oe[78:96].max() / vscale)                                      # velocity entries
             if prev_obs is not None:                                                               # deque shift, bit exact
-                assert np.array_equal(eo[i][0:66], prev_obs[i][33:99]) and np.array_equal(eo[i][99:123], prev_obs[i][111:135])
-            stats['reward'].append(abs(er[i] - orr))
+                assert np.array_equal(eo[e][0:66], prev_obs[e][33:99]) and np.array_equal(eo[e][99:123], prev_obs[e][111:135])
+            stats['reward'].append(abs(er[e] - orr))
             ofd, ofk = B.get_feet(i)
-            stats['feet'].append(max(np.abs(efd[i] - ofd).max(), np.abs(efk[i] - ofk).max()))
-            if bool(ed[i]) != od:
+            stats['feet'].append(max(np.abs(efd[e] - ofd).max(), np.abs(efk[e] - ofk).max()))
+            if bool(ed[e]) != od:
                 stats['done_mismatch'] += 1
-            if od or ed[i]:
+            if od or ed[e]:
                 stats['done'] += 1
                 alive[i] = False             # reference semantics: a finished env waits for reset()
             elif resync:
-                B.set_state(i, es[i].astype(np.float64))
+                B.set_state(i, es[e].astype(np.float64))
         prev_obs = eo
     E.close()
     return {k: (np.array(v) if isinstance(v, list) else v) for k, v in stats.items()}
 
 
-def check_single_step_parity(golden, orc, model_blob, table, lib_path, n_envs=32, n_steps=12, seed=7):
-    st = run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True)
+def check_single_step_parity(golden, orc, model_blob, table, lib_path, n_envs=32, n_steps=12, seed=7, total_envs=None):
+    st = run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True, total_envs=total_envs)
     assert len(st['config']) > n_envs * n_steps * 0.5
     # EVERY sample: configuration within 1e-4, velocities within 1e-3 of (1 + the env's largest joint rate); and at most 1 % of the env-steps
     # above 1e-4 in velocity (float32 rounding through a contact that switches on or off inside the step; 0.4 % measured)

@@ -435,23 +435,28 @@ def check_robot_robot_contact(lib_path):
     return dict(stack_gap=float(zs[-1]))
 
 
-def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5):
+def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5, total_arenas=None):
     """Two robots within reach of each other (side by side, nose to tail, one partly above the other), random joint states and
     velocities, the push active: one control step of real physics, engine (float32, two rows exchanging registers) vs the float64
     oracle's two-robot substep (orc_substep_pair: explicit Jacobians, M^-1 by unit responses) given the same arena records,
-    friction and push forces.  The two share the spec (capsules, pair order, row order) and nothing else."""
+    friction and push forces.  The two share the spec (capsules, pair order, row order) and nothing else.
+    total_arenas: the engine runs that many arenas (above 2048: the larger-batch kernel build) and the n_arenas cases are spread over the
+    first, middle and last wavefronts of its grid."""
     from conftest import make_oracle_batch
     from oracle import oracle as orc
     from lifelike_agility_and_play_amd import mocap, urdf_model
     from parity_common import quat_align
     cfg = env_config((1, 0, 0))
     cfg['env_randomize_config']['disturb_force_config'] = {'start_time': 0.0, 'interval_time': 1.0, 'duration_time': 0.5, 'horizontal_force': [10, 50], 'vertical_force': [0, 10]}
-    E = make_engine(cfg, n_arenas, lib_path, seed=seed)
+    NA = total_arenas or n_arenas
+    third = n_arenas // 3
+    idx = np.arange(n_arenas) if not total_arenas else np.concatenate([np.arange(third), NA // 2 - 5 + np.arange(third), NA - (n_arenas - 2 * third) + np.arange(n_arenas - 2 * third)])
+    E = make_engine(cfg, NA, lib_path, seed=seed)
     E.reset()
     rng = np.random.default_rng(seed)
     st = E.state().astype(np.float64)
     from scipy.spatial.transform import Rotation as R
-    for a in range(n_arenas):
+    for a in idx:
         c = rng.uniform(-1.2, 1.2, 2)
         ang = rng.uniform(0, 2 * np.pi)
         dist = rng.uniform(0.18, 0.62)
@@ -465,7 +470,7 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5):
             st[a, r, 25:37] = rng.normal(size=12)
     E.set_state(st)
     st32 = E.state().astype(np.float64)
-    act = (rng.normal(size=(n_arenas, 2, 12)) * 0.135).astype(np.float32)
+    act = (rng.normal(size=(NA, 2, 12)) * 0.135).astype(np.float32)
     ep = E.episode()
     rows, cnt = E.boxes()
     E.step_host(act)
@@ -474,7 +479,7 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5):
     B = make_oracle_batch(orc, urdf_model.default_model_blob(), mocap.load_mocap('', 0.02), n_envs=1, kd=0.5, max_tau=16.0)
     out = dict(config=[], vel=[], n_rows=0, n_felt=0, who=[])
     ep_after = E.episode()
-    for a in range(n_arenas):
+    for a in idx:
         rec = np.array([[rows[a][b][0] - rows[a][b][3], rows[a][b][0] + rows[a][b][3], rows[a][b][1] - rows[a][b][4], rows[a][b][1] + rows[a][b][4],
                          rows[a][b][2] - rows[a][b][5], rows[a][b][2] + rows[a][b][5], 0.0, 0.0] for b in range(cnt[a])], dtype=np.float64).reshape(-1, 8)
         fl = np.array([ep['flag_x'][a], ep['flag_y'][a], ep['flag_z'][a]], dtype=np.float64)

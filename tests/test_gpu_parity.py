@@ -114,6 +114,14 @@ def test_both_register_budgets_compute_the_same(golden, model_blob, mocap_table)
     A.close(); B.close()
 
 
+def test_larger_batch_build_against_the_oracle(golden, orc, model_blob, mocap_table):
+    """pmc_step_kernel<2> (batches above 4096 envs: every sweep figure above 21 M env-steps/s) held to the float64 oracle DIRECTLY, with the
+    bars of the occupancy-1 build: 4096 + 256 envs, the oracle in lock-step with 48 of them spread over the first, middle and last
+    wavefronts of the grid, every sample."""
+    st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, None, n_envs=48, n_steps=12, total_envs=4096 + 256)
+    print('occupancy-2 build vs oracle: config err 50/99/max', np.percentile(st['config'], [50, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 99, 100]))
+
+
 def test_step_random_is_fill_then_step(model_blob, mocap_table):
     """ll_step_random (actions drawn inside the step kernel) == ll_fill_random_actions + ll_step, bit for bit, including the
     recorded actions and the sampling table the step leaves behind; two batch sizes, so both kernel variants run."""

@@ -35,6 +35,12 @@ def test_pair_physics_against_oracle_gpu():
     print(SC.check_pair_physics_against_oracle(None, n_arenas=64, seed=9))
 
 
+def test_larger_batch_build_against_the_oracle_gpu():
+    """sepmc_step_kernel<2> (above 2048 arenas) against the float64 two-robot oracle DIRECTLY: pair-physics cases spread over the first, middle
+    and last wavefronts of a 2048 + 128 arena grid, every robot within the bars of the occupancy-1 build."""
+    print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=9, total_arenas=2048 + 128))
+
+
 def test_free_running_against_the_oracle_env_gpu():
     print(SC.check_free_running_against_oracle_env(None))
 
