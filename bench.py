@@ -391,11 +391,18 @@ def main_epmc(args):
     eng = epmc_capi.EpmcEngine(cfg, urdf_model.default_model_blob())
     eng.reset()
 
-    def one_step():
-        eng.fill_random_actions(SIGMA)
-        eng.step()
-    for _ in range(args.warmup):
-        one_step()
+    spl = max(1, args.steps_per_launch)
+
+    def run_steps(count):                                   # launches of up to spl control steps (step_random_n draws the actions in the kernel)
+        left = count
+        while left > 0:
+            k = min(spl, left)
+            if k == 1:
+                eng.fill_random_actions(SIGMA); eng.step()
+            else:
+                eng.step_random_n(SIGMA, k)
+            left -= k
+    run_steps(args.warmup)
     if world > 1:
         dist.barrier()
     eng.sync()
@@ -403,15 +410,15 @@ def main_epmc(args):
         torch.cuda.synchronize()
     eng.enable_kernel_timing(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    run_steps(args.steps)
     eng.sync()
     if tc:
         torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    k_ms, k_n = eng.kernel_time_ms()
+    k_launch_ms, k_n, k_steps = eng.kernel_time_stats()
+    k_ms = k_launch_ms * k_n / k_steps if k_steps else 0.0    # per control step
     if world > 1:
         tt = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -425,10 +432,10 @@ def main_epmc(args):
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'EPMC PlayGround env (BASELINE config 4), %d envs per MI355X, element_id %d, 778 rays per env-step, push forces, '
-                                   'random-policy actions N(0, e^-2), auto-reset' % (n, args.element), 'envs_per_gpu': n, 'episodes_finished_rank0': eng.counters()['episodes']},
+                                   'random-policy actions N(0, e^-2), auto-reset' % (n, args.element), 'envs_per_gpu': n, 'steps_per_launch': spl, 'episodes_finished_rank0': eng.counters()['episodes']},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'traffic_source': tsrc, 'single_wave_issue': issue,
-                         'kernel': 'epmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
+                         'kernel': 'epmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n, 'kernel_avg_launch_ms': k_launch_ms,
                          'algorithmic_bytes_per_env_step': EPMC_ALGO_BYTES_PER_ENV_STEP,
                          'note': 'bound by single-wave instruction issue, not HBM; see DESIGN.md 8'}}}), flush=True)
     eng.close()
@@ -467,11 +474,18 @@ def main_sepmc(args):
     eng = sepmc_capi.SepmcEngine(cfg, urdf_model.default_model_blob())
     eng.reset()
 
-    def one_step():
-        eng.fill_random_actions(SIGMA)
-        eng.step()
-    for _ in range(args.warmup):
-        one_step()
+    spl = max(1, args.steps_per_launch)
+
+    def run_steps(count):                                   # launches of up to spl control steps (step_random_n draws the actions in the kernel)
+        left = count
+        while left > 0:
+            k = min(spl, left)
+            if k == 1:
+                eng.fill_random_actions(SIGMA); eng.step()
+            else:
+                eng.step_random_n(SIGMA, k)
+            left -= k
+    run_steps(args.warmup)
     if world > 1:
         dist.barrier()
     eng.sync()
@@ -479,15 +493,15 @@ def main_sepmc(args):
         torch.cuda.synchronize()
     eng.enable_kernel_timing(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    run_steps(args.steps)
     eng.sync()
     if tc:
         torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    k_ms, k_n = eng.kernel_time_ms()
+    k_launch_ms, k_n, k_steps = eng.kernel_time_stats()
+    k_ms = k_launch_ms * k_n / k_steps if k_steps else 0.0    # per control step
     if world > 1:
         tt = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -502,10 +516,10 @@ def main_sepmc(args):
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'SEPMC ChaseTagGameEnv (BASELINE config 5), %d arenas x 2 robots per MI355X, 2 x 778 perception rays + 21 visibility rays per '
                                    'arena-step, two-robot push schedule, robot-robot contact, random-policy actions N(0, e^-2), auto-reset' % n_arenas,
-                       'arenas_per_gpu': n_arenas, 'episodes_finished_rank0': eng.counters()['episodes']},
+                       'arenas_per_gpu': n_arenas, 'steps_per_launch': spl, 'episodes_finished_rank0': eng.counters()['episodes']},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'traffic_source': tsrc, 'single_wave_issue': issue,
-                         'kernel': 'sepmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
+                         'kernel': 'sepmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n, 'kernel_avg_launch_ms': k_launch_ms,
                          'algorithmic_bytes_per_robot_step': SEPMC_ALGO_BYTES_PER_ROBOT_STEP,
                          'note': 'bound by single-wave instruction issue, not HBM; see DESIGN.md 8b'}}}), flush=True)
     eng.close()

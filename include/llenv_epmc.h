@@ -114,6 +114,12 @@ int ll_epmc_device_ptrs(ll_epmc_engine* e, ll_device_ptrs_t* out);
 int ll_epmc_kernel_time_ms(ll_epmc_engine* e, double* avg_ms, int* n_launches);
 int ll_epmc_enable_kernel_timing(ll_epmc_engine* e, int on);
 int ll_epmc_fill_random_actions(ll_epmc_engine* e, float sigma);
+/* n_steps iterations of { ll_epmc_fill_random_actions(sigma); ll_epmc_step(NULL) } as ONE launch (llenv.h ll_step_random_n): every wavefront
+ * walks its own envs through the steps without waiting for the others.  The draws of a step (terrain, targets, pushes, re-seeds) are
+ * keyed on (env, episode, draw index), so the result is bit-identical to n_steps single steps. */
+int ll_epmc_step_random_n(ll_epmc_engine* e, float sigma, int n_steps);
+/* ll_epmc_kernel_time_ms plus the number of control steps the timed launches ran */
+int ll_epmc_kernel_time_stats(ll_epmc_engine* e, double* avg_launch_ms, int* n_launches, int64_t* n_control_steps);
 
 #ifdef __cplusplus
 }

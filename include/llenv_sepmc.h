@@ -77,6 +77,12 @@ int ll_sepmc_reset(ll_sepmc_engine* e, const int32_t* arena_ids, int n, const fl
 int ll_sepmc_step(ll_sepmc_engine* e, const float* d_actions);
 int ll_sepmc_set_actions(ll_sepmc_engine* e, const float* h_actions);
 int ll_sepmc_fill_random_actions(ll_sepmc_engine* e, float sigma);
+/* n_steps iterations of { ll_sepmc_fill_random_actions(sigma); ll_sepmc_step(NULL) } as ONE launch (llenv.h ll_step_random_n): every wavefront
+ * walks its own arenas through the steps without waiting for the others.  The draws of a step (terrain, targets, pushes, re-seeds) are
+ * keyed on (arena, episode, draw index), so the result is bit-identical to n_steps single steps. */
+int ll_sepmc_step_random_n(ll_sepmc_engine* e, float sigma, int n_steps);
+/* ll_sepmc_kernel_time_ms plus the number of control steps the timed launches ran */
+int ll_sepmc_kernel_time_stats(ll_sepmc_engine* e, double* avg_launch_ms, int* n_launches, int64_t* n_control_steps);
 
 /* Parity hook (how gen_sepmc_golden.py drove the reference through its fake BulletClient): one control step in which the caller
  * supplies what PyBullet would have returned -- both robot states after the ten substeps (h_state [n_arenas][2][37]), the answers

@@ -100,14 +100,33 @@ __device__ __forceinline__ float4 random_action_group(const StepParams& P, uint3
   return o;
 }
 
+// The actions of one control step for the lane's leg: drawn here (action_sigma > 0: lanes 0..2 of the row draw the env's three groups of
+// four actions, record them, and hand them to the leg lanes through 48 B of LDS) or read from P.actions.
+template <class Lanes>
+__device__ __forceinline__ void step_actions(const StepParams& P, const Lanes& ln, float* lds, int env, int sl, float* act) {
+  if (P.action_sigma > 0.0f) {
+    float* stash = lds + LC_COUNT * 4 + CAND_TABLE_WORDS * PMC_ROW + (threadIdx.x >> 4) * 12;
+    const int l16 = threadIdx.x & 15;
+    const uint32_t g = (uint32_t)(l16 < 3 ? l16 : 0);
+    const float4 o = random_action_group(P, (uint32_t)env * 3u + g, P.action_sigma, sl);
+    if (l16 < 3) {
+      reinterpret_cast<float4*>(P.actions_out)[(long)env * 3 + l16] = o;
+      reinterpret_cast<float4*>(stash)[l16] = o;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the row's LDS writes have landed (one wave)
+    for (int j = 0; j < 3; j++) act[j] = stash[ln.leg() * 3 + j];
+  } else {
+    for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
+  }
+}
+
 // OCC = wavefronts per SIMD the register budget allows: 1 (512 registers, nothing spills to scratch) while the grid fits the
 // chip one wavefront per SIMD, 2 (256 registers) for larger batches, where a second resident wavefront hides issue stalls.
 // OBST = the set_obstacle build (Pmc::step_env<true>): the jump obstacle takes part in the substeps as a static box.
 template <int OCC, bool OBST = false>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int row = threadIdx.x >> 4;                                         // one env = one 16-lane DPP row
-  const int env0 = blockIdx.x * PMC_ENVS_PER_WAVE + row;
+  const int env0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);      // one env = one 16-lane DPP row
   typedef typename std::conditional<OCC == 1, GpuLanesPmc1, GpuLanes>::type Lanes;
   Lanes ln(lds);
   if constexpr (OCC == 1) ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS, P.basec);   // all 64 lanes copy, also those without an env
@@ -122,21 +141,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
     asm volatile("" : "+v"(env));      // ... and no address of the step's ~150 loads and stores either (they all derive from env)
     if (env < P.n_envs) {
       float act[3];
-      if (P.action_sigma > 0.0f) {
-        // lanes 0..2 of the row draw the env's three groups of four actions, record them, and hand them to the leg lanes via LDS
-        float* stash = lds + LC_COUNT * 4 + CAND_TABLE_WORDS * PMC_ROW + row * 12;
-        const int l16 = threadIdx.x & 15;
-        const uint32_t g = (uint32_t)(l16 < 3 ? l16 : 0);
-        const float4 o = random_action_group(P, (uint32_t)env * 3u + g, P.action_sigma, sl);
-        if (l16 < 3) {
-          reinterpret_cast<float4*>(P.actions_out)[(long)env * 3 + l16] = o;
-          reinterpret_cast<float4*>(stash)[l16] = o;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the row's LDS writes have landed (one wave)
-        for (int j = 0; j < 3; j++) act[j] = stash[ln.leg() * 3 + j];
-      } else {
-        for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
-      }
+      step_actions(P, ln, lds, env, sl, act);
       Pmc<Lanes>::template step_env<OBST>(ln, P, env, act, sl);
     }
   }
@@ -159,14 +164,20 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
 template <int OCC>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, EpmcParams E) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int env = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
+  const int env0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
   typedef typename std::conditional<OCC == 1 && LL_PIN_EPMC, GpuLanes1, GpuLanes>::type Lanes;
   Lanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
-  if (env >= P.n_envs) return;
-  float act[3];
-  for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
-  Epmc<Lanes>::step_env(ln, P, E, env, act);
+  if (env0 >= P.n_envs) return;
+  for (int sl = 0; sl < P.n_steps; sl++) {               // ll_epmc_step_random_n: see pmc_step_kernel
+    if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    ln.new_step();
+    int env = env0;
+    asm volatile("" : "+v"(env));
+    float act[3];
+    step_actions(P, ln, lds, env, sl, act);
+    Epmc<Lanes>::step_env(ln, P, E, env, act);
+  }
 }
 __global__ __launch_bounds__(PMC_WAVE) void epmc_reset_kernel(StepParams P, EpmcParams E, const int32_t* ids, int n, const float* draws, const float* prev_orn) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -183,14 +194,20 @@ __global__ __launch_bounds__(PMC_WAVE) void epmc_reset_kernel(StepParams P, Epmc
 template <int OCC>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P, SepmcParams S) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int row = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
+  const int row0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
   typedef typename std::conditional<OCC == 1 && LL_PIN_SEPMC, GpuLanes1, GpuLanes>::type Lanes;
   Lanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
-  if (row >= P.n_envs) return;
-  float act[3];
-  for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)row * 12 + j, 3);
-  Sepmc<Lanes>::step_env(ln, P, S, row, act);
+  if (row0 >= P.n_envs) return;
+  for (int sl = 0; sl < P.n_steps; sl++) {               // ll_sepmc_step_random_n: see pmc_step_kernel
+    if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    ln.new_step();
+    int row = row0;
+    asm volatile("" : "+v"(row));
+    float act[3];
+    step_actions(P, ln, lds, row, sl, act);
+    Sepmc<Lanes>::step_env(ln, P, S, row, act);
+  }
 }
 __global__ __launch_bounds__(PMC_WAVE) void sepmc_reset_kernel(StepParams P, SepmcParams S, const int32_t* ids, int n, const float* draws, const float* prev_orn) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -322,7 +339,7 @@ struct HipBackend {
   void launch_epmc_step(const StepParams& P, const EpmcParams& E) {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
-    std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin();
+    std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
     if (blocks <= simds) hipLaunchKernelGGL(epmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, E);
     else                 hipLaunchKernelGGL(epmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, E);
     HIPCHK(hipGetLastError());
@@ -337,7 +354,7 @@ struct HipBackend {
   void launch_sepmc_step(const StepParams& P, const SepmcParams& S) {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
-    std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin();
+    std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
     if (blocks <= simds) hipLaunchKernelGGL(sepmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, S);
     else                 hipLaunchKernelGGL(sepmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, S);
     HIPCHK(hipGetLastError());

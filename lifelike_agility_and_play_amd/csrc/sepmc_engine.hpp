@@ -142,6 +142,17 @@ struct SepmcEngine {
     base.bk.launch_sepmc_step(Q, R);
     base.P.step_count += 1;
   }
+  // n_steps control steps of the random-policy loop in one launch (pmc_engine.hpp step_random_n): the draws of a step are keyed on (arena,
+  // episode, draw counter), so nothing but the actions' Philox step index moves from step to step
+  void step_random_n(float sigma, int n_steps) {
+    if (!have_reset) throw PmcError(LL_ESTATE, "ll_sepmc_reset must be called before ll_sepmc_step_random_n");
+    if (!(sigma > 0.0f) || n_steps <= 0) throw PmcError(LL_EINVAL, "sigma and n_steps must be positive");
+    if (pending_step_draws != 0) throw PmcError(LL_ESTATE, "scripted draws apply to single steps only");
+    StepParams Q = base.P;
+    Q.actions = base.d_actions; Q.action_sigma = sigma; Q.n_steps = n_steps;
+    base.bk.launch_sepmc_step(Q, S);
+    base.P.step_count += (uint64_t)n_steps;
+  }
   void step_scripted(const float* h_actions, const float* h_state, const uint8_t* h_hit, const float* h_frac, const uint8_t* h_vis, const int32_t* h_contacts,
                      const float* h_draws, int n_draws) {
     if (!have_reset) throw PmcError(LL_ESTATE, "ll_sepmc_reset must be called before ll_sepmc_step_scripted");

@@ -101,6 +101,8 @@ _SIGS = {
     'll_epmc_get_counters': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     'll_epmc_device_ptrs': (C.c_int, [C.c_void_p, C.POINTER(capi.LLDevicePtrs)]),
     'll_epmc_kernel_time_ms': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    'll_epmc_kernel_time_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    'll_epmc_step_random_n': (C.c_int, [C.c_void_p, C.c_float, C.c_int]),
     'll_epmc_enable_kernel_timing': (C.c_int, [C.c_void_p, C.c_int]),
     'll_epmc_fill_random_actions': (C.c_int, [C.c_void_p, C.c_float]),
 }
@@ -252,6 +254,15 @@ class EpmcEngine(object):
 
     def enable_kernel_timing(self, on=True):
         self._chk(self.lib.ll_epmc_enable_kernel_timing(self.h, 1 if on else 0))
+
+    def step_random_n(self, sigma, n_steps):
+        """n_steps x {fill_random_actions(sigma); step()} in one launch (ll_epmc_step_random_n)"""
+        self._chk(self.lib.ll_epmc_step_random_n(self.h, float(sigma), int(n_steps)))
+
+    def kernel_time_stats(self):
+        ms, n, st = C.c_double(), C.c_int(), C.c_int64()
+        self._chk(self.lib.ll_epmc_kernel_time_stats(self.h, C.byref(ms), C.byref(n), C.byref(st)))
+        return ms.value, n.value, st.value
 
     def kernel_time_ms(self):
         ms, n = C.c_double(0), C.c_int(0)

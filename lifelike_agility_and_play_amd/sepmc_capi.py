@@ -95,6 +95,8 @@ _SIGS = {
     'll_sepmc_get_counters': (C.c_int, [_V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     'll_sepmc_device_ptrs': (C.c_int, [_V, C.POINTER(capi.LLDevicePtrs)]),
     'll_sepmc_kernel_time_ms': (C.c_int, [_V, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    'll_sepmc_kernel_time_stats': (C.c_int, [_V, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    'll_sepmc_step_random_n': (C.c_int, [_V, C.c_float, C.c_int]),
     'll_sepmc_enable_kernel_timing': (C.c_int, [_V, C.c_int]),
 }
 EXPORTED_SYMBOLS = sorted(_SIGS)
@@ -254,6 +256,15 @@ class SepmcEngine(object):
 
     def enable_kernel_timing(self, on=True):
         self._chk(self.lib.ll_sepmc_enable_kernel_timing(self.h, 1 if on else 0))
+
+    def step_random_n(self, sigma, n_steps):
+        """n_steps x {fill_random_actions(sigma); step()} in one launch (ll_sepmc_step_random_n)"""
+        self._chk(self.lib.ll_sepmc_step_random_n(self.h, float(sigma), int(n_steps)))
+
+    def kernel_time_stats(self):
+        ms, n, st = C.c_double(), C.c_int(), C.c_int64()
+        self._chk(self.lib.ll_sepmc_kernel_time_stats(self.h, C.byref(ms), C.byref(n), C.byref(st)))
+        return ms.value, n.value, st.value
 
     def kernel_time_ms(self):
         ms, n = C.c_double(0), C.c_int(0)

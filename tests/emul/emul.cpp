@@ -85,12 +85,21 @@ struct HostBackend {
       actions[4 * gid + 2] = sigma * m2 * cosf(6.283185307179586f * u4); actions[4 * gid + 3] = sigma * m2 * sinf(6.283185307179586f * u4);
     }
   }
+  void draw_step_actions(const StepParams& P, int sl) {
+    if (!(P.action_sigma > 0.0f)) return;
+    StepParams Q = P;
+    Q.step_count = P.step_count + (uint64_t)sl;
+    launch_actions(Q, P.actions_out, P.action_sigma);
+  }
   void launch_epmc_step(const StepParams& P, const EpmcParams& E) {
     HostLanes ln(P.candc);
-    for (int env = 0; env < P.n_envs; env++) {
-      fN act[3];
-      for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
-      Epmc<HostLanes>::step_env(ln, P, E, env, act);
+    for (int sl = 0; sl < P.n_steps; sl++) {
+      draw_step_actions(P, sl);
+      for (int env = 0; env < P.n_envs; env++) {
+        fN act[3];
+        for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
+        Epmc<HostLanes>::step_env(ln, P, E, env, act);
+      }
     }
   }
   void launch_epmc_reset(const StepParams& P, const EpmcParams& E, const int32_t* ids, int n, const float* draws, const float* prev_orn) {
@@ -114,11 +123,14 @@ struct HostBackend {
     }
   }
   void launch_sepmc_step(const StepParams& P, const SepmcParams& S) {
-    run_pairs(P, P.n_envs, [&](HostLanes& ln, int row) {
-      fN act[3];
-      for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)row * 12 + j, 3);
-      Sepmc<HostLanes>::step_env(ln, P, S, row, act);
-    });
+    for (int sl = 0; sl < P.n_steps; sl++) {
+      draw_step_actions(P, sl);
+      run_pairs(P, P.n_envs, [&](HostLanes& ln, int row) {
+        fN act[3];
+        for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)row * 12 + j, 3);
+        Sepmc<HostLanes>::step_env(ln, P, S, row, act);
+      });
+    }
   }
   void launch_sepmc_reset(const StepParams& P, const SepmcParams& S, const int32_t* ids, int n, const float* draws, const float* prev_orn) {
     run_pairs(P, n, [&](HostLanes& ln, int i) {

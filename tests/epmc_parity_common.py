@@ -203,6 +203,34 @@ def check_free_running_invariants(lib_path, n_envs=64, n_steps=80, element=1):
     return done_total
 
 
+def check_multi_step_launch(lib_path, sizes=(12,), k=5, n_launches=4, element=1):
+    """ll_epmc_step_random_n(sigma, k) == k x {ll_epmc_fill_random_actions(sigma); ll_epmc_step()}, bit for bit: state, the 916-float
+    observation (rays included), rewards, done reasons, episode records (terrain seeds, targets, push schedule), counters."""
+    sg = float(np.exp(-2.0))
+    for n in sizes:
+        cfg = env_config(element)
+        cfg['max_steps'] = 3 * k                                     # episodes end (time-out) and re-seed inside the launches
+        A = make_engine(cfg, n, lib_path, auto_reset=1, seed=4)
+        B = make_engine(cfg, n, lib_path, auto_reset=1, seed=4)
+        A.reset(); B.reset()
+        for L in range(n_launches):
+            for _ in range(k):
+                A.fill_random_actions(sg); A.step()
+            B.step_random_n(sg, k)
+            A.sync(); B.sync()
+            np.testing.assert_array_equal(A.state(), B.state())
+            np.testing.assert_array_equal(A.obs(), B.obs())
+            ra, rb = A.reward_done(), B.reward_done()
+            for x, y in zip(ra, rb):
+                np.testing.assert_array_equal(x, y)
+            ea, eb = A.episode(), B.episode()
+            for key in ea:
+                np.testing.assert_array_equal(ea[key], eb[key])
+            assert A.counters() == B.counters()
+        assert A.counters()['episodes'] > 0
+        A.close(); B.close()
+
+
 def statics_to_records(rows):
     """ll_epmc_get_statics rows (creation order: a box, then its two edge cylinders if any) -> the kernel's box records."""
     recs, i = [], 0

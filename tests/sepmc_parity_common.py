@@ -435,6 +435,32 @@ def check_robot_robot_contact(lib_path):
     return dict(stack_gap=float(zs[-1]))
 
 
+def check_multi_step_launch(lib_path, sizes=(6,), k=5, n_launches=4):
+    """ll_sepmc_step_random_n(sigma, k) == k x {ll_sepmc_fill_random_actions(sigma); ll_sepmc_step()}, bit for bit (both robots' states and
+    965-float observations, rewards, done, episode records, counters), with episodes timing out and re-seeding inside the launches."""
+    sg = float(np.exp(-2.0))
+    for n in sizes:
+        cfg = env_config(ALL_ELEMENTS, max_steps=3 * k)
+        A = make_engine(cfg, n, lib_path, auto_reset=1, seed=4)
+        B = make_engine(cfg, n, lib_path, auto_reset=1, seed=4)
+        A.reset(); B.reset()
+        for L in range(n_launches):
+            for _ in range(k):
+                A.fill_random_actions(sg); A.step()
+            B.step_random_n(sg, k)
+            A.sync(); B.sync()
+            np.testing.assert_array_equal(A.state(), B.state())
+            np.testing.assert_array_equal(A.obs(), B.obs())
+            for x, y in zip(A.reward_done(), B.reward_done()):
+                np.testing.assert_array_equal(x, y)
+            ea, eb = A.episode(), B.episode()
+            for key in ea:
+                np.testing.assert_array_equal(ea[key], eb[key])
+            assert A.counters() == B.counters()
+        assert A.counters()['episodes'] > 0
+        A.close(); B.close()
+
+
 def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5, total_arenas=None):
     """Two robots within reach of each other (side by side, nose to tail, one partly above the other), random joint states and
     velocities, the push active: one control step of real physics, engine (float32, two rows exchanging registers) vs the float64

@@ -33,6 +33,10 @@ def test_free_running_invariants(emul_lib):
     assert ec.check_free_running_invariants(emul_lib, n_envs=16, n_steps=70) > 0
 
 
+def test_multi_step_launch(emul_lib):
+    ec.check_multi_step_launch(emul_lib)
+
+
 def test_terrain_physics_against_oracle(emul_lib):
     out = ec.check_terrain_physics_against_oracle(emul_lib)
     assert out['n_terrain'] >= 10

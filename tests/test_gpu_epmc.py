@@ -42,6 +42,11 @@ def test_larger_batch_build_against_the_oracle():
     assert out['n_terrain'] >= 30 and out['n_felt'] >= 20
 
 
+def test_multi_step_launch():
+    """k control steps per launch == k launches, bit for bit; both kernel builds"""
+    ec.check_multi_step_launch(None, sizes=(70, 4200), k=7, n_launches=3)
+
+
 def test_trunk_on_edges_against_oracle():
     out = ec.check_trunk_on_edges_against_oracle(None, n_envs=48)
     assert out['n_edge_felt'] >= 24

@@ -40,6 +40,10 @@ def test_robot_robot_contact(emul_lib):
     print(SC.check_robot_robot_contact(emul_lib))
 
 
+def test_multi_step_launch(emul_lib):
+    SC.check_multi_step_launch(emul_lib)
+
+
 def test_pair_physics_against_oracle(emul_lib):
     print(SC.check_pair_physics_against_oracle(emul_lib))
 
