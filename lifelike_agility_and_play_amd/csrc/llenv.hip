@@ -123,7 +123,8 @@ __device__ __forceinline__ void step_actions(const StepParams& P, const Lanes& l
 // OCC = wavefronts per SIMD the register budget allows: 1 (512 registers, nothing spills to scratch) while the grid fits the
 // chip one wavefront per SIMD, 2 (256 registers) for larger batches, where a second resident wavefront hides issue stalls.
 // OBST = the set_obstacle build (Pmc::step_env<true>): the jump obstacle takes part in the substeps as a static box.
-template <int OCC, bool OBST = false>
+// MULTI = the launch may run several control steps (ll_step_random_n); single-step launches run the loop-free build.
+template <int OCC, bool OBST = false, bool MULTI = false>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);      // one env = one 16-lane DPP row
@@ -131,19 +132,46 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
   Lanes ln(lds);
   if constexpr (OCC == 1) ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS, P.basec);   // all 64 lanes copy, also those without an env
   else ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
-  // ll_step_random_n: n_steps control steps back to back.  A wave walks its four envs through them on its own -- no other wave is waited
-  // for, so a slow step of one wave (leg-leg rows, a re-seed) is not a slow step of the whole chip -- and between two steps it only has
-  // to see its own stores (state, obs row, bookkeeping: workgroup-scope fence = wait for the wave's outstanding memory operations).
-  for (int sl = 0; sl < P.n_steps; sl++) {
-    if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    ln.new_step();
-    int env = env0;
-    asm volatile("" : "+v"(env));      // ... and no address of the step's ~150 loads and stores either (they all derive from env)
-    if (env < P.n_envs) {
+  if constexpr (!MULTI) {
+    if (env0 < P.n_envs) {
       float act[3];
-      step_actions(P, ln, lds, env, sl, act);
-      Pmc<Lanes>::template step_env<OBST>(ln, P, env, act, sl);
+      step_actions(P, ln, lds, env0, 0, act);
+      Pmc<Lanes>::template step_env<OBST>(ln, P, env0, act, 0);
     }
+  } else {
+    // ll_step_random_n: n_steps control steps back to back.  A wave walks its four envs through them on its own -- no other wave is waited
+    // for, so a slow step of one wave (leg-leg rows, a re-seed) is not a slow step of the whole chip -- and between two steps it only has
+    // to see its own stores (state, obs row, bookkeeping: workgroup-scope fence = wait for the wave's outstanding memory operations).
+#if defined(LL_KERNARG_RELOAD)
+    typedef const __attribute__((address_space(4))) StepParams* KP;
+    KP pk = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    const int n_steps = P.n_steps;
+    for (int sl = 0; sl < n_steps; sl++) {
+      if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      ln.new_step();
+      int env = env0;
+      asm volatile("" : "+v"(env));
+      asm volatile("" : "+s"(pk));       // the argument block is re-read per step: scalar values are not carried over in spilled SGPRs
+      const StepParams& Q = *(const StepParams*)pk;
+      if (env < Q.n_envs) {
+        float act[3];
+        step_actions(Q, ln, lds, env, sl, act);
+        Pmc<Lanes>::template step_env<OBST>(ln, Q, env, act, sl);
+      }
+    }
+#else
+    for (int sl = 0; sl < P.n_steps; sl++) {
+      if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      ln.new_step();
+      int env = env0;
+      asm volatile("" : "+v"(env));      // ... and no address of the step's ~150 loads and stores either (they all derive from env)
+      if (env < P.n_envs) {
+        float act[3];
+        step_actions(P, ln, lds, env, sl, act);
+        Pmc<Lanes>::template step_env<OBST>(ln, P, env, act, sl);
+      }
+    }
+#endif
   }
   // The last workgroup to get here folds this step's finished episodes into the sampling table.  The statistics travel by
   // device-scope atomics only (publish_max), so no cache write-back is needed -- a __threadfence() here would flush this
@@ -161,7 +189,11 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
 
 // EPMC (epmc_step.hpp): one control step of PlayGroundEnv for every env; same execution model and register budgets as
 // pmc_step_kernel.  The 778 rays of an env are dealt out over the 16 lanes of its row.
-template <int OCC>
+// MULTI: the launch may run several control steps (ll_epmc_step_random_n).  The step loop costs the larger-batch build registers it does
+// not have (788 instead of 552 B of scratch per lane; 65536 envs: 18.6 -> 16.8 M env-steps/s), and a grid of sixteen wavefronts per SIMD has
+// neither a launch gap nor a slowest wave worth hiding, so multi-step launches exist for the one-wave-per-SIMD build only; larger batches
+// run their steps as single launches (same results: the step's draws are keyed on env, episode and draw index).
+template <int OCC, bool MULTI = false>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, EpmcParams E) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
@@ -169,14 +201,20 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, 
   Lanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
   if (env0 >= P.n_envs) return;
-  for (int sl = 0; sl < P.n_steps; sl++) {               // ll_epmc_step_random_n: see pmc_step_kernel
-    if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    ln.new_step();
-    int env = env0;
-    asm volatile("" : "+v"(env));
+  if constexpr (!MULTI) {
     float act[3];
-    step_actions(P, ln, lds, env, sl, act);
-    Epmc<Lanes>::step_env(ln, P, E, env, act);
+    step_actions(P, ln, lds, env0, 0, act);
+    Epmc<Lanes>::step_env(ln, P, E, env0, act);
+  } else {
+    for (int sl = 0; sl < P.n_steps; sl++) {               // ll_epmc_step_random_n: see pmc_step_kernel
+      if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      ln.new_step();
+      int env = env0;
+      asm volatile("" : "+v"(env));
+      float act[3];
+      step_actions(P, ln, lds, env, sl, act);
+      Epmc<Lanes>::step_env(ln, P, E, env, act);
+    }
   }
 }
 __global__ __launch_bounds__(PMC_WAVE) void epmc_reset_kernel(StepParams P, EpmcParams E, const int32_t* ids, int n, const float* draws, const float* prev_orn) {
@@ -191,7 +229,7 @@ __global__ __launch_bounds__(PMC_WAVE) void epmc_reset_kernel(StepParams P, Epmc
 
 // SEPMC (sepmc_step.hpp): one control step of ChaseTagGameEnv; row = 2 * arena + robot, the two robots of an arena are
 // neighbouring rows of one wave and exchange state with v_permlane16_swap.
-template <int OCC>
+template <int OCC, bool MULTI = false>          // MULTI: see epmc_step_kernel
 __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P, SepmcParams S) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int row0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
@@ -199,14 +237,20 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P,
   Lanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
   if (row0 >= P.n_envs) return;
-  for (int sl = 0; sl < P.n_steps; sl++) {               // ll_sepmc_step_random_n: see pmc_step_kernel
-    if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    ln.new_step();
-    int row = row0;
-    asm volatile("" : "+v"(row));
+  if constexpr (!MULTI) {
     float act[3];
-    step_actions(P, ln, lds, row, sl, act);
-    Sepmc<Lanes>::step_env(ln, P, S, row, act);
+    step_actions(P, ln, lds, row0, 0, act);
+    Sepmc<Lanes>::step_env(ln, P, S, row0, act);
+  } else {
+    for (int sl = 0; sl < P.n_steps; sl++) {               // ll_sepmc_step_random_n: see pmc_step_kernel
+      if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      ln.new_step();
+      int row = row0;
+      asm volatile("" : "+v"(row));
+      float act[3];
+      step_actions(P, ln, lds, row, sl, act);
+      Sepmc<Lanes>::step_env(ln, P, S, row, act);
+    }
   }
 }
 __global__ __launch_bounds__(PMC_WAVE) void sepmc_reset_kernel(StepParams P, SepmcParams S, const int32_t* ids, int n, const float* draws, const float* prev_orn) {
@@ -340,8 +384,16 @@ struct HipBackend {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
-    if (blocks <= simds) hipLaunchKernelGGL(epmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, E);
-    else                 hipLaunchKernelGGL(epmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, E);
+    if (P.n_steps == 1) {
+      if (blocks <= simds) hipLaunchKernelGGL(epmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, E);
+      else                 hipLaunchKernelGGL(epmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, E);
+    } else if (blocks <= simds) {
+      hipLaunchKernelGGL((epmc_step_kernel<1, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, E);
+    } else {
+      StepParams Q = P;                                  // larger batches: the steps of the call as single launches (see epmc_step_kernel)
+      Q.n_steps = 1;
+      for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) hipLaunchKernelGGL(epmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, Q, E);
+    }
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->second, stream));
   }
@@ -355,8 +407,16 @@ struct HipBackend {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
-    if (blocks <= simds) hipLaunchKernelGGL(sepmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, S);
-    else                 hipLaunchKernelGGL(sepmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, S);
+    if (P.n_steps == 1) {
+      if (blocks <= simds) hipLaunchKernelGGL(sepmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, S);
+      else                 hipLaunchKernelGGL(sepmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, S);
+    } else if (blocks <= simds) {
+      hipLaunchKernelGGL((sepmc_step_kernel<1, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, S);
+    } else {
+      StepParams Q = P;                                  // larger batches: single launches (see epmc_step_kernel)
+      Q.n_steps = 1;
+      for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) hipLaunchKernelGGL(sepmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, Q, S);
+    }
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->second, stream));
   }
@@ -370,12 +430,17 @@ struct HipBackend {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
+    const bool one = blocks <= simds, multi = P.n_steps > 1;
     if (P.set_obstacle) {
-      if (blocks <= simds) hipLaunchKernelGGL((pmc_step_kernel<1, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
-      else                 hipLaunchKernelGGL((pmc_step_kernel<2, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
+      if (one) { if (multi) hipLaunchKernelGGL((pmc_step_kernel<1, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
+                 else       hipLaunchKernelGGL((pmc_step_kernel<1, true, false>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P); }
+      else     { if (multi) hipLaunchKernelGGL((pmc_step_kernel<2, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
+                 else       hipLaunchKernelGGL((pmc_step_kernel<2, true, false>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P); }
     } else {
-      if (blocks <= simds) hipLaunchKernelGGL(pmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
-      else                 hipLaunchKernelGGL(pmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
+      if (one) { if (multi) hipLaunchKernelGGL((pmc_step_kernel<1, false, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
+                 else       hipLaunchKernelGGL((pmc_step_kernel<1, false, false>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P); }
+      else     { if (multi) hipLaunchKernelGGL((pmc_step_kernel<2, false, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
+                 else       hipLaunchKernelGGL((pmc_step_kernel<2, false, false>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P); }
     }
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->second, stream));
