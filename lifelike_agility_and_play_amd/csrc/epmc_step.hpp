@@ -544,7 +544,8 @@ struct Epmc {
   // ------------------------------------------------------------------------------------------------------------
   // the control step (PGE:299-364)
   // ------------------------------------------------------------------------------------------------------------
-  static LL_HD void step_env(const L& ln, const StepParams& P, const EpmcParams& E, int env, const F* act_in) {
+  static LL_HD void step_env(const L& ln, const StepParams& P_in, const EpmcParams& E, int env, const F* act_in) {
+    const StepParams& P = ln.params(P_in);
     const int N = P.n_envs;
     Base bs;
     F q[3], qd[3], act[3], tgt[3];

@@ -83,6 +83,9 @@ struct GpuLanes {
 
   int leg_, sub_, lane16_;
   float* lds_;
+  static constexpr int kParamsReload = 0;      // see WithParamsReload below
+  template <class T>
+  LL_D const T& params(const T& as_passed) const { return as_passed; }
   mutable int cbase_;   // LDS word of the per-leg constant table (+ leg)
   mutable int tbase_;   // LDS word of the candidate table (+ lane16)
   int row_scratch_;     // LDS word where the per-row scratch areas start
@@ -480,6 +483,25 @@ struct GpuLanesPinned : GpuLanes {
     return lds_[tbase_ + word * PMC_ROW];
   }
   LL_D float basec(const float* bc, int i) const { return N_BASE > 0 ? bcr_[i] : bc[i]; }
+};
+
+// The kernel's argument block (StepParams is every step kernel's FIRST argument; only step kernels call params()).  A lane policy wrapped
+// in WithParamsReload hands out a reference to the argument block through a pointer the compiler has to treat as new at that point: scalar
+// values derived from the arguments are then re-read from the argument block (scalar loads from the constant cache) where they are needed,
+// instead of being computed once at kernel entry and parked in spilled SGPRs (a v_readlane per use: 576 of them in the multi-step PMC
+// kernel before, 94 after).  LEVEL 1: once per control step; 2: also once per substep.  Which level pays is a matter of register
+// allocation and measured per kernel (A/B on one box, tools/ab3.sh): PMC -2.2 % kernel time at level 1 (both builds); EPMC -0.8 % at
+// level 2 (one wave per SIMD) / -1.2 % at level 1 (larger batches); SEPMC +0.3 % / +20 % (!) -- left alone.
+template <class Base, int LEVEL>
+struct WithParamsReload : Base {
+  using Base::Base;
+  static constexpr int kParamsReload = LEVEL;
+  template <class T>
+  LL_D const T& params(const T&) const {
+    const __attribute__((address_space(4))) void* k = (const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return *(const T*)(const __attribute__((address_space(4))) T*)k;
+  }
 };
 
 #define LL_FMAC_RBCAST(L_)                                                                                               \

@@ -40,6 +40,16 @@ typedef GpuLanesPinned<LC_COUNT> GpuLanes1;                   // the per-leg tab
 #ifndef LL_PIN_PMC
 #define LL_PIN_PMC 1
 #endif
+// re-reading of the argument block (lanes.hpp WithParamsReload), per kernel by A/B; the SEPMC kernels keep the plain lane policies
+#ifndef LL_RELOAD_PMC
+#define LL_RELOAD_PMC 1
+#endif
+#ifndef LL_RELOAD_EPMC1
+#define LL_RELOAD_EPMC1 2
+#endif
+#ifndef LL_RELOAD_EPMC2
+#define LL_RELOAD_EPMC2 1
+#endif
 typedef GpuLanesPinned<LC_COUNT, LL_PIN_PMC ? 7 : 0, LL_PIN_PMC ? BC_COUNT : 0, LL_PIN_PMC ? LK_BASE : 0> GpuLanesPmc1;  // PMC at one wave per SIMD: candidate fields and base constants too
 
 // PLE:235-240 for the batch, by one wavefront: fold the statistics published by finished episodes into the per-clip table
@@ -128,7 +138,7 @@ template <int OCC, bool OBST = false, bool MULTI = false>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);      // one env = one 16-lane DPP row
-  typedef typename std::conditional<OCC == 1, GpuLanesPmc1, GpuLanes>::type Lanes;
+  typedef WithParamsReload<typename std::conditional<OCC == 1, GpuLanesPmc1, GpuLanes>::type, LL_RELOAD_PMC> Lanes;
   Lanes ln(lds);
   if constexpr (OCC == 1) ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS, P.basec);   // all 64 lanes copy, also those without an env
   else ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
@@ -142,24 +152,6 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
     // ll_step_random_n: n_steps control steps back to back.  A wave walks its four envs through them on its own -- no other wave is waited
     // for, so a slow step of one wave (leg-leg rows, a re-seed) is not a slow step of the whole chip -- and between two steps it only has
     // to see its own stores (state, obs row, bookkeeping: workgroup-scope fence = wait for the wave's outstanding memory operations).
-#if defined(LL_KERNARG_RELOAD)
-    typedef const __attribute__((address_space(4))) StepParams* KP;
-    KP pk = (KP)__builtin_amdgcn_kernarg_segment_ptr();
-    const int n_steps = P.n_steps;
-    for (int sl = 0; sl < n_steps; sl++) {
-      if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      ln.new_step();
-      int env = env0;
-      asm volatile("" : "+v"(env));
-      asm volatile("" : "+s"(pk));       // the argument block is re-read per step: scalar values are not carried over in spilled SGPRs
-      const StepParams& Q = *(const StepParams*)pk;
-      if (env < Q.n_envs) {
-        float act[3];
-        step_actions(Q, ln, lds, env, sl, act);
-        Pmc<Lanes>::template step_env<OBST>(ln, Q, env, act, sl);
-      }
-    }
-#else
     for (int sl = 0; sl < P.n_steps; sl++) {
       if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       ln.new_step();
@@ -171,7 +163,6 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
         Pmc<Lanes>::template step_env<OBST>(ln, P, env, act, sl);
       }
     }
-#endif
   }
   // The last workgroup to get here folds this step's finished episodes into the sampling table.  The statistics travel by
   // device-scope atomics only (publish_max), so no cache write-back is needed -- a __threadfence() here would flush this
@@ -197,7 +188,7 @@ template <int OCC, bool MULTI = false>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, EpmcParams E) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
-  typedef typename std::conditional<OCC == 1 && LL_PIN_EPMC, GpuLanes1, GpuLanes>::type Lanes;
+  typedef WithParamsReload<typename std::conditional<OCC == 1 && LL_PIN_EPMC, GpuLanes1, GpuLanes>::type, (OCC == 1 ? LL_RELOAD_EPMC1 : LL_RELOAD_EPMC2)> Lanes;
   Lanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
   if (env0 >= P.n_envs) return;

@@ -634,9 +634,10 @@ struct Pmc {
   // TERRAIN: contact candidates are also tested against ex->shapes, and a contact's normal is that of the shape it touches
   // PAIR: contacts with the other robot of a SEPMC arena (the neighbouring row) are found and solved too
   template <bool TERRAIN, bool PAIR = false>
-  static LL_HD void substep_impl(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env, int sidx, const SubstepExtra* ex,
+  static LL_HD void substep_impl(const L& ln, const StepParams& P_in, Base& bs, F* q, F* qd, const F* tgt, int env, int sidx, const SubstepExtra* ex,
                                  const LinkC* held) {   // held: the own-link constants if the caller keeps them in registers, or null
 #define PMC_TSS(k) do { if (sidx == 5) PMC_TS(k); } while (0)
+    const StepParams& P = (L::kParamsReload > 1) ? ln.params(P_in) : P_in;
     const float* legc = P.legc;
     const float* bc = P.basec;
     const float dt = P.dt;
@@ -1686,7 +1687,8 @@ struct Pmc {
   // OBST (set_obstacle builds): the jump obstacle of the episode is a static box the robot collides with during the substeps
   // sl: index of this control step inside its launch (ll_step_random_n runs n_steps of them back to back; 0 otherwise)
   template <bool OBST = false>
-  static LL_HD void step_env(const L& ln, const StepParams& P, int env, const F* act_in, int sl = 0) {
+  static LL_HD void step_env(const L& ln, const StepParams& P_in, int env, const F* act_in, int sl = 0) {
+    const StepParams& P = ln.params(P_in);
     const int N = P.n_envs;
     Base bs;
     F q[3], qd[3], act[3], tgt[3];

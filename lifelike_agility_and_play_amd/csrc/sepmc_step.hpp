@@ -340,7 +340,8 @@ struct Sepmc {
   // ------------------------------------------------------------------------------------------------------------
   // the control step (CTG:378-424)
   // ------------------------------------------------------------------------------------------------------------
-  static LL_HD void step_env(const L& ln, const StepParams& P, const SepmcParams& S, int row, const F* act_in) {
+  static LL_HD void step_env(const L& ln, const StepParams& P_in, const SepmcParams& S, int row, const F* act_in) {
+    const StepParams& P = ln.params(P_in);
     const EpmcParams& E = S.e;
     const int N = P.n_envs, me = row & 1, arena = row >> 1;
     Base bs;

@@ -105,6 +105,10 @@ struct HostLanes {
   }
   float peer_u(float x) const { return peer(fN(x)).v[0]; }
   void refresh_consts() const {}
+  void new_step() {}
+  static constexpr int kParamsReload = 0;
+  template <class T>
+  const T& params(const T& as_passed) const { return as_passed; }
   bool lane0() const { return true; }
   int ray_first() const { return 0; }
   int ray_stride() const { return 1; }
