@@ -104,17 +104,19 @@ def cpu_baseline(blob, table, budget_s=8.0):
                       % (sn, cores, max(64, 16 * cores), s1, tn, t1)}
 
 
-def committed_counters(kernel, units):
+def committed_counters(kernel, units, spl=1):
     """PMC counters cannot be read from inside this process: `traffic` (HBM bytes per launch, FETCH_SIZE + WRITE_SIZE) and the
     issue-slot accounting of the dominant kernel come from the committed rocprofv3 --pmc passes of the same command at the same
     batch (tools/profile.sh -> tools/profile_summarize.py -> profiles/traffic.json and the per-kernel counters file it names)."""
     try:
         t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))[kernel]
-        if t['units_per_launch'] != units:
+        k = int(t.get('control_steps_per_launch', 1))                  # the committed passes ran launches of k control steps
+        if t['units_per_launch'] != units or k != spl:
             return None, None, None
         c = json.load(open(os.path.join(ROOT, t['counters_file'])))
         n_inst = c['SQ_INSTS_VALU'] + c['SQ_INSTS_SALU'] + c['SQ_INSTS_LDS']
-        issue = {'instructions_per_wave': n_inst / c['SQ_WAVES'], 'issue_slots_per_wave': c['SQ_WAVE_CYCLES'] / c['SQ_WAVES'], 'frac': n_inst / c['SQ_WAVE_CYCLES'],
+        issue = {'instructions_per_wave_per_control_step': n_inst / c['SQ_WAVES'] / k, 'issue_slots_per_wave_per_control_step': c['SQ_WAVE_CYCLES'] / c['SQ_WAVES'] / k,
+                 'control_steps_per_launch': k, 'frac': n_inst / c['SQ_WAVE_CYCLES'],
                  'source': t['counters_file'] + ' (rocprofv3 --pmc SQ_INSTS_*, SQ_WAVE_CYCLES in quad-cycles)'}
         return t['traffic_bytes'], issue, 'profiles/traffic.json <- %s (bytes per launch, FETCH_SIZE + WRITE_SIZE, uncorrected; see DESIGN.md 5.1)' % t['counters_file']
     except Exception:                    # noqa: BLE001
@@ -302,7 +304,7 @@ def main():
         # neglogp, R, V, r, mask) -- stated and added to the algorithmic bytes
         algo_bytes = ALGO_BYTES_PER_ENV_STEP + (4 * int(traj.buf.shape[-1]) if traj is not None else 0)
         achieved = (n * algo_bytes) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
-        traffic, issue, tsrc = committed_counters('pmc_step_kernel', n)
+        traffic, issue, tsrc = committed_counters('pmc_step_kernel', n, spl)
         out = {
             'metric': 'env-steps/sec (whole node), PMC tracking env, random policy',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -323,7 +325,8 @@ def main():
                        **({'unrolls_gathered': traj.n_gathered, 'unroll_row_floats': int(traj.buf.shape[-1]), 'gather_check': gather_check,
                            'gather': gather_stats} if traj is not None else {})},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': (achieved / HBM_PEAK_GBPS) if achieved else None, 'traffic': traffic, 'peak_measured_triad': triad,
+                         'frac': (achieved / HBM_PEAK_GBPS) if achieved else None, 'traffic': traffic, 'traffic_per_control_step': (traffic / spl) if traffic else None,
+                         'algorithmic_bytes_per_launch': n * algo_bytes * spl, 'peak_measured_triad': triad,
                          'traffic_source': tsrc,
                          'kernel': 'pmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
                          'kernel_avg_launch_ms': k_launch_ms, 'control_steps_per_launch': (k_steps / k_n) if k_n else None,
@@ -425,7 +428,7 @@ def main_epmc(args):
         elapsed = float(tt.item())
     if rank == 0:
         achieved = n * EPMC_ALGO_BYTES_PER_ENV_STEP / (k_ms * 1e-3) / 1e9
-        traffic, issue, tsrc = committed_counters('epmc_step_kernel', n)
+        traffic, issue, tsrc = committed_counters('epmc_step_kernel', n, spl)
         extra = {'cpu_baseline': cpu_baseline_env('epmc', epmc_env_config(args.element))} if (world == 1 and not args.no_cpu_baseline) else {}
         print(json.dumps({**extra, **{
             'metric': 'env-steps/sec (whole node), EPMC PlayGround env, random policy', 'value': world * n * args.steps / elapsed, 'unit': 'env-steps/s',
@@ -508,7 +511,7 @@ def main_sepmc(args):
         elapsed = float(tt.item())
     if rank == 0:
         achieved = 2 * n_arenas * SEPMC_ALGO_BYTES_PER_ROBOT_STEP / (k_ms * 1e-3) / 1e9
-        traffic, issue, tsrc = committed_counters('sepmc_step_kernel', 2 * n_arenas)
+        traffic, issue, tsrc = committed_counters('sepmc_step_kernel', 2 * n_arenas, spl)
         extra = {'cpu_baseline': cpu_baseline_env('sepmc', sepmc_env_config())} if (world == 1 and not args.no_cpu_baseline) else {}
         print(json.dumps({**extra, **{
             'metric': 'robot-steps/sec (whole node), SEPMC chase-tag env, random policy', 'value': world * 2 * n_arenas * args.steps / elapsed, 'unit': 'robot-steps/s',

@@ -73,27 +73,32 @@ for KERNEL, prefix, benchlog in (('pmc_step_kernel', '', 'bench.log'), ('epmc_st
     rl = bench['roofline']
     algo_unit = rl.get('algorithmic_bytes_per_env_step', rl.get('algorithmic_bytes_per_robot_step'))
     units = int(meta['grid']) // 64 * 4
+    spl = int(bench['config'].get('steps_per_launch', 1))          # control steps one launch runs (ll_step_random_n)
     counters['_kernel'] = meta
     counters['_notes'] = {
-        'units': 'mean per launch of %s (%d env rows, %d waves of 4 rows); SQ_*_CYCLES and SQ_ACTIVE/WAIT count quad-cycles summed over waves; '
+        'units': 'mean per launch of %s (%d env rows, %d waves of 4 rows, ' + str(spl) + ' control steps per launch); SQ_*_CYCLES and SQ_ACTIVE/WAIT count quad-cycles summed over waves; '
                  'FETCH_SIZE / WRITE_SIZE in KB' % (KERNEL, units, units // 4),
         'traffic_bytes_uncorrected': traffic,
         'traffic_note': 'MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads 1/2 of the bytes of a WIDE (16 B/lane) coalesced stream; this kernel '
                         'issues 4- and 8-byte per-lane loads, for which the guide gives no calibration, so the raw sum is reported and the read '
                         'side may be under-counted by up to 2x',
-        'algorithmic_bytes_per_launch': units * algo_unit,
+        'control_steps_per_launch': spl,
+        'algorithmic_bytes_per_launch': units * algo_unit * spl,
         'instructions_per_wave': (counters['SQ_INSTS_VALU'] + counters['SQ_INSTS_SALU'] + counters['SQ_INSTS_LDS']) / counters['SQ_WAVES'],
         'issue_slots_per_wave': counters['SQ_WAVE_CYCLES'] / counters['SQ_WAVES'],
+        'instructions_per_wave_per_control_step': (counters['SQ_INSTS_VALU'] + counters['SQ_INSTS_SALU'] + counters['SQ_INSTS_LDS']) / counters['SQ_WAVES'] / spl,
+        'issue_slots_per_wave_per_control_step': counters['SQ_WAVE_CYCLES'] / counters['SQ_WAVES'] / spl,
     }
     json.dump(counters, open(os.path.join(dst, '%s_%s_counters.json' % (tag, KERNEL)), 'w'), indent=1)
-    traffic_all[KERNEL] = {'units_per_launch': units, 'fetch_kb': counters['FETCH_SIZE'], 'write_kb': counters['WRITE_SIZE'], 'traffic_bytes': traffic,
+    traffic_all[KERNEL] = {'units_per_launch': units, 'control_steps_per_launch': spl, 'fetch_kb': counters['FETCH_SIZE'], 'write_kb': counters['WRITE_SIZE'], 'traffic_bytes': traffic,
                            'counters_file': 'profiles/%s_%s_counters.json' % (tag, KERNEL)}
     statsf = os.path.join(dst, '%s_%skernel_stats.csv' % (tag, prefix))
     for row in csv.DictReader(open(statsf)):
         if re.search(r'(^|[^a-z])' + KERNEL, row['Name']):
-            print('rocprofv3: %s  calls %s  avg %.1f us   | bench HIP events: %.1f us' % (row['Name'], row['Calls'], float(row['AverageNs']) / 1e3, rl['kernel_avg_ms'] * 1e3))
-    print('  traffic %.2f MB per launch (algorithmic %.2f MB); %.0f instructions on %.0f issue slots per wave; value %.3g %s' % (
-        traffic / 1e6, counters['_notes']['algorithmic_bytes_per_launch'] / 1e6, counters['_notes']['instructions_per_wave'], counters['_notes']['issue_slots_per_wave'],
+            print('rocprofv3: %s  calls %s  avg %.1f us per launch = %.2f us per control step  | bench HIP events: %.2f us per control step' % (
+                row['Name'], row['Calls'], float(row['AverageNs']) / 1e3, float(row['AverageNs']) / 1e3 / spl, rl['kernel_avg_ms'] * 1e3))
+    print('  traffic %.2f MB per launch (algorithmic %.2f MB); %.0f instructions on %.0f issue slots per wave per control step; value %.3g %s' % (
+        traffic / 1e6, counters['_notes']['algorithmic_bytes_per_launch'] / 1e6, counters['_notes']['instructions_per_wave_per_control_step'], counters['_notes']['issue_slots_per_wave_per_control_step'],
         bench['value'], bench['unit']))
 traffic_all['source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/profile.sh %s), bytes per launch, uncorrected' % tag
 json.dump(traffic_all, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
