@@ -77,6 +77,19 @@
 #define LLM_SPEC_WARM_START 10           /* factor applied to the previous substep's multipliers of persisting rows; default 0 = none.  ORACLE ONLY */
 #define LLM_SPEC_TRUNK_EDGES 11         /* 0 / 1   terrain edges under the body box are contact candidates; default 1.  ORACLE ONLY (a test instrument) */
 #define LLM_SPEC_SELECT_EPS 12          /* m       default LLM_SELECT_EPS.  ORACLE ONLY (a test instrument: parity cases on the rule's discontinuity) */
-#define LLM_SPEC_COUNT 13
+/* ---- round 3: Bullet published-algorithm audit.  ORACLE ONLY: each moves the spec towards what btMultiBodyConstraintSolver
+ * / btMultiBody do according to their published source, as far as it can be recalled here (PyBullet itself is absent); tools/deviation_table.py
+ * prices them with the trained policy, tools/deviation_sepmc.py on chase-tag episodes. */
+#define LLM_SPEC_FRICTION_MODE 13       /* 0 (spec): all t1 rows, then all t2 rows, box bounds.  1: after all normal rows, the two friction rows of a
+                                           contact adjacent (t1_c, t2_c), box bounds.  2: adjacent and solved together from one velocity, clipped to the
+                                           cone |(t1, t2)| <= mu * normal (resolveConeFrictionConstraintRows) */
+#define LLM_SPEC_ROW_ORDER 14           /* 0 (spec): slot-major (slot 0 of legs 0..3, slot 1, ...).  1: per body pair as a manifold would list them --
+                                           contacts sorted by link index, then candidate index */
+#define LLM_SPEC_MAX_COORD_VEL 15       /* btMultiBody::m_maxCoordinateVelocity: every generalized velocity clipped to +- this after the free update
+                                           and after the solve.  default 1e30 (none); Bullet: 100 */
+#define LLM_SPEC_LIMIT_ERP 16           /* ERP of the joint-limit rows; default < 0 = LLM_SPEC_ERP (btMultiBodyJointLimitConstraint uses the global erp) */
+#define LLM_SPEC_PAIR_FRICTION 17       /* SEPMC robot-robot rows: mu of two tangential rows per contact; default 0 (frictionless); Bullet: 0.5 x 0.5 */
+#define LLM_SPEC_MAX_PAIR 18            /* SEPMC robot-robot rows per robot pair; default 2, up to 4 (a manifold holds four points) */
+#define LLM_SPEC_COUNT 19
 
 #endif

@@ -549,18 +549,20 @@ static int aba(const OModel* M, const OKin* K, const double* qd, const double* t
 /* Spec overrides (include/llenv_model.h LLM_SPEC_*): process-wide, defaults = the constants of that header.  The engine has the same
  * switches (ll_set_spec_param); tools/deviation_table.py moves them in both to measure what each of this build's own choices is worth. */
 static double g_spec[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS};
+                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, 0.0, 0.0, 1e30, -1.0, 0.0, 2.0};
 int orc_set_spec_param(int id, double v) {
   if (id < 0 || id >= LLM_SPEC_COUNT) return -1;
   if (id == LLM_SPEC_MAX_CONTACTS_PER_LEG && !(v >= 1 && v <= LLM_MAX_CONTACTS_PER_LEG)) return -1;
   if (id == LLM_SPEC_MAX_SELF && !(v >= 0 && v <= LLM_MAX_SELF)) return -1;
+  if (id == LLM_SPEC_MAX_PAIR && !(v >= 0 && v <= 4)) return -1;
+  if (id == LLM_SPEC_FRICTION_MODE && !(v == 0 || v == 1 || v == 2)) return -1;
   g_spec[id] = v;
   return 0;
 }
 double orc_get_spec_param(int id) { return (id >= 0 && id < LLM_SPEC_COUNT) ? g_spec[id] : NAN; }
 void orc_reset_spec(void) {
   const double d[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS};
+                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, 0.0, 0.0, 1e30, -1.0, 0.0, 2.0};
   memcpy(g_spec, d, sizeof d);
 }
 #define g_link_damping (g_spec[LLM_SPEC_LINK_DAMPING])
@@ -958,6 +960,7 @@ typedef struct {
   int fric_of[MAXROWS], order[MAXROWS], lim_row[12], con_row[4][KC];
   int con_leg[MAXC], con_slot[MAXC], con_cand[MAXC];
   int ns, self_pair[LLM_MAX_SELF], self_row[LLM_MAX_SELF], self_rows;
+  int cone, first_self;       /* audit switch: the two friction rows of a ground / terrain contact are solved together inside the cone */
 } ORows;
 
 static int assemble_rows(const OModel* M, double dt, double mu_foot, const double* state, const double* tau_in, OSubstepDiag* diag,
@@ -993,6 +996,7 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
   }
   /* NOTE: d/dt(world velocity) = R (a_lin + w x v); expressed in the (frozen) body frame of this substep */
   for (int i = 0; i < 12; i++) nu[6 + i] = state[25 + i] + dt * acc[6 + i];
+  for (int i = 0; i < NDOF; i++) nu[i] = fmax(-g_spec[LLM_SPEC_MAX_COORD_VEL], fmin(g_spec[LLM_SPEC_MAX_COORD_VEL], nu[i]));   /* audit switch; default: no clip */
 
   /* ---- constraint rows --------------------------------------------------------------------------- */
   OContact C[MAXC];
@@ -1006,7 +1010,8 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
   for (int i = 0; i < 12; i++) {
     double dl = state[13 + i] - M->qlo[i], dh = M->qhi[i] - state[13 + i];
     double d = dl <= dh ? dl : dh, sgn = dl <= dh ? 1.0 : -1.0;
-    double bz = d > 0 ? d / dt : g_spec[LLM_SPEC_ERP] * d / dt;
+    const double lerp = g_spec[LLM_SPEC_LIMIT_ERP] >= 0 ? g_spec[LLM_SPEC_LIMIT_ERP] : g_spec[LLM_SPEC_ERP];
+    double bz = d > 0 ? d / dt : lerp * d / dt;
     lim_row[i] = -1;
     if (!(sgn * nu[6 + i] + bz < g_spec[LLM_SPEC_LIMIT_GATE])) continue;
     memset(J[nr], 0, sizeof J[nr]);
@@ -1141,10 +1146,29 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
   for (int j = 0; j < 3; j++)
     for (int l = 0; l < 4; l++)
       if (lim_row[3 * l + j] >= 0) W->order[no++] = lim_row[3 * l + j];
-  for (int r = 0; r < 3; r++)
-    for (int k = 0; k < KC; k++)
-      for (int l = 0; l < 4; l++)
-        if (con_row[l][k] >= 0) W->order[no++] = con_row[l][k] + r;
+  {
+    /* contacts in solve order: slot-major (spec), or per body pair as a manifold lists them (audit switch LLM_SPEC_ROW_ORDER) */
+    int oc[MAXC], noc = 0;
+    if (g_spec[LLM_SPEC_ROW_ORDER] > 0.5) {
+      for (int b = 0; b < NB; b++)
+        for (int cand = 0; cand < NCAND; cand++)
+          for (int c = 0; c < nc; c++)
+            if (C[c].body == b && C[c].cand == cand) oc[noc++] = con_row[C[c].leg][C[c].slot];
+    } else {
+      for (int k = 0; k < KC; k++)
+        for (int l = 0; l < 4; l++)
+          if (con_row[l][k] >= 0) oc[noc++] = con_row[l][k];
+    }
+    for (int i = 0; i < noc; i++) W->order[no++] = oc[i];                       /* all normal rows */
+    if (g_spec[LLM_SPEC_FRICTION_MODE] > 0.5) {
+      for (int i = 0; i < noc; i++) { W->order[no++] = oc[i] + 1; W->order[no++] = oc[i] + 2; }   /* t1, t2 of a contact adjacent */
+    } else {
+      for (int r = 1; r < 3; r++)
+        for (int i = 0; i < noc; i++) W->order[no++] = oc[i] + r;                /* all t1 rows, then all t2 rows */
+    }
+  }
+  W->cone = g_spec[LLM_SPEC_FRICTION_MODE] > 1.5;
+  W->first_self = nr - ns * self_rows;
   for (int c = 0; c < ns; c++)
     for (int r = 0; r < self_rows; r++) W->order[no++] = self_row[c] + r;
   W->nr = nr; W->no = no;
@@ -1166,8 +1190,24 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
 
 /* one Gauss-Seidel sweep over a robot's own rows (LR:261 numSolverIterations sweeps per substep) */
 static void sweep_rows(ORows* W) {
+  const double vmax = g_spec[LLM_SPEC_MAX_COORD_VEL];
   for (int oi = 0; oi < W->no; oi++) {
     const int r = W->order[oi];
+    if (W->cone && r < W->first_self && W->fric_of[r] == r - 1 && oi + 1 < W->no && W->order[oi + 1] == r + 1) {
+      /* btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows as published: both increments from the SAME velocity, the pair
+       * scaled back onto the cone |(t1, t2)| <= mu * (normal multiplier), then both applied */
+      const int r2 = r + 1, rn = W->fric_of[r];
+      double w1 = W->bias[r], w2 = W->bias[r2];
+      for (int k = 0; k < NDOF; k++) { w1 += W->J[r][k] * W->nu[k]; w2 += W->J[r2][k] * W->nu[k]; }
+      double t1 = W->lam[r] - w1 * W->dinv[r], t2 = W->lam[r2] - w2 * W->dinv[r2];
+      const double lim = W->mu_row[r] * W->lam[rn], len2 = t1 * t1 + t2 * t2;
+      if (len2 > lim * lim) { const double sc = lim > 0 ? lim / sqrt(len2) : 0.0; t1 *= sc; t2 *= sc; }
+      const double d1 = t1 - W->lam[r], d2 = t2 - W->lam[r2];
+      W->lam[r] = t1; W->lam[r2] = t2;
+      for (int k = 0; k < NDOF; k++) W->nu[k] += W->MiJt[r][k] * d1 + W->MiJt[r2][k] * d2;
+      oi++;
+      continue;
+    }
     double w = W->bias[r];
     for (int k = 0; k < NDOF; k++) w += W->J[r][k] * W->nu[k];
     double l_new = W->lam[r] - w * W->dinv[r];
@@ -1179,6 +1219,8 @@ static void sweep_rows(ORows* W) {
     W->lam[r] = l_new;
     for (int k = 0; k < NDOF; k++) W->nu[k] += W->MiJt[r][k] * d;
   }
+  if (vmax < 1e29)
+    for (int k = 0; k < NDOF; k++) W->nu[k] = fmax(-vmax, fmin(vmax, W->nu[k]));
 }
 
 static void integrate_state(const ORows* W, double dt, double* state) {

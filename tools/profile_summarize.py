@@ -76,8 +76,8 @@ for KERNEL, prefix, benchlog in (('pmc_step_kernel', '', 'bench.log'), ('epmc_st
     spl = int(bench['config'].get('steps_per_launch', 1))          # control steps one launch runs (ll_step_random_n)
     counters['_kernel'] = meta
     counters['_notes'] = {
-        'units': 'mean per launch of %s (%d env rows, %d waves of 4 rows, ' + str(spl) + ' control steps per launch); SQ_*_CYCLES and SQ_ACTIVE/WAIT count quad-cycles summed over waves; '
-                 'FETCH_SIZE / WRITE_SIZE in KB' % (KERNEL, units, units // 4),
+        'units': 'mean per launch of %s (%d env rows, %d waves of 4 rows, %d control steps per launch); SQ_*_CYCLES and SQ_ACTIVE/WAIT count quad-cycles summed over waves; '
+                 'FETCH_SIZE / WRITE_SIZE in KB' % (KERNEL, units, units // 4, spl),
         'traffic_bytes_uncorrected': traffic,
         'traffic_note': 'MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads 1/2 of the bytes of a WIDE (16 B/lane) coalesced stream; this kernel '
                         'issues 4- and 8-byte per-lane loads, for which the guide gives no calibration, so the raw sum is reported and the read '
