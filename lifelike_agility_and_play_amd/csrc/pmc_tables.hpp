@@ -310,6 +310,9 @@ inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
     case LLM_SPEC_SELECT_EPS:
       if (v != LLM_SELECT_EPS) return "this switch exists in the oracle only (a test instrument)";
       break;
+    case LLM_SPEC_FRICTION_MODE: case LLM_SPEC_ROW_ORDER: case LLM_SPEC_MAX_COORD_VEL: case LLM_SPEC_LIMIT_ERP: case LLM_SPEC_PAIR_FRICTION:
+    case LLM_SPEC_MAX_PAIR:
+      return "this switch exists in the oracle only (round-3 audit against Bullet's published solver: profiles/r03_deviation_table.md)";
     default: return "unknown spec parameter id";
   }
   return "";

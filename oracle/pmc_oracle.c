@@ -1322,7 +1322,8 @@ static int find_pair_contacts(const OModel* M, const OKin* K0, const OKin* K1, O
       for (int i = 0; i < 3; i++) { o->n[i] = d[i] / len; o->P[i] = 0.5 * ((c1[i] - r1 * o->n[i]) + (c2[i] + r2 * o->n[i])); }
     }
   int n = 0, taken[100] = {0};
-  for (int s = 0; s < 2; s++) {
+  const int max_pair = (int)(g_spec[LLM_SPEC_MAX_PAIR] + 0.5);      /* spec: 2 */
+  for (int s = 0; s < max_pair; s++) {
     int best = -1;
     double dmin = INFINITY;                  /* (cand[] is in pair-id order) */
     for (int i = 0; i < nc; i++)
@@ -1391,53 +1392,80 @@ int orc_substep_pair_model(const OModel* M, double dt, int n_iter, const double*
   double* st[2] = {state0, state1};
   if (assemble_rows(M, dt, mu_foot2[0], state0, tau0, NULL, T0, push0, &W[0])) return -1;
   if (assemble_rows(M, dt, mu_foot2[1], state1, tau1, NULL, T1, push1, &W[1])) return -1;
-  OPair PC[2];
+  /* Shared rows.  Spec: up to 2 contacts per robot pair, one frictionless row each.  Audit switches (deviation study only):
+   * LLM_SPEC_MAX_PAIR contacts (a manifold holds four), LLM_SPEC_PAIR_FRICTION = mu > 0 adds two tangential rows along btPlaneSpace1(n)
+   * per contact, bounded by mu times the normal multiplier, solved right after their normal row. */
+  OPair PC[4];
   const int np = find_pair_contacts(M, &W[0].K, &W[1].K, PC);
-  double Jp[2][2][NDOF], MJ[2][2][NDOF], dinv[2], bias[2], lam[2] = {0, 0};
+  const double mu_pair = g_spec[LLM_SPEC_PAIR_FRICTION];
+  const int prows = mu_pair > 0 ? 3 : 1;
+  static _Thread_local double Jp[12][2][NDOF], MJ[12][2][NDOF];
+  double dinv[12], bias[12], lam[12];
   for (int c = 0; c < np; c++) {
-    double dd = 0;
-    for (int side = 0; side < 2; side++) {
-      const OKin* K = &W[side].K;
-      const int b = PC[c].body[side];
-      double d3[3], ploc[3];
-      for (int i = 0; i < 3; i++) d3[i] = PC[c].P[i] - K->pw[b][i];
-      m3tv(K->Rw[b], d3, ploc);
-      for (int d = 0; d < NDOF; d++) {
-        double e[NDOF], t[3], vl[3], vw[3];
-        memset(e, 0, sizeof e);
-        e[d] = 1.0;
-        OKin Kd;
-        kinematics(M, st[side], e, &Kd);
-        v3cross(Kd.v[b], ploc, t);
-        for (int i = 0; i < 3; i++) vl[i] = Kd.v[b][3 + i] + t[i];
-        m3v(K->Rw[b], vl, vw);
-        Jp[c][side][d] = (side ? -1.0 : 1.0) * v3dot(PC[c].n, vw);       /* n points from robot 1 to robot 0 */
+    double dirs[3][3];
+    {
+      const double* nn = PC[c].n;
+      memcpy(dirs[0], nn, 24);
+      if (fabs(nn[2]) > 0.7071067811865475) {
+        double a = nn[1] * nn[1] + nn[2] * nn[2], kk = 1.0 / sqrt(a);
+        dirs[1][0] = 0; dirs[1][1] = -nn[2] * kk; dirs[1][2] = nn[1] * kk;
+        dirs[2][0] = a * kk; dirs[2][1] = -nn[0] * dirs[1][2]; dirs[2][2] = nn[0] * dirs[1][1];
+      } else {
+        double a = nn[0] * nn[0] + nn[1] * nn[1], kk = 1.0 / sqrt(a);
+        dirs[1][0] = -nn[1] * kk; dirs[1][1] = nn[0] * kk; dirs[1][2] = 0;
+        dirs[2][0] = -nn[2] * dirs[1][1]; dirs[2][1] = nn[2] * dirs[1][0]; dirs[2][2] = a * kk;
       }
-      for (int i = 0; i < NDOF; i++) {
-        double s = 0;
-        for (int k = 0; k < NDOF; k++) s += W[side].Minv[i][k] * Jp[c][side][k];
-        MJ[c][side][i] = s;
-      }
-      for (int k = 0; k < NDOF; k++) dd += Jp[c][side][k] * MJ[c][side][k];
     }
-    dinv[c] = 1.0 / dd;
-    bias[c] = PC[c].depth > 0 ? PC[c].depth / dt : fmax(LLM_ERP * PC[c].depth / dt, -LLM_MAX_DEPEN_SPEED);
-    if (pair_rows) { for (int i = 0; i < 3; i++) { pair_rows[8 * c + i] = PC[c].P[i]; pair_rows[8 * c + 3 + i] = PC[c].n[i]; } pair_rows[8 * c + 6] = PC[c].depth; pair_rows[8 * c + 7] = PC[c].id; }
+    for (int r = 0; r < prows; r++) {
+      const int q = 3 * c + r;
+      double dd = 0;
+      for (int side = 0; side < 2; side++) {
+        const OKin* K = &W[side].K;
+        const int b = PC[c].body[side];
+        double d3[3], ploc[3];
+        for (int i = 0; i < 3; i++) d3[i] = PC[c].P[i] - K->pw[b][i];
+        m3tv(K->Rw[b], d3, ploc);
+        for (int d = 0; d < NDOF; d++) {
+          double e[NDOF], t[3], vl[3], vw[3];
+          memset(e, 0, sizeof e);
+          e[d] = 1.0;
+          OKin Kd;
+          kinematics(M, st[side], e, &Kd);
+          v3cross(Kd.v[b], ploc, t);
+          for (int i = 0; i < 3; i++) vl[i] = Kd.v[b][3 + i] + t[i];
+          m3v(K->Rw[b], vl, vw);
+          Jp[q][side][d] = (side ? -1.0 : 1.0) * v3dot(dirs[r], vw);       /* n points from robot 1 to robot 0 */
+        }
+        for (int i = 0; i < NDOF; i++) {
+          double s = 0;
+          for (int k = 0; k < NDOF; k++) s += W[side].Minv[i][k] * Jp[q][side][k];
+          MJ[q][side][i] = s;
+        }
+        for (int k = 0; k < NDOF; k++) dd += Jp[q][side][k] * MJ[q][side][k];
+      }
+      dinv[q] = 1.0 / dd;
+      bias[q] = r ? 0.0 : (PC[c].depth > 0 ? PC[c].depth / dt : fmax(LLM_ERP * PC[c].depth / dt, -LLM_MAX_DEPEN_SPEED));
+      lam[q] = 0;
+    }
+    if (pair_rows && c < 2) { for (int i = 0; i < 3; i++) { pair_rows[8 * c + i] = PC[c].P[i]; pair_rows[8 * c + 3 + i] = PC[c].n[i]; } pair_rows[8 * c + 6] = PC[c].depth; pair_rows[8 * c + 7] = PC[c].id; }
   }
   for (int it = 0; it < n_iter; it++) {
     sweep_rows(&W[0]);
     sweep_rows(&W[1]);
-    for (int c = 0; c < np; c++) {
-      double w = bias[c];
-      for (int side = 0; side < 2; side++)
-        for (int k = 0; k < NDOF; k++) w += Jp[c][side][k] * W[side].nu[k];
-      double l_new = lam[c] - w * dinv[c];
-      if (l_new < 0) l_new = 0;
-      const double d = l_new - lam[c];
-      lam[c] = l_new;
-      for (int side = 0; side < 2; side++)
-        for (int k = 0; k < NDOF; k++) W[side].nu[k] += MJ[c][side][k] * d;
-    }
+    for (int c = 0; c < np; c++)
+      for (int r = 0; r < prows; r++) {
+        const int q = 3 * c + r;
+        double w = bias[q];
+        for (int side = 0; side < 2; side++)
+          for (int k = 0; k < NDOF; k++) w += Jp[q][side][k] * W[side].nu[k];
+        double l_new = lam[q] - w * dinv[q];
+        if (r == 0) { if (l_new < 0) l_new = 0; }
+        else { const double lim = mu_pair * lam[3 * c]; if (l_new > lim) l_new = lim; if (l_new < -lim) l_new = -lim; }
+        const double d = l_new - lam[q];
+        lam[q] = l_new;
+        for (int side = 0; side < 2; side++)
+          for (int k = 0; k < NDOF; k++) W[side].nu[k] += MJ[q][side][k] * d;
+      }
   }
   integrate_state(&W[0], dt, state0);
   integrate_state(&W[1], dt, state1);

@@ -231,6 +231,27 @@ def check_multi_step_launch(lib_path, sizes=(12,), k=5, n_launches=4, element=1)
         A.close(); B.close()
 
 
+def check_trained_policies_traverse(lib_path, n_envs=8, horizon=(360, 560)):
+    """SURVEY.md 8f-3 for the environmental level -- the only Bullet-facing check of this build's terrain contacts and 778 analytic rays: the
+    reference's TRAINED EPMC policies (data/models/environmental_level_{hurdle,cube}.model, trained against PyBullet; the hole checkpoint of
+    this snapshot does not unpickle) drive our PlayGround env closed-loop under the protocol of test_environmental_level_env.py: target speed
+    3 m/s, pushes, friction 0.4 .. 1, argmax code.  They run 10 m over hurdles / up and down 10 and 25 cm steps and reach the target.  The
+    LSTM cell is tpolicies' published lnlstm restated in oracle/epmc_policy.py; with any other gate order the same weights fall within 3 s
+    (tools/rollout_epmc_policy.py, profiles/r03_epmc_policy_rollout.txt), so a passing run vouches for cell and physics together."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import rollout_epmc_policy as R
+    out = {}
+    for which, hz in zip(('hurdle', 'cube'), horizon):
+        o = R.rollout(which, n_envs, hz, lib_path)
+        reached, fell = int(((o['why'] & 4) != 0).sum()), int(((o['why'] & 1) != 0).sum())
+        out[which] = dict(reached=reached, fell=fell, running=int(o['alive'].sum()), dist=float(o['dist'].mean()), steps=float(o['steps'].mean()))
+        assert reached >= 0.7 * n_envs and fell <= 0.15 * n_envs, (which, out[which])
+        assert o['dist'].mean() > 6.0, (which, out[which])                                      # metres along the course
+    return out
+
+
 def statics_to_records(rows):
     """ll_epmc_get_statics rows (creation order: a box, then its two edge cylinders if any) -> the kernel's box records."""
     recs, i = [], 0

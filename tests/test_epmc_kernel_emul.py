@@ -33,6 +33,10 @@ def test_free_running_invariants(emul_lib):
     assert ec.check_free_running_invariants(emul_lib, n_envs=16, n_steps=70) > 0
 
 
+def test_trained_reference_policies_traverse_our_terrain(emul_lib):
+    print(ec.check_trained_policies_traverse(emul_lib))
+
+
 def test_multi_step_launch(emul_lib):
     ec.check_multi_step_launch(emul_lib)
 

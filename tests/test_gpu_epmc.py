@@ -42,6 +42,11 @@ def test_larger_batch_build_against_the_oracle():
     assert out['n_terrain'] >= 30 and out['n_felt'] >= 20
 
 
+def test_trained_reference_policies_traverse_our_terrain():
+    out = ec.check_trained_policies_traverse(None, n_envs=256, horizon=(500, 700))
+    print(out)
+
+
 def test_multi_step_launch():
     """k control steps per launch == k launches, bit for bit; both kernel builds"""
     ec.check_multi_step_launch(None, sizes=(70, 4200), k=7, n_launches=3)

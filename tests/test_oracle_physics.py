@@ -306,3 +306,45 @@ def test_belly_landing_on_edges_does_not_sink(golden, orc, model_blob, mocap_tab
         assert np.abs(s[7:13]).max() < 0.05, (name, s[7:13])              # at rest
         assert ncs[-1] >= 3, (name, ncs[-1])                              # a support polygon, not a point
         assert B.fk_feet(s)[:, 2].min() > 0.1                             # the feet hang in the air: the belly carries the robot
+
+
+def test_bullet_audit_switches(golden, orc, model_blob, mocap_table):
+    """The round-3 audit switches of the oracle (include/llenv_model.h LLM_SPEC_FRICTION_MODE / ROW_ORDER / MAX_COORD_VEL / LIMIT_ERP) are
+    variants of the SAME constrained problem: a sliding robot obeys their friction bound (box for modes 0 / 1, cone for mode 2), a standing one
+    carries its weight under each of them, the orderings change individual multipliers but not the settled stance; and they default to off."""
+    from oracle import oracle as O
+    dt = 0.002
+    w = 13.000210501828224 * 9.80665
+    ref_z = None
+    try:
+        for spec in (dict(), dict(friction_mode=1), dict(friction_mode=2), dict(row_order=1), dict(friction_mode=2, row_order=1),
+                     dict(max_coord_vel=100.0), dict(limit_erp=0.1)):
+            O.reset_spec(); O.set_spec(**spec)
+            B = make_oracle_batch(orc, model_blob, mocap_table)
+            s = standing_state(golden)
+            s[2] += 0.025 - B.fk_feet(s)[:, 2].min()
+            s[7] = 1.0                                       # sliding start
+            tgt = s[13:25].copy()
+            fn = []
+            for k in range(1500):
+                tau = np.clip(50.0 * (tgt - s[13:25]) - 0.5 * s[25:37], -18, 18)
+                s, nc, lam, acc = B.substep(s, tau)
+                for c in range(nc):
+                    ln, l1, l2 = lam[12 + 3 * c: 15 + 3 * c]
+                    assert ln >= 0
+                    if spec.get('friction_mode') == 2:
+                        assert np.hypot(l1, l2) <= 0.45 * ln + 1e-12, spec         # inside the cone
+                    else:
+                        assert abs(l1) <= 0.45 * ln + 1e-12 and abs(l2) <= 0.45 * ln + 1e-12, spec
+                fn.append(lam[12:12 + 3 * nc:3].sum() / dt)
+            assert abs(s[7]) < 0.3, (spec, s[7])             # friction took the slide away (the soft stance still rocks a little)
+            assert abs(np.mean(fn[-300:]) - w) < 0.03 * w, spec
+            if ref_z is None:
+                ref_z = s[2]
+            assert abs(s[2] - ref_z) < 5e-3, (spec, s[2], ref_z)
+    finally:
+        O.reset_spec()
+    import ctypes
+    get = O.lib().orc_get_spec_param
+    get.restype = ctypes.c_double
+    assert get(13) == 0.0 and get(14) == 0.0 and get(15) == 1e30 and get(18) == 2.0

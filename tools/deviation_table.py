@@ -43,8 +43,16 @@ VARIANTS = [
     ('contact margin 0.01', dict(contact_margin=0.01), 'speculative rows start at 1 cm instead of 2 cm'),
     ('self friction 0.25', dict(self_friction=0.25), 'ORACLE ONLY: two tangential rows per leg-leg contact, mu = 0.5 x 0.5'),
     ('warm start 0.85', dict(warm_start=0.85), 'ORACLE ONLY: multipliers of persisting rows carried over x 0.85'),
+    # round 3: audit against the published order of operations of btMultiBodyConstraintSolver / btMultiBody (oracle switches)
+    ('friction rows adjacent', dict(friction_mode=1), 'ORACLE ONLY: after all normal rows, (t1, t2) of each contact adjacent instead of all t1 then all t2'),
+    ('friction cone-coupled', dict(friction_mode=2), 'ORACLE ONLY: (t1, t2) of a contact solved together from one velocity and clipped to the cone (resolveConeFrictionConstraintRows)'),
+    ('manifold row order', dict(row_order=1), 'ORACLE ONLY: contacts ordered per body pair (link index, candidate) instead of slot-major'),
+    ('cone + manifold order', dict(friction_mode=2, row_order=1), 'ORACLE ONLY: both of the above: the closest restatement of the published solver loop'),
+    ('max coordinate velocity 100', dict(max_coord_vel=100.0), 'ORACLE ONLY: btMultiBody::m_maxCoordinateVelocity clip of all 18 generalized velocities'),
+    ('limit-row ERP 0.1', dict(limit_erp=0.1), 'ORACLE ONLY: joint-limit rows with half the ERP (Bullet uses the global erp 0.2 = the spec)'),
+    ('cone + order + warm start', dict(friction_mode=2, row_order=1, warm_start=0.85), 'ORACLE ONLY'),
 ]
-ORACLE_ONLY = ('self_friction', 'warm_start')
+ORACLE_ONLY = ('self_friction', 'warm_start', 'friction_mode', 'row_order', 'max_coord_vel', 'limit_erp')
 
 
 def starts(table, n, seed):
