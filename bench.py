@@ -7,9 +7,13 @@
 
 One "step" = one 50 Hz control step (10 x 2 ms physics substeps + mocap lookup + obs + reward + termination +
 in-kernel re-seed of finished episodes) of 4096 environments per GPU on all 62 mocap clips, flat terrain, with
-the random policy a ~ N(0, e^-2) drawn on device.  Inputs are resident in HBM before the timed region.  Weak scaling:
-every rank owns 4096 envs; for N > 1 every rank also records its (obs, action, reward, done) rows and rank 0 gathers
-the trajectory batches over RCCL inside the timed region.
+the random policy a ~ N(0, e^-2) drawn on device.  The timed region runs ll_step_random_n: --steps-per-launch (default 32) complete
+control steps per kernel launch -- the random policy needs nothing from the host between two steps, so every wavefront walks its own
+envs through them without waiting for the slowest wave of each step (--steps-per-launch 1: one launch per control step).  Inputs are
+resident in HBM before the timed region.  Weak scaling: every rank owns 4096 envs; for N > 1 the step kernel also writes every
+transition into the env's unroll in the learner's wire format (X | A | neglogp | R | V | r | mask: 224 floats), TD(lambda) returns are
+filled in per 128-step unroll, and rank 0 gathers the unrolls over RCCL, double-buffered against the next unroll's
+steps, inside the timed region (--gather-mode blocking / none: the A/B legs of the overlap measurement).
 
 Rank 0 prints ONE JSON line (see the driver contract), including
   roofline     : HBM roofline of the step kernel from HIP-event timings taken on the engine's launch stream
@@ -211,6 +215,9 @@ def main():
     traj = gather.TrajectoryBuffer(eng, UNROLL, mode=args.gather_mode) if multi else None
     if traj is not None:
         traj.prepare(0)                                    # rank 0's world x 470 MB receive buffers exist before anything is timed
+        # measurement hook (tools/simd_sharing.sh): with a ONE-rank communicator RCCL's gather is a 0.3 ms local copy; repeated k times it
+        # stands in for the residency of an 8-rank gather (7 x 470 MB over xGMI: several ms) on the learner rank
+        traj.extra_gathers = int(os.environ.get('LL_BENCH_GATHER_REPEAT', '0'))
 
     n_done = [0]                                           # control steps executed so far == the engine's step index
     spl = max(1, args.steps_per_launch)

@@ -90,6 +90,11 @@
 #define LLM_SPEC_LIMIT_ERP 16           /* ERP of the joint-limit rows; default < 0 = LLM_SPEC_ERP (btMultiBodyJointLimitConstraint uses the global erp) */
 #define LLM_SPEC_PAIR_FRICTION 17       /* SEPMC robot-robot rows: mu of two tangential rows per contact; default 0 (frictionless); Bullet: 0.5 x 0.5 */
 #define LLM_SPEC_MAX_PAIR 18            /* SEPMC robot-robot rows per robot pair; default 2, up to 4 (a manifold holds four points) */
-#define LLM_SPEC_COUNT 19
+#define LLM_SPEC_FRICTION_DIRS 19       /* 0 (spec): friction directions btPlaneSpace1(n), fixed in the world (-y, +x on the ground).  1: the first direction along
+                                           the contact point's lateral velocity after the unconstrained update (Bullet's default rule in convertMultiBodyContact
+                                           when SOLVER_DISABLE_VELOCITY_DEPENDENT_FRICTION_DIRECTION is not set), the second = t1 x n; btPlaneSpace1 when it
+                                           does not slide.  With box bounds a sliding contact then gets at most mu N along its sliding direction instead of
+                                           up to sqrt(2) mu N diagonally.  Oracle and engine (ll_set_spec_param) */
+#define LLM_SPEC_COUNT 20
 
 #endif

@@ -61,6 +61,8 @@ typedef struct ll_sepmc_config {
   int32_t noise_enabled[4];        /* obs_randomization keys pos_x_bias, pos_y_bias, yaw_bias, pos_z_bias (CTG:207-210) */
   double noise_range[4][2];
   uint64_t seed;
+  double max_tau_robot1;           /* torque limit of robot 1 when the two differ (max_tau given as a [lo, hi] list: one draw per LeggedRobot, LR:244,
+                                      CTG:62-72); <= 0: the same as max_tau */
 } ll_sepmc_config;
 
 typedef struct ll_sepmc_engine ll_sepmc_engine;

@@ -75,7 +75,7 @@ class _ReferenceDraws(object):
         np.random.uniform(*self.rc['friction_range'])                          # CTG:61: the constructor's own friction draw
         self.max_tau = env_config.get('max_tau', 18.0)
         vals = [float(np.random.uniform(*self.max_tau)) if isinstance(self.max_tau, list) else self.max_tau for _ in range(2)]   # LR:244, one per robot
-        self.max_tau_value = vals[0]                                           # (the engine has one torque limit per arena: robot 0's)
+        self.max_tau_value, self.max_tau_robot1 = vals[0], vals[1]             # each robot is clipped with its own draw
 
     def _uniform(self, a, b):
         v = np.random.uniform(a, b)
@@ -150,7 +150,7 @@ class ChaseTagGame(object):
 
     def __init__(self, env_config):
         self._draws = _ReferenceDraws(env_config)                                 # the constructor's draws, in the reference's order
-        self._engine = _build_engine(dict(env_config, max_tau=self._draws.max_tau_value), 1, auto_reset=0)
+        self._engine = _build_engine(dict(env_config, max_tau=self._draws.max_tau_value, max_tau_robot1=self._draws.max_tau_robot1), 1, auto_reset=0)
         obs, act, self._prop = _spaces(env_config['prop_type'])
         self.n_max = 2
         self.observation_space, self.action_space = Tuple([obs] * 2), Tuple([act] * 2)    # CTG:125, :128-135

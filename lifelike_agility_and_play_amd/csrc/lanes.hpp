@@ -3,8 +3,9 @@
 // One environment is stepped by SIXTEEN lanes of a wavefront = one DPP row: lane = (leg, sub), leg = lane / 4 in
 // LegOrder FR, FL, HR, HL, sub = lane % 4.  A wave64 carries 4 environments.  The MAX quadruped is a star (base + 4
 // independent 3-joint chains):
-//   * leg-level work (FK, link inertias, bias forces, the 3x3 joint-space factor) is replicated in the 4 sub-lanes of
-//     a leg (free on a SIMD machine);
+//   * link-level work is SPLIT over the sub-lanes of a leg: sub-lane k < 3 owns link k + 1 (hip, thigh, shank) -- its sine / cosine, its
+//     inertia about the base origin, its bias force, its column of the joint-space inertia -- and composite quantities are suffix sums over
+//     the sub-lanes (DPP quad_perm); only what is genuinely per leg (the 3x3 Cholesky factor, Y = M_bl Lm^-T) is replicated four times;
 //   * the 28 contact candidates of a leg are split 7 per sub-lane; contact slot s of leg l and its three constraint
 //     rows live in the registers of lane (l, s); the limit row of joint j lives in lane (l, j);
 //   * whatever couples legs goes through the base as a reduction / broadcast over the 16-lane row (DPP row_ror /

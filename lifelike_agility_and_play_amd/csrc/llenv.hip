@@ -324,6 +324,12 @@ struct HipBackend {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, dev));
     simds = prop.multiProcessorCount * 4;             // four SIMDs per compute unit
+    // LL_SHARE_SIMDS=1: always launch the 256-register builds, also when the grid would fit one 512-register wavefront per SIMD.  A
+    // wavefront of the one-wave-per-SIMD builds owns its SIMD's whole register file, so any other kernel that is resident at the same
+    // time -- RCCL's gather on the learner rank -- DISPLACES step-kernel waves instead of sharing SIMDs with them, and the step launch
+    // ends later by the full residency of that kernel (measured with an RCCL stand-in: profiles/r03_simd_sharing.txt).
+    const char* sh = getenv("LL_SHARE_SIMDS");
+    if (sh && sh[0] == '1') simds = 0;
     stream = own;
   }
   ~HipBackend() {

@@ -81,7 +81,8 @@ struct StepParams {
   float erp, margin_dist, limit_gate, self_collision;   // self_collision: 1 = links of different legs collide (LR:212-217)
   float rw[5];              // normalised reward weights (PLE:365-370)
   float max_depen;          // cap on the penetration-recovery speed of a contact row (LLM_MAX_DEPEN_SPEED)
-  float self_margin, pad4;  // leg-leg capsule rows start within this distance (LLM_SELF_MARGIN)
+  float self_margin;        // leg-leg capsule rows start within this distance (LLM_SELF_MARGIN)
+  int32_t friction_dirs;    // LLM_SPEC_FRICTION_DIRS: 1 = first friction direction along the contact point's sliding velocity (default 0: btPlaneSpace1)
   int32_t max_contacts, max_self;   // deepest-K per leg (LLM_MAX_CONTACTS_PER_LEG), self-collision rows per robot (LLM_MAX_SELF)
   double dt_d, frame_step, policy_step, sample_factor;
   uint64_t seed;

@@ -350,6 +350,7 @@ struct Pmc {
   // push of randomizer/push_randomizer.py:72-77 -- applyExternalForce(linkIndex 0, LINK_FRAME): a force given in the FR hip
   // link's frame, acting at that link's centre of mass
   struct SubstepExtra {
+    float max_tau = 0.0f;   // > 0: this robot's own torque limit (SEPMC: the two robots of an arena may have different ones, LR:244); else P.max_tau
     float mu_foot;
     bool has_push;
     float push[3];
@@ -607,10 +608,11 @@ struct Pmc {
   }
   // LR:137-141: tau = kp (target - q) + kd (0 - qd), clipped to +-max_tau -- the `forces=` the reference hands to
   // setJointMotorControlArray(TORQUE_CONTROL) before every stepSimulation (golden G8; ll_probe_pd_torque runs exactly this)
-  static LL_HD void pd_torque(const L& ln, const StepParams& P, const F* q, const F* qd, const F* tgt, F* tau) {
+  static LL_HD void pd_torque(const L& ln, const StepParams& P, const F* q, const F* qd, const F* tgt, F* tau, float max_tau = 0.0f) {
+    const float mt = max_tau > 0.0f ? max_tau : P.max_tau;
     for (int j = 0; j < 3; j++) {
       F t = (tgt[j] - q[j]) * P.kp + (ln.lane_f(0.0f) - qd[j]) * P.kd;
-      tau[j] = lm::min_(lm::max_(t, ln.lane_f(-P.max_tau)), ln.lane_f(P.max_tau));
+      tau[j] = lm::min_(lm::max_(t, ln.lane_f(-mt)), ln.lane_f(mt));
     }
   }
   // the target of a control step: joint angles at its start + the policy's action (PLE:199-200), clipped to +-3 rad (LR:126-127)
@@ -650,7 +652,7 @@ struct Pmc {
 
     // --- PD torque with clip (LR:126-141) + URDF joint damping --------------------------------------------
     F tau[3];
-    pd_torque(ln, P, q, qd, tgt, tau);
+    pd_torque(ln, P, q, qd, tgt, tau, (PAIR && ex) ? ex->max_tau : 0.0f);
     for (int j = 0; j < 3; j++) tau[j] = tau[j] - ln.legc(legc, LC_JDAMP + j) * qd[j];
 
     // --- leg kinematics, velocities -------------------------------------------------------------------------
@@ -1054,6 +1056,22 @@ struct Pmc {
       V3l rr1 = Pb - k.p1, rr2 = Pb - k.p2, rr3 = Pb - k.p3;
       V3l a1v = mk3<F>(one, zero, zero);
       V3l d1 = scale(cross(a1v, rr1), on1), d2 = scale(cross(k.a2, rr2), on2), d3 = scale(cross(k.a2, rr3), on3);
+      if (P.friction_dirs) {
+        // LLM_SPEC_FRICTION_DIRS = 1 (deviation study; Bullet's default direction rule as published in convertMultiBodyContact): the first
+        // friction direction runs along the lateral velocity of the contact point after the unconstrained update, the second is t1 x n;
+        // a point that does not slide keeps btPlaneSpace1(n)
+        V3l wv = mk3<F>(ln.lane_f(xi[0]), ln.lane_f(xi[1]), ln.lane_f(xi[2]));
+        V3l vp = cross(wv, Pb) + scale(d1, qs[0]) + scale(d2, qs[1]) + scale(d3, qs[2]);
+        vp = mk3<F>(vp.x + xi[3], vp.y + xi[4], vp.z + xi[5]);
+        F vn = dot(vp, un);
+        V3l lat = vp - scale(un, vn);
+        F l2 = dot(lat, lat);
+        B slides = l2 > 1.1920929e-7f;
+        F il = lm::rsqrt_(lm::max_(l2, ln.lane_f(1e-30f)));
+        V3l a1 = scale(lat, il), a2 = cross(a1, un);
+        ut1 = mk3<F>(lm::sel(slides, a1.x, ut1.x), lm::sel(slides, a1.y, ut1.y), lm::sel(slides, a1.z, ut1.z));
+        ut2 = mk3<F>(lm::sel(slides, a2.x, ut2.x), lm::sel(slides, a2.y, ut2.y), lm::sel(slides, a2.z, ut2.z));
+      }
       // rows n = +z, t1 = -y, t2 = +x (world), expressed in F0
       contact_row(ln, rn, un, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, bias, cvalid);
       contact_row(ln, r1, ut1, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid);

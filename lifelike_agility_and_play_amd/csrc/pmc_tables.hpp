@@ -310,6 +310,9 @@ inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
     case LLM_SPEC_SELECT_EPS:
       if (v != LLM_SELECT_EPS) return "this switch exists in the oracle only (a test instrument)";
       break;
+    case LLM_SPEC_FRICTION_DIRS:
+      if (!(v == 0.0 || v == 1.0)) return "friction_dirs must be 0 or 1";
+      P.friction_dirs = (int)v; break;
     case LLM_SPEC_FRICTION_MODE: case LLM_SPEC_ROW_ORDER: case LLM_SPEC_MAX_COORD_VEL: case LLM_SPEC_LIMIT_ERP: case LLM_SPEC_PAIR_FRICTION:
     case LLM_SPEC_MAX_PAIR:
       return "this switch exists in the oracle only (round-3 audit against Bullet's published solver: profiles/r03_deviation_table.md)";
@@ -330,6 +333,10 @@ inline double pmc_get_spec_param(const StepParams& P, int id) {
     case LLM_SPEC_CONTACT_MARGIN: return P.margin_dist;
     case LLM_SPEC_TRUNK_EDGES: return 1.0;
     case LLM_SPEC_SELECT_EPS: return LLM_SELECT_EPS;
+    case LLM_SPEC_FRICTION_DIRS: return P.friction_dirs;
+    case LLM_SPEC_MAX_COORD_VEL: return 1e30;
+    case LLM_SPEC_LIMIT_ERP: return -1.0;
+    case LLM_SPEC_MAX_PAIR: return 2.0;
     default: return 0.0;
   }
 }

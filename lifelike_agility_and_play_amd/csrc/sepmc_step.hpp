@@ -48,6 +48,7 @@ struct SepmcParams {
   int32_t rand_cube, hurdle, hole, scr_on;
   int32_t robot_contacts, pad0;           // 0: the robots pass through each other (diagnostics)
   float cos_visible, control_spd;         // control_spd < 0: the episode's draw (CTG:264, :361)
+  float max_tau1, pad1;                   // robot 1's torque limit when it differs from P.max_tau (> 0), LR:244
   float* sp;                              // [rows][SEPMC_SP_STRIDE]
   float* info;                            // [rows][4] avg_spd0, avg_spd1, max_spd0, max_spd1 (CTG:404-409)
   float* vis_trace;                       // optional [rows][16][8]: from 3, to 3, blocked, valid -- by lane: leg * 4 + {foot, wheel, handle, base}
@@ -370,6 +371,7 @@ struct Sepmc {
       const float ddx = ln.peer_u(bs.p.x) - bs.p.x, ddy = ln.peer_u(bs.p.y) - bs.p.y, ddz = ln.peer_u(bs.p.z) - bs.p.z;
       ex.pair_active = !E.scr_state && S.robot_contacts && !PMC_ABL(2048) && (ddx * ddx + ddy * ddy + ddz * ddz < 1.5f * 1.5f);
       ex.pair_me = me;
+      ex.max_tau = (me == 1) ? S.max_tau1 : 0.0f;
     }
     const int nb = (int)sp[SP_N_BOXES];
     float* allb = E.boxes + (long)row * EPMC_MAX_BOXES * EPMC_BOX_WORDS;

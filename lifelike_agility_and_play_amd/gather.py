@@ -131,6 +131,7 @@ class TrajectoryBuffer(object):
         self.n_gathered = 0
         self._stall_events = []           # (before, after) event pairs around stream-side waits
         self.host_stall_s = 0.0           # host time spent blocked in wait()
+        self.extra_gathers = 0            # measurement hook: repeat every gather this many more times
         self._stage = None                # gloo test path: pinned staging buffers, side stream, worker thread
         self._thread = None
 
@@ -221,6 +222,8 @@ class TrajectoryBuffer(object):
                 self.last = self.outs
         elif rank == dst:
             self.work = dist.gather(local, gather_list=self.outs, dst=dst, group=group, async_op=True)
+            for _ in range(self.extra_gathers):             # measurement hook (bench.py LL_BENCH_GATHER_REPEAT): RCCL resident for longer
+                self.work = dist.gather(local, gather_list=self.outs, dst=dst, group=group, async_op=True)
             self.last = self.outs
         else:
             self.work = dist.gather(local, gather_list=None, dst=dst, group=group, async_op=True)

@@ -19,7 +19,7 @@ class LLSepmcConfig(C.Structure):   # struct ll_sepmc_config
                 ('solver_iterations', C.c_int32), ('friction_range', C.c_double * 2), ('push_enabled', C.c_int32), ('push_count0', C.c_int32),
                 ('push_interval_step', C.c_int32), ('push_duration_step', C.c_int32), ('horizontal_force', C.c_double * 2),
                 ('vertical_force', C.c_double * 2), ('push_strength_ratio', C.c_double), ('visible_angle', C.c_double), ('control_spd', C.c_double),
-                ('noise_enabled', C.c_int32 * 4), ('noise_range', (C.c_double * 2) * 4), ('seed', C.c_uint64)]
+                ('noise_enabled', C.c_int32 * 4), ('noise_range', (C.c_double * 2) * 4), ('seed', C.c_uint64), ('max_tau_robot1', C.c_double)]
 
 
 def make_sepmc_config(n_arenas, env_config, auto_reset=0, seed=0, device=0, solver_iterations=10):
@@ -34,8 +34,9 @@ def make_sepmc_config(n_arenas, env_config, auto_reset=0, seed=0, device=0, solv
     cfg.control_freq = float(env_config.get('control_freq', 25.0))
     cfg.kp, cfg.kd = float(env_config.get('kp', 50.0)), float(env_config.get('kd', 1.0))
     max_tau = env_config.get('max_tau', 18.0)
-    if isinstance(max_tau, (list, tuple)):                                           # CTG:288-289 redraws per episode; drawn once here
-        max_tau = float(np.random.uniform(*max_tau))
+    cfg.max_tau_robot1 = float(env_config.get('max_tau_robot1', 0.0))               # (the 1-arena shim passes the second robot's own draw, LR:244)
+    if isinstance(max_tau, (list, tuple)):                                           # one draw per LeggedRobot at construction (LR:244, CTG:62-72)
+        max_tau, cfg.max_tau_robot1 = float(np.random.uniform(*max_tau)), float(np.random.uniform(*max_tau))
     cfg.max_tau = float(max_tau)
     cfg.max_steps = int(env_config.get('max_steps', 1000))
     for i in range(5):

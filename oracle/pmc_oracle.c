@@ -549,7 +549,7 @@ static int aba(const OModel* M, const OKin* K, const double* qd, const double* t
 /* Spec overrides (include/llenv_model.h LLM_SPEC_*): process-wide, defaults = the constants of that header.  The engine has the same
  * switches (ll_set_spec_param); tools/deviation_table.py moves them in both to measure what each of this build's own choices is worth. */
 static double g_spec[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, 0.0, 0.0, 1e30, -1.0, 0.0, 2.0};
+                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, 0.0, 0.0, 1e30, -1.0, 0.0, 2.0, 0.0};
 int orc_set_spec_param(int id, double v) {
   if (id < 0 || id >= LLM_SPEC_COUNT) return -1;
   if (id == LLM_SPEC_MAX_CONTACTS_PER_LEG && !(v >= 1 && v <= LLM_MAX_CONTACTS_PER_LEG)) return -1;
@@ -562,7 +562,7 @@ int orc_set_spec_param(int id, double v) {
 double orc_get_spec_param(int id) { return (id >= 0 && id < LLM_SPEC_COUNT) ? g_spec[id] : NAN; }
 void orc_reset_spec(void) {
   const double d[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, 0.0, 0.0, 1e30, -1.0, 0.0, 2.0};
+                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, 0.0, 0.0, 1e30, -1.0, 0.0, 2.0, 0.0};
   memcpy(g_spec, d, sizeof d);
 }
 #define g_link_damping (g_spec[LLM_SPEC_LINK_DAMPING])
@@ -1041,6 +1041,24 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
         double a = nn[0] * nn[0] + nn[1] * nn[1], kk = 1.0 / sqrt(a);
         dirs[1][0] = -nn[1] * kk; dirs[1][1] = nn[0] * kk; dirs[1][2] = 0;
         dirs[2][0] = -nn[2] * dirs[1][1]; dirs[2][1] = nn[2] * dirs[1][0]; dirs[2][2] = a * kk;
+      }
+      if (g_spec[LLM_SPEC_FRICTION_DIRS] > 0.5) {
+        /* audit switch: t1 along the lateral velocity of the contact point (velocities after the unconstrained update, as Bullet converts
+         * contacts after stepVelocities), t2 = t1 x n */
+        OKin Kn;
+        double t[3], vl[3], vw[3];
+        kinematics(M, state, nu, &Kn);
+        v3cross(Kn.v[b], ploc, t);
+        for (int i = 0; i < 3; i++) vl[i] = Kn.v[b][3 + i] + t[i];
+        m3v(K.Rw[b], vl, vw);
+        const double vn = v3dot(vw, nn);
+        double lat[3] = {vw[0] - vn * nn[0], vw[1] - vn * nn[1], vw[2] - vn * nn[2]};
+        const double l2 = v3dot(lat, lat);
+        if (l2 > 1.1920929e-7) {
+          const double il = 1.0 / sqrt(l2);
+          for (int i = 0; i < 3; i++) dirs[1][i] = lat[i] * il;
+          v3cross(dirs[1], nn, dirs[2]);
+        }
       }
     }
     for (int r = 0; r < 3; r++) {

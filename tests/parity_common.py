@@ -62,7 +62,7 @@ def check_reset_against_goldens(golden, model_blob, table, lib_path):
     E.close()
 
 
-def run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True, sigma=SIGMA, policy=None, total_envs=None):
+def run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True, sigma=SIGMA, policy=None, total_envs=None, spec=None):
     """Step engine and oracle side by side from golden (clip, t0) starts with the same random actions.
     With resync the oracle is re-seeded with the engine's float32 state after every control step, so every step
     is an independent single-control-step comparison.
@@ -79,6 +79,9 @@ def run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed
     clip, t0 = golden['g2_clip'][pick], golden['g2_t0'][pick]
     E = make_engine(model_blob, table, N, lib_path)
     B = make_oracle_batch(orc, model_blob, table, n_envs=n_envs)
+    if spec:                                 # a spec switch that exists in both implementations (include/llenv_model.h LLM_SPEC_*)
+        E.set_spec(**spec)
+        orc.reset_spec(); orc.set_spec(**spec)
     E.reset(clip=clip, t0=t0)
     es0 = E.state()
     for i in range(n_envs):
@@ -123,11 +126,13 @@ def run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed
                 B.set_state(i, es[e].astype(np.float64))
         prev_obs = eo
     E.close()
+    if spec:
+        orc.reset_spec()
     return {k: (np.array(v) if isinstance(v, list) else v) for k, v in stats.items()}
 
 
-def check_single_step_parity(golden, orc, model_blob, table, lib_path, n_envs=32, n_steps=12, seed=7, total_envs=None):
-    st = run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True, total_envs=total_envs)
+def check_single_step_parity(golden, orc, model_blob, table, lib_path, n_envs=32, n_steps=12, seed=7, total_envs=None, spec=None):
+    st = run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True, total_envs=total_envs, spec=spec)
     assert len(st['config']) > n_envs * n_steps * 0.5
     # EVERY sample: configuration within 1e-4, velocities within 1e-3 of (1 + the env's largest joint rate); and at most 1 % of the env-steps
     # above 1e-4 in velocity (float32 rounding through a contact that switches on or off inside the step; 0.4 % measured)

@@ -435,6 +435,33 @@ def check_robot_robot_contact(lib_path):
     return dict(stack_gap=float(zs[-1]))
 
 
+def check_per_robot_torque_limit(lib_path, n_arenas=6):
+    """max_tau given as a [lo, hi] list draws one torque limit per LeggedRobot (LR:244, CTG:62-72): ll_sepmc_config.max_tau_robot1.  With large
+    actions, robot 0 of an engine with limits (16, 4) moves exactly like robot 0 of a (16, 16) engine and its robot 1 exactly like robot 1 of a
+    (4, 4) engine (arenas whose robots are too far apart to touch: they share nothing but the arena)."""
+    def run(t0, t1):
+        cfg = env_config((0, 0, 0))
+        cfg['max_tau'] = t0
+        cfg['max_tau_robot1'] = t1
+        E = make_engine(cfg, n_arenas, lib_path, seed=12)
+        E.reset()
+        s0 = E.state()
+        rng = np.random.default_rng(3)
+        for _ in range(3):
+            E.step_host((rng.normal(size=(n_arenas, 2, 12)) * 1.5).astype(np.float32))
+        out = E.state()
+        E.close()
+        return s0, out
+    s0, mixed = run(16.0, 4.0)
+    _, hi = run(16.0, 0.0)                              # 0: robot 1 shares robot 0's limit
+    _, lo = run(4.0, 4.0)
+    far = np.linalg.norm(s0[:, 0, 0:2] - s0[:, 1, 0:2], axis=1) > 1.6
+    assert far.sum() >= 2
+    np.testing.assert_array_equal(mixed[far, 0], hi[far, 0])
+    np.testing.assert_array_equal(mixed[far, 1], lo[far, 1])
+    assert np.abs(mixed[far, 1] - hi[far, 1]).max() > 1e-3            # the limit matters for these actions
+
+
 def check_multi_step_launch(lib_path, sizes=(6,), k=5, n_launches=4):
     """ll_sepmc_step_random_n(sigma, k) == k x {ll_sepmc_fill_random_actions(sigma); ll_sepmc_step()}, bit for bit (both robots' states and
     965-float observations, rewards, done, episode records, counters), with episodes timing out and re-seeding inside the launches."""

@@ -35,6 +35,17 @@ def test_single_control_step_parity(golden, orc, model_blob, mocap_table):
     print('config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
 
 
+def test_sliding_direction_friction_variant(golden, orc, model_blob, mocap_table):
+    """LLM_SPEC_FRICTION_DIRS = 1 (first friction direction along the contact point's sliding velocity, Bullet's published default rule: the one
+    audit switch that exists in the kernel too) against the oracle with the same switch.  The rule is discontinuous where a point stops
+    sliding (|v_lat|^2 = 1.2e-7: btPlaneSpace1 below, the velocity above) and ill-conditioned just above, so this VARIANT -- not the shipped
+    spec -- is held to the standing bars for 98 % of the samples and to 2e-2 for all."""
+    st = pc.run_lockstep(golden, orc, model_blob, mocap_table, None, 32, 12, 7, resync=True, spec=dict(friction_dirs=1))
+    c, v = np.asarray(st['config']), np.asarray(st['vel'])
+    print('friction_dirs=1: config err p50 / p98 / max', np.percentile(c, [50, 98, 100]), 'vel (rel)', np.percentile(v, [50, 98, 100]))
+    assert np.percentile(c, 98) < 1e-4 and np.percentile(v, 98) < 1e-3 and c.max() < 2e-2, (np.percentile(c, [98, 100]), np.percentile(v, [98, 100]))
+
+
 def test_free_running_episode_statistics(golden, orc, model_blob, mocap_table):
     print(pc.check_rollout_statistics(golden, orc, model_blob, mocap_table, None, n_envs=512))
 

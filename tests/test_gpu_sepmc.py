@@ -41,6 +41,10 @@ def test_larger_batch_build_against_the_oracle_gpu():
     print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=9, total_arenas=2048 + 128))
 
 
+def test_per_robot_torque_limit_gpu():
+    SC.check_per_robot_torque_limit(None, n_arenas=40)
+
+
 def test_multi_step_launch_gpu():
     """k control steps per launch == k launches, bit for bit; both kernel builds"""
     SC.check_multi_step_launch(None, sizes=(35, 2100), k=7, n_launches=3)

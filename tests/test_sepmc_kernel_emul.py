@@ -40,6 +40,10 @@ def test_robot_robot_contact(emul_lib):
     print(SC.check_robot_robot_contact(emul_lib))
 
 
+def test_per_robot_torque_limit(emul_lib):
+    SC.check_per_robot_torque_limit(emul_lib)
+
+
 def test_multi_step_launch(emul_lib):
     SC.check_multi_step_launch(emul_lib)
 
