@@ -555,7 +555,7 @@ int orc_set_spec_param(int id, double v) {
   if (id == LLM_SPEC_MAX_CONTACTS_PER_LEG && !(v >= 1 && v <= LLM_MAX_CONTACTS_PER_LEG)) return -1;
   if (id == LLM_SPEC_MAX_SELF && !(v >= 0 && v <= LLM_MAX_SELF)) return -1;
   if (id == LLM_SPEC_MAX_PAIR && !(v >= 0 && v <= 4)) return -1;
-  if (id == LLM_SPEC_FRICTION_MODE && !(v == 0 || v == 1 || v == 2)) return -1;
+  if (id == LLM_SPEC_FRICTION_MODE && !(v == 0 || v == 1 || v == 2 || v == 3)) return -1;
   g_spec[id] = v;
   return 0;
 }
@@ -960,7 +960,7 @@ typedef struct {
   int fric_of[MAXROWS], order[MAXROWS], lim_row[12], con_row[4][KC];
   int con_leg[MAXC], con_slot[MAXC], con_cand[MAXC];
   int ns, self_pair[LLM_MAX_SELF], self_row[LLM_MAX_SELF], self_rows;
-  int cone, first_self;       /* audit switch: the two friction rows of a ground / terrain contact are solved together inside the cone */
+  int cone, ellipse, first_self;       /* audit switch: the two friction rows of a ground / terrain contact are solved together inside the cone */
 } ORows;
 
 static int assemble_rows(const OModel* M, double dt, double mu_foot, const double* state, const double* tau_in, OSubstepDiag* diag,
@@ -1178,14 +1178,15 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
           if (con_row[l][k] >= 0) oc[noc++] = con_row[l][k];
     }
     for (int i = 0; i < noc; i++) W->order[no++] = oc[i];                       /* all normal rows */
-    if (g_spec[LLM_SPEC_FRICTION_MODE] > 0.5) {
+    if (g_spec[LLM_SPEC_FRICTION_MODE] > 0.5 && g_spec[LLM_SPEC_FRICTION_MODE] < 2.5) {
       for (int i = 0; i < noc; i++) { W->order[no++] = oc[i] + 1; W->order[no++] = oc[i] + 2; }   /* t1, t2 of a contact adjacent */
     } else {
       for (int r = 1; r < 3; r++)
         for (int i = 0; i < noc; i++) W->order[no++] = oc[i] + r;                /* all t1 rows, then all t2 rows */
     }
   }
-  W->cone = g_spec[LLM_SPEC_FRICTION_MODE] > 1.5;
+  W->cone = g_spec[LLM_SPEC_FRICTION_MODE] > 1.5 && g_spec[LLM_SPEC_FRICTION_MODE] < 2.5;
+  W->ellipse = g_spec[LLM_SPEC_FRICTION_MODE] > 2.5;
   W->first_self = nr - ns * self_rows;
   for (int c = 0; c < ns; c++)
     for (int r = 0; r < self_rows; r++) W->order[no++] = self_row[c] + r;
@@ -1230,7 +1231,13 @@ static void sweep_rows(ORows* W) {
     for (int k = 0; k < NDOF; k++) w += W->J[r][k] * W->nu[k];
     double l_new = W->lam[r] - w * W->dinv[r];
     double l_lo = W->lo[r], l_hi = W->hi[r];
-    if (W->fric_of[r] >= 0) { l_hi = W->mu_row[r] * W->lam[W->fric_of[r]]; l_lo = -l_hi; }
+    if (W->fric_of[r] >= 0) {
+      l_hi = W->mu_row[r] * W->lam[W->fric_of[r]];
+      /* mode 3: the spec's round structure (all t1, then all t2) with the t2 bound shrunk to what the t1 multiplier leaves of the cone:
+       * |t2| <= sqrt((mu N)^2 - t1^2).  Not Bullet's coupled clip, but the same admissible set, and it fits the kernel's rounds. */
+      if (W->ellipse && r < W->first_self && W->fric_of[r] == r - 2) { const double t1 = W->lam[r - 1]; l_hi = sqrt(fmax(l_hi * l_hi - t1 * t1, 0.0)); }
+      l_lo = -l_hi;
+    }
     if (l_new < l_lo) l_new = l_lo;
     if (l_new > l_hi) l_new = l_hi;
     const double d = l_new - W->lam[r];

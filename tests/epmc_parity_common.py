@@ -320,7 +320,7 @@ def score_case(out, B, orc, es_i, s0, act, push_trace, mu, near):
     return s
 
 
-def assert_within_bars(out, cfg_bar=1e-4, vel_bar=1e-3, factor=4.0, max_ill=0.03):
+def assert_within_bars(out, cfg_bar=1e-4, vel_bar=1e-3, factor=4.0, max_ill=0.03, max_tie=0.04):
     """Every case within the bars of flat-ground motion (1e-4 configuration, 1e-3 relative velocity) -- unless the case is ill-conditioned in
     the ORACLE itself: a stick-slip or make-and-break contact step in which merely rounding the oracle's state to float32 between substeps
     moves its own result by more than a quarter of the bar.  Such a case (at most `max_ill` of the cases) must stay within `factor` times
@@ -331,6 +331,11 @@ def assert_within_bars(out, cfg_bar=1e-4, vel_bar=1e-3, factor=4.0, max_ill=0.03
     bar_c, bar_v = np.maximum(cfg_bar, factor * cc), np.maximum(vel_bar, factor * cv)
     ill = (bar_c > cfg_bar) | (bar_v > vel_bar)
     out['n_ill_conditioned'], out['n_on_selection_tie'] = int(ill.sum()), int(np.sum(out['on_tie']))
+    # the two allowances are counted, printed and capped, so that they cannot quietly absorb a regression: ill-conditioned cases at most
+    # max_ill of the cases (observed: 1 of 32 standing / 2 of 32 dropped), cases on the deepest-K rule's discontinuity at most max_tie (observed: 0 / 3 of 32)
+    print('assert_within_bars: %d cases, %d ill-conditioned in the oracle itself (cap %d), %d on a selection tie (cap %d); worst config %.2e, velocity %.2e'
+          % (len(ill), ill.sum(), max(2, int(max_ill * len(ill))), out['n_on_selection_tie'], max(2, int(max_tie * len(ill))), c.max(), v.max()))
+    assert out['n_on_selection_tie'] <= max(2, int(max_tie * len(ill))), out['n_on_selection_tie']
     assert ill.sum() <= max(2, max_ill * len(ill)), (ill.sum(), len(ill))
     assert (c < bar_c).all(), (np.sort(c)[-5:], cc[np.argsort(c)[-5:]])
     assert (v < bar_v).all(), (np.sort(v)[-5:], cv[np.argsort(v)[-5:]])
@@ -441,7 +446,7 @@ def check_trunk_on_edges_against_oracle(lib_path, n_envs=16, seed=5):
                 out['n_edge_felt'] += 1
         E.close()
     assert out['n_edge_felt'] >= 8, out['n_edge_felt']
-    assert_within_bars(out, max_ill=0.07)         # (bodies dropped onto edges: more make-and-break steps than among standing robots)
+    assert_within_bars(out, max_ill=0.07, max_tie=0.12)         # (bodies dropped flat onto edges: more make-and-break steps and more equal depths than among standing robots)
     return out
 
 

@@ -212,10 +212,13 @@ def check_rollout_statistics(golden, orc, model_blob, table, lib_path, n_envs=25
     fall = {k: float(((why[k] & capi.DONE_FALL) != 0).mean()) for k in 'eo'}
     out = dict(mean_len=(float(le.mean()), float(lo.mean())), ks_p=float(ks.pvalue), reward=(float(me), float(mo)), fall=fall,
                first_steps_equal=float((le == lo).mean()))
-    assert ks.pvalue > 0.01, out
-    assert abs(le.mean() - lo.mean()) < 0.08 * lo.mean() + 2.0, out
-    assert abs(me - mo) < 0.01, out
-    assert abs(fall['e'] - fall['o']) < 0.08, out
+    # bars at what is measured (MI355X, 512 envs: 98 % of the episodes end at the very same step, mean length 58.96 vs 59.09, reward 0.1359 vs
+    # 0.1357, falls 7.6 % vs 7.6 %; CPU emulation, 64 envs: 100 %) with room for one in ten episodes to drift -- not at what chaos would allow
+    assert out['first_steps_equal'] >= 0.9, out
+    assert ks.pvalue > 0.5, out
+    assert abs(le.mean() - lo.mean()) < 0.03 * lo.mean(), out
+    assert abs(me - mo) < 0.003, out
+    assert abs(fall['e'] - fall['o']) < 0.03, out
     return out
 
 
