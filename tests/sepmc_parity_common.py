@@ -435,6 +435,25 @@ def check_robot_robot_contact(lib_path):
     return dict(stack_gap=float(zs[-1]))
 
 
+def check_trained_policy_plays_chase_tag(lib_path, n_arenas=4, horizon=380, min_caught=0.25):
+    """SURVEY.md 8f-3 for the strategic level -- the only Bullet-facing check of this build's robot-robot contact model: the reference's TRAINED
+    SEPMC policy (data/models/strategic_level.model, trained against PyBullet; NumPy restatement oracle/sepmc_policy.py) drives BOTH robots of our
+    chase-tag arenas under the protocol of test_strategic_level_env.py.  The robots run at the commanded 1 m/s, find each other across the 5 m
+    arena and the games end the way they are meant to: by a catch -- a leg of one robot touching the other -- not by falls or time-outs."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import rollout_sepmc_policy as R
+    o = R.rollout(n_arenas, horizon, lib_path)
+    why = o['why']
+    out = dict(caught=float(((why & 8) != 0).mean()), fell=float(((why & 1) != 0).mean()), running=float(o['alive'].mean()),
+               speed=float((o['path'] / (o['steps'][:, None] * 0.02)).mean()), closest=float(np.median(o['closest'])), steps=float(o['steps'].mean()),
+               touch_frac=float(o['touch_frac']))
+    assert out['caught'] >= min_caught and out['fell'] <= 0.15, out
+    assert 0.4 < out['speed'] < 1.5 and out['closest'] < 1.2, out
+    return out
+
+
 def check_per_robot_torque_limit(lib_path, n_arenas=6):
     """max_tau given as a [lo, hi] list draws one torque limit per LeggedRobot (LR:244, CTG:62-72): ll_sepmc_config.max_tau_robot1.  With large
     actions, robot 0 of an engine with limits (16, 4) moves exactly like robot 0 of a (16, 16) engine and its robot 1 exactly like robot 1 of a

@@ -41,6 +41,10 @@ def test_larger_batch_build_against_the_oracle_gpu():
     print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=9, total_arenas=2048 + 128))
 
 
+def test_trained_reference_policy_plays_chase_tag_gpu():
+    print(SC.check_trained_policy_plays_chase_tag(None, n_arenas=128, horizon=700, min_caught=0.6))
+
+
 def test_per_robot_torque_limit_gpu():
     SC.check_per_robot_torque_limit(None, n_arenas=40)
 

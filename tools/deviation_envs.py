@@ -7,9 +7,8 @@ contact under the reference's trained EPMC policies, robot-robot contact in chas
 The ORACLE legs run the float64 CPU envs (oracle/free_run.py: NumPy env logic + analytic rays + the C physics) with one audit switch of
 include/llenv_model.h moved at a time, episodes spread over the host cores; the ENGINE leg runs the spec as shipped on the GPU at full size.
 EPMC: the trained hurdle / cube policies (oracle/epmc_policy.py), protocol of test_environmental_level_env.py; scored by how episodes end
-(reached the target / fell), distance, length.  SEPMC: no trained two-robot policy can be restated (sepmc_net + opponent model), so the
-random policy a ~ N(0, e^-2) of the benchmark: how episodes end (catch / robot 0 fell / time-out), their length, and the fraction of arena
-steps with robot-robot contact."""
+(reached the target / fell), distance, length.  SEPMC: the trained strategic_level policy on both robots (oracle/sepmc_policy.py): how games end (catch / robot 0 fell / time-out), how long a catch takes,
+and the fraction of arena steps with robot-robot contact."""
 import argparse
 import math
 import os
@@ -68,28 +67,34 @@ def _epmc_episode(args):
 
 
 def _sepmc_episode(args):
+    """one arena of the oracle env, BOTH robots driven by the reference's trained SEPMC policy (oracle/sepmc_policy.py), until max_steps
+    arena-steps are spent: (length, reason, steps with robot-robot contact, closest approach) per episode"""
     spec, seed, max_steps = args
+    import rollout_sepmc_policy as R
     from oracle import oracle as orc, free_run as FR, epmc_oracle as EO
+    from oracle.sepmc_policy import SepmcPolicy
     from lifelike_agility_and_play_amd import epmc_capi, mocap, urdf_model
-    from env_configs import sepmc_env_config
     orc.reset_spec(); orc.set_spec(**spec)
-    cfg = sepmc_env_config(0)
+    cfg = R.env_config(1)
     run = FR.SepmcFreeRun(cfg, urdf_model.default_model_blob(), mocap.load_mocap('', 0.02), epmc_capi.default_init_state(), seed=seed)
-    rng = np.random.default_rng(1000 + seed)
-    sg = math.exp(-2.0)
-    out = []                                     # (length, reason, steps with robot-robot contact) per episode until max_steps arena-steps are spent
+    pol = SepmcPolicy(os.path.join(ROOT, 'tests', 'golden', 'sepmc_policy.npz'), 2)
+    out = []
     left = max_steps
     while left > 0:
-        run.reset()
-        n, touch, why = 0, 0, 0
+        obs = run.reset()
+        pol.reset()
+        n, touch, why, closest = 0, 0, 0, 1e9
         while left > 0:
-            o = run.step([rng.normal(size=12) * sg, rng.normal(size=12) * sg])
+            a = pol.act(np.asarray(obs, np.float64).reshape(2, -1))
+            o = run.step([a[0], a[1]])
+            obs = o[0]
             n += 1; left -= 1
             touch += int(run.touch[0][2] or run.touch[1][2])
+            closest = min(closest, float(np.linalg.norm(run.env.states[0][0:2] - run.env.states[1][0:2])))
             if o[2]:
                 why = 1 if EO.check_fall(run.env.states[0][3:7]) else (2 if run.env.counter >= run.env.max_steps else 8)
                 break
-        out.append((n, why, touch))
+        out.append((n, why, touch, closest))
     return out
 
 
@@ -104,7 +109,7 @@ def main():
     ap.add_argument('env', choices=['epmc', 'sepmc'])
     ap.add_argument('--episodes', type=int, default=64); ap.add_argument('--horizon', type=int, default=420)
     ap.add_argument('--arenas', type=int, default=96); ap.add_argument('--steps', type=int, default=400)
-    ap.add_argument('--engine-envs', type=int, default=2048); ap.add_argument('--engine-arenas', type=int, default=2048); ap.add_argument('--engine-steps', type=int, default=1000)
+    ap.add_argument('--engine-envs', type=int, default=2048); ap.add_argument('--engine-arenas', type=int, default=512); ap.add_argument('--engine-steps', type=int, default=1000)
     ap.add_argument('--procs', type=int, default=0); ap.add_argument('--only', default=''); ap.add_argument('--no-oracle', action='store_true')
     args = ap.parse_args()
     import bench
@@ -140,31 +145,20 @@ def main():
                 cells += ['%.3f' % (why == 4).mean(), '%.3f' % (why == 1).mean(), '%.2f' % dist.mean(), '%.1f' % st.mean()]
             print('| oracle, %s | %s |' % (label, ' | '.join(cells)), flush=True)
     else:
-        print('# SEPMC: robot-robot contact choices on chase-tag episodes (random policy)')
+        import rollout_sepmc_policy as RS
+        print('# SEPMC: robot-robot contact choices on chase-tag games played by the reference\'s trained policy')
         print()
-        print('BASELINE config 5 (5 m arena, no elements, pushes), a ~ N(0, e^-2).  oracle = float64 CPU env, %d arenas x %d arena-steps per variant; '
-              'engine = the HIP library as shipped, %d arenas x %d steps.  tools/deviation_envs.py.' % (args.arenas, args.steps, args.engine_arenas, args.engine_steps))
+        print('Protocol of test_strategic_level_env.py (5 m arena, no elements, control_spd 1.0, friction 0.4 .. 1, pushes; the trained strategic_level '
+              'policy on BOTH robots, argmax).  oracle = float64 CPU env, %d arenas x %d arena-steps per variant; engine = the HIP library as shipped, '
+              '%d arenas, horizon %d.  tools/deviation_envs.py.' % (args.arenas, args.steps, args.engine_arenas, args.engine_steps))
         print()
-        print('| simulator / variant | episodes | caught | robot 0 fell | timed out | mean length | arena-steps with robot-robot contact |')
+        print('| simulator / variant | episodes | caught | robot 0 fell | timed out | mean length (steps to the catch) | arena-steps with robot-robot contact |')
         print('|---|---|---|---|---|---|---|')
         if have_gpu:
-            from lifelike_agility_and_play_amd import sepmc_capi, urdf_model
-            from env_configs import sepmc_env_config
-            E = sepmc_capi.SepmcEngine(sepmc_capi.make_sepmc_config(args.engine_arenas, sepmc_env_config(0), auto_reset=1, seed=3), urdf_model.default_model_blob())
-            E.reset()
-            n_ep = np.zeros(4, int); length = []; cur = np.zeros(args.engine_arenas, int); touch = 0
-            for t in range(args.engine_steps):
-                E.fill_random_actions(math.exp(-2.0)); E.step()
-                _, d, w = E.reward_done()
-                ep = E.episode()
-                cur += 1
-                touch += int(((ep['who0'] == 4) | (ep['who_taker'] == 3) | (ep['who_taker'] == 4) | (ep['who0'] == 3)).sum())
-                for bit, k in ((8, 0), (1, 1), (2, 2)):
-                    n_ep[k] += int((d & ((w & bit) != 0)).sum())
-                length += cur[d].tolist(); cur[d] = 0
-            tot = max(1, int(n_ep[:3].sum()))
-            print('| engine (float32), spec | %d | %.4f | %.4f | %.4f | %.1f | %.4f |' % (tot, n_ep[0] / tot, n_ep[1] / tot, n_ep[2] / tot, np.mean(length), touch / (args.engine_arenas * args.engine_steps)), flush=True)
-            E.close()
+            o = RS.rollout(args.engine_arenas, args.engine_steps)
+            why = o['why']; fin = why != 0; tot = max(1, int(fin.sum()))
+            print('| engine (float32), spec | %d | %.4f | %.4f | %.4f | %.1f | %.4f |' % (tot, ((why & 8) != 0).sum() / tot, ((why & 1) != 0).sum() / tot, ((why & 2) != 0).sum() / tot,
+                                                                                      o['steps'][fin].mean() if fin.any() else float('nan'), o['touch_frac']), flush=True)
         for label, spec in SEPMC_VARIANTS:
             if args.no_oracle or (args.only and args.only not in label):
                 continue

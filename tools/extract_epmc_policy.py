@@ -21,3 +21,8 @@ if __name__ == '__main__':
         dst = os.path.join(root, 'tests', 'golden', 'epmc_policy_%s.npz' % el)
         np.savez_compressed(dst, **{'w%d' % i: np.asarray(m[i], dtype=np.float32) for i in keep})
         print('wrote', dst, os.path.getsize(dst))
+    m = _U(open('/root/reference/data/models/strategic_level.model', 'rb')).load().model
+    assert len(m) == 152
+    dst = os.path.join(root, 'tests', 'golden', 'sepmc_policy.npz')
+    np.savez_compressed(dst, **{'w%d' % i: np.asarray(m[i], dtype=np.float32) for i in [0, 1] + list(range(51, 152))})
+    print('wrote', dst, os.path.getsize(dst))
