@@ -219,6 +219,27 @@ def main():
         # stands in for the residency of an 8-rank gather (7 x 470 MB over xGMI: several ms) on the learner rank
         traj.extra_gathers = int(os.environ.get('LL_BENCH_GATHER_REPEAT', '0'))
 
+    def measure_triad():
+        """the nominal HBM figure next to a device triad measured on this box (a = b + s * c on 3 x 1 GiB, torch's own kernel: a
+        calibration of the roofline's denominator, not part of the product)"""
+        if not (rank == 0 and world == 1 and tc):
+            return None
+        try:
+            nel = 1 << 28
+            b_ = torch.ones(nel, device='cuda', dtype=torch.float32); c_ = torch.ones(nel, device='cuda', dtype=torch.float32); a_ = torch.empty_like(b_)
+            for _ in range(3):
+                torch.add(b_, c_, alpha=1.5, out=a_)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                torch.add(b_, c_, alpha=1.5, out=a_)
+            e1.record(); torch.cuda.synchronize()
+            return 10 * 3 * nel * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        except Exception:                # noqa: BLE001
+            return None
+    triad_first = os.environ.get('LL_BENCH_TRIAD_FIRST', '0') == '1'
+    triad = measure_triad() if triad_first else None
+
     n_done = [0]                                           # control steps executed so far == the engine's step index
     spl = max(1, args.steps_per_launch)
     if traj is not None and UNROLL % spl:
@@ -285,24 +306,8 @@ def main():
                 gather_check = 'ok' if got_sig == sigs and len({tuple(x) for x in sigs}) == world else 'MISMATCH %r vs %r' % (got_sig, sigs)
     counters = eng.counters()
     ep_hist = [int(x) for x in eng.episode_histogram()]
-    triad = None
-    if rank == 0 and world == 1 and tc:
-        # the nominal HBM figure next to a device triad measured on this box (a = b + s * c on 3 x 1 GiB, torch's own kernel:
-        # a calibration of the denominator, not part of the product)
-        try:
-            nel = 1 << 28
-            b_ = torch.ones(nel, device='cuda', dtype=torch.float32); c_ = torch.ones(nel, device='cuda', dtype=torch.float32); a_ = torch.empty_like(b_)
-            for _ in range(3):
-                torch.add(b_, c_, alpha=1.5, out=a_)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                torch.add(b_, c_, alpha=1.5, out=a_)
-            e1.record(); torch.cuda.synchronize()
-            triad = 10 * 3 * nel * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-            del a_, b_, c_
-        except Exception:                # noqa: BLE001
-            triad = None
+    if triad is None and not triad_first:
+        triad = measure_triad()
 
     if rank == 0:
         total_env_steps = world * n * args.steps

@@ -1233,9 +1233,13 @@ static void sweep_rows(ORows* W) {
     double l_lo = W->lo[r], l_hi = W->hi[r];
     if (W->fric_of[r] >= 0) {
       l_hi = W->mu_row[r] * W->lam[W->fric_of[r]];
-      /* mode 3: the spec's round structure (all t1, then all t2) with the t2 bound shrunk to what the t1 multiplier leaves of the cone:
-       * |t2| <= sqrt((mu N)^2 - t1^2).  Not Bullet's coupled clip, but the same admissible set, and it fits the kernel's rounds. */
-      if (W->ellipse && r < W->first_self && W->fric_of[r] == r - 2) { const double t1 = W->lam[r - 1]; l_hi = sqrt(fmax(l_hi * l_hi - t1 * t1, 0.0)); }
+      /* mode 3: the spec's round structure (all t1, then all t2) with each friction bound shrunk to what the other row of the contact leaves
+       * of the cone: |t1| <= sqrt((mu N)^2 - t2^2), |t2| <= sqrt((mu N)^2 - t1^2).  Not Bullet's coupled clip, but the same admissible set,
+       * and it fits the kernel's rounds.  (Bounding only t2 -- t1 first come, first served -- starves the forward direction: tracked 0.63.) */
+      if (W->ellipse && r < W->first_self) {     /* each of the two rows is bounded by what the OTHER's current multiplier leaves of the cone */
+        const double other = W->lam[W->fric_of[r] == r - 2 ? r - 1 : r + 1];
+        l_hi = sqrt(fmax(l_hi * l_hi - other * other, 0.0));
+      }
       l_lo = -l_hi;
     }
     if (l_new < l_lo) l_new = l_lo;

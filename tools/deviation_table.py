@@ -51,7 +51,7 @@ VARIANTS = [
     ('max coordinate velocity 100', dict(max_coord_vel=100.0), 'ORACLE ONLY: btMultiBody::m_maxCoordinateVelocity clip of all 18 generalized velocities'),
     ('limit-row ERP 0.1', dict(limit_erp=0.1), 'ORACLE ONLY: joint-limit rows with half the ERP (Bullet uses the global erp 0.2 = the spec)'),
     ('cone + order + warm start', dict(friction_mode=2, row_order=1, warm_start=0.85), 'ORACLE ONLY'),
-    ('friction cone, sequential', dict(friction_mode=3), 'ORACLE ONLY: all t1 rows with +-mu N, then all t2 rows with +-sqrt((mu N)^2 - t1^2): the cone as an admissible set, in the spec\'s round structure'),
+    ('friction cone, sequential', dict(friction_mode=3), 'ORACLE ONLY: the spec\'s rounds, each friction row bounded by what the contact\'s other row leaves of the cone'),
     ('friction along the sliding direction', dict(friction_dirs=1), 'first friction direction along the contact point\'s lateral velocity (Bullet\'s default rule), box bounds'),
     ('sliding direction + cone + order', dict(friction_dirs=1, friction_mode=2, row_order=1), 'ORACLE ONLY: velocity-aligned directions, cone-coupled, manifold order'),
 ]
