@@ -237,7 +237,9 @@ def main():
             return 10 * 3 * nel * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         except Exception:                # noqa: BLE001
             return None
-    triad_first = os.environ.get('LL_BENCH_TRIAD_FIRST', '0') == '1'
+    # The calibration runs BEFORE the warm-up and the timed region (LL_BENCH_TRIAD_FIRST=0: after): a driver-style run of 25 control steps is
+    # 4 ms of GPU work from a cold device; with 40 ms of triad in front the same 20 timed steps run 2 % faster (profiles/r03_driver_style.txt)
+    triad_first = os.environ.get('LL_BENCH_TRIAD_FIRST', '1') == '1'
     triad = measure_triad() if triad_first else None
 
     n_done = [0]                                           # control steps executed so far == the engine's step index
@@ -338,7 +340,7 @@ def main():
                            'gather': gather_stats} if traj is not None else {})},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBPS) if achieved else None, 'traffic': traffic, 'traffic_per_control_step': (traffic / spl) if traffic else None,
-                         'algorithmic_bytes_per_launch': n * algo_bytes * spl, 'peak_measured_triad': triad,
+                         'algorithmic_bytes_per_launch': n * algo_bytes * spl, 'peak_measured_triad': triad, 'peak_measured_triad_when': 'before the warm-up steps' if triad_first else 'after the timed region',
                          'traffic_source': tsrc,
                          'kernel': 'pmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
                          'kernel_avg_launch_ms': k_launch_ms, 'control_steps_per_launch': (k_steps / k_n) if k_n else None,
