@@ -27,7 +27,7 @@ def env_config(element_id, n, seed=0, lib_path=None):
             'num_envs': n, 'auto_reset': False, 'seed': seed, 'lib_path': lib_path}
 
 
-def rollout(which, n, horizon, lib_path=None, gates='ifou', forget_bias=1.0, seed=0, weights=None):
+def rollout(which, n, horizon, lib_path=None, gates='ifou', forget_bias=1.0, seed=0, weights=None, blind=False):
     import lifelike_agility_and_play_amd as lla
     from oracle.epmc_policy import EpmcPolicy
     env = lla.create_playground_game(**env_config(ELEMENT[which], n, seed, lib_path))
@@ -38,6 +38,8 @@ def rollout(which, n, horizon, lib_path=None, gates='ifou', forget_bias=1.0, see
     steps, rsum, why, dist = np.zeros(n, int), np.zeros(n), np.zeros(n, int), np.zeros(n)
     codes = []
     for t in range(horizon):
+        if blind:                            # control experiment: the policy is shown flat ground -- height map 0, nothing within the front rays' 3 m
+            obs = obs.copy(); obs[:, 135:460] = 0.0; obs[:, 588:913] = 3.0
         a = pol.act(obs)
         codes.append(pol.last_code.copy())
         obs, r, d, info = env.step(a)
@@ -60,10 +62,11 @@ if __name__ == '__main__':
     lib = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] != '-' else None
     gates = sys.argv[5] if len(sys.argv) > 5 else 'ifou'
     fb = float(sys.argv[6]) if len(sys.argv) > 6 else 1.0
-    out = rollout(which, n, horizon, lib, gates, fb)
+    blind = len(sys.argv) > 7 and sys.argv[7] == 'blind'
+    out = rollout(which, n, horizon, lib, gates, fb, blind=blind)
     st, why = out['steps'], out['why']
-    print('%s policy, gates %s, forget bias %.1f, %d envs, horizon %d: mean episode length %.1f steps, distance along x %.2f m (median %.2f), '
-          'reward per step %.3f' % (which, gates, fb, n, horizon, st.mean(), out['dist'].mean(), np.median(out['dist']), out['rsum'].sum() / st.sum()))
+    print('%s policy%s, gates %s, forget bias %.1f, %d envs, horizon %d: mean episode length %.1f steps, distance along x %.2f m (median %.2f), '
+          'reward per step %.3f' % (which, ' SHOWN FLAT GROUND (height map and front rays blanked)' if blind else '', gates, fb, n, horizon, st.mean(), out['dist'].mean(), np.median(out['dist']), out['rsum'].sum() / st.sum()))
     print('  ended by: reached the target %d, fell %d, timed out %d, still running at the horizon %d;  distinct codes used %d' % (
         int(((why & 4) != 0).sum()), int(((why & 1) != 0).sum()), int(((why & 2) != 0).sum()), int(out['alive'].sum()), len(np.unique(out['codes']))))
     print('  done-reason histogram', np.bincount(why, minlength=8).tolist())
