@@ -14,8 +14,8 @@ cfg = capi.make_config(4096, control_freq=50.0, kd=0.5, prop_type=PMC_PROP_TYPE,
 E = capi.Engine(cfg, blob, mocap.load_mocap('', 0.02))
 E.reset()
 n = int(sys.argv[1])
-for t in range(n):
-    E.step_random(SIG)
+for t in range(0, n, 64):                       # the multi-step launches the benchmark times (ll_step_random_n)
+    E.step_random_n(SIG, min(64, n - t))
 o, s, c = E.obs(), E.state(), E.counters()
 assert np.isfinite(o).all() and np.isfinite(s).all()
 print('pmc   %6d steps x 4096 envs: %d episodes (mean length %.1f steps), %d non-finite resets, max |q| %.2f, %.1f s' % (n, c['episodes'], c['env_steps'] / max(1, c['episodes']), c['nonfinite'],
@@ -29,8 +29,8 @@ t0 = time.perf_counter()
 E = epmc_capi.EpmcEngine(epmc_capi.make_epmc_config(4096, epmc_env_config(3), auto_reset=1, seed=78), blob)
 E.reset()
 n = int(sys.argv[2])
-for t in range(n):
-    E.fill_random_actions(SIG); E.step()
+for t in range(0, n, 32):
+    E.step_random_n(SIG, min(32, n - t))
 o, s, c = E.obs(), E.state(), E.counters()
 assert np.isfinite(o).all() and np.isfinite(s).all()
 print('epmc  %6d steps x 4096 envs (cubes): %d episodes, %d non-finite resets, x range [%.1f, %.1f], %.1f s' % (n, c['episodes'], c['nonfinite'], s[:, 0].min(), s[:, 0].max(), time.perf_counter() - t0))
@@ -41,9 +41,9 @@ E = sepmc_capi.SepmcEngine(sepmc_capi.make_sepmc_config(2048, sepmc_env_config(1
 E.reset()
 n = int(sys.argv[3])
 why_hist = np.zeros(32, int)
-for t in range(n):
-    E.fill_random_actions(SIG); E.step()
-    if t % 50 == 0:
+for t in range(0, n, 50):
+    E.step_random_n(SIG, 49); E.fill_random_actions(SIG); E.step()
+    if True:
         _, d, w = E.reward_done()
         why_hist += np.bincount(w[d], minlength=32)
 o, s, c = E.obs(), E.state(), E.counters()
