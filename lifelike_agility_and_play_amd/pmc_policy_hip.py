@@ -68,6 +68,7 @@ class HipPmcPolicy(object):
         self._chk(self.lib.ll_policy_act_pg(self.h, C.c_void_p(int(p.obs)), C.c_void_p(int(p.actions)), C.c_void_p(int(d_code)) if d_code else None,
                                             C.c_void_p(int(nl)), C.c_void_p(int(v)), int(p.n_envs), int(seed), int(step), 1 if sample else 0,
                                             C.c_void_p(int(p.stream)) if p.stream else None))
+        engine.pg_mark_current()               # the value buffer now belongs to the current observation (ll_finish_unroll checks the stamp)
 
     def enable_timing(self, on=True):
         self._chk(self.lib.ll_policy_enable_timing(self.h, 1 if on else 0))

@@ -360,6 +360,20 @@ def check_trajectory_ring(model_blob, table, lib_path, read_ring, write_dev=None
                 R[:, k] = adv + f['V'][:, k]
                 vnext = f['V'][:, k].astype(np.float64)
             np.testing.assert_allclose(f['R'], R, rtol=1e-5, atol=1e-5)
+    # the stale-bootstrap guard: once the caller has declared the pg buffers current (ll_pg_mark_current, what act_pg does), a NULL bootstrap
+    # is only accepted while that stamp is the current step -- right after a step the value buffer still holds V(obs_{T-1})
+    E.pg_mark_current()
+    E.finish_unroll(0, 0.95, 0.9)                                            # stamped for this very observation: accepted
+    E.step_host(np.zeros((n, 12), np.float32))
+    try:
+        E.finish_unroll(0, 0.95, 0.9)
+        raise AssertionError('a stale value buffer was accepted as the bootstrap')
+    except capi.LLError as e:
+        assert e.code == capi.LL_ESTATE, e
+    E.finish_unroll(0, 0.95, 0.9, d_bootstrap_value=p_v)                     # an explicit bootstrap pointer is always accepted
+    E.pg_mark_current()
+    E.finish_unroll(0, 0.95, 0.9)
+    E.sync()
     E.close()
     # the flatten itself is the reference's: golden generated by running distill_actor._push_data_to_learner
     g = np.load(os.path.join(GOLDEN_DIR, 'unroll_golden.npz'))

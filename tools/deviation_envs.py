@@ -23,7 +23,6 @@ EPMC_VARIANTS = [
     ('spec (as shipped)', {}),
     ('friction cone-coupled + manifold order', dict(friction_mode=2, row_order=1)),
     ('friction rows adjacent', dict(friction_mode=1)),
-    ('warm start 0.85', dict(warm_start=0.85)),
     ('self friction 0.25', dict(self_friction=0.25)),
     ('depenetration cap off', dict(max_depen_speed=1e30)),
     ('deepest-2 per leg', dict(max_contacts_per_leg=2)),
@@ -37,7 +36,7 @@ SEPMC_VARIANTS = [
     ('4 rows + pair friction 0.25', dict(max_pair=4, pair_friction=0.25)),
     ('1 row per robot pair', dict(max_pair=1)),
     ('no robot-robot rows', dict(max_pair=0)),
-    ('self friction 0.25 + warm start 0.85', dict(self_friction=0.25, warm_start=0.85)),
+    ('self friction 0.25', dict(self_friction=0.25)),
     ('friction cone-coupled + manifold order', dict(friction_mode=2, row_order=1)),
 ]
 
