@@ -341,7 +341,7 @@ def assert_within_bars(out, cfg_bar=1e-4, vel_bar=1e-3, factor=4.0, max_ill=0.03
     assert (v < bar_v).all(), (np.sort(v)[-5:], cv[np.argsort(v)[-5:]])
 
 
-def check_terrain_physics_against_oracle(lib_path, n_envs=16, seed=11, total_envs=None):
+def check_terrain_physics_against_oracle(lib_path, n_envs=16, seed=11, total_envs=None, max_tie=0.04):
     """Robots standing on, straddling and pressed into cube steps and hurdles, with the push active: one control step of real
     physics, engine (float32) vs the float64 oracle given the same terrain records, friction and push forces.  The two share the
     spec (shape_sdf, nearest-surface normal, btPlaneSpace1 tangents) and nothing else.
@@ -391,7 +391,7 @@ def check_terrain_physics_against_oracle(lib_path, n_envs=16, seed=11, total_env
                 out['n_terrain'] += 1
         E.close()
     assert out['n_terrain'] >= 10 and out.get('n_felt', 0) >= 8, (out['n_terrain'], out.get('n_felt', 0))
-    assert_within_bars(out)
+    assert_within_bars(out, max_tie=max_tie)
     return out
 
 
