@@ -231,10 +231,11 @@ def main():
                 torch.add(b_, c_, alpha=1.5, out=a_)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(10):
+            iters = int(os.environ.get('LL_BENCH_TRIAD_ITERS', '10'))
+            for _ in range(iters):
                 torch.add(b_, c_, alpha=1.5, out=a_)
             e1.record(); torch.cuda.synchronize()
-            return 10 * 3 * nel * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            return iters * 3 * nel * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         except Exception:                # noqa: BLE001
             return None
     # The calibration runs BEFORE the warm-up and the timed region (LL_BENCH_TRIAD_FIRST=0: after): a driver-style run of 25 control steps is
