@@ -21,6 +21,7 @@
 #define EPMC_BOX_WORDS 8
 #define EPMC_MAX_NEAR 8       // boxes within reach of the robot's contact candidates during one control step
 #define EPMC_EP_STRIDE 40
+#define EPMC_PARK_AT 544        // row-scratch word: the 64 spare words behind the ray lists (lanes.hpp PMC_ROW_SCRATCH)
 #define EPMC_LIST_A 320         // row-scratch words: the near list (height + front rays) after the staged box records, then the fan's list
 #define EPMC_LIST_A_MAX 12
 #define EPMC_LIST_B (EPMC_LIST_A + EPMC_LIST_A_MAX * EPMC_BOX_WORDS)
@@ -544,6 +545,8 @@ struct Epmc {
   // ------------------------------------------------------------------------------------------------------------
   // the control step (PGE:299-364)
   // ------------------------------------------------------------------------------------------------------------
+  // PARK (the larger-batch build): the 40 per-env scalars wait in LDS and the history chunks are read after the substep loop (sepmc_step.hpp)
+  template <bool PARK = false>
   static LL_HD void step_env(const L& ln, const StepParams& P_in, const EpmcParams& E, int env, const F* act_in) {
     const StepParams& P = ln.params(P_in);
     const int N = P.n_envs;
@@ -554,7 +557,7 @@ struct Epmc {
     load_ep(E.ep + (long)env * EPMC_EP_STRIDE, ep);
     float* row = P.obs + (long)env * P.obs_dim;
     typename K::ObsIn hist;
-    {
+    if (!PARK) {
       const int Pd = P.prop_dim;
       for (int c = 0; c < K::OBS_HIST_CHUNKS; c++) hist.h[c] = ln.ld16(row + Pd, 16 * c, 2 * Pd);
       for (int c = 0; c < 2; c++) hist.ha[c] = ln.ld16(row + 3L * Pd + 12, 16 * c, 24);
@@ -601,6 +604,7 @@ struct Epmc {
       ex.box_mu_scale = E.box_friction / E.plane_friction;
     }
     float* ptrace = E.push_trace + (long)env * P.n_sub * 4;
+    if (PARK) ln.park_row(ep, EPMC_EP_STRIDE, EPMC_PARK_AT);                     // only the push counter and force are touched in the loop
     for (int s = 0; s < P.n_sub; s++) {                                          // PGE:326-331
       ex.has_push = false;
       if (E.push_enabled) {                                                      // PR:56-86, counted in substeps
@@ -619,6 +623,14 @@ struct Epmc {
         for (int i = 0; i < 3; i++) ptrace[s * 4 + 1 + i] = ex.has_push ? ex.push[i] : 0.0f;
       }
       if (!E.scr_state) K::template substep_impl<true>(ln, P, bs, q, qd, tgt, env, s, &ex, nullptr);   // PGE:328-330
+    }
+    if (PARK) {
+      const float keep[4] = {ep[EP_PUSH_COUNT], ep[EP_PUSH_FORCE], ep[EP_PUSH_FORCE + 1], ep[EP_PUSH_FORCE + 2]};
+      ln.unpark_row(ep, EPMC_EP_STRIDE, EPMC_PARK_AT);
+      ep[EP_PUSH_COUNT] = keep[0]; ep[EP_PUSH_FORCE] = keep[1]; ep[EP_PUSH_FORCE + 1] = keep[2]; ep[EP_PUSH_FORCE + 2] = keep[3];
+      const int Pd = P.prop_dim;
+      for (int c = 0; c < K::OBS_HIST_CHUNKS; c++) hist.h[c] = ln.ld16(row + Pd, 16 * c, 2 * Pd);
+      for (int c = 0; c < 2; c++) hist.ha[c] = ln.ld16(row + 3L * Pd + 12, 16 * c, 24);
     }
     if (E.scr_state) {   // parity hook: the caller plays PyBullet
       const float* ss = E.scr_state + (long)env * 37;

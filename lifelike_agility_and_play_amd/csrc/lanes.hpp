@@ -135,6 +135,19 @@ struct GpuLanes {
     return dst;
   }
   LL_D void row_sync() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }   // lane 0's stores visible to the row
+  // Park n row-uniform floats in the row's LDS scratch (word `at`) and take them back later: between the two calls their registers are
+  // free -- the larger-batch EPMC / SEPMC builds carry 40 episode scalars through the substep loop otherwise and spill state around them.
+  LL_D void park_row(const float* v, int n, int at) const {
+    float* dst = row_scratch() + at;
+    if (lane0()) for (int i = 0; i < n; i++) dst[i] = v[i];
+    row_sync();
+    asm volatile("" : : : "memory");                          // the loads of unpark_row must not be forwarded from these stores
+  }
+  LL_D void unpark_row(float* v, int n, int at) const {
+    asm volatile("" : : : "memory");
+    const float* src = row_scratch() + at;                    // (one wave: its LDS operations execute in program order)
+    for (int i = 0; i < n; i++) v[i] = src[i];
+  }
 
   // ---- reductions / broadcasts ------------------------------------------------------------------------------
   // sum over the four LEGS of a leg-uniform value (each leg's value is replicated in its 4 sub-lanes)

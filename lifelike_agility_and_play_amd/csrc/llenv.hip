@@ -41,6 +41,9 @@ typedef GpuLanesPinned<LC_COUNT> GpuLanes1;                   // the per-leg tab
 #define LL_PIN_PMC 1
 #endif
 // re-reading of the argument block (lanes.hpp WithParamsReload), per kernel by A/B; the SEPMC kernels keep the plain lane policies
+#ifndef LL_PARK
+#define LL_PARK 1      // the larger-batch EPMC / SEPMC builds park their per-row scalars in LDS across the substep loop
+#endif
 #ifndef LL_RELOAD_PMC
 #define LL_RELOAD_PMC 1
 #endif
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, 
   if constexpr (!MULTI) {
     float act[3];
     step_actions(P, ln, lds, env0, 0, act);
-    Epmc<Lanes>::step_env(ln, P, E, env0, act);
+    Epmc<Lanes>::template step_env<((OCC == 2 && LL_PARK) || LL_PARK > 1)>(ln, P, E, env0, act);
   } else {
     for (int sl = 0; sl < P.n_steps; sl++) {               // ll_epmc_step_random_n: see pmc_step_kernel
       if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, 
       asm volatile("" : "+v"(env));
       float act[3];
       step_actions(P, ln, lds, env, sl, act);
-      Epmc<Lanes>::step_env(ln, P, E, env, act);
+      Epmc<Lanes>::template step_env<(LL_PARK > 1)>(ln, P, E, env, act);
     }
   }
 }
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P,
   if constexpr (!MULTI) {
     float act[3];
     step_actions(P, ln, lds, row0, 0, act);
-    Sepmc<Lanes>::step_env(ln, P, S, row0, act);
+    Sepmc<Lanes>::template step_env<((OCC == 2 && LL_PARK) || LL_PARK > 1)>(ln, P, S, row0, act);
   } else {
     for (int sl = 0; sl < P.n_steps; sl++) {               // ll_sepmc_step_random_n: see pmc_step_kernel
       if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P,
       asm volatile("" : "+v"(row));
       float act[3];
       step_actions(P, ln, lds, row, sl, act);
-      Sepmc<Lanes>::step_env(ln, P, S, row, act);
+      Sepmc<Lanes>::template step_env<(LL_PARK > 1)>(ln, P, S, row, act);
     }
   }
 }

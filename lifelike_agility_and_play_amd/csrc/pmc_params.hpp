@@ -77,6 +77,7 @@ struct StepParams {
   int32_t prop_off[5];      // offset of each LL_PROP_* key inside one prop frame, or -1
   int32_t keep_term_obs;    // auto-reset: also write the finished episode's last obs to term_obs
   float dt, kp, kd, max_tau;
+  float max_tau1, pad6;     // SEPMC: robot 1's torque limit when it differs (> 0; max_tau given as a list draws one per LeggedRobot, LR:244)
   float mu_foot, mu_link, gravity, link_damping;
   float erp, margin_dist, limit_gate, self_collision;   // self_collision: 1 = links of different legs collide (LR:212-217)
   float rw[5];              // normalised reward weights (PLE:365-370)

@@ -350,7 +350,6 @@ struct Pmc {
   // push of randomizer/push_randomizer.py:72-77 -- applyExternalForce(linkIndex 0, LINK_FRAME): a force given in the FR hip
   // link's frame, acting at that link's centre of mass
   struct SubstepExtra {
-    float max_tau = 0.0f;   // > 0: this robot's own torque limit (SEPMC: the two robots of an arena may have different ones, LR:244); else P.max_tau
     float mu_foot;
     bool has_push;
     float push[3];
@@ -652,7 +651,7 @@ struct Pmc {
 
     // --- PD torque with clip (LR:126-141) + URDF joint damping --------------------------------------------
     F tau[3];
-    pd_torque(ln, P, q, qd, tgt, tau, (PAIR && ex) ? ex->max_tau : 0.0f);
+    pd_torque(ln, P, q, qd, tgt, tau, (PAIR && ex && ex->pair_me == 1) ? P.max_tau1 : 0.0f);      // (SEPMC: robot 1 may have its own limit, LR:244)
     for (int j = 0; j < 3; j++) tau[j] = tau[j] - ln.legc(legc, LC_JDAMP + j) * qd[j];
 
     // --- leg kinematics, velocities -------------------------------------------------------------------------

@@ -67,7 +67,7 @@ struct SepmcEngine {
     S.robot_contacts = 1;
     S.rand_cube = c.rand_cube ? 1 : 0; S.hurdle = c.hurdle ? 1 : 0; S.hole = c.hole ? 1 : 0;
     S.cos_visible = (float)cos(c.visible_angle); S.control_spd = (float)c.control_spd;
-    S.max_tau1 = c.max_tau_robot1 > 0 ? (float)c.max_tau_robot1 : 0.0f;
+    base.P.max_tau1 = c.max_tau_robot1 > 0 ? (float)c.max_tau_robot1 : 0.0f;
     S.sp = base.template dalloc<float>(N * SEPMC_SP_STRIDE);
     S.info = base.template dalloc<float>(N * 4);
     d_reset_draws = base.template dalloc<float>((N / 2) * EPMC_MAX_DRAWS);

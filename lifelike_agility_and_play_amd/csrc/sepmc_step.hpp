@@ -14,6 +14,7 @@
 
 #define SEPMC_OBS_TAIL 52        // percept_vec 5, oppo_info 15, oppo_info_cheat 15, flag_info 7, flag_info_cheat 7, with_flag 2, control_spd 1
 #define SEPMC_SP_STRIDE 40
+#define SEPMC_PARK_AT 544       // row-scratch word: the 64 spare words behind the ray lists (lanes.hpp PMC_ROW_SCRATCH)
 #define SEPMC_MAX_CONTACTS 8     // scripted getContactPoints records per arena
 #define SEPMC_N_VIS 21           // visibility rays per arena: base to base, then head of robot i to the 10 convex points of the other
 #define SEPMC_WALL_SOLID 1.0f     // metres the arena walls extend outwards for the contact tests (the rays see their true 1 cm)
@@ -48,7 +49,6 @@ struct SepmcParams {
   int32_t rand_cube, hurdle, hole, scr_on;
   int32_t robot_contacts, pad0;           // 0: the robots pass through each other (diagnostics)
   float cos_visible, control_spd;         // control_spd < 0: the episode's draw (CTG:264, :361)
-  float max_tau1, pad1;                   // robot 1's torque limit when it differs from P.max_tau (> 0), LR:244
   float* sp;                              // [rows][SEPMC_SP_STRIDE]
   float* info;                            // [rows][4] avg_spd0, avg_spd1, max_spd0, max_spd1 (CTG:404-409)
   float* vis_trace;                       // optional [rows][16][8]: from 3, to 3, blocked, valid -- by lane: leg * 4 + {foot, wheel, handle, base}
@@ -341,6 +341,9 @@ struct Sepmc {
   // ------------------------------------------------------------------------------------------------------------
   // the control step (CTG:378-424)
   // ------------------------------------------------------------------------------------------------------------
+  // PARK (the larger-batch build): the 40 per-row scalars wait in LDS and the history chunks are read after the substep loop instead of
+  // before it (two waves per SIMD hide that round trip; one wave per SIMD would pay it)
+  template <bool PARK = false>
   static LL_HD void step_env(const L& ln, const StepParams& P_in, const SepmcParams& S, int row, const F* act_in) {
     const StepParams& P = ln.params(P_in);
     const EpmcParams& E = S.e;
@@ -352,7 +355,7 @@ struct Sepmc {
     load_sp(S.sp + (long)row * SEPMC_SP_STRIDE, sp);
     float* orow = P.obs + (long)row * P.obs_dim;
     typename K::ObsIn hist;
-    {
+    if (!PARK) {
       const int Pd = P.prop_dim;
       for (int c = 0; c < K::OBS_HIST_CHUNKS; c++) hist.h[c] = ln.ld16(orow + Pd, 16 * c, 2 * Pd);
       for (int c = 0; c < 2; c++) hist.ha[c] = ln.ld16(orow + 3L * Pd + 12, 16 * c, 24);
@@ -371,7 +374,6 @@ struct Sepmc {
       const float ddx = ln.peer_u(bs.p.x) - bs.p.x, ddy = ln.peer_u(bs.p.y) - bs.p.y, ddz = ln.peer_u(bs.p.z) - bs.p.z;
       ex.pair_active = !E.scr_state && S.robot_contacts && !PMC_ABL(2048) && (ddx * ddx + ddy * ddy + ddz * ddz < 1.5f * 1.5f);
       ex.pair_me = me;
-      ex.max_tau = (me == 1) ? S.max_tau1 : 0.0f;
     }
     const int nb = (int)sp[SP_N_BOXES];
     float* allb = E.boxes + (long)row * EPMC_MAX_BOXES * EPMC_BOX_WORDS;
@@ -400,6 +402,7 @@ struct Sepmc {
     }
     float* ptrace = E.push_trace + (long)row * P.n_sub * 4;
     const typename K::LinkC lkh = K::own_link_held(ln, P.legc);                    // (held in registers: faster in both SEPMC kernels)
+    if (PARK) ln.park_row(sp, SEPMC_SP_STRIDE, SEPMC_PARK_AT);                     // only the push counter and force are touched in the loop
     for (int s = 0; s < P.n_sub; s++) {                                          // CTG:383-388
       ex.has_push = false;
       if (E.push_enabled) {                                                      // PR:56-86, the legged_robots branch :78-86
@@ -422,6 +425,16 @@ struct Sepmc {
       }
       ex.want_touch = s == P.n_sub - 1;
       if (!E.scr_state) K::template substep_impl<true, true>(ln, P, bs, q, qd, tgt, row, s, &ex, &lkh);
+    }
+    if (PARK) {
+      const float keep[4] = {sp[SP_PUSH_COUNT], sp[SP_PUSH_FORCE], sp[SP_PUSH_FORCE + 1], sp[SP_PUSH_FORCE + 2]};
+      ln.unpark_row(sp, SEPMC_SP_STRIDE, SEPMC_PARK_AT);
+      sp[SP_PUSH_COUNT] = keep[0]; sp[SP_PUSH_FORCE] = keep[1]; sp[SP_PUSH_FORCE + 1] = keep[2]; sp[SP_PUSH_FORCE + 2] = keep[3];
+    }
+    if (PARK) {
+      const int Pd = P.prop_dim;
+      for (int c = 0; c < K::OBS_HIST_CHUNKS; c++) hist.h[c] = ln.ld16(orow + Pd, 16 * c, 2 * Pd);
+      for (int c = 0; c < 2; c++) hist.ha[c] = ln.ld16(orow + 3L * Pd + 12, 16 * c, 24);
     }
     if (E.scr_state) {   // parity hook: the caller plays PyBullet
       const float* ss = E.scr_state + (long)row * 37;

@@ -113,6 +113,8 @@ struct HostLanes {
   int ray_first() const { return 0; }
   int ray_stride() const { return 1; }
   void row_sync() const {}
+  void park_row(const float*, int, int) const {}
+  void unpark_row(float*, int, int) const {}
   const float* stage_row(const float* g, int) const { return g; }
   alignas(16) mutable float scratch_[608];
   float* row_scratch() const { return scratch_; }
