@@ -505,7 +505,8 @@ struct GpuLanesPinned : GpuLanes {
 // instead of being computed once at kernel entry and parked in spilled SGPRs (a v_readlane per use: 576 of them in the multi-step PMC
 // kernel before, 94 after).  LEVEL 1: once per control step; 2: also once per substep.  Which level pays is a matter of register
 // allocation and measured per kernel (A/B on one box, tools/ab3.sh): PMC -2.2 % kernel time at level 1 (both builds); EPMC -0.8 % at
-// level 2 (one wave per SIMD) / -1.2 % at level 1 (larger batches); SEPMC +0.3 % / +20 % (!) -- left alone.
+// level 2 (one wave per SIMD) / -1.2 % at level 1 (larger batches); SEPMC +0.3 % (one wave per SIMD: left alone); its larger-batch build
+// lost 20 % to it while it carried 40 episode scalars through the substep loop and gains 8 % now that they wait in LDS (park_row).
 template <class Base, int LEVEL>
 struct WithParamsReload : Base {
   using Base::Base;

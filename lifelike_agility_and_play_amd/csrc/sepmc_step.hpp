@@ -401,7 +401,7 @@ struct Sepmc {
       ex.box_mu_scale = E.box_friction / E.plane_friction;
     }
     float* ptrace = E.push_trace + (long)row * P.n_sub * 4;
-    const typename K::LinkC lkh = K::own_link_held(ln, P.legc);                    // (held in registers: faster in both SEPMC kernels)
+    const typename K::LinkC lkh = K::own_link_held(ln, P.legc);                    // (held in registers: faster in both SEPMC kernels, also with PARK)
     if (PARK) ln.park_row(sp, SEPMC_SP_STRIDE, SEPMC_PARK_AT);                     // only the push counter and force are touched in the loop
     for (int s = 0; s < P.n_sub; s++) {                                          // CTG:383-388
       ex.has_push = false;
