@@ -6,14 +6,32 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from extract_policy import _U  # noqa: E402
+from extract_policy import _U, _S  # noqa: E402
+
+
+def load_checkpoint(path):
+    """The reference's checkpoints come in two container formats: a plain pickle (hurdle, cube, primitive_level, strategic_level) and
+    joblib.dump's (hole: NumpyArrayWrapper records with the raw array bytes inline in the stream -- pickle.Unpickler stops at the first one
+    with 'invalid load key').  joblib's own unpickler reads the second; the tleague classes are stubbed in both."""
+    try:
+        return _U(open(path, 'rb')).load().model
+    except Exception:       # noqa: BLE001
+        from joblib.numpy_pickle import NumpyUnpickler
+
+        class _J(NumpyUnpickler):
+            def find_class(self, module, name):
+                if module.startswith('tleague'):
+                    return _S
+                return super().find_class(module, name)
+        with open(path, 'rb') as fh:
+            return _J(path, fh, ensure_native_byte_order=True).load().model
 
 if __name__ == '__main__':
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for el in ('hurdle', 'hole', 'cube'):
         try:
-            m = _U(open('/root/reference/data/models/environmental_level_%s.model' % el, 'rb')).load().model
-        except Exception as e:      # noqa: BLE001  (environmental_level_hole.model of this snapshot does not unpickle: 'invalid load key')
+            m = load_checkpoint('/root/reference/data/models/environmental_level_%s.model' % el)
+        except Exception as e:      # noqa: BLE001
             print('cannot read the %s checkpoint: %r' % (el, e))
             continue
         assert len(m) == 102

@@ -59,6 +59,12 @@ for i in range(1, len(raw)):
     t = raw[i] * 0.01
     w = (t[:, 7] - t[:, 0]).reshape(-1, 4).max(1)
     dur.append(w); nself.append((raw[i][:, 28] - raw[i - 1][:, 28]).reshape(-1, 4).max(1)); rese.append(acc[i][1].reshape(-1, 4).any(1).astype(float))
+per_step = np.stack(dur)                                   # [step][wave]
+tot = per_step.sum(0)
+print('the slowest wave, single-step launches vs one launch over the same %d steps (waves run on without waiting for each other):' % len(per_step))
+print('  mean over steps of (max over waves) %.1f us = mean wave + %.1f %%;   (max over waves of the %d-step sum) / %d = %.1f us = mean wave + %.1f %%' % (
+    per_step.max(1).mean(), 100 * (per_step.max(1).mean() / per_step.mean() - 1), len(per_step), len(per_step), tot.max() / len(per_step),
+    100 * (tot.max() / tot.mean() - 1)))
 dur, nself, rese = np.concatenate(dur), np.concatenate(nself), np.concatenate(rese)
 A = np.stack([np.ones_like(dur), nself, rese], 1)
 coef, res, _, _ = np.linalg.lstsq(A, dur, rcond=None)
