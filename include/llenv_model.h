@@ -96,6 +96,10 @@
                                            when SOLVER_DISABLE_VELOCITY_DEPENDENT_FRICTION_DIRECTION is not set), the second = t1 x n; btPlaneSpace1 when it
                                            does not slide.  With box bounds a sliding contact then gets at most mu N along its sliding direction instead of
                                            up to sqrt(2) mu N diagonally.  Oracle and engine (ll_set_spec_param) */
-#define LLM_SPEC_COUNT 20
+#define LLM_SPEC_LIMIT_SPECULATIVE 20   /* 1 (spec): a joint-limit row exists while the joint is inside its range too, with the free distance d / dt as its bias: the
+                                           joint stops AT the limit.  0: a row only once the limit is passed (d <= 0), bias erp * d / dt -- what
+                                           btMultiBodyJointLimitConstraint::createConstraintRows does as recalled ("if (penetration > 0) continue;"): the joint overshoots by
+                                           up to qd * dt, is stopped there and walks back by erp per substep.  ORACLE ONLY unless stated otherwise in DESIGN.md 4 */
+#define LLM_SPEC_COUNT 21
 
 #endif

@@ -233,8 +233,8 @@ def check_multi_step_launch(lib_path, sizes=(12,), k=5, n_launches=4, element=1)
 
 def check_trained_policies_traverse(lib_path, n_envs=8, horizon=(360, 560)):
     """SURVEY.md 8f-3 for the environmental level -- the only Bullet-facing check of this build's terrain contacts and 778 analytic rays: the
-    reference's TRAINED EPMC policies (data/models/environmental_level_{hurdle,cube}.model, trained against PyBullet; the hole checkpoint of
-    this snapshot does not unpickle) drive our PlayGround env closed-loop under the protocol of test_environmental_level_env.py: target speed
+    reference's TRAINED EPMC policies (data/models/environmental_level_{hurdle,cube}.model, trained against PyBullet; the hole checkpoint
+    does not traverse our bars course and is reported, not asserted: DESIGN.md 2, profiles/r03_epmc_hole_policy.txt) drive our PlayGround env closed-loop under the protocol of test_environmental_level_env.py: target speed
     3 m/s, pushes, friction 0.4 .. 1, argmax code.  They run 10 m over hurdles / up and down 10 and 25 cm steps and reach the target.  The
     LSTM cell is tpolicies' published lnlstm restated in oracle/epmc_policy.py; with any other gate order the same weights fall within 3 s
     (tools/rollout_epmc_policy.py, profiles/r03_epmc_policy_rollout.txt), so a passing run vouches for cell and physics together."""

@@ -141,6 +141,34 @@ def test_joint_limit_rows(golden, orc, model_blob, mocap_table):
     assert lam[0] > 0
 
 
+def test_joint_limit_audit_switch(golden, orc, model_blob, mocap_table):
+    """LLM_SPEC_LIMIT_SPECULATIVE (oracle only): as shipped the joint is stopped AT its limit (a speculative row with the
+    free distance as its bias); with the switch off -- btMultiBodyJointLimitConstraint as recalled -- no row exists inside the range, the joint
+    overshoots by less than one substep of travel, and is then held within the ERP band.  Default: on."""
+    from oracle import oracle as O
+    hi = model_blob[um.OFF_Q_HI]
+    out = {}
+    for mode in (1, 0):
+        O.reset_spec()
+        f = O.lib().orc_get_spec_param; f.restype = O.C.c_double
+        assert f(O.C.c_int(20)) == 1.0
+        O.set_spec(limit_speculative=mode)
+        B = make_oracle_batch(orc, model_blob, mocap_table)
+        s = standing_state(golden, z=3.0)
+        worst, qd_at = -1.0, 0.0
+        for k in range(400):
+            tau = np.zeros(12); tau[0] = 18.0
+            before = s[25]
+            s, nc, lam, acc = B.substep(s, tau)
+            if s[13] - hi > worst:
+                worst, qd_at = s[13] - hi, before
+        out[mode] = (worst, s[13] - hi, qd_at)
+    O.reset_spec()
+    assert out[1][0] < 0.02, out                                        # stopped at the limit (ten Gauss-Seidel iterations leave a residual)
+    assert 2 * out[1][0] < out[0][0] < abs(out[0][2]) * 0.002 * 1.2 + 0.005, out    # past it, by about one substep at the speed it arrived with
+    assert abs(out[0][1]) < 0.02 and abs(out[1][1]) < 0.02, out         # and held near it afterwards
+
+
 def test_fk_feet_matches_numpy(golden, orc, model_blob, mocap_table):
     """LR:199-205 foot FK against an independent numpy/scipy chain product."""
     from scipy.spatial.transform import Rotation as R

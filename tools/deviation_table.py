@@ -53,9 +53,10 @@ VARIANTS = [
     ('cone + order + warm start', dict(friction_mode=2, row_order=1, warm_start=0.85), 'ORACLE ONLY'),
     ('friction cone, sequential', dict(friction_mode=3), 'ORACLE ONLY: the spec\'s rounds, each friction row bounded by what the contact\'s other row leaves of the cone'),
     ('friction along the sliding direction', dict(friction_dirs=1), 'first friction direction along the contact point\'s lateral velocity (Bullet\'s default rule), box bounds'),
+    ('limit rows only once violated', dict(limit_speculative=0), 'ORACLE ONLY: no joint-limit row while the joint is inside its range (btMultiBodyJointLimitConstraint as recalled: "if (penetration > 0) continue"): the joint overshoots, is stopped and walks back by ERP per substep'),
     ('sliding direction + cone + order', dict(friction_dirs=1, friction_mode=2, row_order=1), 'ORACLE ONLY: velocity-aligned directions, cone-coupled, manifold order'),
 ]
-ORACLE_ONLY = ('self_friction', 'warm_start', 'friction_mode', 'row_order', 'max_coord_vel', 'limit_erp')
+ORACLE_ONLY = ('self_friction', 'warm_start', 'friction_mode', 'row_order', 'max_coord_vel', 'limit_erp', 'limit_speculative')
 
 
 def starts(table, n, seed):
