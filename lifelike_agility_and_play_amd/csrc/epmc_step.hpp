@@ -21,11 +21,15 @@
 #define EPMC_BOX_WORDS 8
 #define EPMC_MAX_NEAR 8       // boxes within reach of the robot's contact candidates during one control step
 #define EPMC_EP_STRIDE 40
-#define EPMC_PARK_AT 544        // row-scratch word: the 64 spare words behind the ray lists (lanes.hpp PMC_ROW_SCRATCH)
-#define EPMC_LIST_A 320         // row-scratch words: the near list (height + front rays) after the staged box records, then the fan's list
-#define EPMC_LIST_A_MAX 12
+#define EPMC_LIST_A 320         // row-scratch words: behind the staged box records the three ray lists (height grid, fan, front rays), then 64 spare words.
+#define EPMC_LIST_A_MAX 10      // (PMC_ROW_SCRATCH = 688 words per row is what eight workgroups per CU can afford: 9392 B of tables + 4 x 2752 B <= 160 KB / 8)
 #define EPMC_LIST_B (EPMC_LIST_A + EPMC_LIST_A_MAX * EPMC_BOX_WORDS)
 #define EPMC_LIST_B_MAX 16
+#define EPMC_LIST_C (EPMC_LIST_B + EPMC_LIST_B_MAX * EPMC_BOX_WORDS)
+#define EPMC_LIST_C_MAX 12
+#define EPMC_SPARE (EPMC_LIST_C + EPMC_LIST_C_MAX * EPMC_BOX_WORDS)
+#define EPMC_PARK_AT EPMC_SPARE  // row-scratch word where the episode scalars wait during the substep loop (step_env<PARK>)
+static_assert(EPMC_SPARE + 64 == PMC_ROW_SCRATCH, "row scratch layout: boxes, three ray lists, 64 spare words");
 
 // per-env scalar row (EpmcParams::ep)
 enum EpmcEpField {
@@ -282,10 +286,8 @@ struct Epmc {
     tl = fminf(tl, b);
   }
   // The three percep arrays straight into the obs row; lanes share the rays out.  `boxes` = the env's n_boxes records staged at
-  // the start of the row scratch.  Each family is a dense, branch-light loop: lane 0 first compacts the boxes a family can meet --
-  // within 3.6 m of the base for the height grid (reach 1.35 m) and the front rays (3.4 m); for the horizontal fan, whose rays are
-  // exactly level (PGE:30-38), the boxes whose height range contains the base height, within 20.1 m -- into two lists behind the
-  // staged records; a ray then walks its family's list with one 32-byte LDS read per box and no per-ray set-up beyond its origin
+  // the start of the row scratch.  Each family is a dense, branch-light loop: lane 0 first compacts the boxes a family can meet (see
+  // below) into three lists in the row scratch; a ray then walks its family's list with one 32-byte LDS read per box and no per-ray set-up beyond its origin
   // (the front rays share one direction, the fan one origin; the fan's directions come from one sin/cos per lane and eight exact
   // 45-degree turns).
   static LL_HD void observe_rays(const L& ln, const StepParams& P, const EpmcParams& E, int env, const float* pos, const M3<float>& R, float yaw,
@@ -301,15 +303,28 @@ struct Epmc {
       }
       return;
     }
-    // --- the two compact lists (lane 0 writes, the row reads after the sync) ---
+    // --- the three compact lists (lane 0 writes, the row reads after the sync).  A box is listed for a family iff its extents overlap the
+    //     bounding box of that family's ray bundle (grown by 1 mm against rounding): the 2.4 m x 1.2 m rectangle of the height grid as it lies
+    //     in the world, the 3 m long prism swept by the front rays, and for the fan -- level rays of 20 m -- the boxes whose height range
+    //     contains the base height.  Exact: a ray only ever meets a box inside its bundle's bounds.
     float* listA = ln.row_scratch() + EPMC_LIST_A;
     float* listB = ln.row_scratch() + EPMC_LIST_B;
-    int nA = 0, nB = 0;
+    float* listC = ln.row_scratch() + EPMC_LIST_C;
+    const float slack = 1.0e-3f;
+    const float hgx = fabsf(R.m[0]) * 1.2f + fabsf(R.m[1]) * 0.6f + slack, hgy = fabsf(R.m[3]) * 1.2f + fabsf(R.m[4]) * 0.6f + slack;
+    float flo[3], fhi[3];
+    for (int a = 0; a < 3; a++) {
+      const float ry = fabsf(R.m[3 * a + 1]) * 0.25f, z0 = R.m[3 * a + 2] * -0.3f, z1 = R.m[3 * a + 2] * 0.1f, da = 3.0f * R.m[3 * a];
+      flo[a] = pos[a] - ry + fminf(z0, z1) + fminf(da, 0.0f) - slack;
+      fhi[a] = pos[a] + ry + fmaxf(z0, z1) + fmaxf(da, 0.0f) + slack;
+    }
+    int nA = 0, nB = 0, nC = 0;
     for (int b = 0; b < n_boxes; b++) {
       const float* bx = boxes + b * EPMC_BOX_WORDS;
-      const bool near = bx[1] >= pos[0] - 3.6f && bx[0] <= pos[0] + 3.6f && bx[3] >= pos[1] - 3.6f && bx[2] <= pos[1] + 3.6f;
+      const bool grid = bx[1] >= pos[0] - hgx && bx[0] <= pos[0] + hgx && bx[3] >= pos[1] - hgy && bx[2] <= pos[1] + hgy;
+      const bool front = bx[1] >= flo[0] && bx[0] <= fhi[0] && bx[3] >= flo[1] && bx[2] <= fhi[1] && bx[5] >= flo[2] && bx[4] <= fhi[2];
       const bool fan = bx[1] >= pos[0] - 20.1f && bx[0] <= pos[0] + 20.1f && bx[3] >= pos[1] - 20.1f && bx[2] <= pos[1] + 20.1f && bx[4] <= pos[2] && bx[5] >= pos[2];
-      if (near) {
+      if (grid) {
         if (nA < EPMC_LIST_A_MAX && ln.lane0()) for (int i = 0; i < EPMC_BOX_WORDS; i++) listA[nA * EPMC_BOX_WORDS + i] = bx[i];
         nA++;
       }
@@ -317,11 +332,16 @@ struct Epmc {
         if (nB < EPMC_LIST_B_MAX && ln.lane0()) for (int i = 0; i < EPMC_BOX_WORDS; i++) listB[nB * EPMC_BOX_WORDS + i] = bx[i];
         nB++;
       }
+      if (front) {
+        if (nC < EPMC_LIST_C_MAX && ln.lane0()) for (int i = 0; i < EPMC_BOX_WORDS; i++) listC[nC * EPMC_BOX_WORDS + i] = bx[i];
+        nC++;
+      }
     }
     ln.row_sync();
     const float* LA = nA <= EPMC_LIST_A_MAX ? listA : boxes;                     // a list that does not fit: walk all boxes (the tests are exact anyway)
     const float* LB = nB <= EPMC_LIST_B_MAX ? listB : boxes;
-    const int cA = nA <= EPMC_LIST_A_MAX ? nA : n_boxes, cB = nB <= EPMC_LIST_B_MAX ? nB : n_boxes;
+    const float* LC = nC <= EPMC_LIST_C_MAX ? listC : boxes;
+    const int cA = nA <= EPMC_LIST_A_MAX ? nA : n_boxes, cB = nB <= EPMC_LIST_B_MAX ? nB : n_boxes, cC = nC <= EPMC_LIST_C_MAX ? nC : n_boxes;
     // --- height grid (PGE:431-447): straight down from z = 10 to -10: the highest top under (x, y), or the plane ---
     if (!PMC_ABL(128))
     for (int r = ln.ray_first(); r < EPMC_N_HEIGHT; r += ln.ray_stride()) {
@@ -392,10 +412,10 @@ struct Epmc {
           const float tz = -o[2] * inv[2];
           if (tz >= 0.0f && tz <= 1.0f) best = tz;
         }
-        BoxRec nx = load_box(LA);
-        for (int b = 0; b < cA; b++) {
+        BoxRec nx = load_box(LC);
+        for (int b = 0; b < cC; b++) {
           const BoxRec bx = nx;
-          nx = load_box(LA + (b + 1) * EPMC_BOX_WORDS);
+          nx = load_box(LC + (b + 1) * EPMC_BOX_WORDS);
           float te = -3.0e38f, tl = 3.0e38f;
           slab_axis(bx.a.x, bx.a.y, o[0], d[0], inv[0], te, tl);
           slab_axis(bx.a.z, bx.a.w, o[1], d[1], inv[1], te, tl);

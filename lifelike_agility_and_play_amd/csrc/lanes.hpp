@@ -65,7 +65,7 @@ LL_HD bool eq_(int a, int b) { return a == b; }
 }  // namespace lm
 
 #define PMC_ROW 16   // lanes per environment
-#define PMC_ROW_SCRATCH 608   // floats of LDS scratch per env row (EPMC: 40 boxes x 8, two ray lists of 12 and 16 records, 64 spare)
+#define PMC_ROW_SCRATCH 688   // floats of LDS scratch per env row (EPMC: 40 boxes x 8, three ray lists of 10, 16 and 12 records, 64 spare: epmc_step.hpp)
 
 #if defined(__HIPCC__)
 // DPP helpers.  ctrl encodings (gfx9 DPP16): quad_perm 0x00-0xFF, row_shr:n 0x110+n, row_ror:n 0x120+n, row_newbcast:n 0x150+n.

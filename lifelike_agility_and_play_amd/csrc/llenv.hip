@@ -369,6 +369,8 @@ struct HipBackend {
 
   static size_t lds_bytes() { return ((size_t)LC_COUNT * 4 + (size_t)CAND_TABLE_WORDS * PMC_ROW + PMC_ENVS_PER_WAVE * 12) * sizeof(float); }
   static size_t lds_bytes_epmc() { return lds_bytes() + (size_t)PMC_ENVS_PER_WAVE * PMC_ROW_SCRATCH * sizeof(float); }
+  static_assert(((size_t)LC_COUNT * 4 + (size_t)CAND_TABLE_WORDS * PMC_ROW + PMC_ENVS_PER_WAVE * 12 + (size_t)PMC_ENVS_PER_WAVE * PMC_ROW_SCRATCH) * sizeof(float) <= 160 * 1024 / 8,
+                "eight single-wave workgroups per CU (two per SIMD) must fit the 160 KB of LDS");
   std::pair<hipEvent_t, hipEvent_t>* timing_begin(int n_steps = 1) {
     if (!timing) return nullptr;
     if (ev_used == kMaxTimedLaunches) return nullptr;   // un-polled timing does not grow without bound: later launches go untimed

@@ -14,11 +14,11 @@
 
 #define SEPMC_OBS_TAIL 52        // percept_vec 5, oppo_info 15, oppo_info_cheat 15, flag_info 7, flag_info_cheat 7, with_flag 2, control_spd 1
 #define SEPMC_SP_STRIDE 40
-#define SEPMC_PARK_AT 544       // row-scratch word: the 64 spare words behind the ray lists (lanes.hpp PMC_ROW_SCRATCH)
+#define SEPMC_PARK_AT EPMC_SPARE // row-scratch word: the 64 spare words behind the ray lists (epmc_step.hpp)
 #define SEPMC_MAX_CONTACTS 8     // scripted getContactPoints records per arena
 #define SEPMC_N_VIS 21           // visibility rays per arena: base to base, then head of robot i to the 10 convex points of the other
 #define SEPMC_WALL_SOLID 1.0f     // metres the arena walls extend outwards for the contact tests (the rays see their true 1 cm)
-#define SEPMC_VIS_SCRATCH 544    // word of the row scratch where the visibility end points go (after the staged boxes and the ray lists)
+#define SEPMC_VIS_SCRATCH EPMC_SPARE    // word of the row scratch where the visibility end points go (after the staged boxes and the ray lists)
 
 enum SepmcField {
   SP_FLAG = 0,          // 3 flag position (CTG:231-236)

@@ -147,6 +147,7 @@ typedef EpmcEngine<HostBackend> EPMC_ENGINE;
 #include "../../lifelike_agility_and_play_amd/csrc/epmc_capi.inc"
 typedef SepmcEngine<HostBackend> SEPMC_ENGINE;
 #include "../../lifelike_agility_and_play_amd/csrc/sepmc_capi.inc"
+static_assert(sizeof(HostLanes::scratch_) == PMC_ROW_SCRATCH * sizeof(float), "lanes_host.hpp: the row scratch must have the size lanes.hpp states");
 
 extern "C" {
 // single physics substep on explicit state (staged comparison with the oracle); tgt = PD target joint angles

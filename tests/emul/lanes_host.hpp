@@ -116,7 +116,7 @@ struct HostLanes {
   void park_row(const float*, int, int) const {}
   void unpark_row(float*, int, int) const {}
   const float* stage_row(const float* g, int) const { return g; }
-  alignas(16) mutable float scratch_[608];
+  alignas(16) mutable float scratch_[688];   // = PMC_ROW_SCRATCH (lanes.hpp, included later); checked below
   float* row_scratch() const { return scratch_; }
   void prepare_turn_masks() const {}
   I leg() const { iN r; for (int i = 0; i < EW; i++) r.v[i] = i >> 2; return r; }
