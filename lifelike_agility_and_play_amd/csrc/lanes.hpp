@@ -93,6 +93,7 @@ struct GpuLanes {
   mutable unsigned long long tm_[16];
 
   static constexpr bool kHoldLink = false;   // pmc_step.hpp own_link: re-read the own-link constants every substep
+  static constexpr bool kPrefetchShapes = false;   // see WithShapePrefetch below
   LL_D GpuLanes(float* lds) : leg_((threadIdx.x >> 2) & 3), sub_(threadIdx.x & 3), lane16_(threadIdx.x & 15), lds_(lds), cbase_(0), tbase_(0) {}
 
   // Stage the constant tables in LDS: legc [n_leg_fields][4] then candc [n_cand_words][16].  A constant then costs one
@@ -517,6 +518,15 @@ struct WithParamsReload : Base {
     asm volatile("" : "+s"(k));
     return *(const T*)(const __attribute__((address_space(4))) T*)k;
   }
+};
+
+// Terrain builds (EPMC / SEPMC): read the terrain shape records of the contact-candidate loops one shape ahead (pmc_step.hpp shape_sdf_rec).
+// Measured per kernel on one box (tools/ab.sh): EPMC at 65536 envs 20.4 -> 22.5 M env-steps/s (+10.6 %), at 4096 envs +0.3 % slower;
+// SEPMC at 2048 arenas -1.1 % per step, at 32768 arenas 16.7 -> 16.1 M (-3.7 %): on for the larger-batch EPMC and the one-wave-per-SIMD SEPMC kernels.
+template <class Base, bool ON>
+struct WithShapePrefetch : Base {
+  using Base::Base;
+  static constexpr bool kPrefetchShapes = ON;
 };
 
 #define LL_FMAC_RBCAST(L_)                                                                                               \

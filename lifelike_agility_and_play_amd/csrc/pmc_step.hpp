@@ -383,12 +383,26 @@ struct Pmc {
     shape_sdf<T>(ln, ex->shapes + si * 8, El, d, nl, is_box);
     n = mk3<T>(nl.x * ex->ycs - nl.y * ex->ysn, nl.x * ex->ysn + nl.y * ex->ycs, nl.z);
   }
+  template <class T>
+  static LL_HD void terrain_sdf_rec(const L& ln, const SubstepExtra* ex, const BoxRec& rec, const V3<T>& E, T& d, V3<T>& n, T& is_box) {
+    if (!ex->yawed) { shape_sdf_rec<T>(ln, rec, E, d, n, is_box); return; }
+    const T dx = E.x - ex->ycx, dy = E.y - ex->ycy;
+    V3<T> El = mk3<T>(dx * ex->ycs + dy * ex->ysn, dy * ex->ycs - dx * ex->ysn, E.z), nl;
+    shape_sdf_rec<T>(ln, rec, El, d, nl, is_box);
+    n = mk3<T>(nl.x * ex->ycs - nl.y * ex->ysn, nl.x * ex->ysn + nl.y * ex->ycs, nl.z);
+  }
   // Signed distance of point E to record s (box united with its edge rods) and the outward normal there.  Inside a box the
   // face of least penetration gives both; outside, the nearest point of the box does.
   template <class T>
   static LL_HD void shape_sdf(const L& ln, const float* s, const V3<T>& E, T& d, V3<T>& n, T& is_box) {
+    shape_sdf_rec<T>(ln, load_box(s), E, d, n, is_box);             // two 16-byte reads instead of eight scalar ones
+  }
+  // (the record already in registers: where the lane policy says so -- lanes.hpp WithShapePrefetch, chosen per kernel by A/B -- the candidate
+  //  loops read it one shape ahead, so that the LDS round trip hides behind the previous shape's arithmetic or, for the first shape, behind
+  //  the candidate's own kinematics)
+  template <class T>
+  static LL_HD void shape_sdf_rec(const L& ln, const BoxRec& rec, const V3<T>& E, T& d, V3<T>& n, T& is_box) {
     const T zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f), neg = ln.lane_f(-1.0f);
-    const BoxRec rec = load_box(s);                                  // two 16-byte reads instead of eight scalar ones
     T ax0 = ln.lane_f(rec.a.x) - E.x, ax1 = E.x - ln.lane_f(rec.a.y);
     T ay0 = ln.lane_f(rec.a.z) - E.y, ay1 = E.y - ln.lane_f(rec.a.w);
     T az0 = ln.lane_f(rec.c.x) - E.z, az1 = E.z - ln.lane_f(rec.c.y);
@@ -859,11 +873,19 @@ struct Pmc {
         if (terr) {
           V3l Ew;
           F rs;
+          BoxRec nx;
+          if constexpr (L::kPrefetchShapes) nx = load_box(ex->shapes);    // (lanes.hpp WithShapePrefetch; one record past the list is readable row scratch)
           cand_eval_point(ln, bs, R, tgR[g], tgp[g], gez[g], A, ax, r, az, len, Ew, rs);
           for (int si = 0; si < n_shapes; si++) {
             F ds, isb;
             V3l ns;
-            terrain_sdf<F>(ln, ex, si, Ew, ds, ns, isb);
+            if constexpr (L::kPrefetchShapes) {
+              const BoxRec rec = nx;
+              nx = load_box(ex->shapes + (si + 1) * 8);
+              terrain_sdf_rec<F>(ln, ex, rec, Ew, ds, ns, isb);
+            } else {
+              terrain_sdf<F>(ln, ex, si, Ew, ds, ns, isb);
+            }
             dpt = lm::min_(dpt, ds - rs);
             if (want_touch) {
               B isf = ln.lane_f(si == ex->flag_shape ? 1.0f : 0.0f) > 0.5f;
@@ -1013,6 +1035,8 @@ struct Pmc {
                       lm::sel(l0, zero, lm::sel(l1, k.p1.z, lm::sel(l2, k.p2.z, k.p3.z))));
           V3l Ew;
           F rs;
+          BoxRec nx;
+          if constexpr (L::kPrefetchShapes) nx = load_box(ex->shapes);
           cand_eval_point(ln, bs, R, lR, lp, ezk, A, ax, r, az, len, Ew, rs);
           F best = Ew.z - rs;                                  // the plane
           V3l nw = mk3<F>(zero, zero, one);
@@ -1020,7 +1044,13 @@ struct Pmc {
           for (int si = 0; si < n_shapes; si++) {
             F ds, isb;
             V3l ns;
-            terrain_sdf<F>(ln, ex, si, Ew, ds, ns, isb);
+            if constexpr (L::kPrefetchShapes) {
+              const BoxRec rec = nx;
+              nx = load_box(ex->shapes + (si + 1) * 8);
+              terrain_sdf_rec<F>(ln, ex, rec, Ew, ds, ns, isb);
+            } else {
+              terrain_sdf<F>(ln, ex, si, Ew, ds, ns, isb);
+            }
             B win = (ds - rs) < best;
             best = lm::sel(win, ds - rs, best);
             nw = mk3<F>(lm::sel(win, ns.x, nw.x), lm::sel(win, ns.y, nw.y), lm::sel(win, ns.z, nw.z));

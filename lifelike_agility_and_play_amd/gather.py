@@ -47,7 +47,9 @@ def bind_torch_stream(engine, stream=None):
 
 def use_engine_stream(engine):
     """The other direction of bind_torch_stream, for engines without a set_stream entry (EPMC, SEPMC): torch's current stream becomes
-    the engine's own stream, so torch ops on the engine's buffers are ordered with its kernels."""
+    the engine's own stream, so torch ops on the engine's buffers are ordered with its kernels.  The stream belongs to the engine: before
+    the engine is closed, give torch another one (torch.cuda.set_stream(torch.cuda.default_stream())) -- torch ops queued on a destroyed
+    stream fail with unrelated-looking errors."""
     s = torch.cuda.ExternalStream(int(engine.device_ptrs().stream))
     torch.cuda.set_stream(s)
     return s

@@ -107,6 +107,7 @@ struct HostLanes {
   void refresh_consts() const {}
   void new_step() {}
   static constexpr int kParamsReload = 0;
+  static constexpr bool kPrefetchShapes = true;     // (the host build runs the read-ahead variant: it reads one record past the list)
   template <class T>
   const T& params(const T& as_passed) const { return as_passed; }
   bool lane0() const { return true; }

@@ -77,6 +77,8 @@ def test_zero_copy_torch_views_gpu():
     np.testing.assert_array_equal(T['obs'].cpu().numpy().reshape(64, 2, 965), E.obs())
     live = ~np.repeat(E.reward_done()[1], 2)
     np.testing.assert_allclose(T['obs'][:, 123:135].cpu().numpy()[live], a.cpu().numpy()[live], rtol=1e-6)      # the newest action frame of prop_a
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream())     # the engine's stream dies with the engine: torch must not keep it as its current stream
     E.close()
 
 
