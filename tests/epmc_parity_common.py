@@ -141,6 +141,9 @@ def check_ray_casting_against_oracle(lib_path, n_envs=12, n_steps=6, seed=3):
         for t in range(n_steps):
             s = E.state()
             s[:, 0] += rng.uniform(0.5, 2.5, n_envs) * (t > 0); s[:, 1] = rng.uniform(-0.4, 0.4, n_envs); s[:, 2] = rng.uniform(0.2, 0.45, n_envs)
+            if t >= 2:      # any heading, rolled and pitched: the box lists of the ray families follow the bundles' bounds as they lie in the world
+                from scipy.spatial.transform import Rotation as Rot
+                s[:, 3:7] = Rot.from_euler('zyx', np.c_[rng.uniform(-np.pi, np.pi, n_envs), rng.uniform(-0.6, 0.6, n_envs), rng.uniform(-0.6, 0.6, n_envs)]).as_quat()
             E.set_state(s)
             E.step_host(np.zeros((n_envs, 12), np.float32))
             r, d, why = E.reward_done()
