@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define LL_ABI_VERSION 2   /* 2: ll_enable_trajectory -> ll_enable_unrolls (round 2); ll_step_random_n, ll_unroll_position, ll_pg_mark_current, ll_kernel_time_stats */
+#define LL_ABI_VERSION 2   /* 2: ll_enable_trajectory -> ll_enable_unrolls (round 2); ll_step_random_n, ll_unroll_position, ll_pg_mark_current, ll_kernel_time_stats;
+                              ll_sepmc_config grew max_tau_robot1 at its end (llenv_sepmc.h); spec id LLM_SPEC_LIMIT_SPECULATIVE (llenv_model.h) */
 
 /* per-env sizes (PLE:101-124) */
 #define LL_N_JOINTS 12
