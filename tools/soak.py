@@ -53,3 +53,40 @@ print('sepmc finite', fin, 'robots outside the walls:', len(out), [(int(a), int(
 print('sepmc %6d steps x 2048 arenas (all elements): %d episodes, %d non-finite resets, max |xy| %.2f, sampled end reasons fall %d time %d catch %d, %.1f s' % (
     n, c['episodes'], c['nonfinite'], np.abs(s[:, :, 0:2]).max(), why_hist[1::2].sum(), (why_hist[[2, 3, 6, 7, 10, 11]]).sum(), why_hist[8:16].sum(), time.perf_counter() - t0))
 E.close()
+
+# the larger-batch builds (two waves per SIMD: episode scalars parked in LDS, shape records read ahead, argument block re-read)
+t0 = time.perf_counter()
+cfg = capi.make_config(16384, control_freq=50.0, kd=0.5, prop_type=PMC_PROP_TYPE, prioritized_sample_factor=3.0, reward_weights=PMC_REWARD_WEIGHTS, auto_reset=1, seed=80)
+E = capi.Engine(cfg, blob, mocap.load_mocap('', 0.02))
+E.reset()
+n = int(sys.argv[1]) // 8
+for t in range(0, n, 64):
+    E.step_random_n(SIG, min(64, n - t))
+o, s, c = E.obs(), E.state(), E.counters()
+assert np.isfinite(o).all() and np.isfinite(s).all()
+print('pmc   %6d steps x 16384 envs: %d episodes (mean length %.1f steps), %d non-finite resets, max |q| %.2f, %.1f s' % (n, c['episodes'], c['env_steps'] / max(1, c['episodes']), c['nonfinite'],
+      np.abs(s[:, 13:25]).max(), time.perf_counter() - t0))
+E.close()
+for el in (1, 2, 3):
+    t0 = time.perf_counter()
+    E = epmc_capi.EpmcEngine(epmc_capi.make_epmc_config(16384, epmc_env_config(el), auto_reset=1, seed=81 + el), blob)
+    E.reset()
+    n = int(sys.argv[2]) // 4
+    for t in range(0, n, 32):
+        E.step_random_n(SIG, min(32, n - t))
+    o, s, c = E.obs(), E.state(), E.counters()
+    assert np.isfinite(o).all() and np.isfinite(s).all()
+    print('epmc  %6d steps x 16384 envs (element %d): %d episodes, %d non-finite resets, x range [%.1f, %.1f], z range [%.2f, %.2f], %.1f s' % (
+        n, el, c['episodes'], c['nonfinite'], s[:, 0].min(), s[:, 0].max(), s[:, 2].min(), s[:, 2].max(), time.perf_counter() - t0))
+    E.close()
+t0 = time.perf_counter()
+E = sepmc_capi.SepmcEngine(sepmc_capi.make_sepmc_config(8192, sepmc_env_config(1), auto_reset=1, seed=85), blob)
+E.reset()
+n = int(sys.argv[3]) // 4
+for t in range(0, n, 50):
+    E.step_random_n(SIG, 50)
+o, s, c = E.obs(), E.state(), E.counters()
+out = np.argwhere(np.abs(s[:, :, 0:2]).max(axis=2) >= 2.7)
+print('sepmc %6d steps x 8192 arenas (all elements): finite %s, %d episodes, %d non-finite resets, robots outside the walls %d, max |xy| %.2f, %.1f s' % (
+    n, bool(np.isfinite(o).all() and np.isfinite(s).all()), c['episodes'], c['nonfinite'], len(out), np.abs(s[:, :, 0:2]).max(), time.perf_counter() - t0))
+E.close()
