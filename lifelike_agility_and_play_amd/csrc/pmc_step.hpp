@@ -929,9 +929,9 @@ struct Pmc {
       // first own candidate within the tolerance of the leg's deepest: key = jj if depth <= thr, jj + 100 otherwise, as
       // clamp(jj + (depth - thr) * 1e30, jj, jj + 100) -- a v_fma and a v_med3 per candidate instead of a compare feeding a select
       // (which costs two wait states on gfx950); the smallest key is the answer
-      F nthr = thr * -1.0e30f;
+      // (the difference is formed first: at depth == thr the key is exactly jj on the GPU's fused multiply-add as on the host's multiply and add)
       F am = ln.lane_f(100.0f);
-      for (int jj = NC - 1; jj >= 0; jj--) am = lm::min_(am, lm::med3_(depth[jj] * 1.0e30f + (nthr + (float)jj), ln.lane_f((float)jj), ln.lane_f((float)jj + 100.0f)));
+      for (int jj = NC - 1; jj >= 0; jj--) am = lm::min_(am, lm::med3_((depth[jj] - thr) * 1.0e30f + (float)jj, ln.lane_f((float)jj), ln.lane_f((float)jj + 100.0f)));
       F code = lm::sel(lm::and_(am < 50.0f, mq < far_), L::i2f(ln.sub()) * STRIDE + am, ln.lane_f(1000.0f));
       F wcode = L::submin(code);                            // lowest candidate index among them (1000 = none)
       B winner = lm::and_(code <= wcode, code < 500.0f);
