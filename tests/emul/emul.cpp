@@ -98,7 +98,8 @@ struct HostBackend {
       for (int env = 0; env < P.n_envs; env++) {
         fN act[3];
         for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
-        Epmc<HostLanes>::step_env(ln, P, E, env, act);
+        if (getenv("LL_EMUL_PARK")) Epmc<HostLanes>::step_env<true>(ln, P, E, env, act);      // the larger-batch GPU build's variant (tests)
+        else Epmc<HostLanes>::step_env(ln, P, E, env, act);
       }
     }
   }
@@ -128,7 +129,8 @@ struct HostBackend {
       run_pairs(P, P.n_envs, [&](HostLanes& ln, int row) {
         fN act[3];
         for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)row * 12 + j, 3);
-        Sepmc<HostLanes>::step_env(ln, P, S, row, act);
+        if (getenv("LL_EMUL_PARK")) Sepmc<HostLanes>::step_env<true>(ln, P, S, row, act);
+        else Sepmc<HostLanes>::step_env(ln, P, S, row, act);
       });
     }
   }

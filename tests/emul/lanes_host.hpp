@@ -114,8 +114,9 @@ struct HostLanes {
   int ray_first() const { return 0; }
   int ray_stride() const { return 1; }
   void row_sync() const {}
-  void park_row(const float*, int, int) const {}
-  void unpark_row(float*, int, int) const {}
+  // (really through the scratch, so that step_env<PARK = true> -- LL_EMUL_PARK=1 -- checks on the host that nothing the substep loop changes is lost)
+  void park_row(const float* v, int n, int at) const { for (int i = 0; i < n; i++) scratch_[at + i] = v[i]; }
+  void unpark_row(float* v, int n, int at) const { for (int i = 0; i < n; i++) v[i] = scratch_[at + i]; }
   const float* stage_row(const float* g, int) const { return g; }
   alignas(16) mutable float scratch_[688];   // = PMC_ROW_SCRATCH (lanes.hpp, included later); checked below
   float* row_scratch() const { return scratch_; }

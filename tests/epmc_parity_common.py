@@ -234,6 +234,41 @@ def check_multi_step_launch(lib_path, sizes=(12,), k=5, n_launches=4, element=1)
         A.close(); B.close()
 
 
+def check_parked_variant_equals_plain(lib_path, n=10, n_steps=40, element=1):
+    """step_env<PARK = true> -- what the larger-batch GPU build runs: the episode scalars wait in the row scratch during the substep loop and the
+    observation history is read after it -- against the plain variant on the HOST build (LL_EMUL_PARK=1 switches; there the two are the same
+    float arithmetic, so everything must agree bit for bit: a field the substep loop changes and the parked variant forgets to keep would show
+    here).  Pushes on, episodes ending and re-seeding inside the run."""
+    import os
+    sg = float(np.exp(-2.0))
+    cfg = env_config(element)
+    cfg['max_steps'] = 15
+    cfg['env_randomize_config']['disturb_force_config'] = {'start_time': 0.0, 'interval_time': 0.1, 'duration_time': 0.06, 'horizontal_force': [10, 50], 'vertical_force': [0, 10]}
+    A = make_engine(cfg, n, lib_path, auto_reset=1, seed=4)
+    B = make_engine(cfg, n, lib_path, auto_reset=1, seed=4)
+    A.reset(); B.reset()
+    pushed = 0
+    try:
+        for t in range(n_steps):
+            os.environ.pop('LL_EMUL_PARK', None)
+            A.fill_random_actions(sg); A.step()
+            os.environ['LL_EMUL_PARK'] = '1'
+            B.fill_random_actions(sg); B.step()
+            np.testing.assert_array_equal(A.state(), B.state())
+            np.testing.assert_array_equal(A.obs(), B.obs())
+            for x, y in zip(A.reward_done(), B.reward_done()):
+                np.testing.assert_array_equal(x, y)
+            ea, eb = A.episode(), B.episode()
+            for key in ea:
+                np.testing.assert_array_equal(ea[key], eb[key])
+            np.testing.assert_array_equal(np.asarray(A.push_trace()), np.asarray(B.push_trace()))
+            pushed += int(np.asarray(A.push_trace())[..., 0].sum())
+    finally:
+        os.environ.pop('LL_EMUL_PARK', None)
+    assert A.counters() == B.counters() and A.counters()['episodes'] > 0 and pushed > 0
+    A.close(); B.close()
+
+
 def check_trained_policies_traverse(lib_path, n_envs=8, horizon=(360, 560)):
     """SURVEY.md 8f-3 for the environmental level -- the only Bullet-facing check of this build's terrain contacts and 778 analytic rays: the
     reference's TRAINED EPMC policies (data/models/environmental_level_{hurdle,cube}.model, trained against PyBullet; the hole checkpoint

@@ -507,6 +507,38 @@ def check_multi_step_launch(lib_path, sizes=(6,), k=5, n_launches=4):
         A.close(); B.close()
 
 
+def check_parked_variant_equals_plain(lib_path, n=4, n_steps=30):
+    """step_env<PARK = true> (the larger-batch GPU build: episode scalars in the row scratch during the substep loop, history read after it) against
+    the plain variant on the HOST build, bit for bit (LL_EMUL_PARK=1; see epmc_parity_common.check_parked_variant_equals_plain)."""
+    import os
+    sg = float(np.exp(-2.0))
+    cfg = env_config(ALL_ELEMENTS, max_steps=12)
+    cfg['env_randomize_config']['disturb_force_config'] = {'start_time': 0.0, 'interval_time': 0.1, 'duration_time': 0.06, 'horizontal_force': [10, 50], 'vertical_force': [0, 10]}
+    A = make_engine(cfg, n, lib_path, auto_reset=1, seed=4)
+    B = make_engine(cfg, n, lib_path, auto_reset=1, seed=4)
+    A.reset(); B.reset()
+    pushed = 0
+    try:
+        for t in range(n_steps):
+            os.environ.pop('LL_EMUL_PARK', None)
+            A.fill_random_actions(sg); A.step()
+            os.environ['LL_EMUL_PARK'] = '1'
+            B.fill_random_actions(sg); B.step()
+            np.testing.assert_array_equal(A.state(), B.state())
+            np.testing.assert_array_equal(A.obs(), B.obs())
+            for x, y in zip(A.reward_done(), B.reward_done()):
+                np.testing.assert_array_equal(x, y)
+            ea, eb = A.episode(), B.episode()
+            for key in ea:
+                np.testing.assert_array_equal(ea[key], eb[key])
+            np.testing.assert_array_equal(np.asarray(A.push_trace()), np.asarray(B.push_trace()))
+            pushed += int(np.asarray(A.push_trace())[..., 0].sum())
+    finally:
+        os.environ.pop('LL_EMUL_PARK', None)
+    assert A.counters() == B.counters() and A.counters()['episodes'] > 0 and pushed > 0, (A.counters(), pushed)
+    A.close(); B.close()
+
+
 def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5, total_arenas=None):
     """Two robots within reach of each other (side by side, nose to tail, one partly above the other), random joint states and
     velocities, the push active: one control step of real physics, engine (float32, two rows exchanging registers) vs the float64

@@ -58,3 +58,8 @@ def test_free_running_against_the_oracle_env(emul_lib):
 def test_free_running_with_noise_and_without_edge_cylinders(emul_lib):
     noise = {'pos_x_bias': [-0.1, 0.1], 'pos_y_bias': [-0.1, 0.1], 'yaw_bias': [-0.2, 0.2], 'pos_z_bias': [-0.02, 0.02]}
     print(ec.check_free_running_against_oracle_env(emul_lib, n_steps=3, elements=(2, 1), aux=None, obs_rand=noise))
+
+
+def test_parked_variant_equals_plain(emul_lib):
+    ec.check_parked_variant_equals_plain(emul_lib)
+

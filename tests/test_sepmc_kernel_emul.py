@@ -87,3 +87,8 @@ def test_free_running_with_another_prop_type(emul_lib):
 
 def test_free_running_with_observation_noise(emul_lib):
     print(SC.check_free_running_against_oracle_env(emul_lib, n_steps=3, element_sets=((0, 1, 0),), noisy=True))
+
+
+def test_parked_variant_equals_plain(emul_lib):
+    SC.check_parked_variant_equals_plain(emul_lib)
+
