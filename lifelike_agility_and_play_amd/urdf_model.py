@@ -6,6 +6,14 @@ site legged_robot.py:208-220 (dynamic robot) and :267-275 (kinematic ghost):
 tree topology, joint frames/axes, link mass/COM/inertia, joint limits/damping and
 the primitive collision shapes.
 
+Link inertias come in two flavours (``UrdfModel(path, inertia=...)``):
+  * ``'collision_aabb'`` (what the reference's call builds, and the shipped default since round 4): the
+    reference does NOT pass ``URDF_USE_INERTIA_FROM_FILE`` (legged_robot.py:212-217), and without it Bullet's
+    importer keeps only mass and inertial frame of the URDF ``<inertial>`` and takes the inertia diagonal from
+    ``btCompoundShape::calculateLocalInertia``: the *box inertia of the AABB of the link's collision shapes*,
+    measured in the link's inertial frame, applied at the URDF COM (see ``aabb_box_inertia``);
+  * ``'file'``: the ``<inertia>`` tensors of the URDF (``URDF_USE_INERTIA_FROM_FILE`` behaviour; rounds 1-3).
+
 Differences from Bullet's importer, all dynamically equivalent:
   * fixed joints (feet, wheels, handles) are merged into their parent body
     -> 13 bodies / 12 revolute joints (Bullet keeps 23 links, 10 of them welded);
@@ -80,6 +88,50 @@ def _origin(elem):
     return _floats(o.get('xyz'), 3, [0, 0, 0]), rpy_to_mat(_floats(o.get('rpy'), 3, [0, 0, 0]))
 
 
+# Bullet's collision margins as the importer sets them (URDF importer: ``gUrdfDefaultCollisionMargin`` = 0.001 on
+# every child shape and on the link's btCompoundShape).
+URDF_COLLISION_MARGIN = 0.001
+
+
+def prim_aabb_half_extents(prim, rot_to_frame):
+    """Half extents of one collision primitive's AABB in a frame whose axes are ``rot_to_frame`` @ (primitive axes),
+    as Bullet's shape classes report it (recalled from the published source, PyBullet itself is absent here):
+      * btBoxShape: the full half extents (its margin lives inside the box);
+      * btSphereShape: the radius;
+      * URDF cylinder without URDF_USE_IMPLICIT_CYLINDER (the reference's flags): a btConvexHullShape over a 32-gon
+        prism (vertices at multiples of 2*pi/32: the extremes lie ON the coordinate axes, so the prism spans the full
+        radius) whose cached local AABB already holds the margin and whose getAabb adds it once more: + 2 margins.
+    The local half extents are rotated with the absolute value of the rotation (btTransformAabb)."""
+    t, size, _pos, rot = prim
+    if t == PRIM_BOX:
+        h = np.array(size, dtype=np.float64)
+    elif t == PRIM_SPHERE:
+        h = np.full(3, float(size[0]))
+    elif t == PRIM_CYL:
+        h = np.array([size[0], size[0], size[1]], dtype=np.float64) + 2.0 * URDF_COLLISION_MARGIN
+    else:
+        raise ValueError(t)
+    return np.abs(rot_to_frame @ rot) @ h
+
+
+def aabb_box_inertia(mass, prims, inertial_xyz, inertial_rot):
+    """``btCompoundShape::calculateLocalInertia`` for a link: children sit at inertial_frame^-1 * collision_frame, the
+    compound's AABB is the union of the children's AABBs grown by the compound's own margin, and the inertia is the
+    solid-box formula on the AABB's edge lengths -- diagonal in the inertial frame, used AT the URDF COM wherever the
+    AABB's centre lies.  A link without mass keeps zero inertia (the importer skips the call: ``if (mass)``).
+    Returns the 3x3 tensor in LINK axes (about the COM)."""
+    if mass == 0.0 or not prims:
+        return np.zeros((3, 3))
+    lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+    for p in prims:
+        c = inertial_rot.T @ (p[2] - inertial_xyz)
+        h = prim_aabb_half_extents(p, inertial_rot.T)
+        lo, hi = np.minimum(lo, c - h), np.maximum(hi, c + h)
+    l = (hi - lo) + 2.0 * URDF_COLLISION_MARGIN
+    d = mass / 12.0 * np.array([l[1] ** 2 + l[2] ** 2, l[0] ** 2 + l[2] ** 2, l[0] ** 2 + l[1] ** 2])
+    return inertial_rot @ np.diag(d) @ inertial_rot.T
+
+
 class _Link:
     def __init__(self, elem):
         self.name = elem.get('name')
@@ -87,6 +139,7 @@ class _Link:
         self.mass = 0.0
         self.com = np.zeros(3)
         self.inertia = np.zeros((3, 3))      # about COM, link axes
+        self.inertial_rot = np.eye(3)
         if ine is not None:
             xyz, rot = _origin(ine)
             self.mass = float(ine.find('mass').get('value'))
@@ -109,6 +162,8 @@ class _Link:
                 self.prims.append((PRIM_CYL, np.array([float(cy.get('radius')), float(cy.get('length')) * 0.5, 0]), xyz, rot))
             else:
                 raise ValueError('unsupported collision geometry on ' + self.name)
+        self.inertia_file = self.inertia
+        self.inertia_aabb = aabb_box_inertia(self.mass, self.prims, self.com, self.inertial_rot)
 
 
 def _merge_inertia(m1, c1, I1, m2, c2, I2):
@@ -127,9 +182,14 @@ def _merge_inertia(m1, c1, I1, m2, c2, I2):
 class UrdfModel:
     """Compiled 13-body model.  Attribute names mirror the blob fields."""
 
-    def __init__(self, urdf_path):
+    def __init__(self, urdf_path, inertia='collision_aabb'):
+        assert inertia in ('file', 'collision_aabb'), inertia
+        self.inertia_source = inertia
         root = ET.parse(urdf_path).getroot()
         links = {l.get('name'): _Link(l) for l in root.findall('link')}
+        for l in links.values():                  # per link, BEFORE the fixed joints are merged (Bullet keeps 23 links)
+            l.inertia = l.inertia_aabb if inertia == 'collision_aabb' else l.inertia_file
+        self.urdf_links = {n: dict(mass=l.mass, com=l.com.copy(), inertia=l.inertia.copy()) for n, l in links.items()}
         joints = []
         for j in root.findall('joint'):
             xyz, rot = _origin(j)
@@ -257,7 +317,16 @@ class UrdfModel:
         return b
 
 
-def default_model_blob():
-    """The compiled MAX model shipped with the package (assets/max_model.npy)."""
+def model_blob(inertia='collision_aabb'):
+    """A compiled MAX model shipped with the package: ``assets/max_model.npy`` (link inertias as the reference's
+    ``loadURDF`` flags make Bullet build them) or ``assets/max_model_file_inertia.npy`` (the URDF's ``<inertia>``
+    tensors: the ``URDF_USE_INERTIA_FROM_FILE`` robot, shipped through round 3; kept as the A/B leg)."""
     import os
-    return np.load(os.path.join(os.path.dirname(__file__), 'assets', 'max_model.npy'))
+    name = {'collision_aabb': 'max_model.npy', 'file': 'max_model_file_inertia.npy'}[inertia]
+    return np.load(os.path.join(os.path.dirname(__file__), 'assets', name))
+
+
+def default_model_blob():
+    """The model every env uses unless told otherwise.  ``LL_MODEL_INERTIA=file`` selects the A/B leg."""
+    import os
+    return model_blob(os.environ.get('LL_MODEL_INERTIA', 'collision_aabb'))

@@ -924,6 +924,9 @@ static int find_self_contacts(const OModel* M, const OKin* K, OSelf* out) {
     for (int i = 0; i < nc && best < 0; i++)
       if (!taken[i] && cand[i].depth < g_spec[LLM_SPEC_SELF_MARGIN] && cand[i].depth <= dmin + g_spec[LLM_SPEC_SELECT_EPS]) best = i;
     if (best < 0) break;
+    for (int i = 0; i < nc; i++)             /* the same diagnostic as in find_contacts: a pair's distance near (closest + LLM_SELECT_EPS) */
+      if (!taken[i] && cand[i].depth < g_spec[LLM_SPEC_SELF_MARGIN] && fabs(cand[i].depth - dmin - g_spec[LLM_SPEC_SELECT_EPS]) < tl_sel_margin)
+        tl_sel_margin = fabs(cand[i].depth - dmin - g_spec[LLM_SPEC_SELECT_EPS]);
     taken[best] = 1;
     out[n++] = cand[best];
   }
@@ -1361,6 +1364,9 @@ static int find_pair_contacts(const OModel* M, const OKin* K0, const OKin* K1, O
     for (int i = 0; i < nc && best < 0; i++)
       if (!taken[i] && cand[i].depth < LLM_CONTACT_MARGIN && cand[i].depth <= dmin + g_spec[LLM_SPEC_SELECT_EPS]) best = i;
     if (best < 0) break;
+    for (int i = 0; i < nc; i++)             /* selection diagnostic, as in find_contacts */
+      if (!taken[i] && cand[i].depth < LLM_CONTACT_MARGIN && fabs(cand[i].depth - dmin - g_spec[LLM_SPEC_SELECT_EPS]) < tl_sel_margin)
+        tl_sel_margin = fabs(cand[i].depth - dmin - g_spec[LLM_SPEC_SELECT_EPS]);
     taken[best] = 1;
     out[n++] = cand[best];
   }

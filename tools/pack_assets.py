@@ -1,7 +1,10 @@
 """Build the data assets shipped with the package from the reference's DATA files.
 
 Runs only in the build container (reads /root/reference); outputs:
-  lifelike_agility_and_play_amd/assets/max_model.npy   compiled 13-body model (from max.urdf)
+  lifelike_agility_and_play_amd/assets/max_model.npy               compiled 13-body model (from max.urdf), link inertias as
+                                                                   Bullet builds them WITHOUT URDF_USE_INERTIA_FROM_FILE
+                                                                   (the reference's loadURDF flags, legged_robot.py:212-217)
+  lifelike_agility_and_play_amd/assets/max_model_file_inertia.npy  the same with the URDF's <inertia> tensors (A/B leg)
   lifelike_agility_and_play_amd/assets/mocap_f64.npz   62 clips packed, float64
 """
 import os
@@ -21,8 +24,8 @@ MOCAP = os.path.join(REF, 'data/mocap_data')
 def main():
     assets = os.path.join(ROOT, 'lifelike_agility_and_play_amd', 'assets')
     os.makedirs(assets, exist_ok=True)
-    m = urdf_model.UrdfModel(URDF)
-    np.save(os.path.join(assets, 'max_model.npy'), m.blob())
+    np.save(os.path.join(assets, 'max_model.npy'), urdf_model.UrdfModel(URDF, 'collision_aabb').blob())
+    np.save(os.path.join(assets, 'max_model_file_inertia.npy'), urdf_model.UrdfModel(URDF, 'file').blob())
     frames, lens, step, names = mocap.load_json_clips(MOCAP)
     mocap.save_packed(os.path.join(assets, 'mocap_f64.npz'), frames, lens, step, names)
     print('packed', len(lens), 'clips', frames.shape, 'frame_step', repr(step))
