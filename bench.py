@@ -150,13 +150,14 @@ def main():
     ap.add_argument('--warmup', type=int, default=200)
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-single-step-leg', action='store_true', help='skip the secondary one-launch-per-control-step measurement (N = 1)')
     ap.add_argument('--workload', choices=['pmc', 'epmc', 'sepmc'], default='pmc',
                     help="pmc = BASELINE config 2 (the contract line); epmc = config 4 (PlayGroundEnv, DESIGN.md 8), sepmc = config 5 (ChaseTagGameEnv, 2048 arenas x 2 robots, DESIGN.md 8b), same JSON shape")
     ap.add_argument('--element', type=int, default=1, help='epmc only: env_randomize_config element_id (0 joystick, 1 hurdles, 2 holes, 3 cubes)')
     ap.add_argument('--steps-per-launch', type=int, default=STEPS_PER_LAUNCH,
                     help='pmc: control steps per kernel launch (ll_step_random_n; the random policy needs nothing from the host between two '
                          'steps).  1 = one launch per control step (ll_step_random).  Must divide the unroll length %d when N > 1' % UNROLL)
-    ap.add_argument('--gather-mode', choices=['async', 'blocking', 'none'], default='async',
+    ap.add_argument('--gather-mode', choices=['async', 'blocking', 'none', 'p2p'], default='async',
                     help='N > 1 only: async = the double-buffered gather overlapping the next unroll (the contract line); blocking = every '
                          'gather is waited for before the next step (A/B leg: what the overlap buys); none = no gather (A/B leg: the steps alone)')
     args = ap.parse_args()
@@ -218,6 +219,7 @@ def main():
         # measurement hook (tools/simd_sharing.sh): with a ONE-rank communicator RCCL's gather is a 0.3 ms local copy; repeated k times it
         # stands in for the residency of an 8-rank gather (7 x 470 MB over xGMI: several ms) on the learner rank
         traj.extra_gathers = int(os.environ.get('LL_BENCH_GATHER_REPEAT', '0'))
+        traj.p2p_no_cu = os.environ.get('LL_BENCH_P2P_NO_CU', '1') == '1'     # --gather-mode p2p: SDMA pulls (0: the runtime's default copy path)
 
     def measure_triad():
         """the nominal HBM figure next to a device triad measured on this box (a = b + s * c on 3 x 1 GiB, torch's own kernel: a
@@ -309,6 +311,26 @@ def main():
                 gather_check = 'ok' if got_sig == sigs and len({tuple(x) for x in sigs}) == world else 'MISMATCH %r vs %r' % (got_sig, sigs)
     counters = eng.counters()
     ep_hist = [int(x) for x in eng.episode_histogram()]
+    # The like-for-like leg (round-3 advice): the same loop as ONE launch per control step -- what an actor with a policy between the steps
+    # runs, and what rounds 1-2 reported; the prioritized-sampling table is folded after every step, as PLE:235-240 does.  Measured after the
+    # contract region on the same engine (N = 1 only; a short region of its own), reported beside `value`, never instead of it.
+    single = None
+    if not multi and spl > 1 and not args.no_single_step_leg:
+        ks = max(1, min(args.steps, 200))
+        for _ in range(5):
+            eng.step_random(SIGMA)
+        dev_sync()
+        eng.enable_kernel_timing(True)
+        ts = time.perf_counter()
+        for _ in range(ks):
+            eng.step_random(SIGMA)
+        dev_sync()
+        ts = time.perf_counter() - ts
+        s_launch_ms, s_n, s_steps = eng.kernel_time_stats()
+        eng.enable_kernel_timing(False)
+        single = {'value': n * ks / ts, 'unit': 'env-steps/s', 'steps': ks, 'ms_per_step': ts / ks * 1e3, 'kernel_avg_ms': s_launch_ms,
+                  'note': 'one kernel launch per control step (ll_step_random), the sampling table folded after every step: the loop an actor with a '
+                          'policy between the steps runs'}
     if triad is None and not triad_first:
         triad = measure_triad()
 
@@ -348,6 +370,8 @@ def main():
                          'algorithmic_bytes_per_env_step': algo_bytes, 'single_wave_issue': issue,
                          'note': 'bound by single-wave instruction issue, not HBM (about 7.7e4 instructions per wave per step, four envs, vs 2.5 KB per env); see DESIGN.md 5.1'},
         }
+        if single is not None:
+            out['single_step_launch'] = single
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(blob, table)
         print(json.dumps(out), flush=True)

@@ -498,3 +498,4 @@ typedef EpmcEngine<HipBackend> EPMC_ENGINE;
 typedef SepmcEngine<HipBackend> SEPMC_ENGINE;
 #include "sepmc_capi.inc"
 #include "pmc_policy.inc"
+#include "xfer_capi.inc"

@@ -118,7 +118,18 @@ class TrajectoryBuffer(object):
     What the overlap costs is measured, not assumed: every ``wait()`` brackets the point where the engine's stream has to wait for the
     collective with two events (``stall_ms()``: how long the step kernels actually stood still behind a gather) and counts the host time
     spent blocked.  ``mode='blocking'`` (bench.py --gather-mode blocking) waits for every gather before the next step is launched: the
-    A/B leg that shows what the double buffer buys."""
+    A/B leg that shows what the double buffer buys.
+
+    The RECEIVE side on the learner rank is double-buffered too: unroll k lands in ``outs[k % 2]``, so a learner has the whole next unroll
+    (21 ms at BASELINE config 3) to consume unroll k before anything overwrites it (``received(k)``).
+
+    ``mode='p2p'`` (bench.py --gather-mode p2p) is the same hand-off over a different transport: no collective at all.  Every rank exports
+    its unroll allocation and two interprocess events through HIP IPC (include/llenv_xfer.h); the learner rank pulls block k of every rank
+    with SDMA copies (hipMemcpyDeviceToDeviceNoCU) on a copy stream of its own, each pull ordered behind the producer's event.  Nothing of
+    it occupies a compute unit -- which matters here because the occupancy-1 step kernel shares its SIMDs with nobody: whatever a
+    collective keeps resident, the step launches pay in full (profiles/r03_simd_sharing.txt).  Per unroll the ranks meet once on the host
+    (a gloo barrier: "my event is recorded"); the producer's stream waits for "block copied" only when it is about to overwrite that block,
+    one unroll later."""
 
     def __init__(self, engine, unroll, host_memory=False, mode='async'):
         ptr, w = engine.enable_unrolls(unroll, 2)
@@ -127,13 +138,15 @@ class TrajectoryBuffer(object):
         self.mode = mode
         mk = host_tensor if host_memory else device_tensor
         self.buf = mk(ptr, (2, engine.n_envs, unroll, w))
-        self.outs = None
+        self.outs = None                  # learner rank: [2][world] receive blocks (unroll k lands in outs[k % 2])
         self.work = None
+        self._p2p = None                  # mode 'p2p': IPC handles, events, copy stream (prepare)
         self.last = None
         self.n_gathered = 0
         self._stall_events = []           # (before, after) event pairs around stream-side waits
         self.host_stall_s = 0.0           # host time spent blocked in wait()
         self.extra_gathers = 0            # measurement hook: repeat every gather this many more times
+        self.p2p_no_cu = True             # mode 'p2p': SDMA pulls (False: the runtime's default device-to-device path, the A/B leg)
         self._stage = None                # gloo test path: pinned staging buffers, side stream, worker thread
         self._thread = None
 
@@ -151,9 +164,76 @@ class TrajectoryBuffer(object):
                                stream=torch.cuda.Stream(), ev=[torch.cuda.Event(), torch.cuda.Event()])
         if rank == dst and self.outs is None:
             dev = torch.device('cpu') if staged else like.device
-            self.outs = [torch.empty(like.shape, dtype=like.dtype, device=dev) for _ in range(world)]
-            for o in self.outs:
-                o.zero_()                                   # touch the pages now, not inside the first timed gather
+            self.outs = [[torch.empty(like.shape, dtype=like.dtype, device=dev) for _ in range(world)] for _ in range(2)]
+            for half in self.outs:
+                for o in half:
+                    o.zero_()                               # touch the pages now, not inside the first timed gather
+        if self.mode == 'p2p' and self._p2p is None:
+            self._prepare_p2p(dst, group)
+
+    def _prepare_p2p(self, dst, group):
+        """Exchange the IPC handles (collective: every rank calls it).  Learner rank: maps every other rank's unroll allocation, opens their
+        'block ready' events, owns the copy stream and the two 'block copied' events; the others open those."""
+        from . import xfer
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if not self.buf.is_cuda:
+            raise RuntimeError("gather mode 'p2p' moves device memory (HIP IPC); the host-memory test configuration has no such path")
+        dev = self.buf.device.index if self.buf.device.index is not None else torch.cuda.current_device()
+        ctrl = dist.new_group(backend='gloo') if dist.get_backend(group) != 'gloo' else group     # host-side meeting point, no GPU work
+        ready = [xfer.IpcEvent(dev) for _ in range(2)]
+        mem_h, mem_off = xfer.export_mem(dev, self.buf.data_ptr())
+        mine = dict(mem=mem_h, off=mem_off, ready=[e.handle for e in ready], pid=__import__('os').getpid())
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine, group=ctrl)
+        st = dict(ctrl=ctrl, ready=ready, dev=dev, dst=dst, block_bytes=int(self.buf[0].numel() * self.buf.element_size()))
+        copied_handles = [None, None]
+        if rank == dst:
+            st['stream'] = xfer.CopyStream(dev)
+            st['copied'] = [xfer.IpcEvent(dev) for _ in range(2)]
+            copied_handles = [e.handle for e in st['copied']]
+            st['src'], st['src_ready'], st['bases'] = [], [], []
+            for r, info in enumerate(everyone):
+                if r == rank:
+                    st['src'].append(int(self.buf.data_ptr())); st['src_ready'].append(ready); st['bases'].append(None)
+                else:
+                    ptr = xfer.open_mem(dev, info['mem'], info['off'])
+                    st['src'].append(ptr); st['bases'].append(ptr - info['off'])
+                    st['src_ready'].append([xfer.IpcEvent(dev, h) for h in info['ready']])
+        box = [copied_handles]
+        dist.broadcast_object_list(box, src=dst, group=ctrl)
+        if rank != dst:
+            st['copied'] = [xfer.IpcEvent(dev, h) for h in box[0]]
+        self._p2p = st
+
+    def _gather_p2p(self, k, dst, group):
+        import time
+        st = self._p2p
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        es = int(self.engine.device_ptrs().stream or 0)
+        st['ready'][k % 2].record(es)                       # behind the kernels that wrote block k (and its TD(lambda) pass)
+        t0 = time.perf_counter()
+        dist.barrier(group=st['ctrl'])                      # every rank's event is recorded before anybody's stream is told to wait for it
+        self.host_stall_s += time.perf_counter() - t0
+        if rank == dst:
+            cs = st['stream']
+            for r in range(world):
+                st['src_ready'][r][k % 2].make_stream_wait(cs.handle)
+                for _ in range(1 + self.extra_gathers):     # (extra_gathers: measurement hook -- the residency of more, or slower, peers)
+                    cs.pull(self.outs[k % 2][r].data_ptr(), st['src'][r] + (k % 2) * st['block_bytes'], st['block_bytes'], no_cu=self.p2p_no_cu)
+            st['copied'][k % 2].record(cs.handle)
+            self.last = self.outs[k % 2]
+        if k >= 1:
+            # The next unroll (k + 1) overwrites block (k - 1) % 2: the engine's stream may not get there before the learner has copied it.
+            # That copy was queued one unroll ago -- its event was recorded before the learner entered this unroll's barrier.
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            st['copied'][(k - 1) % 2].make_stream_wait(es)
+            b.record()
+            self._stall_events.append((a, b))
+
+    def received(self, k):
+        """Learner rank: the list (one tensor per rank) unroll k was received into; valid until unroll k + 2 is gathered."""
+        return self.outs[k % 2]
 
     def finish(self, k, gamma=0.95, lam=0.95):
         """TD(lambda) returns of unroll k (ll_finish_unroll), bootstrapped from the engine's value buffer: call it after the policy
@@ -167,6 +247,10 @@ class TrajectoryBuffer(object):
             self._thread.join()
             self.host_stall_s += time.perf_counter() - t0
             self._thread = None
+        if self._p2p is not None and 'stream' in self._p2p:
+            t0 = time.perf_counter()
+            self._p2p['stream'].synchronize()               # learner rank: every pull queued so far has landed
+            self.host_stall_s += time.perf_counter() - t0
         if self.work is not None:
             t0 = time.perf_counter()
             if self.buf.is_cuda:
@@ -191,7 +275,8 @@ class TrajectoryBuffer(object):
 
     def gather_async(self, k, dst=0, group=None):
         """Start gathering unroll k (the block the last `unroll` steps wrote); the previous gather must have finished."""
-        self.wait()
+        if self.mode != 'p2p':
+            self.wait()                                     # (p2p: ordering is by events; nothing to wait for on the host)
         local = self.half(k)
         if local.is_cuda:
             # the collective (and the staging copy of the gloo test path) is ordered against torch's CURRENT stream only: the step
@@ -202,6 +287,10 @@ class TrajectoryBuffer(object):
                                    'call gather.bind_torch_stream(engine) first' % (es, ts))
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         self.prepare(dst, group)
+        if self.mode == 'p2p':
+            self._gather_p2p(k, dst, group)
+            self.n_gathered += 1
+            return
         if local.is_cuda and dist.get_backend(group) == 'gloo':
             # Test configuration only (a 1-GPU box cannot host two RCCL ranks): gloo gathers host tensors.  The block is copied to pinned
             # memory on a side stream behind the step kernels that wrote it, and a helper thread hands it to gloo once the copy has landed,
@@ -213,7 +302,7 @@ class TrajectoryBuffer(object):
             with torch.cuda.stream(st['stream']):
                 host.copy_(local, non_blocking=True)
                 ev.record()
-            outs = self.outs if rank == dst else None
+            outs = self.outs[k % 2] if rank == dst else None
 
             def run():
                 ev.synchronize()
@@ -221,12 +310,12 @@ class TrajectoryBuffer(object):
             self._thread = threading.Thread(target=run)
             self._thread.start()
             if rank == dst:
-                self.last = self.outs
+                self.last = self.outs[k % 2]
         elif rank == dst:
-            self.work = dist.gather(local, gather_list=self.outs, dst=dst, group=group, async_op=True)
+            self.work = dist.gather(local, gather_list=self.outs[k % 2], dst=dst, group=group, async_op=True)
             for _ in range(self.extra_gathers):             # measurement hook (bench.py LL_BENCH_GATHER_REPEAT): RCCL resident for longer
-                self.work = dist.gather(local, gather_list=self.outs, dst=dst, group=group, async_op=True)
-            self.last = self.outs
+                self.work = dist.gather(local, gather_list=self.outs[k % 2], dst=dst, group=group, async_op=True)
+            self.last = self.outs[k % 2]
         else:
             self.work = dist.gather(local, gather_list=None, dst=dst, group=group, async_op=True)
         self.n_gathered += 1

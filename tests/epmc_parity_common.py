@@ -548,3 +548,102 @@ def check_free_running_against_oracle_env(lib_path, n_steps=4, elements=(1, 3, 0
                 break
         E.close()
     return worst
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# Game-level statistics, engine against oracle env, ONE protocol (round-3 review, "What's weak" #3)
+# ------------------------------------------------------------------------------------------------------------------------------------------
+GAME_HORIZON = {'hurdle': 420, 'cube': 600, 'hole': 500}
+
+
+def _game_cfg(which):
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import rollout_epmc_policy as R
+    cfg = R.env_config(R.ELEMENT[which], 1)
+    cfg['max_steps'] = GAME_HORIZON[which]                 # every episode is played to ITS end: target reached, fall, or this many steps
+    return cfg
+
+
+def _oracle_game(job):
+    """One episode of the float64 oracle env (oracle/free_run.py) under the reference's trained policy, drawing from a recorded stream:
+    returns (length, end reason as the engine's bits, the uniforms of the reset, the uniforms of every step)."""
+    which, seed = job
+    from oracle import free_run as FR
+    from oracle.epmc_policy import EpmcPolicy
+    from lifelike_agility_and_play_amd import mocap
+    cfg = _game_cfg(which)
+    run = FR.EpmcFreeRun(cfg, urdf_model.default_model_blob(), mocap.load_mocap('', 0.02), epmc_capi.default_init_state(), seed=0)
+    run.draws = FR.SharedDraws(seed)
+    pol = EpmcPolicy(os.path.join(ROOT, 'tests', 'golden', 'epmc_policy_%s.npz' % which), 1)
+    obs = run.reset()
+    u0, us, why = run.draws.take(), [], 0
+    for t in range(cfg['max_steps'] + 1):
+        a = pol.act(np.asarray(obs, np.float64).reshape(1, -1))[0]
+        obs, r, done, info = run.step(a)
+        us.append(run.draws.take())
+        if done:
+            s = run.env.state
+            why = 1 if eo.check_fall(s[3:7]) else (4 if np.linalg.norm((run.env.target_pos - s[0:3])[:2]) < 0.5 else 2)
+            break
+    assert why, 'the oracle episode did not end by max_steps'
+    return len(us), why, u0, us
+
+
+def check_game_statistics(lib_path, n_per_policy=128, procs=None, policies=('hurdle', 'cube', 'hole'), frac_tol=0.03, len_tol=0.03, hole_frac_tol=0.08, ks_p=0.5):
+    """PMC has check_rollout_statistics; this is the same for the environmental level, at the level the game is decided on.  The engine and the
+    float64 oracle env play the SAME episodes -- same terrain, friction, pushes (the oracle env's uniforms are recorded and handed to the engine
+    draw by draw), same trained policy of the reference acting on each side's own observations -- every episode to its end on both sides
+    (target reached / fell / max_steps).  Chaos decorrelates individual episodes; the DISTRIBUTIONS must agree: end-reason fractions within
+    `frac_tol`, mean length within `len_tol`, Kolmogorov-Smirnov p > 0.5 on the lengths.  The hurdle and stairs policies decide the bars (their
+    outcomes are stable); the overhead-bars ('hole') policy, whose episodes split between reaching and falling, is compared at `hole_frac_tol`."""
+    import multiprocessing as mp
+    from scipy import stats as sst
+    from oracle.epmc_policy import EpmcPolicy
+    import bench
+    procs = procs or bench.effective_cores()[0]
+    out = {}
+    for which in policies:
+        n = n_per_policy
+        with mp.get_context('fork').Pool(procs) as p:
+            res = p.map(_oracle_game, [(which, 1000 * (1 + policies.index(which)) + i) for i in range(n)], chunksize=1)
+        len_o, why_o = np.array([r[0] for r in res]), np.array([r[1] for r in res])
+        cfg = _game_cfg(which)
+        E = make_engine(cfg, n, lib_path, seed=3)
+        U = np.full((n, epmc_capi.LLE_MAX_DRAWS), 0.5, np.float32)
+        for i, r in enumerate(res):
+            U[i, :len(r[2])] = r[2]
+        E.reset(draws=U)
+        pol = EpmcPolicy(os.path.join(ROOT, 'tests', 'golden', 'epmc_policy_%s.npz' % which), n)
+        obs = E.obs()
+        alive = np.ones(n, bool); len_e = np.zeros(n, int); why_e = np.zeros(n, int)
+        for t in range(cfg['max_steps'] + 1):
+            used = [r[3][t] if t < len(r[3]) else [] for r in res]
+            D = np.full((n, max(1, max(len(u) for u in used))), 0.5, np.float32)      # (beyond the oracle episode's end: mid-range pushes)
+            for i, u in enumerate(used):
+                D[i, :len(u)] = u
+            a = pol.act(obs.astype(np.float64))
+            E.set_step_draws(D)
+            E.step_host(a.astype(np.float32))
+            obs = E.obs()
+            r_, d_, w_ = E.reward_done()
+            len_e += alive
+            newly = alive & d_
+            why_e[newly] = w_[newly]
+            alive &= ~d_
+            if not alive.any():
+                break
+        E.close()
+        assert not alive.any(), (which, int(alive.sum()))
+        fr = lambda w, bit: float(((w & bit) != 0).mean())
+        o = dict(n=n, reached=(fr(why_e, 4), fr(why_o, 4)), fell=(fr(why_e, 1), fr(why_o, 1)), timed_out=(fr(why_e & ~5, 2), fr(why_o & ~5, 2)),
+                 mean_len=(float(len_e.mean()), float(len_o.mean())), ks_p=float(sst.ks_2samp(len_e, len_o).pvalue),
+                 same_end=float(((why_e & 7) == (why_o & 7)).mean()), same_step=float((len_e == len_o).mean()))
+        out[which] = o
+        print('game statistics, %s policy, %d episodes (engine / oracle): reached %.3f / %.3f, fell %.3f / %.3f, timed out %.3f / %.3f, mean length %.1f / %.1f, '
+              'KS p %.3f; same end reason %.3f, same end step %.3f' % ((which, n) + o['reached'] + o['fell'] + o['timed_out'] + o['mean_len'] + (o['ks_p'], o['same_end'], o['same_step'])))
+        tol = hole_frac_tol if which == 'hole' else frac_tol
+        for k in ('reached', 'fell', 'timed_out'):
+            assert abs(o[k][0] - o[k][1]) <= tol + 1e-9, (which, k, o[k])
+        assert abs(o['mean_len'][0] - o['mean_len'][1]) <= (2 * len_tol if which == 'hole' else len_tol) * o['mean_len'][1], (which, o['mean_len'])
+        assert o['ks_p'] > (0.2 * ks_p if which == 'hole' else ks_p), (which, o['ks_p'])
+    return out

@@ -70,3 +70,17 @@ def test_sepmc_header_binding_and_library_agree():
     lib = sepmc_capi.load_library()
     for name in declared:
         assert hasattr(lib, name), name
+
+
+def test_xfer_header_binding_and_library_agree():
+    """include/llenv_xfer.h (HIP IPC handles + CU-free pulls: the p2p trajectory hand-off) == xfer._SIGS == what libllenv.so exports."""
+    from lifelike_agility_and_play_amd import xfer
+    text = open(os.path.join(ROOT, 'include', 'llenv_xfer.h')).read()
+    declared = sorted(set(re.findall(r'\b(ll_xfer_[a-z0-9_]+)\s*\(', text)))
+    assert declared == xfer.EXPORTED_SYMBOLS and len(declared) == 13
+    import __graft_entry__ as g
+    g.build_hip()
+    lib = xfer.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert xfer.HANDLE_BYTES == 64

@@ -63,3 +63,9 @@ def test_free_running_with_noise_and_without_edge_cylinders(emul_lib):
 def test_parked_variant_equals_plain(emul_lib):
     ec.check_parked_variant_equals_plain(emul_lib)
 
+
+
+def test_game_statistics_against_the_oracle_env(emul_lib):
+    """the mechanism of the GPU test of the same name (recorded uniforms, both sides to the end of every episode) at a size the CPU build affords;
+    the distribution bars proper are asserted on the GPU with 128 episodes per policy"""
+    ec.check_game_statistics(emul_lib, n_per_policy=6, policies=('hurdle',), frac_tol=0.35, len_tol=0.5, ks_p=0.01)

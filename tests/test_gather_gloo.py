@@ -89,7 +89,10 @@ def _ring_worker(rank, world, port, q, emul_lib):
     if rank == 0:
         got = [o.clone() for o in T.last]                  # the last gathered unroll, one block per rank
         _, other = run(101)                                 # rank 1's engine, recomputed locally
-        q.put((got[0].numpy(), mine[-1].numpy(), got[1].numpy(), other[-1].numpy(), T.n_gathered))
+        # the receive side is double-buffered: unroll 0 is still intact after unroll 1 has arrived (a learner has one unroll's time to consume it)
+        first = [o.clone() for o in T.received(0)]
+        assert all(a is not b for a, b in zip(T.received(0), T.received(1)))
+        q.put((got[0].numpy(), mine[-1].numpy(), got[1].numpy(), other[-1].numpy(), T.n_gathered, first[0].numpy(), mine[0].numpy(), first[1].numpy(), other[0].numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -105,11 +108,14 @@ def test_async_ring_gather_two_ranks():
     procs = [ctx.Process(target=_ring_worker, args=(r, world, port, q, emul_lib)) for r in range(world)]
     for p in procs:
         p.start()
-    a0, b0, a1, b1, n_g = q.get(timeout=180)
+    a0, b0, a1, b1, n_g, f0, g0, f1, g1 = q.get(timeout=180)
     for p in procs:
         p.join(timeout=180)
         assert p.exitcode == 0
     assert n_g == 2
     np.testing.assert_array_equal(a0, b0)                   # rank 0's own block
     np.testing.assert_array_equal(a1, b1)                   # rank 1's block == rank 1's engine recomputed on rank 0
+    np.testing.assert_array_equal(f0, g0)                   # unroll 0 as received, read AFTER unroll 1 arrived: untouched
+    np.testing.assert_array_equal(f1, g1)
+    assert np.abs(f0 - a0).max() > 0
     assert a0.shape == (6, 3, 224) and np.abs(a0 - a1).max() > 0      # [n_envs][unroll][row]: every env's unroll contiguous

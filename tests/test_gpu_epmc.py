@@ -24,6 +24,18 @@ def test_free_running_invariants():
     assert ec.check_free_running_invariants(None, n_envs=4200, n_steps=12, element=3) >= 0
 
 
+def test_full_size_invariants_config_4():
+    """BASELINE config 4 at its exact shape -- 4096 envs = the occupancy-1 build on a full 1024-wave grid (what bench.py --workload epmc runs) --
+    for every terrain element of the training config."""
+    for element in (1, 2, 3):
+        assert ec.check_free_running_invariants(None, n_envs=4096, n_steps=16, element=element) >= 0
+
+
+def test_game_statistics_against_the_oracle_env():
+    """distribution-level engine-vs-oracle test of the environmental level: 3 x 128 episodes played to their end on both sides"""
+    ec.check_game_statistics(None, n_per_policy=128)
+
+
 def test_env_api_contract_gpu():
     from test_epmc_env_api import check_single_env_contract
     check_single_env_contract(None)

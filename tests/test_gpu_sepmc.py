@@ -23,6 +23,16 @@ def test_free_running_invariants_gpu():
     print(out)
 
 
+def test_full_size_invariants_config_5_gpu():
+    """BASELINE config 5 at its exact shape: 2048 arenas x 2 robots = the occupancy-1 build on a full 1024-wave grid (bench.py --workload sepmc)"""
+    print(SC.check_free_running_big(None, n_arenas=2048, steps=60))
+
+
+def test_game_statistics_against_the_oracle_env_gpu():
+    """distribution-level engine-vs-oracle test of the strategic level: 256 chase-tag games played to their end on both sides"""
+    SC.check_game_statistics(None, n_arenas=256)
+
+
 def test_flag_handover_by_physical_contact_gpu():
     SC.check_flag_handover_physical(None)
 

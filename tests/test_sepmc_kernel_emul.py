@@ -92,3 +92,8 @@ def test_free_running_with_observation_noise(emul_lib):
 def test_parked_variant_equals_plain(emul_lib):
     SC.check_parked_variant_equals_plain(emul_lib)
 
+
+
+def test_game_statistics_against_the_oracle_env(emul_lib):
+    """the mechanism of the GPU test of the same name at a size the CPU build affords (the distribution bars are asserted on the GPU, 256 games)"""
+    SC.check_game_statistics(emul_lib, n_arenas=4, frac_tol=0.6, len_tol=1.5, ks_p=0.0)
