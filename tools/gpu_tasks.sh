@@ -26,6 +26,10 @@ case $TARGET in
     cat $OUT/inertia_engine.md; tail -3 $OUT/inertia_engine.err
     python bench.py --no-cpu-baseline > $OUT/bench.log 2>$OUT/bench.err; tail -c 800 $OUT/bench.log ;;
   profile) tools/profile.sh $TAG ;;
+  round2)        # second call of round 4: the suite at the new HEAD, what the register-budget builds disagree on, the p2p hand-off A/B
+    gpu_tests -x
+    python tools/diag_budgets.py > $OUT/diag_budgets.txt 2>&1; cat $OUT/diag_budgets.txt
+    cp gpurun_out/two_rank/*.txt gpurun_out/two_rank/*.json $OUT/ 2>/dev/null; cat $OUT/p2p_no_cu.txt | head -8 ;;
   driver)
     for i in 1 2 3; do LL_BENCH_TRIAD_FIRST=0 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | show "driver-style, no triad first"; done
     for i in 1 2 3; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | show "driver-style (triad first)  "; done

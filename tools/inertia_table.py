@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--kinds', default=','.join(KINDS)); ap.add_argument('--skip', default='')
     args = ap.parse_args()
     spec = {k: float(v) for k, v in (kv.split('=') for kv in args.spec.split(',') if kv)}
+    skip = set(args.skip.split(','))
     import bench
     import deviation_envs as DE
     import deviation_table as DT
@@ -63,17 +64,17 @@ def main():
         if args.oracle:
             t = time.time()
             cells = ['-', '-', '-']
-            if 'pmc' not in args.skip:
+            if 'pmc' not in skip:
                 o = DT.run_oracle(pol, blob, table, args.pmc_episodes or 1024, spec, 11, procs)
                 cells = ['%.4f' % o['reward'], '%.3f' % o['tracked'], '%.1f' % o['length']]
             for which in ('hurdle', 'cube', 'hole'):
                 n = args.epmc_episodes or 128
-                if 'epmc' in args.skip:
+                if 'epmc' in skip:
                     cells.append('-'); continue
                 res = DE._pool(DE._epmc_episode, [(which, spec, 100 + i, HZ[which]) for i in range(n)], procs)
                 why = np.array([r[1] for r in res])
                 cells.append('%d / %d' % ((why == 4).sum(), (why == 1).sum()) + (' / %d' % (why == 0).sum() if which == 'hole' else '') + ' of %d' % n)
-            if 'sepmc' in args.skip:
+            if 'sepmc' in skip:
                 cells.append('-')
             else:
                 res = sum(DE._pool(DE._sepmc_episode, [(spec, i, args.arena_steps) for i in range(args.arenas or 64)], procs), [])
