@@ -120,6 +120,7 @@ def committed_counters(kernel, units, spl=1):
         c = json.load(open(os.path.join(ROOT, t['counters_file'])))
         n_inst = c['SQ_INSTS_VALU'] + c['SQ_INSTS_SALU'] + c['SQ_INSTS_LDS']
         issue = {'instructions_per_wave_per_control_step': n_inst / c['SQ_WAVES'] / k, 'issue_slots_per_wave_per_control_step': c['SQ_WAVE_CYCLES'] / c['SQ_WAVES'] / k,
+                 'valu_per_wave_per_control_step': c['SQ_INSTS_VALU'] / c['SQ_WAVES'] / k,
                  'control_steps_per_launch': k, 'frac': n_inst / c['SQ_WAVE_CYCLES'],
                  'source': t['counters_file'] + ' (rocprofv3 --pmc SQ_INSTS_*, SQ_WAVE_CYCLES in quad-cycles)'}
         return t['traffic_bytes'], issue, 'profiles/traffic.json <- %s (bytes per launch, FETCH_SIZE + WRITE_SIZE, uncorrected; see DESIGN.md 5.1)' % t['counters_file']
@@ -342,6 +343,12 @@ def main():
         algo_bytes = ALGO_BYTES_PER_ENV_STEP + (4 * int(traj.buf.shape[-1]) if traj is not None else 0)
         achieved = (n * algo_bytes) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
         traffic, issue, tsrc = committed_counters('pmc_step_kernel', n, spl)
+        if issue and k_ms > 0:
+            # chip-level VALU utilisation: VALU instructions of all waves of a control step x 2 cycles (a SIMD's rate for a full-rate wave64
+            # instruction with >= 2 resident waves: MI355X_MICROARCH.md, measured in profiles/r04_valu_issue.txt) over the SIMD-cycles the step took
+            issue['chip_valu_frac'] = issue['valu_per_wave_per_control_step'] * (n / 4.0) * 2.0 / (k_ms * 1e-3 * 2.4e9 * 1024.0)
+            issue['chip_valu_frac_note'] = ('one wave per SIMD issues at most one instruction per 4.4 cycles, and the DPP / v_med3 / packed forms this kernel '
+                                            'is made of are half-rate at any occupancy (profiles/r04_valu_issue.txt): the ceiling of this mix is near 0.6, not 1')
         out = {
             'metric': 'env-steps/sec (whole node), PMC tracking env, random policy',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

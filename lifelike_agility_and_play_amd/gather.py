@@ -129,7 +129,7 @@ class TrajectoryBuffer(object):
     it occupies a compute unit -- which matters here because the occupancy-1 step kernel shares its SIMDs with nobody: whatever a
     collective keeps resident, the step launches pay in full (profiles/r03_simd_sharing.txt).  Per unroll the ranks meet once on the host
     (a gloo barrier: "my event is recorded"); the producer's stream waits for "block copied" only when it is about to overwrite that block,
-    one unroll later."""
+    one unroll later.  (ROCm's stream wait on an interprocess event is a HOST-side wait; `_gather_p2p` places the waits accordingly.)"""
 
     def __init__(self, engine, unroll, host_memory=False, mode='async'):
         ptr, w = engine.enable_unrolls(unroll, 2)
@@ -206,30 +206,38 @@ class TrajectoryBuffer(object):
         self._p2p = st
 
     def _gather_p2p(self, k, dst, group):
+        """Hand-off of unroll k without a collective.  ROCm implements hipStreamWaitEvent on an INTERPROCESS event as a host-side wait (the
+        call returns once the event has completed), so the waits are placed where the host has nothing better to do: the learner's waits
+        for the producers' events run in a helper thread that then queues the pulls, and the engine's wait for 'block copied' comes one
+        unroll after the copy was queued (it has normally finished by then).  The main thread goes straight back to launching steps."""
+        import threading
         import time
         st = self._p2p
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         es = int(self.engine.device_ptrs().stream or 0)
         st['ready'][k % 2].record(es)                       # behind the kernels that wrote block k (and its TD(lambda) pass)
         t0 = time.perf_counter()
-        dist.barrier(group=st['ctrl'])                      # every rank's event is recorded before anybody's stream is told to wait for it
-        self.host_stall_s += time.perf_counter() - t0
+        if self._thread is not None:                        # learner rank: the pulls of unroll k - 1 are queued, 'copied' is recorded
+            self._thread.join()
+            self._thread = None
+        dist.barrier(group=st['ctrl'])                      # every rank's event is recorded before anybody is told to wait for it
         if rank == dst:
-            cs = st['stream']
-            for r in range(world):
-                st['src_ready'][r][k % 2].make_stream_wait(cs.handle)
-                for _ in range(1 + self.extra_gathers):     # (extra_gathers: measurement hook -- the residency of more, or slower, peers)
-                    cs.pull(self.outs[k % 2][r].data_ptr(), st['src'][r] + (k % 2) * st['block_bytes'], st['block_bytes'], no_cu=self.p2p_no_cu)
-            st['copied'][k % 2].record(cs.handle)
-            self.last = self.outs[k % 2]
+            cs, outs, half, n_pull = st['stream'], self.outs[k % 2], k % 2, 1 + self.extra_gathers
+
+            def pull():
+                for r in range(world):
+                    st['src_ready'][r][half].make_stream_wait(cs.handle)     # (returns when rank r's unroll k is complete)
+                    for _ in range(n_pull):                  # (extra_gathers: measurement hook -- the residency of more, or slower, peers)
+                        cs.pull(outs[r].data_ptr(), st['src'][r] + half * st['block_bytes'], st['block_bytes'], no_cu=self.p2p_no_cu)
+                st['copied'][half].record(cs.handle)
+            self._thread = threading.Thread(target=pull)
+            self._thread.start()
+            self.last = outs
         if k >= 1:
-            # The next unroll (k + 1) overwrites block (k - 1) % 2: the engine's stream may not get there before the learner has copied it.
-            # That copy was queued one unroll ago -- its event was recorded before the learner entered this unroll's barrier.
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
+            # The next unroll (k + 1) overwrites block (k - 1) % 2: not before the learner has copied it.  That copy was queued one unroll ago
+            # (its event was recorded before the learner entered this unroll's barrier: the join above).
             st['copied'][(k - 1) % 2].make_stream_wait(es)
-            b.record()
-            self._stall_events.append((a, b))
+        self.host_stall_s += time.perf_counter() - t0       # barrier + join + whatever the copy of unroll k - 1 still needed
 
     def received(self, k):
         """Learner rank: the list (one tensor per rank) unroll k was received into; valid until unroll k + 2 is gathered."""
@@ -249,7 +257,7 @@ class TrajectoryBuffer(object):
             self._thread = None
         if self._p2p is not None and 'stream' in self._p2p:
             t0 = time.perf_counter()
-            self._p2p['stream'].synchronize()               # learner rank: every pull queued so far has landed
+            self._p2p['stream'].synchronize()               # learner rank: every pull queued so far (the helper thread was joined above) has landed
             self.host_stall_s += time.perf_counter() - t0
         if self.work is not None:
             t0 = time.perf_counter()

@@ -312,12 +312,12 @@ def test_p2p_pull_occupies_no_compute_unit():
     torch_cuda()
     steps, warm, n = 1024, 256, 4096
     base = ['--gpus', 1, '--steps', steps, '--warmup', warm, '--envs-per-gpu', n, '--no-cpu-baseline']
-    env = {'LL_BENCH_FORCE_GATHER': '1', 'LL_BENCH_BACKEND': 'gloo', 'LL_BENCH_GATHER_REPEAT': os.environ.get('LL_TEST_P2P_REPEAT', '1')}
+    env = {'LL_BENCH_FORCE_GATHER': '1', 'LL_BENCH_BACKEND': 'gloo', 'LL_BENCH_GATHER_REPEAT': os.environ.get('LL_TEST_P2P_REPEAT', '0')}
     res, lines = {}, []
     for rnd in range(2):                                                      # two rounds, best of each (box noise only ever adds time)
         for name, mode, extra in (('none', 'none', {}), ('p2p_sdma', 'p2p', {}), ('p2p_copy_kernel', 'p2p', {'LL_BENCH_P2P_NO_CU': '0'}), ('collective_stand_in', 'async', {'LL_BENCH_BACKEND': 'nccl'})):
             j, raw, root = _run_bench(base + ['--gather-mode', mode], dict(env, **extra))
-            k = (j['ms_per_step'], j['roofline']['kernel_avg_ms'], j['config']['gather']['stream_stall_ms_total'] / steps)
+            k = (j['ms_per_step'], j['roofline']['kernel_avg_ms'], (j['config']['gather']['stream_stall_ms_total'] + j['config']['gather']['host_blocked_ms_total']) / steps)
             res[name] = min(res.get(name, (1e9, 1e9, 1e9)), k)
             lines.append('%s: %s' % (name, raw))
     log_dir = os.path.join(root, 'gpurun_out', 'two_rank')
@@ -325,7 +325,7 @@ def test_p2p_pull_occupies_no_compute_unit():
     with open(os.path.join(log_dir, 'p2p_no_cu.txt'), 'w') as f:
         f.write('one rank, %d envs, every unroll handed off %d times (ms per control step: wall, step kernel by HIP events; best of 2)\n' % (n, 1 + int(env['LL_BENCH_GATHER_REPEAT'])))
         for name, (w, k, st) in res.items():
-            f.write('  %-22s wall %.4f  kernel %.4f  engine stream stalled behind a copy %.4f  (+%.1f %% wall vs none)\n' % (name, w, k, st, 100.0 * (w / res['none'][0] - 1.0)))
+            f.write('  %-22s wall %.4f  kernel %.4f  waited for a copy to finish (stream + host) %.4f  (+%.1f %% wall vs none)\n' % (name, w, k, st, 100.0 * (w / res['none'][0] - 1.0)))
         f.write('\n'.join(lines) + '\n')
     print(res)
     assert res['p2p_sdma'][1] <= 1.015 * res['none'][1], res                  # the step kernel does not notice the pulls
