@@ -100,6 +100,9 @@
                                            joint stops AT the limit.  0: a row only once the limit is passed (d <= 0), bias erp * d / dt -- what
                                            btMultiBodyJointLimitConstraint::createConstraintRows does as recalled ("if (penetration > 0) continue;"): the joint overshoots by
                                            up to qd * dt, is stopped there and walks back by erp per substep.  ORACLE ONLY unless stated otherwise in DESIGN.md 4 */
-#define LLM_SPEC_COUNT 21
+#define LLM_SPEC_GYRO 21                /* 1 (spec, btMultiBody::m_useGyroTerm = true as its constructor sets it): the gyroscopic torque w x (I_c w) of every link is part
+                                           of the velocity-product forces.  0: left out (Bullet's setUseGyroTerm(false)); the remaining terms -- m w x v_c, the
+                                           Coriolis accelerations of the joints -- stay.  ORACLE ONLY (round 4: the third audit item of the bars policy) */
+#define LLM_SPEC_COUNT 22
 
 #endif

@@ -314,8 +314,8 @@ inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
       if (!(v == 0.0 || v == 1.0)) return "friction_dirs must be 0 or 1";
       P.friction_dirs = (int)v; break;
     case LLM_SPEC_FRICTION_MODE: case LLM_SPEC_ROW_ORDER: case LLM_SPEC_MAX_COORD_VEL: case LLM_SPEC_LIMIT_ERP: case LLM_SPEC_PAIR_FRICTION:
-    case LLM_SPEC_MAX_PAIR: case LLM_SPEC_LIMIT_SPECULATIVE:
-      if (id == LLM_SPEC_LIMIT_SPECULATIVE && v == 1.0) break;
+    case LLM_SPEC_MAX_PAIR: case LLM_SPEC_LIMIT_SPECULATIVE: case LLM_SPEC_GYRO:
+      if ((id == LLM_SPEC_LIMIT_SPECULATIVE || id == LLM_SPEC_GYRO) && v == 1.0) break;
       return "this switch exists in the oracle only (round-3 audit against Bullet's published solver: profiles/r03_deviation_table.md)";
     default: return "unknown spec parameter id";
   }
@@ -339,6 +339,7 @@ inline double pmc_get_spec_param(const StepParams& P, int id) {
     case LLM_SPEC_LIMIT_ERP: return -1.0;
     case LLM_SPEC_MAX_PAIR: return 2.0;
     case LLM_SPEC_LIMIT_SPECULATIVE: return 1.0;
+    case LLM_SPEC_GYRO: return 1.0;
     default: return 0.0;
   }
 }

@@ -476,6 +476,7 @@ static int solve6(const double* A, const double* b, double* x) { /* SPD solve by
 
 /* fext[b] = external spatial force acting ON body b, body coordinates (NULL = none).
  * out: a0 = spatial acceleration of the base (body coords), qdd[12].  with_bias=0 drops velocity terms. */
+static double g_spec[LLM_SPEC_COUNT];   /* (defined with its defaults below) */
 static int aba(const OModel* M, const OKin* K, const double* qd, const double* tau, const double (*fext)[6],
                int with_bias, double* a0, double* qdd) {
   double IA[NB][36], pA[NB][6], c[NB][6], U[NB][6], D[NB], u[NB];
@@ -485,6 +486,12 @@ static int aba(const OModel* M, const OKin* K, const double* qd, const double* t
     if (with_bias) {
       m6v(M->I6[b], K->v[b], Iv);
       cross_force(K->v[b], Iv, pA[b]);
+      if (g_spec[LLM_SPEC_GYRO] < 0.5) {       /* audit switch: btMultiBody::setUseGyroTerm(false) drops w x (I_c w), a pure couple */
+        double Iw[3], g[3];
+        m3v(M->Ic[b], K->v[b], Iw);
+        v3cross(K->v[b], Iw, g);
+        for (int i = 0; i < 3; i++) pA[b][i] -= g[i];
+      }
     } else {
       memset(pA[b], 0, sizeof pA[b]);
     }
@@ -549,7 +556,7 @@ static int aba(const OModel* M, const OKin* K, const double* qd, const double* t
 /* Spec overrides (include/llenv_model.h LLM_SPEC_*): process-wide, defaults = the constants of that header.  The engine has the same
  * switches (ll_set_spec_param); tools/deviation_table.py moves them in both to measure what each of this build's own choices is worth. */
 static double g_spec[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, 0.0, 0.0, 1e30, -1.0, 0.0, 2.0, 0.0, 1.0};
+                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, 0.0, 0.0, 1e30, -1.0, 0.0, 2.0, 0.0, 1.0, 1.0};
 int orc_set_spec_param(int id, double v) {
   if (id < 0 || id >= LLM_SPEC_COUNT) return -1;
   if (id == LLM_SPEC_MAX_CONTACTS_PER_LEG && !(v >= 1 && v <= LLM_MAX_CONTACTS_PER_LEG)) return -1;
@@ -562,7 +569,7 @@ int orc_set_spec_param(int id, double v) {
 double orc_get_spec_param(int id) { return (id >= 0 && id < LLM_SPEC_COUNT) ? g_spec[id] : NAN; }
 void orc_reset_spec(void) {
   const double d[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, 0.0, 0.0, 1e30, -1.0, 0.0, 2.0, 0.0, 1.0};
+                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, 0.0, 0.0, 1e30, -1.0, 0.0, 2.0, 0.0, 1.0, 1.0};
   memcpy(g_spec, d, sizeof d);
 }
 #define g_link_damping (g_spec[LLM_SPEC_LINK_DAMPING])

@@ -34,5 +34,12 @@ case $TARGET in
     for i in 1 2 3; do LL_BENCH_TRIAD_FIRST=0 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | show "driver-style, no triad first"; done
     for i in 1 2 3; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | show "driver-style (triad first)  "; done
     python bench.py --gpus 1 --steps 2048 --warmup 256 --no-cpu-baseline 2>/dev/null | show "2048 steps                  " ;;
+  round3)        # the whole suite (no -x), then what the ray families of the EPMC / SEPMC observation cost (ablation build, if it travelled)
+    gpu_tests
+    cp gpurun_out/two_rank/*.txt gpurun_out/two_rank/*.json $OUT/ 2>/dev/null; head -8 $OUT/p2p_no_cu.txt
+    if [ -f tools/_build/libllenv_abl.so ]; then
+      for f in 0 32 64 128; do echo "LL_DEBUG_FLAGS=$f (32: no rays, 64: height grid only, 128: height grid + fan)"; LL_DEBUG_FLAGS=$f LL_LIB=tools/_build/libllenv_abl.so python tools/sweep_epmc.py "4096:1:32,4096:1:1,4096:0:32"; done > $OUT/epmc_ray_ablation.txt 2>&1
+      cat $OUT/epmc_ray_ablation.txt
+    fi ;;
   *) echo "unknown target $TARGET"; exit 2 ;;
 esac
