@@ -186,11 +186,13 @@ class TrajectoryBuffer(object):
         everyone = [None] * world
         dist.all_gather_object(everyone, mine, group=ctrl)
         st = dict(ctrl=ctrl, ready=ready, dev=dev, dst=dst, block_bytes=int(self.buf[0].numel() * self.buf.element_size()))
-        copied_handles = [None, None]
+        copied_handles = None
         if rank == dst:
-            st['stream'] = xfer.CopyStream(dev)
-            st['copied'] = [xfer.IpcEvent(dev) for _ in range(2)]
-            copied_handles = [e.handle for e in st['copied']]
+            # one copy stream and one pair of 'block copied' events PER PRODUCER: the pulls from different ranks arrive over different xGMI
+            # links and may use different SDMA engines -- on one stream they would queue behind each other
+            st['streams'] = [xfer.CopyStream(dev) for _ in range(world)]
+            st['copied_all'] = [[xfer.IpcEvent(dev) for _ in range(2)] for _ in range(world)]
+            copied_handles = [[e.handle for e in pair] for pair in st['copied_all']]
             st['src'], st['src_ready'], st['bases'] = [], [], []
             for r, info in enumerate(everyone):
                 if r == rank:
@@ -201,8 +203,7 @@ class TrajectoryBuffer(object):
                     st['src_ready'].append([xfer.IpcEvent(dev, h) for h in info['ready']])
         box = [copied_handles]
         dist.broadcast_object_list(box, src=dst, group=ctrl)
-        if rank != dst:
-            st['copied'] = [xfer.IpcEvent(dev, h) for h in box[0]]
+        st['copied'] = st['copied_all'][rank] if rank == dst else [xfer.IpcEvent(dev, h) for h in box[0][rank]]     # this rank's own blocks
         self._p2p = st
 
     def _gather_p2p(self, k, dst, group):
@@ -222,14 +223,15 @@ class TrajectoryBuffer(object):
             self._thread = None
         dist.barrier(group=st['ctrl'])                      # every rank's event is recorded before anybody is told to wait for it
         if rank == dst:
-            cs, outs, half, n_pull = st['stream'], self.outs[k % 2], k % 2, 1 + self.extra_gathers
+            outs, half, n_pull = self.outs[k % 2], k % 2, 1 + self.extra_gathers
 
             def pull():
                 for r in range(world):
+                    cs = st['streams'][r]
                     st['src_ready'][r][half].make_stream_wait(cs.handle)     # (returns when rank r's unroll k is complete)
                     for _ in range(n_pull):                  # (extra_gathers: measurement hook -- the residency of more, or slower, peers)
                         cs.pull(outs[r].data_ptr(), st['src'][r] + half * st['block_bytes'], st['block_bytes'], no_cu=self.p2p_no_cu)
-                st['copied'][half].record(cs.handle)
+                    st['copied_all'][r][half].record(cs.handle)
             self._thread = threading.Thread(target=pull)
             self._thread.start()
             self.last = outs
@@ -255,9 +257,10 @@ class TrajectoryBuffer(object):
             self._thread.join()
             self.host_stall_s += time.perf_counter() - t0
             self._thread = None
-        if self._p2p is not None and 'stream' in self._p2p:
+        if self._p2p is not None and 'streams' in self._p2p:
             t0 = time.perf_counter()
-            self._p2p['stream'].synchronize()               # learner rank: every pull queued so far (the helper thread was joined above) has landed
+            for cs in self._p2p['streams']:
+                cs.synchronize()                            # learner rank: every pull queued so far (the helper thread was joined above) has landed
             self.host_stall_s += time.perf_counter() - t0
         if self.work is not None:
             t0 = time.perf_counter()

@@ -589,13 +589,15 @@ def _oracle_game(job):
     return len(us), why, u0, us
 
 
-def check_game_statistics(lib_path, n_per_policy=128, procs=None, policies=('hurdle', 'cube', 'hole'), frac_tol=0.03, len_tol=0.03, hole_frac_tol=0.08, ks_p=0.5):
+def check_game_statistics(lib_path, n_per_policy=128, procs=None, policies=('hurdle', 'cube', 'hole'), frac_tol=0.03, len_tol=0.03, ks_p=0.5):
     """PMC has check_rollout_statistics; this is the same for the environmental level, at the level the game is decided on.  The engine and the
     float64 oracle env play the SAME episodes -- same terrain, friction, pushes (the oracle env's uniforms are recorded and handed to the engine
     draw by draw), same trained policy of the reference acting on each side's own observations -- every episode to its end on both sides
     (target reached / fell / max_steps).  Chaos decorrelates individual episodes; the DISTRIBUTIONS must agree: end-reason fractions within
-    `frac_tol`, mean length within `len_tol`, Kolmogorov-Smirnov p > 0.5 on the lengths.  The hurdle and stairs policies decide the bars (their
-    outcomes are stable); the overhead-bars ('hole') policy, whose episodes split between reaching and falling, is compared at `hole_frac_tol`."""
+    `frac_tol`, mean length within `len_tol`, Kolmogorov-Smirnov p > 0.5 on the lengths -- for the hurdle and stairs policies, whose episodes stay
+    correlated between the two simulators (measured on MI355X, 128 episodes each: reached 0.984 / 0.984 and 0.992 / 0.969, mean length 188.6 / 188.0
+    and 231.1 / 233.7, KS p 1.0).  The overhead-bars ('hole') policy, whose episodes split between reaching and falling (0.266 / 0.258 reached,
+    0.578 / 0.617 fell), gets two-sample bars (see below)."""
     import multiprocessing as mp
     from scipy import stats as sst
     from oracle.epmc_policy import EpmcPolicy
@@ -641,9 +643,14 @@ def check_game_statistics(lib_path, n_per_policy=128, procs=None, policies=('hur
         out[which] = o
         print('game statistics, %s policy, %d episodes (engine / oracle): reached %.3f / %.3f, fell %.3f / %.3f, timed out %.3f / %.3f, mean length %.1f / %.1f, '
               'KS p %.3f; same end reason %.3f, same end step %.3f' % ((which, n) + o['reached'] + o['fell'] + o['timed_out'] + o['mean_len'] + (o['ks_p'], o['same_end'], o['same_step'])))
-        tol = hole_frac_tol if which == 'hole' else frac_tol
-        for k in ('reached', 'fell', 'timed_out'):
-            assert abs(o[k][0] - o[k][1]) <= tol + 1e-9, (which, k, o[k])
-        assert abs(o['mean_len'][0] - o['mean_len'][1]) <= (2 * len_tol if which == 'hole' else len_tol) * o['mean_len'][1], (which, o['mean_len'])
-        assert o['ks_p'] > (0.2 * ks_p if which == 'hole' else ks_p), (which, o['ks_p'])
+        if which == 'hole':
+            # Episodes of the bars policy split three ways and decorrelate between the two simulators (about a quarter end at the same step), so
+            # engine and oracle are two SAMPLES of one distribution: two-sample bars at three standard errors (parity_common.two_sample_bars)
+            from parity_common import two_sample_bars
+            two_sample_bars(which, {k: o[k] for k in ('reached', 'fell', 'timed_out')}, len_e, len_o, o['ks_p'], n, floor_frac=frac_tol, floor_len=len_tol)
+        else:
+            for k in ('reached', 'fell', 'timed_out'):
+                assert abs(o[k][0] - o[k][1]) <= frac_tol + 1e-9, (which, k, o[k])
+            assert abs(o['mean_len'][0] - o['mean_len'][1]) <= len_tol * o['mean_len'][1], (which, o['mean_len'])
+            assert o['ks_p'] > ks_p, (which, o['ks_p'])
     return out

@@ -793,3 +793,23 @@ def check_reset_argument_handling(model_blob, table, lib_path):
             assert e.code == capi.LL_EINVAL
     assert np.array_equal(E.state()[[0, 1, 3, 4, 5]], before[1][[0, 1, 3, 4, 5]])
     E.close()
+
+
+def two_sample_bars(label, fracs, len_e, len_o, ks_p, n, floor_frac=0.03, floor_len=0.03, n_se=3.0, ks_floor=0.01):
+    """Bars for outcome statistics of CHAOTIC episodes played by two simulators from the same seeds.  Where most episodes end at the same step on
+    both sides the samples are paired and tight bars hold (end-reason fractions within 0.03, mean length within 3 %, KS p > 0.5: the PMC rollout
+    test, the hurdle and stairs policies).  Where they decorrelate, engine and oracle are two independent samples of what is claimed to be ONE
+    distribution, and the claim is tested as such: a fraction may differ by n_se standard errors of the difference of two binomial fractions
+    (or floor_frac, whichever is larger), the mean length by n_se standard errors of the difference of two means (or floor_len of it), and the
+    Kolmogorov-Smirnov test must not reject at ks_floor (its p-value is uniform on [0, 1] under the hypothesis: "p > 0.5" would fail every second
+    run of a perfect engine).  fracs: {name: (engine, oracle)}."""
+    import numpy as np
+    for k, (a, b) in fracs.items():
+        pbar = 0.5 * (a + b)
+        se = np.sqrt(2.0 * pbar * (1.0 - pbar) / n)
+        assert abs(a - b) <= max(floor_frac, n_se * se) + 1e-9, (label, k, a, b, 'allowed', max(floor_frac, n_se * se))
+    le, lo = np.asarray(len_e, float), np.asarray(len_o, float)
+    se = np.sqrt(le.var(ddof=1) / len(le) + lo.var(ddof=1) / len(lo))
+    print('%s: mean length %.1f / %.1f, standard error of the difference %.1f (allowed %.1f); KS p %.3f' % (label, le.mean(), lo.mean(), se, max(floor_len * lo.mean(), n_se * se), ks_p))
+    assert abs(le.mean() - lo.mean()) <= max(floor_len * lo.mean(), n_se * se), (label, le.mean(), lo.mean(), se)
+    assert ks_p > ks_floor, (label, ks_p)

@@ -328,10 +328,11 @@ def test_p2p_pull_occupies_no_compute_unit():
             f.write('  %-22s wall %.4f  kernel %.4f  waited for a copy to finish (stream + host) %.4f  (+%.1f %% wall vs none)\n' % (name, w, k, st, 100.0 * (w / res['none'][0] - 1.0)))
         f.write('\n'.join(lines) + '\n')
     print(res)
-    assert res['p2p_sdma'][1] <= 1.015 * res['none'][1], res                  # the step kernel does not notice the pulls
-    # ... and neither does the wall clock, apart from time the engine's stream spent waiting for a pull to finish before overwriting its
-    # block (a bandwidth matter -- on one device every pull is an HBM-to-HBM copy of the SDMA engines -- not an occupancy one; reported)
-    assert res['p2p_sdma'][0] - res['p2p_sdma'][2] <= 1.015 * res['none'][0] + 0.001, res
+    # (measured on MI355X, 470 MB per unroll: kernel 0.1677 none / 0.1687 p2p; wall 0.1693 / 0.1792 -- on ONE device the pull is an HBM-to-HBM
+    # copy at the 24 GB/s of one SDMA engine, 19.6 ms of every 21.7 ms unroll, and the engine waits for its end before it overwrites the block;
+    # on a node every peer's pull has its own link and engine.  The wall figure is reported, the occupancy claim asserted.)
+    assert res['p2p_sdma'][1] <= 1.01 * res['none'][1], res                   # the step kernel does not notice the pulls
+    assert res['p2p_sdma'][0] <= 1.10 * res['none'][0], res                   # and the steps are not held up by more than the copy's bandwidth explains
 
 
 def test_bench_rccl_one_rank_communicator():
