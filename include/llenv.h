@@ -197,6 +197,10 @@ int ll_step_random(ll_engine* e, float sigma);
  * sampling table (PLE:235-240) is folded once per launch, by its last workgroup, in the order one actor would have seen the episodes
  * end (later step first, then higher env) -- episodes that re-seed inside the launch sample from the table as it stood when the launch
  * began.  With prioritized_sample_factor = 0 (uniform sampling) the result is bit-identical to n_steps single-step calls.
+ * With unrolls recorded (ll_enable_unrolls) a launch of more than unroll_length x n_buffers steps would overwrite rows of its own:
+ * LL_EINVAL.  A launch may run from one unroll into the next (the rows land where single steps put them), but the block it runs into
+ * must have been handed over by then -- cut launches at unroll boundaries (ll_unroll_position) when blocks are gathered asynchronously --
+ * and every row of a launch records the neglogp / value pair the pg buffers held when the launch started (a random policy: zeros).
  */
 int ll_step_random_n(ll_engine* e, float sigma, int n_steps);
 
@@ -244,7 +248,10 @@ int ll_device_ptrs(ll_engine* e, ll_device_ptrs_t* out);
 int ll_enable_unrolls(ll_engine* e, int unroll_length, int n_buffers, float** d_base, int* row_floats);
 /* Where the NEXT control step writes: the index of its unroll (counted from ll_enable_unrolls) and its time step inside it. */
 int ll_unroll_position(ll_engine* e, int64_t* unroll_index, int* time_step);
-/* Device buffers [n_envs] in which a policy leaves -log p(a|obs) and V(obs) for the actions it wrote into the action buffer. */
+/* Device buffers [n_envs] in which a policy leaves -log p(a|obs) and V(obs) for the actions it wrote into the action buffer.
+ * Whoever writes them -- ll_policy_act_pg or the caller's own policy (e.g. torch kernels on the engine's stream) -- calls
+ * ll_pg_mark_current afterwards: the stale-bootstrap guard of ll_finish_unroll is armed by the first mark and from then on refuses a
+ * NULL bootstrap whose mark is not of the current step, whoever wrote the buffer.  A caller that never marks is never checked. */
 int ll_pg_ptrs(ll_engine* e, float** d_neglogp, float** d_value);
 /* Tell the engine that those buffers now hold the policy's outputs for the CURRENT observation (the one the next ll_step acts on).
  * A caller that fills them (ll_policy_act_pg on the engine's stream) calls this right after; ll_finish_unroll uses the stamp to refuse a

@@ -512,8 +512,12 @@ template <class Base, int LEVEL>
 struct WithParamsReload : Base {
   using Base::Base;
   static constexpr int kParamsReload = LEVEL;
+  // The kernarg segment starts with the kernel's FIRST by-value argument: params() may only be asked for that one.  Every kernel that
+  // instantiates this lane policy takes `StepParams P` first (llenv.hip: pmc_ / epmc_ / sepmc_step_kernel); the tag below makes any other
+  // type a compile error instead of a silent read of the wrong bytes.
   template <class T>
   LL_D const T& params(const T&) const {
+    static_assert(T::kFirstKernelArgument, "WithParamsReload::params(): only the kernel's first by-value argument lives at the start of the kernarg segment");
     const __attribute__((address_space(4))) void* k = (const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(k));
     return *(const T*)(const __attribute__((address_space(4))) T*)k;

@@ -204,6 +204,13 @@ struct PmcEngine {
     if (!(sigma > 0.0f)) throw PmcError(LL_EINVAL, "sigma must be positive");
     if (n_steps <= 0) throw PmcError(LL_EINVAL, "n_steps must be positive");
     if ((uint64_t)n_steps * ((uint64_t)P.n_envs + 1) >= (1ull << 32)) throw PmcError(LL_EINVAL, "n_steps x n_envs too large for the episode-order tag");
+    if (d_traj && (uint64_t)n_steps > (uint64_t)traj_unroll * (uint64_t)traj_buffers)
+      // With unrolls recorded a launch writes n_steps consecutive rows of the ring: more than the ring holds and it would overwrite rows of
+      // its own.  (Running from one block into the next is allowed -- the rows land where single steps would put them, bit for bit -- but then
+      // the caller must have handed the next block over already, and every row of a launch carries the neglogp / value pair the pg buffers
+      // held when it started: bench.py cuts its launches at unroll boundaries for that reason.)
+      throw PmcError(LL_EINVAL, "ll_step_random_n: " + std::to_string(n_steps) + " steps do not fit the unroll ring of " + std::to_string(traj_unroll) + " x " +
+                                std::to_string(traj_buffers) + " rows per env");
     step(nullptr, sigma, n_steps);
   }
   // parity hook: one control step whose physics result (and optionally foot positions) is supplied by the caller -- the

@@ -71,6 +71,7 @@ enum BaseConst {
 #endif
 
 struct StepParams {
+  static constexpr bool kFirstKernelArgument = true;   // every kernel takes it first, by value: lanes.hpp WithParamsReload re-reads it from the kernarg segment
   int32_t n_envs, n_sub, n_iter, auto_reset;
   int32_t n_clips, prop_dim, obs_dim, frame_rate;
   int32_t margin, envs_per_wave;

@@ -103,3 +103,22 @@ def test_nonfinite_guard(model_blob, mocap_table, emul_lib):
 
 def test_reset_argument_handling(model_blob, mocap_table, emul_lib):
     pc.check_reset_argument_handling(model_blob, mocap_table, emul_lib)
+
+
+def test_multi_step_launch_must_fit_the_unroll_ring(model_blob, mocap_table, emul_lib):
+    """ll_step_random_n with unrolls recorded: a launch longer than the ring (unroll_length x n_buffers rows per env) would overwrite rows of its
+    own and is refused with LL_EINVAL before anything runs (round-3 advice); running from one block into the next is the caller's business."""
+    from lifelike_agility_and_play_amd import capi
+    E = pc.make_engine(model_blob, mocap_table, 8, emul_lib, auto_reset=1, seed=3)
+    E.reset()
+    E.step_random_n(0.1, 20)                      # no unrolls: any length
+    E.enable_unrolls(8, 2)
+    E.step_random_n(0.1, 5)
+    assert E.unroll_position() == (0, 5)
+    with pytest.raises(capi.LLError) as ei:
+        E.step_random_n(0.1, 17)
+    assert ei.value.code == capi.LL_EINVAL and 'unroll ring' in str(ei.value)
+    assert E.unroll_position() == (0, 5)          # nothing ran
+    E.step_random_n(0.1, 16)                      # exactly the ring
+    assert E.unroll_position() == (2, 5)
+    E.close()

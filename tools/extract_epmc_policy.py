@@ -6,7 +6,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from extract_policy import _U, _S  # noqa: E402
+from extract_policy import _U, _S, checked_find_class  # noqa: E402,F401
 
 
 def load_checkpoint(path):
@@ -20,9 +20,7 @@ def load_checkpoint(path):
 
         class _J(NumpyUnpickler):
             def find_class(self, module, name):
-                if module.startswith('tleague'):
-                    return _S
-                return super().find_class(module, name)
+                return checked_find_class(super().find_class, module, name)
         with open(path, 'rb') as fh:
             return _J(path, fh, ensure_native_byte_order=True).load().model
 
