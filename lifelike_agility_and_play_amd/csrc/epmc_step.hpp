@@ -28,6 +28,9 @@
 #define EPMC_LIST_C (EPMC_LIST_B + EPMC_LIST_B_MAX * EPMC_BOX_WORDS)
 #define EPMC_LIST_C_MAX 12
 #define EPMC_SPARE (EPMC_LIST_C + EPMC_LIST_C_MAX * EPMC_BOX_WORDS)
+#ifndef RAY_CHUNK
+#define RAY_CHUNK 7             // rays a lane carries through one walk of its family's box list (325 rays / 16 lanes = 21 = 3 x 7)
+#endif
 #define EPMC_PARK_AT EPMC_SPARE  // row-scratch word where the episode scalars wait during the substep loop (step_env<PARK>)
 static_assert(EPMC_SPARE + 64 == PMC_ROW_SCRATCH, "row scratch layout: boxes, three ray lists, 64 spare words");
 
@@ -318,24 +321,25 @@ struct Epmc {
       flo[a] = pos[a] - ry + fminf(z0, z1) + fminf(da, 0.0f) - slack;
       fhi[a] = pos[a] + ry + fmaxf(z0, z1) + fmaxf(da, 0.0f) + slack;
     }
+    // (round 4: the lanes of the row take 16 boxes at a time -- lane j tests box b0 + j against the three bounds, a ballot over the row counts
+    // and places the hits -- instead of every lane walking all boxes behind lane 0's stores: the lists come out in the same order)
     int nA = 0, nB = 0, nC = 0;
-    for (int b = 0; b < n_boxes; b++) {
-      const float* bx = boxes + b * EPMC_BOX_WORDS;
-      const bool grid = bx[1] >= pos[0] - hgx && bx[0] <= pos[0] + hgx && bx[3] >= pos[1] - hgy && bx[2] <= pos[1] + hgy;
-      const bool front = bx[1] >= flo[0] && bx[0] <= fhi[0] && bx[3] >= flo[1] && bx[2] <= fhi[1] && bx[5] >= flo[2] && bx[4] <= fhi[2];
-      const bool fan = bx[1] >= pos[0] - 20.1f && bx[0] <= pos[0] + 20.1f && bx[3] >= pos[1] - 20.1f && bx[2] <= pos[1] + 20.1f && bx[4] <= pos[2] && bx[5] >= pos[2];
-      if (grid) {
-        if (nA < EPMC_LIST_A_MAX && ln.lane0()) for (int i = 0; i < EPMC_BOX_WORDS; i++) listA[nA * EPMC_BOX_WORDS + i] = bx[i];
-        nA++;
-      }
-      if (fan) {
-        if (nB < EPMC_LIST_B_MAX && ln.lane0()) for (int i = 0; i < EPMC_BOX_WORDS; i++) listB[nB * EPMC_BOX_WORDS + i] = bx[i];
-        nB++;
-      }
-      if (front) {
-        if (nC < EPMC_LIST_C_MAX && ln.lane0()) for (int i = 0; i < EPMC_BOX_WORDS; i++) listC[nC * EPMC_BOX_WORDS + i] = bx[i];
-        nC++;
-      }
+    const int me = ln.ray_first(), W = ln.ray_stride();
+    const uint32_t below = (1u << me) - 1u;
+    for (int b0 = 0; b0 < n_boxes; b0 += W) {
+      const int b = b0 + me;
+      const bool live = b < n_boxes;
+      const float* bx = boxes + (live ? b : 0) * EPMC_BOX_WORDS;
+      const BoxRec r = load_box(bx);
+      const bool grid = live & (r.a.y >= pos[0] - hgx) & (r.a.x <= pos[0] + hgx) & (r.a.w >= pos[1] - hgy) & (r.a.z <= pos[1] + hgy);
+      const bool front = live & (r.a.y >= flo[0]) & (r.a.x <= fhi[0]) & (r.a.w >= flo[1]) & (r.a.z <= fhi[1]) & (r.c.y >= flo[2]) & (r.c.x <= fhi[2]);
+      const bool fan = live & (r.a.y >= pos[0] - 20.1f) & (r.a.x <= pos[0] + 20.1f) & (r.a.w >= pos[1] - 20.1f) & (r.a.z <= pos[1] + 20.1f) & (r.c.x <= pos[2]) & (r.c.y >= pos[2]);
+      const uint32_t mA = ln.row_ballot(grid), mB = ln.row_ballot(fan), mC = ln.row_ballot(front);
+      const int pA = nA + __builtin_popcount(mA & below), pB = nB + __builtin_popcount(mB & below), pC = nC + __builtin_popcount(mC & below);
+      if (grid && pA < EPMC_LIST_A_MAX) store_box(listA + pA * EPMC_BOX_WORDS, r);
+      if (fan && pB < EPMC_LIST_B_MAX) store_box(listB + pB * EPMC_BOX_WORDS, r);
+      if (front && pC < EPMC_LIST_C_MAX) store_box(listC + pC * EPMC_BOX_WORDS, r);
+      nA += __builtin_popcount(mA); nB += __builtin_popcount(mB); nC += __builtin_popcount(mC);
     }
     ln.row_sync();
     const float* LA = nA <= EPMC_LIST_A_MAX ? listA : boxes;                     // a list that does not fit: walk all boxes (the tests are exact anyway)
@@ -343,26 +347,41 @@ struct Epmc {
     const float* LC = nC <= EPMC_LIST_C_MAX ? listC : boxes;
     const int cA = nA <= EPMC_LIST_A_MAX ? nA : n_boxes, cB = nB <= EPMC_LIST_B_MAX ? nB : n_boxes, cC = nC <= EPMC_LIST_C_MAX ? nC : n_boxes;
     // --- height grid (PGE:431-447): straight down from z = 10 to -10: the highest top under (x, y), or the plane ---
+    // (round 4: RAY_CHUNK rays of a lane at a time with the list's records read ONCE per chunk -- box outermost, the rays' running answers in
+    // registers -- instead of one LDS round trip per (ray, box): a lone wave has nothing to hide that latency behind.  Same arithmetic per ray.)
     if (!PMC_ABL(128))
-    for (int r = ln.ray_first(); r < EPMC_N_HEIGHT; r += ln.ray_stride()) {
-      float gx, gy;
-      grid_point(r, -1.2f, 1.2f, -0.6f, 0.6f, &gx, &gy);
-      const float x = R.m[0] * gx + R.m[1] * gy + pos[0], y = R.m[3] * gx + R.m[4] * gy + pos[1];
-      float top = 0.0f;
+    for (int r0 = ln.ray_first(); r0 < EPMC_N_HEIGHT; r0 += RAY_CHUNK * ln.ray_stride()) {
+      float x[RAY_CHUNK], y[RAY_CHUNK], top[RAY_CHUNK];
+      LL_UNROLL
+      for (int j = 0; j < RAY_CHUNK; j++) {
+        const int r = r0 + j * ln.ray_stride();
+        float gx, gy;
+        grid_point(r < EPMC_N_HEIGHT ? r : 0, -1.2f, 1.2f, -0.6f, 0.6f, &gx, &gy);
+        x[j] = R.m[0] * gx + R.m[1] * gy + pos[0]; y[j] = R.m[3] * gx + R.m[4] * gy + pos[1];
+        top[j] = 0.0f;
+      }
       BoxRec nx = load_box(LA);
       for (int b = 0; b < cA; b++) {
         const BoxRec bx = nx;
         nx = load_box(LA + (b + 1) * EPMC_BOX_WORDS);                             // (one record past the list is readable scratch)
-        const bool in = (x >= bx.a.x) & (x <= bx.a.y) & (y >= bx.a.z) & (y <= bx.a.w);
-        top = in ? fmaxf(top, bx.c.y) : top;
+        LL_UNROLL
+        for (int j = 0; j < RAY_CHUNK; j++) {
+          const bool in = (x[j] >= bx.a.x) & (x[j] <= bx.a.y) & (y[j] >= bx.a.z) & (y[j] <= bx.a.w);
+          top[j] = in ? fmaxf(top[j], bx.c.y) : top[j];
+        }
       }
-      const float frac = (10.0f - top) * 0.05f;
-      float v = 10.0f + frac * -20.0f;                                          // PGE:442 hit height
-      if (E.noise_on[3]) v = (v > 0.01f && v < 0.6f) ? v + noise[3] : 0.0f;      // PGE:443-446
-      percep[r] = v;
-      if (E.ray_trace) {
-        float* tr = E.ray_trace + ((long)env * EPMC_N_RAYS + r) * 8;
-        tr[0] = x; tr[1] = y; tr[2] = 10.0f; tr[3] = x; tr[4] = y; tr[5] = -10.0f; tr[6] = 1.0f; tr[7] = frac;
+      LL_UNROLL
+      for (int j = 0; j < RAY_CHUNK; j++) {
+        const int r = r0 + j * ln.ray_stride();
+        if (r >= EPMC_N_HEIGHT) break;
+        const float frac = (10.0f - top[j]) * 0.05f;
+        float v = 10.0f + frac * -20.0f;                                          // PGE:442 hit height
+        if (E.noise_on[3]) v = (v > 0.01f && v < 0.6f) ? v + noise[3] : 0.0f;      // PGE:443-446
+        percep[r] = v;
+        if (E.ray_trace) {
+          float* tr = E.ray_trace + ((long)env * EPMC_N_RAYS + r) * 8;
+          tr[0] = x[j]; tr[1] = y[j]; tr[2] = 10.0f; tr[3] = x[j]; tr[4] = y[j]; tr[5] = -10.0f; tr[6] = 1.0f; tr[7] = frac;
+        }
       }
     }
     if (PMC_ABL(64)) return;                                                     // ablation: height rays only
@@ -402,34 +421,48 @@ struct Epmc {
       const float d[3] = {3.0f * R.m[0], 3.0f * R.m[3], 3.0f * R.m[6]};
       float inv[3];
       for (int a = 0; a < 3; a++) inv[a] = d[a] != 0.0f ? 1.0f / d[a] : 0.0f;
-      for (int i = ln.ray_first(); i < EPMC_N_FRONT; i += ln.ray_stride()) {
-        float gy, gz;
-        grid_point(i, -0.25f, 0.25f, -0.3f, 0.1f, &gy, &gz);
-        float o[3];
-        for (int a = 0; a < 3; a++) o[a] = R.m[3 * a + 1] * gy + R.m[3 * a + 2] * gz + pos[a];
-        float best = 3.0e38f;
-        if (d[2] < 0.0f) {
-          const float tz = -o[2] * inv[2];
-          if (tz >= 0.0f && tz <= 1.0f) best = tz;
+      for (int i0 = ln.ray_first(); i0 < EPMC_N_FRONT; i0 += RAY_CHUNK * ln.ray_stride()) {
+        float o[RAY_CHUNK][3], best[RAY_CHUNK];
+        LL_UNROLL
+        for (int j = 0; j < RAY_CHUNK; j++) {
+          const int i = i0 + j * ln.ray_stride();
+          float gy, gz;
+          grid_point(i < EPMC_N_FRONT ? i : 0, -0.25f, 0.25f, -0.3f, 0.1f, &gy, &gz);
+          LL_UNROLL
+          for (int a = 0; a < 3; a++) o[j][a] = R.m[3 * a + 1] * gy + R.m[3 * a + 2] * gz + pos[a];
+          best[j] = 3.0e38f;
+          if (d[2] < 0.0f) {
+            const float tz = -o[j][2] * inv[2];
+            if (tz >= 0.0f && tz <= 1.0f) best[j] = tz;
+          }
         }
         BoxRec nx = load_box(LC);
         for (int b = 0; b < cC; b++) {
           const BoxRec bx = nx;
           nx = load_box(LC + (b + 1) * EPMC_BOX_WORDS);
-          float te = -3.0e38f, tl = 3.0e38f;
-          slab_axis(bx.a.x, bx.a.y, o[0], d[0], inv[0], te, tl);
-          slab_axis(bx.a.z, bx.a.w, o[1], d[1], inv[1], te, tl);
-          slab_axis(bx.c.x, bx.c.y, o[2], d[2], inv[2], te, tl);
-          const bool ok = (te <= tl) & (te >= 0.0f) & (te <= 1.0f);
-          best = ok ? fminf(best, te) : best;
+          LL_UNROLL
+          for (int j = 0; j < RAY_CHUNK; j++) {
+            float te = -3.0e38f, tl = 3.0e38f;
+            slab_axis(bx.a.x, bx.a.y, o[j][0], d[0], inv[0], te, tl);
+            slab_axis(bx.a.z, bx.a.w, o[j][1], d[1], inv[1], te, tl);
+            slab_axis(bx.c.x, bx.c.y, o[j][2], d[2], inv[2], te, tl);
+            const bool ok = (te <= tl) & (te >= 0.0f) & (te <= 1.0f);
+            best[j] = ok ? fminf(best[j], te) : best[j];
+          }
         }
-        const bool hit = best < 2.0f;
-        const int r = EPMC_N_HEIGHT + EPMC_N_HORIZ + i;
-        percep[r] = hit ? best * 3.0f : 3.0f;
-        if (E.ray_trace) {
-          float* tr = E.ray_trace + ((long)env * EPMC_N_RAYS + r) * 8;
-          for (int a = 0; a < 3; a++) { tr[a] = o[a]; tr[3 + a] = o[a] + d[a]; }
-          tr[6] = hit ? 1.0f : 0.0f; tr[7] = hit ? best : 1.0f;
+        LL_UNROLL
+        for (int j = 0; j < RAY_CHUNK; j++) {
+          const int i = i0 + j * ln.ray_stride();
+          if (i >= EPMC_N_FRONT) break;
+          const bool hit = best[j] < 2.0f;
+          const int r = EPMC_N_HEIGHT + EPMC_N_HORIZ + i;
+          percep[r] = hit ? best[j] * 3.0f : 3.0f;
+          if (E.ray_trace) {
+            float* tr = E.ray_trace + ((long)env * EPMC_N_RAYS + r) * 8;
+            LL_UNROLL
+            for (int a = 0; a < 3; a++) { tr[a] = o[j][a]; tr[3 + a] = o[j][a] + d[a]; }
+            tr[6] = hit ? 1.0f : 0.0f; tr[7] = hit ? best[j] : 1.0f;
+          }
         }
       }
     }

@@ -125,6 +125,8 @@ struct GpuLanes {
   LL_D bool lane0() const { return lane16_ == 0; }
   LL_D int ray_first() const { return lane16_; }
   LL_D int ray_stride() const { return PMC_ROW; }
+  // which lanes of this row hold `pred`: bit j = lane j of the row (round 4: the rows' work lists are compacted 16 entries at a time)
+  LL_D uint32_t row_ballot(bool pred) const { return (uint32_t)(__ballot(pred) >> (threadIdx.x & 48)) & 0xffffu; }
   // copy n floats (a multiple of 4, 16-byte aligned) of per-env data into the row's LDS scratch and return where they are: the
   // row's 16 lanes then read them at LDS latency instead of issuing a global load each
   LL_D float* row_scratch() const { return lds_ + row_scratch_ + (threadIdx.x >> 4) * PMC_ROW_SCRATCH; }

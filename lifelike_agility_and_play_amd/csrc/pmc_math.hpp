@@ -12,6 +12,10 @@ LL_HD BoxRec load_box(const float* p) {
   b.c = *reinterpret_cast<const F4*>(p + 4);
   return b;
 }
+LL_HD void store_box(float* p, const BoxRec& b) {
+  *reinterpret_cast<F4*>(p) = b.a;
+  *reinterpret_cast<F4*>(p + 4) = b.c;
+}
 
 template <class T>
 struct V3 {

@@ -113,6 +113,7 @@ struct HostLanes {
   bool lane0() const { return true; }
   int ray_first() const { return 0; }
   int ray_stride() const { return 1; }
+  uint32_t row_ballot(bool pred) const { return pred ? 1u : 0u; }      // (per-env scalar code runs once here: a "row" of one lane)
   void row_sync() const {}
   // (really through the scratch, so that step_env<PARK = true> -- LL_EMUL_PARK=1 -- checks on the host that nothing the substep loop changes is lost)
   void park_row(const float* v, int n, int at) const { for (int i = 0; i < n; i++) scratch_[at + i] = v[i]; }

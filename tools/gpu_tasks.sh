@@ -41,5 +41,13 @@ case $TARGET in
       for f in 0 32 64 128; do echo "LL_DEBUG_FLAGS=$f (32: no rays, 64: height grid only, 128: height grid + fan)"; LL_DEBUG_FLAGS=$f LL_LIB=tools/_build/libllenv_abl.so python tools/sweep_epmc.py "4096:1:32,4096:1:1,4096:0:32"; done > $OUT/epmc_ray_ablation.txt 2>&1
       cat $OUT/epmc_ray_ablation.txt
     fi ;;
+  rays)          # A/B of the ray-phase variants on ONE box (tools/_build/ab_<v>.so built here with tools/ab.sh build), then the EPMC / SEPMC GPU tests
+    for r in 1 2; do for v in ${AB_VARIANTS:-before rc1 rc3 rc7}; do
+      echo "== $v (round $r)"
+      LL_LIB=tools/_build/ab_$v.so python tools/sweep_epmc.py "4096:1:32,4096:3:32,4096:2:32,65536:1:1"
+      LL_LIB=tools/_build/ab_$v.so python tools/sweep_sepmc.py "2048:0:32,2048:1:32,32768:0:1"
+    done; done > $OUT/ray_ab.txt 2>&1
+    cat $OUT/ray_ab.txt
+    gpu_tests -k "epmc or sepmc" ;;
   *) echo "unknown target $TARGET"; exit 2 ;;
 esac
