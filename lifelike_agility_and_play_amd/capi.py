@@ -151,6 +151,7 @@ class Engine(object):
     def __init__(self, cfg, model_blob, mocap_table, lib_path=None):
         self.lib = load_library(lib_path)
         self.cfg = cfg
+        self._pid = os.getpid()      # a handle is only ever destroyed by the process that created it (a fork()ed child inherits the Python object, not the HIP context)
         self.h = C.c_void_p()
         blob = np.ascontiguousarray(model_blob, dtype=np.float64)
         self._chk(self.lib.ll_create(C.byref(cfg), _ptr(blob), int(blob.size), C.byref(self.h)))
@@ -176,7 +177,8 @@ class Engine(object):
 
     def close(self):
         if self.h:
-            self.lib.ll_destroy(self.h)
+            if getattr(self, '_pid', None) == os.getpid():
+                self.lib.ll_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

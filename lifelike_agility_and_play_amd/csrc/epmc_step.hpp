@@ -28,9 +28,7 @@
 #define EPMC_LIST_C (EPMC_LIST_B + EPMC_LIST_B_MAX * EPMC_BOX_WORDS)
 #define EPMC_LIST_C_MAX 12
 #define EPMC_SPARE (EPMC_LIST_C + EPMC_LIST_C_MAX * EPMC_BOX_WORDS)
-#ifndef RAY_CHUNK
-#define RAY_CHUNK 7             // rays a lane carries through one walk of its family's box list (325 rays / 16 lanes = 21 = 3 x 7)
-#endif
+#define RAY_CHUNK (L::kRayChunk)  // rays a lane carries through one walk of its family's box list (lanes.hpp WithRayChunk; 325 rays / 16 lanes = 21 = 3 x 7)
 #define EPMC_PARK_AT EPMC_SPARE  // row-scratch word where the episode scalars wait during the substep loop (step_env<PARK>)
 static_assert(EPMC_SPARE + 64 == PMC_ROW_SCRATCH, "row scratch layout: boxes, three ray lists, 64 spare words");
 

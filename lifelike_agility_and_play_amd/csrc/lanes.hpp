@@ -125,6 +125,7 @@ struct GpuLanes {
   LL_D bool lane0() const { return lane16_ == 0; }
   LL_D int ray_first() const { return lane16_; }
   LL_D int ray_stride() const { return PMC_ROW; }
+  static constexpr int kRayChunk = 1;           // (see WithRayChunk)
   // which lanes of this row hold `pred`: bit j = lane j of the row (round 4: the rows' work lists are compacted 16 entries at a time)
   LL_D uint32_t row_ballot(bool pred) const { return (uint32_t)(__ballot(pred) >> (threadIdx.x & 48)) & 0xffffu; }
   // copy n floats (a multiple of 4, 16-byte aligned) of per-env data into the row's LDS scratch and return where they are: the
@@ -533,6 +534,17 @@ template <class Base, bool ON>
 struct WithShapePrefetch : Base {
   using Base::Base;
   static constexpr bool kPrefetchShapes = ON;
+};
+
+// Rays of the EPMC / SEPMC observation a lane carries through ONE walk of its family's box list (epmc_step.hpp observe_rays): 7 keeps the
+// running answers of a third of a lane's 21 rays in registers and reads each box record once per chunk instead of once per ray.  Measured on
+// one box (tools/gpu_tasks.sh rays, profiles/r04_ray_ab.txt): one wave per SIMD -1.5 % (hurdles) ... -3 % (chase-tag arenas with elements) on top of
+// the row-parallel list building; the 256-register builds LOSE 11 % (EPMC 65536 envs) and 18 % (SEPMC 32768 arenas) to the extra live
+// registers, so they keep one ray at a time.
+template <class Base, int N>
+struct WithRayChunk : Base {
+  using Base::Base;
+  static constexpr int kRayChunk = N;
 };
 
 #define LL_FMAC_RBCAST(L_)                                                                                               \

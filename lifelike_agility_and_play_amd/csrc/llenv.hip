@@ -194,7 +194,7 @@ template <int OCC, bool MULTI = false>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, EpmcParams E) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
-  typedef WithShapePrefetch<WithParamsReload<typename std::conditional<OCC == 1 && LL_PIN_EPMC, GpuLanes1, GpuLanes>::type, (OCC == 1 ? LL_RELOAD_EPMC1 : LL_RELOAD_EPMC2)>, OCC == 2> Lanes;
+  typedef WithRayChunk<WithShapePrefetch<WithParamsReload<typename std::conditional<OCC == 1 && LL_PIN_EPMC, GpuLanes1, GpuLanes>::type, (OCC == 1 ? LL_RELOAD_EPMC1 : LL_RELOAD_EPMC2)>, OCC == 2>, (OCC == 1 ? (MULTI ? 7 : 3) : 1)> Lanes;   // (single launches at 7: 68 B of scratch)
   Lanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
   if (env0 >= P.n_envs) return;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P,
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int row0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
   typedef typename std::conditional<OCC == 1 && LL_PIN_SEPMC, GpuLanes1, GpuLanes>::type PlainLanes;
-  typedef WithShapePrefetch<typename std::conditional<(OCC == 2 && LL_RELOAD_SEPMC2), WithParamsReload<PlainLanes, LL_RELOAD_SEPMC2>, PlainLanes>::type, OCC == 1> Lanes;
+  typedef WithRayChunk<WithShapePrefetch<typename std::conditional<(OCC == 2 && LL_RELOAD_SEPMC2), WithParamsReload<PlainLanes, LL_RELOAD_SEPMC2>, PlainLanes>::type, OCC == 1>, (OCC == 1 ? 7 : 1)> Lanes;
   Lanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
   if (row0 >= P.n_envs) return;

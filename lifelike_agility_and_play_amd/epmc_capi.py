@@ -132,6 +132,7 @@ class EpmcEngine(object):
     def __init__(self, cfg, model_blob, init_state=None, lib_path=None):
         self.lib = load_library(lib_path)
         self.n_envs = int(cfg.n_envs)
+        self._pid = os.getpid()
         self.h = C.c_void_p()
         blob = np.ascontiguousarray(model_blob, dtype=np.float64)
         init = np.ascontiguousarray(default_init_state() if init_state is None else init_state, dtype=np.float64)
@@ -146,7 +147,8 @@ class EpmcEngine(object):
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
-            self.lib.ll_epmc_destroy(self.h)
+            if getattr(self, '_pid', None) == os.getpid():      # (a fork()ed child inherits the object, not the HIP context: it must not destroy it)
+                self.lib.ll_epmc_destroy(self.h)
             self.h = None
 
     def __del__(self):

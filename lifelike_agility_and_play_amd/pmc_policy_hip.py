@@ -44,6 +44,7 @@ class HipPmcPolicy(object):
     def __init__(self, npz_path=DEFAULT_WEIGHTS, device=0, lib_path=None):
         self.lib = load_library(lib_path)
         w = pack_weights(npz_path)
+        self._pid = os.getpid()
         self.h = C.c_void_p()
         self._chk(self.lib.ll_policy_create(w.ctypes.data_as(C.c_void_p), int(w.size), int(device), C.byref(self.h)))
 
@@ -80,7 +81,8 @@ class HipPmcPolicy(object):
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
-            self.lib.ll_policy_destroy(self.h)
+            if getattr(self, '_pid', None) == os.getpid():      # (a fork()ed child inherits the object, not the HIP context: it must not destroy it)
+                self.lib.ll_policy_destroy(self.h)
             self.h = None
 
     def __del__(self):

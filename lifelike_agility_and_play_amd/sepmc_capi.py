@@ -1,5 +1,6 @@
 """ctypes binding of include/llenv_sepmc.h (the SEPMC / ChaseTagGameEnv engine inside libllenv.so)."""
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -126,6 +127,7 @@ class SepmcEngine(object):
     def __init__(self, cfg, model_blob, init_state=None, lib_path=None):
         self.lib = load_library(lib_path)
         self.n_arenas = int(cfg.n_arenas)
+        self._pid = os.getpid()
         self.h = C.c_void_p()
         blob = np.ascontiguousarray(model_blob, dtype=np.float64)
         init = np.ascontiguousarray(default_init_state() if init_state is None else init_state, dtype=np.float64)
@@ -140,7 +142,8 @@ class SepmcEngine(object):
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
-            self.lib.ll_sepmc_destroy(self.h)
+            if getattr(self, '_pid', None) == os.getpid():      # (a fork()ed child inherits the object, not the HIP context: it must not destroy it)
+                self.lib.ll_sepmc_destroy(self.h)
             self.h = None
 
     def __del__(self):

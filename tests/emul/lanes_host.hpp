@@ -113,6 +113,7 @@ struct HostLanes {
   bool lane0() const { return true; }
   int ray_first() const { return 0; }
   int ray_stride() const { return 1; }
+  static constexpr int kRayChunk = 7;           // (the host build runs the chunked ray loops of the one-wave-per-SIMD kernels)
   uint32_t row_ballot(bool pred) const { return pred ? 1u : 0u; }      // (per-env scalar code runs once here: a "row" of one lane)
   void row_sync() const {}
   // (really through the scratch, so that step_env<PARK = true> -- LL_EMUL_PARK=1 -- checks on the host that nothing the substep loop changes is lost)

@@ -598,6 +598,7 @@ def check_game_statistics(lib_path, n_per_policy=128, procs=None, policies=('hur
     correlated between the two simulators (measured on MI355X, 128 episodes each: reached 0.984 / 0.984 and 0.992 / 0.969, mean length 188.6 / 188.0
     and 231.1 / 233.7, KS p 1.0).  The overhead-bars ('hole') policy, whose episodes split between reaching and falling (0.266 / 0.258 reached,
     0.578 / 0.617 fell), gets two-sample bars (see below)."""
+    import gc
     import multiprocessing as mp
     from scipy import stats as sst
     from oracle.epmc_policy import EpmcPolicy
@@ -606,6 +607,7 @@ def check_game_statistics(lib_path, n_per_policy=128, procs=None, policies=('hur
     out = {}
     for which in policies:
         n = n_per_policy
+        gc.collect()                                          # (no dead engine objects for the forked workers to finalise)
         with mp.get_context('fork').Pool(procs) as p:
             res = p.map(_oracle_game, [(which, 1000 * (1 + policies.index(which)) + i) for i in range(n)], chunksize=1)
         len_o, why_o = np.array([r[0] for r in res]), np.array([r[1] for r in res])

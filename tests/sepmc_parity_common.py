@@ -750,6 +750,7 @@ def check_game_statistics(lib_path, n_arenas=256, procs=None, frac_tol=0.03, len
     CTG:426-470 / robot 0 down / max_steps).  Distributions must agree: end-reason fractions, mean length and the Kolmogorov-Smirnov test on the
     lengths under two-sample bars (`frac_tol` / `len_tol` or three standard errors, whichever is larger), and the fraction of arena-steps whose
     first contact record of robot 0 names the other robot."""
+    import gc
     import multiprocessing as mp
     from scipy import stats as sst
     from oracle.sepmc_policy import SepmcPolicy
@@ -757,6 +758,7 @@ def check_game_statistics(lib_path, n_arenas=256, procs=None, frac_tol=0.03, len
     import bench
     procs = procs or bench.effective_cores()[0]
     n = n_arenas
+    gc.collect()                                              # (no dead engine objects for the forked workers to finalise)
     with mp.get_context('fork').Pool(procs) as p:
         res = p.map(_oracle_game, [5000 + i for i in range(n)], chunksize=1)
     len_o, why_o, named_o = np.array([r[0] for r in res]), np.array([r[1] for r in res]), np.array([r[2] for r in res])

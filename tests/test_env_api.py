@@ -124,3 +124,39 @@ def test_batched_env(golden, emul_lib):
     parts = env.split(obs)
     assert parts['prop'].shape == (8, 99)
     env.close()
+
+
+def test_a_forked_child_does_not_destroy_the_parents_engine(model_blob, mocap_table):
+    """Engine objects inherited through fork() (multiprocessing pools of the test tools) are dropped in the child without calling into the
+    library: the HIP context behind the handle belongs to the parent (a child that called ll_destroy aborted the GPU test run once)."""
+    import os
+    import subprocess
+    emul_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emul')
+    subprocess.check_call(['make', '-C', emul_dir, '-s'])
+    from lifelike_agility_and_play_amd import capi
+    import parity_common as pc
+    E = pc.make_engine(model_blob, mocap_table, 4, os.path.join(emul_dir, '_build', 'libllenv_emul.so'))
+
+    class Spy(object):
+        def __init__(self, lib):
+            self.lib, self.destroyed = lib, 0
+
+        def __getattr__(self, name):
+            if name == 'll_destroy':
+                def f(h):
+                    self.destroyed += 1
+                    return 0
+                return f
+            return getattr(self.lib, name)
+    pid = os.fork()
+    if pid == 0:
+        spy = Spy(E.lib)
+        E.lib = spy
+        E.close()
+        os._exit(10 + spy.destroyed if not E.h else 99)
+    _, status = os.waitpid(pid, 0)
+    assert os.WEXITSTATUS(status) == 10, status            # handle dropped, ll_destroy not called
+    E.reset(); E.fill_random_actions(0.1); E.step()        # the parent's engine is alive
+    assert np.isfinite(E.obs()).all()
+    E.close()
+    assert not E.h
