@@ -15,7 +15,7 @@ show() { grep '^{' | tail -1 | python -c "
 import json,sys
 j=json.loads(sys.stdin.read()); r=j['roofline']
 print('$1: value %.2f M  ms/step %.4f  kernel ms/step %.4f  launches %d' % (j['value']/1e6, j['ms_per_step'], r['kernel_avg_ms'], r['kernel_launches_timed']))"; }
-gpu_tests() { timeout 1500 python -m pytest tests -m gpu -q "$@" > $OUT/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $OUT/pytest_gpu.log; tail -4 $OUT/pytest_gpu.log; }
+gpu_tests() { timeout 1500 python -m pytest tests -m gpu -q -rA "$@" > $OUT/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $OUT/pytest_gpu.log; grep -E "passed|failed|^FAILED|^ERROR|pytest rc" $OUT/pytest_gpu.log | tail -8; }
 case $TARGET in
   tests) gpu_tests ;;
   valu) tools/_build/valu_issue_bench 2000 | tee $OUT/valu_issue.txt ;;
