@@ -155,18 +155,67 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
       Pmc<Lanes>::template step_env<OBST>(ln, P, env0, act, 0);
     }
   } else {
-    // ll_step_random_n: n_steps control steps back to back.  A wave walks its four envs through them on its own -- no other wave is waited
-    // for, so a slow step of one wave (leg-leg rows, a re-seed) is not a slow step of the whole chip -- and between two steps it only has
-    // to see its own stores (state, obs row, bookkeeping: workgroup-scope fence = wait for the wave's outstanding memory operations).
-    for (int sl = 0; sl < P.n_steps; sl++) {
-      if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // ll_step_random_n: n_steps control steps back to back.  STATIC schedule (dyn_n_xcc = 0): a wave walks its own four envs through them -- no
+    // other wave is waited for, so a slow step of one wave (leg-leg rows, a re-seed) is not a slow step of the whole chip -- and between two
+    // steps it only has to see its own stores (state, obs row, bookkeeping: workgroup-scope fence = wait for the wave's outstanding memory
+    // operations).
+    // DYNAMIC schedule (round 4; one wave per SIMD, i.e. every wave of the grid resident): slowness is persistent -- a robot lying with its
+    // legs crossed keeps its leg-leg rows for many steps -- so with fixed envs the slowest wave of a 32-step launch is still 9 % over the
+    // mean (profiles/r03_timeline.txt).  Here the (step, group-of-four-envs) items of the launch are dealt out by a ticket counter, step-major:
+    // a wave that is done early takes the next item, whoever's envs those are.  Item (s, g) needs step s - 1 of group g complete: the wave
+    // polls that group's counter (its holder took a smaller ticket and is running: no deadlock, whatever is resident).  The env rows of a
+    // group then travel between waves through HBM-side caches, which is only cheap inside one XCD (one L2): each XCD has its own queue
+    // and its own share of the groups (g mod n_xcc), a wave serves the queue of the XCD it runs on (HW_REG_XCC_ID).  Within an XCD the
+    // stores of the previous holder are in the shared L2 once its vmcnt has drained; the next holder only has to drop its own L1
+    // (agent-scope acquire = buffer_inv sc1; no L2 write-back anywhere).  Results are identical to the static schedule bit for bit: the
+    // step of an env does not depend on who computes it (test_multi_step_launch).
+    const bool dyn = (OCC == 1) && P.dyn_n_xcc > 0;
+    int xcc = 0, gpx = 0;
+    if (dyn) {
+      unsigned int id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+      xcc = (int)(id & 15u) % P.dyn_n_xcc;
+      gpx = ((int)gridDim.x - xcc + P.dyn_n_xcc - 1) / P.dyn_n_xcc;            // groups g < gridDim.x with g mod n_xcc == xcc
+    }
+    for (int it = 0;; it++) {
+      int sl = it, grp = (int)blockIdx.x;
+      if (dyn) {
+        unsigned int item = 0;
+        if (threadIdx.x == 0) item = __hip_atomic_fetch_add(P.dyn_state + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= (unsigned int)(P.n_steps * gpx)) break;
+        sl = (int)(item / (unsigned int)gpx);
+        grp = (int)(item % (unsigned int)gpx) * P.dyn_n_xcc + xcc;
+        if (sl > 0) {                                                          // the group's previous step (another wave of this XCD, as a rule)
+          unsigned int seen, spins = 0;
+          do {
+            seen = 0;
+            if (threadIdx.x == 0) seen = __hip_atomic_load(P.dyn_state + 16 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen = __builtin_amdgcn_readfirstlane(seen);
+            if (seen >= (unsigned int)sl) break;
+            __builtin_amdgcn_s_sleep(4);
+          } while (++spins < 400000u);                                         // (a legitimate wait is one step: a few hundred polls; bounded so that a bug cannot hang the GPU)
+          if (seen < (unsigned int)sl) {
+            if (threadIdx.x == 0) atomicAdd(P.counters + 3, 1ull);             // reported by the engine as LL_ESTATE
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                      // drop this CU's L1: the rows were written through another CU
+      } else {
+        if (it >= P.n_steps) break;
+        if (it) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      }
       ln.new_step();
-      int env = env0;
+      int env = grp * PMC_ENVS_PER_WAVE + (int)(threadIdx.x >> 4);
       asm volatile("" : "+v"(env));      // ... and no address of the step's ~150 loads and stores either (they all derive from env)
       if (env < P.n_envs) {
         float act[3];
         step_actions(P, ln, lds, env, sl, act);
         Pmc<Lanes>::template step_env<OBST>(ln, P, env, act, sl);
+      }
+      if (dyn) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the step's stores have reached the L2 ...
+        if (threadIdx.x == 0) __hip_atomic_store(P.dyn_state + 16 + grp, (unsigned int)(sl + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the group is handed on
       }
     }
   }
@@ -222,6 +271,14 @@ __global__ __launch_bounds__(PMC_WAVE) void epmc_reset_kernel(StepParams P, Epmc
   if (i >= n) return;
   const int env = ids ? ids[i] : i;
   Epmc<GpuLanes>::reset_env(ln, P, E, env, draws ? draws + (long)i * EPMC_MAX_DRAWS : nullptr, prev_orn ? prev_orn + (long)i * 4 : nullptr);
+}
+
+// which XCD does each single-wave workgroup of a full grid land on?  (HipBackend::probe_xcds: the dynamic step schedule is only switched on
+// where the answer is the even round-robin it is built for)
+__global__ __launch_bounds__(PMC_WAVE) void xcc_probe_kernel(unsigned int* out) {
+  unsigned int id;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+  if (threadIdx.x == 0) out[blockIdx.x] = id & 15u;
 }
 
 // SEPMC (sepmc_step.hpp): one control step of ChaseTagGameEnv; row = 2 * arena + robot, the two robots of an arena are
@@ -338,9 +395,32 @@ struct HipBackend {
     const char* sh = getenv("LL_SHARE_SIMDS");
     if (sh && sh[0] == '1') simds = 0;
     stream = own;
+    probe_xcds();
+  }
+  // Dynamic step scheduling of the multi-step launches (pmc_step_kernel): on when LL_DYNAMIC_STEPS != 0 (default) AND a full grid of
+  // single-wave workgroups spreads over the device's XCDs the way the schedule assumes -- every XCD id below the reported count, each with
+  // its even share of the workgroups.  Anything else (another partition mode, an odd dispatcher) keeps the static schedule.
+  int dyn_n_xcc = 0;
+  uint32_t* d_dyn = nullptr;
+  void probe_xcds() {
+    const char* sw = getenv("LL_DYNAMIC_STEPS");
+    if ((sw && sw[0] == '0') || simds <= 0) return;
+    int n_xcc = 0;
+    if (hipDeviceGetAttribute(&n_xcc, hipDeviceAttributeNumberOfXccs, device) != hipSuccess || n_xcc < 1 || n_xcc > 16 || simds % n_xcc) return;
+    d_dyn = (uint32_t*)alloc((size_t)(16 + simds) * sizeof(uint32_t));
+    std::vector<unsigned int> ids(simds);
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(simds), dim3(PMC_WAVE), 0, stream, d_dyn);
+    if (hipGetLastError() != hipSuccess) return;
+    d2h(ids.data(), d_dyn, (size_t)simds * sizeof(uint32_t));
+    std::vector<int> count(16, 0);
+    for (int i = 0; i < simds; i++) count[ids[i] & 15u]++;
+    for (int x = 0; x < 16; x++)
+      if (count[x] != (x < n_xcc ? simds / n_xcc : 0)) return;
+    dyn_n_xcc = n_xcc;
   }
   ~HipBackend() {
     (void)hipSetDevice(device);
+    if (d_dyn) (void)hipFree(d_dyn);
     for (auto& p : evs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (own) (void)hipStreamDestroy(own);
   }
@@ -437,6 +517,17 @@ struct HipBackend {
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
     const bool one = blocks <= simds, multi = P.n_steps > 1;
+    StepParams Q;
+    if (one && multi && dyn_n_xcc > 0 && P.n_steps > 1) {      // (single-step launches and the larger-batch builds keep their fixed envs)
+      HIPCHK(hipMemsetAsync(d_dyn, 0, (size_t)(16 + blocks) * sizeof(uint32_t), stream));
+      Q = P;
+      Q.dyn_state = d_dyn;
+      Q.dyn_n_xcc = dyn_n_xcc;
+      return launch_step_kernels(Q, blocks, one, multi, ev);
+    }
+    launch_step_kernels(P, blocks, one, multi, ev);
+  }
+  void launch_step_kernels(const StepParams& P, int blocks, bool one, bool multi, std::pair<hipEvent_t, hipEvent_t>* ev) {
     if (P.set_obstacle) {
       if (one) { if (multi) hipLaunchKernelGGL((pmc_step_kernel<1, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
                  else       hipLaunchKernelGGL((pmc_step_kernel<1, true, false>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P); }

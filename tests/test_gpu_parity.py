@@ -176,7 +176,7 @@ def test_multi_step_launch(model_blob, mocap_table):
 
     def read_ring(addr, shape):
         return gather.device_tensor(addr, shape).cpu().numpy()
-    pc.check_multi_step_launch(model_blob, mocap_table, None, read_ring, sizes=(70, 4200), k=9, n_launches=4)
+    pc.check_multi_step_launch(model_blob, mocap_table, None, read_ring, sizes=(70, 4200), k=7, n_launches=5)
 
 
 def test_contact_rich_parity(golden, orc, model_blob, mocap_table):
