@@ -161,48 +161,55 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
     // operations).
     // DYNAMIC schedule (round 4; one wave per SIMD, i.e. every wave of the grid resident): slowness is persistent -- a robot lying with its
     // legs crossed keeps its leg-leg rows for many steps -- so with fixed envs the slowest wave of a 32-step launch is still 9 % over the
-    // mean (profiles/r03_timeline.txt).  Here the (step, group-of-four-envs) items of the launch are dealt out by a ticket counter, step-major:
-    // a wave that is done early takes the next item, whoever's envs those are.  Item (s, g) needs step s - 1 of group g complete: the wave
-    // polls that group's counter (its holder took a smaller ticket and is running: no deadlock, whatever is resident).  The env rows of a
-    // group then travel between waves through HBM-side caches, which is only cheap inside one XCD (one L2): each XCD has its own queue
-    // and its own share of the groups (g mod n_xcc), a wave serves the queue of the XCD it runs on (HW_REG_XCC_ID).  Within an XCD the
-    // stores of the previous holder are in the shared L2 once its vmcnt has drained; the next holder only has to drop its own L1
-    // (agent-scope acquire = buffer_inv sc1; no L2 write-back anywhere).  Results are identical to the static schedule bit for bit: the
-    // step of an env does not depend on who computes it (test_multi_step_launch).
+    // mean (profiles/r03_timeline.txt).  Here a wave that has finished step s of a group of four envs puts (s + 1, group) at the tail of a
+    // READY queue and takes whatever is at its head: an item is in the queue exactly when its predecessor is complete, so nobody ever waits
+    // for a dependency, only for work.  (A first version dealt the items out step-major by a ticket counter and polled the predecessor: a
+    // wave that was done early usually drew a group whose previous step was still running, and waited -- no gain, profiles/r04_dyn_steps.txt.)
+    // The env rows of a group travel between waves through the caches, which is only cheap inside one XCD (one L2): each XCD has its own
+    // queue and keeps the groups that start on it (workgroup b runs on XCD b mod n_xcc: HipBackend::probe_xcds checks it), a wave serves
+    // the queue of the XCD it runs on (HW_REG_XCC_ID).  Within an XCD the stores of the previous holder are in the shared L2 once its
+    // vmcnt has drained; the next holder only has to drop its own L1 (agent-scope acquire = buffer_inv sc1; no L2 write-back anywhere).
+    // Results are identical to the static schedule bit for bit: the step of an env does not depend on who computes it (test_multi_step_launch).
+    // Queue of XCD x: dyn_state[x] = head (pops so far), dyn_state[16 + x] = tail (pushes so far), entries at dyn_state[32 + x * cap ...),
+    // cap = (n_steps - 1) * gpx = exactly the number of items ever pushed; an entry is step << 16 | group, 0xffffffff while empty.
     const bool dyn = (OCC == 1) && P.dyn_n_xcc > 0;
-    int xcc = 0, gpx = 0;
+    int xcc = 0, gpx = 0, cap = 0;
+    unsigned int* ring = nullptr;
     if (dyn) {
       unsigned int id;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
       xcc = (int)(id & 15u) % P.dyn_n_xcc;
-      gpx = ((int)gridDim.x - xcc + P.dyn_n_xcc - 1) / P.dyn_n_xcc;            // groups g < gridDim.x with g mod n_xcc == xcc
+      gpx = (int)gridDim.x / P.dyn_n_xcc;                                       // (the launch code only switches this on for whole multiples)
+      cap = (P.n_steps - 1) * gpx;
+      ring = P.dyn_state + 32 + (long)xcc * cap;
     }
+    int sl = 0, grp = (int)blockIdx.x;                                           // every wave starts with step 0 of its own group
     for (int it = 0;; it++) {
-      int sl = it, grp = (int)blockIdx.x;
       if (dyn) {
-        unsigned int item = 0;
-        if (threadIdx.x == 0) item = __hip_atomic_fetch_add(P.dyn_state + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= (unsigned int)(P.n_steps * gpx)) break;
-        sl = (int)(item / (unsigned int)gpx);
-        grp = (int)(item % (unsigned int)gpx) * P.dyn_n_xcc + xcc;
-        if (sl > 0) {                                                          // the group's previous step (another wave of this XCD, as a rule)
-          unsigned int seen, spins = 0;
-          do {
-            seen = 0;
-            if (threadIdx.x == 0) seen = __hip_atomic_load(P.dyn_state + 16 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            seen = __builtin_amdgcn_readfirstlane(seen);
-            if (seen >= (unsigned int)sl) break;
-            __builtin_amdgcn_s_sleep(4);
-          } while (++spins < 400000u);                                         // (a legitimate wait is one step: a few hundred polls; bounded so that a bug cannot hang the GPU)
-          if (seen < (unsigned int)sl) {
-            if (threadIdx.x == 0) atomicAdd(P.counters + 3, 1ull);             // reported by the engine as LL_ESTATE
+        if (it) {
+          unsigned int idx = 0;
+          if (threadIdx.x == 0) idx = __hip_atomic_fetch_add(P.dyn_state + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          idx = __builtin_amdgcn_readfirstlane(idx);
+          if (idx >= (unsigned int)cap) break;                                   // everything that will ever be queued has been taken
+          unsigned int item, spins = 0;
+          do {                                                                   // (empty only while every group of this XCD is being worked on)
+            item = 0xffffffffu;
+            if (threadIdx.x == 0) item = __hip_atomic_load(ring + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            item = __builtin_amdgcn_readfirstlane(item);
+            if (item != 0xffffffffu) break;
+            __builtin_amdgcn_s_sleep(2);
+          } while (++spins < 400000u);                                           // bounded, so that a bug cannot hang the GPU
+          if (item == 0xffffffffu) {
+            if (threadIdx.x == 0) atomicAdd(P.counters + 3, 1ull);               // reported by the engine as LL_ESTATE
             break;
           }
+          sl = (int)(item >> 16);
+          grp = (int)(item & 0xffffu);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                      // drop this CU's L1: the rows were written through another CU
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                      // drop this CU's L1: the rows were written through another CU
       } else {
         if (it >= P.n_steps) break;
+        sl = it;
         if (it) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       }
       ln.new_step();
@@ -213,9 +220,13 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
         step_actions(P, ln, lds, env, sl, act);
         Pmc<Lanes>::template step_env<OBST>(ln, P, env, act, sl);
       }
-      if (dyn) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the step's stores have reached the L2 ...
-        if (threadIdx.x == 0) __hip_atomic_store(P.dyn_state + 16 + grp, (unsigned int)(sl + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the group is handed on
+      if (dyn && sl + 1 < P.n_steps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the step's stores have reached the L2 ...
+        if (threadIdx.x == 0) {                                                  // ... before the group's next step is offered
+          const unsigned int slot = __hip_atomic_fetch_add(P.dyn_state + 16 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (slot < (unsigned int)cap) __hip_atomic_store(ring + slot, ((unsigned int)(sl + 1) << 16) | (unsigned int)grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else atomicAdd(P.counters + 3, 1ull);                                  // (more groups on this XCD than the probe promised: reported)
+        }
       }
     }
   }
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P,
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int row0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
   typedef typename std::conditional<OCC == 1 && LL_PIN_SEPMC, GpuLanes1, GpuLanes>::type PlainLanes;
-  typedef WithRayChunk<WithShapePrefetch<typename std::conditional<(OCC == 2 && LL_RELOAD_SEPMC2), WithParamsReload<PlainLanes, LL_RELOAD_SEPMC2>, PlainLanes>::type, OCC == 1>, (OCC == 1 ? 7 : 1)> Lanes;
+  typedef WithRayChunk<WithShapePrefetch<typename std::conditional<(OCC == 2 && LL_RELOAD_SEPMC2), WithParamsReload<PlainLanes, LL_RELOAD_SEPMC2>, PlainLanes>::type, OCC == 1>, (OCC == 1 ? 3 : 1)> Lanes;   // (chunk 7 fails the arena invariants on the GPU in this kernel -- at 256 + 255 registers; 3 is what was validated: profiles/r04_ray_ab.txt)
   Lanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
   if (row0 >= P.n_envs) return;
@@ -401,13 +412,15 @@ struct HipBackend {
   // single-wave workgroups spreads over the device's XCDs the way the schedule assumes -- every XCD id below the reported count, each with
   // its even share of the workgroups.  Anything else (another partition mode, an odd dispatcher) keeps the static schedule.
   int dyn_n_xcc = 0;
+  size_t dyn_words = 0;
   uint32_t* d_dyn = nullptr;
   void probe_xcds() {
     const char* sw = getenv("LL_DYNAMIC_STEPS");
     if ((sw && sw[0] == '0') || simds <= 0) return;
     int n_xcc = 0;
     if (hipDeviceGetAttribute(&n_xcc, hipDeviceAttributeNumberOfXccs, device) != hipSuccess || n_xcc < 1 || n_xcc > 16 || simds % n_xcc) return;
-    d_dyn = (uint32_t*)alloc((size_t)(16 + simds) * sizeof(uint32_t));
+    dyn_words = 32 + (size_t)simds * 256;                                  // queues for launches of up to 257 control steps on a full grid
+    d_dyn = (uint32_t*)alloc(dyn_words * sizeof(uint32_t));
     std::vector<unsigned int> ids(simds);
     hipLaunchKernelGGL(xcc_probe_kernel, dim3(simds), dim3(PMC_WAVE), 0, stream, d_dyn);
     if (hipGetLastError() != hipSuccess) return;
@@ -518,8 +531,10 @@ struct HipBackend {
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
     const bool one = blocks <= simds, multi = P.n_steps > 1;
     StepParams Q;
-    if (one && multi && dyn_n_xcc > 0 && P.n_steps > 1) {      // (single-step launches and the larger-batch builds keep their fixed envs)
-      HIPCHK(hipMemsetAsync(d_dyn, 0, (size_t)(16 + blocks) * sizeof(uint32_t), stream));
+    if (one && multi && dyn_n_xcc > 0 && blocks % dyn_n_xcc == 0 && blocks / dyn_n_xcc < 65536 && P.n_steps < 65536 &&
+        (size_t)32 + (size_t)(P.n_steps - 1) * blocks <= dyn_words) {    // (single-step launches and the larger-batch builds keep their fixed envs)
+      HIPCHK(hipMemsetAsync(d_dyn, 0, 32 * sizeof(uint32_t), stream));                                             // heads and tails
+      HIPCHK(hipMemsetAsync(d_dyn + 32, 0xff, (size_t)(P.n_steps - 1) * blocks * sizeof(uint32_t), stream));       // empty entries
       Q = P;
       Q.dyn_state = d_dyn;
       Q.dyn_n_xcc = dyn_n_xcc;
