@@ -540,7 +540,8 @@ struct WithShapePrefetch : Base {
 // running answers of a third of a lane's 21 rays in registers and reads each box record once per chunk instead of once per ray.  Measured on
 // one box (tools/gpu_tasks.sh rays, profiles/r04_ray_ab.txt): one wave per SIMD -1.5 % (hurdles) ... -3 % (chase-tag arenas with elements) on top of
 // the row-parallel list building; the 256-register builds LOSE 11 % (EPMC 65536 envs) and 18 % (SEPMC 32768 arenas) to the extra live
-// registers, so they keep one ray at a time.
+// registers, so they keep one ray at a time.  The SEPMC one-wave-per-SIMD kernel (256 + 255 registers) fails its arena invariants on the
+// GPU with 7 and passes with 3 (tools/diag_sepmc_rays.py): it runs 3.
 template <class Base, int N>
 struct WithRayChunk : Base {
   using Base::Base;

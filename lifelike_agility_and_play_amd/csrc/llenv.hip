@@ -155,78 +155,20 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
       Pmc<Lanes>::template step_env<OBST>(ln, P, env0, act, 0);
     }
   } else {
-    // ll_step_random_n: n_steps control steps back to back.  STATIC schedule (dyn_n_xcc = 0): a wave walks its own four envs through them -- no
-    // other wave is waited for, so a slow step of one wave (leg-leg rows, a re-seed) is not a slow step of the whole chip -- and between two
-    // steps it only has to see its own stores (state, obs row, bookkeeping: workgroup-scope fence = wait for the wave's outstanding memory
-    // operations).
-    // DYNAMIC schedule (round 4; one wave per SIMD, i.e. every wave of the grid resident): slowness is persistent -- a robot lying with its
-    // legs crossed keeps its leg-leg rows for many steps -- so with fixed envs the slowest wave of a 32-step launch is still 9 % over the
-    // mean (profiles/r03_timeline.txt).  Here a wave that has finished step s of a group of four envs puts (s + 1, group) at the tail of a
-    // READY queue and takes whatever is at its head: an item is in the queue exactly when its predecessor is complete, so nobody ever waits
-    // for a dependency, only for work.  (A first version dealt the items out step-major by a ticket counter and polled the predecessor: a
-    // wave that was done early usually drew a group whose previous step was still running, and waited -- no gain, profiles/r04_dyn_steps.txt.)
-    // The env rows of a group travel between waves through the caches, which is only cheap inside one XCD (one L2): each XCD has its own
-    // queue and keeps the groups that start on it (workgroup b runs on XCD b mod n_xcc: HipBackend::probe_xcds checks it), a wave serves
-    // the queue of the XCD it runs on (HW_REG_XCC_ID).  Within an XCD the stores of the previous holder are in the shared L2 once its
-    // vmcnt has drained; the next holder only has to drop its own L1 (agent-scope acquire = buffer_inv sc1; no L2 write-back anywhere).
-    // Results are identical to the static schedule bit for bit: the step of an env does not depend on who computes it (test_multi_step_launch).
-    // Queue of XCD x: dyn_state[x] = head (pops so far), dyn_state[16 + x] = tail (pushes so far), entries at dyn_state[32 + x * cap ...),
-    // cap = (n_steps - 1) * gpx = exactly the number of items ever pushed; an entry is step << 16 | group, 0xffffffff while empty.
-    const bool dyn = (OCC == 1) && P.dyn_n_xcc > 0;
-    int xcc = 0, gpx = 0, cap = 0;
-    unsigned int* ring = nullptr;
-    if (dyn) {
-      unsigned int id;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-      xcc = (int)(id & 15u) % P.dyn_n_xcc;
-      gpx = (int)gridDim.x / P.dyn_n_xcc;                                       // (the launch code only switches this on for whole multiples)
-      cap = (P.n_steps - 1) * gpx;
-      ring = P.dyn_state + 32 + (long)xcc * cap;
-    }
-    int sl = 0, grp = (int)blockIdx.x;                                           // every wave starts with step 0 of its own group
-    for (int it = 0;; it++) {
-      if (dyn) {
-        if (it) {
-          unsigned int idx = 0;
-          if (threadIdx.x == 0) idx = __hip_atomic_fetch_add(P.dyn_state + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          idx = __builtin_amdgcn_readfirstlane(idx);
-          if (idx >= (unsigned int)cap) break;                                   // everything that will ever be queued has been taken
-          unsigned int item, spins = 0;
-          do {                                                                   // (empty only while every group of this XCD is being worked on)
-            item = 0xffffffffu;
-            if (threadIdx.x == 0) item = __hip_atomic_load(ring + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            item = __builtin_amdgcn_readfirstlane(item);
-            if (item != 0xffffffffu) break;
-            __builtin_amdgcn_s_sleep(2);
-          } while (++spins < 400000u);                                           // bounded, so that a bug cannot hang the GPU
-          if (item == 0xffffffffu) {
-            if (threadIdx.x == 0) atomicAdd(P.counters + 3, 1ull);               // reported by the engine as LL_ESTATE
-            break;
-          }
-          sl = (int)(item >> 16);
-          grp = (int)(item & 0xffffu);
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                      // drop this CU's L1: the rows were written through another CU
-        }
-      } else {
-        if (it >= P.n_steps) break;
-        sl = it;
-        if (it) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      }
+    // ll_step_random_n: n_steps control steps back to back.  A wave walks its four envs through them on its own -- no other wave is waited
+    // for, so a slow step of one wave (leg-leg rows, a re-seed) is not a slow step of the whole chip -- and between two steps it only has
+    // to see its own stores (state, obs row, bookkeeping: workgroup-scope fence = wait for the wave's outstanding memory operations).
+    // (Dealing the steps out dynamically -- a per-XCD ready queue of (step, group) items -- was built and measured in round 4: 0.8 % slower,
+    // there is no imbalance left to win inside a multi-step launch; profiles/r04_dyn_steps.txt.)
+    for (int sl = 0; sl < P.n_steps; sl++) {
+      if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       ln.new_step();
-      int env = grp * PMC_ENVS_PER_WAVE + (int)(threadIdx.x >> 4);
+      int env = env0;
       asm volatile("" : "+v"(env));      // ... and no address of the step's ~150 loads and stores either (they all derive from env)
       if (env < P.n_envs) {
         float act[3];
         step_actions(P, ln, lds, env, sl, act);
         Pmc<Lanes>::template step_env<OBST>(ln, P, env, act, sl);
-      }
-      if (dyn && sl + 1 < P.n_steps) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the step's stores have reached the L2 ...
-        if (threadIdx.x == 0) {                                                  // ... before the group's next step is offered
-          const unsigned int slot = __hip_atomic_fetch_add(P.dyn_state + 16 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (slot < (unsigned int)cap) __hip_atomic_store(ring + slot, ((unsigned int)(sl + 1) << 16) | (unsigned int)grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else atomicAdd(P.counters + 3, 1ull);                                  // (more groups on this XCD than the probe promised: reported)
-        }
       }
     }
   }
@@ -282,14 +224,6 @@ __global__ __launch_bounds__(PMC_WAVE) void epmc_reset_kernel(StepParams P, Epmc
   if (i >= n) return;
   const int env = ids ? ids[i] : i;
   Epmc<GpuLanes>::reset_env(ln, P, E, env, draws ? draws + (long)i * EPMC_MAX_DRAWS : nullptr, prev_orn ? prev_orn + (long)i * 4 : nullptr);
-}
-
-// which XCD does each single-wave workgroup of a full grid land on?  (HipBackend::probe_xcds: the dynamic step schedule is only switched on
-// where the answer is the even round-robin it is built for)
-__global__ __launch_bounds__(PMC_WAVE) void xcc_probe_kernel(unsigned int* out) {
-  unsigned int id;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-  if (threadIdx.x == 0) out[blockIdx.x] = id & 15u;
 }
 
 // SEPMC (sepmc_step.hpp): one control step of ChaseTagGameEnv; row = 2 * arena + robot, the two robots of an arena are
@@ -406,34 +340,9 @@ struct HipBackend {
     const char* sh = getenv("LL_SHARE_SIMDS");
     if (sh && sh[0] == '1') simds = 0;
     stream = own;
-    probe_xcds();
-  }
-  // Dynamic step scheduling of the multi-step launches (pmc_step_kernel): on when LL_DYNAMIC_STEPS != 0 (default) AND a full grid of
-  // single-wave workgroups spreads over the device's XCDs the way the schedule assumes -- every XCD id below the reported count, each with
-  // its even share of the workgroups.  Anything else (another partition mode, an odd dispatcher) keeps the static schedule.
-  int dyn_n_xcc = 0;
-  size_t dyn_words = 0;
-  uint32_t* d_dyn = nullptr;
-  void probe_xcds() {
-    const char* sw = getenv("LL_DYNAMIC_STEPS");
-    if ((sw && sw[0] == '0') || simds <= 0) return;
-    int n_xcc = 0;
-    if (hipDeviceGetAttribute(&n_xcc, hipDeviceAttributeNumberOfXccs, device) != hipSuccess || n_xcc < 1 || n_xcc > 16 || simds % n_xcc) return;
-    dyn_words = 32 + (size_t)simds * 256;                                  // queues for launches of up to 257 control steps on a full grid
-    d_dyn = (uint32_t*)alloc(dyn_words * sizeof(uint32_t));
-    std::vector<unsigned int> ids(simds);
-    hipLaunchKernelGGL(xcc_probe_kernel, dim3(simds), dim3(PMC_WAVE), 0, stream, d_dyn);
-    if (hipGetLastError() != hipSuccess) return;
-    d2h(ids.data(), d_dyn, (size_t)simds * sizeof(uint32_t));
-    std::vector<int> count(16, 0);
-    for (int i = 0; i < simds; i++) count[ids[i] & 15u]++;
-    for (int x = 0; x < 16; x++)
-      if (count[x] != (x < n_xcc ? simds / n_xcc : 0)) return;
-    dyn_n_xcc = n_xcc;
   }
   ~HipBackend() {
     (void)hipSetDevice(device);
-    if (d_dyn) (void)hipFree(d_dyn);
     for (auto& p : evs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (own) (void)hipStreamDestroy(own);
   }
@@ -530,19 +439,6 @@ struct HipBackend {
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
     const bool one = blocks <= simds, multi = P.n_steps > 1;
-    StepParams Q;
-    if (one && multi && dyn_n_xcc > 0 && blocks % dyn_n_xcc == 0 && blocks / dyn_n_xcc < 65536 && P.n_steps < 65536 &&
-        (size_t)32 + (size_t)(P.n_steps - 1) * blocks <= dyn_words) {    // (single-step launches and the larger-batch builds keep their fixed envs)
-      HIPCHK(hipMemsetAsync(d_dyn, 0, 32 * sizeof(uint32_t), stream));                                             // heads and tails
-      HIPCHK(hipMemsetAsync(d_dyn + 32, 0xff, (size_t)(P.n_steps - 1) * blocks * sizeof(uint32_t), stream));       // empty entries
-      Q = P;
-      Q.dyn_state = d_dyn;
-      Q.dyn_n_xcc = dyn_n_xcc;
-      return launch_step_kernels(Q, blocks, one, multi, ev);
-    }
-    launch_step_kernels(P, blocks, one, multi, ev);
-  }
-  void launch_step_kernels(const StepParams& P, int blocks, bool one, bool multi, std::pair<hipEvent_t, hipEvent_t>* ev) {
     if (P.set_obstacle) {
       if (one) { if (multi) hipLaunchKernelGGL((pmc_step_kernel<1, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
                  else       hipLaunchKernelGGL((pmc_step_kernel<1, true, false>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P); }

@@ -144,8 +144,4 @@ struct StepParams {
   const float* legc;        // [LC_COUNT][4]
   const float* candc;       // [CAND_TABLE_WORDS][16]
   const float* basec;       // [BC_COUNT]
-  // dynamic step scheduling of the multi-step launch (llenv.hip pmc_step_kernel<1, ., true>; the host build never sets it): per XCD the
-  // head and tail of a ready queue, then the queues' entries.  dyn_n_xcc = 0: off.
-  uint32_t* dyn_state;      // [32 + (n_steps - 1) * groups]
-  int32_t dyn_n_xcc, dyn_pad;
 };

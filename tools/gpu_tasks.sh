@@ -49,11 +49,5 @@ case $TARGET in
     done; done > $OUT/ray_ab.txt 2>&1
     cat $OUT/ray_ab.txt
     gpu_tests -k "epmc or sepmc" ;;
-  dyn)           # dynamic step scheduling: bit-identity tests, then A/B against the static schedule on one box; SEPMC ray-variant diagnosis
-    python tools/diag_sepmc_rays.py default > $OUT/diag_sepmc_rays.txt 2>&1; cat $OUT/diag_sepmc_rays.txt
-    gpu_tests -k "multi_step or step_random or two_ranks or full_size"
-    for r in 1 2; do for d in 0 1; do echo "== LL_DYNAMIC_STEPS=$d (round $r)"; LL_DYNAMIC_STEPS=$d python tools/sweep.py "4096:4:10:10:32,4096:4:10:10:128,4096:4:10:10:8,2048:4:10:10:32"; done; done > $OUT/dyn_ab.txt 2>&1
-    cat $OUT/dyn_ab.txt
-    for d in 0 1; do LL_DYNAMIC_STEPS=$d python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | show "driver-style, LL_DYNAMIC_STEPS=$d"; done ;;
   *) echo "unknown target $TARGET"; exit 2 ;;
 esac
