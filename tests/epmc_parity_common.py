@@ -358,7 +358,7 @@ def score_case(out, B, orc, es_i, s0, act, push_trace, mu, near):
     return s
 
 
-def assert_within_bars(out, cfg_bar=1e-4, vel_bar=1e-3, factor=4.0, max_ill=0.03, max_tie=0.04):
+def assert_within_bars(out, cfg_bar=1e-4, vel_bar=1e-3, factor=4.0, max_ill=0.03, max_tie=0.04, cap_ill=None, cap_tie=None):
     """Every case within the bars of flat-ground motion (1e-4 configuration, 1e-3 relative velocity) -- unless the case is ill-conditioned in
     the ORACLE itself: a stick-slip or make-and-break contact step in which merely rounding the oracle's state to float32 between substeps
     moves its own result by more than a quarter of the bar.  Such a case (at most `max_ill` of the cases) must stay within `factor` times
@@ -371,15 +371,18 @@ def assert_within_bars(out, cfg_bar=1e-4, vel_bar=1e-3, factor=4.0, max_ill=0.03
     out['n_ill_conditioned'], out['n_on_selection_tie'] = int(ill.sum()), int(np.sum(out['on_tie']))
     # the two allowances are counted, printed and capped, so that they cannot quietly absorb a regression: ill-conditioned cases at most
     # max_ill of the cases (observed: 1 of 32 standing / 2 of 32 dropped), cases on the deepest-K rule's discontinuity at most max_tie (observed: 0 / 3 of 32)
+    # caps: what the case set was observed to need + 1 where the caller knows it (the GPU-sized sets, round 4), a fraction of the cases otherwise
+    cap_ill = cap_ill if cap_ill is not None else max(2, int(max_ill * len(ill)))
+    cap_tie = cap_tie if cap_tie is not None else max(2, int(max_tie * len(ill)))
     print('assert_within_bars: %d cases, %d ill-conditioned in the oracle itself (cap %d), %d on a selection tie (cap %d); worst config %.2e, velocity %.2e'
-          % (len(ill), ill.sum(), max(2, int(max_ill * len(ill))), out['n_on_selection_tie'], max(2, int(max_tie * len(ill))), c.max(), v.max()))
-    assert out['n_on_selection_tie'] <= max(2, int(max_tie * len(ill))), out['n_on_selection_tie']
-    assert ill.sum() <= max(2, max_ill * len(ill)), (ill.sum(), len(ill))
+          % (len(ill), ill.sum(), cap_ill, out['n_on_selection_tie'], cap_tie, c.max(), v.max()))
+    assert out['n_on_selection_tie'] <= cap_tie, out['n_on_selection_tie']
+    assert ill.sum() <= cap_ill, (ill.sum(), len(ill))
     assert (c < bar_c).all(), (np.sort(c)[-5:], cc[np.argsort(c)[-5:]])
     assert (v < bar_v).all(), (np.sort(v)[-5:], cv[np.argsort(v)[-5:]])
 
 
-def check_terrain_physics_against_oracle(lib_path, n_envs=16, seed=11, total_envs=None, max_tie=0.04):
+def check_terrain_physics_against_oracle(lib_path, n_envs=16, seed=11, total_envs=None, max_tie=0.04, cap_ill=None, cap_tie=None):
     """Robots standing on, straddling and pressed into cube steps and hurdles, with the push active: one control step of real
     physics, engine (float32) vs the float64 oracle given the same terrain records, friction and push forces.  The two share the
     spec (shape_sdf, nearest-surface normal, btPlaneSpace1 tangents) and nothing else.
@@ -429,11 +432,11 @@ def check_terrain_physics_against_oracle(lib_path, n_envs=16, seed=11, total_env
                 out['n_terrain'] += 1
         E.close()
     assert out['n_terrain'] >= 10 and out.get('n_felt', 0) >= 8, (out['n_terrain'], out.get('n_felt', 0))
-    assert_within_bars(out, max_tie=max_tie)
+    assert_within_bars(out, max_tie=max_tie, cap_ill=cap_ill, cap_tie=cap_tie)
     return out
 
 
-def check_trunk_on_edges_against_oracle(lib_path, n_envs=16, seed=5):
+def check_trunk_on_edges_against_oracle(lib_path, n_envs=16, seed=5, cap_ill=None, cap_tie=None):
     """DESIGN 8 "edges under the trunk" and the side point of a sphere on a wall: robots dropped belly-first across the edges of cube steps
     and hurdles (legs folded back so that the trunk gets there first), one control step, engine vs oracle -- and against the oracle with the
     reverse candidates switched off, to show that the cases are what they claim to be."""
@@ -484,7 +487,7 @@ def check_trunk_on_edges_against_oracle(lib_path, n_envs=16, seed=5):
                 out['n_edge_felt'] += 1
         E.close()
     assert out['n_edge_felt'] >= 8, out['n_edge_felt']
-    assert_within_bars(out, max_ill=0.07, max_tie=0.12)         # (bodies dropped flat onto edges: more make-and-break steps and more equal depths than among standing robots)
+    assert_within_bars(out, max_ill=0.07, max_tie=0.12, cap_ill=cap_ill, cap_tie=cap_tie)         # (bodies dropped flat onto edges: more make-and-break steps and more equal depths than among standing robots)
     return out
 
 

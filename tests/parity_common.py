@@ -210,7 +210,7 @@ def bars_with_conditioning(st, label, vel_hi=10 * PHYS_STEP_TOL):
 def check_single_step_parity(golden, orc, model_blob, table, lib_path, n_envs=32, n_steps=12, seed=7, total_envs=None, spec=None):
     st = run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True, total_envs=total_envs, spec=spec)
     assert len(st['config']) > n_envs * n_steps * 0.5
-    assert st['on_tie'] <= max(1, len(st['config']) // 200), st['on_tie']          # samples on the selection rule's discontinuity: counted, capped
+    assert st['on_tie'] <= max(2, len(st['config']) // 500), st['on_tie']          # samples on the selection rule's discontinuity: counted, capped (observed: 0 - 1 per run)
     # EVERY sample: configuration within 1e-4, velocities within 1e-3 of (1 + the env's largest joint rate); and at most 1 % of the env-steps
     # above 1e-4 in velocity (float32 rounding through a contact that switches on or off inside the step; 0.4 % measured)
     bars_with_conditioning(st, 'single control step')
@@ -235,8 +235,8 @@ def check_policy_driven_parity(golden, orc, model_blob, table, lib_path, n_envs=
     from oracle.pmc_policy import PmcPolicy
     st = run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed, resync=True, policy=PmcPolicy(POLICY_WEIGHTS))
     assert len(st['config']) > n_envs * n_steps * 0.7                                # the policy keeps most episodes alive
-    print('policy-driven parity: %d samples, %d on a selection tie (cap %d)' % (len(st['config']), st['on_tie'], max(1, len(st['config']) // 200)))
-    assert st['on_tie'] <= max(1, len(st['config']) // 200), st['on_tie']
+    print('policy-driven parity: %d samples, %d on a selection tie (cap %d)' % (len(st['config']), st['on_tie'], max(2, len(st['config']) // 500)))
+    assert st['on_tie'] <= max(2, len(st['config']) // 500), st['on_tie']
     bars_with_conditioning(st, 'policy-driven parity')
     v = np.asarray(st['vel']).reshape(-1)
     # every sample within 1e-3 relative (bars_with_conditioning); a gait's joint rates are a few rad/s, so the same absolute error weighs more

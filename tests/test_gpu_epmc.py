@@ -42,14 +42,14 @@ def test_env_api_contract_gpu():
 
 
 def test_terrain_physics_against_oracle():
-    out = ec.check_terrain_physics_against_oracle(None, n_envs=48)
+    out = ec.check_terrain_physics_against_oracle(None, n_envs=48, cap_ill=1, cap_tie=2)        # observed on MI355X (round 4, 96 cases): 0 / 1
     assert out['n_terrain'] >= 30 and out['n_felt'] >= 20
 
 
 def test_larger_batch_build_against_the_oracle():
     """epmc_step_kernel<2> (batches above 4096 envs) against the float64 oracle DIRECTLY: terrain physics cases spread over the first, middle
     and last wavefronts of a 4096 + 256 env grid, the bars of the occupancy-1 build."""
-    out = ec.check_terrain_physics_against_oracle(None, n_envs=48, total_envs=4096 + 256, max_tie=0.08)     # (this case set: 6 of 96 on a tie -- a property of the cases, decided by the oracle)
+    out = ec.check_terrain_physics_against_oracle(None, n_envs=48, total_envs=4096 + 256, cap_ill=2, cap_tie=7)     # (observed: 1 / 6 of 96 -- properties of the case set, decided by the oracle)
     print('occupancy-2 EPMC vs oracle: %d cases, ill-conditioned %d, on a selection tie %d' % (len(out['config']), out['n_ill_conditioned'], out['n_on_selection_tie']))
     assert out['n_terrain'] >= 30 and out['n_felt'] >= 20
 
@@ -65,7 +65,7 @@ def test_multi_step_launch():
 
 
 def test_trunk_on_edges_against_oracle():
-    out = ec.check_trunk_on_edges_against_oracle(None, n_envs=48)
+    out = ec.check_trunk_on_edges_against_oracle(None, n_envs=48, cap_ill=7, cap_tie=9)         # observed (96 cases): 6 / 8
     assert out['n_edge_felt'] >= 24
 
 

@@ -133,7 +133,7 @@ def test_both_register_budgets_compute_the_same(golden, orc, model_blob, mocap_t
         B.set_state(sb_all)
     print('register budgets: worst config %.2e, velocity %.2e outside of %d samples examined with the oracle: %s' % (worst_c, worst_v, len(ill), ill))
     assert worst_c < 1e-4 and worst_v < 1e-3, (worst_c, worst_v)
-    assert len(ill) <= 3, ill                                                   # of 96 x 40 samples (about 1 in 3000 under random actions)
+    assert len(ill) <= 2, ill                                                   # of 96 x 40 samples (about 1 in 3000 under random actions; observed on MI355X: 1)
     for (ce, ve, cc, cv) in ill:
         assert ce <= max(1e-4, pc.ILL_FACTOR * cc) and ve <= max(1e-3, pc.ILL_FACTOR * cv), ('between the builds', ce, ve, 'oracle self-deviation', cc, cv)
     assert n_reason <= 1 + len(ill), n_reason                                   # (a threshold test may fall either way once)

@@ -129,5 +129,5 @@ def test_both_register_budgets_compute_the_same_gpu():
           (len(c), np.median(c), out.sum(), c.max(), v.max()))
     # (round 4, AABB link inertias: 9 of 1920 outside, worst 6.4e-3 / 1.39 -- a 170 g shank at its joint limit takes or leaves the limit row at
     # LLM_LIMIT_GATE = 20 rad/s: the one decision in the spec that can move a joint rate by tens of rad/s)
-    assert out.sum() <= 12 and c.max() < 1e-2 and v.max() < 2.0, (out.sum(), c.max(), v.max())
+    assert out.sum() <= 10 and c.max() < 1e-2 and v.max() < 2.0, (out.sum(), c.max(), v.max())          # (observed + 1)
     A.close(); B.close()
