@@ -483,7 +483,7 @@ def main_epmc(args):
             'config': {'workload': 'EPMC PlayGround env (BASELINE config 4), %d envs per MI355X, element_id %d, 778 rays per env-step, push forces, '
                                    'random-policy actions N(0, e^-2), auto-reset' % (n, args.element), 'envs_per_gpu': n, 'steps_per_launch': spl, 'episodes_finished_rank0': eng.counters()['episodes']},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                         'traffic_source': tsrc, 'single_wave_issue': issue,
+                         'traffic_source': tsrc, 'traffic_note': 'counter traffic of a multi-step launch UNDER-counts HBM bytes: the rows a wave writes in one step of the launch and overwrites in the next (observation, state, bookkeeping) meet in its L2 / the Infinity Cache and need not reach HBM, so FETCH_SIZE + WRITE_SIZE can come out below the algorithmic bytes (0.8 - 0.9 x); single launches per step measure 1.1 - 1.5 x', 'single_wave_issue': issue,
                          'kernel': 'epmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n, 'kernel_avg_launch_ms': k_launch_ms,
                          'algorithmic_bytes_per_env_step': EPMC_ALGO_BYTES_PER_ENV_STEP,
                          'note': 'bound by single-wave instruction issue, not HBM; see DESIGN.md 8'}}}), flush=True)
@@ -567,7 +567,7 @@ def main_sepmc(args):
                                    'arena-step, two-robot push schedule, robot-robot contact, random-policy actions N(0, e^-2), auto-reset' % n_arenas,
                        'arenas_per_gpu': n_arenas, 'steps_per_launch': spl, 'episodes_finished_rank0': eng.counters()['episodes']},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                         'traffic_source': tsrc, 'single_wave_issue': issue,
+                         'traffic_source': tsrc, 'traffic_note': 'counter traffic of a multi-step launch UNDER-counts HBM bytes: the rows a wave writes in one step of the launch and overwrites in the next (observation, state, bookkeeping) meet in its L2 / the Infinity Cache and need not reach HBM, so FETCH_SIZE + WRITE_SIZE can come out below the algorithmic bytes (0.8 - 0.9 x); single launches per step measure 1.1 - 1.5 x', 'single_wave_issue': issue,
                          'kernel': 'sepmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n, 'kernel_avg_launch_ms': k_launch_ms,
                          'algorithmic_bytes_per_robot_step': SEPMC_ALGO_BYTES_PER_ROBOT_STEP,
                          'note': 'bound by single-wave instruction issue, not HBM; see DESIGN.md 8b'}}}), flush=True)

@@ -55,9 +55,12 @@ for KERNEL, prefix, benchlog in (('pmc_step_kernel', '', 'bench.log'), ('epmc_st
         continue
     for sub in ('pmc_sq', 'pmc_fetch', 'pmc_write'):
         acc, n = {}, {}
-        for row in csv.DictReader(open(one(prefix + sub + '/**/*counter_collection.csv'))):
-            if not re.search(r'(^|[^a-z])' + KERNEL, row['Kernel_Name']):
-                continue
+        rows = [r for r in csv.DictReader(open(one(prefix + sub + '/**/*counter_collection.csv'))) if re.search(r'(^|[^a-z])' + KERNEL, r['Kernel_Name'])]
+        # the command runs the contract region as multi-step launches (template argument MULTI = true) and, since round 4, a short
+        # one-launch-per-step leg beside it: the counters are those of the contract region's kernel
+        if any(', true>' in r['Kernel_Name'] for r in rows):
+            rows = [r for r in rows if ', true>' in r['Kernel_Name']]
+        for row in rows:
             k = row['Counter_Name']
             acc[k] = acc.get(k, 0.0) + float(row['Counter_Value']); n[k] = n.get(k, 0) + 1
             meta = {'kernel_name': row['Kernel_Name'], 'grid': row['Grid_Size'], 'wg': row['Workgroup_Size'],
@@ -94,7 +97,7 @@ for KERNEL, prefix, benchlog in (('pmc_step_kernel', '', 'bench.log'), ('epmc_st
                            'counters_file': 'profiles/%s_%s_counters.json' % (tag, KERNEL)}
     statsf = os.path.join(dst, '%s_%skernel_stats.csv' % (tag, prefix))
     for row in csv.DictReader(open(statsf)):
-        if re.search(r'(^|[^a-z])' + KERNEL, row['Name']):
+        if re.search(r'(^|[^a-z])' + KERNEL, row['Name']) and (spl == 1 or ', true>' in row['Name']):
             print('rocprofv3: %s  calls %s  avg %.1f us per launch = %.2f us per control step  | bench HIP events: %.2f us per control step' % (
                 row['Name'], row['Calls'], float(row['AverageNs']) / 1e3, float(row['AverageNs']) / 1e3 / spl, rl['kernel_avg_ms'] * 1e3))
     print('  traffic %.2f MB per launch (algorithmic %.2f MB); %.0f instructions on %.0f issue slots per wave per control step; value %.3g %s' % (
