@@ -53,6 +53,9 @@ typedef GpuLanesPinned<LC_COUNT> GpuLanes1;                   // the per-leg tab
 #ifndef LL_RELOAD_EPMC2
 #define LL_RELOAD_EPMC2 1
 #endif
+#ifndef LL_SEPMC_RAY_CHUNK
+#define LL_SEPMC_RAY_CHUNK 3      // rays per chunk in the one-wave-per-SIMD SEPMC kernels (lanes.hpp WithRayChunk; 7 fails on the GPU: tools/diag_sepmc_rays.py)
+#endif
 #ifndef LL_RELOAD_SEPMC2
 #define LL_RELOAD_SEPMC2 1      // (with the episode scalars parked in LDS the re-read pays here too: 32768 arenas 14.8 -> 16.0 M robot-steps/s)
 #endif
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P,
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int row0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
   typedef typename std::conditional<OCC == 1 && LL_PIN_SEPMC, GpuLanes1, GpuLanes>::type PlainLanes;
-  typedef WithRayChunk<WithShapePrefetch<typename std::conditional<(OCC == 2 && LL_RELOAD_SEPMC2), WithParamsReload<PlainLanes, LL_RELOAD_SEPMC2>, PlainLanes>::type, OCC == 1>, (OCC == 1 ? 3 : 1)> Lanes;   // (chunk 7 fails the arena invariants on the GPU in this kernel -- at 256 + 255 registers; 3 is what was validated: profiles/r04_ray_ab.txt)
+  typedef WithRayChunk<WithShapePrefetch<typename std::conditional<(OCC == 2 && LL_RELOAD_SEPMC2), WithParamsReload<PlainLanes, LL_RELOAD_SEPMC2>, PlainLanes>::type, OCC == 1>, (OCC == 1 ? LL_SEPMC_RAY_CHUNK : 1)> Lanes;   // (chunk 7 fails the arena invariants on the GPU in this kernel -- at 256 + 255 registers; 3 is what was validated: profiles/r04_ray_ab.txt)
   Lanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
   if (row0 >= P.n_envs) return;
