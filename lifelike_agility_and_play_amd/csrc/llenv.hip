@@ -143,7 +143,8 @@ __device__ __forceinline__ void step_actions(const StepParams& P, const Lanes& l
 // chip one wavefront per SIMD, 2 (256 registers) for larger batches, where a second resident wavefront hides issue stalls.
 // OBST = the set_obstacle build (Pmc::step_env<true>): the jump obstacle takes part in the substeps as a static box.
 // MULTI = the launch may run several control steps (ll_step_random_n); single-step launches run the loop-free build.
-template <int OCC, bool OBST = false, bool MULTI = false>
+// CONE = the cone-coupled friction solve (LLM_SPEC_FRICTION_MODE = 2, flat-terrain builds): an option, its own instantiations.
+template <int OCC, bool OBST = false, bool MULTI = false, bool CONE = false>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);      // one env = one 16-lane DPP row
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
     if (env0 < P.n_envs) {
       float act[3];
       step_actions(P, ln, lds, env0, 0, act);
-      Pmc<Lanes>::template step_env<OBST>(ln, P, env0, act, 0);
+      Pmc<Lanes>::template step_env<OBST, CONE>(ln, P, env0, act, 0);
     }
   } else {
     // ll_step_random_n: n_steps control steps back to back.  A wave walks its four envs through them on its own -- no other wave is waited
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
       if (env < P.n_envs) {
         float act[3];
         step_actions(P, ln, lds, env, sl, act);
-        Pmc<Lanes>::template step_env<OBST>(ln, P, env, act, sl);
+        Pmc<Lanes>::template step_env<OBST, CONE>(ln, P, env, act, sl);
       }
     }
   }
@@ -447,6 +448,11 @@ struct HipBackend {
                  else       hipLaunchKernelGGL((pmc_step_kernel<1, true, false>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P); }
       else     { if (multi) hipLaunchKernelGGL((pmc_step_kernel<2, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
                  else       hipLaunchKernelGGL((pmc_step_kernel<2, true, false>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P); }
+    } else if (P.friction_mode == 2) {
+      if (one) { if (multi) hipLaunchKernelGGL((pmc_step_kernel<1, false, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
+                 else       hipLaunchKernelGGL((pmc_step_kernel<1, false, false, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P); }
+      else     { if (multi) hipLaunchKernelGGL((pmc_step_kernel<2, false, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
+                 else       hipLaunchKernelGGL((pmc_step_kernel<2, false, false, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P); }
     } else {
       if (one) { if (multi) hipLaunchKernelGGL((pmc_step_kernel<1, false, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
                  else       hipLaunchKernelGGL((pmc_step_kernel<1, false, false>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P); }

@@ -315,6 +315,67 @@ struct Pmc {
     permute4(ln, jt[0], jt[1], jt[2], zero, t);
     r.cj01 = L::pair(t[0], t[1]); r.cj23 = L::pair(t[2], t[3]);
   }
+  // ---- cone-coupled friction (LLM_SPEC_FRICTION_MODE = 2: the published default of btMultiBodyConstraintSolver, resolveConeFrictionConstraintRows;
+  //      an OPTION of the PMC kernels since round 4 -- DESIGN.md 4 says why the pyramid stays the default).  The two friction rows of a contact are
+  //      solved TOGETHER: both increments from the same velocity, the pair scaled back onto |(t1, t2)| <= mu N, both applied.  Besides the Gram
+  //      scalars of each row kind (Row::nk) that takes the CROSS scalars between the t1 and t2 rows of different lanes:
+  struct ConeX {
+    F n12[16];               // -(gt1 . gt2_L + [same leg] jt1 . jt2_L) * inv1 : what lane L's t2 increment does to my t1 row's pending increment
+    F n21[16];               // -(gt2 . gt1_L + [same leg] jt2 . jt1_L) * inv2
+  };
+  // out[L] = -(gt_mine . gt_oth(lane L) + [same leg] jt_mine . jt_oth(lane L)) * inv_mine   (finish_row's scalars, between two row kinds)
+  static LL_HD void cross_gram(const L& ln, const F& inv_mine, const F* gt_mine, const F* jt_mine, const F* gt_oth, const F* jt_oth, F* out) {
+    F zero = ln.lane_f(0.0f);
+    F ninv = zero - inv_mine;
+    F yg[6], yj[3];
+    for (int i = 0; i < 6; i++) yg[i] = gt_mine[i] * ninv;
+    for (int i = 0; i < 3; i++) yj[i] = jt_mine[i] * ninv;
+    F nj[4];
+    nj[0] = yj[0] * L::template subbcast<0>(jt_oth[0]) + yj[1] * L::template subbcast<0>(jt_oth[1]) + yj[2] * L::template subbcast<0>(jt_oth[2]);
+    nj[1] = yj[0] * L::template subbcast<1>(jt_oth[0]) + yj[1] * L::template subbcast<1>(jt_oth[1]) + yj[2] * L::template subbcast<1>(jt_oth[2]);
+    nj[2] = yj[0] * L::template subbcast<2>(jt_oth[0]) + yj[1] * L::template subbcast<2>(jt_oth[1]) + yj[2] * L::template subbcast<2>(jt_oth[2]);
+    nj[3] = yj[0] * L::template subbcast<3>(jt_oth[0]) + yj[1] * L::template subbcast<3>(jt_oth[1]) + yj[2] * L::template subbcast<3>(jt_oth[2]);
+    for (int L_ = 0; L_ < 16; L_++) out[L_] = lm::sel(ln.is_leg(L_ >> 2), nj[L_ & 3], zero);
+    L::template gram4<0>(gt_oth, yg, out);
+    L::template gram4<1>(gt_oth, yg, out);
+    L::template gram4<2>(gt_oth, yg, out);
+    L::template gram4<3>(gt_oth, yg, out);
+  }
+  // the turn of lane L_ (slot-major like every round): every lane forms what ITS pair would commit, lane L_'s is the one that counts
+  template <int L_>
+  static LL_HD void cone_turn(const L& ln, const Row& r1, const Row& r2, const ConeX& cx, const F& lim, F& u1, F& u2, F& d1, F& d2) {
+    F zero = ln.lane_f(0.0f);
+    F s1 = r1.lam + u1, s2 = r2.lam + u2;
+    F len2 = s1 * s1 + s2 * s2;
+    B over = len2 > lim * lim;
+    F sc = lm::sel(lim > 0.0f, lim * lm::rsqrt_(lm::max_(len2, ln.lane_f(1.0e-30f))), zero);
+    s1 = lm::sel(over, s1 * sc, s1); s2 = lm::sel(over, s2 * sc, s2);
+    F e1 = s1 - r1.lam, e2 = s2 - r2.lam;
+    B me = ln.is_lane(L_);
+    d1 = lm::sel(me, e1, d1); d2 = lm::sel(me, e2, d2);
+    L::template fmac_rbcast<L_>(u1, e1, r1.nk[L_]);
+    L::template fmac_rbcast<L_>(u1, e2, cx.n12[L_]);
+    L::template fmac_rbcast<L_>(u2, e1, cx.n21[L_]);
+    L::template fmac_rbcast<L_>(u2, e2, r2.nk[L_]);
+  }
+  static LL_HD void gs_cone_round(const L& ln, Row& r1, Row& r2, const ConeX& cx, const F& lim, F& VA, F& VB, F& VJ) {
+    F zero = ln.lane_f(0.0f);
+    F w1 = L::vel_dot(r1.c, r1.ca01, r1.ca23, r1.cb01, r1.cj01, r1.cj23, VA, VB, VJ);
+    F w2 = L::vel_dot(r2.c, r2.ca01, r2.ca23, r2.cb01, r2.cj01, r2.cj23, VA, VB, VJ);
+    F u1 = (zero - w1) * r1.inv, u2 = (zero - w2) * r2.inv;
+    F d1 = zero, d2 = zero;
+    cone_turn<0>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<4>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
+    cone_turn<8>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<12>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
+    cone_turn<1>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<5>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
+    cone_turn<9>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<13>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
+    cone_turn<2>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<6>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
+    cone_turn<10>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<14>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
+    cone_turn<3>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<7>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
+    cone_turn<11>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<15>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
+    L::vel_commit(d1, r1.lam, r1.ca01, r1.ca23, r1.cb01, r1.cj01, r1.cj23, VA, VB, VJ);      // (also lam += d)
+    L::vel_commit(d2, r2.lam, r2.ca01, r2.ca23, r2.cb01, r2.cj01, r2.cj23, VA, VB, VJ);
+  }
+
   template <int K_>
   static LL_HD void pick_rank(const L& ln, const F& rank, const F& me, const F& d, const F& sb, const F& jj, F& nd, F& ns, F& nj) {
     B take = lm::abs_(L::template subbcast<K_>(rank) - me) < 0.5f;
@@ -604,6 +665,11 @@ struct Pmc {
   static LL_HD void contact_row(const L& ln, Row& rw, const V3l& uu, const V3l& Pb, const V3l& d1, const V3l& d2, const V3l& d3, const LegFactor& lf,
                                 const float* Sb, const float* Sd, const float* xi, const F* qs, const F& bias, const B& cvalid) {
     F gt[6], jt[3];
+    contact_row(ln, rw, uu, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, bias, cvalid, gt, jt);
+  }
+  // ... leaving the whitened coefficients gt[6], jt[3] with the caller (the cone-coupled friction solve forms cross Gram scalars from them)
+  static LL_HD void contact_row(const L& ln, Row& rw, const V3l& uu, const V3l& Pb, const V3l& d1, const V3l& d2, const V3l& d3, const LegFactor& lf,
+                                const float* Sb, const float* Sd, const float* xi, const F* qs, const F& bias, const B& cvalid, F* gt, F* jt) {
     jt[0] = dot(uu, d1); jt[1] = dot(uu, d2); jt[2] = dot(uu, d3);
     V3l pxu = cross(Pb, uu);
     // free row velocity J_b xi + J_l qd*
@@ -648,7 +714,7 @@ struct Pmc {
   }
   // TERRAIN: contact candidates are also tested against ex->shapes, and a contact's normal is that of the shape it touches
   // PAIR: contacts with the other robot of a SEPMC arena (the neighbouring row) are found and solved too
-  template <bool TERRAIN, bool PAIR = false>
+  template <bool TERRAIN, bool PAIR = false, bool CONE = false>
   static LL_HD void substep_impl(const L& ln, const StepParams& P_in, Base& bs, F* q, F* qd, const F* tgt, int env, int sidx, const SubstepExtra* ex,
                                  const LinkC* held) {   // held: the own-link constants if the caller keeps them in registers, or null
 #define PMC_TSS(k) do { if (sidx == 5) PMC_TS(k); } while (0)
@@ -971,6 +1037,7 @@ struct Pmc {
     PMC_TSS(24);
     // --- rows -------------------------------------------------------------------------------------------------------------------
     Row rl, rn, r1, r2;
+    ConeX cx;                          // (CONE builds only; otherwise never touched and never allocated)
     F mu = zero;
     {   // joint-limit row of joint j = sub (sub-lane 3 holds none)
       B has = sub_lt3;
@@ -1103,8 +1170,16 @@ struct Pmc {
       }
       // rows n = +z, t1 = -y, t2 = +x (world), expressed in F0
       contact_row(ln, rn, un, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, bias, cvalid);
-      contact_row(ln, r1, ut1, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid);
-      contact_row(ln, r2, ut2, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid);
+      if (CONE) {
+        F g1[6], j1[3], g2[6], j2[3];
+        contact_row(ln, r1, ut1, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid, g1, j1);
+        contact_row(ln, r2, ut2, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid, g2, j2);
+        cross_gram(ln, r1.inv, g1, j1, g2, j2, cx.n12);
+        cross_gram(ln, r2.inv, g2, j2, g1, j1, cx.n21);
+      } else {
+        contact_row(ln, r1, ut1, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid);
+        contact_row(ln, r2, ut2, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid);
+      }
     }
 
     // --- self-collision (LR:212-217: links of different legs): each leg is two capsules, the closest pairs within the
@@ -1409,8 +1484,12 @@ struct Pmc {
       if (any_contact) {
         gs_round<false, true>(ln, rn, big, VA, VB, VJ);
         F hi = mu * rn.lam;
-        gs_round<false, false>(ln, r1, hi, VA, VB, VJ);
-        gs_round<false, false>(ln, r2, hi, VA, VB, VJ);
+        if (CONE) {
+          gs_cone_round(ln, r1, r2, cx, hi, VA, VB, VJ);
+        } else {
+          gs_round<false, false>(ln, r1, hi, VA, VB, VJ);
+          gs_round<false, false>(ln, r2, hi, VA, VB, VJ);
+        }
       }
       if (any_self) {                                                        // then the self-collision rows, one after the other
         self_turn(ln, sr[0], VA, VB, VJ);
@@ -1733,7 +1812,7 @@ struct Pmc {
   // act_in: the env's actions, one register per joint of the lane's leg (read from P.actions or drawn by the caller)
   // OBST (set_obstacle builds): the jump obstacle of the episode is a static box the robot collides with during the substeps
   // sl: index of this control step inside its launch (ll_step_random_n runs n_steps of them back to back; 0 otherwise)
-  template <bool OBST = false>
+  template <bool OBST = false, bool CONE = false>
   static LL_HD void step_env(const L& ln, const StepParams& P_in, int env, const F* act_in, int sl = 0) {
     const StepParams& P = ln.params(P_in);
     const int N = P.n_envs;
@@ -1775,7 +1854,7 @@ struct Pmc {
     if (L::kHoldLink) { lkh = own_link_held(ln, P.legc); held = &lkh; }
     for (int s = 0; s < P.n_sub; s++) {                                      // PLE:202
       if (OBST) substep_impl<true>(ln, P, bs, q, qd, tgt, env, s, &ex, held);
-      else substep_impl<false>(ln, P, bs, q, qd, tgt, env, s, nullptr, held);   // PLE:204-206
+      else substep_impl<false, false, CONE>(ln, P, bs, q, qd, tgt, env, s, nullptr, held);   // PLE:204-206
       t_loc = t;                                                             // PLE:208 motion.step(time BEFORE the increment), quirk Q2
       t += P.dt_d;                                                           // PLE:210
     PMC_TS(10 + (s < 20 ? s : 20));

@@ -313,7 +313,11 @@ inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
     case LLM_SPEC_FRICTION_DIRS:
       if (!(v == 0.0 || v == 1.0)) return "friction_dirs must be 0 or 1";
       P.friction_dirs = (int)v; break;
-    case LLM_SPEC_FRICTION_MODE: case LLM_SPEC_ROW_ORDER: case LLM_SPEC_MAX_COORD_VEL: case LLM_SPEC_LIMIT_ERP: case LLM_SPEC_PAIR_FRICTION:
+    case LLM_SPEC_FRICTION_MODE:
+      if (!(v == 0.0 || v == 2.0)) return "friction_mode: the engine has 0 (pyramid, the spec) and 2 (cone-coupled, btMultiBodyConstraintSolver's published default); 1 and 3 exist in the oracle only";
+      if (v == 2.0 && P.set_obstacle) return "cone-coupled friction is built for the flat-terrain PMC kernels (set_obstacle = False)";
+      P.friction_mode = (int)v; break;
+    case LLM_SPEC_ROW_ORDER: case LLM_SPEC_MAX_COORD_VEL: case LLM_SPEC_LIMIT_ERP: case LLM_SPEC_PAIR_FRICTION:
     case LLM_SPEC_MAX_PAIR: case LLM_SPEC_LIMIT_SPECULATIVE: case LLM_SPEC_GYRO:
       if ((id == LLM_SPEC_LIMIT_SPECULATIVE || id == LLM_SPEC_GYRO) && v == 1.0) break;
       return "this switch exists in the oracle only (round-3 audit against Bullet's published solver: profiles/r03_deviation_table.md)";
@@ -335,6 +339,7 @@ inline double pmc_get_spec_param(const StepParams& P, int id) {
     case LLM_SPEC_TRUNK_EDGES: return 1.0;
     case LLM_SPEC_SELECT_EPS: return LLM_SELECT_EPS;
     case LLM_SPEC_FRICTION_DIRS: return P.friction_dirs;
+    case LLM_SPEC_FRICTION_MODE: return P.friction_mode;
     case LLM_SPEC_MAX_COORD_VEL: return 1e30;
     case LLM_SPEC_LIMIT_ERP: return -1.0;
     case LLM_SPEC_MAX_PAIR: return 2.0;

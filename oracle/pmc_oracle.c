@@ -1223,7 +1223,7 @@ static void sweep_rows(ORows* W) {
   const double vmax = g_spec[LLM_SPEC_MAX_COORD_VEL];
   for (int oi = 0; oi < W->no; oi++) {
     const int r = W->order[oi];
-    if (W->cone && r < W->first_self && W->fric_of[r] == r - 1 && oi + 1 < W->no && W->order[oi + 1] == r + 1) {
+    if (W->cone && r < W->first_self && W->fric_of[r] >= 0 && W->fric_of[r] == r - 1 && oi + 1 < W->no && W->order[oi + 1] == r + 1) {
       /* btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows as published: both increments from the SAME velocity, the pair
        * scaled back onto the cone |(t1, t2)| <= mu * (normal multiplier), then both applied */
       const int r2 = r + 1, rn = W->fric_of[r];

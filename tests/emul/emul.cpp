@@ -36,6 +36,7 @@ struct HostBackend {
         fN act[3];
         for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
         if (P.set_obstacle) K::step_env<true>(ln, P, env, act, sl);
+        else if (P.friction_mode == 2) K::step_env<false, true>(ln, P, env, act, sl);
         else K::step_env<false>(ln, P, env, act, sl);
       }
     }

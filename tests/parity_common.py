@@ -138,16 +138,16 @@ def run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed
             os_ = B.get_state(i)
             err = np.abs(quat_align(es[e].astype(np.float64), os_) - os_)
             vscale = 1.0 + np.abs(os_[25:37]).max()
-            if sel < TIE_ZONE and not spec and max(err[0:7].max(), err[13:25].max(), err[7:13].max() / vscale, err[25:37].max() / vscale) > PHYS_STEP_TOL:
+            if sel < TIE_ZONE and max(err[0:7].max(), err[13:25].max(), err[7:13].max() / vscale, err[25:37].max() / vscale) > PHYS_STEP_TOL:
                 # A contact point's depth or a capsule pair's distance came within float32 resolution of (deepest + LLM_SELECT_EPS), where the
                 # deepest-K pick changes hands: float32 and float64 may legitimately keep different rows.  The engine must then
                 # agree with the oracle for SOME tie tolerance within +-2 TIE_ZONE of the nominal one; such samples are counted and capped.
                 stats['on_tie'] += 1
                 adopted = False
                 for d in (-2.0 * TIE_ZONE, 2.0 * TIE_ZONE):
-                    orc.reset_spec(); orc.set_spec(select_eps=capi.LL_SELECT_EPS + d)
+                    orc.reset_spec(); orc.set_spec(select_eps=capi.LL_SELECT_EPS + d, **(spec or {}))
                     B2.reset_env(0, int(clip[e]), float(t0[e])); B2.set_state(0, pre); B2.step_env(0, act[e].astype(np.float64))
-                    orc.reset_spec()
+                    orc.reset_spec(); orc.set_spec(**(spec or {}))
                     o2 = B2.get_state(0)
                     e2 = np.abs(quat_align(es[e].astype(np.float64), o2) - o2)
                     if e2[25:37].max() < err[25:37].max():
@@ -155,7 +155,7 @@ def run_lockstep(golden, orc, model_blob, table, lib_path, n_envs, n_steps, seed
             else:
                 adopted = False
             ce, ve = max(err[0:7].max(), err[13:25].max()), max(err[7:13].max(), err[25:37].max()) / vscale
-            if resync and not spec and (ce > PHYS_STEP_TOL or ve > 10 * PHYS_STEP_TOL):
+            if resync and (ce > PHYS_STEP_TOL or ve > 10 * PHYS_STEP_TOL):
                 # outside the bars: is the step ill-conditioned in the oracle itself?  (counted, printed, capped by the callers)
                 cc, cv, base = oracle_self_deviation(B2, pre, act[e], kd=kd_, max_tau=max_tau_)
                 assert np.abs(quat_align(base, os_) - os_).max() < 1e-9 or adopted, 'oracle_self_deviation does not restate step_env'
@@ -465,7 +465,7 @@ def check_trajectory_ring(model_blob, table, lib_path, read_ring, write_dev=None
     assert list(g['shapes']) == [72, 99, 36, 12]
 
 
-def check_multi_step_launch(model_blob, table, lib_path, read_ring, sizes=(24,), k=7, n_launches=5):
+def check_multi_step_launch(model_blob, table, lib_path, read_ring, sizes=(24,), k=7, n_launches=5, spec=None):
     """ll_step_random_n(sigma, k) == k x ll_step_random(sigma), bit for bit -- state, ghost, observation, reward, done reasons, bookkeeping,
     counters, episode histogram, the recorded actions and every row of the unroll buffers -- in the two settings in which the one stated
     difference (the sampling table is folded once per launch) cannot show: uniform sampling with auto-reset (factor 0: the table never
@@ -476,6 +476,8 @@ def check_multi_step_launch(model_blob, table, lib_path, read_ring, sizes=(24,),
         for kw in (dict(auto_reset=1, prioritized_sample_factor=0.0), dict(auto_reset=0, prioritized_sample_factor=3.0)):
             A = make_engine(model_blob, table, n, lib_path, seed=31, **kw)
             B = make_engine(model_blob, table, n, lib_path, seed=31, **kw)
+            if spec:                                                 # (a kernel option with its own builds: LLM_SPEC_FRICTION_MODE = 2)
+                A.set_spec(**spec); B.set_spec(**spec)
             A.reset(); B.reset()
             for _ in range(3):                                       # unrolls start wherever they are enabled (not at step 0)
                 A.step_random(SIGMA); B.step_random(SIGMA)
@@ -503,6 +505,8 @@ def check_multi_step_launch(model_blob, table, lib_path, read_ring, sizes=(24,),
             A.close(); B.close()
         # both on: the launch-granular table.  Same number of env-steps, everything finite, episodes keep ending and re-seeding
         C = make_engine(model_blob, table, n, lib_path, seed=32, auto_reset=1, prioritized_sample_factor=3.0)
+        if spec:
+            C.set_spec(**spec)
         C.reset()
         for _ in range(n_launches):
             C.step_random_n(SIGMA, 4 * k)

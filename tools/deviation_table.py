@@ -45,7 +45,7 @@ VARIANTS = [
     ('warm start 0.85', dict(warm_start=0.85), 'ORACLE ONLY: multipliers of persisting rows carried over x 0.85'),
     # round 3: audit against the published order of operations of btMultiBodyConstraintSolver / btMultiBody (oracle switches)
     ('friction rows adjacent', dict(friction_mode=1), 'ORACLE ONLY: after all normal rows, (t1, t2) of each contact adjacent instead of all t1 then all t2'),
-    ('friction cone-coupled', dict(friction_mode=2), 'ORACLE ONLY: (t1, t2) of a contact solved together from one velocity and clipped to the cone (resolveConeFrictionConstraintRows)'),
+    ('friction cone-coupled', dict(friction_mode=2), 'engine option since round 4 (Pmc::gs_cone_round): (t1, t2) of a contact solved together from one velocity and clipped to the cone (resolveConeFrictionConstraintRows)'),
     ('manifold row order', dict(row_order=1), 'ORACLE ONLY: contacts ordered per body pair (link index, candidate) instead of slot-major'),
     ('cone + manifold order', dict(friction_mode=2, row_order=1), 'ORACLE ONLY: both of the above: the closest restatement of the published solver loop'),
     ('max coordinate velocity 100', dict(max_coord_vel=100.0), 'ORACLE ONLY: btMultiBody::m_maxCoordinateVelocity clip of all 18 generalized velocities'),
@@ -57,6 +57,11 @@ VARIANTS = [
     ('sliding direction + cone + order', dict(friction_dirs=1, friction_mode=2, row_order=1), 'ORACLE ONLY: velocity-aligned directions, cone-coupled, manifold order'),
 ]
 ORACLE_ONLY = ('self_friction', 'warm_start', 'friction_mode', 'row_order', 'max_coord_vel', 'limit_erp', 'limit_speculative')
+
+
+def engine_has(over):
+    """the engine carries a switch unless it is oracle-only; of the friction modes it has the pyramid (0) and the cone-coupled solve (2)"""
+    return not any(k in over and not (k == 'friction_mode' and over[k] in (0, 2)) for k in ORACLE_ONLY)
 
 
 def starts(table, n, seed):
@@ -154,12 +159,12 @@ def main():
         if args.only and args.only not in label:
             continue
         cells = []
-        if args.engine and not any(k in over for k in ORACLE_ONLY):
+        if args.engine and engine_has(over):
             t = time.time(); e = run_engine(pol, blob, table, args.engine_episodes, over, 11)
             cells += ['%.4f' % e['reward'], '%.3f' % e['tracked'], '%.1f' % e['length']]
         else:
             cells += ['-', '-', '-']
-        if args.oracle and (args.oracle_all or not over or any(k in over for k in ORACLE_ONLY)):
+        if args.oracle and (args.oracle_all or not over or not engine_has(over) or 'friction_mode' in over):
             o = run_oracle(pol, blob, table, args.episodes, over, 11, threads)
             cells += ['%.4f' % o['reward'], '%.3f' % o['tracked'], '%.1f' % o['length']]
         else:

@@ -5,6 +5,7 @@
 #   tests     the -m gpu suite alone
 #   valu      tools/valu_issue_bench.hip: wave64 VALU issue rate per SIMD at 1 .. 8 resident waves
 #   profile   tools/profile.sh (bench lines, rocprofv3 stats + PMC passes, sweeps, timeline)
+#   cone      the cone-coupled friction builds: GPU parity, kernel time, the trained tracking policy under pyramid and cone
 #   driver    the driver's own invocation against longer runs, with and without the HBM triad first
 TARGET=${1:-tests}
 TAG=${2:-r04_$TARGET}
@@ -49,5 +50,10 @@ case $TARGET in
     done; done > $OUT/ray_ab.txt 2>&1
     cat $OUT/ray_ab.txt
     gpu_tests -k "epmc or sepmc" ;;
+  cone)          # the cone-coupled friction builds (LLM_SPEC_FRICTION_MODE = 2): GPU parity, kernel time next to the pyramid's, and the trained tracking policy under both
+    gpu_tests -k "test_gpu_parity"
+    for r in 1 2; do for sp in "" "friction_mode=2"; do echo "== spec '$sp' (round $r)"; LL_SWEEP_SPEC=$sp python tools/sweep.py "4096:4:10:10:32,4096:4:10:10:1,65536:4:10:10:1,65536:4:10:10:8"; done; done > $OUT/cone_sweep.txt 2>&1
+    cat $OUT/cone_sweep.txt
+    for v in "spec (as shipped)" "friction cone-coupled"; do python tools/deviation_table.py --engine --only "$v" 2>&1 | tail -1; done > $OUT/cone_policy.txt; cat $OUT/cone_policy.txt ;;
   *) echo "unknown target $TARGET"; exit 2 ;;
 esac

@@ -1,4 +1,5 @@
-"""GPU sweep: step-kernel time per spec n_envs:epw:solver_iterations:substeps:steps_per_launch.  python tools/sweep.py "4096:4,8192:4:10:10:32,..." """
+"""GPU sweep: step-kernel time per spec n_envs:epw:solver_iterations:substeps:steps_per_launch.  python tools/sweep.py "4096:4,8192:4:10:10:32,..."
+LL_SWEEP_SPEC=friction_mode=2 : spec switches for every engine of the sweep (include/llenv_model.h LLM_SPEC_*)."""
 import os, sys, time, math
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
@@ -21,6 +22,7 @@ for item in sys.argv[1].split(','):
             E.step_random_n(math.exp(-2), spl)
     cfg = capi.make_config(n, control_freq=50.0, sim_freq=50.0 * nsub, kd=0.5, reward_weights=RW, prop_type=PT, prioritized_sample_factor=3.0, auto_reset=1, seed=1, solver_iterations=iters)
     E = capi.Engine(cfg, blob, table, lib_path=os.environ.get('LL_LIB'))
+    E.set_spec(**{k: float(v) for k, v in (kv.split('=') for kv in os.environ.get('LL_SWEEP_SPEC', '').split(',') if kv)})
     E.reset()
     for _ in range(max(2, 32 // spl)):
         go()
