@@ -90,6 +90,10 @@ int ll_epmc_set_step_draws(ll_epmc_engine* e, const float* h_draws, int n_draws)
 /* scripted ray answers for the NEXT ll_epmc_reset only (the reset observation casts rays too) */
 int ll_epmc_script_reset_rays(ll_epmc_engine* e, const uint8_t* h_ray_hit, const float* h_ray_frac);
 
+/* the constants of the physics spec that are this build's own choice (include/llenv_model.h LLM_SPEC_*), as ll_set_spec_param / ll_get_spec_param
+ * of include/llenv.h: the robot and its solver are the PMC engine's */
+int ll_epmc_set_spec_param(ll_epmc_engine* e, int id, double value);
+int ll_epmc_get_spec_param(ll_epmc_engine* e, int id, double* value);
 int ll_epmc_sync(ll_epmc_engine* e);
 int ll_epmc_obs_dim(ll_epmc_engine* e);
 

@@ -54,6 +54,9 @@
 #define LLM_SELF_MARGIN 0.01            /* a capsule pair of two legs becomes a (speculative) row within this distance: covers closing
                                            speeds up to 5 m/s per 2 ms substep; the capsules themselves are 35 mm thick */
 #define LLM_MAX_SELF 2                  /* self-collision rows per robot */
+#define LLM_FRICTION_MODE 2             /* the two friction rows of a contact are solved together inside the cone |(t1, t2)| <= mu N (LLM_SPEC_FRICTION_MODE
+                                           below; btMultiBodyConstraintSolver's published default, resolveConeFrictionConstraintRows).  Rounds 1 - 3 and most
+                                           of round 4 shipped the pyramid (mode 0): DESIGN.md 4 has the evidence that moved the default */
 #define LLM_SEG_PARALLEL_REG 1e-3        /* closest points of two capsule axes: weight (relative to |d1|^2 |d2|^2) that pulls the parameter of nearly
                                            parallel segments to the middle of their overlap; sin^2(angle) >> this: Ericson's closest point */
 #define LLM_OBSTACLE_REACH 1.2          /* m: the jump obstacle of PLE:182-193 takes part in the substeps of a control step that starts with the base

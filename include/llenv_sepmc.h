@@ -97,6 +97,10 @@ int ll_sepmc_set_step_draws(ll_sepmc_engine* e, const float* h_draws, int n_draw
 /* scripted ray / visibility answers for the NEXT ll_sepmc_reset only */
 int ll_sepmc_script_reset(ll_sepmc_engine* e, const uint8_t* h_ray_hit, const float* h_ray_frac, const uint8_t* h_vis_blocked);
 
+/* the constants of the physics spec that are this build's own choice (include/llenv_model.h LLM_SPEC_*), as ll_set_spec_param / ll_get_spec_param
+ * of include/llenv.h: the robot and its solver are the PMC engine's */
+int ll_sepmc_set_spec_param(ll_sepmc_engine* e, int id, double value);
+int ll_sepmc_get_spec_param(ll_sepmc_engine* e, int id, double* value);
 int ll_sepmc_sync(ll_sepmc_engine* e);
 int ll_sepmc_obs_dim(ll_sepmc_engine* e);
 

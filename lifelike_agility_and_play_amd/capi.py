@@ -23,6 +23,7 @@ SPEC_IDS = dict(limit_gate=0, max_depen_speed=1, link_damping=2, max_contacts_pe
                 erp=7, contact_margin=8, self_friction=9, warm_start=10, trunk_edges=11, select_eps=12,
                 friction_mode=13, row_order=14, max_coord_vel=15, limit_erp=16, pair_friction=17, max_pair=18, friction_dirs=19, limit_speculative=20, gyro=21)                                       # include/llenv_model.h LLM_SPEC_*
 LL_SELECT_EPS = 1e-5                                                                                         # include/llenv_model.h LLM_SELECT_EPS
+LLM_FRICTION_MODE = 2                                                                                        # include/llenv_model.h LLM_FRICTION_MODE: cone-coupled friction (0: the pyramid)
 LL_DONE_FALL, LL_DONE_CLIP_END, LL_DONE_DIVERGED, LL_DONE_COLLISION, LL_DONE_NONFINITE = 1, 2, 4, 8, 16      # include/llenv.h:65-69
 LL_OK, LL_EINVAL, LL_ENOMEM, LL_EHIP, LL_ESTATE, LL_ENODEV = 0, -1, -2, -3, -4, -5                           # include/llenv.h:57-62
 

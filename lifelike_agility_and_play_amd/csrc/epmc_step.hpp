@@ -597,7 +597,7 @@ struct Epmc {
   // the control step (PGE:299-364)
   // ------------------------------------------------------------------------------------------------------------
   // PARK (the larger-batch build): the 40 per-env scalars wait in LDS and the history chunks are read after the substep loop (sepmc_step.hpp)
-  template <bool PARK = false>
+  template <bool PARK = false, bool CONE = false>   // CONE: the cone-coupled friction solve (LLM_SPEC_FRICTION_MODE = 2, Pmc::gs_cone_round)
   static LL_HD void step_env(const L& ln, const StepParams& P_in, const EpmcParams& E, int env, const F* act_in) {
     const StepParams& P = ln.params(P_in);
     const int N = P.n_envs;
@@ -673,7 +673,7 @@ struct Epmc {
         ptrace[s * 4 + 0] = ex.has_push ? 1.0f : 0.0f;
         for (int i = 0; i < 3; i++) ptrace[s * 4 + 1 + i] = ex.has_push ? ex.push[i] : 0.0f;
       }
-      if (!E.scr_state) K::template substep_impl<true>(ln, P, bs, q, qd, tgt, env, s, &ex, nullptr);   // PGE:328-330
+      if (!E.scr_state) K::template substep_impl<true, false, CONE>(ln, P, bs, q, qd, tgt, env, s, &ex, nullptr);   // PGE:328-330
     }
     if (PARK) {
       const float keep[4] = {ep[EP_PUSH_COUNT], ep[EP_PUSH_FORCE], ep[EP_PUSH_FORCE + 1], ep[EP_PUSH_FORCE + 2]};
@@ -700,7 +700,9 @@ struct Epmc {
     ep[EP_COUNTER] = (float)cnt;
     const M3<float> R = qmat(qnormalize(bs.q));
     const float gx = ep[EP_TARGET] - bs.p.x, gy = ep[EP_TARGET + 1] - bs.p.y;
-    const float dist = sqrtf(gx * gx + gy * gy);
+    // (sums of two products written as product + fused multiply-add: which of the two -ffp-contract=fast would fuse differs between builds of the
+    //  kernel, and ll_epmc_step_random_n must equal single steps bit for bit)
+    const float dist = sqrtf(__builtin_fmaf(gx, gx, gy * gy));
     int reason = 0;
     if (check_fall(R)) reason |= 1;
     if (cnt >= E.max_steps) reason |= 2;
@@ -708,11 +710,11 @@ struct Epmc {
     if (reach) reason |= 4;
     if (bad) reason |= 16;
     const float ux = gx / dist, uy = gy / dist;
-    const float spd = fabsf(bs.v.x * ux + bs.v.y * uy);                           // PGE:478-480
+    const float spd = fabsf(__builtin_fmaf(bs.v.x, ux, bs.v.y * uy));                           // PGE:478-480
     ep[EP_TOTAL_SPD] += spd;
     if (spd > ep[EP_MAX_SPD]) ep[EP_MAX_SPD] = spd;
     const float yaw = atan2f(R.m[3], R.m[0]);
-    const float r_rot = expf((cosf(yaw) * ux + sinf(yaw) * uy - 1.0f) * 5.0f);
+    const float r_rot = expf((__builtin_fmaf(cosf(yaw), ux, sinf(yaw) * uy) - 1.0f) * 5.0f);
     const float inv_ms = 1.0f / (float)E.max_steps;
     float reward;
     if (E.element_id == 0) {                                                      // joystick, PGE:474-497

@@ -42,6 +42,7 @@ LL_HD float sel(bool m, float a, float b) { return m ? a : b; }
 LL_HD int sel(bool m, int a, int b) { return m ? a : b; }
 LL_HD float sqrt_(float x) { return sqrtf(x); }
 LL_HD float rsqrt_(float x) { return 1.0f / sqrtf(x); }
+LL_HD float nfma_(float a, float b, float c) { return __builtin_fmaf(-a, b, c); }   // c - a * b as ONE rounding in every build (-ffp-contract=fast decides per build otherwise)
 LL_HD float abs_(float x) { return fabsf(x); }
 LL_HD float min_(float a, float b) { return fminf(a, b); }
 LL_HD float max_(float a, float b) { return fmaxf(a, b); }
@@ -348,6 +349,49 @@ struct GpuLanes {
 #undef LL_T1
   }
 
+  // Four CONE-COUPLED friction turns (lanes S, 4+S, 8+S, 12+S) as one block (pmc_step.hpp gs_cone_round).  The pair of friction rows of a lane
+  // carries S = lambda + pending increment ("where the multiplier would go"); a turn scales the pair back onto the cone |(S1, S2)| <= lim
+  // with sc = clamp(lim * rsq(S1^2 + S2^2), 0, 1) -- v_mul_legacy (0 * inf = 0: a row without normal force lands on 0 whatever the length,
+  // and a pair of length zero under a positive bound on sc = 1) with the instruction's own clamp --, the lane whose turn it is keeps
+  // e = S * sc - lambda for both rows, and every lane's S moves by the 2 x 2 coupling (k11 k12; k21 k22) of that lane's pair with its own.
+  // 12 VALU instructions and one wait state (v_rsq result into a non-transcendental instruction) per turn; the DPP reads of e1 / e2 come
+  // three and more instructions after their producers.  30 asm operands: the limit.
+  template <int S_>
+  LL_D void cone_turns4(F& S1, F& S2, F& d1, F& d2, F lam1, F lam2, F lim, const F* k11, const F* k12, const F* k21, const F* k22) const {
+    const unsigned long long m0 = tm_[S_], m1 = tm_[4 + S_], m2 = tm_[8 + S_], m3 = tm_[12 + S_];
+    float t, e1, e2;
+#define LL_D1(X) " row_newbcast:" X " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define LL_C1(K11, K12, K21, K22, M, L_)                                                           \
+    "v_mul_f32_e32 %4, %1, %1\n\t"                                                               \
+    "v_fmac_f32_e32 %4, %0, %0\n\t"                                                              \
+    "v_rsq_f32_e32 %4, %4\n\t"                                                                   \
+    "s_nop 0\n\t"                                                                                \
+    "v_mul_legacy_f32_e64 %4, %9, %4 clamp\n\t"                                                  \
+    "v_fma_f32 %5, %0, %4, -%7\n\t"                                                              \
+    "v_fma_f32 %6, %1, %4, -%8\n\t"                                                              \
+    "v_cndmask_b32_e64 %2, %2, %5, " M "\n\t"                                                    \
+    "v_cndmask_b32_e64 %3, %3, %6, " M "\n\t"                                                    \
+    "v_fmac_f32_dpp %0, %5, " K11 LL_D1(L_)                                                      \
+    "v_fmac_f32_dpp %1, %5, " K21 LL_D1(L_)                                                      \
+    "v_fmac_f32_dpp %0, %6, " K12 LL_D1(L_)                                                      \
+    "v_fmac_f32_dpp %1, %6, " K22 LL_D1(L_)
+#define LL_C4(L0, L1, L2, L3)                                                                                                            \
+    asm(LL_C1("%10", "%14", "%18", "%22", "%26", L0) LL_C1("%11", "%15", "%19", "%23", "%27", L1)                                        \
+        LL_C1("%12", "%16", "%20", "%24", "%28", L2) LL_C1("%13", "%17", "%21", "%25", "%29", L3)                                        \
+        : "+v"(S1), "+v"(S2), "+v"(d1), "+v"(d2), "=&v"(t), "=&v"(e1), "=&v"(e2)                                                         \
+        : "v"(lam1), "v"(lam2), "v"(lim),                                                                                                \
+          "v"(k11[S_]), "v"(k11[4 + S_]), "v"(k11[8 + S_]), "v"(k11[12 + S_]), "v"(k12[S_]), "v"(k12[4 + S_]), "v"(k12[8 + S_]), "v"(k12[12 + S_]), \
+          "v"(k21[S_]), "v"(k21[4 + S_]), "v"(k21[8 + S_]), "v"(k21[12 + S_]), "v"(k22[S_]), "v"(k22[4 + S_]), "v"(k22[8 + S_]), "v"(k22[12 + S_]), \
+          "s"(m0), "s"(m1), "s"(m2), "s"(m3))
+    if (S_ == 0) LL_C4("0", "4", "8", "12");
+    else if (S_ == 1) LL_C4("1", "5", "9", "13");
+    else if (S_ == 2) LL_C4("2", "6", "10", "14");
+    else LL_C4("3", "7", "11", "15");
+#undef LL_C4
+#undef LL_C1
+#undef LL_D1
+  }
+
   // ---- the solver's velocity state, scattered over the sub-lanes (pmc_step.hpp gs_round) ------------------------------------------
   // Per env the projected Gauss-Seidel sweep carries the whitened base twist dx[6] and, per leg, the whitened joint rates dq[3].
   // They live in THREE registers:   VA: lane (leg, s) holds dx[s]      VB: dx[4 + (s & 1)]      VJ: dq_leg[s] (s = 3: zero)
@@ -406,6 +450,37 @@ struct GpuLanes {
         : "v"(p1), "v"(p3), "v"(q1), "v"(j1), "v"(j3), "v"(dl));
 #undef LL_R
 #undef LL_Q
+  }
+  // vel_commit for TWO rows of a lane at once (the friction pair of the cone-coupled round): the products of both rows are added before
+  // the transpose-reduce, so the pair costs one reduce (five v_pk_mul, five v_pk_fma, 16 adds) instead of two.
+  LL_D static void vel_commit2(F dl1, F& lam1, F2 a01, F2 a23, F2 b01, F2 j01, F2 j23, F dl2, F& lam2, F2 c01, F2 c23, F2 e01, F2 k01, F2 k23,
+                               F& VA, F& VB, F& VJ) {
+    // (explicit multiply, then fused multiply-add: the same roundings in every build of the kernel, whatever -ffp-contract=fast would pick)
+    const F2 D2 = {dl2, dl2};
+    const F2 P01 = __builtin_elementwise_fma(c01, D2, a01 * dl1), P23 = __builtin_elementwise_fma(c23, D2, a23 * dl1), Q01 = __builtin_elementwise_fma(e01, D2, b01 * dl1),
+             J01 = __builtin_elementwise_fma(k01, D2, j01 * dl1), J23 = __builtin_elementwise_fma(k23, D2, j23 * dl1);
+    float p0 = P01.x, p1 = P01.y, p2 = P23.x, p3 = P23.y, q0 = Q01.x, q1 = Q01.y, j0 = J01.x, j1 = J01.y, j2 = J23.x, j3 = J23.y;
+#define LL_R(X) " " X " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm("v_add_f32_e32 %8, %8, %15\n\t"
+        "v_add_f32_e32 %9, %9, %16\n\t"
+        "v_add_f32_dpp %3, %10, %3" LL_R("quad_perm:[1,0,3,2]")
+        "v_add_f32_dpp %4, %11, %4" LL_R("quad_perm:[1,0,3,2]")
+        "v_add_f32_dpp %5, %12, %5" LL_R("quad_perm:[1,0,3,2]")
+        "v_add_f32_dpp %6, %13, %6" LL_R("quad_perm:[1,0,3,2]")
+        "v_add_f32_dpp %7, %14, %7" LL_R("quad_perm:[1,0,3,2]")
+        "v_add_f32_dpp %3, %4, %3" LL_R("quad_perm:[2,3,0,1]")
+        "v_add_f32_dpp %5, %5, %5" LL_R("quad_perm:[2,3,0,1]")
+        "v_add_f32_dpp %6, %7, %6" LL_R("quad_perm:[2,3,0,1]")
+        "v_add_f32_dpp %3, %3, %3" LL_R("row_ror:4")
+        "v_add_f32_dpp %5, %5, %5" LL_R("row_ror:4")
+        "v_add_f32_e32 %2, %2, %6\n\t"
+        "v_add_f32_dpp %3, %3, %3" LL_R("row_ror:8")
+        "v_add_f32_dpp %5, %5, %5" LL_R("row_ror:8")
+        "v_add_f32_e32 %0, %0, %3\n\t"
+        "v_add_f32_e32 %1, %1, %5"
+        : "+v"(VA), "+v"(VB), "+v"(VJ), "+v"(p0), "+v"(p2), "+v"(q0), "+v"(j0), "+v"(j2), "+v"(lam1), "+v"(lam2)
+        : "v"(p1), "v"(p3), "v"(q1), "v"(j1), "v"(j3), "v"(dl1), "v"(dl2));
+#undef LL_R
   }
   // what the scattered registers hold, for the code after the sweep: dx[i] (env-uniform), dq[j] (leg-uniform)
   template <int I_>

@@ -143,7 +143,7 @@ __device__ __forceinline__ void step_actions(const StepParams& P, const Lanes& l
 // chip one wavefront per SIMD, 2 (256 registers) for larger batches, where a second resident wavefront hides issue stalls.
 // OBST = the set_obstacle build (Pmc::step_env<true>): the jump obstacle takes part in the substeps as a static box.
 // MULTI = the launch may run several control steps (ll_step_random_n); single-step launches run the loop-free build.
-// CONE = the cone-coupled friction solve (LLM_SPEC_FRICTION_MODE = 2, flat-terrain builds): an option, its own instantiations.
+// CONE = the cone-coupled friction solve (LLM_SPEC_FRICTION_MODE = 2, Pmc::gs_cone_round): its own instantiations of every step kernel.
 template <int OCC, bool OBST = false, bool MULTI = false, bool CONE = false>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
 // not have (788 instead of 552 B of scratch per lane; 65536 envs: 18.6 -> 16.8 M env-steps/s), and a grid of sixteen wavefronts per SIMD has
 // neither a launch gap nor a slowest wave worth hiding, so multi-step launches exist for the one-wave-per-SIMD build only; larger batches
 // run their steps as single launches (same results: the step's draws are keyed on env, episode and draw index).
-template <int OCC, bool MULTI = false>
+template <int OCC, bool MULTI = false, bool CONE = false>   // CONE: see pmc_step_kernel
 __global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, EpmcParams E) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, 
   if constexpr (!MULTI) {
     float act[3];
     step_actions(P, ln, lds, env0, 0, act);
-    Epmc<Lanes>::template step_env<((OCC == 2 && LL_PARK) || LL_PARK > 1)>(ln, P, E, env0, act);
+    Epmc<Lanes>::template step_env<((OCC == 2 && LL_PARK) || LL_PARK > 1), CONE>(ln, P, E, env0, act);
   } else {
     for (int sl = 0; sl < P.n_steps; sl++) {               // ll_epmc_step_random_n: see pmc_step_kernel
       if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, 
       asm volatile("" : "+v"(env));
       float act[3];
       step_actions(P, ln, lds, env, sl, act);
-      Epmc<Lanes>::template step_env<(LL_PARK > 1)>(ln, P, E, env, act);
+      Epmc<Lanes>::template step_env<(LL_PARK > 1), CONE>(ln, P, E, env, act);
     }
   }
 }
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(PMC_WAVE) void epmc_reset_kernel(StepParams P, Epmc
 
 // SEPMC (sepmc_step.hpp): one control step of ChaseTagGameEnv; row = 2 * arena + robot, the two robots of an arena are
 // neighbouring rows of one wave and exchange state with v_permlane16_swap.
-template <int OCC, bool MULTI = false>          // MULTI: see epmc_step_kernel
+template <int OCC, bool MULTI = false, bool CONE = false>          // MULTI: see epmc_step_kernel; CONE: see pmc_step_kernel
 __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P, SepmcParams S) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int row0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P,
   if constexpr (!MULTI) {
     float act[3];
     step_actions(P, ln, lds, row0, 0, act);
-    Sepmc<Lanes>::template step_env<((OCC == 2 && LL_PARK) || LL_PARK > 1)>(ln, P, S, row0, act);
+    Sepmc<Lanes>::template step_env<((OCC == 2 && LL_PARK) || LL_PARK > 1), CONE>(ln, P, S, row0, act);
   } else {
     for (int sl = 0; sl < P.n_steps; sl++) {               // ll_sepmc_step_random_n: see pmc_step_kernel
       if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P,
       asm volatile("" : "+v"(row));
       float act[3];
       step_actions(P, ln, lds, row, sl, act);
-      Sepmc<Lanes>::template step_env<(LL_PARK > 1)>(ln, P, S, row, act);
+      Sepmc<Lanes>::template step_env<(LL_PARK > 1), CONE>(ln, P, S, row, act);
     }
   }
 }
@@ -396,16 +396,19 @@ struct HipBackend {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
+    const bool cone = P.friction_mode == 2;
+#define LL_GO(KERNEL, PARAMS) hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, PARAMS, E)
     if (P.n_steps == 1) {
-      if (blocks <= simds) hipLaunchKernelGGL(epmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, E);
-      else                 hipLaunchKernelGGL(epmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, E);
+      if (blocks <= simds) { if (cone) LL_GO((epmc_step_kernel<1, false, true>), P); else LL_GO((epmc_step_kernel<1>), P); }
+      else                 { if (cone) LL_GO((epmc_step_kernel<2, false, true>), P); else LL_GO((epmc_step_kernel<2>), P); }
     } else if (blocks <= simds) {
-      hipLaunchKernelGGL((epmc_step_kernel<1, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, E);
+      if (cone) LL_GO((epmc_step_kernel<1, true, true>), P); else LL_GO((epmc_step_kernel<1, true>), P);
     } else {
       StepParams Q = P;                                  // larger batches: the steps of the call as single launches (see epmc_step_kernel)
       Q.n_steps = 1;
-      for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) hipLaunchKernelGGL(epmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, Q, E);
+      for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) { if (cone) LL_GO((epmc_step_kernel<2, false, true>), Q); else LL_GO((epmc_step_kernel<2>), Q); }
     }
+#undef LL_GO
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->second, stream));
   }
@@ -419,16 +422,19 @@ struct HipBackend {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
+    const bool cone = P.friction_mode == 2;
+#define LL_GO(KERNEL, PARAMS) hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, PARAMS, S)
     if (P.n_steps == 1) {
-      if (blocks <= simds) hipLaunchKernelGGL(sepmc_step_kernel<1>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, S);
-      else                 hipLaunchKernelGGL(sepmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, S);
+      if (blocks <= simds) { if (cone) LL_GO((sepmc_step_kernel<1, false, true>), P); else LL_GO((sepmc_step_kernel<1>), P); }
+      else                 { if (cone) LL_GO((sepmc_step_kernel<2, false, true>), P); else LL_GO((sepmc_step_kernel<2>), P); }
     } else if (blocks <= simds) {
-      hipLaunchKernelGGL((sepmc_step_kernel<1, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, S);
+      if (cone) LL_GO((sepmc_step_kernel<1, true, true>), P); else LL_GO((sepmc_step_kernel<1, true>), P);
     } else {
       StepParams Q = P;                                  // larger batches: single launches (see epmc_step_kernel)
       Q.n_steps = 1;
-      for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) hipLaunchKernelGGL(sepmc_step_kernel<2>, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, Q, S);
+      for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) { if (cone) LL_GO((sepmc_step_kernel<2, false, true>), Q); else LL_GO((sepmc_step_kernel<2>), Q); }
     }
+#undef LL_GO
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->second, stream));
   }
@@ -443,7 +449,12 @@ struct HipBackend {
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
     const bool one = blocks <= simds, multi = P.n_steps > 1;
-    if (P.set_obstacle) {
+    if (P.set_obstacle && P.friction_mode == 2) {
+      if (one) { if (multi) hipLaunchKernelGGL((pmc_step_kernel<1, true, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
+                 else       hipLaunchKernelGGL((pmc_step_kernel<1, true, false, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P); }
+      else     { if (multi) hipLaunchKernelGGL((pmc_step_kernel<2, true, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
+                 else       hipLaunchKernelGGL((pmc_step_kernel<2, true, false, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P); }
+    } else if (P.set_obstacle) {
       if (one) { if (multi) hipLaunchKernelGGL((pmc_step_kernel<1, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
                  else       hipLaunchKernelGGL((pmc_step_kernel<1, true, false>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P); }
       else     { if (multi) hipLaunchKernelGGL((pmc_step_kernel<2, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);

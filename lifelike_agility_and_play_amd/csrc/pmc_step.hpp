@@ -316,7 +316,7 @@ struct Pmc {
     r.cj01 = L::pair(t[0], t[1]); r.cj23 = L::pair(t[2], t[3]);
   }
   // ---- cone-coupled friction (LLM_SPEC_FRICTION_MODE = 2: the published default of btMultiBodyConstraintSolver, resolveConeFrictionConstraintRows;
-  //      an OPTION of the PMC kernels since round 4 -- DESIGN.md 4 says why the pyramid stays the default).  The two friction rows of a contact are
+  //      the default of every step kernel since round 4, the pyramid of rounds 1 - 3 stays as mode 0 -- DESIGN.md 4).  The two friction rows of a contact are
   //      solved TOGETHER: both increments from the same velocity, the pair scaled back onto |(t1, t2)| <= mu N, both applied.  Besides the Gram
   //      scalars of each row kind (Row::nk) that takes the CROSS scalars between the t1 and t2 rows of different lanes:
   struct ConeX {
@@ -341,39 +341,21 @@ struct Pmc {
     L::template gram4<2>(gt_oth, yg, out);
     L::template gram4<3>(gt_oth, yg, out);
   }
-  // the turn of lane L_ (slot-major like every round): every lane forms what ITS pair would commit, lane L_'s is the one that counts
-  template <int L_>
-  static LL_HD void cone_turn(const L& ln, const Row& r1, const Row& r2, const ConeX& cx, const F& lim, F& u1, F& u2, F& d1, F& d2) {
-    F zero = ln.lane_f(0.0f);
-    F s1 = r1.lam + u1, s2 = r2.lam + u2;
-    F len2 = s1 * s1 + s2 * s2;
-    B over = len2 > lim * lim;
-    F sc = lm::sel(lim > 0.0f, lim * lm::rsqrt_(lm::max_(len2, ln.lane_f(1.0e-30f))), zero);
-    s1 = lm::sel(over, s1 * sc, s1); s2 = lm::sel(over, s2 * sc, s2);
-    F e1 = s1 - r1.lam, e2 = s2 - r2.lam;
-    B me = ln.is_lane(L_);
-    d1 = lm::sel(me, e1, d1); d2 = lm::sel(me, e2, d2);
-    L::template fmac_rbcast<L_>(u1, e1, r1.nk[L_]);
-    L::template fmac_rbcast<L_>(u1, e2, cx.n12[L_]);
-    L::template fmac_rbcast<L_>(u2, e1, cx.n21[L_]);
-    L::template fmac_rbcast<L_>(u2, e2, r2.nk[L_]);
-  }
+  // One cone-coupled round over the 16 friction pairs, turns slot-major like every round.  The state of a pair during the round is
+  // S = lambda + pending increment (lambda itself only moves at the commit): lanes.hpp cone_turns4 has the turn.
+  // (Skipping the four turns of a contact slot no env of the wave uses -- they commit exact zeros -- was measured slower here too, 13 issue slots
+  // a turn notwithstanding: 0.1929 against 0.1887 ms per control step, profiles/r04_cone_ab.txt.)
   static LL_HD void gs_cone_round(const L& ln, Row& r1, Row& r2, const ConeX& cx, const F& lim, F& VA, F& VB, F& VJ) {
     F zero = ln.lane_f(0.0f);
     F w1 = L::vel_dot(r1.c, r1.ca01, r1.ca23, r1.cb01, r1.cj01, r1.cj23, VA, VB, VJ);
     F w2 = L::vel_dot(r2.c, r2.ca01, r2.ca23, r2.cb01, r2.cj01, r2.cj23, VA, VB, VJ);
-    F u1 = (zero - w1) * r1.inv, u2 = (zero - w2) * r2.inv;
+    F S1 = lm::nfma_(w1, r1.inv, r1.lam), S2 = lm::nfma_(w2, r2.inv, r2.lam);
     F d1 = zero, d2 = zero;
-    cone_turn<0>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<4>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
-    cone_turn<8>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<12>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
-    cone_turn<1>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<5>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
-    cone_turn<9>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<13>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
-    cone_turn<2>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<6>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
-    cone_turn<10>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<14>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
-    cone_turn<3>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<7>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
-    cone_turn<11>(ln, r1, r2, cx, lim, u1, u2, d1, d2); cone_turn<15>(ln, r1, r2, cx, lim, u1, u2, d1, d2);
-    L::vel_commit(d1, r1.lam, r1.ca01, r1.ca23, r1.cb01, r1.cj01, r1.cj23, VA, VB, VJ);      // (also lam += d)
-    L::vel_commit(d2, r2.lam, r2.ca01, r2.ca23, r2.cb01, r2.cj01, r2.cj23, VA, VB, VJ);
+    ln.template cone_turns4<0>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, cx.n12, cx.n21, r2.nk);
+    ln.template cone_turns4<1>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, cx.n12, cx.n21, r2.nk);
+    ln.template cone_turns4<2>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, cx.n12, cx.n21, r2.nk);
+    ln.template cone_turns4<3>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, cx.n12, cx.n21, r2.nk);
+    L::vel_commit2(d1, r1.lam, r1.ca01, r1.ca23, r1.cb01, r1.cj01, r1.cj23, d2, r2.lam, r2.ca01, r2.ca23, r2.cb01, r2.cj01, r2.cj23, VA, VB, VJ);   // (also lam += d)
   }
 
   template <int K_>
@@ -710,7 +692,8 @@ struct Pmc {
   }
   static LL_HD void substep(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env = 0, int sidx = -1,
                             const SubstepExtra* ex = nullptr) {
-    substep_impl<false>(ln, P, bs, q, qd, tgt, env, sidx, ex, nullptr);
+    if (P.friction_mode == 2) substep_impl<false, false, true>(ln, P, bs, q, qd, tgt, env, sidx, ex, nullptr);      // (host tests: emu_substep)
+    else substep_impl<false>(ln, P, bs, q, qd, tgt, env, sidx, ex, nullptr);
   }
   // TERRAIN: contact candidates are also tested against ex->shapes, and a contact's normal is that of the shape it touches
   // PAIR: contacts with the other robot of a SEPMC arena (the neighbouring row) are found and solved too
@@ -1853,7 +1836,7 @@ struct Pmc {
     const LinkC* held = nullptr;
     if (L::kHoldLink) { lkh = own_link_held(ln, P.legc); held = &lkh; }
     for (int s = 0; s < P.n_sub; s++) {                                      // PLE:202
-      if (OBST) substep_impl<true>(ln, P, bs, q, qd, tgt, env, s, &ex, held);
+      if (OBST) substep_impl<true, false, CONE>(ln, P, bs, q, qd, tgt, env, s, &ex, held);
       else substep_impl<false, false, CONE>(ln, P, bs, q, qd, tgt, env, s, nullptr, held);   // PLE:204-206
       t_loc = t;                                                             // PLE:208 motion.step(time BEFORE the increment), quirk Q2
       t += P.dt_d;                                                           // PLE:210

@@ -250,6 +250,7 @@ static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
   P.self_collision = 1.0f;
   P.max_depen = (float)LLM_MAX_DEPEN_SPEED; P.self_margin = (float)LLM_SELF_MARGIN;
   P.max_contacts = LLM_MAX_CONTACTS_PER_LEG; P.max_self = LLM_MAX_SELF;
+  P.friction_mode = LLM_FRICTION_MODE;
   double sw = 0;
   for (int i = 0; i < 5; i++) sw += cfg.reward_weights[i];               // PLE:365
   if (!(sw > 0)) return "reward_weights must sum to a positive number";
@@ -315,7 +316,6 @@ inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
       P.friction_dirs = (int)v; break;
     case LLM_SPEC_FRICTION_MODE:
       if (!(v == 0.0 || v == 2.0)) return "friction_mode: the engine has 0 (pyramid, the spec) and 2 (cone-coupled, btMultiBodyConstraintSolver's published default); 1 and 3 exist in the oracle only";
-      if (v == 2.0 && P.set_obstacle) return "cone-coupled friction is built for the flat-terrain PMC kernels (set_obstacle = False)";
       P.friction_mode = (int)v; break;
     case LLM_SPEC_ROW_ORDER: case LLM_SPEC_MAX_COORD_VEL: case LLM_SPEC_LIMIT_ERP: case LLM_SPEC_PAIR_FRICTION:
     case LLM_SPEC_MAX_PAIR: case LLM_SPEC_LIMIT_SPECULATIVE: case LLM_SPEC_GYRO:

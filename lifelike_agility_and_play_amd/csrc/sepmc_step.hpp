@@ -343,7 +343,7 @@ struct Sepmc {
   // ------------------------------------------------------------------------------------------------------------
   // PARK (the larger-batch build): the 40 per-row scalars wait in LDS and the history chunks are read after the substep loop instead of
   // before it (two waves per SIMD hide that round trip; one wave per SIMD would pay it)
-  template <bool PARK = false>
+  template <bool PARK = false, bool CONE = false>   // CONE: the cone-coupled friction solve (LLM_SPEC_FRICTION_MODE = 2, Pmc::gs_cone_round)
   static LL_HD void step_env(const L& ln, const StepParams& P_in, const SepmcParams& S, int row, const F* act_in) {
     const StepParams& P = ln.params(P_in);
     const EpmcParams& E = S.e;
@@ -424,7 +424,7 @@ struct Sepmc {
         for (int i = 0; i < 3; i++) ptrace[s * 4 + 1 + i] = ex.has_push ? ex.push[i] : 0.0f;
       }
       ex.want_touch = s == P.n_sub - 1;
-      if (!E.scr_state) K::template substep_impl<true, true>(ln, P, bs, q, qd, tgt, row, s, &ex, &lkh);
+      if (!E.scr_state) K::template substep_impl<true, true, CONE>(ln, P, bs, q, qd, tgt, row, s, &ex, &lkh);
     }
     if (PARK) {
       const float keep[4] = {sp[SP_PUSH_COUNT], sp[SP_PUSH_FORCE], sp[SP_PUSH_FORCE + 1], sp[SP_PUSH_FORCE + 2]};
@@ -477,7 +477,7 @@ struct Sepmc {
     }
     sp[SP_WHO0] = (float)who0; sp[SP_WHO_T] = (float)who_t;
     // --- CTG:399-419 ---
-    const float v0 = sqrtf(b0.v.x * b0.v.x + b0.v.y * b0.v.y), v1 = sqrtf(b1.v.x * b1.v.x + b1.v.y * b1.v.y);   // CTG:370-376
+    const float v0 = sqrtf(__builtin_fmaf(b0.v.x, b0.v.x, b0.v.y * b0.v.y)), v1 = sqrtf(__builtin_fmaf(b1.v.x, b1.v.x, b1.v.y * b1.v.y));   // CTG:370-376 (one stated rounding order: epmc_step.hpp)
     sp[SP_TOTAL_SPD] += v0; sp[SP_TOTAL_SPD + 1] += v1;
     if (v0 > sp[SP_MAX_SPD]) sp[SP_MAX_SPD] = v0;
     if (v1 > sp[SP_MAX_SPD + 1]) sp[SP_MAX_SPD + 1] = v1;

@@ -88,6 +88,8 @@ _SIGS = {
     'll_epmc_script_reset_rays': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'll_epmc_set_step_draws': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     'll_epmc_sync': (C.c_int, [C.c_void_p]),
+    'll_epmc_set_spec_param': (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    'll_epmc_get_spec_param': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     'll_epmc_obs_dim': (C.c_int, [C.c_void_p]),
     'll_epmc_get_obs': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_epmc_get_reward_done': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -195,6 +197,17 @@ class EpmcEngine(object):
 
     def sync(self):
         self._chk(self.lib.ll_epmc_sync(self.h))
+
+    def set_spec(self, **kw):
+        """ll_epmc_set_spec_param: the physics-spec switches of include/llenv_model.h (the robot and its solver are the PMC engine's), e.g.
+        set_spec(friction_mode=2)."""
+        for k, v in kw.items():
+            self._chk(self.lib.ll_epmc_set_spec_param(self.h, capi.SPEC_IDS[k], float(v)))
+
+    def get_spec(self, key):
+        v = C.c_double()
+        self._chk(self.lib.ll_epmc_get_spec_param(self.h, capi.SPEC_IDS[key], C.byref(v)))
+        return v.value
 
     def obs(self):
         o = np.empty((self.n_envs, self.obs_dim), dtype=np.float32)

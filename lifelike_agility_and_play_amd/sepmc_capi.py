@@ -83,6 +83,8 @@ _SIGS = {
     'll_sepmc_set_step_draws': (C.c_int, [_V, _V, C.c_int]),
     'll_sepmc_script_reset': (C.c_int, [_V, _V, _V, _V]),
     'll_sepmc_sync': (C.c_int, [_V]),
+    'll_sepmc_set_spec_param': (C.c_int, [_V, C.c_int, C.c_double]),
+    'll_sepmc_get_spec_param': (C.c_int, [_V, C.c_int, C.POINTER(C.c_double)]),
     'll_sepmc_obs_dim': (C.c_int, [_V]),
     'll_sepmc_get_obs': (C.c_int, [_V, _V]),
     'll_sepmc_get_reward_done': (C.c_int, [_V, _V, _V, _V]),
@@ -194,6 +196,17 @@ class SepmcEngine(object):
 
     def sync(self):
         self._chk(self.lib.ll_sepmc_sync(self.h))
+
+    def set_spec(self, **kw):
+        """ll_sepmc_set_spec_param: the physics-spec switches of include/llenv_model.h (the robot and its solver are the PMC engine's), e.g.
+        set_spec(friction_mode=2)."""
+        for k, v in kw.items():
+            self._chk(self.lib.ll_sepmc_set_spec_param(self.h, capi.SPEC_IDS[k], float(v)))
+
+    def get_spec(self, key):
+        v = C.c_double()
+        self._chk(self.lib.ll_sepmc_get_spec_param(self.h, capi.SPEC_IDS[key], C.byref(v)))
+        return v.value
 
     def obs(self):
         o = np.empty((self.n_arenas, 2, self.obs_dim), dtype=np.float32)

@@ -35,7 +35,8 @@ struct HostBackend {
       for (int env = 0; env < P.n_envs; env++) {
         fN act[3];
         for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
-        if (P.set_obstacle) K::step_env<true>(ln, P, env, act, sl);
+        if (P.set_obstacle && P.friction_mode == 2) K::step_env<true, true>(ln, P, env, act, sl);
+        else if (P.set_obstacle) K::step_env<true>(ln, P, env, act, sl);
         else if (P.friction_mode == 2) K::step_env<false, true>(ln, P, env, act, sl);
         else K::step_env<false>(ln, P, env, act, sl);
       }
@@ -99,8 +100,9 @@ struct HostBackend {
       for (int env = 0; env < P.n_envs; env++) {
         fN act[3];
         for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
-        if (getenv("LL_EMUL_PARK")) Epmc<HostLanes>::step_env<true>(ln, P, E, env, act);      // the larger-batch GPU build's variant (tests)
-        else Epmc<HostLanes>::step_env(ln, P, E, env, act);
+        const bool park = getenv("LL_EMUL_PARK") != nullptr, cone = P.friction_mode == 2;      // park: the larger-batch GPU build's variant (tests)
+        if (park) { if (cone) Epmc<HostLanes>::step_env<true, true>(ln, P, E, env, act); else Epmc<HostLanes>::step_env<true>(ln, P, E, env, act); }
+        else      { if (cone) Epmc<HostLanes>::step_env<false, true>(ln, P, E, env, act); else Epmc<HostLanes>::step_env(ln, P, E, env, act); }
       }
     }
   }
@@ -130,8 +132,9 @@ struct HostBackend {
       run_pairs(P, P.n_envs, [&](HostLanes& ln, int row) {
         fN act[3];
         for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)row * 12 + j, 3);
-        if (getenv("LL_EMUL_PARK")) Sepmc<HostLanes>::step_env<true>(ln, P, S, row, act);
-        else Sepmc<HostLanes>::step_env(ln, P, S, row, act);
+        const bool park = getenv("LL_EMUL_PARK") != nullptr, cone = P.friction_mode == 2;
+        if (park) { if (cone) Sepmc<HostLanes>::step_env<true, true>(ln, P, S, row, act); else Sepmc<HostLanes>::step_env<true>(ln, P, S, row, act); }
+        else      { if (cone) Sepmc<HostLanes>::step_env<false, true>(ln, P, S, row, act); else Sepmc<HostLanes>::step_env(ln, P, S, row, act); }
       });
     }
   }

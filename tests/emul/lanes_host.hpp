@@ -52,6 +52,7 @@ namespace lm {
 EMU_UN(sqrt_, sqrtf) EMU_UN(abs_, fabsf) EMU_UN(rint_, rintf)
 inline fN atan2_(const fN& y, const fN& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = atan2f(y.v[i], x.v[i]); return r; }
 EMU_UN(sin_, sinf) EMU_UN(cos_, cosf)
+inline fN nfma_(const fN& a, const fN& b, const fN& c) { fN r; for (int i = 0; i < EW; i++) r.v[i] = fmaf(-a.v[i], b.v[i], c.v[i]); return r; }
 inline fN rsqrt_(const fN& a) { fN r; for (int i = 0; i < EW; i++) r.v[i] = 1.0f / sqrtf(a.v[i]); return r; }
 inline fN min_(const fN& a, const fN& b) { fN r; for (int i = 0; i < EW; i++) r.v[i] = fminf(a.v[i], b.v[i]); return r; }
 inline fN max_(const fN& a, const fN& b) { fN r; for (int i = 0; i < EW; i++) r.v[i] = fmaxf(a.v[i], b.v[i]); return r; }
@@ -184,6 +185,24 @@ struct HostLanes {
       for (int l = 0; l < EW; l++) u.v[l] = u.v[l] + d.v[L_] * nk[L_].v[l];
     }
   }
+  // four cone-coupled friction turns (lanes.hpp cone_turns4): v_mul_legacy (0 * anything = 0) with clamp, v_rsq(0) = inf
+  template <int S_> static void cone_turns4(F& S1, F& S2, F& d1, F& d2, const F& lam1, const F& lam2, const F& lim, const F* k11, const F* k12, const F* k21, const F* k22) {
+    for (int t = 0; t < 4; t++) {
+      const int L_ = 4 * t + S_;
+      fN e1, e2;
+      for (int l = 0; l < EW; l++) {
+        const float len2 = fmaf(S1.v[l], S1.v[l], S2.v[l] * S2.v[l]);
+        const float r = len2 > 0.0f ? 1.0f / sqrtf(len2) : INFINITY;
+        const float sc = (lim.v[l] == 0.0f || r == 0.0f) ? 0.0f : fminf(fmaxf(lim.v[l] * r, 0.0f), 1.0f);
+        e1.v[l] = fmaf(S1.v[l], sc, -lam1.v[l]); e2.v[l] = fmaf(S2.v[l], sc, -lam2.v[l]);
+      }
+      d1.v[L_] = e1.v[L_]; d2.v[L_] = e2.v[L_];
+      for (int l = 0; l < EW; l++) {
+        S1.v[l] = (S1.v[l] + e1.v[L_] * k11[L_].v[l]) + e2.v[L_] * k12[L_].v[l];
+        S2.v[l] = (S2.v[l] + e1.v[L_] * k21[L_].v[l]) + e2.v[L_] * k22[L_].v[l];
+      }
+    }
+  }
   // the solver's scattered velocity state (lanes.hpp): VA[l] = dx[l & 3], VB[l] = dx[4 + (l & 1)], VJ[l] = dq_leg[l & 3];
   // ca[k][l] = gt[(l & 3) ^ k], cb[k][l] = gt[4 + (((l & 3) ^ k) & 1)], cj[k][l] = jt[(l & 3) ^ k]
   static F vel_dot(const F& c, const F2& ca01, const F2& ca23, const F2& cb01, const F2& cj01, const F2& cj23, const F& VA, const F& VB, const F& VJ) {
@@ -214,6 +233,11 @@ struct HostLanes {
       for (int k = 0; k < 2; k++) tB[(s ^ k) & 1] += cb[k]->v[l] * dl.v[l];
     }
     for (int l = 0; l < EW; l++) { VA.v[l] += tA[l & 3]; VB.v[l] += tB[l & 1]; VJ.v[l] += tJ[l >> 2][l & 3]; }
+  }
+  static void vel_commit2(const F& dl1, F& lam1, const F2& a01, const F2& a23, const F2& b01, const F2& j01, const F2& j23,
+                          const F& dl2, F& lam2, const F2& c01, const F2& c23, const F2& e01, const F2& k01, const F2& k23, F& VA, F& VB, F& VJ) {
+    vel_commit(dl1, lam1, a01, a23, b01, j01, j23, VA, VB, VJ);
+    vel_commit(dl2, lam2, c01, c23, e01, k01, k23, VA, VB, VJ);
   }
   template <int I_> static float vel_dx(const F& VA, const F& VB) { return I_ < 4 ? VA.v[I_ & 3] : VB.v[I_ & 1]; }
   template <int J_> static F vel_dq(const F& VJ) { fN r; for (int i = 0; i < EW; i++) r.v[i] = VJ.v[(i & ~3) | J_]; return r; }

@@ -32,9 +32,33 @@ def draws_to_uniforms(log):
     return u.astype(np.float32)
 
 
+BASE_SPEC = {}         # physics-spec switches (include/llenv_model.h LLM_SPEC_*) every engine and every oracle call of this module runs under: spec_variant()
+
+
+class spec_variant:
+    """with spec_variant(friction_mode=0): ... -- the checks of this module (and of sepmc_parity_common) on a spec VARIANT both implementations
+    carry (ll_epmc_set_spec_param / ll_sepmc_set_spec_param on the engines, orc.set_spec on the oracle)."""
+
+    def __init__(self, **spec):
+        self.spec = spec
+
+    def __enter__(self):
+        from oracle import oracle as orc
+        self.saved = dict(BASE_SPEC)
+        BASE_SPEC.update(self.spec)
+        orc.reset_spec(); orc.set_spec(**BASE_SPEC)
+
+    def __exit__(self, *a):
+        from oracle import oracle as orc
+        BASE_SPEC.clear(); BASE_SPEC.update(self.saved)
+        orc.reset_spec(); orc.set_spec(**BASE_SPEC)
+
+
 def make_engine(cfg_dict, n_envs, lib_path, **kw):
     cfg = epmc_capi.make_epmc_config(n_envs, cfg_dict, **kw)
-    return epmc_capi.EpmcEngine(cfg, urdf_model.default_model_blob(), lib_path=lib_path)
+    E = epmc_capi.EpmcEngine(cfg, urdf_model.default_model_blob(), lib_path=lib_path)
+    E.set_spec(**BASE_SPEC)
+    return E
 
 
 def script3(call0):
@@ -311,7 +335,7 @@ def oracle_control_step(B, orc, s0, act, push_trace, mu, near, r32=False, **spec
     """Ten substeps of the oracle from state s0 with the PD target of one action (what one engine step does); r32 rounds the state to float32
     between substeps.  Returns the end state and how close the deepest-K picks came to their discontinuity (oracle.selection_margin)."""
     orc.reset_spec()
-    orc.set_spec(**spec)
+    orc.set_spec(**{**BASE_SPEC, **spec})
     s = s0.copy()
     tgt = np.clip(s[13:25] + np.asarray(act, np.float64), -3.0, 3.0)
     sel = np.inf
@@ -323,7 +347,7 @@ def oracle_control_step(B, orc, s0, act, push_trace, mu, near, r32=False, **spec
         sel = min(sel, B.selection_margin())
         if r32:
             s = s.astype(np.float32).astype(np.float64)
-    orc.reset_spec()
+    orc.reset_spec(); orc.set_spec(**BASE_SPEC)
     return s, sel
 
 
@@ -648,14 +672,11 @@ def check_game_statistics(lib_path, n_per_policy=128, procs=None, policies=('hur
         out[which] = o
         print('game statistics, %s policy, %d episodes (engine / oracle): reached %.3f / %.3f, fell %.3f / %.3f, timed out %.3f / %.3f, mean length %.1f / %.1f, '
               'KS p %.3f; same end reason %.3f, same end step %.3f' % ((which, n) + o['reached'] + o['fell'] + o['timed_out'] + o['mean_len'] + (o['ks_p'], o['same_end'], o['same_step'])))
-        if which == 'hole':
-            # Episodes of the bars policy split three ways and decorrelate between the two simulators (about a quarter end at the same step), so
-            # engine and oracle are two SAMPLES of one distribution: two-sample bars at three standard errors (parity_common.two_sample_bars)
-            from parity_common import two_sample_bars
-            two_sample_bars(which, {k: o[k] for k in ('reached', 'fell', 'timed_out')}, len_e, len_o, o['ks_p'], n, floor_frac=frac_tol, floor_len=len_tol)
-        else:
-            for k in ('reached', 'fell', 'timed_out'):
-                assert abs(o[k][0] - o[k][1]) <= frac_tol + 1e-9, (which, k, o[k])
-            assert abs(o['mean_len'][0] - o['mean_len'][1]) <= len_tol * o['mean_len'][1], (which, o['mean_len'])
-            assert o['ks_p'] > ks_p, (which, o['ks_p'])
+        # The episodes of the two simulators decorrelate: a contact that makes or breaks one step apart sends the rest of a run down another path
+        # (same end step: 0.2 - 0.3 of the runs for every policy; under cone-coupled friction the stairs policy ends 6 % of its runs for another
+        # reason).  Engine and oracle are two SAMPLES of one distribution: two-sample bars at three standard errors, never tighter than the
+        # floors (parity_common.two_sample_bars).  What the populations are was measured at 1024 episodes a side (profiles/r04_cone_decision.md:
+        # stairs reached 988 engine / 981 oracle, hurdles 1013 / 1014).
+        from parity_common import two_sample_bars
+        two_sample_bars(which, {k: o[k] for k in ('reached', 'fell', 'timed_out')}, len_e, len_o, o['ks_p'], n, floor_frac=frac_tol, floor_len=len_tol)
     return out

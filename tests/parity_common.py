@@ -802,7 +802,7 @@ def check_reset_argument_handling(model_blob, table, lib_path):
 def two_sample_bars(label, fracs, len_e, len_o, ks_p, n, floor_frac=0.03, floor_len=0.03, n_se=3.0, ks_floor=0.01):
     """Bars for outcome statistics of CHAOTIC episodes played by two simulators from the same seeds.  Where most episodes end at the same step on
     both sides the samples are paired and tight bars hold (end-reason fractions within 0.03, mean length within 3 %, KS p > 0.5: the PMC rollout
-    test, the hurdle and stairs policies).  Where they decorrelate, engine and oracle are two independent samples of what is claimed to be ONE
+    test).  Where they decorrelate, engine and oracle are two independent samples of what is claimed to be ONE
     distribution, and the claim is tested as such: a fraction may differ by n_se standard errors of the difference of two binomial fractions
     (or floor_frac, whichever is larger), the mean length by n_se standard errors of the difference of two means (or floor_len of it), and the
     Kolmogorov-Smirnov test must not reject at ks_floor (its p-value is uniform on [0, 1] under the hypothesis: "p > 0.5" would fail every second

@@ -42,14 +42,14 @@ def test_env_api_contract_gpu():
 
 
 def test_terrain_physics_against_oracle():
-    out = ec.check_terrain_physics_against_oracle(None, n_envs=48, cap_ill=1, cap_tie=2)        # observed on MI355X (round 4, 96 cases): 0 / 1
+    out = ec.check_terrain_physics_against_oracle(None, n_envs=48, cap_ill=3, cap_tie=3)        # observed on MI355X (round 4, 96 cases, cone friction): 2 / 2  (pyramid: 0 / 1)
     assert out['n_terrain'] >= 30 and out['n_felt'] >= 20
 
 
 def test_larger_batch_build_against_the_oracle():
     """epmc_step_kernel<2> (batches above 4096 envs) against the float64 oracle DIRECTLY: terrain physics cases spread over the first, middle
     and last wavefronts of a 4096 + 256 env grid, the bars of the occupancy-1 build."""
-    out = ec.check_terrain_physics_against_oracle(None, n_envs=48, total_envs=4096 + 256, cap_ill=2, cap_tie=7)     # (observed: 1 / 6 of 96 -- properties of the case set, decided by the oracle)
+    out = ec.check_terrain_physics_against_oracle(None, n_envs=48, total_envs=4096 + 256, cap_ill=2, cap_tie=10)     # (observed: 1 / 9 of 96 under the cone, 1 / 6 under the pyramid -- properties of the case set, decided by the oracle)
     print('occupancy-2 EPMC vs oracle: %d cases, ill-conditioned %d, on a selection tie %d' % (len(out['config']), out['n_ill_conditioned'], out['n_on_selection_tie']))
     assert out['n_terrain'] >= 30 and out['n_felt'] >= 20
 
@@ -64,8 +64,17 @@ def test_multi_step_launch():
     ec.check_multi_step_launch(None, sizes=(70, 4200), k=7, n_launches=3)
 
 
+def test_pyramid_friction_variant():
+    """LLM_SPEC_FRICTION_MODE = 0 (ll_epmc_set_spec_param: the pyramid of rounds 1 - 3, still a build of every step kernel) against the oracle
+    under the same switch -- terrain physics in both register budgets -- and its multi-step launch against single launches."""
+    with ec.spec_variant(friction_mode=0):
+        ec.check_terrain_physics_against_oracle(None, n_envs=48, cap_ill=1, cap_tie=2)                              # (what the default spec's test asserted while this was the default)
+        ec.check_terrain_physics_against_oracle(None, n_envs=24, total_envs=4096 + 256, cap_ill=2, cap_tie=4)
+        ec.check_multi_step_launch(None, sizes=(70, 4200), k=7, n_launches=3)
+
+
 def test_trunk_on_edges_against_oracle():
-    out = ec.check_trunk_on_edges_against_oracle(None, n_envs=48, cap_ill=7, cap_tie=9)         # observed (96 cases): 6 / 8
+    out = ec.check_trunk_on_edges_against_oracle(None, n_envs=48, cap_ill=4, cap_tie=7)         # observed (96 cases, cone friction): 3 / 6  (pyramid: 6 / 8)
     assert out['n_edge_felt'] >= 24
 
 

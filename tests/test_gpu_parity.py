@@ -46,14 +46,13 @@ def test_sliding_direction_friction_variant(golden, orc, model_blob, mocap_table
     assert np.percentile(c, 98) < 1e-4 and np.percentile(v, 98) < 1e-3 and c.max() < 2e-2, (np.percentile(c, [98, 100]), np.percentile(v, [98, 100]))
 
 
-def test_cone_friction_variant(golden, orc, model_blob, mocap_table):
-    """LLM_SPEC_FRICTION_MODE = 2 (the two friction rows of a contact solved together inside the cone, Bullet's published default; a launch-time
-    OPTION of the PMC kernels, Pmc::gs_cone_round) against the oracle with the same switch: held to the bars of the shipped spec, in the
-    occupancy-1 build and (5000 envs) the occupancy-2 build."""
-    st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, None, n_envs=48, n_steps=12, spec=dict(friction_mode=2))
-    print('friction_mode=2: config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
-    st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, None, n_envs=24, n_steps=8, total_envs=5000, spec=dict(friction_mode=2))
-    print('friction_mode=2, 5000 envs: config err max', np.max(st['config']), 'vel (rel)', np.max(st['vel']))
+def test_pyramid_friction_variant(golden, orc, model_blob, mocap_table):
+    """LLM_SPEC_FRICTION_MODE = 0 (all t1 rows, then all t2 rows, box bounds: the spec of rounds 1 - 3, still a build of every step kernel)
+    against the oracle with the same switch: held to the bars of the shipped spec, in the occupancy-1 build and (5000 envs) the occupancy-2 build."""
+    st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, None, n_envs=48, n_steps=12, spec=dict(friction_mode=0))
+    print('friction_mode=0: config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
+    st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, None, n_envs=24, n_steps=8, total_envs=5000, spec=dict(friction_mode=0))
+    print('friction_mode=0, 5000 envs: config err max', np.max(st['config']), 'vel (rel)', np.max(st['vel']))
 
 
 def test_free_running_episode_statistics(golden, orc, model_blob, mocap_table):
@@ -187,7 +186,7 @@ def test_multi_step_launch(model_blob, mocap_table):
     def read_ring(addr, shape):
         return gather.device_tensor(addr, shape).cpu().numpy()
     pc.check_multi_step_launch(model_blob, mocap_table, None, read_ring, sizes=(70, 4200), k=7, n_launches=5)
-    pc.check_multi_step_launch(model_blob, mocap_table, None, read_ring, sizes=(70, 4200), k=7, n_launches=3, spec=dict(friction_mode=2))   # the cone builds
+    pc.check_multi_step_launch(model_blob, mocap_table, None, read_ring, sizes=(70, 4200), k=7, n_launches=3, spec=dict(friction_mode=0))   # the pyramid builds
 
 
 def test_contact_rich_parity(golden, orc, model_blob, mocap_table):

@@ -51,6 +51,16 @@ def test_larger_batch_build_against_the_oracle_gpu():
     print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=9, total_arenas=2048 + 128))
 
 
+def test_pyramid_friction_variant_gpu():
+    """LLM_SPEC_FRICTION_MODE = 0 (ll_sepmc_set_spec_param: the pyramid of rounds 1 - 3) against the two-robot oracle under the same switch, both
+    register budgets, and its multi-step launch against single launches."""
+    import epmc_parity_common as ec
+    with ec.spec_variant(friction_mode=0):
+        print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=9))
+        print(SC.check_pair_physics_against_oracle(None, n_arenas=24, seed=9, total_arenas=2048 + 128))
+        SC.check_multi_step_launch(None, sizes=(35, 2100), k=7, n_launches=3)
+
+
 def test_trained_reference_policy_plays_chase_tag_gpu():
     print(SC.check_trained_policy_plays_chase_tag(None, n_arenas=128, horizon=700, min_caught=0.6))
 
@@ -97,8 +107,8 @@ def test_both_register_budgets_compute_the_same_gpu():
     same arena, spawn poses and pushes per arena; re-synchronised after each control step.  The two kernels are compiled from the same source
     but not to the same float32 instruction sequence (the larger-batch build parks its episode scalars in LDS around the substep loop, and
     -ffp-contract=fast then fuses a few multiply-adds differently: the median difference is 5e-8), so a robot lying on the ground can take the
-    other side of a deepest-contact or limit-gate decision for one step: those row-steps are counted, printed and capped -- at most 1 % of
-    row-steps outside the oracle bars, none by more than 1e-2.  (The larger-batch kernel is held to the oracle itself in
+    other side of a deepest-contact or limit-gate decision for one step: those row-steps are counted, printed and capped -- at most 5 of the
+    1920 row-steps outside the oracle bars, none by more than 2e-2.  (The larger-batch kernel is held to the oracle itself in
     test_larger_batch_build_against_the_oracle_gpu.)"""
     from parity_common import quat_align
     n_small, n_big = 32, 2048 + 64
@@ -129,5 +139,6 @@ def test_both_register_budgets_compute_the_same_gpu():
           (len(c), np.median(c), out.sum(), c.max(), v.max()))
     # (round 4, AABB link inertias: 9 of 1920 outside, worst 6.4e-3 / 1.39 -- a 170 g shank at its joint limit takes or leaves the limit row at
     # LLM_LIMIT_GATE = 20 rad/s: the one decision in the spec that can move a joint rate by tens of rad/s)
-    assert out.sum() <= 10 and c.max() < 1e-2 and v.max() < 2.0, (out.sum(), c.max(), v.max())          # (observed + 1)
+    # (cone friction, the default since: 4 of 1920 outside, worst 1.56e-2 / 0.66)
+    assert out.sum() <= 5 and c.max() < 2e-2 and v.max() < 1.0, (out.sum(), c.max(), v.max())          # (observed + 1; worst: observed x 1.3 - 1.5)
     A.close(); B.close()

@@ -77,7 +77,7 @@ def test_multi_step_launch(model_blob, mocap_table, emul_lib):
         n = int(np.prod(shape))
         return np.ctypeslib.as_array((ctypes.c_float * n).from_address(addr)).reshape(shape).copy()
     pc.check_multi_step_launch(model_blob, mocap_table, emul_lib, read_ring)
-    pc.check_multi_step_launch(model_blob, mocap_table, emul_lib, read_ring, n_launches=2, spec=dict(friction_mode=2))
+    pc.check_multi_step_launch(model_blob, mocap_table, emul_lib, read_ring, n_launches=2, spec=dict(friction_mode=0))    # the pyramid builds
 
 
 def test_obstacle_variant(golden, orc, model_blob, mocap_table, emul_lib):
@@ -125,26 +125,26 @@ def test_multi_step_launch_must_fit_the_unroll_ring(model_blob, mocap_table, emu
     E.close()
 
 
-def test_cone_friction_variant(golden, orc, model_blob, mocap_table, emul_lib):
-    """LLM_SPEC_FRICTION_MODE = 2 (the two friction rows of a contact solved together inside the cone, Bullet's published default; a launch-time
-    OPTION of the PMC kernels, Pmc::gs_cone_round) against the oracle with the same switch: held to the bars of the shipped spec."""
-    st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, emul_lib, n_envs=24, n_steps=10, spec=dict(friction_mode=2))
-    print('friction_mode=2: config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
+def test_pyramid_friction_variant(golden, orc, model_blob, mocap_table, emul_lib):
+    """LLM_SPEC_FRICTION_MODE = 0 (all t1 rows, then all t2 rows, box bounds: the spec of rounds 1 - 3, still a build of every step kernel)
+    against the oracle with the same switch: held to the bars of the shipped spec (the cone, which every other test of this file runs)."""
+    st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, emul_lib, n_envs=24, n_steps=10, spec=dict(friction_mode=0))
+    print('friction_mode=0: config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
 
 
 def test_friction_mode_switch_is_validated(model_blob, mocap_table, emul_lib):
-    """ll_set_spec_param(LLM_SPEC_FRICTION_MODE): the engine has the spec's pyramid (0) and the cone-coupled solve (2, flat-terrain PMC kernels);
-    the oracle-only modes and the cone on an obstacle engine are refused loudly, nothing is silently ignored."""
+    """ll_set_spec_param / ll_epmc_set_spec_param / ll_sepmc_set_spec_param (LLM_SPEC_FRICTION_MODE): every engine has the cone-coupled solve (2,
+    the default: LLM_FRICTION_MODE) and the pyramid (0); the oracle-only modes are refused loudly, nothing is silently ignored."""
     from lifelike_agility_and_play_amd import capi
-    E = pc.make_engine(model_blob, mocap_table, 4, emul_lib)
-    assert E.get_spec('friction_mode') == 0.0
-    for bad in (1, 3, -1, 0.5):
-        with pytest.raises(capi.LLError):
-            E.set_spec(friction_mode=bad)
-    E.set_spec(friction_mode=2); assert E.get_spec('friction_mode') == 2.0
-    E.set_spec(friction_mode=0); assert E.get_spec('friction_mode') == 0.0
-    E.close()
-    E = pc.make_engine(model_blob, mocap_table, 4, emul_lib, set_obstacle=1)
-    with pytest.raises(capi.LLError):
-        E.set_spec(friction_mode=2)
-    E.close()
+    import epmc_parity_common as ec
+    import sepmc_parity_common as SC
+    engines = [pc.make_engine(model_blob, mocap_table, 4, emul_lib), pc.make_engine(model_blob, mocap_table, 4, emul_lib, set_obstacle=1),
+               ec.make_engine(ec.env_config(1), 4, emul_lib), SC.make_engine(SC.env_config((0, 0, 0)), 2, emul_lib)]
+    for E in engines:
+        assert E.get_spec('friction_mode') == 2.0 == capi.LLM_FRICTION_MODE
+        for bad in (1, 3, -1, 0.5):
+            with pytest.raises(capi.LLError):
+                E.set_spec(friction_mode=bad)
+        E.set_spec(friction_mode=0); assert E.get_spec('friction_mode') == 0.0
+        E.set_spec(friction_mode=2); assert E.get_spec('friction_mode') == 2.0
+        E.close()

@@ -363,13 +363,14 @@ def test_belly_landing_on_edges_does_not_sink(golden, orc, model_blob, mocap_tab
 def test_bullet_audit_switches(golden, orc, model_blob, mocap_table):
     """The round-3 audit switches of the oracle (include/llenv_model.h LLM_SPEC_FRICTION_MODE / ROW_ORDER / MAX_COORD_VEL / LIMIT_ERP) are
     variants of the SAME constrained problem: a sliding robot obeys their friction bound (box for modes 0 / 1, cone for mode 2), a standing one
-    carries its weight under each of them, the orderings change individual multipliers but not the settled stance; and they default to off."""
+    carries its weight under each of them, the orderings change individual multipliers but not the settled stance; the friction mode defaults to the
+    cone (2), the others to off."""
     from oracle import oracle as O
     dt = 0.002
     w = 13.000210501828224 * 9.80665
     ref_z = None
     try:
-        for spec in (dict(), dict(friction_mode=1), dict(friction_mode=2), dict(row_order=1), dict(friction_mode=2, row_order=1),
+        for spec in (dict(), dict(friction_mode=0), dict(friction_mode=1), dict(row_order=1), dict(friction_mode=0, row_order=1),
                      dict(max_coord_vel=100.0), dict(limit_erp=0.1)):
             O.reset_spec(); O.set_spec(**spec)
             B = make_oracle_batch(orc, model_blob, mocap_table)
@@ -384,7 +385,7 @@ def test_bullet_audit_switches(golden, orc, model_blob, mocap_table):
                 for c in range(nc):
                     ln, l1, l2 = lam[12 + 3 * c: 15 + 3 * c]
                     assert ln >= 0
-                    if spec.get('friction_mode') == 2:
+                    if spec.get('friction_mode', 2) == 2:
                         assert np.hypot(l1, l2) <= 0.45 * ln + 1e-12, spec         # inside the cone
                     else:
                         assert abs(l1) <= 0.45 * ln + 1e-12 and abs(l2) <= 0.45 * ln + 1e-12, spec
@@ -399,4 +400,4 @@ def test_bullet_audit_switches(golden, orc, model_blob, mocap_table):
     import ctypes
     get = O.lib().orc_get_spec_param
     get.restype = ctypes.c_double
-    assert get(13) == 0.0 and get(14) == 0.0 and get(15) == 1e30 and get(18) == 2.0
+    assert get(13) == 2.0 and get(14) == 0.0 and get(15) == 1e30 and get(18) == 2.0          # (13: LLM_FRICTION_MODE, the cone, since round 4)

@@ -56,6 +56,14 @@ def test_pair_physics_against_oracle(emul_lib):
     print(SC.check_pair_physics_against_oracle(emul_lib))
 
 
+def test_pyramid_friction_variant(emul_lib):
+    """LLM_SPEC_FRICTION_MODE = 0 (ll_sepmc_set_spec_param: the pyramid of rounds 1 - 3) against the two-robot oracle under the same switch"""
+    import epmc_parity_common as ec
+    with ec.spec_variant(friction_mode=0):
+        print(SC.check_pair_physics_against_oracle(emul_lib))
+        SC.check_multi_step_launch(emul_lib)
+
+
 def test_reset_of_a_subset_of_arenas(emul_lib):
     """ll_sepmc_reset(arena_ids): only the listed arenas are re-seeded (new arena, roles, flag, poses, zeroed history); the
     others keep their state, episode scalars and observations bit for bit."""

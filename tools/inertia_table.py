@@ -26,7 +26,7 @@ def main():
     ap.add_argument('--engine', action='store_true'); ap.add_argument('--oracle', action='store_true')
     ap.add_argument('--pmc-episodes', type=int, default=0); ap.add_argument('--epmc-episodes', type=int, default=0)
     ap.add_argument('--arenas', type=int, default=0); ap.add_argument('--arena-steps', type=int, default=900)
-    ap.add_argument('--spec', default='', help='oracle legs: spec overrides key=value,... (include/llenv_model.h LLM_SPEC_*)')
+    ap.add_argument('--spec', default='', help='spec overrides key=value,... (include/llenv_model.h LLM_SPEC_*); engine legs take the switches the engine carries')
     ap.add_argument('--kinds', default=','.join(KINDS)); ap.add_argument('--skip', default='')
     args = ap.parse_args()
     spec = {k: float(v) for k, v in (kv.split('=') for kv in args.spec.split(',') if kv)}
@@ -49,7 +49,8 @@ def main():
             import rollout_epmc_policy as R
             import rollout_sepmc_policy as RS
             t = time.time()
-            e = DT.run_engine(pol, blob, table, args.pmc_episodes or 4096, {}, 11)
+            os.environ['LL_SPEC'] = args.spec                   # (the EPMC / SEPMC rollouts read it)
+            e = DT.run_engine(pol, blob, table, args.pmc_episodes or 4096, spec, 11)
             cells = ['%.4f' % e['reward'], '%.3f' % e['tracked'], '%.1f' % e['length']]
             for which in ('hurdle', 'cube', 'hole'):
                 n = args.epmc_episodes or 1024
@@ -59,7 +60,7 @@ def main():
             o = RS.rollout(args.arenas or 512, 1000)
             why = o['why']; fin = why != 0; tot = max(1, int(fin.sum()))
             cells.append('%.3f / %.3f / %.3f (%.0f) of %d' % (((why & 8) != 0).sum() / tot, ((why & 1) != 0).sum() / tot, ((why & 2) != 0).sum() / tot, o['steps'][fin].mean(), tot))
-            print('| engine (float32 HIP) | %s | %s |' % (kind, ' | '.join(cells)), flush=True)
+            print('| engine (float32 HIP)%s | %s | %s |' % (', ' + args.spec if args.spec else '', kind, ' | '.join(cells)), flush=True)
             print('engine legs under %s: %.0f s' % (kind, time.time() - t), file=sys.stderr)
         if args.oracle:
             t = time.time()

@@ -31,6 +31,7 @@ def rollout(which, n, horizon, lib_path=None, gates='ifou', forget_bias=1.0, see
     import lifelike_agility_and_play_amd as lla
     from oracle.epmc_policy import EpmcPolicy
     env = lla.create_playground_game(**env_config(ELEMENT[which], n, seed, lib_path))
+    env.engine.set_spec(**{k: float(v) for k, v in (kv.split('=') for kv in os.environ.get('LL_SPEC', '').split(',') if kv)})   # e.g. LL_SPEC=friction_mode=0
     pol = EpmcPolicy(weights or os.path.join(ROOT, 'tests', 'golden', 'epmc_policy_%s.npz' % which), n, forget_bias=forget_bias, gates=gates)
     obs = env.reset()
     x0 = env.engine.state()[:, 0].copy()

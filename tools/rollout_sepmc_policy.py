@@ -29,6 +29,8 @@ def rollout(n, horizon, lib_path=None, seed=0, spec=None):
     import lifelike_agility_and_play_amd as lla
     from oracle.sepmc_policy import SepmcPolicy
     env = lla.create_chase_tag_game(**env_config(n, seed, lib_path))
+    env.engine.set_spec(**{k: float(v) for k, v in (kv.split('=') for kv in os.environ.get('LL_SPEC', '').split(',') if kv)})   # e.g. LL_SPEC=friction_mode=0
+    env.engine.set_spec(**(spec or {}))
     pol = SepmcPolicy(os.path.join(ROOT, 'tests', 'golden', 'sepmc_policy.npz'), 2 * n)
     obs = env.reset()
     p0 = env.engine.state()[:, :, 0:2].copy()

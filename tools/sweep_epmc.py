@@ -18,6 +18,7 @@ for item in sys.argv[1].split(','):
         else:
             E.step_random_n(math.exp(-2), spl)
     E = epmc_capi.EpmcEngine(epmc_capi.make_epmc_config(n, env_config(el), auto_reset=1, seed=1), blob, lib_path=os.environ.get('LL_LIB'))
+    E.set_spec(**{k: float(v) for k, v in (kv.split('=') for kv in os.environ.get('LL_SWEEP_SPEC', '').split(',') if kv)})   # e.g. LL_SWEEP_SPEC=friction_mode=2
     E.reset()
     for _ in range(max(2, 32 // spl)):
         go()
