@@ -49,6 +49,15 @@ def static_info():
 
 STATIC, LDS_BYTES = static_info()
 traffic_all = {}
+def is_multi(name):
+    """template argument MULTI = true: pmc_step_kernel<OCC, OBST, MULTI, CONE>, epmc_step_kernel / sepmc_step_kernel<OCC, MULTI, CONE>"""
+    m = re.search(r'(s?e?pmc)_step_kernel<([^>]*)>', name)
+    if not m:
+        return False
+    args = [a.strip() for a in m.group(2).split(',')]
+    return args[2 if m.group(1) == 'pmc' else 1] == 'true'
+
+
 for KERNEL, prefix, benchlog in (('pmc_step_kernel', '', 'bench.log'), ('epmc_step_kernel', 'epmc_', 'epmc_bench.log'), ('sepmc_step_kernel', 'sepmc_', 'sepmc_bench.log')):
     counters, meta = {}, {}
     if not glob.glob(os.path.join(src, prefix + 'pmc_sq/**/*counter_collection.csv'), recursive=True):
@@ -58,8 +67,8 @@ for KERNEL, prefix, benchlog in (('pmc_step_kernel', '', 'bench.log'), ('epmc_st
         rows = [r for r in csv.DictReader(open(one(prefix + sub + '/**/*counter_collection.csv'))) if re.search(r'(^|[^a-z])' + KERNEL, r['Kernel_Name'])]
         # the command runs the contract region as multi-step launches (template argument MULTI = true) and, since round 4, a short
         # one-launch-per-step leg beside it: the counters are those of the contract region's kernel
-        if any(', true>' in r['Kernel_Name'] for r in rows):
-            rows = [r for r in rows if ', true>' in r['Kernel_Name']]
+        if any(is_multi(r['Kernel_Name']) for r in rows):
+            rows = [r for r in rows if is_multi(r['Kernel_Name'])]
         for row in rows:
             k = row['Counter_Name']
             acc[k] = acc.get(k, 0.0) + float(row['Counter_Value']); n[k] = n.get(k, 0) + 1
@@ -97,7 +106,7 @@ for KERNEL, prefix, benchlog in (('pmc_step_kernel', '', 'bench.log'), ('epmc_st
                            'counters_file': 'profiles/%s_%s_counters.json' % (tag, KERNEL)}
     statsf = os.path.join(dst, '%s_%skernel_stats.csv' % (tag, prefix))
     for row in csv.DictReader(open(statsf)):
-        if re.search(r'(^|[^a-z])' + KERNEL, row['Name']) and (spl == 1 or ', true>' in row['Name']):
+        if re.search(r'(^|[^a-z])' + KERNEL, row['Name']) and (spl == 1 or is_multi(row['Name'])):
             print('rocprofv3: %s  calls %s  avg %.1f us per launch = %.2f us per control step  | bench HIP events: %.2f us per control step' % (
                 row['Name'], row['Calls'], float(row['AverageNs']) / 1e3, float(row['AverageNs']) / 1e3 / spl, rl['kernel_avg_ms'] * 1e3))
     print('  traffic %.2f MB per launch (algorithmic %.2f MB); %.0f instructions on %.0f issue slots per wave per control step; value %.3g %s' % (
