@@ -66,6 +66,7 @@ LL_HD bool eq_(int a, int b) { return a == b; }
 }  // namespace lm
 
 #define PMC_ROW 16   // lanes per environment
+#define CONE_LDS_AT 64        // row-scratch word where a row's cone cross scalars live during the substeps (16 lanes x 32 words; GpuLanes::cone_store)
 #define PMC_ROW_SCRATCH 688   // floats of LDS scratch per env row (EPMC: 40 boxes x 8, three ray lists of 10, 16 and 12 records, 64 spare: epmc_step.hpp)
 
 #if defined(__HIPCC__)
@@ -138,6 +139,18 @@ struct GpuLanes {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
     return dst;
+  }
+  // ---- the cone round's cross scalars in the row scratch (WithConeInLds: the 256-register builds have no room for their 32 registers) ----
+  // word CONE_LDS_AT + ((kind * 4 + S) * 16 + lane) * 4 + t holds scalar [4 t + S] of kind (0: ConeX::n12, 1: n21) of this lane: one ds_write_b128 /
+  // ds_read_b128 per (kind, turn block S), consecutive lanes 16 B apart.  The words are idle during the substeps: in front of them the (at most eight)
+  // near-box records the contact search reads, behind them the ray lists of the observation phase and the parked episode scalars (epmc_step.hpp).
+  static constexpr bool kConeInLds = false;
+  LL_D void cone_store(int kind, int S, F a, F b, F c, F d) const {
+    *reinterpret_cast<float4*>(row_scratch() + CONE_LDS_AT + ((kind * 4 + S) * PMC_ROW + lane16_) * 4) = make_float4(a, b, c, d);
+  }
+  LL_D void cone_load(int kind, int S, F& a, F& b, F& c, F& d) const {
+    const float4 v = *reinterpret_cast<const float4*>(row_scratch() + CONE_LDS_AT + ((kind * 4 + S) * PMC_ROW + lane16_) * 4);
+    a = v.x; b = v.y; c = v.z; d = v.w;
   }
   LL_D void row_sync() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }   // lane 0's stores visible to the row
   // Park n row-uniform floats in the row's LDS scratch (word `at`) and take them back later: between the two calls their registers are
@@ -617,6 +630,13 @@ struct WithShapePrefetch : Base {
 // the row-parallel list building; the 256-register builds LOSE 11 % (EPMC 65536 envs) and 18 % (SEPMC 32768 arenas) to the extra live
 // registers, so they keep one ray at a time.  The SEPMC one-wave-per-SIMD kernel (256 + 255 registers) fails its arena invariants on the
 // GPU with 7 and passes with 3 (tools/diag_sepmc_rays.py): it runs 3.
+// the cone round keeps its cross scalars in the row's LDS scratch instead of 32 registers (the two-waves-per-SIMD builds; launch with the row scratch allocated)
+template <class Base>
+struct WithConeInLds : Base {
+  using Base::Base;
+  static constexpr bool kConeInLds = true;
+};
+
 template <class Base, int N>
 struct WithRayChunk : Base {
   using Base::Base;

@@ -41,6 +41,12 @@ typedef GpuLanesPinned<LC_COUNT> GpuLanes1;                   // the per-leg tab
 #define LL_PIN_PMC 1
 #endif
 // re-reading of the argument block (lanes.hpp WithParamsReload), per kernel by A/B; the one-wave-per-SIMD SEPMC kernels keep the plain lane policy
+#ifndef LL_CONE_LDS
+#define LL_CONE_LDS 1   // the larger-batch PMC / EPMC builds keep the cone round's cross scalars in the row's LDS scratch (lanes.hpp WithConeInLds):
+#endif                  // 65536 envs 2.305 -> 2.255 ms (PMC), 3.862 -> 3.724 ms (EPMC hurdles); SEPMC 5.035 -> 5.079 ms at 32768 arenas: not there (profiles/r04_cone_lds_ab.txt)
+#ifndef LL_CONE_LDS_SEPMC
+#define LL_CONE_LDS_SEPMC 0
+#endif
 #ifndef LL_PARK
 #define LL_PARK 1      // the larger-batch EPMC / SEPMC builds park their per-row scalars in LDS across the substep loop
 #endif
@@ -148,7 +154,8 @@ template <int OCC, bool OBST = false, bool MULTI = false, bool CONE = false>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);      // one env = one 16-lane DPP row
-  typedef WithParamsReload<typename std::conditional<OCC == 1, GpuLanesPmc1, GpuLanes>::type, LL_RELOAD_PMC> Lanes;
+  typedef WithParamsReload<typename std::conditional<OCC == 1, GpuLanesPmc1, GpuLanes>::type, LL_RELOAD_PMC> Lanes0;
+  typedef typename std::conditional<(OCC == 2 && CONE && LL_CONE_LDS), WithConeInLds<Lanes0>, Lanes0>::type Lanes;     // (launched with the row scratch allocated: launch_step)
   Lanes ln(lds);
   if constexpr (OCC == 1) ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS, P.basec);   // all 64 lanes copy, also those without an env
   else ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
@@ -200,7 +207,8 @@ template <int OCC, bool MULTI = false, bool CONE = false>   // CONE: see pmc_ste
 __global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, EpmcParams E) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
-  typedef WithRayChunk<WithShapePrefetch<WithParamsReload<typename std::conditional<OCC == 1 && LL_PIN_EPMC, GpuLanes1, GpuLanes>::type, (OCC == 1 ? LL_RELOAD_EPMC1 : LL_RELOAD_EPMC2)>, OCC == 2>, (OCC == 1 ? (MULTI ? 7 : 3) : 1)> Lanes;   // (single launches at 7: 68 B of scratch)
+  typedef WithRayChunk<WithShapePrefetch<WithParamsReload<typename std::conditional<OCC == 1 && LL_PIN_EPMC, GpuLanes1, GpuLanes>::type, (OCC == 1 ? LL_RELOAD_EPMC1 : LL_RELOAD_EPMC2)>, OCC == 2>, (OCC == 1 ? (MULTI ? 7 : 3) : 1)> Lanes0;   // (single launches at 7: 68 B of scratch)
+  typedef typename std::conditional<(OCC == 2 && CONE && LL_CONE_LDS), WithConeInLds<Lanes0>, Lanes0>::type Lanes;
   Lanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
   if (env0 >= P.n_envs) return;
@@ -237,7 +245,8 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P,
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int row0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
   typedef typename std::conditional<OCC == 1 && LL_PIN_SEPMC, GpuLanes1, GpuLanes>::type PlainLanes;
-  typedef WithRayChunk<WithShapePrefetch<typename std::conditional<(OCC == 2 && LL_RELOAD_SEPMC2), WithParamsReload<PlainLanes, LL_RELOAD_SEPMC2>, PlainLanes>::type, OCC == 1>, (OCC == 1 ? LL_SEPMC_RAY_CHUNK : 1)> Lanes;   // (chunk 7 fails the arena invariants on the GPU in this kernel -- at 256 + 255 registers; 3 is what was validated: profiles/r04_ray_ab.txt)
+  typedef WithRayChunk<WithShapePrefetch<typename std::conditional<(OCC == 2 && LL_RELOAD_SEPMC2), WithParamsReload<PlainLanes, LL_RELOAD_SEPMC2>, PlainLanes>::type, OCC == 1>, (OCC == 1 ? LL_SEPMC_RAY_CHUNK : 1)> Lanes0;   // (chunk 7 fails the arena invariants on the GPU in this kernel -- at 256 + 255 registers; 3 is what was validated: profiles/r04_ray_ab.txt)
+  typedef typename std::conditional<(OCC == 2 && CONE && LL_CONE_LDS_SEPMC), WithConeInLds<Lanes0>, Lanes0>::type Lanes;
   Lanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
   if (row0 >= P.n_envs) return;
@@ -462,8 +471,8 @@ struct HipBackend {
     } else if (P.friction_mode == 2) {
       if (one) { if (multi) hipLaunchKernelGGL((pmc_step_kernel<1, false, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
                  else       hipLaunchKernelGGL((pmc_step_kernel<1, false, false, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P); }
-      else     { if (multi) hipLaunchKernelGGL((pmc_step_kernel<2, false, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
-                 else       hipLaunchKernelGGL((pmc_step_kernel<2, false, false, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P); }
+      else     { if (multi) hipLaunchKernelGGL((pmc_step_kernel<2, false, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);      // (row scratch: WithConeInLds)
+                 else       hipLaunchKernelGGL((pmc_step_kernel<2, false, false, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P); }
     } else {
       if (one) { if (multi) hipLaunchKernelGGL((pmc_step_kernel<1, false, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
                  else       hipLaunchKernelGGL((pmc_step_kernel<1, false, false>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P); }

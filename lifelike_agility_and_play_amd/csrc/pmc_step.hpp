@@ -351,10 +351,23 @@ struct Pmc {
     F w2 = L::vel_dot(r2.c, r2.ca01, r2.ca23, r2.cb01, r2.cj01, r2.cj23, VA, VB, VJ);
     F S1 = lm::nfma_(w1, r1.inv, r1.lam), S2 = lm::nfma_(w2, r2.inv, r2.lam);
     F d1 = zero, d2 = zero;
-    ln.template cone_turns4<0>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, cx.n12, cx.n21, r2.nk);
-    ln.template cone_turns4<1>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, cx.n12, cx.n21, r2.nk);
-    ln.template cone_turns4<2>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, cx.n12, cx.n21, r2.nk);
-    ln.template cone_turns4<3>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, cx.n12, cx.n21, r2.nk);
+    if (L::kConeInLds) {
+      // the cross scalars of turn block S come from the row's LDS scratch (substep_impl put them there), one block ahead of their use
+      F a[16], b[16];
+      ln.cone_load(0, 0, a[0], a[4], a[8], a[12]); ln.cone_load(1, 0, b[0], b[4], b[8], b[12]);
+      ln.cone_load(0, 1, a[1], a[5], a[9], a[13]); ln.cone_load(1, 1, b[1], b[5], b[9], b[13]);
+      ln.template cone_turns4<0>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, a, b, r2.nk);
+      ln.cone_load(0, 2, a[2], a[6], a[10], a[14]); ln.cone_load(1, 2, b[2], b[6], b[10], b[14]);
+      ln.template cone_turns4<1>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, a, b, r2.nk);
+      ln.cone_load(0, 3, a[3], a[7], a[11], a[15]); ln.cone_load(1, 3, b[3], b[7], b[11], b[15]);
+      ln.template cone_turns4<2>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, a, b, r2.nk);
+      ln.template cone_turns4<3>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, a, b, r2.nk);
+    } else {
+      ln.template cone_turns4<0>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, cx.n12, cx.n21, r2.nk);
+      ln.template cone_turns4<1>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, cx.n12, cx.n21, r2.nk);
+      ln.template cone_turns4<2>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, cx.n12, cx.n21, r2.nk);
+      ln.template cone_turns4<3>(S1, S2, d1, d2, r1.lam, r2.lam, lim, r1.nk, cx.n12, cx.n21, r2.nk);
+    }
     L::vel_commit2(d1, r1.lam, r1.ca01, r1.ca23, r1.cb01, r1.cj01, r1.cj23, d2, r2.lam, r2.ca01, r2.ca23, r2.cb01, r2.cj01, r2.cj23, VA, VB, VJ);   // (also lam += d)
   }
 
@@ -1159,6 +1172,11 @@ struct Pmc {
         contact_row(ln, r2, ut2, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid, g2, j2);
         cross_gram(ln, r1.inv, g1, j1, g2, j2, cx.n12);
         cross_gram(ln, r2.inv, g2, j2, g1, j1, cx.n21);
+        if (L::kConeInLds)                                   // the 256-register builds: the 32 scalars wait in the row's LDS scratch, the round reads them block by block
+          for (int S = 0; S < 4; S++) {
+            ln.cone_store(0, S, cx.n12[S], cx.n12[4 + S], cx.n12[8 + S], cx.n12[12 + S]);
+            ln.cone_store(1, S, cx.n21[S], cx.n21[4 + S], cx.n21[8 + S], cx.n21[12 + S]);
+          }
       } else {
         contact_row(ln, r1, ut1, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid);
         contact_row(ln, r2, ut2, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid);

@@ -13,6 +13,7 @@
 #include "../../lifelike_agility_and_play_amd/csrc/pmc_step.hpp"
 
 typedef Pmc<HostLanes> K;
+typedef WithConeInLdsHost<HostLanes> HostLanesLds;      // what the larger-batch GPU builds run (LL_EMUL_PARK): the cone round's cross scalars through the row scratch
 
 struct HostBackend {
   explicit HostBackend(int) {}
@@ -35,7 +36,12 @@ struct HostBackend {
       for (int env = 0; env < P.n_envs; env++) {
         fN act[3];
         for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
-        if (P.set_obstacle && P.friction_mode == 2) K::step_env<true, true>(ln, P, env, act, sl);
+        if (P.friction_mode == 2 && getenv("LL_EMUL_PARK")) {                 // the larger-batch GPU build's variant (tests)
+          HostLanesLds lq(P.candc);
+          if (P.set_obstacle) Pmc<HostLanesLds>::step_env<true, true>(lq, P, env, act, sl);
+          else Pmc<HostLanesLds>::step_env<false, true>(lq, P, env, act, sl);
+        }
+        else if (P.set_obstacle && P.friction_mode == 2) K::step_env<true, true>(ln, P, env, act, sl);
         else if (P.set_obstacle) K::step_env<true>(ln, P, env, act, sl);
         else if (P.friction_mode == 2) K::step_env<false, true>(ln, P, env, act, sl);
         else K::step_env<false>(ln, P, env, act, sl);
@@ -101,7 +107,7 @@ struct HostBackend {
         fN act[3];
         for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
         const bool park = getenv("LL_EMUL_PARK") != nullptr, cone = P.friction_mode == 2;      // park: the larger-batch GPU build's variant (tests)
-        if (park) { if (cone) Epmc<HostLanes>::step_env<true, true>(ln, P, E, env, act); else Epmc<HostLanes>::step_env<true>(ln, P, E, env, act); }
+        if (park) { if (cone) { HostLanesLds lq(P.candc); Epmc<HostLanesLds>::step_env<true, true>(lq, P, E, env, act); } else Epmc<HostLanes>::step_env<true>(ln, P, E, env, act); }
         else      { if (cone) Epmc<HostLanes>::step_env<false, true>(ln, P, E, env, act); else Epmc<HostLanes>::step_env(ln, P, E, env, act); }
       }
     }
@@ -112,14 +118,14 @@ struct HostBackend {
       Epmc<HostLanes>::reset_env(ln, P, E, ids ? ids[i] : i, draws ? draws + (long)i * EPMC_MAX_DRAWS : nullptr, prev_orn ? prev_orn + (long)i * 4 : nullptr);
   }
   // SEPMC: the two robots of an arena run as two threads that meet in HostLanes::peer (on the GPU: two rows of one wave)
-  template <class FN>
+  template <class LANES = HostLanes, class FN>
   static void run_pairs(const StepParams& P, int n_rows, FN fn) {
     for (int i = 0; i + 1 < n_rows; i += 2) {
       PairLink link;
       std::thread t[2];
       for (int side = 0; side < 2; side++)
         t[side] = std::thread([&, side]() {
-          HostLanes ln(P.candc);
+          LANES ln(P.candc);
           ln.link_ = &link; ln.side_ = side;
           fn(ln, i + side);
         });
@@ -129,13 +135,21 @@ struct HostBackend {
   void launch_sepmc_step(const StepParams& P, const SepmcParams& S) {
     for (int sl = 0; sl < P.n_steps; sl++) {
       draw_step_actions(P, sl);
-      run_pairs(P, P.n_envs, [&](HostLanes& ln, int row) {
-        fN act[3];
-        for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)row * 12 + j, 3);
-        const bool park = getenv("LL_EMUL_PARK") != nullptr, cone = P.friction_mode == 2;
-        if (park) { if (cone) Sepmc<HostLanes>::step_env<true, true>(ln, P, S, row, act); else Sepmc<HostLanes>::step_env<true>(ln, P, S, row, act); }
-        else      { if (cone) Sepmc<HostLanes>::step_env<false, true>(ln, P, S, row, act); else Sepmc<HostLanes>::step_env(ln, P, S, row, act); }
-      });
+      const bool park = getenv("LL_EMUL_PARK") != nullptr, cone = P.friction_mode == 2;
+      if (park && cone)
+        run_pairs<HostLanesLds>(P, P.n_envs, [&](HostLanesLds& ln, int row) {
+          fN act[3];
+          for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)row * 12 + j, 3);
+          Sepmc<HostLanesLds>::step_env<true, true>(ln, P, S, row, act);
+        });
+      else
+        run_pairs(P, P.n_envs, [&](HostLanes& ln, int row) {
+          fN act[3];
+          for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)row * 12 + j, 3);
+          if (park) Sepmc<HostLanes>::step_env<true>(ln, P, S, row, act);
+          else if (cone) Sepmc<HostLanes>::step_env<false, true>(ln, P, S, row, act);
+          else Sepmc<HostLanes>::step_env(ln, P, S, row, act);
+        });
     }
   }
   void launch_sepmc_reset(const StepParams& P, const SepmcParams& S, const int32_t* ids, int n, const float* draws, const float* prev_orn) {
@@ -154,6 +168,7 @@ typedef EpmcEngine<HostBackend> EPMC_ENGINE;
 typedef SepmcEngine<HostBackend> SEPMC_ENGINE;
 #include "../../lifelike_agility_and_play_amd/csrc/sepmc_capi.inc"
 static_assert(sizeof(HostLanes::scratch_) == PMC_ROW_SCRATCH * sizeof(float), "lanes_host.hpp: the row scratch must have the size lanes.hpp states");
+static_assert(HostLanes::kConeLdsAt == CONE_LDS_AT, "lanes_host.hpp: the cone cross scalars must live where lanes.hpp puts them");
 
 extern "C" {
 // single physics substep on explicit state (staged comparison with the oracle); tgt = PD target joint angles

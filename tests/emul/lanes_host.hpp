@@ -123,6 +123,14 @@ struct HostLanes {
   const float* stage_row(const float* g, int) const { return g; }
   alignas(16) mutable float scratch_[688];   // = PMC_ROW_SCRATCH (lanes.hpp, included later); checked below
   float* row_scratch() const { return scratch_; }
+  static constexpr bool kConeInLds = false;          // (lanes.hpp WithConeInLds; emul.cpp runs that variant under LL_EMUL_PARK)
+  static constexpr int kConeLdsAt = 64;              // = CONE_LDS_AT (lanes.hpp, included later); checked in emul.cpp
+  void cone_store(int kind, int S, const F& a, const F& b, const F& c, const F& d) const {
+    for (int i = 0; i < EW; i++) { float* w = scratch_ + kConeLdsAt + ((kind * 4 + S) * 16 + i) * 4; w[0] = a.v[i]; w[1] = b.v[i]; w[2] = c.v[i]; w[3] = d.v[i]; }
+  }
+  void cone_load(int kind, int S, F& a, F& b, F& c, F& d) const {
+    for (int i = 0; i < EW; i++) { const float* w = scratch_ + kConeLdsAt + ((kind * 4 + S) * 16 + i) * 4; a.v[i] = w[0]; b.v[i] = w[1]; c.v[i] = w[2]; d.v[i] = w[3]; }
+  }
   void prepare_turn_masks() const {}
   I leg() const { iN r; for (int i = 0; i < EW; i++) r.v[i] = i >> 2; return r; }
   I sub() const { iN r; for (int i = 0; i < EW; i++) r.v[i] = i & 3; return r; }
@@ -266,4 +274,11 @@ struct HostLanes {
   static F d2f(const D& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = (float)x.v[i]; return r; }
   static F i2f(const I& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = (float)x.v[i]; return r; }
   static I f2i(const F& x) { iN r; for (int i = 0; i < EW; i++) r.v[i] = (int)x.v[i]; return r; }
+};
+
+// lanes.hpp WithConeInLds for the host lanes (emul.cpp: LL_EMUL_PARK runs the cone round's cross scalars through the row scratch)
+template <class Base>
+struct WithConeInLdsHost : Base {
+  using Base::Base;
+  static constexpr bool kConeInLds = true;
 };

@@ -148,3 +148,25 @@ def test_friction_mode_switch_is_validated(model_blob, mocap_table, emul_lib):
         E.set_spec(friction_mode=0); assert E.get_spec('friction_mode') == 0.0
         E.set_spec(friction_mode=2); assert E.get_spec('friction_mode') == 2.0
         E.close()
+
+
+def test_cone_scalars_through_the_row_scratch_equal_registers(model_blob, mocap_table, emul_lib):
+    """lanes.hpp WithConeInLds -- what the larger-batch GPU builds run: the cone round's 32 cross scalars wait in the row's LDS scratch and are read
+    block by block -- against the register version, bit for bit (the host build runs the variant under LL_EMUL_PARK; flat ground and set_obstacle)."""
+    import os
+    for kw in (dict(), dict(set_obstacle=1)):
+        A = pc.make_engine(model_blob, mocap_table, 8, emul_lib, seed=3, auto_reset=1, **kw)
+        B = pc.make_engine(model_blob, mocap_table, 8, emul_lib, seed=3, auto_reset=1, **kw)
+        A.reset(); B.reset()
+        try:
+            for t in range(25):
+                os.environ.pop('LL_EMUL_PARK', None)
+                A.step_random(pc.SIGMA)
+                os.environ['LL_EMUL_PARK'] = '1'
+                B.step_random(pc.SIGMA)
+                np.testing.assert_array_equal(A.state(), B.state())
+                np.testing.assert_array_equal(A.obs(), B.obs())
+        finally:
+            os.environ.pop('LL_EMUL_PARK', None)
+        assert np.abs(A.state()[:, 25:37]).max() > 0.1
+        A.close(); B.close()

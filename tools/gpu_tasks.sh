@@ -6,6 +6,7 @@
 #   valu      tools/valu_issue_bench.hip: wave64 VALU issue rate per SIMD at 1 .. 8 resident waves
 #   profile   tools/profile.sh (bench lines, rocprofv3 stats + PMC passes, sweeps, timeline)
 #   cone      the cone-coupled friction builds: GPU parity, kernel time, the trained tracking policy under pyramid and cone
+#   final     the -m gpu suite at HEAD, then the three bench lines and the large-batch sweep points
 #   driver    the driver's own invocation against longer runs, with and without the HBM triad first
 TARGET=${1:-tests}
 TAG=${2:-r04_$TARGET}
@@ -55,5 +56,11 @@ case $TARGET in
     for r in 1 2; do for sp in "" "friction_mode=2"; do echo "== spec '$sp' (round $r)"; LL_SWEEP_SPEC=$sp python tools/sweep.py "4096:4:10:10:32,4096:4:10:10:1,65536:4:10:10:1,65536:4:10:10:8"; done; done > $OUT/cone_sweep.txt 2>&1
     cat $OUT/cone_sweep.txt
     for v in "spec (as shipped)" "friction cone-coupled"; do python tools/deviation_table.py --engine --only "$v" 2>&1 | tail -1; done > $OUT/cone_policy.txt; cat $OUT/cone_policy.txt ;;
+  final)         # the round's closing call: the whole -m gpu suite at HEAD, then the three bench lines against the committed counters
+    gpu_tests
+    python bench.py > $OUT/bench.log 2>$OUT/bench.err; tail -c 400 $OUT/bench.log
+    for W in epmc sepmc; do python bench.py --workload $W --no-cpu-baseline > $OUT/${W}_bench.log 2>$OUT/${W}_bench.err; tail -c 300 $OUT/${W}_bench.log; done
+    python tools/sweep.py "4096:4:10:10:32,16384:4:10:10:32,65536:4:10:10:32,65536:4:10:10:1" > $OUT/sweep_tail.txt 2>&1; cat $OUT/sweep_tail.txt
+    python tools/sweep_epmc.py "65536:1:1" >> $OUT/sweep_tail.txt 2>&1; python tools/sweep_sepmc.py "32768:0:1" >> $OUT/sweep_tail.txt 2>&1; tail -2 $OUT/sweep_tail.txt ;;
   *) echo "unknown target $TARGET"; exit 2 ;;
 esac
