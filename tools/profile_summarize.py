@@ -78,8 +78,9 @@ for KERNEL, prefix, benchlog in (('pmc_step_kernel', '', 'bench.log'), ('epmc_st
         for k in acc:
             counters[k] = acc[k] / n[k]
     bench = json.loads([l for l in open(os.path.join(src, benchlog)) if l.startswith('{')][-1])
-    occ = '1' if 'Li1E' in meta['kernel_name'] or '<1' in meta['kernel_name'] else '2'
-    st = [v for k, v in STATIC.items() if ('%d%s' % (len(KERNEL), KERNEL)) in k and ('ILi%s' % occ) in k and 'Lb1' not in k]
+    targs = [a.strip() for a in re.search(r'_step_kernel<([^>]*)>', meta['kernel_name']).group(1).split(',')]      # the profiled instantiation, as rocprofv3 names it ...
+    mangled = 'ILi%sE' % targs[0] + ''.join('Lb%dE' % (a == 'true') for a in targs[1:]) + 'E'                        # ... and as the assembly does
+    st = [v for k, v in STATIC.items() if ('%d%s' % (len(KERNEL), KERNEL)) in k and mangled in k]
     meta['compiled'] = dict(st[0], dynamic_lds_bytes=LDS_BYTES[KERNEL]) if st else None
     traffic = (counters['FETCH_SIZE'] + counters['WRITE_SIZE']) * 1024.0
     rl = bench['roofline']
