@@ -375,7 +375,7 @@ def main():
                          'kernel': 'pmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
                          'kernel_avg_launch_ms': k_launch_ms, 'control_steps_per_launch': (k_steps / k_n) if k_n else None,
                          'algorithmic_bytes_per_env_step': algo_bytes, 'single_wave_issue': issue,
-                         'note': 'bound by single-wave instruction issue, not HBM (about 7.7e4 instructions per wave per step, four envs, vs 2.5 KB per env); see DESIGN.md 5.1'},
+                         'note': 'bound by single-wave instruction issue, not HBM (%s instructions per wave per step, four envs, vs 2.5 KB per env); see DESIGN.md 5.1' % ('%.1fe4' % (issue['instructions_per_wave_per_control_step'] / 1e4) if issue else 'about 8e4')},
         }
         if single is not None:
             out['single_step_launch'] = single

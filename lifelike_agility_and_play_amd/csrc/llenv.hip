@@ -47,6 +47,9 @@ typedef GpuLanesPinned<LC_COUNT> GpuLanes1;                   // the per-leg tab
 #ifndef LL_CONE_LDS_SEPMC
 #define LL_CONE_LDS_SEPMC 0
 #endif
+#ifndef LL_CONE_LDS_SEPMC1
+#define LL_CONE_LDS_SEPMC1 1   // the one-wave-per-SIMD SEPMC builds too: they are the ones that do not fit 512 registers (scratch 364 -> 184 B multi-step, 184 -> 0 single; 0.324 -> 0.318 ms)
+#endif
 #ifndef LL_PARK
 #define LL_PARK 1      // the larger-batch EPMC / SEPMC builds park their per-row scalars in LDS across the substep loop
 #endif
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P,
   const int row0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
   typedef typename std::conditional<OCC == 1 && LL_PIN_SEPMC, GpuLanes1, GpuLanes>::type PlainLanes;
   typedef WithRayChunk<WithShapePrefetch<typename std::conditional<(OCC == 2 && LL_RELOAD_SEPMC2), WithParamsReload<PlainLanes, LL_RELOAD_SEPMC2>, PlainLanes>::type, OCC == 1>, (OCC == 1 ? LL_SEPMC_RAY_CHUNK : 1)> Lanes0;   // (chunk 7 fails the arena invariants on the GPU in this kernel -- at 256 + 255 registers; 3 is what was validated: profiles/r04_ray_ab.txt)
-  typedef typename std::conditional<(OCC == 2 && CONE && LL_CONE_LDS_SEPMC), WithConeInLds<Lanes0>, Lanes0>::type Lanes;
+  typedef typename std::conditional<(CONE && ((OCC == 2 && LL_CONE_LDS_SEPMC) || (OCC == 1 && LL_CONE_LDS_SEPMC1))), WithConeInLds<Lanes0>, Lanes0>::type Lanes;
   Lanes ln(lds);
   ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
   if (row0 >= P.n_envs) return;
