@@ -519,9 +519,11 @@ def check_multi_step_launch(model_blob, table, lib_path, read_ring, sizes=(24,),
         C.close()
 
 
-def check_obstacle_variant(golden, orc, model_blob, table, lib_path, n_envs=24, n_steps=60, seed=2):
+def check_obstacle_variant(golden, orc, model_blob, table, lib_path, n_envs=24, n_steps=60, seed=2, total_envs=None):
     """set_obstacle=True (PLE:173-193, :262-268, :341-346): engine vs oracle on the jump clips, random policy.  The robot does
-    not clear the box, so episodes must end with the COLLISION bit in both, at the same step."""
+    not clear the box, so episodes must end with the COLLISION bit in both, at the same step.
+    total_envs: the engine runs that many envs (above 4096: the larger-batch build of the obstacle kernel) and the oracle follows n_envs of them,
+    spread over the first, middle and last wavefronts of the grid."""
     cnt, tab = table.obstacles()
     clips = np.where(cnt > 0)[0]
     assert len(clips) == 20 and cnt.sum() == 78                          # SURVEY a21 [probe]
@@ -532,20 +534,28 @@ def check_obstacle_variant(golden, orc, model_blob, table, lib_path, n_envs=24, 
     t0 = np.array([max(0.0, tab[off[c] + rng.integers(0, cnt[c]), 3] - 0.2) for c in clip])
     t0 = np.minimum(t0, [table.frame_step * (table.clip_len[c] - table.margin - 2) for c in clip])
     kw = dict(set_obstacle=True, obstacle_height=0.2)
-    E = make_engine(model_blob, table, n_envs, lib_path, **kw)
+    N = total_envs or n_envs
+    third = n_envs // 3
+    idx = np.arange(n_envs) if not total_envs else np.concatenate([np.arange(third), N // 2 - 7 + np.arange(third), N - (n_envs - 2 * third) + np.arange(n_envs - 2 * third)])
+    reps = (N + n_envs - 1) // n_envs
+    clip_all, t0_all = np.tile(clip, reps)[:N], np.tile(t0, reps)[:N]
+    clip_all[idx], t0_all[idx] = clip, t0
+    E = make_engine(model_blob, table, N, lib_path, **kw)
     B = make_oracle_batch(orc, model_blob, table, n_envs=n_envs, **kw)
-    E.reset(clip=clip, t0=t0)
+    E.reset(clip=clip_all, t0=t0_all)
+    es0 = E.state()
     for i in range(n_envs):
         B.reset_env(i, int(clip[i]), float(t0[i]))
-        B.set_state(i, E.state()[i].astype(np.float64))
+        B.set_state(i, es0[idx[i]].astype(np.float64))
     alive = np.ones(n_envs, bool)
     n_coll = mism = 0
     cfg_err, vel_err = [], []
     for t in range(n_steps):
-        act = (rng.normal(size=(n_envs, 12)) * SIGMA).astype(np.float32)
-        E.step_host(act)
-        r, d, why = E.reward_done()
-        es = E.state()
+        act_all = (rng.normal(size=(N, 12)) * SIGMA).astype(np.float32)
+        E.step_host(act_all)
+        r, d, why = (x[idx] for x in E.reward_done())
+        es = E.state()[idx]
+        act = act_all[idx]
         for i in range(n_envs):
             if not alive[i]:
                 continue

@@ -202,6 +202,8 @@ def test_trained_reference_policy_tracks_in_our_simulator():
 def test_obstacle_variant(golden, orc, model_blob, mocap_table):
     n = pc.check_obstacle_variant(golden, orc, model_blob, mocap_table, None)
     print('obstacle variant: %d episodes ended on the box' % n)
+    n = pc.check_obstacle_variant(golden, orc, model_blob, mocap_table, None, total_envs=4096 + 128)        # pmc_step_kernel<2, true, ., .>: the larger-batch build
+    print('obstacle variant, 4224 envs: %d episodes ended on the box' % n)
 
 
 def test_scripted_episodes_against_reference_goldens(golden, model_blob, mocap_table):
