@@ -83,12 +83,12 @@
 /* ---- round 3: Bullet published-algorithm audit.  ORACLE ONLY: each moves the spec towards what btMultiBodyConstraintSolver
  * / btMultiBody do according to their published source, as far as it can be recalled here (PyBullet itself is absent); tools/deviation_table.py
  * prices them with the trained policy, tools/deviation_sepmc.py on chase-tag episodes. */
-#define LLM_SPEC_FRICTION_MODE 13       /* 0 (spec): all t1 rows, then all t2 rows, box bounds.  1: after all normal rows, the two friction rows of a
+#define LLM_SPEC_FRICTION_MODE 13       /* default LLM_FRICTION_MODE = 2.  0 (the spec of rounds 1 - 3): all t1 rows, then all t2 rows, box bounds.  1: after all normal rows, the two friction rows of a
                                            contact adjacent (t1_c, t2_c), box bounds.  2: adjacent and solved together from one velocity, clipped to the
                                            cone |(t1, t2)| <= mu * normal (resolveConeFrictionConstraintRows).  3: the spec's rounds with each friction bound
                                            shrunk to what the contact's other row leaves of the cone: the same admissible set in the kernel's round structure.
-                                           ENGINE: 0 and 2 (round 4: the flat-terrain PMC kernels have cone builds, Pmc::gs_cone_round; parity to the standing
-                                           bars); 1 and 3 exist in the oracle only */
+                                           ENGINE: 2 (the default, LLM_FRICTION_MODE) and 0; every step kernel has both builds (Pmc::gs_cone_round; parity to the
+                                           standing bars under either); 1 and 3 exist in the oracle only */
 #define LLM_SPEC_ROW_ORDER 14           /* 0 (spec): slot-major (slot 0 of legs 0..3, slot 1, ...).  1: per body pair as a manifold would list them --
                                            contacts sorted by link index, then candidate index */
 #define LLM_SPEC_MAX_COORD_VEL 15       /* btMultiBody::m_maxCoordinateVelocity: every generalized velocity clipped to +- this after the free update

@@ -85,8 +85,9 @@ struct StepParams {
   float max_depen;          // cap on the penetration-recovery speed of a contact row (LLM_MAX_DEPEN_SPEED)
   float self_margin;        // leg-leg capsule rows start within this distance (LLM_SELF_MARGIN)
   int32_t friction_dirs;    // LLM_SPEC_FRICTION_DIRS: 1 = first friction direction along the contact point's sliding velocity (default 0: btPlaneSpace1)
-  int32_t friction_mode;    // LLM_SPEC_FRICTION_MODE: 0 = the spec's pyramid (all t1 rows, then all t2 rows, box bounds); 2 = the two friction rows of a contact solved
-                            // together inside the cone (Bullet's published default; PMC flat-terrain kernels only, selected at launch: Pmc::gs_cone_round)
+  int32_t friction_mode;    // LLM_SPEC_FRICTION_MODE: 2 (LLM_FRICTION_MODE, the spec since round 4) = the two friction rows of a contact solved together inside the
+                            // cone (Bullet's published default; Pmc::gs_cone_round); 0 = the pyramid of rounds 1 - 3 (all t1 rows, then all t2 rows, box bounds).
+                            // Every step kernel has both builds; the launch picks
   int32_t pad_fm;
   int32_t max_contacts, max_self;   // deepest-K per leg (LLM_MAX_CONTACTS_PER_LEG), self-collision rows per robot (LLM_MAX_SELF)
   double dt_d, frame_step, policy_step, sample_factor;
