@@ -630,17 +630,18 @@ struct WithShapePrefetch : Base {
 // the row-parallel list building; the 256-register builds LOSE 11 % (EPMC 65536 envs) and 18 % (SEPMC 32768 arenas) to the extra live
 // registers, so they keep one ray at a time.  The SEPMC one-wave-per-SIMD kernel (256 + 255 registers) fails its arena invariants on the
 // GPU with 7 and passes with 3 (tools/diag_sepmc_rays.py): it runs 3.
-// the cone round keeps its cross scalars in the row's LDS scratch instead of 32 registers (the two-waves-per-SIMD builds; launch with the row scratch allocated)
-template <class Base>
-struct WithConeInLds : Base {
-  using Base::Base;
-  static constexpr bool kConeInLds = true;
-};
-
 template <class Base, int N>
 struct WithRayChunk : Base {
   using Base::Base;
   static constexpr int kRayChunk = N;
+};
+
+// the cone round keeps its cross scalars in the row's LDS scratch instead of 32 registers (the two-waves-per-SIMD PMC / EPMC builds and the
+// one-wave-per-SIMD SEPMC builds, llenv.hip LL_CONE_LDS*; the launch must allocate the row scratch)
+template <class Base>
+struct WithConeInLds : Base {
+  using Base::Base;
+  static constexpr bool kConeInLds = true;
 };
 
 #define LL_FMAC_RBCAST(L_)                                                                                               \
