@@ -108,6 +108,10 @@
 #define LLM_SPEC_GYRO 21                /* 1 (spec, btMultiBody::m_useGyroTerm = true as its constructor sets it): the gyroscopic torque w x (I_c w) of every link is part
                                            of the velocity-product forces.  0: left out (Bullet's setUseGyroTerm(false)); the remaining terms -- m w x v_c, the
                                            Coriolis accelerations of the joints -- stay.  ORACLE ONLY (round 4: the third audit item of the bars policy) */
-#define LLM_SPEC_COUNT 22
+#define LLM_SPEC_FRICTION_KEEP 22       /* 0 (spec): the friction rows of a contact whose normal multiplier is zero are clipped to zero (bound mu * 0).  1: they are
+                                           left as they are in that sweep -- btMultiBodyConstraintSolver::solveSingleIteration as recalled guards the friction solve of a
+                                           contact with "if (totalImpulse > 0)" --, so friction gathered in earlier iterations of the substep survives a normal row that has
+                                           let go.  ORACLE ONLY (round 4, priced in profiles/r04_cone_decision.md) */
+#define LLM_SPEC_COUNT 23
 
 #endif

@@ -302,6 +302,7 @@ inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
     case LLM_SPEC_ERP: P.erp = (float)v; break;
     case LLM_SPEC_CONTACT_MARGIN: P.margin_dist = (float)v; break;
     case LLM_SPEC_SELF_FRICTION:
+    case LLM_SPEC_FRICTION_KEEP:
     case LLM_SPEC_WARM_START:
       if (v != 0.0) return "this switch exists in the oracle only (tools/deviation_table.py reports what it is worth)";
       break;

@@ -556,7 +556,7 @@ static int aba(const OModel* M, const OKin* K, const double* qd, const double* t
 /* Spec overrides (include/llenv_model.h LLM_SPEC_*): process-wide, defaults = the constants of that header.  The engine has the same
  * switches (ll_set_spec_param); tools/deviation_table.py moves them in both to measure what each of this build's own choices is worth. */
 static double g_spec[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, 1e30, -1.0, 0.0, 2.0, 0.0, 1.0, 1.0};
+                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, 1e30, -1.0, 0.0, 2.0, 0.0, 1.0, 1.0, 0.0};
 int orc_set_spec_param(int id, double v) {
   if (id < 0 || id >= LLM_SPEC_COUNT) return -1;
   if (id == LLM_SPEC_MAX_CONTACTS_PER_LEG && !(v >= 1 && v <= LLM_MAX_CONTACTS_PER_LEG)) return -1;
@@ -569,7 +569,7 @@ int orc_set_spec_param(int id, double v) {
 double orc_get_spec_param(int id) { return (id >= 0 && id < LLM_SPEC_COUNT) ? g_spec[id] : NAN; }
 void orc_reset_spec(void) {
   const double d[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, 1e30, -1.0, 0.0, 2.0, 0.0, 1.0, 1.0};
+                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, 1e30, -1.0, 0.0, 2.0, 0.0, 1.0, 1.0, 0.0};
   memcpy(g_spec, d, sizeof d);
 }
 #define g_link_damping (g_spec[LLM_SPEC_LINK_DAMPING])
@@ -1221,12 +1221,14 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
 /* one Gauss-Seidel sweep over a robot's own rows (LR:261 numSolverIterations sweeps per substep) */
 static void sweep_rows(ORows* W) {
   const double vmax = g_spec[LLM_SPEC_MAX_COORD_VEL];
+  const int keep = g_spec[LLM_SPEC_FRICTION_KEEP] > 0.5;
   for (int oi = 0; oi < W->no; oi++) {
     const int r = W->order[oi];
     if (W->cone && r < W->first_self && W->fric_of[r] >= 0 && W->fric_of[r] == r - 1 && oi + 1 < W->no && W->order[oi + 1] == r + 1) {
       /* btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows as published: both increments from the SAME velocity, the pair
        * scaled back onto the cone |(t1, t2)| <= mu * (normal multiplier), then both applied */
       const int r2 = r + 1, rn = W->fric_of[r];
+      if (keep && !(W->lam[rn] > 0)) { oi++; continue; }        /* (audit switch LLM_SPEC_FRICTION_KEEP: "if (totalImpulse > 0)") */
       double w1 = W->bias[r], w2 = W->bias[r2];
       for (int k = 0; k < NDOF; k++) { w1 += W->J[r][k] * W->nu[k]; w2 += W->J[r2][k] * W->nu[k]; }
       double t1 = W->lam[r] - w1 * W->dinv[r], t2 = W->lam[r2] - w2 * W->dinv[r2];
@@ -1243,6 +1245,7 @@ static void sweep_rows(ORows* W) {
     double l_new = W->lam[r] - w * W->dinv[r];
     double l_lo = W->lo[r], l_hi = W->hi[r];
     if (W->fric_of[r] >= 0) {
+      if (keep && !(W->lam[W->fric_of[r]] > 0)) continue;
       l_hi = W->mu_row[r] * W->lam[W->fric_of[r]];
       /* mode 3: the spec's round structure (all t1, then all t2) with each friction bound shrunk to what the other row of the contact leaves
        * of the cone: |t1| <= sqrt((mu N)^2 - t2^2), |t2| <= sqrt((mu N)^2 - t1^2).  Not Bullet's coupled clip, but the same admissible set,

@@ -51,12 +51,13 @@ VARIANTS = [
     ('max coordinate velocity 100', dict(max_coord_vel=100.0), 'ORACLE ONLY: btMultiBody::m_maxCoordinateVelocity clip of all 18 generalized velocities'),
     ('limit-row ERP 0.1', dict(limit_erp=0.1), 'ORACLE ONLY: joint-limit rows with half the ERP (Bullet uses the global erp 0.2 = the spec)'),
     ('cone + order + warm start', dict(friction_mode=2, row_order=1, warm_start=0.85), 'ORACLE ONLY'),
+    ('friction kept while the normal multiplier is zero', dict(friction_keep=1), 'ORACLE ONLY: btMultiBodyConstraintSolver as recalled solves a contact\'s friction rows only "if (totalImpulse > 0)"; the spec clips them to zero'),
     ('friction cone, sequential', dict(friction_mode=3), 'ORACLE ONLY: the spec\'s rounds, each friction row bounded by what the contact\'s other row leaves of the cone'),
     ('friction along the sliding direction', dict(friction_dirs=1), 'first friction direction along the contact point\'s lateral velocity (Bullet\'s default rule), box bounds'),
     ('limit rows only once violated', dict(limit_speculative=0), 'ORACLE ONLY: no joint-limit row while the joint is inside its range (btMultiBodyJointLimitConstraint as recalled: "if (penetration > 0) continue"): the joint overshoots, is stopped and walks back by ERP per substep'),
     ('sliding direction + cone + order', dict(friction_dirs=1, friction_mode=2, row_order=1), 'ORACLE ONLY: velocity-aligned directions, cone-coupled, manifold order'),
 ]
-ORACLE_ONLY = ('self_friction', 'warm_start', 'friction_mode', 'row_order', 'max_coord_vel', 'limit_erp', 'limit_speculative')
+ORACLE_ONLY = ('self_friction', 'warm_start', 'friction_mode', 'row_order', 'max_coord_vel', 'limit_erp', 'limit_speculative', 'gyro', 'friction_keep')
 
 
 def engine_has(over):
