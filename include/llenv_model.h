@@ -54,6 +54,11 @@
 #define LLM_SELF_MARGIN 0.01            /* a capsule pair of two legs becomes a (speculative) row within this distance: covers closing
                                            speeds up to 5 m/s per 2 ms substep; the capsules themselves are 35 mm thick */
 #define LLM_MAX_SELF 2                  /* self-collision rows per robot */
+#define LLM_MAX_COORD_VEL 100.0          /* btMultiBody::m_maxCoordinateVelocity (its constructor's value): every generalized velocity -- base twist, joint rates -- is clipped
+                                           to +- this after the unconstrained update and after the solve (applyDeltaVeeMultiDof as recalled).  Inert in every gait
+                                           (joint rates stay below 35 rad/s); it is what keeps a robot sane that is RESET onto a discontinuity of the mocap data (clip 27 at
+                                           7.07 s, clip 8 at 18.90 s: an IK branch flip between two frames = 600 - 750 rad/s by finite differences, ML:48-63): without it
+                                           both oracle and engine blow up there (round 4: every non-finite reset of a soak run was one of these) */
 #define LLM_FRICTION_MODE 2             /* the two friction rows of a contact are solved together inside the cone |(t1, t2)| <= mu N (LLM_SPEC_FRICTION_MODE
                                            below; btMultiBodyConstraintSolver's published default, resolveConeFrictionConstraintRows).  Rounds 1 - 3 and most
                                            of round 4 shipped the pyramid (mode 0): DESIGN.md 4 has the evidence that moved the default */
@@ -91,8 +96,7 @@
                                            standing bars under either); 1 and 3 exist in the oracle only */
 #define LLM_SPEC_ROW_ORDER 14           /* 0 (spec): slot-major (slot 0 of legs 0..3, slot 1, ...).  1: per body pair as a manifold would list them --
                                            contacts sorted by link index, then candidate index */
-#define LLM_SPEC_MAX_COORD_VEL 15       /* btMultiBody::m_maxCoordinateVelocity: every generalized velocity clipped to +- this after the free update
-                                           and after the solve.  default 1e30 (none); Bullet: 100 */
+#define LLM_SPEC_MAX_COORD_VEL 15       /* default LLM_MAX_COORD_VEL = 100 (the spec since round 4; Bullet's value).  1e30: no clip (rounds 1 - 3).  Oracle and engine */
 #define LLM_SPEC_LIMIT_ERP 16           /* ERP of the joint-limit rows; default < 0 = LLM_SPEC_ERP (btMultiBodyJointLimitConstraint uses the global erp) */
 #define LLM_SPEC_PAIR_FRICTION 17       /* SEPMC robot-robot rows: mu of two tangential rows per contact; default 0 (frictionless); Bullet: 0.5 x 0.5 */
 #define LLM_SPEC_MAX_PAIR 18            /* SEPMC robot-robot rows per robot pair; default 2, up to 4 (a manifold holds four points) */

@@ -88,7 +88,7 @@ struct StepParams {
   int32_t friction_mode;    // LLM_SPEC_FRICTION_MODE: 2 (LLM_FRICTION_MODE, the spec since round 4) = the two friction rows of a contact solved together inside the
                             // cone (Bullet's published default; Pmc::gs_cone_round); 0 = the pyramid of rounds 1 - 3 (all t1 rows, then all t2 rows, box bounds).
                             // Every step kernel has both builds; the launch picks
-  int32_t pad_fm;
+  float max_coord_vel;      // LLM_SPEC_MAX_COORD_VEL (btMultiBody::m_maxCoordinateVelocity, 100): base twist and joint rates clipped after the unconstrained update and after the solve
   int32_t max_contacts, max_self;   // deepest-K per leg (LLM_MAX_CONTACTS_PER_LEG), self-collision rows per robot (LLM_MAX_SELF)
   double dt_d, frame_step, policy_step, sample_factor;
   uint64_t seed;

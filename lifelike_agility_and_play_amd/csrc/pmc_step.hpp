@@ -703,6 +703,14 @@ struct Pmc {
     pd_torque(ln, P, q, qd, tgt, tau);
     for (int j = 0; j < 3; j++) ln.stl(out, j, 3, tau[j]);
   }
+  // btMultiBody::m_maxCoordinateVelocity: finite velocities are clipped to +-vmax with one v_med3; a NaN or an infinity must NOT become a bound (v_med3 /
+  // fmin / fmax would make it one) -- the non-finite guard of the step tail has to see it -- so x * 0 (0 for a finite x, NaN otherwise) rides along: 2 instructions a value
+  static LL_HD float clip1(float x, float vmax) { return __builtin_fmaf(x, 0.0f, lm::med3_(x, -vmax, vmax)); }
+  static LL_HD void clip_velocities(const L& ln, float* xi, F* qs, float vmax) {
+    for (int i = 0; i < 6; i++) xi[i] = clip1(xi[i], vmax);
+    F hi = ln.lane_f(vmax), lo = ln.lane_f(-vmax), zero = ln.lane_f(0.0f);
+    for (int j = 0; j < 3; j++) qs[j] = lm::med3_(qs[j], lo, hi) + qs[j] * zero;
+  }
   static LL_HD void substep(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env = 0, int sidx = -1,
                             const SubstepExtra* ex = nullptr) {
     if (P.friction_mode == 2) substep_impl<false, false, true>(ln, P, bs, q, qd, tgt, env, sidx, ex, nullptr);      // (host tests: emu_substep)
@@ -881,6 +889,10 @@ struct Pmc {
     }
     F qs[3];
     for (int j = 0; j < 3; j++) qs[j] = qd[j] + u[j] * dt;
+    // btMultiBody::m_maxCoordinateVelocity (LLM_MAX_COORD_VEL): every generalized velocity clipped when a delta is applied -- here and after the solve.
+    // Inert in every gait; it keeps a robot sane that was reset onto a discontinuity of the mocap data (include/llenv_model.h)
+    const float vmax = P.max_coord_vel;
+    clip_velocities(ln, xi, qs, vmax);
 
     PMC_TSS(23);
     // --- contact candidates (DESIGN.md "contact candidates"): 28 points per leg, 7 per sub-lane, grouped by link --------------
@@ -1517,6 +1529,7 @@ struct Pmc {
     lm_bwd(lf, du);
     for (int i = 0; i < 6; i++) xi[i] += dx[i];
     for (int j = 0; j < 3; j++) qs[j] = qs[j] + du[j];
+    clip_velocities(ln, xi, qs, vmax);
 
     // --- integrate positions with the new velocities (semi-implicit Euler) ---------------------------------------------------------
     bs.w = mul(R, mk3<float>(xi[0], xi[1], xi[2]));

@@ -251,6 +251,7 @@ static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
   P.max_depen = (float)LLM_MAX_DEPEN_SPEED; P.self_margin = (float)LLM_SELF_MARGIN;
   P.max_contacts = LLM_MAX_CONTACTS_PER_LEG; P.max_self = LLM_MAX_SELF;
   P.friction_mode = LLM_FRICTION_MODE;
+  P.max_coord_vel = (float)LLM_MAX_COORD_VEL;
   double sw = 0;
   for (int i = 0; i < 5; i++) sw += cfg.reward_weights[i];               // PLE:365
   if (!(sw > 0)) return "reward_weights must sum to a positive number";
@@ -318,7 +319,10 @@ inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
     case LLM_SPEC_FRICTION_MODE:
       if (!(v == 0.0 || v == 2.0)) return "friction_mode: the engine has 0 (pyramid, the spec) and 2 (cone-coupled, btMultiBodyConstraintSolver's published default); 1 and 3 exist in the oracle only";
       P.friction_mode = (int)v; break;
-    case LLM_SPEC_ROW_ORDER: case LLM_SPEC_MAX_COORD_VEL: case LLM_SPEC_LIMIT_ERP: case LLM_SPEC_PAIR_FRICTION:
+    case LLM_SPEC_MAX_COORD_VEL:
+      if (!(v > 0.0)) return "max_coord_vel must be positive (1e30: no clip)";
+      P.max_coord_vel = (float)(v < 3.0e38 ? v : 3.0e38); break;
+    case LLM_SPEC_ROW_ORDER: case LLM_SPEC_LIMIT_ERP: case LLM_SPEC_PAIR_FRICTION:
     case LLM_SPEC_MAX_PAIR: case LLM_SPEC_LIMIT_SPECULATIVE: case LLM_SPEC_GYRO:
       if ((id == LLM_SPEC_LIMIT_SPECULATIVE || id == LLM_SPEC_GYRO) && v == 1.0) break;
       return "this switch exists in the oracle only (round-3 audit against Bullet's published solver: profiles/r03_deviation_table.md)";
@@ -341,7 +345,7 @@ inline double pmc_get_spec_param(const StepParams& P, int id) {
     case LLM_SPEC_SELECT_EPS: return LLM_SELECT_EPS;
     case LLM_SPEC_FRICTION_DIRS: return P.friction_dirs;
     case LLM_SPEC_FRICTION_MODE: return P.friction_mode;
-    case LLM_SPEC_MAX_COORD_VEL: return 1e30;
+    case LLM_SPEC_MAX_COORD_VEL: return P.max_coord_vel;
     case LLM_SPEC_LIMIT_ERP: return -1.0;
     case LLM_SPEC_MAX_PAIR: return 2.0;
     case LLM_SPEC_LIMIT_SPECULATIVE: return 1.0;

@@ -556,7 +556,7 @@ static int aba(const OModel* M, const OKin* K, const double* qd, const double* t
 /* Spec overrides (include/llenv_model.h LLM_SPEC_*): process-wide, defaults = the constants of that header.  The engine has the same
  * switches (ll_set_spec_param); tools/deviation_table.py moves them in both to measure what each of this build's own choices is worth. */
 static double g_spec[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, 1e30, -1.0, 0.0, 2.0, 0.0, 1.0, 1.0, 0.0};
+                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, LLM_MAX_COORD_VEL, -1.0, 0.0, 2.0, 0.0, 1.0, 1.0, 0.0};
 int orc_set_spec_param(int id, double v) {
   if (id < 0 || id >= LLM_SPEC_COUNT) return -1;
   if (id == LLM_SPEC_MAX_CONTACTS_PER_LEG && !(v >= 1 && v <= LLM_MAX_CONTACTS_PER_LEG)) return -1;
@@ -569,7 +569,7 @@ int orc_set_spec_param(int id, double v) {
 double orc_get_spec_param(int id) { return (id >= 0 && id < LLM_SPEC_COUNT) ? g_spec[id] : NAN; }
 void orc_reset_spec(void) {
   const double d[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, 1e30, -1.0, 0.0, 2.0, 0.0, 1.0, 1.0, 0.0};
+                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, LLM_MAX_COORD_VEL, -1.0, 0.0, 2.0, 0.0, 1.0, 1.0, 0.0};
   memcpy(g_spec, d, sizeof d);
 }
 #define g_link_damping (g_spec[LLM_SPEC_LINK_DAMPING])
@@ -1006,7 +1006,8 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
   }
   /* NOTE: d/dt(world velocity) = R (a_lin + w x v); expressed in the (frozen) body frame of this substep */
   for (int i = 0; i < 12; i++) nu[6 + i] = state[25 + i] + dt * acc[6 + i];
-  for (int i = 0; i < NDOF; i++) nu[i] = fmax(-g_spec[LLM_SPEC_MAX_COORD_VEL], fmin(g_spec[LLM_SPEC_MAX_COORD_VEL], nu[i]));   /* audit switch; default: no clip */
+  { const double vm = g_spec[LLM_SPEC_MAX_COORD_VEL];        /* btMultiBody::m_maxCoordinateVelocity (LLM_MAX_COORD_VEL); a NaN or an infinity is an error state, not a bound */
+    for (int i = 0; i < NDOF; i++) nu[i] = !isfinite(nu[i]) ? NAN : (nu[i] > vm ? vm : (nu[i] < -vm ? -vm : nu[i])); }
 
   /* ---- constraint rows --------------------------------------------------------------------------- */
   OContact C[MAXC];
@@ -1220,7 +1221,6 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
 
 /* one Gauss-Seidel sweep over a robot's own rows (LR:261 numSolverIterations sweeps per substep) */
 static void sweep_rows(ORows* W) {
-  const double vmax = g_spec[LLM_SPEC_MAX_COORD_VEL];
   const int keep = g_spec[LLM_SPEC_FRICTION_KEEP] > 0.5;
   for (int oi = 0; oi < W->no; oi++) {
     const int r = W->order[oi];
@@ -1262,8 +1262,11 @@ static void sweep_rows(ORows* W) {
     W->lam[r] = l_new;
     for (int k = 0; k < NDOF; k++) W->nu[k] += W->MiJt[r][k] * d;
   }
-  if (vmax < 1e29)
-    for (int k = 0; k < NDOF; k++) W->nu[k] = fmax(-vmax, fmin(vmax, W->nu[k]));
+}
+/* ... and once more when the solver's result is written back (applyDeltaVeeMultiDof), before the positions are integrated */
+static void clip_velocities(ORows* W) {
+  const double vmax = g_spec[LLM_SPEC_MAX_COORD_VEL];
+  for (int k = 0; k < NDOF; k++) W->nu[k] = !isfinite(W->nu[k]) ? NAN : (W->nu[k] > vmax ? vmax : (W->nu[k] < -vmax ? -vmax : W->nu[k]));
 }
 
 static void integrate_state(const ORows* W, double dt, double* state) {
@@ -1315,6 +1318,7 @@ static int substep_terrain(const OModel* M, double dt, int n_iter, double mu_foo
   if (assemble_rows(M, dt, mu_foot, state, tau_in, diag, T, push, &W)) return -1;
   if (tl_warm && g_spec[LLM_SPEC_WARM_START] > 0) warm_apply(&W, tl_warm, g_spec[LLM_SPEC_WARM_START]);
   for (int it = 0; it < n_iter; it++) sweep_rows(&W);
+  clip_velocities(&W);
   if (tl_warm) warm_store(&W, tl_warm);
   if (diag) {   /* fixed layout for the tests: [12 limit rows (0 when gated out)] [3 rows per contact, contact order] */
     diag->n_contacts = W.nc; diag->n_rows = 12 + 3 * W.nc;
@@ -1513,6 +1517,7 @@ int orc_substep_pair_model(const OModel* M, double dt, int n_iter, const double*
           for (int k = 0; k < NDOF; k++) W[side].nu[k] += MJ[q][side][k] * d;
       }
   }
+  clip_velocities(&W[0]); clip_velocities(&W[1]);
   integrate_state(&W[0], dt, state0);
   integrate_state(&W[1], dt, state1);
   return np;

@@ -580,6 +580,43 @@ def check_obstacle_variant(golden, orc, model_blob, table, lib_path, n_envs=24, 
     return n_coll
 
 
+def check_reset_onto_a_mocap_discontinuity(orc, model_blob, table, lib_path):
+    """The retargeted clips hold IK branch flips between two consecutive frames (clip 27 at 7.07 s, clip 8 at 18.90 s: a hind leg's three joints jump by
+    1 - 6 rad): the reference's finite-difference joint velocity (ML:48-63) is 600 - 750 rad/s there, and a uniformly random start lands on such a frame
+    once in 2 - 4e7 env-steps.  Every non-finite reset of round 4's soak runs was one of these (tools/diag_nonfinite.py).  With Bullet's velocity clip
+    (LLM_MAX_COORD_VEL = btMultiBody::m_maxCoordinateVelocity = 100) engine and oracle come through finite, and agree; without it both blow up
+    (the float32 engine to inf -> LL_DONE_NONFINITE, the float64 oracle to 1e30)."""
+    cases = [(27, 7.068370648298843), (8, 18.901122098221997), (27, 7.066725201181503)]
+    E = make_engine(model_blob, table, len(cases), lib_path)
+    B = make_oracle_batch(orc, model_blob, table, n_envs=len(cases))
+    clip, t0 = np.array([c for c, _ in cases]), np.array([t for _, t in cases])
+    E.reset(clip=clip, t0=t0)
+    s0 = E.state()
+    assert (np.abs(s0[:, 25:37]).max(1) > 500.0).all(), np.abs(s0[:, 25:37]).max(1)          # the reference's own reset state (G-goldens pin the formula)
+    for i, (c, t) in enumerate(cases):
+        B.reset_env(i, c, t); B.set_state(i, s0[i].astype(np.float64))
+    act = np.zeros((len(cases), 12), np.float32)
+    E.step_host(act)
+    r, d, why = E.reward_done()
+    es = E.state().astype(np.float64)
+    assert np.isfinite(es).all() and not (why & capi.LL_DONE_NONFINITE).any(), why
+    assert np.abs(es[:, 25:37]).max() <= 100.0 + 1e-3
+    worst = 0.0
+    for i in range(len(cases)):
+        _, _, od = B.step_env(i, act[i].astype(np.float64))
+        os_ = B.get_state(i)
+        err = np.abs(quat_align(es[i], os_) - os_)
+        worst = max(worst, err[0:7].max(), err[13:25].max())
+        assert err[0:7].max() < PHYS_STEP_TOL and err[13:25].max() < PHYS_STEP_TOL, (i, err[0:7].max(), err[13:25].max())     # (a violent step -- joint rates at the clip, limit rows deep in penetration -- and still within the standing bars: 1.5e-6)
+        assert bool(d[i]) == od, (i, d[i], od)
+    E.set_spec(max_coord_vel=1e30)                                   # the switch that turns the clip off: the blow-up is back (and caught by the guard)
+    E.reset(clip=clip, t0=t0)
+    E.step_host(act)
+    assert (E.reward_done()[2] & capi.LL_DONE_NONFINITE).any()
+    E.close()
+    return worst
+
+
 def check_scripted_episodes_against_goldens(golden, model_blob, table, lib_path):
     """The engine's whole step() control flow against the REFERENCE's own outputs (golden G5): 12 scripted episodes driven
     exactly as gen_golden.py drove the reference through its fake BulletClient -- physics result and foot positions
@@ -743,17 +780,18 @@ def check_nonfinite_guard(model_blob, table, lib_path):
     assert np.array_equal(A.state(), B.state()) and A.counters()['nonfinite'] == 0
     s = A.state()
     s[2, 13 + 4] = np.nan                                   # a joint angle of env 2 (wave 0)
-    s[5, 7] = np.inf                                        # a base velocity of env 5 (wave 1)
+    s[5, 7] = np.inf                                        # a base velocity of env 5 (wave 1): the velocity clip (LLM_MAX_COORD_VEL) must not turn it into a bound
+    s[7, 25 + 3] = np.nan                                   # a joint RATE of env 7: the velocity clip must not turn a NaN into a bound
     A.set_state(s)
     a = (rng.normal(size=(n, 12)) * SIGMA).astype(np.float32)
     ep0 = A.counters()['episodes']
     A.step_host(a); B.step_host(a)
     r, d, why = A.reward_done()
     rb, db, whyb = B.reward_done()
-    bad, good = np.array([2, 5]), np.array([0, 1, 3, 4, 6, 7])
+    bad, good = np.array([2, 5, 7]), np.array([0, 1, 3, 4, 6])
     assert d[bad].all() and ((why[bad] & capi.LL_DONE_NONFINITE) != 0).all() and (r[bad] == 0.0).all()
     c = A.counters()
-    assert c['nonfinite'] == 2 and c['episodes'] - ep0 == 2 + int(db[good].sum())
+    assert c['nonfinite'] == 3 and c['episodes'] - ep0 == 3 + int(db[good].sum())
     sa, oa = A.state(), A.obs()
     assert np.isfinite(sa).all() and np.isfinite(oa).all() and np.isfinite(A.ref_state()).all()      # re-seeded from the clip table
     info = A.episode_info()
@@ -764,7 +802,7 @@ def check_nonfinite_guard(model_blob, table, lib_path):
     # the run goes on as if nothing had happened
     for t in range(3):
         A.step_random(SIGMA)
-    assert np.isfinite(A.state()).all() and A.counters()['nonfinite'] == 2
+    assert np.isfinite(A.state()).all() and A.counters()['nonfinite'] == 3
     A.close(); B.close()
     # without auto-reset the env is flagged and stays the caller's to reset; the poison does not spread
     E = make_engine(model_blob, table, 4, lib_path, auto_reset=0, seed=2)

@@ -199,6 +199,10 @@ def test_trained_reference_policy_tracks_in_our_simulator():
     print('trained PMC policy on GPU: mean reward/step %.3f, tracked %.0f%%' % (out['mean_reward'], 100 * out['tracked']))
 
 
+def test_reset_onto_a_mocap_discontinuity(orc, model_blob, mocap_table):
+    print('worst configuration error against the oracle: %.2e' % pc.check_reset_onto_a_mocap_discontinuity(orc, model_blob, mocap_table, None))
+
+
 def test_obstacle_variant(golden, orc, model_blob, mocap_table):
     n = pc.check_obstacle_variant(golden, orc, model_blob, mocap_table, None)
     print('obstacle variant: %d episodes ended on the box' % n)

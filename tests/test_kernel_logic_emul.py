@@ -170,3 +170,7 @@ def test_cone_scalars_through_the_row_scratch_equal_registers(model_blob, mocap_
             os.environ.pop('LL_EMUL_PARK', None)
         assert np.abs(A.state()[:, 25:37]).max() > 0.1
         A.close(); B.close()
+
+
+def test_reset_onto_a_mocap_discontinuity(orc, model_blob, mocap_table, emul_lib):
+    print('worst configuration error against the oracle: %.2e' % pc.check_reset_onto_a_mocap_discontinuity(orc, model_blob, mocap_table, emul_lib))

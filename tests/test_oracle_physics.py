@@ -371,7 +371,7 @@ def test_bullet_audit_switches(golden, orc, model_blob, mocap_table):
     ref_z = None
     try:
         for spec in (dict(), dict(friction_mode=0), dict(friction_mode=1), dict(row_order=1), dict(friction_mode=0, row_order=1),
-                     dict(max_coord_vel=100.0), dict(limit_erp=0.1), dict(friction_keep=1)):
+                     dict(max_coord_vel=1e30), dict(limit_erp=0.1), dict(friction_keep=1)):
             O.reset_spec(); O.set_spec(**spec)
             B = make_oracle_batch(orc, model_blob, mocap_table)
             s = standing_state(golden)
@@ -402,4 +402,4 @@ def test_bullet_audit_switches(golden, orc, model_blob, mocap_table):
     import ctypes
     get = O.lib().orc_get_spec_param
     get.restype = ctypes.c_double
-    assert get(13) == 2.0 and get(14) == 0.0 and get(15) == 1e30 and get(18) == 2.0 and get(22) == 0.0          # (13: LLM_FRICTION_MODE, the cone, since round 4)
+    assert get(13) == 2.0 and get(14) == 0.0 and get(15) == 100.0 and get(18) == 2.0 and get(22) == 0.0          # (13: LLM_FRICTION_MODE, the cone, since round 4)
