@@ -48,7 +48,7 @@ VARIANTS = [
     ('friction cone-coupled', dict(friction_mode=2), 'engine option since round 4 (Pmc::gs_cone_round): (t1, t2) of a contact solved together from one velocity and clipped to the cone (resolveConeFrictionConstraintRows)'),
     ('manifold row order', dict(row_order=1), 'ORACLE ONLY: contacts ordered per body pair (link index, candidate) instead of slot-major'),
     ('cone + manifold order', dict(friction_mode=2, row_order=1), 'ORACLE ONLY: both of the above: the closest restatement of the published solver loop'),
-    ('max coordinate velocity 100', dict(max_coord_vel=100.0), 'ORACLE ONLY: btMultiBody::m_maxCoordinateVelocity clip of all 18 generalized velocities'),
+    ('no coordinate-velocity clip', dict(max_coord_vel=1e30), 'btMultiBody::m_maxCoordinateVelocity (100, the spec since round 4: LLM_MAX_COORD_VEL) switched off: the spec of rounds 1 - 3'),
     ('limit-row ERP 0.1', dict(limit_erp=0.1), 'ORACLE ONLY: joint-limit rows with half the ERP (Bullet uses the global erp 0.2 = the spec)'),
     ('cone + order + warm start', dict(friction_mode=2, row_order=1, warm_start=0.85), 'ORACLE ONLY'),
     ('friction kept while the normal multiplier is zero', dict(friction_keep=1), 'ORACLE ONLY: btMultiBodyConstraintSolver as recalled solves a contact\'s friction rows only "if (totalImpulse > 0)"; the spec clips them to zero'),
@@ -57,7 +57,7 @@ VARIANTS = [
     ('limit rows only once violated', dict(limit_speculative=0), 'ORACLE ONLY: no joint-limit row while the joint is inside its range (btMultiBodyJointLimitConstraint as recalled: "if (penetration > 0) continue"): the joint overshoots, is stopped and walks back by ERP per substep'),
     ('sliding direction + cone + order', dict(friction_dirs=1, friction_mode=2, row_order=1), 'ORACLE ONLY: velocity-aligned directions, cone-coupled, manifold order'),
 ]
-ORACLE_ONLY = ('self_friction', 'warm_start', 'friction_mode', 'row_order', 'max_coord_vel', 'limit_erp', 'limit_speculative', 'gyro', 'friction_keep')
+ORACLE_ONLY = ('self_friction', 'warm_start', 'friction_mode', 'row_order', 'limit_erp', 'limit_speculative', 'gyro', 'friction_keep')
 
 
 def engine_has(over):
