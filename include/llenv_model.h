@@ -55,7 +55,8 @@
                                            speeds up to 5 m/s per 2 ms substep; the capsules themselves are 35 mm thick */
 #define LLM_MAX_SELF 2                  /* self-collision rows per robot */
 #define LLM_MAX_COORD_VEL 100.0          /* btMultiBody::m_maxCoordinateVelocity (its constructor's value): every generalized velocity -- base twist, joint rates -- is clipped
-                                           to +- this after the unconstrained update and after the solve (applyDeltaVeeMultiDof as recalled).  Inert in every gait
+                                           to +- this after the unconstrained update and after the solve (applyDeltaVeeMultiDof as recalled; a NaN or an infinity is NOT made a bound: it stays
+                                           non-finite for the engine's guard, LL_DONE_NONFINITE).  Inert in every gait
                                            (joint rates stay below 35 rad/s); it is what keeps a robot sane that is RESET onto a discontinuity of the mocap data (clip 27 at
                                            7.07 s, clip 8 at 18.90 s: an IK branch flip between two frames = 600 - 750 rad/s by finite differences, ML:48-63): without it
                                            both oracle and engine blow up there (round 4: every non-finite reset of a soak run was one of these) */
