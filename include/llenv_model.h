@@ -46,6 +46,10 @@
 #define LLM_LINK_FRICTION 0.5          /* Bullet default lateralFriction of every non-foot link */
 #define LLM_CONTACT_MARGIN 0.02        /* Bullet contact breaking threshold */
 #define LLM_ERP 0.2                    /* PyBullet default erp / contactERP */
+#define LLM_LIMIT_ERP (-1.0)            /* ERP of the joint-limit rows; < 0: LLM_ERP */
+#define LLM_LIMIT_SPECULATIVE 1         /* LLM_SPEC_LIMIT_SPECULATIVE below */
+#define LLM_ERP_DEEP (-1.0)             /* LLM_SPEC_ERP_DEEP below; < 0: one ERP at every depth */
+#define LLM_ERP_DEEP_BELOW (-0.04)      /* btContactSolverInfo::m_splitImpulsePenetrationThreshold (see LLM_SPEC_ERP_DEEP) */
 #define LLM_MAX_DEPEN_SPEED 0.5        /* m/s: cap on the penetration-recovery part of a contact row's bias (a body that starts inside an
                                           obstacle -- SEPMC spawns at random -- is pushed out gently instead of being shot out) */
 #define LLM_LINK_DAMPING 0.04          /* btMultiBody default linear & angular damping (quirk Q12) */
@@ -98,7 +102,7 @@
 #define LLM_SPEC_ROW_ORDER 14           /* 0 (spec): slot-major (slot 0 of legs 0..3, slot 1, ...).  1: per body pair as a manifold would list them --
                                            contacts sorted by link index, then candidate index */
 #define LLM_SPEC_MAX_COORD_VEL 15       /* default LLM_MAX_COORD_VEL = 100 (the spec since round 4; Bullet's value).  1e30: no clip (rounds 1 - 3).  Oracle and engine */
-#define LLM_SPEC_LIMIT_ERP 16           /* ERP of the joint-limit rows; default < 0 = LLM_SPEC_ERP (btMultiBodyJointLimitConstraint uses the global erp) */
+#define LLM_SPEC_LIMIT_ERP 16           /* ERP of the joint-limit rows; < 0 = LLM_SPEC_ERP (btMultiBodyJointLimitConstraint uses the world's m_erp, PyBullet's "erp", 0.2).  Oracle and engine */
 #define LLM_SPEC_PAIR_FRICTION 17       /* SEPMC robot-robot rows: mu of two tangential rows per contact; default 0 (frictionless); Bullet: 0.5 x 0.5 */
 #define LLM_SPEC_MAX_PAIR 18            /* SEPMC robot-robot rows per robot pair; default 2, up to 4 (a manifold holds four points) */
 #define LLM_SPEC_FRICTION_DIRS 19       /* 0 (spec): friction directions btPlaneSpace1(n), fixed in the world (-y, +x on the ground).  1: the first direction along
@@ -106,10 +110,11 @@
                                            when SOLVER_DISABLE_VELOCITY_DEPENDENT_FRICTION_DIRECTION is not set), the second = t1 x n; btPlaneSpace1 when it
                                            does not slide.  With box bounds a sliding contact then gets at most mu N along its sliding direction instead of
                                            up to sqrt(2) mu N diagonally.  Oracle and engine (ll_set_spec_param) */
-#define LLM_SPEC_LIMIT_SPECULATIVE 20   /* 1 (spec): a joint-limit row exists while the joint is inside its range too, with the free distance d / dt as its bias: the
-                                           joint stops AT the limit.  0: a row only once the limit is passed (d <= 0), bias erp * d / dt -- what
-                                           btMultiBodyJointLimitConstraint::createConstraintRows does as recalled ("if (penetration > 0) continue;"): the joint overshoots by
-                                           up to qd * dt, is stopped there and walks back by erp per substep.  ORACLE ONLY unless stated otherwise in DESIGN.md 4 */
+#define LLM_SPEC_LIMIT_SPECULATIVE 20   /* 1 (spec of rounds 1 - 4): a joint-limit row exists while the joint is inside its range too, with the free distance d / dt as its bias: the
+                                           joint stops AT the limit; rows whose free approach speed exceeds LLM_LIMIT_GATE stay out.  0: a row only once the limit is passed (d <= 0),
+                                           bias erp * d / dt, no gate -- what btMultiBodyJointLimitConstraint::createConstraintRows does as recalled ("if (penetration > 0)
+                                           continue;"): the joint overshoots by up to qd * dt, is stopped there and walks back by erp per substep.  Oracle and engine
+                                           (round 5: every step kernel; a wave none of whose robots is past a limit skips the limit section of the substep) */
 #define LLM_SPEC_GYRO 21                /* 1 (spec, btMultiBody::m_useGyroTerm = true as its constructor sets it): the gyroscopic torque w x (I_c w) of every link is part
                                            of the velocity-product forces.  0: left out (Bullet's setUseGyroTerm(false)); the remaining terms -- m w x v_c, the
                                            Coriolis accelerations of the joints -- stay.  ORACLE ONLY (round 4: the third audit item of the bars policy) */
@@ -117,6 +122,10 @@
                                            left as they are in that sweep -- btMultiBodyConstraintSolver::solveSingleIteration as recalled guards the friction solve of a
                                            contact with "if (totalImpulse > 0)" --, so friction gathered in earlier iterations of the substep survives a normal row that has
                                            let go.  ORACLE ONLY (round 4, priced in profiles/r04_cone_decision.md) */
-#define LLM_SPEC_COUNT 23
+#define LLM_SPEC_ERP_DEEP 23            /* ERP of a row whose penetration is deeper than LLM_SPEC_ERP_DEEP_BELOW; < 0 (default) = no second ERP.  Bullet's btContactSolverInfo carries two:
+                                           m_erp ("erp", 0.2) and m_erp2 ("contactERP"; PyBullet's server sets 0.08 as recalled); btSequentialImpulseConstraintSolver::setupContactConstraint
+                                           and btMultiBodyJointLimitConstraint pick m_erp while penetration > m_splitImpulsePenetrationThreshold (-0.04) and m_erp2 below.  Oracle and engine */
+#define LLM_SPEC_ERP_DEEP_BELOW 24      /* m (rad for limit rows): default LLM_ERP_DEEP_BELOW = -0.04 */
+#define LLM_SPEC_COUNT 25
 
 #endif

@@ -88,6 +88,11 @@ struct StepParams {
   int32_t friction_mode;    // LLM_SPEC_FRICTION_MODE: 2 (LLM_FRICTION_MODE, the spec since round 4) = the two friction rows of a contact solved together inside the
                             // cone (Bullet's published default; Pmc::gs_cone_round); 0 = the pyramid of rounds 1 - 3 (all t1 rows, then all t2 rows, box bounds).
                             // Every step kernel has both builds; the launch picks
+  float limit_erp;          // ERP of the joint-limit rows as the kernel uses it (LLM_SPEC_LIMIT_ERP; the setter resolves "< 0 = erp")
+  float erp_deep, limit_erp_deep, erp_deep_below;   // LLM_SPEC_ERP_DEEP / _BELOW as the kernel uses them: a row deeper than erp_deep_below takes erp_deep (limit rows: limit_erp_deep);
+                            // without a second ERP both equal erp / limit_erp, so the kernel selects unconditionally
+  float spec_erp_deep, spec_limit_erp;   // what ll_set_spec_param was given (< 0: follow erp), kept for ll_get_spec_param and for re-resolving when erp moves
+  int32_t limit_speculative;   // LLM_SPEC_LIMIT_SPECULATIVE: 1 = a limit row inside the range too (gated by limit_gate); 0 = Bullet's rule, a row only once the limit is passed
   float max_coord_vel;      // LLM_SPEC_MAX_COORD_VEL (btMultiBody::m_maxCoordinateVelocity, 100): base twist and joint rates clipped after the unconstrained update and after the solve
   int32_t max_contacts, max_self;   // deepest-K per leg (LLM_MAX_CONTACTS_PER_LEG), self-collision rows per robot (LLM_MAX_SELF)
   double dt_d, frame_step, policy_step, sample_factor;

@@ -1065,8 +1065,11 @@ struct Pmc {
       fwd6(Sb, Sd, lgt);
       F nn = ljt[0] * ljt[0] + ljt[1] * ljt[1] + ljt[2] * ljt[2];
       for (int i = 0; i < 6; i++) nn = nn + lgt[i] * lgt[i];
-      rl.c = sg * qsj + lm::sel(d > 0.0f, d * inv_dt, d * (P.erp * inv_dt));
-      B lvalid = lm::and_(lm::and_(has, rl.c < P.limit_gate), ln.lane_f(PMC_ABL(2) ? 0.0f : 1.0f) > 0.5f);     // rows that cannot act this substep stay out of the solve
+      rl.c = sg * qsj + lm::sel(d > 0.0f, d * inv_dt, d * lm::sel(d > P.erp_deep_below, ln.lane_f(P.limit_erp * inv_dt), ln.lane_f(P.limit_erp_deep * inv_dt)));
+      // which rows enter the solve.  limit_speculative (rounds 1 - 4): every row that can act within the substep (free approach speed below the gate);
+      // otherwise Bullet's rule (btMultiBodyJointLimitConstraint): only a joint that is past its limit has a row -- rare, so most substeps
+      // of most waves skip the limit section altogether (any_l below)
+      B lvalid = lm::and_(lm::and_(has, P.limit_speculative ? (rl.c < P.limit_gate) : lm::not_(d > 0.0f)), ln.lane_f(PMC_ABL(2) ? 0.0f : 1.0f) > 0.5f);
       rl.inv = lm::sel(lvalid, one / nn, zero);
       any_l[0] = L::any(lm::and_(lvalid, ln.is_sub(0))); any_l[1] = L::any(lm::and_(lvalid, ln.is_sub(1)));
       any_l[2] = L::any(lm::and_(lvalid, ln.is_sub(2)));
@@ -1154,7 +1157,8 @@ struct Pmc {
         }
       }
       F depth_c = my_depth;
-      F bias = lm::sel(depth_c > 0.0f, depth_c * inv_dt, lm::max_(depth_c * (P.erp * inv_dt), ln.lane_f(-P.max_depen)));
+      F bias = lm::sel(depth_c > 0.0f, depth_c * inv_dt,
+                       lm::max_(depth_c * lm::sel(depth_c > P.erp_deep_below, ln.lane_f(P.erp * inv_dt), ln.lane_f(P.erp_deep * inv_dt)), ln.lane_f(-P.max_depen)));
       // joint j moves the point iff the point's link is at or below joint j: link >= j+1
       F on1 = lm::sel(link > 0.5f, one, zero), on2 = lm::sel(link > 1.5f, one, zero), on3 = lm::sel(link > 2.5f, one, zero);
       V3l rr1 = Pb - k.p1, rr2 = Pb - k.p2, rr3 = Pb - k.p3;
@@ -1295,7 +1299,7 @@ struct Pmc {
           float nn = L::qsum(sjt[0] * sjt[0] + sjt[1] * sjt[1] + sjt[2] * sjt[2]);
           for (int i = 0; i < 6; i++) nn += sgt[i] * sgt[i];
           self_row_pack(ln, sjt, sgt, rw);
-          rw.c = vrow + ((dsel > 0.0f) ? dsel * inv_dt : fmaxf(dsel * (P.erp * inv_dt), -P.max_depen));
+          rw.c = vrow + ((dsel > 0.0f) ? dsel * inv_dt : fmaxf(dsel * ((dsel > P.erp_deep_below ? P.erp : P.erp_deep) * inv_dt), -P.max_depen));
           rw.inv = have ? 1.0f / nn : 0.0f;
           rw.lam = 0.0f;
           if (!have) self_row_clear(ln, rw);
@@ -1469,7 +1473,7 @@ struct Pmc {
             for (int i = 0; i < 6; i++) nn += sgt[i] * sgt[i];
             self_row_pack(ln, sjt, sgt, rw);
             const float vo = ln.peer_u(vrow), no = ln.peer_u(nn);
-            rw.c = ((me == 0) ? vrow + vo : vo + vrow) + ((dsel > 0.0f) ? dsel * inv_dt : fmaxf(dsel * (P.erp * inv_dt), -P.max_depen));
+            rw.c = ((me == 0) ? vrow + vo : vo + vrow) + ((dsel > 0.0f) ? dsel * inv_dt : fmaxf(dsel * ((dsel > P.erp_deep_below ? P.erp : P.erp_deep) * inv_dt), -P.max_depen));
             rw.inv = have ? 1.0f / ((me == 0) ? nn + no : no + nn) : 0.0f;
             rw.lam = 0.0f;
             if (!have) self_row_clear(ln, rw);

@@ -223,6 +223,13 @@ static inline std::string pmc_build_cand_table(const double* blob, std::vector<f
   return "";
 }
 
+// the ERPs as the kernel uses them, from what the spec switches say (LLM_SPEC_ERP, _LIMIT_ERP, _ERP_DEEP: "< 0" = follow the contact ERP / no second ERP)
+static inline void pmc_resolve_erps(StepParams& P) {
+  P.limit_erp = P.spec_limit_erp >= 0.0f ? P.spec_limit_erp : P.erp;
+  P.erp_deep = P.spec_erp_deep >= 0.0f ? P.spec_erp_deep : P.erp;
+  P.limit_erp_deep = P.spec_erp_deep >= 0.0f ? P.spec_erp_deep : P.limit_erp;
+}
+
 // scalar part of StepParams from the reference-style config; returns "" or an error
 static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
   if (cfg.abi_version != LL_ABI_VERSION) return "ll_config.abi_version mismatch";
@@ -252,6 +259,9 @@ static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
   P.max_contacts = LLM_MAX_CONTACTS_PER_LEG; P.max_self = LLM_MAX_SELF;
   P.friction_mode = LLM_FRICTION_MODE;
   P.max_coord_vel = (float)LLM_MAX_COORD_VEL;
+  P.limit_speculative = LLM_LIMIT_SPECULATIVE;
+  P.spec_limit_erp = (float)LLM_LIMIT_ERP; P.spec_erp_deep = (float)LLM_ERP_DEEP; P.erp_deep_below = (float)LLM_ERP_DEEP_BELOW;
+  pmc_resolve_erps(P);
   double sw = 0;
   for (int i = 0; i < 5; i++) sw += cfg.reward_weights[i];               // PLE:365
   if (!(sw > 0)) return "reward_weights must sum to a positive number";
@@ -300,7 +310,13 @@ inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
     case LLM_SPEC_MAX_SELF:
       if (!(v >= 0 && v <= LLM_MAX_SELF)) return "self-collision rows per robot must be 0..2";
       P.max_self = (int)v; break;
-    case LLM_SPEC_ERP: P.erp = (float)v; break;
+    case LLM_SPEC_ERP: P.erp = (float)v; pmc_resolve_erps(P); break;
+    case LLM_SPEC_LIMIT_ERP: P.spec_limit_erp = (float)v; pmc_resolve_erps(P); break;
+    case LLM_SPEC_ERP_DEEP: P.spec_erp_deep = (float)v; pmc_resolve_erps(P); break;
+    case LLM_SPEC_ERP_DEEP_BELOW: P.erp_deep_below = (float)v; break;
+    case LLM_SPEC_LIMIT_SPECULATIVE:
+      if (!(v == 0.0 || v == 1.0)) return "limit_speculative must be 0 or 1";
+      P.limit_speculative = (int)v; break;
     case LLM_SPEC_CONTACT_MARGIN: P.margin_dist = (float)v; break;
     case LLM_SPEC_SELF_FRICTION:
     case LLM_SPEC_FRICTION_KEEP:
@@ -322,9 +338,9 @@ inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
     case LLM_SPEC_MAX_COORD_VEL:
       if (!(v > 0.0)) return "max_coord_vel must be positive (1e30: no clip)";
       P.max_coord_vel = (float)(v < 3.0e38 ? v : 3.0e38); break;
-    case LLM_SPEC_ROW_ORDER: case LLM_SPEC_LIMIT_ERP: case LLM_SPEC_PAIR_FRICTION:
-    case LLM_SPEC_MAX_PAIR: case LLM_SPEC_LIMIT_SPECULATIVE: case LLM_SPEC_GYRO:
-      if ((id == LLM_SPEC_LIMIT_SPECULATIVE || id == LLM_SPEC_GYRO) && v == 1.0) break;
+    case LLM_SPEC_ROW_ORDER: case LLM_SPEC_PAIR_FRICTION:
+    case LLM_SPEC_MAX_PAIR: case LLM_SPEC_GYRO:
+      if (id == LLM_SPEC_GYRO && v == 1.0) break;
       return "this switch exists in the oracle only (round-3 audit against Bullet's published solver: profiles/r03_deviation_table.md)";
     default: return "unknown spec parameter id";
   }
@@ -346,9 +362,11 @@ inline double pmc_get_spec_param(const StepParams& P, int id) {
     case LLM_SPEC_FRICTION_DIRS: return P.friction_dirs;
     case LLM_SPEC_FRICTION_MODE: return P.friction_mode;
     case LLM_SPEC_MAX_COORD_VEL: return P.max_coord_vel;
-    case LLM_SPEC_LIMIT_ERP: return -1.0;
+    case LLM_SPEC_LIMIT_ERP: return P.spec_limit_erp;
+    case LLM_SPEC_ERP_DEEP: return P.spec_erp_deep;
+    case LLM_SPEC_ERP_DEEP_BELOW: return P.erp_deep_below;
     case LLM_SPEC_MAX_PAIR: return 2.0;
-    case LLM_SPEC_LIMIT_SPECULATIVE: return 1.0;
+    case LLM_SPEC_LIMIT_SPECULATIVE: return P.limit_speculative;
     case LLM_SPEC_GYRO: return 1.0;
     default: return 0.0;
   }

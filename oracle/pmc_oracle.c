@@ -556,7 +556,7 @@ static int aba(const OModel* M, const OKin* K, const double* qd, const double* t
 /* Spec overrides (include/llenv_model.h LLM_SPEC_*): process-wide, defaults = the constants of that header.  The engine has the same
  * switches (ll_set_spec_param); tools/deviation_table.py moves them in both to measure what each of this build's own choices is worth. */
 static double g_spec[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, LLM_MAX_COORD_VEL, -1.0, 0.0, 2.0, 0.0, 1.0, 1.0, 0.0};
+                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, LLM_MAX_COORD_VEL, LLM_LIMIT_ERP, 0.0, 2.0, 0.0, LLM_LIMIT_SPECULATIVE, 1.0, 0.0, LLM_ERP_DEEP, LLM_ERP_DEEP_BELOW};
 int orc_set_spec_param(int id, double v) {
   if (id < 0 || id >= LLM_SPEC_COUNT) return -1;
   if (id == LLM_SPEC_MAX_CONTACTS_PER_LEG && !(v >= 1 && v <= LLM_MAX_CONTACTS_PER_LEG)) return -1;
@@ -569,8 +569,16 @@ int orc_set_spec_param(int id, double v) {
 double orc_get_spec_param(int id) { return (id >= 0 && id < LLM_SPEC_COUNT) ? g_spec[id] : NAN; }
 void orc_reset_spec(void) {
   const double d[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, LLM_MAX_COORD_VEL, -1.0, 0.0, 2.0, 0.0, 1.0, 1.0, 0.0};
+                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, LLM_MAX_COORD_VEL, LLM_LIMIT_ERP, 0.0, 2.0, 0.0, LLM_LIMIT_SPECULATIVE, 1.0, 0.0, LLM_ERP_DEEP, LLM_ERP_DEEP_BELOW};
   memcpy(g_spec, d, sizeof d);
+}
+/* bias of a unilateral row from its signed distance: a separated row may close the gap within the substep; a penetrating one is pushed
+ * out by ERP per substep -- with a second, deeper ERP when LLM_SPEC_ERP_DEEP is set, and (contact rows only) capped at LLM_SPEC_MAX_DEPEN_SPEED */
+static double row_bias(double depth, double dt, double erp, int capped) {
+  if (depth > 0) return depth / dt;
+  const double e = (g_spec[LLM_SPEC_ERP_DEEP] >= 0 && !(depth > g_spec[LLM_SPEC_ERP_DEEP_BELOW])) ? g_spec[LLM_SPEC_ERP_DEEP] : erp;
+  const double b = e * depth / dt;
+  return capped ? fmax(b, -g_spec[LLM_SPEC_MAX_DEPEN_SPEED]) : b;
 }
 #define g_link_damping (g_spec[LLM_SPEC_LINK_DAMPING])
 #define g_self_collision (g_spec[LLM_SPEC_SELF_COLLISION] > 0.5)
@@ -1022,10 +1030,11 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
     double dl = state[13 + i] - M->qlo[i], dh = M->qhi[i] - state[13 + i];
     double d = dl <= dh ? dl : dh, sgn = dl <= dh ? 1.0 : -1.0;
     const double lerp = g_spec[LLM_SPEC_LIMIT_ERP] >= 0 ? g_spec[LLM_SPEC_LIMIT_ERP] : g_spec[LLM_SPEC_ERP];
-    double bz = d > 0 ? d / dt : lerp * d / dt;
+    double bz = row_bias(d, dt, lerp, 0);
     lim_row[i] = -1;
-    if (g_spec[LLM_SPEC_LIMIT_SPECULATIVE] < 0.5 && d > 0) continue;            /* (audit switch: rows only once the limit is passed) */
-    if (!(sgn * nu[6 + i] + bz < g_spec[LLM_SPEC_LIMIT_GATE])) continue;
+    if (g_spec[LLM_SPEC_LIMIT_SPECULATIVE] < 0.5) {                              /* Bullet's rule: a row only once the limit is passed, and then whatever the speed */
+      if (d > 0) continue;
+    } else if (!(sgn * nu[6 + i] + bz < g_spec[LLM_SPEC_LIMIT_GATE])) continue;
     memset(J[nr], 0, sizeof J[nr]);
     J[nr][6 + i] = sgn;
     bias[nr] = bz;
@@ -1087,7 +1096,7 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
         J[nr][d] = v3dot(dirs[r], vw);
       }
       if (r == 0) {
-        bias[nr] = C[c].depth > 0 ? C[c].depth / dt : fmax(g_spec[LLM_SPEC_ERP] * C[c].depth / dt, -g_spec[LLM_SPEC_MAX_DEPEN_SPEED]);
+        bias[nr] = row_bias(C[c].depth, dt, g_spec[LLM_SPEC_ERP], 1);
         lo[nr] = 0; hi[nr] = INFINITY; fric_of[nr] = -1; mu_row[nr] = 0;
       } else {
         bias[nr] = 0; lo[nr] = 0; hi[nr] = 0; fric_of[nr] = nr - r; mu_row[nr] = C[c].mu;
@@ -1140,7 +1149,7 @@ static int assemble_rows(const OModel* M, double dt, double mu_foot, const doubl
         J[nr][d] = rel;
       }
       if (r == 0) {
-        bias[nr] = SC[c].depth > 0 ? SC[c].depth / dt : fmax(g_spec[LLM_SPEC_ERP] * SC[c].depth / dt, -g_spec[LLM_SPEC_MAX_DEPEN_SPEED]);
+        bias[nr] = row_bias(SC[c].depth, dt, g_spec[LLM_SPEC_ERP], 1);
         lo[nr] = 0; hi[nr] = INFINITY; fric_of[nr] = -1; mu_row[nr] = 0;
       } else {
         bias[nr] = 0; lo[nr] = 0; hi[nr] = 0; fric_of[nr] = nr - r; mu_row[nr] = mu_self;
@@ -1494,7 +1503,7 @@ int orc_substep_pair_model(const OModel* M, double dt, int n_iter, const double*
         for (int k = 0; k < NDOF; k++) dd += Jp[q][side][k] * MJ[q][side][k];
       }
       dinv[q] = 1.0 / dd;
-      bias[q] = r ? 0.0 : (PC[c].depth > 0 ? PC[c].depth / dt : fmax(LLM_ERP * PC[c].depth / dt, -LLM_MAX_DEPEN_SPEED));
+      bias[q] = r ? 0.0 : row_bias(PC[c].depth, dt, g_spec[LLM_SPEC_ERP], 1);
       lam[q] = 0;
     }
     if (pair_rows && c < 2) { for (int i = 0; i < 3; i++) { pair_rows[8 * c + i] = PC[c].P[i]; pair_rows[8 * c + 3 + i] = PC[c].n[i]; } pair_rows[8 * c + 6] = PC[c].depth; pair_rows[8 * c + 7] = PC[c].id; }

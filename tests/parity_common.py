@@ -617,6 +617,44 @@ def check_reset_onto_a_mocap_discontinuity(orc, model_blob, table, lib_path):
     return worst
 
 
+def check_deep_penetration_against_oracle(orc, model_blob, table, lib_path, spec, depths=(0.005, 0.03, 0.045, 0.08)):
+    """Robots set INTO the ground (feet 5 ... 80 mm below the plane: shallow, around and beyond Bullet's -0.04 threshold) and stepped once, engine against
+    oracle under the same penetration-recovery switches (LLM_SPEC_ERP, _ERP_DEEP, _MAX_DEPEN_SPEED): the push-out speed is where those switches act, and
+    the deep branch is not met by the random-action parity runs.  Returns the base's upward speeds after the step, per depth."""
+    n = len(depths)
+    E = make_engine(model_blob, table, n, lib_path, auto_reset=0)
+    E.set_spec(**spec)
+    orc.reset_spec(); orc.set_spec(**spec)
+    try:
+        B = make_oracle_batch(orc, model_blob, table, n_envs=n)
+        clip, t0 = np.zeros(n, np.int32), np.full(n, 0.3)
+        E.reset(clip=clip, t0=t0)
+        s0 = E.state().astype(np.float64)
+        foot_z = np.array([np.asarray(B.fk_feet(s0[i])).reshape(4, 3)[:, 2].min() for i in range(n)]) - 0.025        # lowest point of the foot spheres (URDF:158)
+        for i, d in enumerate(depths):
+            s0[i, 2] -= foot_z[i] + d                                   # lowest foot sphere d below the plane
+            s0[i, 7:13] = 0.0; s0[i, 25:37] = 0.0                       # at rest: what moves it afterwards is the push-out (and gravity)
+        E.set_state(s0.astype(np.float32))
+        s0 = E.state().astype(np.float64)
+        for i in range(n):
+            B.reset_env(i, 0, 0.3); B.set_state(i, s0[i])
+        act = np.zeros((n, 12), np.float32)
+        E.step_host(act)
+        es = E.state().astype(np.float64)
+        up = []
+        for i in range(n):
+            B.step_env(i, act[i].astype(np.float64))
+            os_ = B.get_state(i)
+            err = np.abs(quat_align(es[i], os_) - os_)
+            assert err[0:7].max() < PHYS_STEP_TOL and err[13:25].max() < PHYS_STEP_TOL, (spec, depths[i], err[0:7].max(), err[13:25].max())
+            assert err[7:13].max() < 1e-3 * (1 + np.abs(os_[25:37]).max()), (spec, depths[i], err[7:13].max())
+            up.append(os_[2] - s0[i, 2])
+        return np.array(up)
+    finally:
+        orc.reset_spec()
+        E.close()
+
+
 def check_scripted_episodes_against_goldens(golden, model_blob, table, lib_path):
     """The engine's whole step() control flow against the REFERENCE's own outputs (golden G5): 12 scripted episodes driven
     exactly as gen_golden.py drove the reference through its fake BulletClient -- physics result and foot positions

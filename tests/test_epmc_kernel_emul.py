@@ -53,6 +53,16 @@ def test_pyramid_friction_variant(emul_lib):
         ec.check_multi_step_launch(emul_lib)
 
 
+def test_bullet_limit_rows_variant(emul_lib):
+    """LLM_SPEC_LIMIT_SPECULATIVE = 0 (btMultiBodyJointLimitConstraint's rule: a row only once the limit is passed, no gate) on terrain, engine against the
+    oracle under the same switch; and the two-ERP penetration recovery without the cap (LLM_SPEC_ERP_DEEP)"""
+    with ec.spec_variant(limit_speculative=0):
+        ec.check_terrain_physics_against_oracle(emul_lib, cap_ill=4)
+        ec.check_multi_step_launch(emul_lib)
+    with ec.spec_variant(limit_speculative=0, erp_deep=0.08, max_depen_speed=1e30):
+        ec.check_terrain_physics_against_oracle(emul_lib, cap_ill=4)
+
+
 def test_trunk_on_edges_against_oracle(emul_lib):
     out = ec.check_trunk_on_edges_against_oracle(emul_lib)
     print(out['n_edge_felt'], max(out['config']), max(out['vel']))

@@ -73,6 +73,17 @@ def test_pyramid_friction_variant():
         ec.check_multi_step_launch(None, sizes=(70, 4200), k=7, n_launches=3)
 
 
+def test_bullet_limit_rows_variant():
+    """LLM_SPEC_LIMIT_SPECULATIVE = 0 (btMultiBodyJointLimitConstraint's rule, round 5: an engine switch) against the oracle under the same switch --
+    terrain physics in both register budgets -- and its multi-step launch against single launches; then with the penetration recovery moved too."""
+    with ec.spec_variant(limit_speculative=0):
+        ec.check_terrain_physics_against_oracle(None, n_envs=48, cap_ill=3, cap_tie=3)
+        ec.check_terrain_physics_against_oracle(None, n_envs=24, total_envs=4096 + 256, cap_ill=2, cap_tie=5)
+        ec.check_multi_step_launch(None, sizes=(70, 4200), k=7, n_launches=3)
+    with ec.spec_variant(limit_speculative=0, erp=0.08, limit_erp=0.2, max_depen_speed=1e30):
+        ec.check_terrain_physics_against_oracle(None, n_envs=48, cap_ill=3, cap_tie=3)
+
+
 def test_trunk_on_edges_against_oracle():
     out = ec.check_trunk_on_edges_against_oracle(None, n_envs=48, cap_ill=4, cap_tie=7)         # observed (96 cases, cone friction): 3 / 6  (pyramid: 6 / 8)
     assert out['n_edge_felt'] >= 24

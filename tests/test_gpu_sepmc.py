@@ -61,6 +61,18 @@ def test_pyramid_friction_variant_gpu():
         SC.check_multi_step_launch(None, sizes=(35, 2100), k=7, n_launches=3)
 
 
+def test_bullet_limit_rows_variant_gpu():
+    """LLM_SPEC_LIMIT_SPECULATIVE = 0 (btMultiBodyJointLimitConstraint's rule, round 5: an engine switch) against the two-robot oracle under the same
+    switch, both register budgets, and its multi-step launch against single launches; then with the penetration recovery moved too."""
+    import epmc_parity_common as ec
+    with ec.spec_variant(limit_speculative=0):
+        print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=9))
+        print(SC.check_pair_physics_against_oracle(None, n_arenas=24, seed=9, total_arenas=2048 + 128))
+        SC.check_multi_step_launch(None, sizes=(35, 2100), k=7, n_launches=3)
+    with ec.spec_variant(limit_speculative=0, erp=0.08, limit_erp=0.2, max_depen_speed=1e30):
+        print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=9, cap_ill=3))
+
+
 def test_trained_reference_policy_plays_chase_tag_gpu():
     print(SC.check_trained_policy_plays_chase_tag(None, n_arenas=128, horizon=700, min_caught=0.6))
 

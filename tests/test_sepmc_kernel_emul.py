@@ -64,6 +64,19 @@ def test_pyramid_friction_variant(emul_lib):
         SC.check_multi_step_launch(emul_lib)
 
 
+def test_bullet_limit_rows_variant(emul_lib):
+    """LLM_SPEC_LIMIT_SPECULATIVE = 0 (btMultiBodyJointLimitConstraint's rule) with two robots, engine against the oracle under the same switch; and
+    the two-ERP penetration recovery without the cap (robots that spawn inside each other are where the cap was meant to act)"""
+    import epmc_parity_common as ec
+    with ec.spec_variant(limit_speculative=0):
+        print(SC.check_pair_physics_against_oracle(emul_lib))
+        SC.check_multi_step_launch(emul_lib)
+    with ec.spec_variant(limit_speculative=0, erp_deep=0.08, max_depen_speed=1e30):
+        # (robots of this case set START up to 5 cm inside each other; without the cap their push-out hangs on the closest-point normal of two crossing
+        # capsule axes, and the second ERP is a step in the bias at -0.04: two of the 48 robots are ill-conditioned in the oracle itself, one with the cap on)
+        print(SC.check_pair_physics_against_oracle(emul_lib, cap_ill=2))
+
+
 def test_reset_of_a_subset_of_arenas(emul_lib):
     """ll_sepmc_reset(arena_ids): only the listed arenas are re-seeded (new arena, roles, flag, poses, zeroed history); the
     others keep their state, episode scalars and observations bit for bit."""

@@ -56,6 +56,17 @@ case $TARGET in
     for r in 1 2; do for sp in "" "friction_mode=2"; do echo "== spec '$sp' (round $r)"; LL_SWEEP_SPEC=$sp python tools/sweep.py "4096:4:10:10:32,4096:4:10:10:1,65536:4:10:10:1,65536:4:10:10:8"; done; done > $OUT/cone_sweep.txt 2>&1
     cat $OUT/cone_sweep.txt
     for v in "spec (as shipped)" "friction cone-coupled"; do python tools/deviation_table.py --engine --only "$v" 2>&1 | tail -1; done > $OUT/cone_policy.txt; cat $OUT/cone_policy.txt ;;
+  r05a)          # round 5, first call: the engine twins of the joint-limit rule and the penetration-recovery switches -- GPU parity, kernel time, and the five policies per variant (one process per variant)
+    gpu_tests -k "bullet_limit or two_erp"
+    for r in 1 2; do for sp in "" "limit_speculative=0" "limit_speculative=0,erp=0.08,limit_erp=0.2,max_depen_speed=1e30"; do echo "== spec '$sp' (round $r)"; LL_SWEEP_SPEC=$sp python tools/sweep.py "4096:4:10:10:32,4096:4:10:10:1,65536:4:10:10:1"; LL_SWEEP_SPEC=$sp python tools/sweep_epmc.py "4096:1:32,65536:1:1"; LL_SWEEP_SPEC=$sp python tools/sweep_sepmc.py "2048:0:32,32768:0:1"; done; done > $OUT/limit_sweep.txt 2>&1
+    cat $OUT/limit_sweep.txt
+    i=0
+    while IFS= read -r v; do
+      OMP_NUM_THREADS=2 python tools/spec_table.py --engine --variants "$v" > $OUT/engine_$i.md 2> $OUT/engine_$i.err &
+      i=$((i+1))
+    done < tools/r05_variants.txt
+    wait
+    cat $OUT/engine_*.md | grep -v "^| simulator\|^|---" ; tail -n 2 $OUT/engine_*.err | tail -20 ;;
   final)         # the round's closing call: the whole -m gpu suite at HEAD, then the three bench lines against the committed counters
     gpu_tests
     python bench.py > $OUT/bench.log 2>$OUT/bench.err; tail -c 400 $OUT/bench.log
