@@ -197,6 +197,14 @@ def main():
             import socket
             s_ = socket.socket(); s_.bind(('127.0.0.1', 0)); os.environ['MASTER_PORT'] = str(s_.getsockname()[1]); s_.close()
         kw = {'device_id': torch.device('cuda', local_rank)} if backend == 'nccl' else {}
+        rccl_log = None
+        if backend == 'nccl' and rank == 0:
+            # RCCL's own version line (NCCL_DEBUG=VERSION prints it at communicator creation) goes to a file of this process and from there into the JSON,
+            # so that a scaling record can be checked against the library that actually ran
+            import tempfile
+            rccl_log = os.path.join(tempfile.gettempdir(), 'll_bench_rccl_%d.log' % os.getpid())
+            os.environ.setdefault('NCCL_DEBUG', 'VERSION')
+            os.environ.setdefault('NCCL_DEBUG_FILE', rccl_log)
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     def dev_sync():
@@ -248,10 +256,12 @@ def main():
 
     n_done = [0]                                           # control steps executed so far == the engine's step index
     spl = max(1, args.steps_per_launch)
+    # the timed region is never ONE launch, however few steps the caller asks for (the driver's own invocation times 20): a third of them per launch at most
+    spl_timed = max(1, min(spl, -(-args.steps // 3)))
     if traj is not None and UNROLL % spl:
         raise SystemExit('--steps-per-launch must divide the unroll length %d' % UNROLL)
 
-    def run_steps(count):
+    def run_steps(count, spl=spl):
         """`count` control steps of the random-policy loop: launches of up to `spl` steps each (ll_step_random_n draws a ~ N(0, sigma^2)
         on device and steps, `spl` times per launch), cut at unroll boundaries, where the finished unroll is handed to the gather."""
         left = count
@@ -278,7 +288,7 @@ def main():
     dev_sync()
     eng.enable_kernel_timing(True)
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(args.steps, spl_timed)
     if traj is not None:
         traj.wait()                                          # an in-flight gather belongs to the timed region
     dev_sync()
@@ -299,6 +309,23 @@ def main():
         elapsed = float(tt[0].item())
         gather_stats = {'mode': args.gather_mode, 'backend': backend, 'stream_stall_ms_total': float(tt[1].item()), 'host_blocked_ms_total': float(tt[2].item()),
                         'bytes_per_rank_per_unroll': int(traj.buf[0].numel() * 4)}
+        # who took part: every rank reports itself over the process group (rank, pid, device ordinal and name, envs it stepped, episodes it finished)
+        me = {'rank': rank, 'pid': os.getpid(), 'device': local_rank, 'device_name': torch.cuda.get_device_name(local_rank) if tc else None,
+              'envs': n, 'control_steps': int(n_done[0]), 'episodes': int(eng.counters()['episodes']), 'stale_reseeds': int(eng.table_sync())}
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        gather_stats['ranks_seen'] = seen
+        gather_stats['receive_blocks'] = [len(traj.outs), len(traj.outs[0])] if (rank == 0 and traj.outs is not None) else None     # [2][world] on the learner rank
+        if backend == 'nccl':
+            try:
+                gather_stats['rccl_version'] = '.'.join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:            # noqa: BLE001
+                gather_stats['rccl_version'] = None
+            try:
+                lines_ = [l.strip() for l in open(os.environ.get('NCCL_DEBUG_FILE', '')).read().splitlines() if 'version' in l.lower()] if rank == 0 else []
+                gather_stats['rccl_version_line'] = lines_[0] if lines_ else None
+            except OSError:
+                gather_stats['rccl_version_line'] = None
         if os.environ.get('LL_BENCH_VERIFY') and traj.n_gathered > 0:
             # what rank 0 received for the last gathered unroll == what each rank's engine holds in that block (float64 checksums + probes)
             k_last = traj.n_gathered - 1
@@ -311,6 +338,7 @@ def main():
                 got_sig = [[float(g.sum()), float(g.abs().sum()), float(g[0, 0, 0]), float(g[-1, -1, -1]), float(g[n // 2, UNROLL // 2, 207])] for g in got]
                 gather_check = 'ok' if got_sig == sigs and len({tuple(x) for x in sigs}) == world else 'MISMATCH %r vs %r' % (got_sig, sigs)
     counters = eng.counters()
+    stale_reseeds = eng.table_sync()                         # (before the single-step leg; 0 unless the chip was shared: ll_get_table_sync)
     ep_hist = [int(x) for x in eng.episode_histogram()]
     # The like-for-like leg (round-3 advice): the same loop as ONE launch per control step -- what an actor with a policy between the steps
     # runs, and what rounds 1-2 reported; the prioritized-sampling table is folded after every step, as PLE:235-240 does.  Measured after the
@@ -342,7 +370,8 @@ def main():
         # neglogp, R, V, r, mask) -- stated and added to the algorithmic bytes
         algo_bytes = ALGO_BYTES_PER_ENV_STEP + (4 * int(traj.buf.shape[-1]) if traj is not None else 0)
         achieved = (n * algo_bytes) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
-        traffic, issue, tsrc = committed_counters('pmc_step_kernel', n, spl)
+        traffic, issue, tsrc = committed_counters('pmc_step_kernel', n, spl)               # (the committed passes ran launches of `spl` steps)
+        cspl = (k_steps / k_n) if k_n else float(spl_timed)                               # control steps per timed launch, as run
         if issue and k_ms > 0:
             # chip-level VALU utilisation: VALU instructions of all waves of a control step x 2 cycles (a SIMD's rate for a full-rate wave64
             # instruction with >= 2 resident waves: MI355X_MICROARCH.md, measured in profiles/r04_valu_issue.txt) over the SIMD-cycles the step took
@@ -359,18 +388,22 @@ def main():
             'config': {'workload': 'PMC tracking env, %d parallel envs per MI355X, flat terrain, full mocap_data clip set '
                                    '(62 clips), random-policy actions N(0, e^-2), auto-reset%s' % (n, ', RCCL trajectory gather to rank 0 every %d steps' % UNROLL if multi else ''),
                        'envs_per_gpu': n, 'substeps_per_step': 10, 'solver_iterations': 10,
-                       'steps_per_launch': spl,
-                       'steps_per_launch_note': 'the timed region runs ll_step_random_n: %d control steps of the random-policy loop per kernel launch '
-                                                '(every step is complete: physics, mocap, obs, reward, termination, re-seed, unroll row); '
-                                                '--steps-per-launch 1 is one launch per control step' % spl,
+                       'steps_per_launch': spl_timed,
+                       'steps_per_launch_note': 'the timed region runs ll_step_random_n: up to %d control steps of the random-policy loop per kernel launch, at least three '
+                                                'launches (every step is complete: physics, mocap, obs, reward, termination, re-seed, unroll row, and the prioritized-sampling '
+                                                'table folded after EVERY step -- a re-seed at step s of a launch draws from the table steps 0 .. s - 1 left, PLE:235-240: k steps in one '
+                                                'launch are k launches bit for bit); --steps-per-launch 1 is one launch per control step' % spl_timed,
+                       'table_sync_stale_reseeds_rank0': stale_reseeds,
                        'episodes_finished_rank0': counters['episodes'], 'nonfinite_resets_rank0': counters['nonfinite'],
                        'mean_episode_length_steps_rank0': (counters['env_steps'] / counters['episodes']) if counters['episodes'] else None,
                        'episode_length_histogram_rank0': {'bucket_lower_edges_steps': [1 << b for b in range(16)], 'episodes': ep_hist},
                        **({'unrolls_gathered': traj.n_gathered, 'unroll_row_floats': int(traj.buf.shape[-1]), 'gather_check': gather_check,
                            'gather': gather_stats} if traj is not None else {})},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': (achieved / HBM_PEAK_GBPS) if achieved else None, 'traffic': traffic, 'traffic_per_control_step': (traffic / spl) if traffic else None,
-                         'algorithmic_bytes_per_launch': n * algo_bytes * spl, 'peak_measured_triad': triad, 'peak_measured_triad_when': 'before the warm-up steps' if triad_first else 'after the timed region',
+                         'frac': (achieved / HBM_PEAK_GBPS) if achieved else None,
+                         # per launch like `achieved`: the committed counter passes ran launches of `spl` control steps; this run's launches average cspl
+                         'traffic': (traffic / spl * cspl) if traffic else None, 'traffic_per_control_step': (traffic / spl) if traffic else None,
+                         'algorithmic_bytes_per_launch': n * algo_bytes * cspl, 'peak_measured_triad': triad, 'peak_measured_triad_when': 'before the warm-up steps' if triad_first else 'after the timed region',
                          'traffic_source': tsrc,
                          'kernel': 'pmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n,
                          'kernel_avg_launch_ms': k_launch_ms, 'control_steps_per_launch': (k_steps / k_n) if k_n else None,
@@ -382,6 +415,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(blob, table)
         print(json.dumps(out), flush=True)
+    if traj is not None:
+        if multi:
+            dist.barrier()                                   # nobody unmaps what a peer may still be pulling
+        traj.close()
     eng.close()
     if multi:
         dist.destroy_process_group()

@@ -290,6 +290,10 @@ int ll_get_feet(ll_engine* e, float* h_feet_dyn /*[n_envs][4][3]*/, float* h_fee
 
 /* Counters for bench/diagnostics: total env-steps executed, episodes finished, non-finite resets. */
 int ll_get_counters(ll_engine* e, uint64_t* steps, uint64_t* episodes, uint64_t* nonfinite);
+/* Episodes that re-seeded inside a multi-step launch (ll_step_random_n) from an OLDER version of the sampling table than the exact one (the table as the
+ * steps before theirs left it, primitive_level_env.py:235-240): zero whenever the launch had the chip to itself.  A re-seeding wavefront waits for the
+ * version it needs only once every wavefront of its launch has started; while another kernel holds some of their SIMDs it takes the newest version there is. */
+int ll_get_table_sync(ll_engine* e, uint64_t* stale_reseeds);
 /* Finished episodes by length since creation: counts16[b] = episodes of 2^b .. 2^(b+1) - 1 control steps (b = 15: and longer); SURVEY 8d asks
  * for it next to the throughput so that the reset frequency of a benchmark is visible. */
 int ll_get_episode_histogram(ll_engine* e, uint64_t* counts16);

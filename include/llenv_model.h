@@ -49,6 +49,7 @@
 #define LLM_LIMIT_ERP (-1.0)            /* ERP of the joint-limit rows; < 0: LLM_ERP */
 #define LLM_LIMIT_SPECULATIVE 1         /* LLM_SPEC_LIMIT_SPECULATIVE below */
 #define LLM_ERP_DEEP (-1.0)             /* LLM_SPEC_ERP_DEEP below; < 0: one ERP at every depth */
+#define LLM_LIMIT_ERP_DEEP (-1.0)       /* LLM_SPEC_LIMIT_ERP_DEEP below */
 #define LLM_ERP_DEEP_BELOW (-0.04)      /* btContactSolverInfo::m_splitImpulsePenetrationThreshold (see LLM_SPEC_ERP_DEEP) */
 #define LLM_MAX_DEPEN_SPEED 0.5        /* m/s: cap on the penetration-recovery part of a contact row's bias (a body that starts inside an
                                           obstacle -- SEPMC spawns at random -- is pushed out gently instead of being shot out) */
@@ -126,6 +127,10 @@
                                            m_erp ("erp", 0.2) and m_erp2 ("contactERP"; PyBullet's server sets 0.08 as recalled); btSequentialImpulseConstraintSolver::setupContactConstraint
                                            and btMultiBodyJointLimitConstraint pick m_erp while penetration > m_splitImpulsePenetrationThreshold (-0.04) and m_erp2 below.  Oracle and engine */
 #define LLM_SPEC_ERP_DEEP_BELOW 24      /* m (rad for limit rows): default LLM_ERP_DEEP_BELOW = -0.04 */
-#define LLM_SPEC_COUNT 25
+#define LLM_SPEC_LIMIT_ERP_DEEP 25      /* ERP of a joint-limit row whose joint is further past its limit than LLM_SPEC_ERP_DEEP_BELOW (0.04 rad); < 0 = LLM_SPEC_ERP_DEEP, or no second ERP.
+                                           btMultiBodyJointLimitConstraint::createConstraintRows as recalled: with m_splitImpulse (btContactSolverInfo's default: true) and penetration
+                                           below m_splitImpulsePenetrationThreshold the positional part goes to m_rhsPenetration -- which no multibody solver pass applies -- and
+                                           m_rhs keeps the velocity part alone: the row stops the joint and does not push it back, i.e. ERP 0.  Oracle and engine */
+#define LLM_SPEC_COUNT 26
 
 #endif

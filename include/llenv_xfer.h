@@ -56,6 +56,20 @@ int ll_xfer_stream_synchronize(void* hip_stream);
  * no_cu == 0: the runtime's default device-to-device path (a copy kernel when source and destination share a device): the A/B leg. */
 int ll_xfer_pull(void* d_dst, const void* d_src, size_t bytes, int no_cu, void* hip_stream);
 
+
+/* ---- stream-ordered hand-shake on a 32-bit word (round 5): takes the HOST out of the producer's side of the hand-off.  ROCm implements a
+ * stream wait on an INTERPROCESS event as a host-side wait (the call returns when the event has completed), so a producer that must not overwrite
+ * block k - 1 before the learner has copied it used to block its launching thread.  Instead: a word of signal memory of the producer's own
+ * (hipExtMallocWithFlags(hipMallocSignalMemory)); the engine's stream waits on the DEVICE until the word has reached the unroll number
+ * (ll_xfer_stream_wait_value: hipStreamWaitValue32, >=), and a helper thread -- the only one that ever blocks on the interprocess event -- raises it
+ * from a stream of its own (ll_xfer_stream_write_value).  The launching thread queues and goes on. */
+int ll_xfer_can_wait_value(int device, int* yes);                                  /* hipDeviceAttributeCanUseStreamWaitValue */
+int ll_xfer_signal_create(int device, void** d_word_out);                          /* one zeroed 64-bit word of signal memory */
+int ll_xfer_signal_destroy(int device, void* d_word);
+int ll_xfer_stream_wait_value(void* hip_stream, void* d_word, uint32_t value);    /* nothing queued on hip_stream afterwards runs before *d_word >= value */
+int ll_xfer_stream_write_value(void* hip_stream, void* d_word, uint32_t value);   /* *d_word = value, in stream order */
+int ll_xfer_set_device(int device);                                                /* hipSetDevice for the CALLING thread (helper threads start on device 0) */
+
 #ifdef __cplusplus
 }
 #endif

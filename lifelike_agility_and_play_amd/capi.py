@@ -21,7 +21,7 @@ PLE_DEFAULT_REWARD_WEIGHTS = {'joint_pos': 0.6, 'joint_vel': 0.05, 'end_effector
 DONE_FALL, DONE_CLIP_END, DONE_DIVERGED, DONE_COLLISION, DONE_NONFINITE = 1, 2, 4, 8, 16
 SPEC_IDS = dict(limit_gate=0, max_depen_speed=1, link_damping=2, max_contacts_per_leg=3, self_collision=4, self_margin=5, max_self=6,
                 erp=7, contact_margin=8, self_friction=9, warm_start=10, trunk_edges=11, select_eps=12,
-                friction_mode=13, row_order=14, max_coord_vel=15, limit_erp=16, pair_friction=17, max_pair=18, friction_dirs=19, limit_speculative=20, gyro=21, friction_keep=22, erp_deep=23, erp_deep_below=24)                                       # include/llenv_model.h LLM_SPEC_*
+                friction_mode=13, row_order=14, max_coord_vel=15, limit_erp=16, pair_friction=17, max_pair=18, friction_dirs=19, limit_speculative=20, gyro=21, friction_keep=22, erp_deep=23, erp_deep_below=24, limit_erp_deep=25)                                       # include/llenv_model.h LLM_SPEC_*
 LL_SELECT_EPS = 1e-5                                                                                         # include/llenv_model.h LLM_SELECT_EPS
 LLM_FRICTION_MODE = 2                                                                                        # include/llenv_model.h LLM_FRICTION_MODE: cone-coupled friction (0: the pyramid)
 LL_DONE_FALL, LL_DONE_CLIP_END, LL_DONE_DIVERGED, LL_DONE_COLLISION, LL_DONE_NONFINITE = 1, 2, 4, 8, 16      # include/llenv.h:65-69
@@ -116,6 +116,7 @@ _SIGS = {
     'll_set_sampling_table': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_get_feet': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'll_get_counters': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'll_get_table_sync': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_get_episode_histogram': (C.c_int, [C.c_void_p, C.c_void_p]),
     'll_kernel_time_ms': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'll_enable_kernel_timing': (C.c_int, [C.c_void_p, C.c_int]),
@@ -338,6 +339,12 @@ class Engine(object):
         a = np.ascontiguousarray(avg_reward_sum, dtype=np.float64)
         assert a.shape == (self.n_clips,)
         self._chk(self.lib.ll_set_sampling_table(self.h, _ptr(a)))
+
+    def table_sync(self):
+        """episodes that re-seeded inside a multi-step launch from an older table version than the exact one (ll_get_table_sync; 0 unless the chip was shared)"""
+        a = C.c_uint64()
+        self._chk(self.lib.ll_get_table_sync(self.h, C.byref(a)))
+        return a.value
 
     def counters(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -541,7 +541,8 @@ struct GpuLanes {
     float c = 0.0f;
     for (int i0 = 0; i0 < n; i0 += PMC_ROW) {
       const int i = i0 + lane16_;
-      if (i < n && p[i] <= u) c += 1.0f;
+      // (device-scope load: inside a multi-step launch the table version was written by a wave on another XCD, whose L2 is not this one's)
+      if (i < n && __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= u) c += 1.0f;
     }
     return (int)qsum(subsum(c));
   }

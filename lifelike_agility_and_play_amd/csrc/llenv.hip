@@ -77,40 +77,93 @@ __device__ __forceinline__ double wave_sum(double x) {
   for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
   return x;
 }
-__device__ __forceinline__ void table_fold_wave(const StepParams& P) {
+// (Everything the fold reads and writes goes through device-scope accesses: inside a multi-step launch consecutive folds run on different
+// wavefronts, possibly on different XCDs whose L2s are not coherent with each other, and the versions are read by re-seeding waves anywhere.)
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the kernel's first by-value argument where it lies in the kernarg segment (StepParams::kFirstKernelArgument; lanes.hpp WithParamsReload::params)
+__device__ __forceinline__ const StepParams& kernarg_params() {
+  const __attribute__((address_space(4))) void* k = (const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(k));
+  return *(const StepParams*)(const __attribute__((address_space(4))) StepParams*)k;
+}
+// (table_fold_wave_out_of_line) Out of line on purpose in the multi-step kernels: inlined into the step loop its double-precision pow and scans cost the step kernel registers it does not have (the
+// one-wave-per-SIMD multi-step build went from 234 to 256 AGPRs plus 76 B of scratch).
+// sl: the control step of the launch whose finished episodes are folded; the resulting CDF goes to `cdf` itself after the launch's last step and to
+// version slot sl + 1 otherwise (what a re-seed at step sl + 1 samples from: Pmc::table_for_reseed)
+__device__ __forceinline__ void table_fold_wave(const StepParams& P, int sl, bool last_step) {
   const int lane = threadIdx.x & 63, n = P.n_clips;
+  unsigned long long* pend_r = P.pending_reward + (long)sl * n;
+  unsigned long long* pend_l = P.pending_len + (long)sl * n;
+  const double* prev = sl == 0 ? P.cdf : P.cdf_ver + (long)sl * n;
+  double* dst = last_step ? P.cdf : P.cdf_ver + (long)(sl + 1) * n;
   bool mine = false;
   for (int c = lane; c < n; c += PMC_WAVE) {
-    const unsigned long long pr = __hip_atomic_load(P.pending_reward + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long pl = __hip_atomic_load(P.pending_len + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long pr = __hip_atomic_load(pend_r + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long pl = __hip_atomic_load(pend_l + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (pr) {
-      P.avg_reward[c] = (double)__uint_as_float((uint32_t)pr);
-      P.avg_len[c] = (double)__uint_as_float((uint32_t)pl);
-      __hip_atomic_store(P.pending_reward + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(P.pending_len + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      st_agent(P.avg_reward + c, (double)__uint_as_float((uint32_t)pr));
+      st_agent(P.avg_len + c, (double)__uint_as_float((uint32_t)pl));
+      __hip_atomic_store(pend_r + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(pend_l + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       mine = true;
     }
   }
-  if (!__any(mine)) return;
+  if (!__any(mine)) {                                 // nothing ended in this step: the next version is the previous one
+    if (dst != prev) for (int c = lane; c < n; c += PMC_WAVE) st_agent(dst + c, ld_agent(prev + c));
+    return;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (a lane re-reads what it has just stored)
   double part = 0.0;
   for (int c = lane; c < n; c += PMC_WAVE) {
-    const double p = pow(1.0 - P.avg_reward[c], P.sample_factor);
-    P.prob[c] = p;
+    const double p = pow(1.0 - ld_agent(P.avg_reward + c), P.sample_factor);
+    st_agent(P.prob + c, p);
     part += p;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const double inv = 1.0 / wave_sum(part);
   double carry = 0.0;
   for (int c0 = 0; c0 < n; c0 += PMC_WAVE) {       // inclusive scan, 64 clips per pass
     const int c = c0 + lane;
     double x = 0.0;
-    if (c < n) { x = P.prob[c] * inv; P.prob[c] = x; }
+    if (c < n) { x = ld_agent(P.prob + c) * inv; st_agent(P.prob + c, x); }
     for (int d = 1; d < PMC_WAVE; d <<= 1) {
       const double y = __shfl_up(x, d);
       if (lane >= d) x += y;
     }
     x += carry;
-    if (c < n) P.cdf[c] = (c == n - 1) ? 1.0 : x;
+    if (c < n) st_agent(dst + c, (c == n - 1) ? 1.0 : x);
     carry = __shfl(x, PMC_WAVE - 1);
+  }
+}
+__device__ __attribute__((noinline)) void table_fold_wave_out_of_line(const StepParams& P, int sl, bool last_step) { table_fold_wave(P, sl, last_step); }
+// The last workgroup to finish control step `sl` of the launch folds that step's finished episodes into the sampling table.  The statistics travel
+// by device-scope atomics only (publish_max), so no cache write-back is needed -- a __threadfence() here would flush this XCD's L2 once per
+// workgroup.  Waiting for the wave's own atomics to be acknowledged before it takes its ticket orders them ahead of the ticket.  Folds run in step
+// order: the wave that folds step sl first waits for the mark of step sl - 1 (every wave has finished step sl - 1 by then, so its folding wave is
+// running or done).  `multi`: the launch runs several steps and re-seeds read the versions, so the fold is published with a mark.
+__device__ __forceinline__ void step_done_fold(const StepParams& P, int sl, bool last_step, bool multi) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned int ticket = 0;
+  if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(P.block_ticket + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket != gridDim.x - 1) return;
+  if (multi && sl > 0)
+    while (__hip_atomic_load(P.ver_ready + (sl - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.launch_serial) __builtin_amdgcn_s_sleep(2);
+  asm volatile("" ::: "memory");
+  if (multi) table_fold_wave_out_of_line(P, sl, last_step);      // (P: a reference into the kernarg segment -- nothing is copied to the stack for the call)
+  else table_fold_wave(P, sl, last_step);                        // the single-step kernels fold inline at their very end, as they always have
+  if (threadIdx.x == 0) __hip_atomic_store(P.block_ticket + sl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (multi) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the version's (write-through, device-scope) stores are acknowledged before its mark goes out
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(P.ver_ready + sl, P.launch_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (last_step) __hip_atomic_store(P.resident, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -168,12 +221,17 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
       step_actions(P, ln, lds, env0, 0, act);
       Pmc<Lanes>::template step_env<OBST, CONE>(ln, P, env0, act, 0);
     }
+    step_done_fold(P, 0, true, false);
   } else {
     // ll_step_random_n: n_steps control steps back to back.  A wave walks its four envs through them on its own -- no other wave is waited
     // for, so a slow step of one wave (leg-leg rows, a re-seed) is not a slow step of the whole chip -- and between two steps it only has
     // to see its own stores (state, obs row, bookkeeping: workgroup-scope fence = wait for the wave's outstanding memory operations).
     // (Dealing the steps out dynamically -- a per-XCD ready queue of (step, group) items -- was built and measured in round 4: 0.8 % slower,
     // there is no imbalance left to win inside a multi-step launch; profiles/r04_dyn_steps.txt.)
+    // The sampling table keeps PLE:235-240 inside the launch: every step is folded by the last wave to finish it into a version of its own, and an
+    // episode that re-seeds at step s draws from the version steps 0 .. s - 1 left (step_done_fold, Pmc::table_for_reseed): k steps in one launch are
+    // k launches, bit for bit, table included.
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(P.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // "this wave has started"
     for (int sl = 0; sl < P.n_steps; sl++) {
       if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       ln.new_step();
@@ -184,19 +242,9 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
         step_actions(P, ln, lds, env, sl, act);
         Pmc<Lanes>::template step_env<OBST, CONE>(ln, P, env, act, sl);
       }
+      const StepParams& Pr = kernarg_params();      // (re-read from the kernarg segment like the step itself: nothing of it is parked in spilled SGPRs across the step)
+      step_done_fold(Pr, sl, sl == Pr.n_steps - 1, true);
     }
-  }
-  // The last workgroup to get here folds this step's finished episodes into the sampling table.  The statistics travel by
-  // device-scope atomics only (publish_max), so no cache write-back is needed -- a __threadfence() here would flush this
-  // XCD's L2 once per workgroup.  Waiting for the wave's own atomics to be acknowledged before it takes its ticket orders
-  // them ahead of the ticket; the folding wave reads them back with device-scope atomic loads.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  unsigned int ticket = 0;
-  if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(P.block_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  ticket = __builtin_amdgcn_readfirstlane(ticket);
-  if (ticket == gridDim.x - 1) {
-    table_fold_wave(P);
-    if (threadIdx.x == 0) __hip_atomic_store(P.block_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -349,6 +397,7 @@ struct HipBackend {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, dev));
     simds = prop.multiProcessorCount * 4;             // four SIMDs per compute unit
+    simds_hw = simds;
     // LL_SHARE_SIMDS=1: always launch the 256-register builds, also when the grid would fit one 512-register wavefront per SIMD.  A
     // wavefront of the one-wave-per-SIMD builds owns its SIMD's whole register file, so any other kernel that is resident at the same
     // time -- RCCL's gather on the learner rank -- DISPLACES step-kernel waves instead of sharing SIMDs with them, and the step launch
@@ -363,6 +412,13 @@ struct HipBackend {
     if (own) (void)hipStreamDestroy(own);
   }
   void use() { HIPCHK(hipSetDevice(device)); }
+  int simds_hw = 1024;
+  // can every workgroup of a step launch be on the chip at once?  (one 512-register wave per SIMD while the grid fits, two 256-register waves otherwise:
+  // launch_step.)  A multi-step launch needs it -- its waves wait for each other's finished episodes (PmcEngine::step)
+  bool co_resident(const StepParams& P) const {
+    const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
+    return blocks <= simds || blocks <= 2 * simds_hw;
+  }
   void set_stream(void* s) { stream = s ? (hipStream_t)s : own; }
   void* stream_handle() { return (void*)stream; }
   void* alloc(size_t bytes) {

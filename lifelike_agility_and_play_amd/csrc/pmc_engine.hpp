@@ -69,7 +69,9 @@ struct PmcEngine {
     P.actions = d_actions;
     P.counters = dalloc<unsigned long long>(4 + (size_t)PMC_TS_SLOTS * N);
     P.ep_hist = dalloc<unsigned long long>(16);
-    P.block_ticket = dalloc<unsigned int>(2);
+    P.block_ticket = dalloc<unsigned int>(LL_MAX_STEPS_PER_LAUNCH);
+    P.ver_ready = dalloc<unsigned int>(LL_MAX_STEPS_PER_LAUNCH);
+    P.resident = dalloc<unsigned int>(2);
     P.actions_out = d_actions;
     d_reset_ids = dalloc<int32_t>(N); d_reset_clip = dalloc<int32_t>(N); d_reset_t0 = dalloc<double>(N);
   }
@@ -103,8 +105,9 @@ struct PmcEngine {
     P.frames = fr; P.clip_off = dco; P.clip_len = dcl; P.max_steps = dms;
     d_avg_reward = dalloc<double>(n_clips); d_avg_len = dalloc<double>(n_clips);
     d_prob = dalloc<double>(n_clips); d_cdf = dalloc<double>(n_clips);
-    P.pending_reward = dalloc<unsigned long long>(n_clips);
-    P.pending_len = dalloc<unsigned long long>(n_clips);
+    P.pending_reward = dalloc<unsigned long long>((size_t)LL_MAX_STEPS_PER_LAUNCH * n_clips);
+    P.pending_len = dalloc<unsigned long long>((size_t)LL_MAX_STEPS_PER_LAUNCH * n_clips);
+    P.cdf_ver = dalloc<double>((size_t)LL_MAX_STEPS_PER_LAUNCH * n_clips);
     std::vector<double> prob(n_clips, 1.0 / n_clips), cdf(n_clips);            // ML:46
     double acc = 0;
     for (int c = 0; c < n_clips; c++) { acc += prob[c]; cdf[c] = acc; }
@@ -186,24 +189,36 @@ struct PmcEngine {
   // Philox stream as fill_random_actions(), so step_random(s) == fill_random_actions(s); step(nullptr).
   void step(const float* d_act, float sigma = 0.0f, int n_steps = 1) {
     need(true, true);
-    StepParams Q = P;
-    Q.actions = d_act ? d_act : d_actions;
-    Q.action_sigma = sigma;
-    Q.n_steps = n_steps;
-    set_unroll_slot(Q);
-    bk.launch_step(Q);
-    P.step_count += (uint64_t)n_steps;
+    // A launch runs at most LL_MAX_STEPS_PER_LAUNCH control steps (the per-step slots of the sampling table), and a multi-step launch whose grid
+    // the chip cannot hold at once runs as single launches: its waves could not wait for each other's finished episodes (bk.co_resident)
+    const int per = (n_steps > 1 && !bk.co_resident(P)) ? 1 : LL_MAX_STEPS_PER_LAUNCH;
+    for (int done = 0; done < n_steps;) {
+      const int k = n_steps - done < per ? n_steps - done : per;
+      StepParams Q = P;
+      Q.actions = d_act ? d_act : d_actions;
+      Q.action_sigma = sigma;
+      Q.n_steps = k;
+      if (++launch_serial == 0) launch_serial = 1;
+      Q.launch_serial = launch_serial;
+      Q.table_versions = (k > 1) ? 1 : 0;
+      set_unroll_slot(Q);
+      bk.launch_step(Q);
+      P.step_count += (uint64_t)k;
+      done += k;
+    }
   }
+  uint32_t launch_serial = 0;
   void step_random(float sigma) {
     if (!(sigma > 0.0f)) throw PmcError(LL_EINVAL, "sigma must be positive");
     step(nullptr, sigma);
   }
   // n_steps control steps of the random-policy loop in ONE launch: every wave walks its envs through the steps on its own, nothing
-  // waits for the slowest wave of a step and there is no launch gap.  The sampling table is folded once, by the launch's last workgroup.
+  // waits for the slowest wave of a step and there is no launch gap.  The sampling table is folded after EVERY step, by the last workgroup to
+  // finish that step, into a version of its own; an episode that re-seeds at step s samples from the version steps 0 .. s - 1 left (PLE:235-240
+  // as k single launches keep it), waiting for it if need be -- in practice only a wave that has run a whole step ahead of the slowest one waits.
   void step_random_n(float sigma, int n_steps) {
     if (!(sigma > 0.0f)) throw PmcError(LL_EINVAL, "sigma must be positive");
     if (n_steps <= 0) throw PmcError(LL_EINVAL, "n_steps must be positive");
-    if ((uint64_t)n_steps * ((uint64_t)P.n_envs + 1) >= (1ull << 32)) throw PmcError(LL_EINVAL, "n_steps x n_envs too large for the episode-order tag");
     if (d_traj && (uint64_t)n_steps > (uint64_t)traj_unroll * (uint64_t)traj_buffers)
       // With unrolls recorded a launch writes n_steps consecutive rows of the ring: more than the ring holds and it would overwrite rows of
       // its own.  (Running from one block into the next is allowed -- the rows land where single steps would put them, bit for bit -- but then

@@ -70,6 +70,8 @@ enum BaseConst {
 #define PMC_TS(k) do { } while (0)
 #endif
 
+#define LL_MAX_STEPS_PER_LAUNCH 128   // control steps one launch of ll_step_random_n runs at most (longer calls are split); sizes the per-step table slots
+
 struct StepParams {
   static constexpr bool kFirstKernelArgument = true;   // every kernel takes it first, by value: lanes.hpp WithParamsReload re-reads it from the kernarg segment
   int32_t n_envs, n_sub, n_iter, auto_reset;
@@ -91,7 +93,7 @@ struct StepParams {
   float limit_erp;          // ERP of the joint-limit rows as the kernel uses it (LLM_SPEC_LIMIT_ERP; the setter resolves "< 0 = erp")
   float erp_deep, limit_erp_deep, erp_deep_below;   // LLM_SPEC_ERP_DEEP / _BELOW as the kernel uses them: a row deeper than erp_deep_below takes erp_deep (limit rows: limit_erp_deep);
                             // without a second ERP both equal erp / limit_erp, so the kernel selects unconditionally
-  float spec_erp_deep, spec_limit_erp;   // what ll_set_spec_param was given (< 0: follow erp), kept for ll_get_spec_param and for re-resolving when erp moves
+  float spec_erp_deep, spec_limit_erp, spec_limit_erp_deep;   // what ll_set_spec_param was given (< 0: follow erp), kept for ll_get_spec_param and for re-resolving when erp moves
   int32_t limit_speculative;   // LLM_SPEC_LIMIT_SPECULATIVE: 1 = a limit row inside the range too (gated by limit_gate); 0 = Bullet's rule, a row only once the limit is passed
   float max_coord_vel;      // LLM_SPEC_MAX_COORD_VEL (btMultiBody::m_maxCoordinateVelocity, 100): base twist and joint rates clipped after the unconstrained update and after the solve
   int32_t max_contacts, max_self;   // deepest-K per leg (LLM_MAX_CONTACTS_PER_LEG), self-collision rows per robot (LLM_MAX_SELF)
@@ -134,7 +136,16 @@ struct StepParams {
   double* prob;             // [n_clips] p ~ (1 - avg_reward_sum)^factor, normalised (PLE:239-240)
   double* avg_reward;       // [n_clips] _avg_reward_sum (PLE:235-238)
   double* avg_len;          // [n_clips] avg_episode_len
-  unsigned int* block_ticket;   // workgroups of the running step kernel that have finished; the last one folds the table
+  unsigned int* block_ticket;   // [LL_MAX_STEPS_PER_LAUNCH] per control step of the launch: workgroups that have finished it; the last one folds that step's
+                                // finished episodes into the table (PLE:235-240), so a launch of k steps leaves behind -- and re-seeds from -- the tables k launches would
+  // ---- the sampling table INSIDE a multi-step launch (ll_step_random_n): one version per control step, so that an episode that re-seeds at step s of a launch
+  // samples from the table as the steps before s left it -- what k single launches do
+  double* cdf_ver;              // [LL_MAX_STEPS_PER_LAUNCH][n_clips]: slot s (1 <= s < n_steps) = the CDF after step s - 1 of this launch; the launch's last step writes `cdf` itself
+  unsigned int* ver_ready;      // [LL_MAX_STEPS_PER_LAUNCH]: slot s holds launch_serial once step s of this launch has been folded (device-scope release by the folding wave)
+  unsigned int* resident;       // waves of the running launch that have started: a re-seeding wave only WAITS for a version when all of them have (then every wave is running
+                                // or done, so the wait ends); otherwise it takes the newest version there is and counts the episode in counters[3]
+  uint32_t launch_serial;       // distinguishes this launch's ver_ready marks from older ones (never 0)
+  int32_t table_versions;       // 1: re-seeds inside a multi-step launch read the per-step versions (set by the engine when the grid is co-resident and n_steps > 1)
   float* actions_out;       // where a step that draws its own actions (action_sigma > 0) records them, [n_envs][12]
   float action_sigma;
   int32_t n_steps;           // control steps per launch (ll_step_random_n); 1 everywhere else
@@ -145,9 +156,9 @@ struct StepParams {
   int32_t* ob_id;           // [n_envs] current obstacle of the episode (PLE:179,:264-265)
   float ob_half_height, ob_pad;
   int32_t set_obstacle, debug_flags;   // debug_flags: read only by builds with -DPMC_ABLATION (tools/ablate.sh), 0 otherwise
-  unsigned long long* pending_reward;  // [n_clips] packed (env+1)<<32 | float bits of reward_sum/max_steps
-  unsigned long long* pending_len;     // [n_clips] packed (env+1)<<32 | float bits of avg_episode_len
-  unsigned long long* counters;        // [4] env-steps, episodes, non-finite resets, -
+  unsigned long long* pending_reward;  // [LL_MAX_STEPS_PER_LAUNCH][n_clips] per control step of the launch: packed (env+1)<<32 | float bits of reward_sum/max_steps
+  unsigned long long* pending_len;     // [LL_MAX_STEPS_PER_LAUNCH][n_clips] packed (env+1)<<32 | float bits of avg_episode_len
+  unsigned long long* counters;        // [4] env-steps, episodes, non-finite resets, episodes re-seeded from a table version older than the exact one (see `resident`)
   unsigned long long* ep_hist;         // [16] finished episodes by length: bucket b counts lengths in [2^b, 2^(b+1)) control steps (the last: and longer)
   // constants
   const float* legc;        // [LC_COUNT][4]

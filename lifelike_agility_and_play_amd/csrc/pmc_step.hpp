@@ -28,36 +28,45 @@
 #define LLS_DONE_COLLISION 8
 #define LLS_DONE_NONFINITE 16
 
-// PLE:235-240 for the batch: fold the statistics published by finished episodes into the per-clip table and rebuild
-// the sampling distribution  p ~ (1 - avg_reward_sum)^factor  (stored as an inclusive CDF).  Run by ONE thread
-// between control steps (pre-step kernel), so every env of a step samples from the same table.
-LL_HD void pmc_finalize_table(const StepParams& P, double* avg_reward_sum, double* avg_episode_len, double* prob, double* cdf) {
+// PLE:235-240 for the batch, host statement (the CPU build of this source; the GPU folds with one wavefront, llenv.hip table_fold_wave): fold the
+// statistics published by the episodes that finished in control step `sl` of a launch into the per-clip table and rebuild the sampling
+// distribution  p ~ (1 - avg_reward_sum)^factor  as an inclusive CDF -- into `cdf` itself after the launch's last step, into version slot sl + 1
+// otherwise (StepParams::cdf_ver: what a re-seed at step sl + 1 of the same launch samples from).
+LL_HD void pmc_finalize_table(const StepParams& P, int sl, bool last_step) {
+  const int n = P.n_clips;
+  unsigned long long* pend_r = P.pending_reward + (long)sl * n;
+  unsigned long long* pend_l = P.pending_len + (long)sl * n;
+  const double* prev = sl == 0 ? P.cdf : P.cdf_ver + (long)sl * n;
+  double* dst = last_step ? P.cdf : P.cdf_ver + (long)(sl + 1) * n;
   bool any = false;
-  for (int c = 0; c < P.n_clips; c++) {
-    unsigned long long pr = P.pending_reward[c], pl = P.pending_len[c];
+  for (int c = 0; c < n; c++) {
+    unsigned long long pr = pend_r[c], pl = pend_l[c];
     if (pr) {
       union { float f; uint32_t u; } a, b;
       a.u = (uint32_t)pr; b.u = (uint32_t)pl;
-      avg_reward_sum[c] = (double)a.f;
-      avg_episode_len[c] = (double)b.f;
-      P.pending_reward[c] = 0ull;
-      P.pending_len[c] = 0ull;
+      P.avg_reward[c] = (double)a.f;
+      P.avg_len[c] = (double)b.f;
+      pend_r[c] = 0ull;
+      pend_l[c] = 0ull;
       any = true;
     }
   }
-  if (!any) return;
+  if (!any) {
+    if (dst != prev) for (int c = 0; c < n; c++) dst[c] = prev[c];
+    return;
+  }
   double sum = 0.0;
-  for (int c = 0; c < P.n_clips; c++) {
-    prob[c] = pow(1.0 - avg_reward_sum[c], P.sample_factor);
-    sum += prob[c];
+  for (int c = 0; c < n; c++) {
+    P.prob[c] = pow(1.0 - P.avg_reward[c], P.sample_factor);
+    sum += P.prob[c];
   }
   double acc = 0.0;
-  for (int c = 0; c < P.n_clips; c++) {
-    prob[c] /= sum;
-    acc += prob[c];
-    cdf[c] = acc;
+  for (int c = 0; c < n; c++) {
+    P.prob[c] /= sum;
+    acc += P.prob[c];
+    dst[c] = acc;
   }
-  cdf[P.n_clips - 1] = 1.0;
+  dst[n - 1] = 1.0;
 }
 
 template <class L>
@@ -1813,12 +1822,13 @@ struct Pmc {
   }
 
   // sample (clip, t0) for a new episode: ML:59-63 + ML:50-51, Philox stream keyed on (seed; env, episode)
-  static LL_HD void sample_start(const L& ln, const StepParams& P, int env, uint32_t episode, int* clip, double* t0) {
+  static LL_HD void sample_start(const L& ln, const StepParams& P, int env, uint32_t episode, int* clip, double* t0, const double* cdf = nullptr) {
+    if (!cdf) cdf = P.cdf;
     uint32_t r[4];
     philox4x32((uint32_t)env, episode, 0x5eedu, 0u, (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r);
     double u1 = u01_from(r[0], r[1]), u2 = u01_from(r[2], r[3]);
     // first i with u1 < cdf[i] (np.random.choice's inverse-cdf search) == the number of entries <= u1, cdf being non-decreasing
-    int c = ln.count_le16(P.cdf, P.n_clips, u1);
+    int c = ln.count_le16(cdf, P.n_clips, u1);
     if (c > P.n_clips - 1) c = P.n_clips - 1;
     *clip = c;
     *t0 = u2 * (P.frame_step * (double)(P.clip_len[c] - P.margin - 1));
@@ -1998,10 +2008,11 @@ struct Pmc {
     if (reason) {
       float avg_r = (float)((double)rsum / max_steps), avg_l = (float)((double)steps / (max_steps + 1.0));
       if (bad) avg_r = 0.0f;
-      // (inside a multi-step launch the later step wins, then the higher env: the order in which one actor would have seen them)
-      unsigned long long tag = ((unsigned long long)((unsigned)sl * (unsigned)(N + 1) + (unsigned)(env + 1))) << 32;
-      publish_max(ln, P.pending_reward + clip, tag | (unsigned long long)f2u(avg_r));
-      publish_max(ln, P.pending_len + clip, tag | (unsigned long long)f2u(avg_l));
+      // (every control step of a launch has its own slots -- folded by the last wave to finish that step, in step order: the later step wins, then
+      // the higher env, the order in which one actor would have seen the episodes end)
+      unsigned long long tag = ((unsigned long long)(unsigned)(env + 1)) << 32;
+      publish_max(ln, P.pending_reward + (long)sl * P.n_clips + clip, tag | (unsigned long long)f2u(avg_r));
+      publish_max(ln, P.pending_len + (long)sl * P.n_clips + clip, tag | (unsigned long long)f2u(avg_l));
       count_add(ln, P.counters + 1);
       if (bad) count_add(ln, P.counters + 2);
       {
@@ -2016,7 +2027,7 @@ struct Pmc {
         if (P.keep_term_obs) obs_emit(ln, P, P.term_obs + (long)env * P.obs_dim, false, oin, bs, R, q, qd, act);   // PLE:227
         int nclip;
         double nt0;
-        sample_start(ln, P, env, ep0 + 1, &nclip, &nt0);
+        sample_start(ln, P, env, ep0 + 1, &nclip, &nt0, table_for_reseed(ln, P, sl));
         const int fid2 = (int)floor(nt0 / P.frame_step);                      // ML:52
         const double frac2 = (nt0 - fid2 * P.frame_step) / P.frame_step;      // ML:53
         const double* rows2 = P.frames + (long)P.clip_off[nclip] * 19;
@@ -2057,6 +2068,31 @@ struct Pmc {
     P.done[env] = reason ? 1 : 0;
     P.done_reason[env] = (uint8_t)reason;
     PMC_TS(7);
+  }
+
+  // The sampling table an episode that re-seeds in control step `sl` of the running launch draws from: the table as steps 0 .. sl - 1 of the launch
+  // left it (PLE:235-240; what k single launches give).  Step 0 reads `cdf` (the previous launch's last fold); later steps read the version the
+  // last wave to finish step sl - 1 has written (llenv.hip), WAITING for it if it is not there yet -- which takes a wave that has run a whole
+  // control step ahead of the slowest one.  Waiting is safe exactly when every wave of the launch has started (then each is running or done and the
+  // chain of folds ends); while some have not -- another kernel holds their SIMDs -- the episode takes the newest version there is and is
+  // counted in counters[3] (ll_get_table_sync: zero in every run that has the chip to itself).
+  static LL_HD const double* table_for_reseed(const L& ln, const StepParams& P, int sl) {
+    if (sl == 0 || !P.table_versions) return P.cdf;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned int serial = P.launch_serial;
+    int j = sl - 1;
+    if (__hip_atomic_load(P.resident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) {
+      while (__hip_atomic_load(P.ver_ready + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != serial) __builtin_amdgcn_s_sleep(4);
+    } else {
+      while (j >= 0 && __hip_atomic_load(P.ver_ready + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != serial) j--;
+      if (j != sl - 1) count_add(ln, P.counters + 3);
+    }
+    asm volatile("" ::: "memory");                 // the version is read after its mark (device-scope loads, issued in order)
+    return j < 0 ? P.cdf : P.cdf_ver + (long)(j + 1) * P.n_clips;
+#else
+    (void)ln;
+    return P.cdf_ver + (long)sl * P.n_clips;       // (the CPU build runs a launch step-major and folds after every step: emul.cpp)
+#endif
   }
 
   static LL_HD uint32_t f2u(float x) {

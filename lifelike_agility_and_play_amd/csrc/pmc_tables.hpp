@@ -227,7 +227,7 @@ static inline std::string pmc_build_cand_table(const double* blob, std::vector<f
 static inline void pmc_resolve_erps(StepParams& P) {
   P.limit_erp = P.spec_limit_erp >= 0.0f ? P.spec_limit_erp : P.erp;
   P.erp_deep = P.spec_erp_deep >= 0.0f ? P.spec_erp_deep : P.erp;
-  P.limit_erp_deep = P.spec_erp_deep >= 0.0f ? P.spec_erp_deep : P.limit_erp;
+  P.limit_erp_deep = P.spec_limit_erp_deep >= 0.0f ? P.spec_limit_erp_deep : (P.spec_erp_deep >= 0.0f ? P.spec_erp_deep : P.limit_erp);
 }
 
 // scalar part of StepParams from the reference-style config; returns "" or an error
@@ -260,7 +260,7 @@ static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
   P.friction_mode = LLM_FRICTION_MODE;
   P.max_coord_vel = (float)LLM_MAX_COORD_VEL;
   P.limit_speculative = LLM_LIMIT_SPECULATIVE;
-  P.spec_limit_erp = (float)LLM_LIMIT_ERP; P.spec_erp_deep = (float)LLM_ERP_DEEP; P.erp_deep_below = (float)LLM_ERP_DEEP_BELOW;
+  P.spec_limit_erp = (float)LLM_LIMIT_ERP; P.spec_erp_deep = (float)LLM_ERP_DEEP; P.spec_limit_erp_deep = (float)LLM_LIMIT_ERP_DEEP; P.erp_deep_below = (float)LLM_ERP_DEEP_BELOW;
   pmc_resolve_erps(P);
   double sw = 0;
   for (int i = 0; i < 5; i++) sw += cfg.reward_weights[i];               // PLE:365
@@ -314,6 +314,7 @@ inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
     case LLM_SPEC_LIMIT_ERP: P.spec_limit_erp = (float)v; pmc_resolve_erps(P); break;
     case LLM_SPEC_ERP_DEEP: P.spec_erp_deep = (float)v; pmc_resolve_erps(P); break;
     case LLM_SPEC_ERP_DEEP_BELOW: P.erp_deep_below = (float)v; break;
+    case LLM_SPEC_LIMIT_ERP_DEEP: P.spec_limit_erp_deep = (float)v; pmc_resolve_erps(P); break;
     case LLM_SPEC_LIMIT_SPECULATIVE:
       if (!(v == 0.0 || v == 1.0)) return "limit_speculative must be 0 or 1";
       P.limit_speculative = (int)v; break;
@@ -365,6 +366,7 @@ inline double pmc_get_spec_param(const StepParams& P, int id) {
     case LLM_SPEC_LIMIT_ERP: return P.spec_limit_erp;
     case LLM_SPEC_ERP_DEEP: return P.spec_erp_deep;
     case LLM_SPEC_ERP_DEEP_BELOW: return P.erp_deep_below;
+    case LLM_SPEC_LIMIT_ERP_DEEP: return P.spec_limit_erp_deep;
     case LLM_SPEC_MAX_PAIR: return 2.0;
     case LLM_SPEC_LIMIT_SPECULATIVE: return P.limit_speculative;
     case LLM_SPEC_GYRO: return 1.0;

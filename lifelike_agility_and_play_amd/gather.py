@@ -149,6 +149,8 @@ class TrajectoryBuffer(object):
         self.p2p_no_cu = True             # mode 'p2p': SDMA pulls (False: the runtime's default device-to-device path, the A/B leg)
         self._stage = None                # gloo test path: pinned staging buffers, side stream, worker thread
         self._thread = None
+        self._thread_error = None         # an exception raised inside a helper thread: re-raised on the launching thread at the next join
+        self._watcher = None              # mode 'p2p': the thread that turns "the learner has copied block k" (an interprocess event) into the signal word
 
     def half(self, k):
         return self.buf[k % 2]
@@ -185,7 +187,11 @@ class TrajectoryBuffer(object):
         mine = dict(mem=mem_h, off=mem_off, ready=[e.handle for e in ready], pid=__import__('os').getpid())
         everyone = [None] * world
         dist.all_gather_object(everyone, mine, group=ctrl)
-        st = dict(ctrl=ctrl, ready=ready, dev=dev, dst=dst, block_bytes=int(self.buf[0].numel() * self.buf.element_size()))
+        st = dict(ctrl=ctrl, ready=ready, dev=dev, dst=dst, block_bytes=int(self.buf[0].numel() * self.buf.element_size()), bases=[])
+        # the producer's side without a host-side wait on the launching thread (include/llenv_xfer.h, round 5): the engine's stream waits ON THE DEVICE
+        # for a word of signal memory; a watcher thread -- the only one that blocks on the learner's interprocess 'copied' event -- raises it
+        st['signal'] = xfer.SignalWord(dev) if (xfer.can_wait_value(dev) and not __import__('os').environ.get('LL_P2P_HOST_WAIT')) else None
+        st['aux'] = xfer.CopyStream(dev) if st['signal'] is not None else None
         copied_handles = None
         if rank == dst:
             # one copy stream and one pair of 'block copied' events PER PRODUCER: the pulls from different ranks arrive over different xGMI
@@ -193,7 +199,7 @@ class TrajectoryBuffer(object):
             st['streams'] = [xfer.CopyStream(dev) for _ in range(world)]
             st['copied_all'] = [[xfer.IpcEvent(dev) for _ in range(2)] for _ in range(world)]
             copied_handles = [[e.handle for e in pair] for pair in st['copied_all']]
-            st['src'], st['src_ready'], st['bases'] = [], [], []
+            st['src'], st['src_ready'] = [], []
             for r, info in enumerate(everyone):
                 if r == rank:
                     st['src'].append(int(self.buf.data_ptr())); st['src_ready'].append(ready); st['bases'].append(None)
@@ -206,21 +212,48 @@ class TrajectoryBuffer(object):
         st['copied'] = st['copied_all'][rank] if rank == dst else [xfer.IpcEvent(dev, h) for h in box[0][rank]]     # this rank's own blocks
         self._p2p = st
 
+    def _join(self, which='_thread'):
+        """join a helper thread and re-raise, on the launching thread, whatever it died of (a dead pull would otherwise leave the learner with a stale
+        block and the producers waiting on an event that is never re-recorded)"""
+        t = getattr(self, which)
+        if t is not None:
+            t.join()
+            setattr(self, which, None)
+        if self._thread_error is not None:
+            e, self._thread_error = self._thread_error, None
+            raise RuntimeError('gather helper thread failed: %r' % (e,)) from e
+
+    def _spawn(self, fn, which='_thread'):
+        import threading
+        from . import xfer
+        dev = self._p2p['dev'] if self._p2p is not None else None
+
+        def run():
+            try:
+                if dev is not None:
+                    xfer.set_device(dev)                     # a new thread starts on device 0
+                fn()
+            except BaseException as e:                      # noqa: BLE001  (kept for the launching thread: _join)
+                self._thread_error = e
+        t = threading.Thread(target=run)
+        setattr(self, which, t)
+        t.start()
+
     def _gather_p2p(self, k, dst, group):
         """Hand-off of unroll k without a collective.  ROCm implements hipStreamWaitEvent on an INTERPROCESS event as a host-side wait (the
-        call returns once the event has completed), so the waits are placed where the host has nothing better to do: the learner's waits
-        for the producers' events run in a helper thread that then queues the pulls, and the engine's wait for 'block copied' comes one
-        unroll after the copy was queued (it has normally finished by then).  The main thread goes straight back to launching steps."""
-        import threading
+        call returns once the event has completed), so no such wait is ever issued from the launching thread: the learner's waits for the
+        producers' events run in a helper thread that then queues the pulls; a producer's wait for 'block copied' is a DEVICE-side wait of its engine's
+        stream on a word of signal memory, which a watcher thread raises once the learner's interprocess event has completed (round 5; before, this
+        was a host-side wait on the launching thread: + 5.8 % wall in profiles/r04_p2p_no_cu.txt).  The launching thread goes straight back to
+        launching steps; per unroll it meets the other ranks once on the host (a gloo barrier: "my event is recorded")."""
         import time
         st = self._p2p
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         es = int(self.engine.device_ptrs().stream or 0)
         st['ready'][k % 2].record(es)                       # behind the kernels that wrote block k (and its TD(lambda) pass)
         t0 = time.perf_counter()
-        if self._thread is not None:                        # learner rank: the pulls of unroll k - 1 are queued, 'copied' is recorded
-            self._thread.join()
-            self._thread = None
+        self._join('_thread')                               # learner rank: the pulls of unroll k - 1 are queued, 'copied' is recorded
+        self._join('_watcher')                              # (the watcher of unroll k - 2: long done)
         dist.barrier(group=st['ctrl'])                      # every rank's event is recorded before anybody is told to wait for it
         if rank == dst:
             outs, half, n_pull = self.outs[k % 2], k % 2, 1 + self.extra_gathers
@@ -232,14 +265,46 @@ class TrajectoryBuffer(object):
                     for _ in range(n_pull):                  # (extra_gathers: measurement hook -- the residency of more, or slower, peers)
                         cs.pull(outs[r].data_ptr(), st['src'][r] + half * st['block_bytes'], st['block_bytes'], no_cu=self.p2p_no_cu)
                     st['copied_all'][r][half].record(cs.handle)
-            self._thread = threading.Thread(target=pull)
-            self._thread.start()
+            self._spawn(pull, '_thread')
             self.last = outs
         if k >= 1:
             # The next unroll (k + 1) overwrites block (k - 1) % 2: not before the learner has copied it.  That copy was queued one unroll ago
             # (its event was recorded before the learner entered this unroll's barrier: the join above).
-            st['copied'][(k - 1) % 2].make_stream_wait(es)
-        self.host_stall_s += time.perf_counter() - t0       # barrier + join + whatever the copy of unroll k - 1 still needed
+            copied = st['copied'][(k - 1) % 2]
+            if st['signal'] is not None:
+                st['signal'].make_stream_wait(es, k)          # device-side: the engine's stream stands still until the word says "unrolls 0 .. k - 1 copied"
+
+                def watch():
+                    copied.synchronize()                     # (host-side, in this thread only)
+                    st['signal'].write(st['aux'].handle, k)
+                self._spawn(watch, '_watcher')
+            else:
+                copied.make_stream_wait(es)                  # (no hipStreamWaitValue32 on this device: the host-side wait of round 4)
+        self.host_stall_s += time.perf_counter() - t0       # barrier + joins (+ the host-side wait of the fallback path)
+
+    def close(self):
+        """Join the helper threads, drain the copy streams and give back what prepare() took: IPC mappings, events, streams, the signal word."""
+        from . import xfer
+        try:
+            self._join('_thread'); self._join('_watcher')
+        finally:
+            st, self._p2p = self._p2p, None
+            if st is not None:
+                for cs in st.get('streams', []) + ([st['aux']] if st.get('aux') else []):
+                    cs.synchronize()
+                for base in st.get('bases', []):
+                    if base is not None:
+                        xfer.close_mem(st['dev'], base)
+                evs = {}
+                for group_ in [st['ready'], st['copied']] + list(st.get('copied_all', [])) + list(st.get('src_ready', [])):
+                    for e in group_:
+                        evs[id(e)] = e
+                for e in evs.values():
+                    e.close()
+                for cs in st.get('streams', []) + ([st['aux']] if st.get('aux') else []):
+                    cs.close()
+                if st.get('signal') is not None:
+                    st['signal'].close()
 
     def received(self, k):
         """Learner rank: the list (one tensor per rank) unroll k was received into; valid until unroll k + 2 is gathered."""
@@ -252,11 +317,10 @@ class TrajectoryBuffer(object):
 
     def wait(self):
         import time
-        if self._thread is not None:                        # gloo test path: the staged gather runs in a helper thread
+        if self._thread is not None or self._watcher is not None or self._thread_error is not None:      # helper threads (gloo-staged gather; p2p pulls / watcher)
             t0 = time.perf_counter()
-            self._thread.join()
+            self._join('_thread'); self._join('_watcher')
             self.host_stall_s += time.perf_counter() - t0
-            self._thread = None
         if self._p2p is not None and 'streams' in self._p2p:
             t0 = time.perf_counter()
             for cs in self._p2p['streams']:
@@ -316,8 +380,11 @@ class TrajectoryBuffer(object):
             outs = self.outs[k % 2] if rank == dst else None
 
             def run():
-                ev.synchronize()
-                dist.gather(host, gather_list=outs, dst=dst, group=group)
+                try:
+                    ev.synchronize()
+                    dist.gather(host, gather_list=outs, dst=dst, group=group)
+                except BaseException as e:                  # noqa: BLE001  (re-raised on the launching thread: _join)
+                    self._thread_error = e
             self._thread = threading.Thread(target=run)
             self._thread.start()
             if rank == dst:

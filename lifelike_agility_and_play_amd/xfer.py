@@ -26,6 +26,12 @@ _SIGS = {
     'll_xfer_stream_destroy': (C.c_int, [C.c_void_p]),
     'll_xfer_stream_synchronize': (C.c_int, [C.c_void_p]),
     'll_xfer_pull': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    'll_xfer_can_wait_value': (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    'll_xfer_signal_create': (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    'll_xfer_signal_destroy': (C.c_int, [C.c_int, C.c_void_p]),
+    'll_xfer_stream_wait_value': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    'll_xfer_stream_write_value': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    'll_xfer_set_device': (C.c_int, [C.c_int]),
 }
 EXPORTED_SYMBOLS = sorted(_SIGS)
 _bound = {}
@@ -116,3 +122,39 @@ class CopyStream(object):
         if self.handle:
             self.lib.ll_xfer_stream_destroy(C.c_void_p(self.handle))
             self.handle = 0
+
+
+def set_device(device, lib=None):
+    """hipSetDevice for the calling THREAD (a new thread starts on device 0)"""
+    lib = lib or load_library()
+    _chk(lib, lib.ll_xfer_set_device(int(device)))
+
+
+def can_wait_value(device, lib=None):
+    lib = lib or load_library()
+    v = C.c_int()
+    _chk(lib, lib.ll_xfer_can_wait_value(int(device), C.byref(v)))
+    return bool(v.value)
+
+
+class SignalWord(object):
+    """One word of signal memory: a stream can be made to wait ON THE DEVICE until it has reached a value (hipStreamWaitValue32) and another stream
+    raises it in stream order (hipStreamWriteValue32) -- the launching thread blocks on neither."""
+
+    def __init__(self, device, lib=None):
+        self.lib = lib or load_library()
+        self.device = int(device)
+        p = C.c_void_p()
+        _chk(self.lib, self.lib.ll_xfer_signal_create(self.device, C.byref(p)))
+        self.ptr = int(p.value)
+
+    def make_stream_wait(self, stream_handle, value):
+        _chk(self.lib, self.lib.ll_xfer_stream_wait_value(C.c_void_p(int(stream_handle or 0)), C.c_void_p(self.ptr), C.c_uint32(int(value))))
+
+    def write(self, stream_handle, value):
+        _chk(self.lib, self.lib.ll_xfer_stream_write_value(C.c_void_p(int(stream_handle or 0)), C.c_void_p(self.ptr), C.c_uint32(int(value))))
+
+    def close(self):
+        if self.ptr:
+            self.lib.ll_xfer_signal_destroy(self.device, C.c_void_p(self.ptr))
+            self.ptr = 0

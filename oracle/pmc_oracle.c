@@ -556,7 +556,7 @@ static int aba(const OModel* M, const OKin* K, const double* qd, const double* t
 /* Spec overrides (include/llenv_model.h LLM_SPEC_*): process-wide, defaults = the constants of that header.  The engine has the same
  * switches (ll_set_spec_param); tools/deviation_table.py moves them in both to measure what each of this build's own choices is worth. */
 static double g_spec[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, LLM_MAX_COORD_VEL, LLM_LIMIT_ERP, 0.0, 2.0, 0.0, LLM_LIMIT_SPECULATIVE, 1.0, 0.0, LLM_ERP_DEEP, LLM_ERP_DEEP_BELOW};
+                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, LLM_MAX_COORD_VEL, LLM_LIMIT_ERP, 0.0, 2.0, 0.0, LLM_LIMIT_SPECULATIVE, 1.0, 0.0, LLM_ERP_DEEP, LLM_ERP_DEEP_BELOW, LLM_LIMIT_ERP_DEEP};
 int orc_set_spec_param(int id, double v) {
   if (id < 0 || id >= LLM_SPEC_COUNT) return -1;
   if (id == LLM_SPEC_MAX_CONTACTS_PER_LEG && !(v >= 1 && v <= LLM_MAX_CONTACTS_PER_LEG)) return -1;
@@ -569,14 +569,16 @@ int orc_set_spec_param(int id, double v) {
 double orc_get_spec_param(int id) { return (id >= 0 && id < LLM_SPEC_COUNT) ? g_spec[id] : NAN; }
 void orc_reset_spec(void) {
   const double d[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, LLM_MAX_COORD_VEL, LLM_LIMIT_ERP, 0.0, 2.0, 0.0, LLM_LIMIT_SPECULATIVE, 1.0, 0.0, LLM_ERP_DEEP, LLM_ERP_DEEP_BELOW};
+                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, LLM_MAX_COORD_VEL, LLM_LIMIT_ERP, 0.0, 2.0, 0.0, LLM_LIMIT_SPECULATIVE, 1.0, 0.0, LLM_ERP_DEEP, LLM_ERP_DEEP_BELOW, LLM_LIMIT_ERP_DEEP};
   memcpy(g_spec, d, sizeof d);
 }
 /* bias of a unilateral row from its signed distance: a separated row may close the gap within the substep; a penetrating one is pushed
  * out by ERP per substep -- with a second, deeper ERP when LLM_SPEC_ERP_DEEP is set, and (contact rows only) capped at LLM_SPEC_MAX_DEPEN_SPEED */
 static double row_bias(double depth, double dt, double erp, int capped) {
   if (depth > 0) return depth / dt;
-  const double e = (g_spec[LLM_SPEC_ERP_DEEP] >= 0 && !(depth > g_spec[LLM_SPEC_ERP_DEEP_BELOW])) ? g_spec[LLM_SPEC_ERP_DEEP] : erp;
+  /* (capped = a contact row; the others are joint-limit rows, whose deep ERP may be given separately) */
+  const double deep = (!capped && g_spec[LLM_SPEC_LIMIT_ERP_DEEP] >= 0) ? g_spec[LLM_SPEC_LIMIT_ERP_DEEP] : g_spec[LLM_SPEC_ERP_DEEP];
+  const double e = (deep >= 0 && !(depth > g_spec[LLM_SPEC_ERP_DEEP_BELOW])) ? deep : erp;
   const double b = e * depth / dt;
   return capped ? fmax(b, -g_spec[LLM_SPEC_MAX_DEPEN_SPEED]) : b;
 }

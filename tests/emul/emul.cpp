@@ -27,7 +27,7 @@ struct HostBackend {
   void sync() {}
   void launch_step(const StepParams& P) {
     HostLanes ln(P.candc);
-    for (int sl = 0; sl < P.n_steps; sl++) {               // ll_step_random_n: the table is folded once per launch
+    for (int sl = 0; sl < P.n_steps; sl++) {               // ll_step_random_n: step-major, the table folded after every step into that step's version
       if (P.action_sigma > 0.0f) {
         StepParams Q = P;
         Q.step_count = P.step_count + (uint64_t)sl;
@@ -46,9 +46,10 @@ struct HostBackend {
         else if (P.friction_mode == 2) K::step_env<false, true>(ln, P, env, act, sl);
         else K::step_env<false>(ln, P, env, act, sl);
       }
+      pmc_finalize_table(P, sl, sl == P.n_steps - 1);
     }
-    pmc_finalize_table(P, P.avg_reward, P.avg_len, P.prob, P.cdf);
   }
+  bool co_resident(const StepParams&) const { return true; }
   void launch_reset(const StepParams& P, const int32_t* ids, int n, const int32_t* clip, const double* t0) {
     HostLanes ln(P.candc);
     for (int i = 0; i < n; i++) {

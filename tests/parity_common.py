@@ -467,26 +467,33 @@ def check_trajectory_ring(model_blob, table, lib_path, read_ring, write_dev=None
 
 def check_multi_step_launch(model_blob, table, lib_path, read_ring, sizes=(24,), k=7, n_launches=5, spec=None):
     """ll_step_random_n(sigma, k) == k x ll_step_random(sigma), bit for bit -- state, ghost, observation, reward, done reasons, bookkeeping,
-    counters, episode histogram, the recorded actions and every row of the unroll buffers -- in the two settings in which the one stated
-    difference (the sampling table is folded once per launch) cannot show: uniform sampling with auto-reset (factor 0: the table never
-    changes what is drawn), and prioritized sampling without auto-reset (nobody draws; the table the launch leaves behind must then
-    equal the step-by-step one: later step wins, then the higher env).  With both on, the counters and invariants still hold."""
+    counters, episode histogram, the recorded actions, every row of the unroll buffers and the sampling table -- with uniform sampling and
+    auto-reset, with prioritized sampling without auto-reset, and (round 5) WITH BOTH: the table is folded after every control step of a launch
+    into a version of its own, and an episode that re-seeds at step s draws from the version steps 0 .. s - 1 left (PLE:235-240 as k launches keep
+    it).  The last leg is the one with power: a table that starts at avg_reward 0.9 everywhere, where one finished episode changes what everybody after it draws."""
     unroll = 4
     for n in sizes:
-        for kw in (dict(auto_reset=1, prioritized_sample_factor=0.0), dict(auto_reset=0, prioritized_sample_factor=3.0)):
+        for kw in (dict(auto_reset=1, prioritized_sample_factor=0.0), dict(auto_reset=0, prioritized_sample_factor=3.0),
+                   dict(auto_reset=1, prioritized_sample_factor=3.0), dict(auto_reset=1, prioritized_sample_factor=3.0 + 1e-9)):
             A = make_engine(model_blob, table, n, lib_path, seed=31, **kw)
             B = make_engine(model_blob, table, n, lib_path, seed=31, **kw)
             if spec:                                                 # (a kernel option with its own builds: LLM_SPEC_FRICTION_MODE = 2)
                 A.set_spec(**spec); B.set_spec(**spec)
             A.reset(); B.reset()
+            sig = SIGMA
+            if kw['prioritized_sample_factor'] > 3.0:
+                # the leg with power: every clip starts at avg_reward 0.9 (p ~ 1e-3 each), so the first episode that ends makes ITS clip a thousand
+                # times likelier than the rest -- whoever re-seeds after it, and from which table, shows at once; wild actions end episodes fast
+                A.set_sampling_table(np.full(table.n_clips, 0.9)); B.set_sampling_table(np.full(table.n_clips, 0.9))
+                sig = 0.7
             for _ in range(3):                                       # unrolls start wherever they are enabled (not at step 0)
-                A.step_random(SIGMA); B.step_random(SIGMA)
+                A.step_random(sig); B.step_random(sig)
             pa, w = A.enable_unrolls(unroll, 2); pb, _ = B.enable_unrolls(unroll, 2)
             assert A.unroll_position() == (0, 0)
             for L in range(n_launches):
                 for _ in range(k):
-                    A.step_random(SIGMA)
-                B.step_random_n(SIGMA, k)
+                    A.step_random(sig)
+                B.step_random_n(sig, k)
                 A.sync(); B.sync()
                 assert A.unroll_position() == B.unroll_position() == divmod((L + 1) * k, unroll)
                 for x, y in ((A.state(), B.state()), (A.ref_state(), B.ref_state()), (A.obs(), B.obs()), (A.feet()[0], B.feet()[0])):
@@ -502,8 +509,10 @@ def check_multi_step_launch(model_blob, table, lib_path, read_ring, sizes=(24,),
                 for x, y in zip(A.sampling_table(), B.sampling_table()):
                     np.testing.assert_array_equal(x, y)
             assert A.counters()['episodes'] > 0
+            if hasattr(B, 'table_sync'):
+                assert B.table_sync() == 0                          # no episode re-seeded from an older version than the exact one
             A.close(); B.close()
-        # both on: the launch-granular table.  Same number of env-steps, everything finite, episodes keep ending and re-seeding
+        # longer launches, both on: same number of env-steps, everything finite, episodes keep ending and re-seeding
         C = make_engine(model_blob, table, n, lib_path, seed=32, auto_reset=1, prioritized_sample_factor=3.0)
         if spec:
             C.set_spec(**spec)

@@ -255,6 +255,32 @@ def test_bench_two_ranks_on_one_device(tmp_path):
         f.write(raw + '\n')
 
 
+def test_bench_eight_ranks_on_one_device():
+    """BASELINE config 3's control flow at its real rank count (the driver's 8-GPU run cannot be rehearsed on a 1-GPU box): exactly
+    `python bench.py --gpus 8` -- the command starts its own eight ranks -- all on device 0, 512 envs each (8 x 128 single-wave workgroups: one per
+    SIMD, all resident together), gather staged through gloo.  ONE line from rank 0, eight ranks seen, every rank's gathered block equal to what
+    its engine recorded, the learner's receive side 2 x 8 blocks; then the same hand-off as seven peer-to-peer pulls (--gather-mode p2p)."""
+    import os
+    torch_cuda()
+    steps, warm, n = 256, 128, 512
+    for mode in ('async', 'p2p'):
+        j, raw, root = _run_bench(['--gpus', 8, '--steps', steps, '--warmup', warm, '--envs-per-gpu', n, '--gather-mode', mode], dict(ONE_DEVICE, LL_BENCH_VERIFY='1'), timeout=1500)
+        c = j['config']
+        assert j['n_gpus'] == 8 and j['steps'] == steps and j['scaling'] == 'weak'
+        assert abs(j['value'] - 8 * n * steps / (j['ms_per_step'] * 1e-3 * steps)) < 1e-6 * j['value']           # whole-job aggregate over the eight ranks
+        assert c['gather_check'] == 'ok' and c['unrolls_gathered'] == (steps + warm) // 128, c
+        g = c['gather']
+        assert g['mode'] == mode and g['receive_blocks'] == [2, 8] and g['bytes_per_rank_per_unroll'] == n * 128 * 224 * 4
+        seen = g['ranks_seen']
+        assert [r['rank'] for r in seen] == list(range(8)) and len({r['pid'] for r in seen}) == 8             # eight processes
+        assert all(r['envs'] == n and r['control_steps'] == steps + warm and r['episodes'] > 0 for r in seen), seen
+        print(mode, 'stale re-seeds per rank (ranks sharing ONE device may start a launch while another rank holds some SIMDs):', [r['stale_reseeds'] for r in seen])
+        log_dir = os.path.join(root, 'gpurun_out', 'two_rank')
+        os.makedirs(log_dir, exist_ok=True)
+        with open(os.path.join(log_dir, 'bench_eight_ranks_one_device_%s.json' % mode), 'w') as f:
+            f.write(raw + '\n')
+
+
 def test_gather_overlaps_with_the_next_unroll():
     """An overlap measurement that can fail: the same two-rank run three times -- without the gather (the steps alone), with every gather
     waited for before the next step is launched (--gather-mode blocking), and as shipped (async, double-buffered).  Blocking costs the
