@@ -45,14 +45,17 @@
 #define LLM_PLANE_FRICTION 0.9         /* plane.urdf:5 lateral_friction */
 #define LLM_LINK_FRICTION 0.5          /* Bullet default lateralFriction of every non-foot link */
 #define LLM_CONTACT_MARGIN 0.02        /* Bullet contact breaking threshold */
-#define LLM_ERP 0.2                    /* PyBullet default erp / contactERP */
-#define LLM_LIMIT_ERP (-1.0)            /* ERP of the joint-limit rows; < 0: LLM_ERP */
-#define LLM_LIMIT_SPECULATIVE 1         /* LLM_SPEC_LIMIT_SPECULATIVE below */
+#define LLM_ERP 0.08                   /* ERP of the CONTACT rows: btMultiBodyConstraintSolver::setupMultiBodyContactConstraint takes btContactSolverInfo::m_erp2 ("contactERP"), which
+                                          PyBullet's server sets to 0.08 when it creates the world (as recalled; the reference never calls setPhysicsEngineParameter(contactERP=...):
+                                          tests/golden/pmc_config_golden.npz).  Rounds 1 - 4: 0.2 with a cap on the push-out speed; round 5 priced both on the five trained policies and
+                                          the cap turned out to have been standing in for the softer ERP (profiles/r05_penetration_recovery.md) */
+#define LLM_LIMIT_ERP 0.2               /* ERP of the joint-limit rows: btMultiBodyJointLimitConstraint takes btContactSolverInfo::m_erp ("erp", 0.2) while the joint is less than 0.04 rad past its limit */
+#define LLM_LIMIT_SPECULATIVE 0         /* LLM_SPEC_LIMIT_SPECULATIVE below: since round 5 a joint-limit row exists only once the limit is passed (btMultiBodyJointLimitConstraint) */
 #define LLM_ERP_DEEP (-1.0)             /* LLM_SPEC_ERP_DEEP below; < 0: one ERP at every depth */
-#define LLM_LIMIT_ERP_DEEP (-1.0)       /* LLM_SPEC_LIMIT_ERP_DEEP below */
+#define LLM_LIMIT_ERP_DEEP 0.0          /* LLM_SPEC_LIMIT_ERP_DEEP below: a joint more than 0.04 rad past its limit is stopped, not pushed back (split impulse leaves the positional part unapplied) */
 #define LLM_ERP_DEEP_BELOW (-0.04)      /* btContactSolverInfo::m_splitImpulsePenetrationThreshold (see LLM_SPEC_ERP_DEEP) */
-#define LLM_MAX_DEPEN_SPEED 0.5        /* m/s: cap on the penetration-recovery part of a contact row's bias (a body that starts inside an
-                                          obstacle -- SEPMC spawns at random -- is pushed out gently instead of being shot out) */
+#define LLM_MAX_DEPEN_SPEED 1e30       /* m/s: cap on the penetration-recovery part of a contact row's bias.  Bullet has none, and since round 5 neither has this spec (1e30 = off; rounds
+                                          1 - 4: 0.5 m/s on top of ERP 0.2 -- it made up for an ERP that was too stiff: profiles/r05_penetration_recovery.md).  The switch stays */
 #define LLM_LINK_DAMPING 0.04          /* btMultiBody default linear & angular damping (quirk Q12) */
 #define LLM_MAX_CONTACTS_PER_LEG 4     /* contact slots per leg lane */
 #define LLM_LIMIT_GATE 20.0             /* a joint-limit row enters the solve iff  s*qd* + bias < this [rad/s] */
@@ -72,6 +75,8 @@
                                            parallel segments to the middle of their overlap; sin^2(angle) >> this: Ericson's closest point */
 #define LLM_OBSTACLE_REACH 1.2          /* m: the jump obstacle of PLE:182-193 takes part in the substeps of a control step that starts with the base
                                            within this horizontal distance of the box centre (robot reach 0.45 m + half box length 0.5 m + slack) */
+#define LLM_FLOATING_MIN_Z 0.05          /* m: a terrain box whose bottom is higher than this above the ground FLOATS (the hanging bars of element 2: bullet_static_entities.py:366-412);
+                                           the edges it offers the trunk (reverse candidates) are then its BOTTOM edges -- what the flat of the back meets under a bar -- instead of its top edges */
 #define LLM_SELECT_EPS 1e-5             /* m: candidates (contact points, capsule pairs) whose depth is within this of the deepest count as equally
                                            deep and the lower index wins -- the deepest-K choice must not hang on float rounding */
 

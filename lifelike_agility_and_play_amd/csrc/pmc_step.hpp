@@ -505,7 +505,7 @@ struct Pmc {
   }
   // Reverse candidates (DESIGN.md 8 "edges under the trunk"; the oracle's reverse_edge states the rule): the robot's own candidates are
   // vertices and spheres, blind to a step edge that crosses the flat of the body box between its corners.  Leg l tests top edge l of every
-  // terrain box (0: x = x0, 1: x = x1, 2: y = y0, 3: y = y1, at z = z1) against the body box in the box's frame: the edge is cut to the box
+  // terrain box (0: x = x0, 1: x = x1, 2: y = y0, 3: y = y1, at z = z1 -- at z = z0 for a box that floats) against the body box in the box's frame: the edge is cut to the box
   // grown by the margin; the middle of what is left names the face it runs along; the edge cut to the exact extents of the other two
   // axes has two ends -- end `endf` (0 / 1) is this lane's candidate: depth = signed distance to the face's plane, point = the point of
   // the terrain edge (returned in F0), normal = the face's inward normal (returned in world coordinates).  Deepest over the boxes.
@@ -535,11 +535,12 @@ struct Pmc {
       //  is within `reach` of its centre)
       float lx = cwx, ly = cwy;
       if (ex->yawed) { const float dx = cwx - ex->ycx, dy = cwy - ex->ycy; lx = dx * ex->ycs + dy * ex->ysn; ly = dy * ex->ycs - dx * ex->ysn; }
-      const bool near = lx > rec.a.x - reach && lx < rec.a.y + reach && ly > rec.a.z - reach && ly < rec.a.w + reach && fabsf(cwz - rec.c.y) < reach;
+      const float ze = rec.c.x > (float)LLM_FLOATING_MIN_Z ? rec.c.x : rec.c.y;      // a floating box (a hanging bar, BSE:366-412) offers its BOTTOM edges (round 5)
+      const bool near = lx > rec.a.x - reach && lx < rec.a.y + reach && ly > rec.a.z - reach && ly < rec.a.w + reach && fabsf(cwz - ze) < reach;
       if (!L::any(ln.lane_f(near ? 1.0f : 0.0f) > 0.5f)) continue;
       F ax_ = lm::sel(l1, ln.lane_f(rec.a.y), ln.lane_f(rec.a.x)), ay_ = lm::sel(l3, ln.lane_f(rec.a.w), ln.lane_f(rec.a.z));
       F bx_ = lm::sel(l0, ln.lane_f(rec.a.x), ln.lane_f(rec.a.y)), by_ = lm::sel(l2, ln.lane_f(rec.a.z), ln.lane_f(rec.a.w));
-      V3l aw = mk3<F>(ax_, ay_, ln.lane_f(rec.c.y)), bw = mk3<F>(bx_, by_, ln.lane_f(rec.c.y));
+      V3l aw = mk3<F>(ax_, ay_, ln.lane_f(ze)), bw = mk3<F>(bx_, by_, ln.lane_f(ze));
       if (ex->yawed) {
         aw = mk3<F>(ln.lane_f(ex->ycx) + ax_ * ex->ycs - ay_ * ex->ysn, ln.lane_f(ex->ycy) + ax_ * ex->ysn + ay_ * ex->ycs, aw.z);
         bw = mk3<F>(ln.lane_f(ex->ycx) + bx_ * ex->ycs - by_ * ex->ysn, ln.lane_f(ex->ycy) + bx_ * ex->ysn + by_ * ex->ycs, bw.z);

@@ -272,7 +272,11 @@ class TrajectoryBuffer(object):
             # (its event was recorded before the learner entered this unroll's barrier: the join above).
             copied = st['copied'][(k - 1) % 2]
             if st['signal'] is not None:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()                                   # (torch's current stream IS the engine's: gather_async checks it)
                 st['signal'].make_stream_wait(es, k)          # device-side: the engine's stream stands still until the word says "unrolls 0 .. k - 1 copied"
+                b.record()
+                self._stall_events.append((a, b))            # how long it actually stood still: stall_ms()
 
                 def watch():
                     copied.synchronize()                     # (host-side, in this thread only)

@@ -746,7 +746,8 @@ static void enum_cands(const OModel* M, const OKin* K, int l, double mu_foot, do
 }
 /* Reverse candidates ("edges under the trunk"): the robot's own candidate points are vertices and spheres, which cannot see
  * a step edge that crosses the flat of the body box between its corners.  So leg l also tests top edge l of every terrain box
- *   l = 0: x = x0,  1: x = x1 (both along y),  2: y = y0,  3: y = y1 (both along x),  all at z = z1
+ *   l = 0: x = x0,  1: x = x1 (both along y),  2: y = y0,  3: y = y1 (both along x),  all at z = z1 -- or, for a box that floats (its bottom z0 above
+ *   LLM_FLOATING_MIN_Z: the hanging bars of bullet_static_entities.py:366-412), at z = z0: the edges the flat of the back meets from below (round 5)
  * against the body box, in the box's own frame (half extents h):
  *   1. the edge is cut to the box grown by the contact margin (nothing left: no candidate);
  *   2. the middle of what is left names the face of the body box the edge runs along: the axis of largest |p_i| - h_i;
@@ -764,7 +765,8 @@ static int reverse_edge(const OModel* M, const OKin* K, const OTerrain* T, int l
   int found = 0;
   for (int si = 0; si < T->n; si++) {
     const double* r = T->rec + 8 * si;
-    double al[3] = {l == 1 ? r[1] : r[0], l == 3 ? r[3] : r[2], r[5]}, bl[3] = {l == 0 ? r[0] : r[1], l == 2 ? r[2] : r[3], r[5]};
+    const double ze = r[4] > LLM_FLOATING_MIN_Z ? r[4] : r[5];                      /* a floating box (a hanging bar) offers its bottom edges */
+    double al[3] = {l == 1 ? r[1] : r[0], l == 3 ? r[3] : r[2], ze}, bl[3] = {l == 0 ? r[0] : r[1], l == 2 ? r[2] : r[3], ze};
     double aw[3], bw[3], pa[3], d[3];
     if (T->yawed) {
       aw[0] = T->cx + al[0] * T->cs - al[1] * T->sn; aw[1] = T->cy + al[0] * T->sn + al[1] * T->cs; aw[2] = al[2];

@@ -364,6 +364,7 @@ def score_case(out, B, orc, es_i, s0, act, push_trace, mu, near):
     s, sel = oracle_control_step(B, orc, s0, act, push_trace, mu, near)
     c, v = errs(es_i, s)
     on_tie = sel < TIE_ZONE
+    c_nominal, v_nominal = c, v
     if on_tie:
         # Some candidate's depth came within float32 resolution of (deepest + LLM_SELECT_EPS), where the deepest-K pick changes hands: float32
         # and float64 may legitimately keep different points.  The engine must then agree with the oracle for SOME tie tolerance within
@@ -379,6 +380,9 @@ def score_case(out, B, orc, es_i, s0, act, push_trace, mu, near):
     out['config'].append(c); out['vel'].append(v)
     out.setdefault('cond_config', []).append(cc); out.setdefault('cond_vel', []).append(cv)
     out.setdefault('on_tie', []).append(on_tie)
+    # ... and whether the allowance was NEEDED: the nominal comparison outside the plain bars, a shifted tolerance inside them (round 5: this is what the cap counts;
+    # that some depth of ten substeps came within 4 um of the rule's boundary happens to a few per cent of all cases and decides nothing in most of them)
+    out.setdefault('tie_used', []).append(bool(on_tie and (c_nominal >= 1e-4 or v_nominal >= 1e-3) and (c < c_nominal)))
     return s
 
 
@@ -392,14 +396,15 @@ def assert_within_bars(out, cfg_bar=1e-4, vel_bar=1e-3, factor=4.0, max_ill=0.03
     cc, cv = np.array(out['cond_config']), np.array(out['cond_vel'])
     bar_c, bar_v = np.maximum(cfg_bar, factor * cc), np.maximum(vel_bar, factor * cv)
     ill = (bar_c > cfg_bar) | (bar_v > vel_bar)
-    out['n_ill_conditioned'], out['n_on_selection_tie'] = int(ill.sum()), int(np.sum(out['on_tie']))
+    out['n_ill_conditioned'], out['n_on_selection_tie'] = int(ill.sum()), int(np.sum(out.get('tie_used', out['on_tie'])))
+    out['n_near_selection_boundary'] = int(np.sum(out['on_tie']))
     # the two allowances are counted, printed and capped, so that they cannot quietly absorb a regression: ill-conditioned cases at most
     # max_ill of the cases (observed: 1 of 32 standing / 2 of 32 dropped), cases on the deepest-K rule's discontinuity at most max_tie (observed: 0 / 3 of 32)
     # caps: what the case set was observed to need + 1 where the caller knows it (the GPU-sized sets, round 4), a fraction of the cases otherwise
     cap_ill = cap_ill if cap_ill is not None else max(2, int(max_ill * len(ill)))
     cap_tie = cap_tie if cap_tie is not None else max(2, int(max_tie * len(ill)))
-    print('assert_within_bars: %d cases, %d ill-conditioned in the oracle itself (cap %d), %d on a selection tie (cap %d); worst config %.2e, velocity %.2e'
-          % (len(ill), ill.sum(), cap_ill, out['n_on_selection_tie'], cap_tie, c.max(), v.max()))
+    print('assert_within_bars: %d cases, %d ill-conditioned in the oracle itself (cap %d), %d decided by a selection tie (cap %d; %d came within 4 um of the rule\'s boundary); worst config %.2e, velocity %.2e'
+          % (len(ill), ill.sum(), cap_ill, out['n_on_selection_tie'], cap_tie, out['n_near_selection_boundary'], c.max(), v.max()))
     assert out['n_on_selection_tie'] <= cap_tie, out['n_on_selection_tie']
     assert ill.sum() <= cap_ill, (ill.sum(), len(ill))
     assert (c < bar_c).all(), (np.sort(c)[-5:], cc[np.argsort(c)[-5:]])
@@ -415,6 +420,9 @@ def check_terrain_physics_against_oracle(lib_path, n_envs=16, seed=11, total_env
     from conftest import make_oracle_batch
     from oracle import oracle as orc
     from lifelike_agility_and_play_amd import mocap
+    from scipy.spatial.transform import Rotation as Rot
+    blob_ = urdf_model.default_model_blob()
+    qlo, qhi = blob_[241:253], blob_[253:265]                              # LLM_OFF_Q_LO / _HI
     out = dict(config=[], vel=[], n_terrain=0)
     N = total_envs or n_envs
     third = n_envs // 3
@@ -435,6 +443,11 @@ def check_terrain_physics_against_oracle(lib_path, n_envs=16, seed=11, total_env
             st[i, 2] = b[5] + rng.uniform(0.22, 0.33) if b[4] < 0.01 else rng.uniform(0.2, b[4] + 0.05)   # above a step / bar, or under a hanging bar
             st[i, 7:13] = rng.normal(size=6) * 0.3
             st[i, 25:37] = rng.normal(size=12)
+            # (round 5) not the reset pose itself: a level trunk on four identically bent legs puts the left and right vertices of every link box -- and
+            # all four feet -- at the same depth up to rounding, and the deepest-4 rule of a leg was decided by the last bit in 6 - 9 % of such cases
+            # (the rounds' tie counts were a property of this case set, not of the rule).  A few degrees of roll / pitch / yaw and of every joint:
+            st[i, 3:7] = (Rot.from_euler('xyz', [rng.normal() * 0.06, rng.normal() * 0.06, rng.normal() * 0.3]) * Rot.from_quat(st[i, 3:7])).as_quat()
+            st[i, 13:25] = np.clip(st[i, 13:25] + rng.normal(size=12) * 0.1, qlo + 0.02, qhi - 0.02)
         E.set_state(st)
         st32 = E.state().astype(np.float64)
         act = (rng.normal(size=(N, 12)) * 0.135).astype(np.float32)
@@ -473,7 +486,7 @@ def check_trunk_on_edges_against_oracle(lib_path, n_envs=16, seed=5, cap_ill=Non
     blob = urdf_model.default_model_blob()
     box = blob[urdf_model.OFF_BASE_PRIMS:urdf_model.OFF_BASE_PRIMS + urdf_model.PRIM_STRIDE]
     hz, cz = box[3], box[6]
-    for element in (3, 1):
+    for element in (3, 1, 2):
         cfg = env_config(element)
         E = make_engine(cfg, n_envs, lib_path, seed=seed)
         E.reset()
@@ -481,15 +494,24 @@ def check_trunk_on_edges_against_oracle(lib_path, n_envs=16, seed=5, cap_ill=Non
         rng = np.random.default_rng(seed)
         st = E.state().astype(np.float64)
         recs_all = [statics_to_records(rows[i, :cnt[i]].astype(np.float64)) for i in range(n_envs)]
+        felt0 = out['n_edge_felt']
         for i in range(n_envs):
             rec = recs_all[i]
-            cand = [b for b in rec[2:10] if b[4] < 0.01 and b[5] > 0.05]              # boxes standing on the ground
-            b = cand[rng.integers(0, len(cand))]
-            edge = b[0] if rng.uniform() < 0.5 else b[1]
-            st[i, 0] = edge + rng.uniform(-0.1, 0.1); st[i, 1] = rng.uniform(-0.1, 0.1)
-            st[i, 2] = b[5] + hz - cz + rng.uniform(-0.015, 0.012)                     # the belly within the margin of, or a little into, the top
+            if element == 2:
+                # (round 5) under a HANGING bar (BSE:366-412: 0.1 m long, its underside 0.25 m up): the flat of the back within the margin of, or a little
+                # into, the underside, the robot on its way up -- the bar's bottom edges against the body box (LLM_FLOATING_MIN_Z)
+                cand = [b for b in rec[2:12] if b[4] > 0.05]
+                b = cand[rng.integers(0, len(cand))]
+                st[i, 0] = 0.5 * (b[0] + b[1]) + rng.uniform(-0.12, 0.12); st[i, 1] = rng.uniform(-0.1, 0.1)
+                st[i, 2] = b[4] - hz - cz + rng.uniform(-0.012, 0.015)
+            else:
+                cand = [b for b in rec[2:10] if b[4] < 0.01 and b[5] > 0.05]              # boxes standing on the ground
+                b = cand[rng.integers(0, len(cand))]
+                edge = b[0] if rng.uniform() < 0.5 else b[1]
+                st[i, 0] = edge + rng.uniform(-0.1, 0.1); st[i, 1] = rng.uniform(-0.1, 0.1)
+                st[i, 2] = b[5] + hz - cz + rng.uniform(-0.015, 0.012)                     # the belly within the margin of, or a little into, the top
             st[i, 3:7] = Rot.from_euler('zyx', [rng.uniform(-0.5, 0.5), rng.uniform(-0.15, 0.15), rng.uniform(-0.1, 0.1)]).as_quat()
-            st[i, 7:13] = rng.normal(size=6) * 0.3; st[i, 9] -= 0.5
+            st[i, 7:13] = rng.normal(size=6) * 0.3; st[i, 9] += 0.5 if element == 2 else -0.5
             st[i, 13:25] = np.tile([0.0, 1.4, -2.4], 4) + rng.normal(size=12) * 0.05     # legs folded up and back
             st[i, 25:37] = rng.normal(size=12) * 0.5
         E.set_state(st)
@@ -510,7 +532,8 @@ def check_trunk_on_edges_against_oracle(lib_path, n_envs=16, seed=5, cap_ill=Non
             if np.abs(s - s_off).max() > 1e-3:
                 out['n_edge_felt'] += 1
         E.close()
-    assert out['n_edge_felt'] >= 8, out['n_edge_felt']
+        out.setdefault('felt_by_element', {})[element] = out['n_edge_felt'] - felt0
+    assert out['n_edge_felt'] >= 8 and out['felt_by_element'][2] >= max(2, n_envs // 8), (out['n_edge_felt'], out['felt_by_element'])
     assert_within_bars(out, max_ill=0.07, max_tie=0.12, cap_ill=cap_ill, cap_tie=cap_tie)         # (bodies dropped flat onto edges: more make-and-break steps and more equal depths than among standing robots)
     return out
 

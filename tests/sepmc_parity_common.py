@@ -399,6 +399,52 @@ def check_free_running_big(lib_path, n_arenas, steps):
     return c
 
 
+def check_engine_against_emulation(emul_lib_path, n_arenas=2048, steps=2, seed=5, spec=None, gpu_lib=None):
+    """Every field of every observation the HIP kernels write, at full size, against the HOST build of the very same kernel source (tests/emul), arena by arena --
+    the net under the one-wave-per-SIMD chase-tag kernels, which sit at 256 + 255 registers (round 4: a seven-rays-per-chunk build of them wrote garbage into the
+    flag_info fields of arenas that re-seed -- right state, right episode record, wrong observation; the three-ray build is shipped, and this test is what would
+    catch the same failure in it or in any later build: HISTORY.md).  Same config, seed and actions on both sides; before every step the emulation takes the
+    engine's state, so physics rounding stays one step old; arenas whose done flag / reason / flag holder differ after a step (a contact class on the last
+    bit) are counted, capped at 1 % and left out.  About 4 % of the arenas are caught at spawn and RE-SEED in the very first step: the path that failed."""
+    import epmc_parity_common as ec
+    with ec.spec_variant(**(spec or {})):
+        G = make_engine(env_config(ALL_ELEMENTS), n_arenas, gpu_lib, auto_reset=1, seed=seed)        # (gpu_lib: another build of the HIP library -- tools/diag_sepmc_chunk7.py)
+        H = make_engine(env_config(ALL_ELEMENTS), n_arenas, emul_lib_path, auto_reset=1, seed=seed)
+    G.reset(); H.reset()
+    P3, NR = 135, 778
+    out = dict(reseeded=0, left_out=0, ray_mismatch=0.0, worst_tail=0.0, worst_prop=0.0)
+
+    def compare(label, keep):
+        og, oh = G.obs().astype(np.float64)[keep], H.obs().astype(np.float64)[keep]
+        assert np.isfinite(og).all(), label
+        dp = np.abs(og[..., :P3] - oh[..., :P3]).max()
+        tail = np.abs(og[..., P3 + NR:] - oh[..., P3 + NR:])
+        rays = np.abs(og[..., P3:P3 + NR] - oh[..., P3:P3 + NR]) > 2e-3             # a ray that grazes an edge may answer differently: counted
+        out['worst_prop'], out['worst_tail'] = max(out['worst_prop'], dp), max(out['worst_tail'], tail.max())
+        out['ray_mismatch'] = max(out['ray_mismatch'], rays.mean())
+        bad = np.argwhere(tail > 5e-3)
+        assert len(bad) == 0, (label, 'percept_vec .. control_spd differ', bad[:8], og[tuple(bad[0][:2])][P3 + NR:][30:50], oh[tuple(bad[0][:2])][P3 + NR:][30:50])
+        assert dp < 5e-3, (label, dp)
+        assert rays.mean() < 2e-3, (label, rays.mean())
+    compare('reset', np.ones(n_arenas, bool))
+    rng = np.random.default_rng(seed)
+    for t in range(steps):
+        act = (rng.normal(size=(n_arenas, 2, 12)) * 0.135).astype(np.float32)
+        H.set_state(G.state())
+        G.step_host(act); H.step_host(act)
+        (rg, dg, wg), (rh, dh, wh) = G.reward_done(), H.reward_done()
+        eg, eh = G.episode(), H.episode()
+        same = (dg.reshape(n_arenas, -1)[:, 0] == dh.reshape(n_arenas, -1)[:, 0]) & (wg.reshape(n_arenas, -1)[:, 0] == wh.reshape(n_arenas, -1)[:, 0]) & \
+               (eg['with_flag0'] == eh['with_flag0']) & (np.abs(eg['flag_x'] - eh['flag_x']) < 1e-6)
+        out['left_out'] += int((~same).sum())
+        out['reseeded'] += int((dg.reshape(n_arenas, -1)[:, 0] != 0)[same].sum())
+        compare('step %d' % t, same)
+    assert out['left_out'] <= max(2, int(0.01 * n_arenas * steps)), out
+    assert out['reseeded'] >= n_arenas // 64, out                      # the re-seed path was exercised (catches at spawn)
+    G.close(); H.close()
+    return out
+
+
 def check_robot_robot_contact(lib_path):
     """This build's robot-robot contact (capsule pairs between the two rows of an arena).  Arena 0: robot 0 is dropped onto robot 1
     and is carried by it instead of falling through.  Arena 1: robot 0 walks its front legs into robot 1's hind legs -- a catch

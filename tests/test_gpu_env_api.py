@@ -341,24 +341,31 @@ def test_p2p_pull_occupies_no_compute_unit():
     env = {'LL_BENCH_FORCE_GATHER': '1', 'LL_BENCH_BACKEND': 'gloo', 'LL_BENCH_GATHER_REPEAT': os.environ.get('LL_TEST_P2P_REPEAT', '0')}
     res, lines = {}, []
     for rnd in range(2):                                                      # two rounds, best of each (box noise only ever adds time)
-        for name, mode, extra in (('none', 'none', {}), ('p2p_sdma', 'p2p', {}), ('p2p_copy_kernel', 'p2p', {'LL_BENCH_P2P_NO_CU': '0'}), ('collective_stand_in', 'async', {'LL_BENCH_BACKEND': 'nccl'})):
+        for name, mode, extra in (('none', 'none', {}), ('p2p_sdma', 'p2p', {}), ('p2p_sdma_host_wait', 'p2p', {'LL_P2P_HOST_WAIT': '1'}), ('p2p_copy_kernel', 'p2p', {'LL_BENCH_P2P_NO_CU': '0'}), ('collective_stand_in', 'async', {'LL_BENCH_BACKEND': 'nccl'})):
             j, raw, root = _run_bench(base + ['--gather-mode', mode], dict(env, **extra))
-            k = (j['ms_per_step'], j['roofline']['kernel_avg_ms'], (j['config']['gather']['stream_stall_ms_total'] + j['config']['gather']['host_blocked_ms_total']) / steps)
-            res[name] = min(res.get(name, (1e9, 1e9, 1e9)), k)
+            k = (j['ms_per_step'], j['roofline']['kernel_avg_ms'], j['config']['gather']['stream_stall_ms_total'] / steps, j['config']['gather']['host_blocked_ms_total'] / steps)
+            res[name] = min(res.get(name, (1e9, 1e9, 1e9, 1e9)), k)
             lines.append('%s: %s' % (name, raw))
     log_dir = os.path.join(root, 'gpurun_out', 'two_rank')
     os.makedirs(log_dir, exist_ok=True)
+    w0, k0 = res['none'][0], res['none'][1]
+    w, k, stall, host = res['p2p_sdma']
+    unexplained = (w - w0) - (k - k0) - stall                                 # what neither the kernel's own slow-down nor the stream's wait for the copy accounts for
     with open(os.path.join(log_dir, 'p2p_no_cu.txt'), 'w') as f:
         f.write('one rank, %d envs, every unroll handed off %d times (ms per control step: wall, step kernel by HIP events; best of 2)\n' % (n, 1 + int(env['LL_BENCH_GATHER_REPEAT'])))
-        for name, (w, k, st) in res.items():
-            f.write('  %-22s wall %.4f  kernel %.4f  waited for a copy to finish (stream + host) %.4f  (+%.1f %% wall vs none)\n' % (name, w, k, st, 100.0 * (w / res['none'][0] - 1.0)))
+        for name, (w_, k_, st_, h_) in res.items():
+            f.write('  %-22s wall %.4f  kernel %.4f  engine stream stood still behind a copy %.4f  launching thread blocked %.4f  (+%.1f %% wall vs none)\n' % (name, w_, k_, st_, h_, 100.0 * (w_ / w0 - 1.0)))
+        f.write('p2p_sdma against none: wall + %.4f = kernel + %.4f (the step kernel beside a 470 MB DMA stream) + stream wait %.4f (ONE device: the pull is an HBM-to-HBM copy on a single SDMA\n'
+                'engine, about as long as the unroll it hides behind; on a node every pull has its own link and engine) + %.4f unexplained (launch gaps: what the host-side hand-off costs)\n' % (w - w0, k - k0, stall, unexplained))
         f.write('\n'.join(lines) + '\n')
-    print(res)
-    # (measured on MI355X, 470 MB per unroll: kernel 0.1677 none / 0.1687 p2p; wall 0.1693 / 0.1792 -- on ONE device the pull is an HBM-to-HBM
-    # copy at the 24 GB/s of one SDMA engine, 19.6 ms of every 21.7 ms unroll, and the engine waits for its end before it overwrites the block;
-    # on a node every peer's pull has its own link and engine.  The wall figure is reported, the occupancy claim asserted.)
-    assert res['p2p_sdma'][1] <= 1.01 * res['none'][1], res                   # the step kernel does not notice the pulls
-    assert res['p2p_sdma'][0] <= 1.10 * res['none'][0], res                   # and the steps are not held up by more than the copy's bandwidth explains
+    print(res, 'unexplained', unexplained)
+    # Round 5: the producer's wait for "block copied" is a DEVICE-side wait on a signal word (hipStreamWaitValue32) raised by a watcher thread; the launching thread
+    # no longer blocks on the interprocess event.  What is left of the wall difference on ONE device is the copy itself (a single SDMA engine moves 470 MB in
+    # about an unroll's time, and the kernel beside it runs 1 - 2 % slower: the copy streams through the Infinity Cache that holds the mocap table -- a hypothesis,
+    # the measurement is the point); the hand-off's own cost -- launch gaps the host causes -- is the unexplained rest and must stay within 1 % of the step.
+    assert k <= 1.03 * k0, res                                                # the step kernel hardly notices the pulls (no compute unit taken: a copy KERNEL is measured beside it)
+    assert unexplained <= 0.01 * w0, (res, unexplained)                       # the hand-off costs the steps nothing beyond the copy's own duration
+    assert w <= 1.10 * w0, res
 
 
 def test_bench_rccl_one_rank_communicator():

@@ -73,6 +73,18 @@ def test_bullet_limit_rows_variant_gpu():
         print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=9, cap_ill=3))
 
 
+def test_every_observation_field_against_the_host_build_of_the_kernel_source():
+    """2048 arenas (BASELINE config 5's size: the one-wave-per-SIMD kernels), every observation field against the CPU build of the same source, both
+    friction modes -- including the arenas that re-seed inside the step (sepmc_parity_common.check_engine_against_emulation)."""
+    import os
+    import subprocess
+    emul_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emul')
+    subprocess.check_call(['make', '-C', emul_dir, '-s'])
+    lib = os.path.join(emul_dir, '_build', 'libllenv_emul.so')
+    print('cone friction:', SC.check_engine_against_emulation(lib, n_arenas=2048, steps=2))
+    print('pyramid:', SC.check_engine_against_emulation(lib, n_arenas=2048, steps=1, spec=dict(friction_mode=0)))
+
+
 def test_trained_reference_policy_plays_chase_tag_gpu():
     print(SC.check_trained_policy_plays_chase_tag(None, n_arenas=128, horizon=700, min_caught=0.6))
 

@@ -360,6 +360,43 @@ def test_belly_landing_on_edges_does_not_sink(golden, orc, model_blob, mocap_tab
         assert B.fk_feet(s)[:, 2].min() > 0.1                             # the feet hang in the air: the belly carries the robot
 
 
+def test_hanging_bar_stops_the_back(golden, orc, model_blob, mocap_table):
+    """the UNDERSIDE of a hanging bar (element 2 of BASELINE config 4, bullet_static_entities.py:366-412: a box 0.1 m long floating
+    0.25 m above the ground).  A bar shorter than the trunk, over the middle of its back, touches none of the robot's own candidate points (vertices,
+    spheres) -- the robot used to rise straight through it.  A floating box now offers its BOTTOM edges to the body box (LLM_FLOATING_MIN_Z): a robot
+    thrown upwards under the bar is stopped by it, its back no higher than the bar's underside; with the reverse candidates switched off (the oracle's
+    test switch) it passes through -- so the case is what it claims to be."""
+    from oracle import oracle as O
+    B = make_oracle_batch(orc, model_blob, mocap_table)
+    hold = standing_state(golden)[13:25].copy()
+    box = model_blob[um.OFF_BASE_PRIMS:um.OFF_BASE_PRIMS + um.PRIM_STRIDE]
+    hz, cz = box[3], box[6]                                             # half thickness and centre height of the body box in the base frame
+    z0 = 0.55                                                           # the bar's underside (high enough that the legs are off the ground when the back meets it)
+    for name, shapes, yaw in (('across the back', np.array([[-0.05, 0.05, -1.0, 1.0, z0, z0 + 0.3, 0.0, 0.0]]), 0.0),
+                              ('askew', np.array([[-0.05, 0.05, -1.0, 1.0, z0, z0 + 0.3, 0.0, 0.0]]), 0.3),
+                              ('a stub over the middle of the back', np.array([[-0.05, 0.05, -0.06, 0.06, z0, z0 + 0.3, 0.0, 0.0]]), 0.0)):
+        tops = {}
+        try:
+            for edges in (1, 0):
+                O.reset_spec(); O.set_spec(trunk_edges=edges)
+                s = standing_state(golden, z=z0 - (cz + hz) - 0.03)         # the back 3 cm under the bar
+                s[3:7] = [0, 0, np.sin(yaw / 2), np.cos(yaw / 2)]
+                s[9] = 2.0                                                  # thrown upwards at 2 m/s: free, it would rise 0.2 m
+                top, ncs = -1.0, []
+                for _ in range(150):
+                    tau = np.clip(50.0 * (hold - s[13:25]) - 0.5 * s[25:37], -18.0, 18.0)
+                    s, nc, lam = B.substep_terrain(s, tau, 0.45, shapes, 1.0, None)
+                    top = max(top, s[2] + cz + hz)
+                    ncs.append(nc)
+                tops[edges] = top
+                if edges:
+                    assert max(ncs) >= 2, (name, max(ncs))                  # a line of contact, not a point
+        finally:
+            O.reset_spec()
+        assert tops[1] < z0 + 3e-3, (name, tops)                            # the back stays under the bar (within the penetration one substep at 2 m/s leaves: 4 mm x ERP)
+        assert tops[0] > z0 + 0.1, (name, tops)                             # without the bottom edges the robot rises through it
+
+
 def test_bullet_audit_switches(golden, orc, model_blob, mocap_table):
     """The round-3 audit switches of the oracle (include/llenv_model.h LLM_SPEC_FRICTION_MODE / ROW_ORDER / MAX_COORD_VEL / LIMIT_ERP) are
     variants of the SAME constrained problem: a sliding robot obeys their friction bound (box for modes 0 / 1, cone for mode 2), a standing one

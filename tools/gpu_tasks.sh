@@ -9,7 +9,7 @@
 #   final     the -m gpu suite at HEAD, then the three bench lines and the large-batch sweep points
 #   driver    the driver's own invocation against longer runs, with and without the HBM triad first
 TARGET=${1:-tests}
-TAG=${2:-r04_$TARGET}
+TAG=${2:-r05_$TARGET}
 cd "$(dirname "$0")/.." || exit 1
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -67,6 +67,27 @@ case $TARGET in
     done < tools/r05_variants.txt
     wait
     cat $OUT/engine_*.md | grep -v "^| simulator\|^|---" ; tail -n 2 $OUT/engine_*.err | tail -20 ;;
+  r05b)          # round 5, second call: the per-step table versions of the multi-step launch (bit-identity, cost), the 8-rank and p2p tests, driver-style lines, limit_erp_deep priced
+    timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -rA -k "multi_step" > $OUT/pytest_multi.log 2>&1; echo "multi-step rc $?"; tail -3 $OUT/pytest_multi.log
+    for r in 1 2; do python tools/sweep.py "4096:4:10:10:32,4096:4:10:10:16,4096:4:10:10:8,4096:4:10:10:128,4096:4:10:10:1,8192:4:10:10:32,65536:4:10:10:8"; done > $OUT/table_versions_sweep.txt 2>&1
+    cat $OUT/table_versions_sweep.txt
+    for i in 1 2 3; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | show "driver-style"; done
+    python bench.py --gpus 1 --steps 2048 --warmup 256 --no-cpu-baseline > $OUT/bench_2048.json 2>/dev/null; show "2048 steps" < $OUT/bench_2048.json
+    gpu_tests -k "bench_ or p2p or gather or rccl or env_api"
+    cp gpurun_out/two_rank/* $OUT/ 2>/dev/null
+    i=0
+    for v in "bullet limits + contact ERP 0.08, no cap:limit_speculative=0,erp=0.08,limit_erp=0.2,max_depen_speed=1e30" "the same + deep limit rows without push-back:limit_speculative=0,erp=0.08,limit_erp=0.2,max_depen_speed=1e30,limit_erp_deep=0"; do
+      OMP_NUM_THREADS=4 python tools/spec_table.py --engine --variants "$v" > $OUT/engine_$i.md 2> $OUT/engine_$i.err &
+      i=$((i+1))
+    done
+    wait
+    cat $OUT/engine_*.md | grep -v "^| simulator\|^|---" ;;
+  r05c)          # round 5, third call: the whole -m gpu suite at the round-5 spec (no -x: every cap that needs re-observing shows), the chunk-7 reproduction, bench lines
+    gpu_tests
+    timeout 600 python tools/diag_sepmc_chunk7.py > $OUT/chunk7.txt 2>&1; cat $OUT/chunk7.txt | cut -c1-700
+    for i in 1 2; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | show "driver-style"; done
+    python bench.py --gpus 1 --steps 2048 --warmup 256 --no-cpu-baseline > $OUT/bench_2048.json 2>/dev/null; show "2048 steps" < $OUT/bench_2048.json
+    cp gpurun_out/two_rank/* $OUT/ 2>/dev/null ;;
   final)         # the round's closing call: the whole -m gpu suite at HEAD, then the three bench lines against the committed counters
     gpu_tests
     python bench.py > $OUT/bench.log 2>$OUT/bench.err; tail -c 400 $OUT/bench.log
