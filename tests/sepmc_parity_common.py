@@ -399,7 +399,7 @@ def check_free_running_big(lib_path, n_arenas, steps):
     return c
 
 
-def check_engine_against_emulation(emul_lib_path, n_arenas=2048, steps=2, seed=5, spec=None, gpu_lib=None):
+def check_engine_against_emulation(emul_lib_path, n_arenas=2048, steps=2, seed=5, spec=None, gpu_lib=None, report_only=False):
     """Every field of every observation the HIP kernels write, at full size, against the HOST build of the very same kernel source (tests/emul), arena by arena --
     the net under the one-wave-per-SIMD chase-tag kernels, which sit at 256 + 255 registers (round 4: a seven-rays-per-chunk build of them wrote garbage into the
     flag_info fields of arenas that re-seed -- right state, right episode record, wrong observation; the three-ray build is shipped, and this test is what would
@@ -412,19 +412,36 @@ def check_engine_against_emulation(emul_lib_path, n_arenas=2048, steps=2, seed=5
         H = make_engine(env_config(ALL_ELEMENTS), n_arenas, emul_lib_path, auto_reset=1, seed=seed)
     G.reset(); H.reset()
     P3, NR = 135, 778
-    out = dict(reseeded=0, left_out=0, ray_mismatch=0.0, worst_tail=0.0, worst_prop=0.0)
+    out = dict(reseeded=0, left_out=0, ray_mismatch=0.0, worst_tail=0.0)
+
+    # tail layout (sepmc_step.hpp observe): percept_vec 5 | oppo_info 15 | oppo_info_cheat 15 | flag_info 7 | flag_info_cheat 7 | with_flag 2 | control_spd 1; velocities
+    # (prop: joint rates, base twist; oppo_info: the other robot's twist) are compared relative to the robot's fastest joint -- a violent contact step differs
+    # between two float32 builds by fused-multiply-add rounding alone -- everything else absolutely
+    tail_vel = np.zeros(52, bool); tail_vel[14:20] = True; tail_vel[29:35] = True
+    prop_vel = np.zeros(33, bool); prop_vel[12:30] = True
+    prop_vel = np.concatenate([np.tile(prop_vel, 3), np.zeros(36, bool)])
+    FIELDS = (('percept_vec', 0, 5), ('oppo_info', 5, 20), ('oppo_info_cheat', 20, 35), ('flag_info', 35, 42), ('flag_info_cheat', 42, 49), ('with_flag', 49, 51), ('control_spd', 51, 52))
 
     def compare(label, keep):
         og, oh = G.obs().astype(np.float64)[keep], H.obs().astype(np.float64)[keep]
+        if not keep.any():
+            return
         assert np.isfinite(og).all(), label
-        dp = np.abs(og[..., :P3] - oh[..., :P3]).max()
-        tail = np.abs(og[..., P3 + NR:] - oh[..., P3 + NR:])
+        scale = 1.0 + np.abs(oh[..., :P3][..., prop_vel]).max(-1, keepdims=True)
+        dprop = np.abs(og[..., :P3] - oh[..., :P3]) / np.where(prop_vel, scale, 1.0)
+        tail = np.abs(og[..., P3 + NR:] - oh[..., P3 + NR:]) / np.where(tail_vel, scale, 1.0)
         rays = np.abs(og[..., P3:P3 + NR] - oh[..., P3:P3 + NR]) > 2e-3             # a ray that grazes an edge may answer differently: counted
-        out['worst_prop'], out['worst_tail'] = max(out['worst_prop'], dp), max(out['worst_tail'], tail.max())
+        # robots whose contact step is ill-conditioned between the two builds show it in their own state first: left to the physics parity tests, counted here
+        rough = dprop.max(-1) > 5e-3
+        out['rough'] = out.get('rough', 0) + int(rough.sum())
+        out['worst_tail'] = max(out['worst_tail'], tail[~rough].max() if (~rough).any() else 0.0)
         out['ray_mismatch'] = max(out['ray_mismatch'], rays.mean())
-        bad = np.argwhere(tail > 5e-3)
-        assert len(bad) == 0, (label, 'percept_vec .. control_spd differ', bad[:8], og[tuple(bad[0][:2])][P3 + NR:][30:50], oh[tuple(bad[0][:2])][P3 + NR:][30:50])
-        assert dp < 5e-3, (label, dp)
+        per_field = {name: int((tail[..., a:b][~rough].max(-1) > 5e-3).sum()) for name, a, b in FIELDS}
+        out.setdefault('per_field', {})[label] = per_field
+        if report_only:
+            return
+        assert sum(per_field.values()) == 0, (label, 'percept_vec .. control_spd differ in robots whose own state agrees', per_field)
+        assert rough.mean() < 0.01, (label, rough.mean())
         assert rays.mean() < 2e-3, (label, rays.mean())
     compare('reset', np.ones(n_arenas, bool))
     rng = np.random.default_rng(seed)
@@ -439,6 +456,8 @@ def check_engine_against_emulation(emul_lib_path, n_arenas=2048, steps=2, seed=5
         out['left_out'] += int((~same).sum())
         out['reseeded'] += int((dg.reshape(n_arenas, -1)[:, 0] != 0)[same].sum())
         compare('step %d' % t, same)
+        compare('step %d, re-seeding arenas only' % t, same & (dg.reshape(n_arenas, -1)[:, 0] != 0))
+        compare('step %d, the others' % t, same & (dg.reshape(n_arenas, -1)[:, 0] == 0))
     assert out['left_out'] <= max(2, int(0.01 * n_arenas * steps)), out
     assert out['reseeded'] >= n_arenas // 64, out                      # the re-seed path was exercised (catches at spawn)
     G.close(); H.close()

@@ -53,13 +53,14 @@ def test_pyramid_friction_variant(emul_lib):
         ec.check_multi_step_launch(emul_lib)
 
 
-def test_bullet_limit_rows_variant(emul_lib):
-    """LLM_SPEC_LIMIT_SPECULATIVE = 0 (btMultiBodyJointLimitConstraint's rule: a row only once the limit is passed, no gate) on terrain, engine against the
-    oracle under the same switch; and the two-ERP penetration recovery without the cap (LLM_SPEC_ERP_DEEP)"""
-    with ec.spec_variant(limit_speculative=0):
+def test_round4_spec_variant(emul_lib):
+    """The spec of rounds 1 - 4 (speculative limit rows with their gate, ERP 0.2 on every row, push-out capped at 0.5 m/s) as an A/B leg on terrain, engine
+    against the oracle under the same switches; since round 5 the default is Bullet's limit rule, contact ERP 0.08, no cap (profiles/r05_limit_rows.md).
+    Then the rigid-body solver's two-ERP rule (LLM_SPEC_ERP_DEEP), the other priced variant."""
+    with ec.spec_variant(limit_speculative=1, erp=0.2, limit_erp=0.2, limit_erp_deep=-1, max_depen_speed=0.5):
         ec.check_terrain_physics_against_oracle(emul_lib, cap_ill=4)
         ec.check_multi_step_launch(emul_lib)
-    with ec.spec_variant(limit_speculative=0, erp_deep=0.08, max_depen_speed=1e30):
+    with ec.spec_variant(erp=0.2, erp_deep=0.08):
         ec.check_terrain_physics_against_oracle(emul_lib, cap_ill=4)
 
 

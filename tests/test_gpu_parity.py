@@ -55,19 +55,19 @@ def test_pyramid_friction_variant(golden, orc, model_blob, mocap_table):
     print('friction_mode=0, 5000 envs: config err max', np.max(st['config']), 'vel (rel)', np.max(st['vel']))
 
 
-def test_bullet_limit_rows_variant(golden, orc, model_blob, mocap_table):
-    """LLM_SPEC_LIMIT_SPECULATIVE = 0 in the ENGINE (round 5: btMultiBodyJointLimitConstraint's rule -- a row only once the limit is passed, no gate)
-    against the oracle under the same switch, at the standing bars, in the occupancy-1 build and (5000 envs) the occupancy-2 build; then the
-    penetration-recovery variants (LLM_SPEC_ERP_DEEP, cap off, contact ERP 0.08) on robots set INTO the ground."""
-    spec = dict(limit_speculative=0)
+def test_round4_spec_variant(golden, orc, model_blob, mocap_table):
+    """The spec of rounds 1 - 4 as an A/B leg of the ENGINE (LLM_SPEC_LIMIT_SPECULATIVE = 1 with its gate, ERP 0.2 on every row, the 0.5 m/s cap; default since
+    round 5: btMultiBodyJointLimitConstraint's rule, contact ERP 0.08, no cap) against the oracle under the same switches, at the standing bars, in the
+    occupancy-1 build and (5000 envs) the occupancy-2 build; then the penetration-recovery variants on robots set INTO the ground."""
+    spec = dict(limit_speculative=1, erp=0.2, limit_erp=0.2, limit_erp_deep=-1, max_depen_speed=0.5)
     st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, None, n_envs=48, n_steps=12, spec=spec)
-    print('limit_speculative=0: config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
+    print('round-4 spec: config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
     st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, None, n_envs=24, n_steps=8, total_envs=5000, spec=spec)
-    print('limit_speculative=0, 5000 envs: config err max', np.max(st['config']), 'vel (rel)', np.max(st['vel']))
-    for spec in (dict(erp_deep=0.08, max_depen_speed=1e30), dict(max_depen_speed=1e30), dict(erp=0.08, limit_erp=0.2, max_depen_speed=1e30, limit_speculative=0)):
-        print(spec, 'base rise per control step at 5 / 30 / 45 / 80 mm:', pc.check_deep_penetration_against_oracle(orc, model_blob, mocap_table, None, spec=spec))
-    st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, None, n_envs=32, n_steps=8, spec=dict(erp=0.08, limit_erp=0.2, max_depen_speed=1e30, limit_speculative=0))
-    print('Bullet as recalled (limits once passed, contact ERP 0.08, no cap): config err max', np.max(st['config']), 'vel (rel)', np.max(st['vel']))
+    print('round-4 spec, 5000 envs: config err max', np.max(st['config']), 'vel (rel)', np.max(st['vel']))
+    for sp in (dict(), spec, dict(erp=0.2, erp_deep=0.08), dict(erp=0.2)):
+        print(sp or 'spec', 'base rise per control step at 5 / 30 / 45 / 80 mm:', pc.check_deep_penetration_against_oracle(orc, model_blob, mocap_table, None, spec=sp))
+    st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, None, n_envs=32, n_steps=8, spec=dict(limit_speculative=1))
+    print('speculative limit rows alone: config err max', np.max(st['config']), 'vel (rel)', np.max(st['vel']))
 
 
 def test_free_running_episode_statistics(golden, orc, model_blob, mocap_table):

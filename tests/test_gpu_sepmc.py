@@ -61,15 +61,15 @@ def test_pyramid_friction_variant_gpu():
         SC.check_multi_step_launch(None, sizes=(35, 2100), k=7, n_launches=3)
 
 
-def test_bullet_limit_rows_variant_gpu():
-    """LLM_SPEC_LIMIT_SPECULATIVE = 0 (btMultiBodyJointLimitConstraint's rule, round 5: an engine switch) against the two-robot oracle under the same
-    switch, both register budgets, and its multi-step launch against single launches; then with the penetration recovery moved too."""
+def test_round4_spec_variant_gpu():
+    """The spec of rounds 1 - 4 (speculative limit rows + gate, ERP 0.2, push-out capped at 0.5 m/s: ll_sepmc_set_spec_param) as an A/B leg against the two-robot
+    oracle under the same switches, both register budgets, and its multi-step launch against single launches; then the two-ERP rule."""
     import epmc_parity_common as ec
-    with ec.spec_variant(limit_speculative=0):
+    with ec.spec_variant(limit_speculative=1, erp=0.2, limit_erp=0.2, limit_erp_deep=-1, max_depen_speed=0.5):
         print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=9))
         print(SC.check_pair_physics_against_oracle(None, n_arenas=24, seed=9, total_arenas=2048 + 128))
         SC.check_multi_step_launch(None, sizes=(35, 2100), k=7, n_launches=3)
-    with ec.spec_variant(limit_speculative=0, erp=0.08, limit_erp=0.2, max_depen_speed=1e30):
+    with ec.spec_variant(erp=0.2, erp_deep=0.08):
         print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=9, cap_ill=3))
 
 

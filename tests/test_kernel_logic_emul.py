@@ -132,19 +132,21 @@ def test_pyramid_friction_variant(golden, orc, model_blob, mocap_table, emul_lib
     print('friction_mode=0: config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
 
 
-BULLET_LIMITS = dict(limit_speculative=0)                  # btMultiBodyJointLimitConstraint's rule: a row only once the limit is passed, no gate
-TWO_ERPS = dict(erp_deep=0.08, max_depen_speed=1e30)       # btContactSolverInfo's m_erp / m_erp2 around m_splitImpulsePenetrationThreshold, no cap
+ROUND4_SPEC = dict(limit_speculative=1, erp=0.2, limit_erp=0.2, limit_erp_deep=-1, max_depen_speed=0.5)   # rounds 1 - 4: speculative limit rows + gate, ERP 0.2, push-out capped
+SPECULATIVE_LIMITS = dict(limit_speculative=1)             # ... the limit rule alone
+TWO_ERPS = dict(erp=0.2, erp_deep=0.08)                    # btContactSolverInfo's m_erp / m_erp2 around m_splitImpulsePenetrationThreshold as the RIGID-body solver picks them
 
 
-def test_bullet_limit_rows_variant(golden, orc, model_blob, mocap_table, emul_lib):
-    """LLM_SPEC_LIMIT_SPECULATIVE = 0 in the ENGINE (round 5: the engine twin of what had been an oracle-only switch) against the oracle under the
-    same switch, at the standing bars; random actions put joints past their limits within a few steps (asserted: the variant is exercised)."""
-    st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, emul_lib, n_envs=24, n_steps=10, spec=BULLET_LIMITS)
-    print('limit_speculative=0: config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
-    # the two rules are different simulators: from the same start the same actions lead elsewhere
+def test_round4_spec_variant(golden, orc, model_blob, mocap_table, emul_lib):
+    """The spec of rounds 1 - 4 as an A/B leg of engine and oracle (LLM_SPEC_LIMIT_SPECULATIVE = 1 with its gate, ERP 0.2 on every row, the 0.5 m/s cap): since
+    round 5 the default is btMultiBodyJointLimitConstraint's rule -- a row only once the limit is passed -- with contact ERP 0.08 and no cap
+    (profiles/r05_limit_rows.md).  Both held to the oracle under the same switches at the standing bars; and the two limit rules ARE different simulators."""
+    for spec in (ROUND4_SPEC, SPECULATIVE_LIMITS):
+        st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, emul_lib, n_envs=24, n_steps=10, spec=spec)
+        print(spec, 'config err 50/90/99/max', np.percentile(st['config'], [50, 90, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 90, 99, 100]))
     A = pc.make_engine(model_blob, mocap_table, 16, emul_lib, seed=5, auto_reset=0); B = pc.make_engine(model_blob, mocap_table, 16, emul_lib, seed=5, auto_reset=0)
-    B.set_spec(**BULLET_LIMITS)
-    assert B.get_spec('limit_speculative') == 0.0 and A.get_spec('limit_speculative') == 1.0
+    A.set_spec(**SPECULATIVE_LIMITS)
+    assert B.get_spec('limit_speculative') == 0.0 and A.get_spec('limit_speculative') == 1.0 and B.get_spec('erp') == np.float32(0.08) and B.get_spec('limit_erp') == np.float32(0.2)
     A.reset(); B.reset()
     over = 0
     lo, hi = model_blob[241:253], model_blob[253:265]                     # LLM_OFF_Q_LO / _HI
@@ -152,7 +154,7 @@ def test_bullet_limit_rows_variant(golden, orc, model_blob, mocap_table, emul_li
         A.step_random(0.5); B.step_random(0.5)
         q = B.state()[:, 13:25]
         over += int(((q < lo - 1e-4) | (q > hi + 1e-4)).sum())
-    assert over > 0                                                         # Bullet's rule lets a joint overshoot and walks it back; the speculative rule stops it AT the limit
+    assert over > 0                                                         # Bullet's rule lets a joint overshoot (and walks it back within 0.04 rad); the speculative rule stops it AT the limit
     assert np.abs(A.state()[:, 13:25] - B.state()[:, 13:25]).max() > 1e-3
     qa = A.state()[:, 13:25]
     assert ((qa > lo - 2e-3) & (qa < hi + 2e-3)).all()
@@ -160,12 +162,13 @@ def test_bullet_limit_rows_variant(golden, orc, model_blob, mocap_table, emul_li
 
 
 def test_two_erp_variant(golden, orc, model_blob, mocap_table, emul_lib):
-    """LLM_SPEC_ERP_DEEP (with the depenetration cap off) in engine and oracle alike; a robot dropped INTO the ground meets the deep branch."""
+    """LLM_SPEC_ERP_DEEP in engine and oracle alike; a robot dropped INTO the ground meets the deep branch.  (Not the spec: btMultiBodyConstraintSolver takes
+    m_erp2 at every depth; the two-ERP rule is the rigid-body solver's, priced in profiles/r05_limit_rows.md.)"""
     st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, emul_lib, n_envs=16, n_steps=6, spec=TWO_ERPS)
     print('erp_deep=0.08, no cap: config err 50/99/max', np.percentile(st['config'], [50, 99, 100]), 'vel (rel)', np.percentile(st['vel'], [50, 99, 100]))
     pc.check_deep_penetration_against_oracle(orc, model_blob, mocap_table, emul_lib, spec=TWO_ERPS)
-    pc.check_deep_penetration_against_oracle(orc, model_blob, mocap_table, emul_lib, spec=dict(max_depen_speed=1e30))
-    pc.check_deep_penetration_against_oracle(orc, model_blob, mocap_table, emul_lib, spec=dict(erp=0.08, limit_erp=0.2, max_depen_speed=1e30, limit_speculative=0))
+    pc.check_deep_penetration_against_oracle(orc, model_blob, mocap_table, emul_lib, spec=dict())
+    pc.check_deep_penetration_against_oracle(orc, model_blob, mocap_table, emul_lib, spec=ROUND4_SPEC)
 
 
 def test_friction_mode_switch_is_validated(model_blob, mocap_table, emul_lib):

@@ -130,15 +130,29 @@ def test_friction_cone_and_sliding(golden, orc, model_blob, mocap_table):
 
 
 def test_joint_limit_rows(golden, orc, model_blob, mocap_table):
-    """Driving a hip against its limit with full torque stops at the limit (within the ERP band)."""
+    """Joint limits as btMultiBodyJointLimitConstraint solves them (the spec since round 5): no row inside the range; a hip driven against its limit
+    passes it by less than one substep of travel and is stopped there; within 0.04 rad it walks back by ERP 0.2 per substep, beyond that it is held and not
+    pushed back (split impulse leaves the positional part unapplied: LLM_LIMIT_ERP_DEEP = 0)."""
     B = make_oracle_batch(orc, model_blob, mocap_table)
-    s = standing_state(golden, z=3.0)                    # in the air: no contacts involved
-    lo, hi = model_blob[um.OFF_Q_LO], model_blob[um.OFF_Q_HI]
-    for k in range(400):
-        tau = np.zeros(12); tau[0] = 18.0
-        s, nc, lam, acc = B.substep(s, tau)
-    assert s[13] < hi + 0.02 and s[13] > hi - 0.05, s[13]
-    assert lam[0] > 0
+    hi = model_blob[um.OFF_Q_HI]
+    for torque, deep in ((18.0, True), (1.0, False)):
+        s = standing_state(golden, z=10.0)                   # in the air for the 0.8 s of the run: no contacts involved
+        vmax, first_over = 0.0, None
+        for k in range(400):
+            tau = np.zeros(12); tau[0] = torque
+            v_before = s[25]
+            s, nc, lam, acc = B.substep(s, tau)
+            if first_over is None and s[13] > hi:
+                first_over = (s[13] - hi, v_before)
+            vmax = max(vmax, abs(s[25]))
+        over = s[13] - hi
+        assert first_over is not None and first_over[0] <= abs(first_over[1]) * 0.002 + 0.5 * 0.002 * 0.002 * 5e3, first_over      # passed by one substep of travel
+        if deep:
+            assert lam[0] > 0 and abs(s[25]) < 1e-6, (lam[0], s[25])           # arrived fast: more than 0.04 rad past the limit, stopped, held, NOT pushed back
+            assert 0.04 < over < first_over[0] + 1e-6, (over, first_over)
+        else:
+            assert -1e-3 < over < 2e-3 and abs(s[25]) < 0.3, (over, s[25])     # arrived slowly: walked back by ERP per substep; it now hovers AT the limit
+            # (inside the range there is no row: the torque moves it out by a dt^2 in a substep, the row of the next one brings it back)
 
 
 def test_cone_friction_leaves_limit_rows_alone(golden, orc, model_blob, mocap_table):
@@ -162,23 +176,24 @@ def test_cone_friction_leaves_limit_rows_alone(golden, orc, model_blob, mocap_ta
     finally:
         O.reset_spec()
     assert np.array_equal(out[0][0], out[2][0]) and np.array_equal(out[0][1], out[2][1])
-    assert out[2][0][13] < hi + 0.02 and out[2][0][14] < model_blob[um.OFF_Q_HI + 1] + 0.02 and out[2][1][0] > 0 and out[2][1][1] > 0, (out[2][0][13:15], out[2][1][:2])
+    # both joints are past their limits (by less than a substep of travel: Bullet's rule, test_joint_limit_rows), held there, and both rows carry load
+    assert hi < out[2][0][13] < hi + 0.08 and model_blob[um.OFF_Q_HI + 1] < out[2][0][14] < model_blob[um.OFF_Q_HI + 1] + 0.08 and out[2][1][0] > 0 and out[2][1][1] > 0, (out[2][0][13:15], out[2][1][:2])
 
 
 def test_joint_limit_audit_switch(golden, orc, model_blob, mocap_table):
-    """LLM_SPEC_LIMIT_SPECULATIVE (oracle only): as shipped the joint is stopped AT its limit (a speculative row with the
-    free distance as its bias); with the switch off -- btMultiBodyJointLimitConstraint as recalled -- no row exists inside the range, the joint
-    overshoots by less than one substep of travel, and is then held within the ERP band.  Default: on."""
+    """LLM_SPEC_LIMIT_SPECULATIVE.  Default since round 5: 0 -- btMultiBodyJointLimitConstraint as recalled: no row inside the range, the joint
+    overshoots by less than one substep of travel and is stopped.  1 (rounds 1 - 4, still a switch of oracle and engine): a speculative row with the free
+    distance as its bias stops the joint AT its limit."""
     from oracle import oracle as O
     hi = model_blob[um.OFF_Q_HI]
     out = {}
     for mode in (1, 0):
         O.reset_spec()
         f = O.lib().orc_get_spec_param; f.restype = O.C.c_double
-        assert f(O.C.c_int(20)) == 1.0
+        assert f(O.C.c_int(20)) == 0.0
         O.set_spec(limit_speculative=mode)
         B = make_oracle_batch(orc, model_blob, mocap_table)
-        s = standing_state(golden, z=3.0)
+        s = standing_state(golden, z=10.0)
         worst, qd_at = -1.0, 0.0
         for k in range(400):
             tau = np.zeros(12); tau[0] = 18.0
@@ -188,9 +203,9 @@ def test_joint_limit_audit_switch(golden, orc, model_blob, mocap_table):
                 worst, qd_at = s[13] - hi, before
         out[mode] = (worst, s[13] - hi, qd_at)
     O.reset_spec()
-    assert out[1][0] < 0.02, out                                        # stopped at the limit (ten Gauss-Seidel iterations leave a residual)
-    assert 2 * out[1][0] < out[0][0] < abs(out[0][2]) * 0.002 * 1.2 + 0.005, out    # past it, by about one substep at the speed it arrived with
-    assert abs(out[0][1]) < 0.02 and abs(out[1][1]) < 0.02, out         # and held near it afterwards
+    assert out[1][0] < 0.02, out                                        # speculative: stopped at the limit (ten Gauss-Seidel iterations leave a residual)
+    assert 2 * out[1][0] < out[0][0] < abs(out[0][2]) * 0.002 * 1.2 + 0.005, out    # Bullet's rule: past it, by about one substep at the speed it arrived with
+    assert abs(out[1][1]) < 0.02 and out[0][1] <= out[0][0] + 1e-9, out  # held afterwards (Bullet's rule: where it was stopped -- not pushed back beyond 0.04 rad)
 
 
 def test_fk_feet_matches_numpy(golden, orc, model_blob, mocap_table):
@@ -218,7 +233,8 @@ def test_two_robots_exchange_momentum(golden, orc, frictionless_blob, mocap_tabl
     gains: the total linear momentum changes by gravity alone, the z component of the total angular momentum not at all, while each
     robot's own momentum changes by much more (the shared rows act)."""
     orc.set_link_damping(0.0)
-    try:
+    orc.set_spec(max_depen_speed=0.5)      # (ERP pushes a penetration out at erp * depth / dt: at this test's dt of 0.1 ms that is twenty times the speed the spec's 2 ms gives,
+    try:                                   #  and the integrator's O(dt v^2) momentum drift with it -- the test is about what the rows conserve, so the push-out is bounded here)
         B = make_oracle_batch(orc, frictionless_blob, mocap_table, sim_freq=10000.0, control_freq=1000.0)     # (small dt: the first-order
         s0, s1 = standing_state(golden, z=3.0), standing_state(golden, z=3.0)                                      #  integrator's own drift is O(dt))
         s0[0:3] = [0.0, 0.0, 3.0]; s1[0:3] = [0.30, 0.05, 3.02]                      # trunks 30 cm apart: legs and trunks interleave
@@ -238,6 +254,7 @@ def test_two_robots_exchange_momentum(golden, orc, frictionless_blob, mocap_tabl
         assert abs((P1[2] - P0[2]) + 2 * mass * 9.80665 * dt * n) < 2e-3
         assert abs(P1[5] - P0[5]) < 5e-3                                              # Lz of the pair about the world origin
     finally:
+        orc.reset_spec()
         orc.set_link_damping(um_default_damping())
 
 
@@ -245,6 +262,7 @@ def test_self_collision_is_internal(golden, orc, frictionless_blob, mocap_table)
     """Self-collision rows push two legs of the same robot apart: the joint velocities end up different from a run with the rows
     switched off, the robot's total momentum does not (beyond gravity and the integrator's O(dt) drift)."""
     orc.set_link_damping(0.0)
+    orc.set_spec(max_depen_speed=0.5)      # (see test_two_robots_exchange_momentum: dt is 0.1 ms here)
     try:
         B = make_oracle_batch(orc, frictionless_blob, mocap_table, sim_freq=10000.0, control_freq=1000.0)
         s_init = standing_state(golden, z=3.0)
@@ -267,6 +285,7 @@ def test_self_collision_is_internal(golden, orc, frictionless_blob, mocap_table)
             assert abs((P1[2] - P0[2]) + mass * 9.80665 * dt * n) < 1e-3
         assert np.abs(out[1][25:31] - out[0][25:31]).max() > 0.5          # the rows acted on the front legs' joints
     finally:
+        orc.reset_spec()
         orc.set_self_collision(1)
         orc.set_link_damping(um_default_damping())
 
@@ -328,7 +347,7 @@ def test_jump_obstacle_is_a_solid_body(golden, orc, model_blob, mocap_table):
     np.testing.assert_allclose(with_box[max(k - 3, 0)][:3], free[max(k - 3, 0)][:3], atol=0.05)   # same flight until the touch ...
     # ... then the box pushes back.  The episode ends with the step of the first touch, so the push is one control step's worth: the
     # base loses speed towards the box and the touching leg's joints are knocked (free flight leaves them at ~1e-3 rad/s)
-    assert v_along(with_box[k]) < v_along(free[k]) - 0.01, (v_along(with_box[k]), v_along(free[k]))
+    assert v_along(with_box[k]) < v_along(free[k]) - 1e-3, (v_along(with_box[k]), v_along(free[k]))      # (2e-3 m/s at contact ERP 0.08; 1.5e-2 under round 4's ERP 0.2)
     assert np.abs(with_box[k][25:37] - free[k][25:37]).max() > 0.05
     assert along(with_box[k]) < 0.0                                                               # the base is still on its own side
 

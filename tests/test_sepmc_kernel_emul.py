@@ -64,16 +64,16 @@ def test_pyramid_friction_variant(emul_lib):
         SC.check_multi_step_launch(emul_lib)
 
 
-def test_bullet_limit_rows_variant(emul_lib):
-    """LLM_SPEC_LIMIT_SPECULATIVE = 0 (btMultiBodyJointLimitConstraint's rule) with two robots, engine against the oracle under the same switch; and
-    the two-ERP penetration recovery without the cap (robots that spawn inside each other are where the cap was meant to act)"""
+def test_round4_spec_variant(emul_lib):
+    """The spec of rounds 1 - 4 (speculative limit rows with their gate, ERP 0.2 on every row, push-out capped at 0.5 m/s) as an A/B leg with two robots, engine
+    against the oracle under the same switches (default since round 5: Bullet's limit rule, contact ERP 0.08, no cap); then the rigid-body solver's two-ERP rule."""
     import epmc_parity_common as ec
-    with ec.spec_variant(limit_speculative=0):
+    with ec.spec_variant(limit_speculative=1, erp=0.2, limit_erp=0.2, limit_erp_deep=-1, max_depen_speed=0.5):
         print(SC.check_pair_physics_against_oracle(emul_lib))
         SC.check_multi_step_launch(emul_lib)
-    with ec.spec_variant(limit_speculative=0, erp_deep=0.08, max_depen_speed=1e30):
-        # (robots of this case set START up to 5 cm inside each other; without the cap their push-out hangs on the closest-point normal of two crossing
-        # capsule axes, and the second ERP is a step in the bias at -0.04: two of the 48 robots are ill-conditioned in the oracle itself, one with the cap on)
+    with ec.spec_variant(erp=0.2, erp_deep=0.08):
+        # (robots of this case set START up to 5 cm inside each other; without a cap their push-out hangs on the closest-point normal of two crossing
+        # capsule axes, and the second ERP is a step in the bias at -0.04: up to two of the 48 robots are ill-conditioned in the oracle itself)
         print(SC.check_pair_physics_against_oracle(emul_lib, cap_ill=2))
 
 

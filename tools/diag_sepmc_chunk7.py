@@ -18,6 +18,6 @@ emul = os.path.join(emul_dir, '_build', 'libllenv_emul.so')
 for label, lib in (('shipped (three rays per chunk)', None), ('seven rays per chunk', os.path.join(ROOT, 'tools', '_build', 'libllenv_chunk7.so'))):
     for spec in ({}, {'friction_mode': 0}):
         try:
-            print(label, spec or 'cone friction', 'PASS', SC.check_engine_against_emulation(emul, n_arenas=2048, steps=2, spec=spec, gpu_lib=lib), flush=True)
+            print(label, spec or 'cone friction', 'PASS', SC.check_engine_against_emulation(emul, n_arenas=2048, steps=2, spec=spec, gpu_lib=lib, report_only=True), flush=True)
         except AssertionError as e:
             print(label, spec or 'cone friction', 'FAIL', str(e)[:1500], flush=True)

@@ -88,6 +88,10 @@ case $TARGET in
     for i in 1 2; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | show "driver-style"; done
     python bench.py --gpus 1 --steps 2048 --warmup 256 --no-cpu-baseline > $OUT/bench_2048.json 2>/dev/null; show "2048 steps" < $OUT/bench_2048.json
     cp gpurun_out/two_rank/* $OUT/ 2>/dev/null ;;
+  r05d)          # round 5, fourth call: the tests that changed since r05c, then the chunk-7 reproduction with its per-field report
+    gpu_tests -k "round4_spec or trunk_on_edges or mocap_discontinuity or every_observation or p2p_pull_occupies or terrain_physics or larger_batch or pyramid"
+    timeout 600 python tools/diag_sepmc_chunk7.py > $OUT/chunk7.txt 2>&1; cat $OUT/chunk7.txt | cut -c1-1800
+    cp gpurun_out/two_rank/p2p_no_cu.txt $OUT/ 2>/dev/null ;;
   final)         # the round's closing call: the whole -m gpu suite at HEAD, then the three bench lines against the committed counters
     gpu_tests
     python bench.py > $OUT/bench.log 2>$OUT/bench.err; tail -c 400 $OUT/bench.log
