@@ -434,6 +434,16 @@ def check_engine_against_emulation(emul_lib_path, n_arenas=2048, steps=2, seed=5
         # robots whose contact step is ill-conditioned between the two builds show it in their own state first: left to the physics parity tests, counted here
         rough = dprop.max(-1) > 5e-3
         out['rough'] = out.get('rough', 0) + int(rough.sum())
+        if report_only and keep.all():
+            # where the differences sit (tools/diag_sepmc_chunk7.py): by the robot's 16-lane row inside its wavefront (row = (2 arena + robot) % 4), by
+            # observation entry, and the rays by family
+            wr = (2 * np.arange(n_arenas)[:, None] + np.arange(2)[None, :]) % 4
+            det = out.setdefault('detail', {}).setdefault(label, {})
+            det['rough_by_wave_row'] = [int(rough[wr == k].sum()) for k in range(4)]
+            det['rough_prop_entries'] = [int(x) for x in (dprop[rough] > 5e-3).sum(0).reshape(-1)[:33]] if rough.any() else []
+            det['ray_mismatch_by_wave_row'] = [float(rays[wr == k].mean()) for k in range(4)]
+            det['ray_mismatch_height_fan_front'] = [float(rays[..., 0:325].mean()), float(rays[..., 325:453].mean()), float(rays[..., 453:778].mean())]
+            det['robots_with_ray_mismatch'] = int(rays.any(-1).sum())
         out['worst_tail'] = max(out['worst_tail'], tail[~rough].max() if (~rough).any() else 0.0)
         out['ray_mismatch'] = max(out['ray_mismatch'], rays.mean())
         per_field = {name: int((tail[..., a:b][~rough].max(-1) > 5e-3).sum()) for name, a, b in FIELDS}

@@ -92,6 +92,8 @@ case $TARGET in
     gpu_tests -k "round4_spec or trunk_on_edges or mocap_discontinuity or every_observation or p2p_pull_occupies or terrain_physics or larger_batch or pyramid"
     timeout 600 python tools/diag_sepmc_chunk7.py > $OUT/chunk7.txt 2>&1; cat $OUT/chunk7.txt | cut -c1-1800
     cp gpurun_out/two_rank/p2p_no_cu.txt $OUT/ 2>/dev/null ;;
+  chunk7)        # the seven-ray SEPMC build against the host build of the same source, with where the differences sit
+    timeout 600 python tools/diag_sepmc_chunk7.py > $OUT/chunk7.txt 2>&1; grep -o "^[a-z (]*chunk[^{]*\|'detail': {.*" $OUT/chunk7.txt | cut -c1-1500 ;;
   final)         # the round's closing call: the whole -m gpu suite at HEAD, then the three bench lines against the committed counters
     gpu_tests
     python bench.py > $OUT/bench.log 2>$OUT/bench.err; tail -c 400 $OUT/bench.log
