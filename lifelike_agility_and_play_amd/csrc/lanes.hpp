@@ -66,6 +66,9 @@ LL_HD bool eq_(int a, int b) { return a == b; }
 }  // namespace lm
 
 #define PMC_ROW 16   // lanes per environment
+#ifndef LL_MFMA_GRAM
+#define LL_MFMA_GRAM 1   // the Gram blocks of the solver's rows on the matrix cores (GpuLanes::gram16); 0: 96 v_fmac_f32_dpp per block (gram4), the A/B leg
+#endif
 #define CONE_LDS_AT 64        // row-scratch word where a row's cone cross scalars live during the substeps (16 lanes x 32 words; GpuLanes::cone_store)
 #define PMC_ROW_SCRATCH 688   // floats of LDS scratch per env row (EPMC: 40 boxes x 8, three ray lists of 10, 16 and 12 records, 64 spare: epmc_step.hpp)
 
@@ -316,6 +319,30 @@ struct GpuLanes {
 #undef LL_G6
 #undef LL_G1
     g[S_] = g0; g[4 + S_] = g1; g[8 + S_] = g2; g[12 + S_] = g3;
+  }
+  // The whole 16 x 16 Gram block of a round on the MATRIX cores (round 5):  g[L] = sum_i y[i] * (x[i] of lane L of my row), L = 0 .. 15, for the four env rows
+  // of the wavefront at once.  v_mfma_f32_16x16x1_4b_f32 is four independent 16 x 16 outer products -- exactly the four env rows: A = x (lane i of a row holds
+  // x_i[k]), B = y (lane j holds y_j[k]), six of them chained over the six base coefficients.  D_b[i][j] lands in lane 16 (i / 4) + j, register 4 b + i % 4:
+  // lane j of row group g holds ITS OWN entries g_{b,j}[4 g .. 4 g + 3], only in the wrong row group -- a 4 x 4 block transpose between register block and row
+  // group (8 v_permlane32_swap + 8 v_permlane16_swap, gfx950) brings them home, register index = column index.  6 MFMA + 16 swaps instead of 96 half-rate
+  // v_fmac_f32_dpp (gram4 x 4); exact float32 (tools/mfma_gram_probe.hip: bit-identical to the shuffle statement on MI355X).  MFMA ignores EXEC: callers are wave-uniform.
+  static constexpr bool kGram16 = LL_MFMA_GRAM != 0;
+  typedef float ll_f16v __attribute__((ext_vector_type(16)));
+  static LL_D void gram16(const F* x, const F* y, F* g) {
+    ll_f16v acc;
+    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+    for (int i = 0; i < 6; i++) acc = __builtin_amdgcn_mfma_f32_16x16x1f32(x[i], y[i], acc, 0, 0, 0);
+    unsigned R[16];
+    for (int i = 0; i < 16; i++) R[i] = __float_as_uint(acc[i]);
+    for (int r = 0; r < 4; r++) {
+      const auto a = __builtin_amdgcn_permlane32_swap(R[r], R[8 + r], false, false); R[r] = a[0]; R[8 + r] = a[1];
+      const auto b = __builtin_amdgcn_permlane32_swap(R[4 + r], R[12 + r], false, false); R[4 + r] = b[0]; R[12 + r] = b[1];
+    }
+    for (int r = 0; r < 4; r++) {
+      const auto a = __builtin_amdgcn_permlane16_swap(R[r], R[4 + r], false, false); R[r] = a[0]; R[4 + r] = a[1];
+      const auto b = __builtin_amdgcn_permlane16_swap(R[8 + r], R[12 + r], false, false); R[8 + r] = b[0]; R[12 + r] = b[1];
+    }
+    for (int i = 0; i < 16; i++) g[i] = __uint_as_float(R[i]);
   }
   // Four Gauss-Seidel turns (lanes S, 4+S, 8+S, 12+S) as one block: v_med3 (clamp the pending increment), v_cndmask (the lane
   // whose turn it is keeps its increment; masks m0..m3 are the lane masks of the four turns), one wait state, v_fmac with a

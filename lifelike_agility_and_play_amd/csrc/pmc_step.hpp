@@ -309,12 +309,22 @@ struct Pmc {
     nj[1] = yj[0] * L::template subbcast<1>(jt[0]) + yj[1] * L::template subbcast<1>(jt[1]) + yj[2] * L::template subbcast<1>(jt[2]);
     nj[2] = yj[0] * L::template subbcast<2>(jt[0]) + yj[1] * L::template subbcast<2>(jt[1]) + yj[2] * L::template subbcast<2>(jt[2]);
     if (!LIMIT) nj[3] = yj[0] * L::template subbcast<3>(jt[0]) + yj[1] * L::template subbcast<3>(jt[1]) + yj[2] * L::template subbcast<3>(jt[2]);
-    for (int L_ = 0; L_ < 16; L_++)
-      if (!(LIMIT && (L_ & 3) == 3)) r.nk[L_] = lm::sel(ln.is_leg(L_ >> 2), nj[L_ & 3], zero);      // the rows of the own leg also meet in the joints
-    L::template gram4<0>(gt, yg, r.nk);                          // nk[L] += sum_i yg[i] * gt_L[i]
-    L::template gram4<1>(gt, yg, r.nk);
-    L::template gram4<2>(gt, yg, r.nk);
-    if (!LIMIT) L::template gram4<3>(gt, yg, r.nk);
+    if constexpr (L::kGram16) {
+      // the base part of all 16 scalars as ONE 16 x 16 x 6 product on the matrix cores (lanes.hpp gram16); the rows of the own leg also meet in the joints
+      F d[16];
+      L::gram16(gt, yg, d);
+      const F one = ln.lane_f(1.0f);
+      const F lf[4] = {lm::sel(ln.is_leg(0), one, zero), lm::sel(ln.is_leg(1), one, zero), lm::sel(ln.is_leg(2), one, zero), lm::sel(ln.is_leg(3), one, zero)};
+      for (int L_ = 0; L_ < 16; L_++)
+        if (!(LIMIT && (L_ & 3) == 3)) r.nk[L_] = d[L_] + lf[L_ >> 2] * nj[L_ & 3];
+    } else {
+      for (int L_ = 0; L_ < 16; L_++)
+        if (!(LIMIT && (L_ & 3) == 3)) r.nk[L_] = lm::sel(ln.is_leg(L_ >> 2), nj[L_ & 3], zero);      // the rows of the own leg also meet in the joints
+      L::template gram4<0>(gt, yg, r.nk);                          // nk[L] += sum_i yg[i] * gt_L[i]
+      L::template gram4<1>(gt, yg, r.nk);
+      L::template gram4<2>(gt, yg, r.nk);
+      if (!LIMIT) L::template gram4<3>(gt, yg, r.nk);
+    }
     r.lam = zero;
     F t[4];
     permute4(ln, gt[0], gt[1], gt[2], gt[3], t);
@@ -344,11 +354,19 @@ struct Pmc {
     nj[1] = yj[0] * L::template subbcast<1>(jt_oth[0]) + yj[1] * L::template subbcast<1>(jt_oth[1]) + yj[2] * L::template subbcast<1>(jt_oth[2]);
     nj[2] = yj[0] * L::template subbcast<2>(jt_oth[0]) + yj[1] * L::template subbcast<2>(jt_oth[1]) + yj[2] * L::template subbcast<2>(jt_oth[2]);
     nj[3] = yj[0] * L::template subbcast<3>(jt_oth[0]) + yj[1] * L::template subbcast<3>(jt_oth[1]) + yj[2] * L::template subbcast<3>(jt_oth[2]);
-    for (int L_ = 0; L_ < 16; L_++) out[L_] = lm::sel(ln.is_leg(L_ >> 2), nj[L_ & 3], zero);
-    L::template gram4<0>(gt_oth, yg, out);
-    L::template gram4<1>(gt_oth, yg, out);
-    L::template gram4<2>(gt_oth, yg, out);
-    L::template gram4<3>(gt_oth, yg, out);
+    if constexpr (L::kGram16) {
+      F d[16];
+      L::gram16(gt_oth, yg, d);
+      const F one = ln.lane_f(1.0f);
+      const F lf[4] = {lm::sel(ln.is_leg(0), one, zero), lm::sel(ln.is_leg(1), one, zero), lm::sel(ln.is_leg(2), one, zero), lm::sel(ln.is_leg(3), one, zero)};
+      for (int L_ = 0; L_ < 16; L_++) out[L_] = d[L_] + lf[L_ >> 2] * nj[L_ & 3];
+    } else {
+      for (int L_ = 0; L_ < 16; L_++) out[L_] = lm::sel(ln.is_leg(L_ >> 2), nj[L_ & 3], zero);
+      L::template gram4<0>(gt_oth, yg, out);
+      L::template gram4<1>(gt_oth, yg, out);
+      L::template gram4<2>(gt_oth, yg, out);
+      L::template gram4<3>(gt_oth, yg, out);
+    }
   }
   // One cone-coupled round over the 16 friction pairs, turns slot-major like every round.  The state of a pair during the round is
   // S = lambda + pending increment (lambda itself only moves at the commit): lanes.hpp cone_turns4 has the turn.
@@ -1075,7 +1093,10 @@ struct Pmc {
       fwd6(Sb, Sd, lgt);
       F nn = ljt[0] * ljt[0] + ljt[1] * ljt[1] + ljt[2] * ljt[2];
       for (int i = 0; i < 6; i++) nn = nn + lgt[i] * lgt[i];
-      rl.c = sg * qsj + lm::sel(d > 0.0f, d * inv_dt, d * lm::sel(d > P.erp_deep_below, ln.lane_f(P.limit_erp * inv_dt), ln.lane_f(P.limit_erp_deep * inv_dt)));
+      // (the second ERP -- Bullet: none beyond 0.04 rad -- under a wave-uniform test of its own: nothing of it is live in the common path of the builds that are short of registers)
+      F lerp = ln.lane_f(P.limit_erp * inv_dt);
+      if (P.limit_erp_deep != P.limit_erp) lerp = lm::sel(d > P.erp_deep_below, lerp, ln.lane_f(P.limit_erp_deep * inv_dt));
+      rl.c = sg * qsj + lm::sel(d > 0.0f, d * inv_dt, d * lerp);
       // which rows enter the solve.  limit_speculative (rounds 1 - 4): every row that can act within the substep (free approach speed below the gate);
       // otherwise Bullet's rule (btMultiBodyJointLimitConstraint): only a joint that is past its limit has a row -- rare, so most substeps
       // of most waves skip the limit section altogether (any_l below)
@@ -1167,8 +1188,9 @@ struct Pmc {
         }
       }
       F depth_c = my_depth;
-      F bias = lm::sel(depth_c > 0.0f, depth_c * inv_dt,
-                       lm::max_(depth_c * lm::sel(depth_c > P.erp_deep_below, ln.lane_f(P.erp * inv_dt), ln.lane_f(P.erp_deep * inv_dt)), ln.lane_f(-P.max_depen)));
+      F cerp = ln.lane_f(P.erp * inv_dt);
+      if (P.erp_deep != P.erp) cerp = lm::sel(depth_c > P.erp_deep_below, cerp, ln.lane_f(P.erp_deep * inv_dt));       // (LLM_SPEC_ERP_DEEP: not the spec; wave-uniform, see the limit rows)
+      F bias = lm::sel(depth_c > 0.0f, depth_c * inv_dt, lm::max_(depth_c * cerp, ln.lane_f(-P.max_depen)));
       // joint j moves the point iff the point's link is at or below joint j: link >= j+1
       F on1 = lm::sel(link > 0.5f, one, zero), on2 = lm::sel(link > 1.5f, one, zero), on3 = lm::sel(link > 2.5f, one, zero);
       V3l rr1 = Pb - k.p1, rr2 = Pb - k.p2, rr3 = Pb - k.p3;

@@ -167,6 +167,13 @@ struct HostLanes {
   template <int L_> static void fmac_rbcast(F& acc, const F& x, const F& k) { for (int i = 0; i < EW; i++) acc.v[i] = acc.v[i] + x.v[L_] * k.v[i]; }
   template <int L_> static void fmac_rbcast_settled(F& acc, const F& x, const F& k) { fmac_rbcast<L_>(acc, x, k); }
   static F settle(const F& x) { return x; }
+  static constexpr bool kGram16 = true;
+  static void gram16(const F* x, const F* y, F* g) {     // lanes.hpp GpuLanes::gram16: g[L] = sum_i y[i] * (x[i] of lane L), in the order the MFMA chain accumulates (i = 0 .. 5)
+    for (int L_ = 0; L_ < EW; L_++) {
+      for (int l = 0; l < EW; l++) g[L_].v[l] = 0.0f;
+      for (int i = 0; i < 6; i++) for (int l = 0; l < EW; l++) g[L_].v[l] = g[L_].v[l] + x[i].v[L_] * y[i].v[l];
+    }
+  }
   template <int S_> static void gram4(const F* x, const F* y, F* g) {
     for (int t = 0; t < 4; t++) {
       const int L_ = 4 * t + S_;

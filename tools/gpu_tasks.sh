@@ -94,6 +94,13 @@ case $TARGET in
     cp gpurun_out/two_rank/p2p_no_cu.txt $OUT/ 2>/dev/null ;;
   chunk7)        # the seven-ray SEPMC build against the host build of the same source, with where the differences sit
     timeout 600 python tools/diag_sepmc_chunk7.py > $OUT/chunk7.txt 2>&1; grep -o "^[a-z (]*chunk[^{]*\|'detail': {.*" $OUT/chunk7.txt | cut -c1-1500 ;;
+  mfma)          # A/B on one box: the Gram blocks on the matrix cores (the in-tree library) against the DPP form (tools/_build/ab_nomfma.so, -DLL_MFMA_GRAM=0); SEPMC larger-batch knobs; then parity
+    for r in 1 2 3; do for v in "" tools/_build/ab_nomfma.so; do echo "== ${v:-in-tree (MFMA Gram)} (round $r)"
+      LL_LIB=$v python tools/sweep.py "4096:4:10:10:32,4096:4:10:10:1,8192:4:10:10:32,65536:4:10:10:1"; LL_LIB=$v python tools/sweep_epmc.py "4096:1:32,65536:1:1"; LL_LIB=$v python tools/sweep_sepmc.py "2048:0:32,32768:0:1"; done; done > $OUT/mfma_ab.txt 2>&1
+    cat $OUT/mfma_ab.txt
+    for r in 1 2; do for v in conelds noreload; do echo "== $v (round $r)"; LL_LIB=tools/_build/ab_$v.so python tools/sweep_sepmc.py "32768:0:1,2048:0:32"; done; done > $OUT/sepmc2_ab.txt 2>&1
+    cat $OUT/sepmc2_ab.txt
+    gpu_tests -k "test_gpu_parity or test_gpu_epmc or test_gpu_sepmc" ;;
   final)         # the round's closing call: the whole -m gpu suite at HEAD, then the three bench lines against the committed counters
     gpu_tests
     python bench.py > $OUT/bench.log 2>$OUT/bench.err; tail -c 400 $OUT/bench.log
