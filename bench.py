@@ -388,6 +388,9 @@ def main():
             'config': {'workload': 'PMC tracking env, %d parallel envs per MI355X, flat terrain, full mocap_data clip set '
                                    '(62 clips), random-policy actions N(0, e^-2), auto-reset%s' % (n, ', RCCL trajectory gather to rank 0 every %d steps' % UNROLL if multi else ''),
                        'envs_per_gpu': n, 'substeps_per_step': 10, 'solver_iterations': 10,
+                       'physics_spec': {'link_inertias': urdf_model.default_inertia_source(), 'friction_mode': eng.get_spec('friction_mode'), 'limit_speculative': eng.get_spec('limit_speculative'),
+                                        'contact_erp': eng.get_spec('erp'), 'limit_erp': eng.get_spec('limit_erp'), 'max_depen_speed': eng.get_spec('max_depen_speed'),
+                                        'max_coord_vel': eng.get_spec('max_coord_vel')},
                        'steps_per_launch': spl_timed,
                        'steps_per_launch_note': 'the timed region runs ll_step_random_n: up to %d control steps of the random-policy loop per kernel launch, at least three '
                                                 'launches (every step is complete: physics, mocap, obs, reward, termination, re-seed, unroll row, and the prioritized-sampling '

@@ -67,7 +67,9 @@ LL_HD bool eq_(int a, int b) { return a == b; }
 
 #define PMC_ROW 16   // lanes per environment
 #ifndef LL_MFMA_GRAM
-#define LL_MFMA_GRAM 1   // the Gram blocks of the solver's rows on the matrix cores (GpuLanes::gram16); 0: 96 v_fmac_f32_dpp per block (gram4), the A/B leg
+#define LL_MFMA_GRAM 0   // 1: the Gram blocks of the solver's rows on the matrix cores (GpuLanes::gram16) instead of 96 v_fmac_f32_dpp per block (gram4).  Built and measured in round 5
+                         // (profiles/r05_mfma_gram_ab.txt, one box): 344 fewer instructions per substep, and 0.1921 -> 0.1912 ms per control step at 4096 envs (0.5 %), EPMC 0.9 %, SEPMC 1.6 % SLOWER,
+                         // the 256-register builds 8 - 10 % slower (the 16-register accumulator tuple costs them scratch; a lone wave does not hide the MFMA chain): off.  Kept as an experiment
 #endif
 #define CONE_LDS_AT 64        // row-scratch word where a row's cone cross scalars live during the substeps (16 lanes x 32 words; GpuLanes::cone_store)
 #define PMC_ROW_SCRATCH 688   // floats of LDS scratch per env row (EPMC: 40 boxes x 8, three ray lists of 10, 16 and 12 records, 64 spare: epmc_step.hpp)
@@ -325,7 +327,9 @@ struct GpuLanes {
   // x_i[k]), B = y (lane j holds y_j[k]), six of them chained over the six base coefficients.  D_b[i][j] lands in lane 16 (i / 4) + j, register 4 b + i % 4:
   // lane j of row group g holds ITS OWN entries g_{b,j}[4 g .. 4 g + 3], only in the wrong row group -- a 4 x 4 block transpose between register block and row
   // group (8 v_permlane32_swap + 8 v_permlane16_swap, gfx950) brings them home, register index = column index.  6 MFMA + 16 swaps instead of 96 half-rate
-  // v_fmac_f32_dpp (gram4 x 4); exact float32 (tools/mfma_gram_probe.hip: bit-identical to the shuffle statement on MI355X).  MFMA ignores EXEC: callers are wave-uniform.
+  // v_fmac_f32_dpp (gram4 x 4); exact float32 (tools/mfma_gram_probe.hip: bit-identical to the shuffle statement on MI355X).  MFMA ignores EXEC; the swaps fetch from lanes outside
+  // EXEC too (fi = 1: a wave whose last rows hold no env still owns the registers the matrix core wrote there -- with fi = 0 the first version read zeros and failed every test with a
+  // partial wave).  EXPERIMENT, off by default (LL_MFMA_GRAM above): the fi = 1 form has not been through the GPU suite.
   static constexpr bool kGram16 = LL_MFMA_GRAM != 0;
   typedef float ll_f16v __attribute__((ext_vector_type(16)));
   static LL_D void gram16(const F* x, const F* y, F* g) {
@@ -335,12 +339,12 @@ struct GpuLanes {
     unsigned R[16];
     for (int i = 0; i < 16; i++) R[i] = __float_as_uint(acc[i]);
     for (int r = 0; r < 4; r++) {
-      const auto a = __builtin_amdgcn_permlane32_swap(R[r], R[8 + r], false, false); R[r] = a[0]; R[8 + r] = a[1];
-      const auto b = __builtin_amdgcn_permlane32_swap(R[4 + r], R[12 + r], false, false); R[4 + r] = b[0]; R[12 + r] = b[1];
+      const auto a = __builtin_amdgcn_permlane32_swap(R[r], R[8 + r], true, false); R[r] = a[0]; R[8 + r] = a[1];
+      const auto b = __builtin_amdgcn_permlane32_swap(R[4 + r], R[12 + r], true, false); R[4 + r] = b[0]; R[12 + r] = b[1];
     }
     for (int r = 0; r < 4; r++) {
-      const auto a = __builtin_amdgcn_permlane16_swap(R[r], R[4 + r], false, false); R[r] = a[0]; R[4 + r] = a[1];
-      const auto b = __builtin_amdgcn_permlane16_swap(R[8 + r], R[12 + r], false, false); R[8 + r] = b[0]; R[12 + r] = b[1];
+      const auto a = __builtin_amdgcn_permlane16_swap(R[r], R[4 + r], true, false); R[r] = a[0]; R[4 + r] = a[1];
+      const auto b = __builtin_amdgcn_permlane16_swap(R[8 + r], R[12 + r], true, false); R[8 + r] = b[0]; R[12 + r] = b[1];
     }
     for (int i = 0; i < 16; i++) g[i] = __uint_as_float(R[i]);
   }

@@ -45,8 +45,8 @@ typedef GpuLanesPinned<LC_COUNT> GpuLanes1;                   // the per-leg tab
 #define LL_CONE_LDS 1   // the larger-batch PMC / EPMC builds keep the cone round's cross scalars in the row's LDS scratch (lanes.hpp WithConeInLds):
 #endif                  // 65536 envs 2.305 -> 2.255 ms (PMC), 3.862 -> 3.724 ms (EPMC hurdles); SEPMC 5.035 -> 5.079 ms at 32768 arenas: not there (profiles/r04_cone_lds_ab.txt)
 #ifndef LL_CONE_LDS_SEPMC
-#define LL_CONE_LDS_SEPMC 0
-#endif
+#define LL_CONE_LDS_SEPMC 1   // ... and since round 5 the larger-batch SEPMC build too: 32768 arenas 6.57 -> 5.13 ms per step on one box (profiles/r05_sepmc_large_batch_ab.txt).  Round 4 had measured
+#endif                        // it useless there (5.035 -> 5.079); the round-5 source landed on a worse register allocation (5.04 -> 6.96 ms with 400 more scratch instructions) and this buys it back
 #ifndef LL_CONE_LDS_SEPMC1
 #define LL_CONE_LDS_SEPMC1 1   // the one-wave-per-SIMD SEPMC builds too: they are the ones that do not fit 512 registers (scratch 364 -> 184 B multi-step, 184 -> 0 single; 0.324 -> 0.318 ms)
 #endif

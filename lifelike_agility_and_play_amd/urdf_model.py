@@ -322,11 +322,19 @@ def model_blob(inertia='collision_aabb'):
     ``loadURDF`` flags make Bullet build them) or ``assets/max_model_file_inertia.npy`` (the URDF's ``<inertia>``
     tensors: the ``URDF_USE_INERTIA_FROM_FILE`` robot, shipped through round 3; kept as the A/B leg)."""
     import os
-    name = {'collision_aabb': 'max_model.npy', 'file': 'max_model_file_inertia.npy'}[inertia]
+    names = {'collision_aabb': 'max_model.npy', 'file': 'max_model_file_inertia.npy'}
+    if inertia not in names:
+        raise ValueError("inertia source %r: one of %s (LL_MODEL_INERTIA selects it for default_model_blob())" % (inertia, sorted(names)))
+    name = names[inertia]
     return np.load(os.path.join(os.path.dirname(__file__), 'assets', name))
 
 
 def default_model_blob():
     """The model every env uses unless told otherwise.  ``LL_MODEL_INERTIA=file`` selects the A/B leg."""
+    return model_blob(default_inertia_source())
+
+
+def default_inertia_source():
+    """'collision_aabb' (the default) or 'file', as LL_MODEL_INERTIA says -- recorded in the bench line and the rollout tools so that A/B legs cannot be mixed up"""
     import os
-    return model_blob(os.environ.get('LL_MODEL_INERTIA', 'collision_aabb'))
+    return os.environ.get('LL_MODEL_INERTIA', 'collision_aabb')

@@ -4,6 +4,12 @@ import sys
 import numpy as np
 import pytest
 
+if os.environ.get('LL_TEST_LIB'):
+    # run the suite against ANOTHER build of the HIP library (an A/B leg under tools/_build/, e.g. -DLL_MFMA_GRAM=1): test infrastructure only
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from lifelike_agility_and_play_amd import capi as _capi
+    _capi.DEFAULT_LIB = os.path.abspath(os.environ['LL_TEST_LIB'])
+
 try:                # torch bundles its own copy of the HIP runtime under the same SONAME as the system one libllenv.so links: whichever is
     import torch    # noqa: F401  loaded first serves the process.  Load torch's first, the order bench.py has (and every full-suite run had)
 except ImportError:

@@ -167,7 +167,7 @@ struct HostLanes {
   template <int L_> static void fmac_rbcast(F& acc, const F& x, const F& k) { for (int i = 0; i < EW; i++) acc.v[i] = acc.v[i] + x.v[L_] * k.v[i]; }
   template <int L_> static void fmac_rbcast_settled(F& acc, const F& x, const F& k) { fmac_rbcast<L_>(acc, x, k); }
   static F settle(const F& x) { return x; }
-  static constexpr bool kGram16 = true;
+  static constexpr bool kGram16 = false;       // (as the shipped GPU build: lanes.hpp LL_MFMA_GRAM)
   static void gram16(const F* x, const F* y, F* g) {     // lanes.hpp GpuLanes::gram16: g[L] = sum_i y[i] * (x[i] of lane L), in the order the MFMA chain accumulates (i = 0 .. 5)
     for (int L_ = 0; L_ < EW; L_++) {
       for (int l = 0; l < EW; l++) g[L_].v[l] = 0.0f;

@@ -101,6 +101,10 @@ case $TARGET in
     for r in 1 2; do for v in conelds noreload; do echo "== $v (round $r)"; LL_LIB=tools/_build/ab_$v.so python tools/sweep_sepmc.py "32768:0:1,2048:0:32"; done; done > $OUT/sepmc2_ab.txt 2>&1
     cat $OUT/sepmc2_ab.txt
     gpu_tests -k "test_gpu_parity or test_gpu_epmc or test_gpu_sepmc" ;;
+  r05g)          # the whole suite at HEAD (MFMA Gram off, cone scalars in LDS for the larger-batch SEPMC build), the MFMA experiment (fi = 1) through the parity tests, large-batch sweeps
+    gpu_tests
+    LL_TEST_LIB=tools/_build/ab_mfma.so timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_sepmc.py tests/test_gpu_epmc.py -m gpu -q -k "single_control_step or multi_step or partial_wave or auto_reset or pair_physics or robot_robot or terrain_physics" > $OUT/pytest_mfma.log 2>&1; echo "MFMA-Gram library through the parity tests: rc $?"; tail -3 $OUT/pytest_mfma.log
+    python tools/sweep.py "4096:4:10:10:32,65536:4:10:10:1" > $OUT/sweeps.txt 2>&1; python tools/sweep_epmc.py "4096:1:32,65536:1:1" >> $OUT/sweeps.txt 2>&1; python tools/sweep_sepmc.py "2048:0:32,32768:0:1" >> $OUT/sweeps.txt 2>&1; cat $OUT/sweeps.txt ;;
   final)         # the round's closing call: the whole -m gpu suite at HEAD, then the three bench lines against the committed counters
     gpu_tests
     python bench.py > $OUT/bench.log 2>$OUT/bench.err; tail -c 400 $OUT/bench.log
