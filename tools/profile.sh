@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 python bench.py > $OUT/bench.log 2>$OUT/bench.err          # exactly what the driver runs at N = 1
 B="python bench.py --gpus 1 --steps 320 --warmup 32 --no-cpu-baseline --no-single-step-leg"     # (multiples of the 32 control steps a launch runs)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > $OUT/bench_under_rocprof.log 2>&1
-S="python bench.py --gpus 1 --steps 64 --warmup 32 --no-cpu-baseline --no-single-step-leg"
+S="python bench.py --gpus 1 --steps 96 --warmup 32 --no-cpu-baseline --no-single-step-leg"     # (three launches of 32 control steps: bench.py never times fewer than three)
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq -- $S > /dev/null 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -- $S > /dev/null 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -- $S > /dev/null 2>&1
