@@ -526,6 +526,7 @@ def main_epmc(args):
                          'traffic_source': tsrc, 'traffic_note': 'counter traffic of a multi-step launch UNDER-counts HBM bytes: the rows a wave writes in one step of the launch and overwrites in the next (observation, state, bookkeeping) meet in its L2 / the Infinity Cache and need not reach HBM, so FETCH_SIZE + WRITE_SIZE can come out below the algorithmic bytes (0.8 - 0.9 x); single launches per step measure 1.1 - 1.5 x', 'single_wave_issue': issue,
                          'kernel': 'epmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n, 'kernel_avg_launch_ms': k_launch_ms,
                          'algorithmic_bytes_per_env_step': EPMC_ALGO_BYTES_PER_ENV_STEP,
+                         'algorithmic_bytes_per_launch': n * EPMC_ALGO_BYTES_PER_ENV_STEP * (k_launch_ms / k_ms if k_ms > 0 else spl),       # x the control steps a timed launch ran
                          'note': 'bound by single-wave instruction issue, not HBM; see DESIGN.md 8'}}}), flush=True)
     eng.close()
     if world > 1:
@@ -610,6 +611,7 @@ def main_sepmc(args):
                          'traffic_source': tsrc, 'traffic_note': 'counter traffic of a multi-step launch UNDER-counts HBM bytes: the rows a wave writes in one step of the launch and overwrites in the next (observation, state, bookkeeping) meet in its L2 / the Infinity Cache and need not reach HBM, so FETCH_SIZE + WRITE_SIZE can come out below the algorithmic bytes (0.8 - 0.9 x); single launches per step measure 1.1 - 1.5 x', 'single_wave_issue': issue,
                          'kernel': 'sepmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n, 'kernel_avg_launch_ms': k_launch_ms,
                          'algorithmic_bytes_per_robot_step': SEPMC_ALGO_BYTES_PER_ROBOT_STEP,
+                         'algorithmic_bytes_per_launch': 2 * n_arenas * SEPMC_ALGO_BYTES_PER_ROBOT_STEP * (k_launch_ms / k_ms if k_ms > 0 else spl),
                          'note': 'bound by single-wave instruction issue, not HBM; see DESIGN.md 8b'}}}), flush=True)
     eng.close()
     if world > 1:

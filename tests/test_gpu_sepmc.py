@@ -161,8 +161,8 @@ def test_both_register_budgets_compute_the_same_gpu():
     out = (c >= 1e-4) | (v >= 1e-3)
     print('register budgets, %d row-steps: median config difference %.2e, outside the oracle bars %d (worst config %.2e, velocity %.2e)' %
           (len(c), np.median(c), out.sum(), c.max(), v.max()))
-    # (round 4, AABB link inertias: 9 of 1920 outside, worst 6.4e-3 / 1.39 -- a 170 g shank at its joint limit takes or leaves the limit row at
-    # LLM_LIMIT_GATE = 20 rad/s: the one decision in the spec that can move a joint rate by tens of rad/s)
-    # (cone friction, the default since: 4 of 1920 outside, worst 1.56e-2 / 0.66)
-    assert out.sum() <= 5 and c.max() < 2e-2 and v.max() < 1.0, (out.sum(), c.max(), v.max())          # (observed + 1; worst: observed x 1.3 - 1.5)
+    # (round 4: 4 - 9 of 1920 outside, worst 1.56e-2 / 0.66 - 1.39 -- a 170 g shank at its joint limit took or left its speculative limit row at LLM_LIMIT_GATE = 20 rad/s, the one
+    # decision in that spec that could move a joint rate by tens of rad/s.  Round 5, Bullet's limit rule (no speculative row, no gate): 2 of 1920 outside, worst 1.2e-4 / 6.0e-3 on MI355X:
+    # what is left are deepest-contact decisions of lying robots; the bars are back within an order of magnitude of the standing ones)
+    assert out.sum() <= 4 and c.max() < 1e-3 and v.max() < 3e-2, (out.sum(), c.max(), v.max())
     A.close(); B.close()
