@@ -105,6 +105,12 @@ case $TARGET in
     gpu_tests
     LL_TEST_LIB=tools/_build/ab_mfma.so timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_sepmc.py tests/test_gpu_epmc.py -m gpu -q -k "single_control_step or multi_step or partial_wave or auto_reset or pair_physics or robot_robot or terrain_physics" > $OUT/pytest_mfma.log 2>&1; echo "MFMA-Gram library through the parity tests: rc $?"; tail -3 $OUT/pytest_mfma.log
     python tools/sweep.py "4096:4:10:10:32,65536:4:10:10:1" > $OUT/sweeps.txt 2>&1; python tools/sweep_epmc.py "4096:1:32,65536:1:1" >> $OUT/sweeps.txt 2>&1; python tools/sweep_sepmc.py "2048:0:32,32768:0:1" >> $OUT/sweeps.txt 2>&1; cat $OUT/sweeps.txt ;;
+  r05h)          # the bars policy's fall histogram; driver-style lines with and without the triad in front; the EPMC / SEPMC bench lines with their CPU legs
+    python tools/hole_fall_histogram.py 1024 600 > $OUT/hole_fall_histogram.txt 2>/dev/null; cat $OUT/hole_fall_histogram.txt
+    for i in 1 2 3; do LL_BENCH_TRIAD_FIRST=0 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tee -a $OUT/driver_style_raw.txt | show "driver-style, no triad first"; done > $OUT/driver_style.txt
+    for i in 1 2 3; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tee -a $OUT/driver_style_raw.txt | show "driver-style (triad first)  "; done >> $OUT/driver_style.txt
+    python bench.py --gpus 1 --steps 2048 --warmup 256 --no-cpu-baseline 2>/dev/null | show "2048 steps                  " >> $OUT/driver_style.txt; cat $OUT/driver_style.txt
+    python bench.py --workload epmc > $OUT/epmc_bench.log 2>/dev/null; python bench.py --workload sepmc > $OUT/sepmc_bench.log 2>/dev/null; tail -c 300 $OUT/sepmc_bench.log ;;
   final)         # the round's closing call: the whole -m gpu suite at HEAD, then the three bench lines against the committed counters
     gpu_tests
     python bench.py > $OUT/bench.log 2>$OUT/bench.err; tail -c 400 $OUT/bench.log
