@@ -66,6 +66,9 @@ LL_HD bool eq_(int a, int b) { return a == b; }
 }  // namespace lm
 
 #define PMC_ROW 16   // lanes per environment
+#ifndef LL_CONE_PIPE
+#define LL_CONE_PIPE 1   // cone turns: a turn's second select rides in the next turn's v_rsq wait state (GpuLanes::cone_turns4); 0: the round-4 turn, the A/B leg
+#endif
 #ifndef LL_MFMA_GRAM
 #define LL_MFMA_GRAM 0   // 1: the Gram blocks of the solver's rows on the matrix cores (GpuLanes::gram16) instead of 96 v_fmac_f32_dpp per block (gram4).  Built and measured in round 5
                          // (profiles/r05_mfma_gram_ab.txt, one box): 344 fewer instructions per substep, and 0.1921 -> 0.1912 ms per control step at 4096 envs (0.5 %), EPMC 0.9 %, SEPMC 1.6 % SLOWER,
@@ -419,6 +422,45 @@ struct GpuLanes {
     "v_fmac_f32_dpp %1, %5, " K21 LL_D1(L_)                                                      \
     "v_fmac_f32_dpp %0, %6, " K12 LL_D1(L_)                                                      \
     "v_fmac_f32_dpp %1, %6, " K22 LL_D1(L_)
+#if LL_CONE_PIPE
+    // (round 5) inside a block the second select of a turn (d2 <- e2 under the turn's mask) waits in the NEXT turn's wait state behind v_rsq instead of an s_nop: e2 is not
+    // rewritten before that turn's second v_fma, the select of d2 is read by nobody inside the block.  3 issue slots less per block of four turns.
+#define LL_CF(K11, K12, K21, K22, M, L_)      /* first turn of a block: its own d2 select is left to the next turn */                          \
+    "v_mul_f32_e32 %4, %1, %1\n\t"                                                               \
+    "v_fmac_f32_e32 %4, %0, %0\n\t"                                                              \
+    "v_rsq_f32_e32 %4, %4\n\t"                                                                   \
+    "s_nop 0\n\t"                                                                                \
+    "v_mul_legacy_f32_e64 %4, %9, %4 clamp\n\t"                                                  \
+    "v_fma_f32 %5, %0, %4, -%7\n\t"                                                              \
+    "v_fma_f32 %6, %1, %4, -%8\n\t"                                                              \
+    "v_cndmask_b32_e64 %2, %2, %5, " M "\n\t"                                                    \
+    "v_fmac_f32_dpp %0, %5, " K11 LL_D1(L_)                                                      \
+    "v_fmac_f32_dpp %1, %5, " K21 LL_D1(L_)                                                      \
+    "v_fmac_f32_dpp %0, %6, " K12 LL_D1(L_)                                                      \
+    "v_fmac_f32_dpp %1, %6, " K22 LL_D1(L_)
+#define LL_CN(K11, K12, K21, K22, M, MP, L_)  /* later turns: the previous turn's d2 select (mask MP) in the wait state */                   \
+    "v_mul_f32_e32 %4, %1, %1\n\t"                                                               \
+    "v_fmac_f32_e32 %4, %0, %0\n\t"                                                              \
+    "v_rsq_f32_e32 %4, %4\n\t"                                                                   \
+    "v_cndmask_b32_e64 %3, %3, %6, " MP "\n\t"                                                   \
+    "v_mul_legacy_f32_e64 %4, %9, %4 clamp\n\t"                                                  \
+    "v_fma_f32 %5, %0, %4, -%7\n\t"                                                              \
+    "v_fma_f32 %6, %1, %4, -%8\n\t"                                                              \
+    "v_cndmask_b32_e64 %2, %2, %5, " M "\n\t"                                                    \
+    "v_fmac_f32_dpp %0, %5, " K11 LL_D1(L_)                                                      \
+    "v_fmac_f32_dpp %1, %5, " K21 LL_D1(L_)                                                      \
+    "v_fmac_f32_dpp %0, %6, " K12 LL_D1(L_)                                                      \
+    "v_fmac_f32_dpp %1, %6, " K22 LL_D1(L_)
+#define LL_C4(L0, L1, L2, L3)                                                                                                            \
+    asm(LL_CF("%10", "%14", "%18", "%22", "%26", L0) LL_CN("%11", "%15", "%19", "%23", "%27", "%26", L1)                                 \
+        LL_CN("%12", "%16", "%20", "%24", "%28", "%27", L2) LL_CN("%13", "%17", "%21", "%25", "%29", "%28", L3)                          \
+        "v_cndmask_b32_e64 %3, %3, %6, %29\n\t"                                                                                        \
+        : "+v"(S1), "+v"(S2), "+v"(d1), "+v"(d2), "=&v"(t), "=&v"(e1), "=&v"(e2)                                                         \
+        : "v"(lam1), "v"(lam2), "v"(lim),                                                                                                \
+          "v"(k11[S_]), "v"(k11[4 + S_]), "v"(k11[8 + S_]), "v"(k11[12 + S_]), "v"(k12[S_]), "v"(k12[4 + S_]), "v"(k12[8 + S_]), "v"(k12[12 + S_]), \
+          "v"(k21[S_]), "v"(k21[4 + S_]), "v"(k21[8 + S_]), "v"(k21[12 + S_]), "v"(k22[S_]), "v"(k22[4 + S_]), "v"(k22[8 + S_]), "v"(k22[12 + S_]), \
+          "s"(m0), "s"(m1), "s"(m2), "s"(m3))
+#else
 #define LL_C4(L0, L1, L2, L3)                                                                                                            \
     asm(LL_C1("%10", "%14", "%18", "%22", "%26", L0) LL_C1("%11", "%15", "%19", "%23", "%27", L1)                                        \
         LL_C1("%12", "%16", "%20", "%24", "%28", L2) LL_C1("%13", "%17", "%21", "%25", "%29", L3)                                        \
@@ -427,6 +469,7 @@ struct GpuLanes {
           "v"(k11[S_]), "v"(k11[4 + S_]), "v"(k11[8 + S_]), "v"(k11[12 + S_]), "v"(k12[S_]), "v"(k12[4 + S_]), "v"(k12[8 + S_]), "v"(k12[12 + S_]), \
           "v"(k21[S_]), "v"(k21[4 + S_]), "v"(k21[8 + S_]), "v"(k21[12 + S_]), "v"(k22[S_]), "v"(k22[4 + S_]), "v"(k22[8 + S_]), "v"(k22[12 + S_]), \
           "s"(m0), "s"(m1), "s"(m2), "s"(m3))
+#endif
     if (S_ == 0) LL_C4("0", "4", "8", "12");
     else if (S_ == 1) LL_C4("1", "5", "9", "13");
     else if (S_ == 2) LL_C4("2", "6", "10", "14");
@@ -434,6 +477,8 @@ struct GpuLanes {
 #undef LL_C4
 #undef LL_C1
 #undef LL_D1
+#undef LL_CF
+#undef LL_CN
   }
 
   // ---- the solver's velocity state, scattered over the sub-lanes (pmc_step.hpp gs_round) ------------------------------------------

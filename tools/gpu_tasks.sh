@@ -111,6 +111,11 @@ case $TARGET in
     for i in 1 2 3; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tee -a $OUT/driver_style_raw.txt | show "driver-style (triad first)  "; done >> $OUT/driver_style.txt
     python bench.py --gpus 1 --steps 2048 --warmup 256 --no-cpu-baseline 2>/dev/null | show "2048 steps                  " >> $OUT/driver_style.txt; cat $OUT/driver_style.txt
     python bench.py --workload epmc > $OUT/epmc_bench.log 2>/dev/null; python bench.py --workload sepmc > $OUT/sepmc_bench.log 2>/dev/null; tail -c 300 $OUT/sepmc_bench.log ;;
+  pipe)          # A/B on one box: cone turns with the second select in the next turn's wait state (in-tree) against the round-4 turn (tools/_build/ab_nopipe.so); then parity
+    for r in 1 2 3; do for v in "" tools/_build/ab_nopipe.so; do echo "== ${v:-in-tree (pipelined cone turns)} (round $r)"
+      LL_LIB=$v python tools/sweep.py "4096:4:10:10:32,4096:4:10:10:1,65536:4:10:10:1"; LL_LIB=$v python tools/sweep_epmc.py "4096:1:32,65536:1:1"; LL_LIB=$v python tools/sweep_sepmc.py "2048:0:32,32768:0:1"; done; done > $OUT/cone_pipe_ab.txt 2>&1
+    cat $OUT/cone_pipe_ab.txt
+    gpu_tests -k "test_gpu_parity or pair_physics or terrain_physics or multi_step" ;;
   final)         # the round's closing call: the whole -m gpu suite at HEAD, then the three bench lines against the committed counters
     gpu_tests
     python bench.py > $OUT/bench.log 2>$OUT/bench.err; tail -c 400 $OUT/bench.log
