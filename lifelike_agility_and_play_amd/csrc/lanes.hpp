@@ -69,9 +69,6 @@ LL_HD bool eq_(int a, int b) { return a == b; }
 #ifndef LL_CONE_PIPE
 #define LL_CONE_PIPE 1   // cone turns: a turn's second select rides in the next turn's v_rsq wait state (GpuLanes::cone_turns4); 0: the round-4 turn, the A/B leg
 #endif
-#ifndef LL_UNI_MAX
-#define LL_UNI_MAX 1     // unilateral Gauss-Seidel turns clamp with v_max_f32 (full rate) instead of v_med3_f32 against a constant 3e38 (half rate); 0: the A/B leg
-#endif
 #ifndef LL_MFMA_GRAM
 #define LL_MFMA_GRAM 0   // 1: the Gram blocks of the solver's rows on the matrix cores (GpuLanes::gram16) instead of 96 v_fmac_f32_dpp per block (gram4).  Built and measured in round 5
                          // (profiles/r05_mfma_gram_ab.txt, one box): 344 fewer instructions per substep, and 0.1921 -> 0.1912 ms per control step at 4096 envs (0.5 %), EPMC 0.9 %, SEPMC 1.6 % SLOWER,
@@ -362,30 +359,16 @@ struct GpuLanes {
     const unsigned long long m0 = tm_[S_], m1 = tm_[4 + S_], m2 = tm_[8 + S_], m3 = tm_[12 + S_];
     float d;
     if (NEG_LO) lo = -lo;
-    // (round 5) a UNILATERAL round's upper bound is the constant 3e38: its clamp is a plain maximum -- v_max_f32 is a full-rate instruction, v_med3_f32 half-rate
 #define LL_T1(K, M, L_)                                                                          \
-    LL_CLAMP_T4                                                                                \
+    "v_med3_f32 %2, %0, %3, %4\n\t"                                                            \
     "v_cndmask_b32_e64 %1, %1, %2, " M "\n\t"                                                  \
     "s_nop 0\n\t"                                                                              \
     "v_fmac_f32_dpp %0, %2, " K " row_newbcast:" L_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-#define LL_CLAMP_T4 "v_med3_f32 %2, %0, %3, %4\n\t"
-    if (NEG_LO && LL_UNI_MAX) {
-#undef LL_CLAMP_T4
-#define LL_CLAMP_T4 "v_max_f32_e32 %2, %0, %3\n\t"
-      if (S_ == 0)      asm(LL_T1("%5", "%9", "0") LL_T1("%6", "%10", "4") LL_T1("%7", "%11", "8") LL_T1("%8", "%12", "12") : "+v"(u), "+v"(dl), "=&v"(d) : "v"(lo), "v"(hi), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
-      else if (S_ == 1) asm(LL_T1("%5", "%9", "1") LL_T1("%6", "%10", "5") LL_T1("%7", "%11", "9") LL_T1("%8", "%12", "13") : "+v"(u), "+v"(dl), "=&v"(d) : "v"(lo), "v"(hi), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
-      else if (S_ == 2) asm(LL_T1("%5", "%9", "2") LL_T1("%6", "%10", "6") LL_T1("%7", "%11", "10") LL_T1("%8", "%12", "14") : "+v"(u), "+v"(dl), "=&v"(d) : "v"(lo), "v"(hi), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
-      else              asm(LL_T1("%5", "%9", "3") LL_T1("%6", "%10", "7") LL_T1("%7", "%11", "11") LL_T1("%8", "%12", "15") : "+v"(u), "+v"(dl), "=&v"(d) : "v"(lo), "v"(hi), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
-      return;
-    }
-#undef LL_CLAMP_T4
-#define LL_CLAMP_T4 "v_med3_f32 %2, %0, %3, %4\n\t"
     if (S_ == 0)      asm(LL_T1("%5", "%9", "0") LL_T1("%6", "%10", "4") LL_T1("%7", "%11", "8") LL_T1("%8", "%12", "12") : "+v"(u), "+v"(dl), "=&v"(d) : "v"(lo), "v"(hi), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
     else if (S_ == 1) asm(LL_T1("%5", "%9", "1") LL_T1("%6", "%10", "5") LL_T1("%7", "%11", "9") LL_T1("%8", "%12", "13") : "+v"(u), "+v"(dl), "=&v"(d) : "v"(lo), "v"(hi), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
     else if (S_ == 2) asm(LL_T1("%5", "%9", "2") LL_T1("%6", "%10", "6") LL_T1("%7", "%11", "10") LL_T1("%8", "%12", "14") : "+v"(u), "+v"(dl), "=&v"(d) : "v"(lo), "v"(hi), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
     else              asm(LL_T1("%5", "%9", "3") LL_T1("%6", "%10", "7") LL_T1("%7", "%11", "11") LL_T1("%8", "%12", "15") : "+v"(u), "+v"(dl), "=&v"(d) : "v"(lo), "v"(hi), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
 #undef LL_T1
-#undef LL_CLAMP_T4
   }
   // Eight Gauss-Seidel turns as ONE block (H_ = 0: lanes 0,4,8,12, 1,5,9,13;  H_ = 1: lanes 2,6,10,14, 3,7,11,15): between two
   // separate asm statements the compiler puts a wait state of its own.
@@ -405,17 +388,7 @@ struct GpuLanes {
           : "+v"(u), "+v"(dl), "=&v"(d)                                                                                                  \
           : "v"(lo), "v"(hi), "v"(nk[A]), "v"(nk[4 + A]), "v"(nk[8 + A]), "v"(nk[12 + A]), "v"(nk[B]), "v"(nk[4 + B]), "v"(nk[8 + B]), "v"(nk[12 + B]), \
             "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4), "s"(m5), "s"(m6), "s"(m7))
-    if (NEG_LO && LL_UNI_MAX) {              // unilateral: max(u, -lam) -- see turns4
-#undef LL_T1
-#define LL_T1(LO, K, M, L_)                                                                      \
-    "v_max_f32_e64 %2, %0, " LO "\n\t"                                                         \
-    "v_cndmask_b32_e64 %1, %1, %2, " M "\n\t"                                                  \
-    "s_nop 0\n\t"                                                                              \
-    "v_fmac_f32_dpp %0, %2, " K " row_newbcast:" L_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      if (H_ == 0) LL_T8("-%3", "0", "4", "8", "12", "1", "5", "9", "13");
-      else LL_T8("-%3", "2", "6", "10", "14", "3", "7", "11", "15");
-    }
-    else if (H_ == 0 && !NEG_LO) LL_T8("%3", "0", "4", "8", "12", "1", "5", "9", "13");
+    if (H_ == 0 && !NEG_LO) LL_T8("%3", "0", "4", "8", "12", "1", "5", "9", "13");
     else if (H_ == 0) LL_T8("-%3", "0", "4", "8", "12", "1", "5", "9", "13");
     else if (!NEG_LO) LL_T8("%3", "2", "6", "10", "14", "3", "7", "11", "15");
     else LL_T8("-%3", "2", "6", "10", "14", "3", "7", "11", "15");

@@ -146,8 +146,10 @@ __device__ __attribute__((noinline)) void table_fold_wave_out_of_line(const Step
 // workgroup.  Waiting for the wave's own atomics to be acknowledged before it takes its ticket orders them ahead of the ticket.  Folds run in step
 // order: the wave that folds step sl first waits for the mark of step sl - 1 (every wave has finished step sl - 1 by then, so its folding wave is
 // running or done).  `multi`: the launch runs several steps and re-seeds read the versions, so the fold is published with a mark.
-__device__ __forceinline__ void step_done_fold(const StepParams& P, int sl, bool last_step, bool multi, unsigned ticket) {
-  // (the ticket was taken inside the step, right after the wave published -- Pmc::take_step_ticket -- so its round trip is long over)
+__device__ __forceinline__ void step_done_fold(const StepParams& P, int sl, bool last_step, bool multi) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned int ticket = 0;
+  if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(P.block_ticket + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   ticket = __builtin_amdgcn_readfirstlane(ticket);
   if (ticket != gridDim.x - 1) return;
   if (multi && sl > 0)
@@ -214,13 +216,12 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
   if constexpr (OCC == 1) ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS, P.basec);   // all 64 lanes copy, also those without an env
   else ln.stage_consts(P.legc, LC_COUNT, P.candc, CAND_TABLE_WORDS);
   if constexpr (!MULTI) {
-    unsigned ticket = 0;                     // (thread 0 always has an env: the grid has no empty workgroup)
     if (env0 < P.n_envs) {
       float act[3];
       step_actions(P, ln, lds, env0, 0, act);
-      ticket = Pmc<Lanes>::template step_env<OBST, CONE>(ln, P, env0, act, 0);
+      Pmc<Lanes>::template step_env<OBST, CONE>(ln, P, env0, act, 0);
     }
-    step_done_fold(P, 0, true, false, ticket);
+    step_done_fold(P, 0, true, false);
   } else {
     // ll_step_random_n: n_steps control steps back to back.  A wave walks its four envs through them on its own -- no other wave is waited
     // for, so a slow step of one wave (leg-leg rows, a re-seed) is not a slow step of the whole chip -- and between two steps it only has
@@ -236,14 +237,13 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
       ln.new_step();
       int env = env0;
       asm volatile("" : "+v"(env));      // ... and no address of the step's ~150 loads and stores either (they all derive from env)
-      unsigned ticket = 0;
       if (env < P.n_envs) {
         float act[3];
         step_actions(P, ln, lds, env, sl, act);
-        ticket = Pmc<Lanes>::template step_env<OBST, CONE>(ln, P, env, act, sl);
+        Pmc<Lanes>::template step_env<OBST, CONE>(ln, P, env, act, sl);
       }
       const StepParams& Pr = kernarg_params();      // (re-read from the kernarg segment like the step itself: nothing of it is parked in spilled SGPRs across the step)
-      step_done_fold(Pr, sl, sl == Pr.n_steps - 1, true, ticket);
+      step_done_fold(Pr, sl, sl == Pr.n_steps - 1, true);
     }
   }
 }

@@ -1864,15 +1864,13 @@ struct Pmc {
   // OBST (set_obstacle builds): the jump obstacle of the episode is a static box the robot collides with during the substeps
   // sl: index of this control step inside its launch (ll_step_random_n runs n_steps of them back to back; 0 otherwise)
   template <bool OBST = false, bool CONE = false>
-  // Returns (GPU builds, thread 0 of the wave) the wave's TICKET for control step `sl`: taken as soon as the step's finished episodes are published (see
-  // take_step_ticket), so that its round trip hides behind the observation and the stores; the kernel folds the sampling table when the ticket is the last one.
-  static LL_HD unsigned step_env(const L& ln, const StepParams& P_in, int env, const F* act_in, int sl = 0) {
+  static LL_HD void step_env(const L& ln, const StepParams& P_in, int env, const F* act_in, int sl = 0) {
     const StepParams& P = ln.params(P_in);
     const int N = P.n_envs;
     Base bs;
     F q[3], qd[3], act[3], tgt[3];
     PMC_TS(0);
-    if (PMC_ABL(8)) return take_step_ticket(ln, P_in, sl);
+    if (PMC_ABL(8)) return;
     load_state(ln, P.state, N, env, bs, q, qd);
     for (int j = 0; j < 3; j++) act[j] = act_in[j];
     pd_target(ln, q, act, tgt);                                              // PLE:199-200, LR:126-127
@@ -1912,7 +1910,7 @@ struct Pmc {
       t += P.dt_d;                                                           // PLE:210
     PMC_TS(10 + (s < 20 ? s : 20));
     }
-    if (PMC_ABL(4)) { store_state(ln, P.state, N, env, bs, q, qd); P.time[env] = t; return take_step_ticket(ln, P, sl); }
+    if (PMC_ABL(4)) { store_state(ln, P.state, N, env, bs, q, qd); P.time[env] = t; return; }
     int fid = (int)floor(t_loc / P.frame_step);                              // ML:66
     {                                                                        // keep a done-but-still-stepped env inside its clip
       int fmax = clen - P.frame_rate - 3;
@@ -2075,7 +2073,6 @@ struct Pmc {
       }
     }
     PMC_TS(6);
-    const unsigned ticket = take_step_ticket(ln, P, sl);           // everything the table fold needs from this wave is out: take the step's ticket now, read it after the stores
     // --- observation (PLE:227), state, ghost, feet, bookkeeping ---
     obs_emit(ln, P, row, fill, oin, bs, R, oq, oqd, oact);
     PMC_TS(8);
@@ -2094,22 +2091,6 @@ struct Pmc {
     P.done[env] = reason ? 1 : 0;
     P.done_reason[env] = (uint8_t)reason;
     PMC_TS(7);
-    return ticket;
-  }
-
-  // "This wave has published the episodes it finished in control step sl" (llenv.hip step_done_fold counts the tickets; the last one folds the table).  The wave's own
-  // publishing atomics are acknowledged first (s_waitcnt), which orders them ahead of the ticket; the atomic's return is not waited for here.
-  static LL_HD unsigned take_step_ticket(const L& ln, const StepParams& P, int sl) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    (void)ln;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned t = 0;
-    if (threadIdx.x == 0) t = __hip_atomic_fetch_add(P.block_ticket + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return t;
-#else
-    (void)ln; (void)P; (void)sl;
-    return 0u;
-#endif
   }
 
   // The sampling table an episode that re-seeds in control step `sl` of the running launch draws from: the table as steps 0 .. sl - 1 of the launch
