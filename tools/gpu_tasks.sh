@@ -116,6 +116,11 @@ case $TARGET in
       LL_LIB=$v python tools/sweep.py "4096:4:10:10:32,4096:4:10:10:1,65536:4:10:10:1"; LL_LIB=$v python tools/sweep_epmc.py "4096:1:32,65536:1:1"; LL_LIB=$v python tools/sweep_sepmc.py "2048:0:32,32768:0:1"; done; done > $OUT/cone_pipe_ab.txt 2>&1
     cat $OUT/cone_pipe_ab.txt
     gpu_tests -k "test_gpu_parity or pair_physics or terrain_physics or multi_step" ;;
+  ab)            # A/B on one box: the in-tree library against tools/_build/ab_base.so (a previous build); then the parity tests of the changed paths
+    for r in 1 2 3; do for v in "" tools/_build/ab_base.so; do echo "== ${v:-in-tree} (round $r)"
+      LL_LIB=$v python tools/sweep.py "4096:4:10:10:32,4096:4:10:10:1,4096:4:10:10:8,65536:4:10:10:1"; LL_LIB=$v python tools/sweep_epmc.py "4096:1:32"; LL_LIB=$v python tools/sweep_sepmc.py "2048:0:32"; done; done > $OUT/ab.txt 2>&1
+    cat $OUT/ab.txt
+    gpu_tests -k "test_gpu_parity or pair_physics or terrain_physics or multi_step or env_api" ;;
   final)         # the round's closing call: the whole -m gpu suite at HEAD, then the three bench lines against the committed counters
     gpu_tests
     python bench.py > $OUT/bench.log 2>$OUT/bench.err; tail -c 400 $OUT/bench.log
