@@ -250,7 +250,11 @@ class TrajectoryBuffer(object):
         st = self._p2p
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         es = int(self.engine.device_ptrs().stream or 0)
-        st['ready'][k % 2].record(es)                       # behind the kernels that wrote block k (and its TD(lambda) pass)
+        diag = __import__('os').environ.get('LL_P2P_DIAG', '')      # measurement hook (tools/diag_p2p_gaps.py): leave out one element of the hand-off at a time
+        if diag == 'nothing':
+            return
+        if diag != 'norecord':
+            st['ready'][k % 2].record(es)                   # behind the kernels that wrote block k (and its TD(lambda) pass)
         t0 = time.perf_counter()
         self._join('_thread')                               # learner rank: the pulls of unroll k - 1 are queued, 'copied' is recorded
         self._join('_watcher')                              # (the watcher of unroll k - 2: long done)
@@ -261,8 +265,9 @@ class TrajectoryBuffer(object):
             def pull():
                 for r in range(world):
                     cs = st['streams'][r]
-                    st['src_ready'][r][half].make_stream_wait(cs.handle)     # (returns when rank r's unroll k is complete)
-                    for _ in range(n_pull):                  # (extra_gathers: measurement hook -- the residency of more, or slower, peers)
+                    if diag != 'norecord':
+                        st['src_ready'][r][half].make_stream_wait(cs.handle)     # (returns when rank r's unroll k is complete)
+                    for _ in range(n_pull if diag not in ('nopull', 'norecord') else 0):      # (extra_gathers: measurement hook -- the residency of more, or slower, peers)
                         cs.pull(outs[r].data_ptr(), st['src'][r] + half * st['block_bytes'], st['block_bytes'], no_cu=self.p2p_no_cu)
                     st['copied_all'][r][half].record(cs.handle)
             self._spawn(pull, '_thread')
@@ -271,7 +276,9 @@ class TrajectoryBuffer(object):
             # The next unroll (k + 1) overwrites block (k - 1) % 2: not before the learner has copied it.  That copy was queued one unroll ago
             # (its event was recorded before the learner entered this unroll's barrier: the join above).
             copied = st['copied'][(k - 1) % 2]
-            if st['signal'] is not None:
+            if diag == 'nowait':
+                pass
+            elif st['signal'] is not None:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()                                   # (torch's current stream IS the engine's: gather_async checks it)
                 st['signal'].make_stream_wait(es, k)          # device-side: the engine's stream stands still until the word says "unrolls 0 .. k - 1 copied"
