@@ -66,6 +66,9 @@ LL_HD bool eq_(int a, int b) { return a == b; }
 }  // namespace lm
 
 #define PMC_ROW 16   // lanes per environment
+#ifndef LL_PEER_MODE
+#define LL_PEER_MODE 0   // how a chase-tag robot reads its neighbour row: 0 = v_permlane16_swap (shipped); 1, 2: diagnostic forms (GpuLanes::peer)
+#endif
 #ifndef LL_CONE_PIPE
 #define LL_CONE_PIPE 1   // cone turns: a turn's second select rides in the next turn's v_rsq wait state (GpuLanes::cone_turns4); 0: the round-4 turn, the A/B leg
 #endif
@@ -193,10 +196,22 @@ struct GpuLanes {
   static LL_D F from_next_leg(F x) { return LL_DPP_MOV(x, 0x12C); }   // row_ror:12: the same sub-lane of leg (leg + 1) % 4
   // value of x held by the same lane of the NEIGHBOURING row (row ^ 1 of the wave): the other robot of a SEPMC arena.
   // gfx950 v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second.
+  // (LL_PEER_MODE, diagnostic builds only -- tools/diag_sepmc_builds.py: 1 = the same exchange through ds_bpermute_b32, 2 = the swap fenced by wait states)
   LL_D F peer(F x) const {
-    const unsigned u = __float_as_uint(x);
+    unsigned u = __float_as_uint(x);
+#if LL_PEER_MODE == 1
+    return __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x ^ 16u) & 63u) << 2), (int)u));
+#else
+#if LL_PEER_MODE == 2
+    asm volatile("s_nop 7" : "+v"(u));
+#endif
     const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return __uint_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+    unsigned o = (threadIdx.x & 16) ? r[0] : r[1];
+#if LL_PEER_MODE == 2
+    asm volatile("s_nop 7" : "+v"(o));
+#endif
+    return __uint_as_float(o);
+#endif
   }
   LL_D float peer_u(float x) const { return peer(x); }
   // minimum over the 16 lanes of the row

@@ -389,6 +389,9 @@ struct Sepmc {
               // for contacts the four arena walls (boxes 0..3, BS4:897-902: 1 cm thick) are solid outwards: a point pressed more than
               // half-way into a thin box would otherwise be pushed out of its far side
               if (b < 4) near[n_near * EPMC_BOX_WORDS + (b == 0 ? 3 : (b == 1 ? 2 : (b == 2 ? 1 : 0)))] += (b == 0 || b == 2) ? SEPMC_WALL_SOLID : -SEPMC_WALL_SOLID;
+              // ... and longer by the same at both ends, so that the four thickened walls close the corners (round 5: without it a point pressed into one wall next to a
+              // corner was nearest to that wall's END face and left the arena through the pocket between the two thickened walls -- 1 robot in 16 M robot-steps of the soak)
+              if (b < 4) { near[n_near * EPMC_BOX_WORDS + (b < 2 ? 0 : 2)] -= SEPMC_WALL_SOLID; near[n_near * EPMC_BOX_WORDS + (b < 2 ? 1 : 3)] += SEPMC_WALL_SOLID; }
             }
             if (b == nb) ex.flag_shape = n_near;
           }

@@ -91,6 +91,7 @@ class SepmcFreeRun(object):
         bx = self.env.all_boxes()                                                  # arena boxes, then the flag
         rec = np.c_[bx[:, 1] - bx[:, 4], bx[:, 1] + bx[:, 4], bx[:, 2] - bx[:, 5], bx[:, 2] + bx[:, 5], bx[:, 3] - bx[:, 6], bx[:, 3] + bx[:, 6], np.zeros(len(bx)), np.zeros(len(bx))]
         rec[0, 3] += 1.0; rec[1, 2] -= 1.0; rec[2, 1] += 1.0; rec[3, 0] -= 1.0      # the walls are solid outwards for contacts
+        rec[0:2, 0] -= 1.0; rec[0:2, 1] += 1.0; rec[2:4, 2] -= 1.0; rec[2:4, 3] += 1.0      # ... and longer by the same at both ends: the corners are closed
         return rec
 
     def _contacts(self):

@@ -513,6 +513,32 @@ def check_robot_robot_contact(lib_path):
     return dict(stack_gap=float(zs[-1]))
 
 
+def check_arena_corners_are_closed(lib_path):
+    """A robot pressed into a wall right next to a corner is pushed back into the arena.  (Round 5: the walls were thickened outwards but not lengthened -- a point inside one thickened wall
+    within a few centimetres of its end was nearest to the END face and left through the pocket between the two walls: one robot in 16 M robot-steps of the soak run.)"""
+    E = make_engine(env_config((0, 0, 0)), 4, lib_path, auto_reset=0, seed=23)
+    E.reset()
+    st = E.state().astype(np.float64)
+    for a, (sx, sy) in enumerate(((-1, -1), (1, -1), (-1, 1), (1, 1))):
+        for r in range(2):
+            st[a, r, 3:7] = [0, 0, 0, 1]
+            st[a, r, 7:13] = 0.0
+        st[a, 1, 0:3] = [-sx * 1.5, -sy * 1.5, 0.36]
+        st[a, 0, 0:3] = [sx * 2.44, sy * 2.62, 0.36]          # the base 12 cm inside the thickened wall along x, 6 cm from that wall's end face
+    E.set_state(st)
+    zero = np.zeros((4, 2, 12))
+    far = 0.0
+    for t in range(50):
+        E.step_host(zero)
+        s = E.state()
+        assert np.isfinite(s).all()
+        far = max(far, float(np.abs(s[:, 0, 0:2]).max()))
+    s = E.state()
+    assert far < 2.75 and np.abs(s[:, 0, 0:2]).max() < 2.6, (far, s[:, 0, 0:3])
+    E.close()
+    return dict(farthest=far, final=float(np.abs(s[:, 0, 0:2]).max()))
+
+
 def check_trained_policy_plays_chase_tag(lib_path, n_arenas=4, horizon=380, min_caught=0.25):
     """SURVEY.md 8f-3 for the strategic level -- the only Bullet-facing check of this build's robot-robot contact model: the reference's TRAINED
     SEPMC policy (data/models/strategic_level.model, trained against PyBullet; NumPy restatement oracle/sepmc_policy.py) drives BOTH robots of our
@@ -667,6 +693,7 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5, total_arena
         fl = np.array([ep['flag_x'][a], ep['flag_y'][a], ep['flag_z'][a]], dtype=np.float64)
         rec = np.vstack([rec, [[fl[0] - 0.05, fl[0] + 0.05, fl[1] - 0.05, fl[1] + 0.05, fl[2] - 0.25, fl[2] + 0.25, 0.0, 0.0]]]).astype(np.float32).astype(np.float64)
         rec[0, 3] += 1.0; rec[1, 2] -= 1.0; rec[2, 1] += 1.0; rec[3, 0] -= 1.0        # the walls are solid outwards for contacts (SEPMC_WALL_SOLID)
+        rec[0:2, 0] -= 1.0; rec[0:2, 1] += 1.0; rec[2:4, 2] -= 1.0; rec[2:4, 3] += 1.0      # ... and longer by the same at both ends: the corners are closed
         rec = rec.astype(np.float32).astype(np.float64)
         near, s, s_free, flag_at = [], [], [], []
         for r in range(2):
@@ -731,6 +758,7 @@ def arena_records(rows_a, cnt_a, ep, a):
     fl = np.array([ep['flag_x'][a], ep['flag_y'][a], ep['flag_z'][a]], dtype=np.float64)
     rec = np.vstack([rec, [[fl[0] - 0.05, fl[0] + 0.05, fl[1] - 0.05, fl[1] + 0.05, fl[2] - 0.25, fl[2] + 0.25, 0.0, 0.0]]]).astype(np.float32).astype(np.float64)
     rec[0, 3] += 1.0; rec[1, 2] -= 1.0; rec[2, 1] += 1.0; rec[3, 0] -= 1.0        # the walls are solid outwards for contacts (SEPMC_WALL_SOLID)
+    rec[0:2, 0] -= 1.0; rec[0:2, 1] += 1.0; rec[2:4, 2] -= 1.0; rec[2:4, 3] += 1.0      # ... and longer by the same at both ends: the corners are closed
     return rec.astype(np.float32).astype(np.float64)
 
 

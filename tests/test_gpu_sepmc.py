@@ -41,6 +41,10 @@ def test_robot_robot_contact_gpu():
     print(SC.check_robot_robot_contact(None))
 
 
+def test_arena_corners_are_closed_gpu():
+    print(SC.check_arena_corners_are_closed(None))
+
+
 def test_pair_physics_against_oracle_gpu():
     print(SC.check_pair_physics_against_oracle(None, n_arenas=64, seed=9))
 

@@ -40,6 +40,10 @@ def test_robot_robot_contact(emul_lib):
     print(SC.check_robot_robot_contact(emul_lib))
 
 
+def test_arena_corners_are_closed(emul_lib):
+    print(SC.check_arena_corners_are_closed(emul_lib))
+
+
 def test_trained_reference_policy_plays_chase_tag(emul_lib):
     print(SC.check_trained_policy_plays_chase_tag(emul_lib))
 

@@ -121,6 +121,11 @@ case $TARGET in
       LL_LIB=$v python tools/sweep.py "4096:4:10:10:32,4096:4:10:10:1,4096:4:10:10:8,65536:4:10:10:1"; LL_LIB=$v python tools/sweep_epmc.py "4096:1:32"; LL_LIB=$v python tools/sweep_sepmc.py "2048:0:32"; done; done > $OUT/ab.txt 2>&1
     cat $OUT/ab.txt
     gpu_tests -k "test_gpu_parity or pair_physics or terrain_physics or multi_step or env_api" ;;
+  r05i)          # which builds of the chase-tag kernels go wrong (seven rays per chunk and its variants, GPU against GPU); where the p2p hand-off's launch gaps come from; soak; the suite at HEAD
+    timeout 900 python tools/diag_sepmc_builds.py tools/_build/diag/libllenv_c7.so tools/_build/diag/libllenv_c5.so tools/_build/diag/libllenv_c7O2.so tools/_build/diag/libllenv_c7prealloc.so tools/_build/diag/libllenv_c7bperm.so tools/_build/diag/libllenv_c7fence.so > $OUT/sepmc_builds.txt 2>&1; cut -c1-420 $OUT/sepmc_builds.txt
+    timeout 600 python tools/diag_p2p_gaps.py > $OUT/p2p_gaps.txt 2>&1; cat $OUT/p2p_gaps.txt
+    timeout 600 python tools/soak.py 60000 8000 8000 > $OUT/soak.txt 2>&1; cat $OUT/soak.txt
+    gpu_tests ;;
   final)         # the round's closing call: the whole -m gpu suite at HEAD, then the three bench lines against the committed counters
     gpu_tests
     python bench.py > $OUT/bench.log 2>$OUT/bench.err; tail -c 400 $OUT/bench.log
