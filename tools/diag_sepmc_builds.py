@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import sepmc_parity_common as SC  # noqa: E402
 
-N, STEPS, SEED = 2048, 3, 5
+N, STEPS, SEED = int(os.environ.get("LL_DIAG_N", "2048")), int(os.environ.get("LL_DIAG_STEPS", "3")), 5
 
 
 def run(lib):
@@ -34,9 +34,10 @@ FIELDS = (('prop', 0, P3), ('height rays', P3, P3 + 325), ('fan rays', P3 + 325,
           ('oppo_info_cheat', P3 + NR + 20, P3 + NR + 35), ('flag_info', P3 + NR + 35, P3 + NR + 42), ('flag_info_cheat', P3 + NR + 42, P3 + NR + 49), ('with_flag', P3 + NR + 49, P3 + NR + 51), ('control_spd', P3 + NR + 51, P3 + NR + 52))
 
 
-ref = run(None)
-ref2 = run(None)
-print('shipped library, run to run: states identical', all(np.array_equal(a, b) for a, b in zip(ref, ref2)), flush=True)
+REF = os.environ.get('LL_DIAG_REF') or None          # another library as the reference (default: the shipped one)
+ref = run(REF)
+ref2 = run(REF)
+print('reference %s, run to run: states identical' % (REF or 'shipped library'), all(np.array_equal(a, b) for a, b in zip(ref, ref2)), flush=True)
 for lib in sys.argv[1:]:
     if not os.path.exists(lib):
         print(lib, 'missing'); continue
@@ -51,7 +52,7 @@ for lib in sys.argv[1:]:
         print('    after step %d: robots off %4d (arenas %4d, both robots in %4d), by wave row %s, bitwise-equal robots %d of %d; base distance of those arenas: median %.2f max %.2f (all arenas: median %.2f, within 1.5 m: %d); set %s'
               % (t, bad.sum(), ba.sum(), bad.all(-1).sum(), [int(bad[wr == k].sum()) for k in range(4)], int((d.max(-1) == 0).sum()), 2 * N,
                  np.median(dist[ba]) if ba.any() else 0, dist[ba].max() if ba.any() else 0, np.median(dist), int((dist < 1.5).sum()), hashlib.md5(np.packbits(bad).tobytes()).hexdigest()[:8]), flush=True)
-        og, orf = OBS[lib][t], OBS[None][t]
+        og, orf = OBS[lib][t], OBS[REF][t]
         print('      observations: robots with an entry off by > 2e-3, per field: %s; bitwise-equal observation rows %d of %d'
               % ({n: int((np.abs(og[..., a:b] - orf[..., a:b]) > 2e-3).any(-1).sum()) for n, a, b in FIELDS}, int((og == orf).all(-1).sum()), 2 * N), flush=True)
         if t == 1 and ba.any():

@@ -14,8 +14,8 @@ import sepmc_parity_common as SC  # noqa: E402
 
 emul_dir = os.path.join(ROOT, 'tests', 'emul')
 subprocess.check_call(['make', '-C', emul_dir, '-s'])
-emul = os.path.join(emul_dir, '_build', 'libllenv_emul.so')
-for label, lib in (('shipped (three rays per chunk)', None), ('seven rays per chunk', os.path.join(ROOT, 'tools', '_build', 'libllenv_chunk7.so'))):
+emul = os.environ.get('LL_DIAG_EMUL') or os.path.join(emul_dir, '_build', 'libllenv_emul.so')
+for label, lib in (('shipped (three rays per chunk)', os.environ.get('LL_DIAG_LIB3') or None), ('seven rays per chunk', os.environ.get('LL_DIAG_LIB7') or os.path.join(ROOT, 'tools', '_build', 'libllenv_chunk7.so'))):
     for spec in ({}, {'friction_mode': 0}):
         try:
             print(label, spec or 'cone friction', 'PASS', SC.check_engine_against_emulation(emul, n_arenas=2048, steps=2, spec=spec, gpu_lib=lib, report_only=True), flush=True)

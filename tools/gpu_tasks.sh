@@ -126,6 +126,26 @@ case $TARGET in
     timeout 600 python tools/diag_p2p_gaps.py > $OUT/p2p_gaps.txt 2>&1; cat $OUT/p2p_gaps.txt
     timeout 600 python tools/soak.py 60000 8000 8000 > $OUT/soak.txt 2>&1; cat $OUT/soak.txt
     gpu_tests ;;
+  r05j)          # the chase-tag builds again, observations included, and against the host build; the SEPMC GPU tests with the closed corners; soak
+    timeout 600 python tools/diag_sepmc_builds.py tools/_build/diag/libllenv_c7.so tools/_build/diag/libllenv_c5.so tools/_build/diag/libllenv_c7pyr.so > $OUT/sepmc_builds.txt 2>&1; cut -c1-600 $OUT/sepmc_builds.txt
+    timeout 600 python tools/diag_sepmc_chunk7.py > $OUT/chunk7.txt 2>&1; cut -c1-900 $OUT/chunk7.txt
+    gpu_tests -k "sepmc"
+    timeout 600 python tools/soak.py 60000 8000 8000 > $OUT/soak.txt 2>&1; cat $OUT/soak.txt ;;
+  r05k)          # was the seven-ray failure of profiles/r05_sepmc_chunk7_diag.txt the build's or a stale library's?  Libraries rebuilt from the source of that commit (efa7b7a): seven against three rays, GPU against GPU and against that commit's host build
+    D=tools/_build/diag
+    LL_DIAG_REF=$D/libllenv_old_c3.so timeout 600 python tools/diag_sepmc_builds.py $D/libllenv_old_c7.so > $OUT/old_builds.txt 2>&1; cut -c1-600 $OUT/old_builds.txt
+    LL_DIAG_EMUL=$D/libllenv_old_emul.so LL_DIAG_LIB3=$D/libllenv_old_c3.so LL_DIAG_LIB7=$D/libllenv_old_c7.so timeout 600 python tools/diag_sepmc_chunk7.py > $OUT/old_chunk7.txt 2>&1; cut -c1-500 $OUT/old_chunk7.txt
+    LL_DIAG_LIB3=$D/libllenv_old_c3.so LL_DIAG_LIB7=$D/libllenv_old_c7.so timeout 600 python tools/diag_sepmc_chunk7.py > $OUT/old_libs_new_emul.txt 2>&1; cut -c1-500 $OUT/old_libs_new_emul.txt ;;
+  r05l)          # round 4's own diagnosis re-run on libraries rebuilt from round 4's source (commit 9b75351, its python tree under tools/_build/r04b_tree); today's builds at 201 arenas (a partial last wave) and over 40 steps
+    (cd tools/_build/r04b_tree && timeout 600 python tools/diag_sepmc_rays.py s7) > $OUT/r04_tree_rays.txt 2>&1; cut -c1-400 $OUT/r04_tree_rays.txt
+    D=tools/_build/diag
+    LL_DIAG_N=201 LL_DIAG_STEPS=40 timeout 600 python tools/diag_sepmc_builds.py $D/libllenv_c7.so $D/libllenv_c5.so 2>&1 | grep -v "after step [0-9]*: robots off    0\|'flag_info': 0, 'flag_info_cheat': 0, 'with_flag': 0, 'control_spd': 0}; bitwise-equal observation rows 402 of 402" > $OUT/builds_201.txt; cut -c1-500 $OUT/builds_201.txt
+    LL_DIAG_REF=$D/libllenv_r04_c3.so LL_DIAG_N=201 LL_DIAG_STEPS=40 timeout 600 python tools/diag_sepmc_builds.py $D/libllenv_r04_c7.so 2>&1 | grep -v "after step [0-9]*: robots off    0\|'flag_info': 0, 'flag_info_cheat': 0, 'with_flag': 0, 'control_spd': 0}; bitwise-equal observation rows 402 of 402" > $OUT/builds_r04final_201.txt; cut -c1-500 $OUT/builds_r04final_201.txt ;;
+  r05m)          # bisect over the source revisions between round 4's seven-ray failure and today (libraries under tools/_build/bis, built here)
+    timeout 900 python tools/diag_sepmc_bisect.py 9b75351 7477004 4596d44 e6ab84b a9cbc3e 184caf2 033b865 aab0946 884b8d2 19cfcab 01da58d 34ca010 > $OUT/bisect.txt 2>&1; cut -c1-700 $OUT/bisect.txt ;;
+  r05n)          # A/B on one box: seven / five / three rays per chunk in the one-wave-per-SIMD chase-tag kernels (tools/_build/diag, built from this source)
+    for r in 1 2 3; do for v in "" tools/_build/diag/libllenv_c5.so tools/_build/diag/libllenv_c7.so; do echo "== ${v:-in-tree (three rays)} (round $r)"; LL_LIB=$v python tools/sweep_sepmc.py "2048:0:32,2048:1:32,2048:0:1"; done; done > $OUT/ray_chunk_ab.txt 2>&1
+    cat $OUT/ray_chunk_ab.txt | cut -c1-200 ;;
   final)         # the round's closing call: the whole -m gpu suite at HEAD, then the three bench lines against the committed counters
     gpu_tests
     python bench.py > $OUT/bench.log 2>$OUT/bench.err; tail -c 400 $OUT/bench.log

@@ -4,8 +4,14 @@
   C  a transcendental result read by a non-transcendental VALU in the next wait state
   D  a VALU write of a VGPR followed within 1 wait state by v_readlane / v_readfirstlane of it
 Linear scan per function (fall-through order; a label does not reset the window, a branch does not follow its target).
-    python tools/isa_hazards.py file.s [function-substring]"""
-import re, sys
+  E  (a code-generation defect, not a hazard -- the root cause of round 4's seven-rays-per-chunk chase-tag failure, HISTORY.md)  a block that is the target of an
+     s_cbranch_execz -- the join block behind a masked region -- and runs VALU writes AHEAD of the s_or_b64 exec that re-converges the wavefront there: those
+     writes reach only the lanes that were inside the region.  hipcc (ROCm 7.2) placed a live-range copy there in one build of sepmc_step_kernel<1, false>;
+     check_library() looks for it in the code object of the built library itself (llvm-objcopy + clang-offload-bundler + llvm-objdump), __graft_entry__.build()
+     and tests/test_built_code.py call it.
+    python tools/isa_hazards.py file.s [function-substring] [lines shown]        (a hipcc -save-temps .s)
+    python tools/isa_hazards.py --library [path/to/libllenv.so]                  (check E on the shipped code object)"""
+import os, re, subprocess, sys, tempfile
 TRANS = ('v_rsq_', 'v_rcp_', 'v_sqrt_', 'v_sin_', 'v_cos_', 'v_exp_', 'v_log_')
 def regs(tok):
     tok = tok.strip().lstrip('-|').rstrip('|')
@@ -49,7 +55,60 @@ def scan(lines, name):
             if 'permlane' in op and 'swap' in op: dst += regs(args[1].split()[0])
             for r in dst: age[r] = (0, s, op.startswith(TRANS), in_asm)
     return found
+
+LABEL = re.compile(r'^(?:(\.LBB\d+_\d+)|<(L\d+)>):')
+FUNC = re.compile(r'^(?:(_Z\w+):|<(_Z\w+)>:)')
+
+
+def exec_restore_scan(text):
+    """[(function, label, line number, [VALU instructions ahead of the exec restore])] over a -save-temps .s or an llvm-objdump --symbolize-operands listing."""
+    lines = text.split('\n')
+    fn, targets = None, {}
+    for l in lines:
+        m = FUNC.match(l)
+        if m: fn = m.group(1) or m.group(2)
+        m = re.match(r'\s+s_cbranch_execz\s+(\.LBB\d+_\d+|L\d+)', l)
+        if m and fn: targets.setdefault(fn, set()).add(m.group(1))
+    fn, found = None, []
+    for i, l in enumerate(lines):
+        m = FUNC.match(l)
+        if m: fn = m.group(1) or m.group(2)
+        m = LABEL.match(l)
+        lab = m and (m.group(1) or m.group(2))
+        if not lab or lab not in targets.get(fn, ()): continue
+        pre, j = [], i + 1
+        while j < len(lines):
+            s = re.split(r';|//', lines[j])[0].strip()
+            j += 1
+            if not s: continue
+            if s.startswith('s_or_b64 exec, exec'):
+                if pre: found.append((fn, lab, i + 1, pre))
+                break
+            if s.startswith('v_') and not s.startswith(('v_readlane', 'v_writelane', 'v_readfirstlane', 'v_cmp', 'v_nop')): pre.append(s); continue
+            if s.startswith(('v_readlane', 's_mov', 's_nop', 's_waitcnt')) and j - i < 16: continue       # an SGPR reload of the saved mask
+            break
+    return found
+
+
+def check_library(lib, llvm_bin='/opt/rocm/lib/llvm/bin'):
+    """Check E on the gfx950 code object inside a built HIP library; returns the findings (empty = clean)."""
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, 'fat.bin'), os.path.join(d, 'dev.co')
+        subprocess.check_call([os.path.join(llvm_bin, 'llvm-objcopy'), '--dump-section', '.hip_fatbin=' + fat, lib, os.path.join(d, 'copy.so')])
+        subprocess.check_call([os.path.join(llvm_bin, 'clang-offload-bundler'), '--type=o', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--input=' + fat, '--output=' + co, '--unbundle'])
+        dis = subprocess.run([os.path.join(llvm_bin, 'llvm-objdump'), '-d', '--symbolize-operands', '--no-show-raw-insn', '--no-leading-addr', co], check=True, capture_output=True, text=True).stdout
+    if dis.count('s_cbranch_execz') < 100:
+        raise RuntimeError('the disassembly of %s does not look like the step kernels (%d s_cbranch_execz)' % (lib, dis.count('s_cbranch_execz')))
+    return exec_restore_scan(dis)
+
+
 def main():
+    if sys.argv[1] == '--library':
+        lib = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lifelike_agility_and_play_amd', 'csrc', 'libllenv.so')
+        f = check_library(lib)
+        for fn, lab, ln, pre in f: print('%s %s (listing line %d): %d VALU writes ahead of the exec restore: %s' % (fn, lab, ln, len(pre), '; '.join(pre[:4])))
+        print('check E on %s: %d finding(s)' % (lib, len(f)))
+        sys.exit(1 if f else 0)
     path = sys.argv[1]; want = sys.argv[2] if len(sys.argv) > 2 else ''
     cur, buf, funcs = None, [], []
     for i, l in enumerate(open(path), 1):
@@ -68,5 +127,11 @@ def main():
         print('%-70s %s' % (n[:70], kinds or 'clean'))
         for x in f[:int(sys.argv[3]) if len(sys.argv) > 3 else 4]: print('     line %d %s: %s   <- %s' % (x[1], x[2], x[3], x[4]))
         tot += len(f)
-    print('total', tot)
-main()
+    e = exec_restore_scan(open(path).read())
+    for fn, lab, ln, pre in e:
+        if want in fn: print('E  %s %s (line %d): %d VALU writes ahead of the exec restore: %s' % (fn[:60], lab, ln, len(pre), '; '.join(pre[:4])))
+    print('total', tot, '+ E', len([x for x in e if want in x[0]]))
+
+
+if __name__ == '__main__':
+    main()
