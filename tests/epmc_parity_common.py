@@ -192,6 +192,82 @@ def check_ray_casting_against_oracle(lib_path, n_envs=12, n_steps=6, seed=3):
     return n_checked
 
 
+def check_engine_against_host_build(emul_lib_path, n_envs=4096, steps=7, element=1, seed=5, gpu_lib=None, report_only=False):
+    """The net under the EPMC step kernels at BASELINE config 4's size (the chase-tag one: sepmc_parity_common.check_engine_against_emulation): every entry of every observation, reward, done flag and reason,
+    episode record and terrain the HIP kernel writes, env by env against the HOST build of the same kernel source.  max_steps = 3: every env runs out of time at steps 2 and 5 and RE-SEEDS inside the step --
+    new terrain, new target, new friction, the first observation of the new episode -- the rare path where a misplaced register copy would show (HISTORY.md).  The host build takes the engine's state before
+    every step; envs whose own state differs by more than 5e-3 after it are counted, capped at 1 % and left to the physics parity tests."""
+    cfg = env_config(element, cmd_range=(25, 200))
+    cfg['max_steps'] = 3
+    G = make_engine(cfg, n_envs, gpu_lib, auto_reset=1, seed=seed)
+    H = make_engine(cfg, n_envs, emul_lib_path, auto_reset=1, seed=seed)
+    G.reset(); H.reset()
+    out = dict(reseeded=0, left_out=0, rough=0, worst_prop=0.0, worst_tail=0.0, ray_mismatch=0.0)
+    vel = np.zeros(33, bool); vel[12:30] = True
+    prop_vel = np.concatenate([np.tile(vel, 3), np.zeros(36, bool)])
+
+    recent = []
+
+    def compare(label, keep):
+        og, oh = G.obs().astype(np.float64), H.obs().astype(np.float64)
+        assert np.isfinite(og).all(), label
+        sg, sh = G.state().astype(np.float64), H.state().astype(np.float64)
+        scale = 1.0 + np.maximum(np.abs(sh[:, 7:13]).max(-1, keepdims=True), np.abs(sh[:, 25:37]).max(-1, keepdims=True))
+        ds = np.abs(sg - sh); ds[:, 7:13] /= scale; ds[:, 25:37] /= scale            # (base twist and joint rates relative to the fastest of them)
+        rough = ds.max(-1) > 5e-3
+        out['rough'] += int((keep & rough).sum())
+        if not label.endswith('only'):
+            recent.append(rough)
+        rough = np.logical_or.reduce(recent[-3:])                  # (the observation carries the two older proprioceptive frames)
+        ok = keep & ~rough
+        dprop = np.abs(og[:, :135] - oh[:, :135]) / np.where(prop_vel, scale, 1.0)
+        rays = np.abs(og[:, 135:913] - oh[:, 135:913]) > 2e-3                       # a ray grazing an edge may answer differently: counted
+        tail = np.abs(og[:, 913:] - oh[:, 913:])
+        eg, eh = G.episode(), H.episode()
+        rec = np.zeros(n_envs, bool)
+        for k in eg:
+            if k not in ('total_spd', 'max_spd', 'last_pos_diff_len'):
+                rec |= np.abs(eg[k].astype(np.float64) - eh[k]) > 1e-5 * (1.0 + np.abs(eh[k]))
+        res = dict(prop=int((ok & (dprop.max(-1) > 5e-3)).sum()), tail=int((ok & (tail.max(-1) > 5e-3)).sum()), episode_record=int((ok & rec).sum()))
+        if ok.any():
+            out['worst_prop'] = max(out['worst_prop'], float(dprop[ok].max())); out['worst_tail'] = max(out['worst_tail'], float(tail[ok].max()))
+            out['ray_mismatch'] = max(out['ray_mismatch'], float(rays[ok].mean()))
+            res['rays'] = int(rays[ok].mean() > 2e-3)
+        out.setdefault('per_step', {})[label] = res
+        if not report_only:
+            assert sum(res.values()) == 0, (label, res)
+            assert (keep & rough).mean() < 0.01, (label, (keep & rough).mean())
+
+    def terrain_off():
+        (rg_, ng_), (rh_, nh_) = G.statics(), H.statics()
+        live = np.arange(rg_.shape[1])[None, :] < ng_[:, None]
+        return (ng_ != nh_) | (np.abs(rg_ - rh_).max(-1) * live > 1e-4).any(-1)
+
+    compare('reset', np.ones(n_envs, bool))
+    assert not terrain_off().any()
+    rng = np.random.default_rng(seed)
+    for t in range(steps):
+        act = (rng.normal(size=(n_envs, 12)) * 0.135).astype(np.float32)
+        H.set_state(G.state())
+        G.step_host(act); H.step_host(act)
+        (rg, dg, wg), (rh, dh, wh) = G.reward_done(), H.reward_done()
+        same = (dg == dh) & (wg == wh)
+        out['left_out'] += int((~same).sum())
+        out['reseeded'] += int((dg & same).sum())
+        compare('step %d' % t, same)
+        if dg.any():
+            compare('step %d, re-seeding envs only' % t, same & dg)
+            assert not (terrain_off() & same).any(), t                                                   # the terrain of the new episodes
+        calm = same & (np.abs(G.state() - H.state()).max(-1) < 5e-3)
+        if not report_only:
+            assert np.abs(rg - rh)[calm].max() < 5e-3, (t, np.abs(rg - rh)[calm].max())
+    if not report_only:
+        assert out['left_out'] <= max(2, int(0.01 * n_envs * steps)), out
+        assert out['reseeded'] >= n_envs, out                                   # every env re-seeded at least once
+    G.close(); H.close()
+    return out
+
+
 def check_free_running_invariants(lib_path, n_envs=64, n_steps=80, element=1):
     """Real physics, real rays, Philox draws, auto-reset: size-independent properties of a random-policy run."""
     cfg = env_config(element, cmd_range=(25, 200))

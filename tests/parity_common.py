@@ -748,6 +748,80 @@ def check_auto_reset_equals_manual_reset(model_blob, table, lib_path, n_envs=24,
     return n_reset
 
 
+def check_engine_against_host_build(model_blob, table, emul_lib, n_envs=4096, steps=10, seed=17, gpu_lib=None, report_only=False, sigma=0.4):
+    """The net under the PMC step kernels at BASELINE config 2's size: every entry of every observation, reward, done flag and reason, ghost state, feet and episode record the HIP kernel writes, env by env against
+    the HOST build of the very same kernel source (tests/emul) -- the envs that finish and RE-SEED inside the step included (actions wild enough to end a few hundred episodes within the run: the rare path on which round 4's chase-tag build lost a
+    register to a misplaced copy, HISTORY.md; `profiles/r05_sepmc_seven_ray_root_cause.txt`).  Same config, seed and actions; before every step the host build takes the engine's state, so physics rounding stays one
+    step old; bars: 2e-2 on observation entries of envs whose state agrees to 5e-3, 2e-4 on the observations of RE-SEEDED envs (no physics in between).  Envs whose own state differs by more than 5e-3 after the step (a contact step conditioned on the last bit between two float32 builds) are counted, capped at 1 % and left to the physics parity tests;
+    envs whose done flag or re-seed draw differs are counted and capped likewise."""
+    G = make_engine(model_blob, table, n_envs, gpu_lib, auto_reset=1, seed=seed)
+    H = make_engine(model_blob, table, n_envs, emul_lib, auto_reset=1, seed=seed)
+    G.reset(); H.reset()
+    out = dict(reseeded=0, left_out=0, rough=0, worst_obs=0.0, worst_reseeded_obs=0.0, worst_reward=0.0)
+    vel = np.zeros(33, bool); vel[12:30] = True
+    obs_vel = np.concatenate([np.zeros(72, bool), np.tile(vel, 3), np.zeros(36, bool)])              # future 72 | prop 3 x 33 (joint rates, base twist: relative) | prop_a 36
+
+    recent = []
+
+    def compare(label, keep, reseeded=None):
+        og, oh = G.obs().astype(np.float64), H.obs().astype(np.float64)
+        assert np.isfinite(og).all(), label
+        sg, sh = G.state().astype(np.float64), H.state().astype(np.float64)
+        scale = 1.0 + np.maximum(np.abs(sh[:, 7:13]).max(-1, keepdims=True), np.abs(sh[:, 25:37]).max(-1, keepdims=True))
+        ds = np.abs(sg - sh); ds[:, 7:13] /= scale; ds[:, 25:37] /= scale            # (base twist and joint rates relative to the fastest of them)
+        rough = ds.max(-1) > 5e-3
+        do = np.abs(og - oh) / np.where(obs_vel, scale, 1.0)
+        out['rough'] += int((keep & rough).sum())
+        recent.append(rough)
+        rough = np.logical_or.reduce(recent[-3:])                  # (the observation carries the two older proprioceptive frames: an env stays set aside while a rough step is among them)
+        ok = keep & ~rough
+        if ok.any():
+            out['worst_obs'] = max(out['worst_obs'], float(do[ok].max()))
+        bad = ok & (do.max(-1) > 2e-2)              # (orientation-derived entries amplify a state difference of 5e-3 a few times; a wrong register is an O(0.1 .. 1) error)
+        res = dict(envs_with_an_observation_entry_off=int(bad.sum()))
+        gg, gh = G.ref_state().astype(np.float64), H.ref_state().astype(np.float64)
+        res['ghost_off'] = int((ok & (np.abs(gg - gh).max(-1) > 1e-3)).sum())
+        if reseeded is not None and (ok & reseeded).any():
+            # a re-seeded env starts from its clip's frame: no physics in between, so the two builds must agree far below the contact tolerance
+            m = ok & reseeded
+            out['worst_reseeded_obs'] = max(out['worst_reseeded_obs'], float(do[m].max()))
+            res['reseeded_envs_off'] = int((do[m].max(-1) > 2e-4).sum())
+            res['reseeded_state_off'] = int((ds[m].max(-1) > 2e-5).sum())
+        out.setdefault('per_step', {})[label] = res
+        if not report_only:
+            assert sum(res.values()) == 0, (label, res, np.flatnonzero(bad)[:8], do[bad].argmax(-1)[:8] if bad.any() else None)
+            assert (keep & rough).mean() < 0.02, (label, (keep & rough).mean())
+
+    compare('reset', np.ones(n_envs, bool), np.ones(n_envs, bool))
+    ig, ih = G.episode_info(), H.episode_info()
+    assert np.array_equal(ig['clip'], ih['clip']) and np.allclose(ig['time'], ih['time'], atol=1e-9)
+    rng = np.random.default_rng(seed)
+    for t in range(steps):
+        act = (rng.normal(size=(n_envs, 12)) * sigma).astype(np.float32)
+        H.set_state(G.state())
+        G.step_host(act); H.step_host(act)
+        (rg, dg, wg), (rh, dh, wh) = G.reward_done(), H.reward_done()
+        ig, ih = G.episode_info(), H.episode_info()
+        same = (dg == dh) & (wg == wh) & (ig['clip'] == ih['clip']) & (np.abs(ig['time'] - ih['time']) < 1e-9) & (ig['steps'] == ih['steps'])
+        out['left_out'] += int((~same).sum())
+        out['reseeded'] += int((dg & same).sum())
+        compare('step %d' % t, same, dg & same)
+        sg, sh = G.state(), H.state()
+        calm = same & (np.abs(sg - sh).max(-1) < 5e-3)
+        out['worst_reward'] = max(out['worst_reward'], float(np.abs(rg - rh)[calm].max()))
+        if not report_only:
+            assert np.abs(rg - rh)[calm].max() < 5e-3, (t, np.abs(rg - rh)[calm].max())
+        pg, ph = G.sampling_table()[0], H.sampling_table()[0]
+        out['table'] = float(np.abs(pg - ph).max())
+        if not report_only:
+            assert out['table'] < 1e-6, out
+    if not report_only:
+        assert out['left_out'] <= max(2, int(0.01 * n_envs * steps)), out
+        assert out['reseeded'] >= n_envs // 64, out                               # the in-kernel re-seed was exercised
+    G.close(); H.close()
+    return out
+
+
 def check_self_collision_parity(golden, orc, model_blob, table, lib_path, n_envs=16, seed=5):
     """Legs driven into one another in mid-air (same-side front/hind pairs, left/right pairs, diagonal): one control step,
     engine vs oracle -- same capsule spec, different formulations -- and the oracle WITHOUT self-collision as the control: the

@@ -29,6 +29,11 @@ def test_ray_casting_against_oracle(emul_lib):
     assert ec.check_ray_casting_against_oracle(emul_lib) > 100
 
 
+def test_host_build_net_runs(emul_lib):
+    out = ec.check_engine_against_host_build(emul_lib, n_envs=96, steps=6, gpu_lib=emul_lib)
+    assert out['worst_prop'] == 0.0 and out['worst_tail'] == 0.0 and out['reseeded'] >= 96, out
+
+
 def test_free_running_invariants(emul_lib):
     assert ec.check_free_running_invariants(emul_lib, n_envs=16, n_steps=70) > 0
 

@@ -122,3 +122,12 @@ def test_both_register_budgets_compute_the_same():
         B.set_state(sb_all)
     assert worst_c < 1e-4 and worst_v < 1e-3, (worst_c, worst_v)
     A.close(); B.close()
+
+
+def test_every_observation_entry_against_the_host_build_of_the_kernel_source():
+    import os
+    import subprocess
+    emul_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emul')
+    subprocess.check_call(['make', '-C', emul_dir, '-s'])
+    for element in (1, 3):
+        print(element, ec.check_engine_against_host_build(os.path.join(emul_dir, '_build', 'libllenv_emul.so'), element=element))

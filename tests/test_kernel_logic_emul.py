@@ -89,6 +89,12 @@ def test_scripted_episodes_against_reference_goldens(golden, model_blob, mocap_t
     pc.check_scripted_episodes_against_goldens(golden, model_blob, mocap_table, emul_lib)
 
 
+def test_host_build_net_runs(model_blob, mocap_table, emul_lib):
+    # (the checker of tests/test_gpu_parity.py::test_every_observation_entry_..., here the host build against itself: every difference is exactly zero)
+    out = pc.check_engine_against_host_build(model_blob, mocap_table, emul_lib, n_envs=192, steps=10, gpu_lib=emul_lib)
+    assert out['worst_obs'] == 0.0 and out['left_out'] == 0 and out['reseeded'] >= 3, out
+
+
 def test_auto_reset_equals_manual_reset(model_blob, mocap_table, emul_lib):
     assert pc.check_auto_reset_equals_manual_reset(model_blob, mocap_table, emul_lib) >= 5
 

@@ -19,7 +19,7 @@ j=json.loads(sys.stdin.read()); r=j['roofline']
 print('$1: value %.2f M  ms/step %.4f  kernel ms/step %.4f  launches %d' % (j['value']/1e6, j['ms_per_step'], r['kernel_avg_ms'], r['kernel_launches_timed']))"; }
 gpu_tests() { timeout 1500 python -m pytest tests -m gpu -q -rA "$@" > $OUT/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $OUT/pytest_gpu.log; grep -E "passed|failed|^FAILED|^ERROR|pytest rc" $OUT/pytest_gpu.log | tail -8; }
 case $TARGET in
-  tests) gpu_tests ;;
+  tests) [ $# -ge 1 ] && shift; [ $# -ge 1 ] && shift; gpu_tests "$@" ;;     # tools/gpu_tasks.sh tests TAG -k expr
   valu) tools/_build/valu_issue_bench 2000 | tee $OUT/valu_issue.txt ;;
   inertia)
     tools/_build/valu_issue_bench 2000 > $OUT/valu_issue.txt 2>&1; cat $OUT/valu_issue.txt
@@ -146,6 +146,19 @@ case $TARGET in
   r05n)          # A/B on one box: seven / five / three rays per chunk in the one-wave-per-SIMD chase-tag kernels (tools/_build/diag, built from this source)
     for r in 1 2 3; do for v in "" tools/_build/diag/libllenv_c5.so tools/_build/diag/libllenv_c7.so; do echo "== ${v:-in-tree (three rays)} (round $r)"; LL_LIB=$v python tools/sweep_sepmc.py "2048:0:32,2048:1:32,2048:0:1"; done; done > $OUT/ray_chunk_ab.txt 2>&1
     cat $OUT/ray_chunk_ab.txt | cut -c1-200 ;;
+  r05o)          # the host-build nets under the PMC and EPMC step kernels (report first, then the tests as written)
+    python - > $OUT/nets_report.txt 2>&1 <<'PY'
+import sys, time; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import subprocess; subprocess.check_call(['make', '-C', 'tests/emul', '-s'])
+import parity_common as pc, epmc_parity_common as ec
+from lifelike_agility_and_play_amd import mocap, urdf_model
+E = 'tests/emul/_build/libllenv_emul.so'
+t0 = time.time(); print('PMC', pc.check_engine_against_host_build(urdf_model.default_model_blob(), mocap.load_mocap('', 0.02), E, report_only=True), '%.0f s' % (time.time() - t0), flush=True)
+for el in (1, 3):
+    t0 = time.time(); print('EPMC element', el, ec.check_engine_against_host_build(E, element=el, report_only=True), '%.0f s' % (time.time() - t0), flush=True)
+PY
+    cut -c1-1500 $OUT/nets_report.txt
+    gpu_tests -k "every_observation" ;;
   final)         # the round's closing call: the whole -m gpu suite at HEAD, then the three bench lines against the committed counters
     gpu_tests
     python bench.py > $OUT/bench.log 2>$OUT/bench.err; tail -c 400 $OUT/bench.log
