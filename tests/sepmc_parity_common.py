@@ -444,9 +444,14 @@ def check_engine_against_emulation(emul_lib_path, n_arenas=2048, steps=2, seed=5
             det['ray_mismatch_by_wave_row'] = [float(rays[wr == k].mean()) for k in range(4)]
             det['ray_mismatch_height_fan_front'] = [float(rays[..., 0:325].mean()), float(rays[..., 325:453].mean()), float(rays[..., 453:778].mean())]
             det['robots_with_ray_mismatch'] = int(rays.any(-1).sum())
-        out['worst_tail'] = max(out['worst_tail'], tail[~rough].max() if (~rough).any() else 0.0)
         out['ray_mismatch'] = max(out['ray_mismatch'], rays.mean())
-        per_field = {name: int((tail[..., a:b][~rough].max(-1) > 5e-3).sum()) for name, a, b in FIELDS}
+        # the visibility flag (oppo_info[0] = oppo_info_cheat[0]; it also masks oppo_info) is a ray test and an angle test decided on the last bit now and then: counted, capped, set aside
+        vis_tie = (og[..., P3 + NR + 20] != oh[..., P3 + NR + 20]) & ~rough
+        out['visibility_ties'] = out.get('visibility_ties', 0) + int(vis_tie.sum())
+        assert vis_tie.sum() <= max(2, int(1e-3 * vis_tie.size)), (label, int(vis_tie.sum()))
+        settled = ~rough & ~vis_tie
+        out['worst_tail'] = max(out['worst_tail'], tail[settled].max() if settled.any() else 0.0)
+        per_field = {name: int((tail[..., a:b][settled].max(-1) > 5e-3).sum()) for name, a, b in FIELDS}
         out.setdefault('per_field', {})[label] = per_field
         if report_only:
             return

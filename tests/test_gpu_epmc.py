@@ -129,5 +129,7 @@ def test_every_observation_entry_against_the_host_build_of_the_kernel_source():
     import subprocess
     emul_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emul')
     subprocess.check_call(['make', '-C', emul_dir, '-s'])
+    lib = os.path.join(emul_dir, '_build', 'libllenv_emul.so')
     for element in (1, 3):
-        print(element, ec.check_engine_against_host_build(os.path.join(emul_dir, '_build', 'libllenv_emul.so'), element=element))
+        print('4096 envs, element', element, ec.check_engine_against_host_build(lib, element=element))
+    print('8192 envs (the 256-register build), element 2', ec.check_engine_against_host_build(lib, n_envs=8192, steps=4, element=2, seed=11))

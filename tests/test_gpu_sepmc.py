@@ -87,6 +87,7 @@ def test_every_observation_field_against_the_host_build_of_the_kernel_source():
     lib = os.path.join(emul_dir, '_build', 'libllenv_emul.so')
     print('cone friction:', SC.check_engine_against_emulation(lib, n_arenas=2048, steps=2))
     print('pyramid:', SC.check_engine_against_emulation(lib, n_arenas=2048, steps=1, spec=dict(friction_mode=0)))
+    print('4096 arenas (the 256-register build):', SC.check_engine_against_emulation(lib, n_arenas=4096, steps=1, seed=9))
 
 
 def test_trained_reference_policy_plays_chase_tag_gpu():
