@@ -61,7 +61,7 @@ def test_trained_reference_policies_traverse_our_terrain():
 
 def test_multi_step_launch():
     """k control steps per launch == k launches, bit for bit; both kernel builds"""
-    ec.check_multi_step_launch(None, sizes=(70, 4200), k=7, n_launches=3)
+    ec.check_multi_step_launch(None, sizes=(70, 4096, 4200), k=7, n_launches=3)
 
 
 def test_pyramid_friction_variant():
@@ -70,7 +70,7 @@ def test_pyramid_friction_variant():
     with ec.spec_variant(friction_mode=0):
         ec.check_terrain_physics_against_oracle(None, n_envs=48, cap_ill=1, cap_tie=1)                              # (what the default spec's test asserted while this was the default)
         ec.check_terrain_physics_against_oracle(None, n_envs=24, total_envs=4096 + 256, cap_ill=2, cap_tie=1)
-        ec.check_multi_step_launch(None, sizes=(70, 4200), k=7, n_launches=3)
+        ec.check_multi_step_launch(None, sizes=(70, 4096, 4200), k=7, n_launches=3)
 
 
 def test_round4_spec_variant():
@@ -79,7 +79,7 @@ def test_round4_spec_variant():
     with ec.spec_variant(limit_speculative=1, erp=0.2, limit_erp=0.2, limit_erp_deep=-1, max_depen_speed=0.5):
         ec.check_terrain_physics_against_oracle(None, n_envs=48, cap_ill=3, cap_tie=1)
         ec.check_terrain_physics_against_oracle(None, n_envs=24, total_envs=4096 + 256, cap_ill=2, cap_tie=1)
-        ec.check_multi_step_launch(None, sizes=(70, 4200), k=7, n_launches=3)
+        ec.check_multi_step_launch(None, sizes=(70, 4096, 4200), k=7, n_launches=3)
     with ec.spec_variant(erp=0.2, erp_deep=0.08):
         ec.check_terrain_physics_against_oracle(None, n_envs=48, cap_ill=3, cap_tie=1)
 

@@ -198,7 +198,7 @@ def test_step_random_is_fill_then_step(model_blob, mocap_table):
 
 
 def test_multi_step_launch(model_blob, mocap_table):
-    """ll_step_random_n: k control steps in one launch == k launches, bit for bit (both kernel variants: 70 and 4200 envs)."""
+    """ll_step_random_n: k control steps in one launch == k launches, bit for bit (both kernel variants: 70 / 4096 and 4200 envs)."""
     from lifelike_agility_and_play_amd import gather
     import torch
     if not torch.cuda.is_available():
@@ -206,7 +206,7 @@ def test_multi_step_launch(model_blob, mocap_table):
 
     def read_ring(addr, shape):
         return gather.device_tensor(addr, shape).cpu().numpy()
-    pc.check_multi_step_launch(model_blob, mocap_table, None, read_ring, sizes=(70, 4200), k=7, n_launches=5)
+    pc.check_multi_step_launch(model_blob, mocap_table, None, read_ring, sizes=(70, 4096, 4200), k=7, n_launches=5)        # (4096: the benchmark's own kernel at its own size)
     pc.check_multi_step_launch(model_blob, mocap_table, None, read_ring, sizes=(70, 4200), k=7, n_launches=3, spec=dict(friction_mode=0))   # the pyramid builds
 
 

@@ -62,7 +62,7 @@ def test_pyramid_friction_variant_gpu():
     with ec.spec_variant(friction_mode=0):
         print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=9))
         print(SC.check_pair_physics_against_oracle(None, n_arenas=24, seed=9, total_arenas=2048 + 128))
-        SC.check_multi_step_launch(None, sizes=(35, 2100), k=7, n_launches=3)
+        SC.check_multi_step_launch(None, sizes=(35, 2048, 2100), k=7, n_launches=3)
 
 
 def test_round4_spec_variant_gpu():
@@ -72,7 +72,7 @@ def test_round4_spec_variant_gpu():
     with ec.spec_variant(limit_speculative=1, erp=0.2, limit_erp=0.2, limit_erp_deep=-1, max_depen_speed=0.5):
         print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=9))
         print(SC.check_pair_physics_against_oracle(None, n_arenas=24, seed=9, total_arenas=2048 + 128))
-        SC.check_multi_step_launch(None, sizes=(35, 2100), k=7, n_launches=3)
+        SC.check_multi_step_launch(None, sizes=(35, 2048, 2100), k=7, n_launches=3)
     with ec.spec_variant(erp=0.2, erp_deep=0.08):
         print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=9, cap_ill=3))
 
@@ -100,7 +100,7 @@ def test_per_robot_torque_limit_gpu():
 
 def test_multi_step_launch_gpu():
     """k control steps per launch == k launches, bit for bit; both kernel builds"""
-    SC.check_multi_step_launch(None, sizes=(35, 2100), k=7, n_launches=3)
+    SC.check_multi_step_launch(None, sizes=(35, 2048, 2100), k=7, n_launches=3)
 
 
 def test_free_running_against_the_oracle_env_gpu():
