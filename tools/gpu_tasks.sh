@@ -159,6 +159,10 @@ for el in (1, 3):
 PY
     cut -c1-1500 $OUT/nets_report.txt
     gpu_tests -k "every_observation" ;;
+  ab2)           # A/B on one box, sweeps only: the in-tree library against tools/_build/ab_base.so
+    for r in 1 2 3; do for v in "" tools/_build/ab_base.so; do echo "== ${v:-in-tree} (round $r)"
+      LL_LIB=$v python tools/sweep.py "4096:4:10:10:32,4096:4:10:10:1,65536:4:10:10:1"; LL_LIB=$v python tools/sweep_epmc.py "4096:1:32"; LL_LIB=$v python tools/sweep_sepmc.py "2048:0:32"; done; done > $OUT/ab.txt 2>&1
+    grep "==\|steps/s" $OUT/ab.txt | cut -c1-150 ;;
   final)         # the round's closing call: the whole -m gpu suite at HEAD, then the three bench lines against the committed counters
     gpu_tests
     python bench.py > $OUT/bench.log 2>$OUT/bench.err; tail -c 400 $OUT/bench.log
