@@ -85,6 +85,7 @@ def exec_restore_scan(text):
                 if pre: found.append((fn, lab, i + 1, pre))
                 break
             if s.startswith('v_') and not s.startswith(('v_readlane', 'v_writelane', 'v_readfirstlane', 'v_cmp', 'v_nop')): pre.append(s); continue
+            if s.startswith(('scratch_', 'global_', 'flat_', 'buffer_', 'ds_')): pre.append(s); continue            # a spill reload or a store under the region's mask is the same defect
             if s.startswith(('v_readlane', 's_mov', 's_nop', 's_waitcnt')) and j - i < 16: continue       # an SGPR reload of the saved mask
             break
     return found
