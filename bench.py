@@ -44,6 +44,15 @@ PMC_REWARD_WEIGHTS = {'joint_pos': 0.3, 'joint_vel': 0.05, 'end_effector': 0.1, 
 PMC_PROP_TYPE = ['joint_pos', 'joint_vel', 'root_ang_vel_loc', 'root_lin_vel_loc', 'e_g']
 
 
+def build_record():
+    """hipcc's version and the sha256 of the gfx950 code object this process runs (written next to the library by __graft_entry__.build_hip; round-5 review #9)."""
+    try:
+        import __graft_entry__ as ge
+        return ge.build_info()
+    except Exception as e:               # noqa: BLE001
+        return {'error': repr(e)}
+
+
 def effective_cores():
     """Host threads this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container can see 256
     hardware threads and be allowed 8 cores' worth of time: 256 OpenMP threads then only take turns)."""
@@ -128,19 +137,99 @@ def committed_counters(kernel, units, spl=1):
         return None, None, None
 
 
+# ---- the N > 1 failure path (round-5 review #6: the first real 8-rank RCCL exchange will be the driver's, on a box nobody can rehearse on) ----------------
+# Whatever goes wrong in a rank -- an exception, a peer that died (the launcher then terminates the others), a collective that never returns --
+# ONE JSON line {"error", "rank", "phase", "rccl_version_line", ...} reaches stdout before the rank exits non-zero, the way the reference's actor
+# logs before it reboots (bin/run_pg_actor.py:143-155).  There is no fallback for the contract line: a failed gather is reported, not retried without it.
+METRIC = 'env-steps/sec (whole node), PMC tracking env, random policy'
+_PHASE = ['init']                       # init | warmup | timed | gather | report
+_BEAT = [time.monotonic()]
+_FAIL = {'armed': False, 'rank': 0, 'world': 1, 'lock': None, 'rccl_log': None, 'stall_s': float(os.environ.get('LL_BENCH_STALL_S', '150'))}
+
+
+def set_phase(p):
+    _PHASE[0] = p
+    _BEAT[0] = time.monotonic()
+
+
+def _rccl_lines():
+    ver, tail = None, []
+    try:
+        lines = [l.rstrip() for l in open(_FAIL['rccl_log'] or '').read().splitlines() if l.strip()]
+        v = [l for l in lines if 'version' in l.lower()]
+        ver, tail = (v[0].strip() if v else None), lines[-8:]
+    except OSError:
+        pass
+    return ver, tail
+
+
+def report_failure(what, code=1):
+    """The one error line of a failed launch: the first rank to fail claims it (an exclusive lock file per launch), later ones only write to stderr."""
+    ver, tail = _rccl_lines()
+    line = json.dumps({'error': str(what)[-2000:], 'rank': _FAIL['rank'], 'world': _FAIL['world'], 'phase': _PHASE[0], 'rccl_version_line': ver, 'rccl_log_tail': tail,
+                       'metric': METRIC, 'value': None, 'n_gpus': _FAIL['world']})
+    first = True
+    if _FAIL['lock']:
+        try:
+            os.close(os.open(_FAIL['lock'], os.O_CREAT | os.O_EXCL | os.O_WRONLY))
+        except FileExistsError:
+            first = False
+        except OSError:
+            pass
+    print(line, file=sys.stdout if first else sys.stderr, flush=True)
+    os._exit(code)                       # no destructors: a process group with a dead peer does not tear down
+
+
+def arm_failure_path(rank, world):
+    """A helper thread that can speak while the main thread sits in a collective or a stream wait: it hears SIGTERM (the launcher ending the ranks because a
+    peer died) through the wake-up descriptor, and it notices a timed region that makes no progress for LL_BENCH_STALL_S seconds."""
+    import signal
+    import socket
+    import tempfile
+    import threading
+    _FAIL.update(rank=rank, world=world, armed=True)
+    if world > 1:
+        _FAIL['lock'] = os.path.join(tempfile.gettempdir(), 'll_bench_err_%s_%d.lock' % (os.environ.get('MASTER_PORT', '0'), os.getppid()))
+    r, w = socket.socketpair()
+    w.setblocking(False)
+    signal.signal(signal.SIGTERM, lambda *_: None)           # (the C-level handler writes the signal number to the descriptor at once, whatever the main thread is doing)
+    signal.set_wakeup_fd(w.fileno(), warn_on_full_buffer=False)
+    _FAIL['socks'] = (r, w)
+
+    def watch():
+        import select
+        while _FAIL['armed']:
+            ready, _, _ = select.select([r], [], [], 1.0)
+            if ready and signal.SIGTERM in r.recv(64):
+                report_failure('terminated by the launcher in phase %s: a peer rank failed or the launch was cut off' % _PHASE[0], 143)
+            if _PHASE[0] in ('init', 'warmup', 'timed', 'gather') and time.monotonic() - _BEAT[0] > _FAIL['stall_s']:
+                report_failure('no progress for %.0f s in phase %s (a collective or a stream wait that does not return)' % (_FAIL['stall_s'], _PHASE[0]), 3)
+    threading.Thread(target=watch, daemon=True).start()
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this very command line, one per GPU, the way the driver's
-    explicit launch line does (torch.distributed.run, rendezvous on 127.0.0.1, a free port), and pass rank 0's ONE JSON line through."""
+    explicit launch line does (torch.distributed.run, rendezvous on 127.0.0.1, a free port), and pass rank 0's ONE JSON line through.  A launch that
+    fails has printed one error line from the first rank that noticed (report_failure); if no rank got that far the launcher's exit code is reported here."""
     import socket
     import subprocess
+    import tempfile
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault('OMP_NUM_THREADS', '1')                  # what torchrun would set (with a warning) anyway
     sys.stdout.flush()
-    rc = subprocess.call(cmd, env=env)                      # the ranks inherit stdout: rank 0 prints the line
+    proc = subprocess.Popen(cmd, env=env)                   # the ranks inherit stdout: rank 0 prints the line
+    rc = proc.wait()
+    lock = os.path.join(tempfile.gettempdir(), 'll_bench_err_%d_%d.lock' % (port, proc.pid))
+    reported = os.path.exists(lock)
+    if reported:
+        os.unlink(lock)
     if rc != 0:
+        if not reported:
+            print(json.dumps({'error': 'the launcher (torch.distributed.run) exited with code %d and no rank reported' % rc, 'rank': None, 'world': n, 'phase': 'launch',
+                              'rccl_version_line': None, 'metric': METRIC, 'value': None, 'n_gpus': n}), flush=True)
         raise SystemExit(rc)
 
 
@@ -168,7 +257,20 @@ def main():
         return main_epmc(args)
     if args.workload == 'sepmc':
         return main_sepmc(args)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1 or os.environ.get('LL_BENCH_FORCE_GATHER'):
+        arm_failure_path(int(os.environ.get('RANK', '0')), world)
+        try:
+            main_pmc(args)
+        except BaseException as e:       # noqa: BLE001  (SystemExit included: a rank that bows out is a failed launch)
+            import traceback
+            report_failure('%s: %s | %s' % (type(e).__name__, e, ' <- '.join(l.strip() for l in traceback.format_exc().splitlines()[-6:])), 1)
+        _FAIL['armed'] = False
+    else:
+        main_pmc(args)
 
+
+def main_pmc(args):
     import torch
     import torch.distributed as dist
     from lifelike_agility_and_play_amd import capi, mocap, urdf_model, gather
@@ -198,14 +300,22 @@ def main():
             s_ = socket.socket(); s_.bind(('127.0.0.1', 0)); os.environ['MASTER_PORT'] = str(s_.getsockname()[1]); s_.close()
         kw = {'device_id': torch.device('cuda', local_rank)} if backend == 'nccl' else {}
         rccl_log = None
-        if backend == 'nccl' and rank == 0:
-            # RCCL's own version line (NCCL_DEBUG=VERSION prints it at communicator creation) goes to a file of this process and from there into the JSON,
-            # so that a scaling record can be checked against the library that actually ran
+        if backend == 'nccl':
+            # RCCL's own log of THIS rank (NCCL_DEBUG=WARN: its version line at communicator creation, then whatever it warns about) goes to a file per rank; the version
+            # line travels in the JSON so that a scaling record can be checked against the library that ran, the tail travels in the error line of a failed launch
             import tempfile
-            rccl_log = os.path.join(tempfile.gettempdir(), 'll_bench_rccl_%d.log' % os.getpid())
-            os.environ.setdefault('NCCL_DEBUG', 'VERSION')
+            rccl_log = os.path.join(tempfile.gettempdir(), 'll_bench_rccl_%s_r%d_%d.log' % (os.environ['MASTER_PORT'], rank, os.getpid()))
+            os.environ.setdefault('NCCL_DEBUG', 'WARN')
             os.environ.setdefault('NCCL_DEBUG_FILE', rccl_log)
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+            _FAIL['rccl_log'] = os.environ['NCCL_DEBUG_FILE']
+        import datetime
+        # a rendezvous or a collective that a dead or wedged peer never joins ends after LL_BENCH_PG_TIMEOUT_S (120 s) instead of the backend's 10 - 30 minutes
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=float(os.environ.get('LL_BENCH_PG_TIMEOUT_S', '120'))), **kw)
+
+    def die_here(phase):                                   # test hook (tests/test_gpu_env_api.py): rank LL_BENCH_KILL_RANK dies without a word at the start of a phase
+        if os.environ.get('LL_BENCH_KILL_RANK') == str(rank) and os.environ.get('LL_BENCH_KILL_PHASE', 'timed') == phase:
+            import signal
+            os.kill(os.getpid(), signal.SIGKILL)
 
     def dev_sync():
         eng.sync()
@@ -271,6 +381,7 @@ def main():
                 eng.step_random(SIGMA)
             else:
                 eng.step_random_n(SIGMA, k)
+            _BEAT[0] = time.monotonic()
             n_done[0] += k
             left -= k
             if traj is not None and n_done[0] % UNROLL == 0:   # the step kernel itself records the rows (ll_enable_unrolls);
@@ -279,6 +390,8 @@ def main():
                 if args.gather_mode != 'none':
                     traj.gather_async(u, 0)                    # the gather of this unroll overlaps with the next unroll's steps
 
+    set_phase('warmup')
+    die_here('warmup')
     run_steps(args.warmup)
     if traj is not None:
         traj.wait()
@@ -286,9 +399,12 @@ def main():
     if multi:
         dist.barrier()
     dev_sync()
+    set_phase('timed')
+    die_here('timed')
     eng.enable_kernel_timing(True)
     t0 = time.perf_counter()
     run_steps(args.steps, spl_timed)
+    set_phase('gather')
     if traj is not None:
         traj.wait()                                          # an in-flight gather belongs to the timed region
     dev_sync()
@@ -321,11 +437,7 @@ def main():
                 gather_stats['rccl_version'] = '.'.join(str(x) for x in torch.cuda.nccl.version())
             except Exception:            # noqa: BLE001
                 gather_stats['rccl_version'] = None
-            try:
-                lines_ = [l.strip() for l in open(os.environ.get('NCCL_DEBUG_FILE', '')).read().splitlines() if 'version' in l.lower()] if rank == 0 else []
-                gather_stats['rccl_version_line'] = lines_[0] if lines_ else None
-            except OSError:
-                gather_stats['rccl_version_line'] = None
+            gather_stats['rccl_version_line'] = _rccl_lines()[0] if rank == 0 else None
         if os.environ.get('LL_BENCH_VERIFY') and traj.n_gathered > 0:
             # what rank 0 received for the last gathered unroll == what each rank's engine holds in that block (float64 checksums + probes)
             k_last = traj.n_gathered - 1
@@ -337,6 +449,7 @@ def main():
                 got = [o.double().cpu() for o in traj.last]
                 got_sig = [[float(g.sum()), float(g.abs().sum()), float(g[0, 0, 0]), float(g[-1, -1, -1]), float(g[n // 2, UNROLL // 2, 207])] for g in got]
                 gather_check = 'ok' if got_sig == sigs and len({tuple(x) for x in sigs}) == world else 'MISMATCH %r vs %r' % (got_sig, sigs)
+    set_phase('report')
     counters = eng.counters()
     stale_reseeds = eng.table_sync()                         # (before the single-step leg; 0 unless the chip was shared: ll_get_table_sync)
     ep_hist = [int(x) for x in eng.episode_histogram()]
@@ -379,7 +492,7 @@ def main():
             issue['chip_valu_frac_note'] = ('one wave per SIMD issues at most one instruction per 4.4 cycles, and the DPP / v_med3 / packed forms this kernel '
                                             'is made of are half-rate at any occupancy (profiles/r04_valu_issue.txt): the ceiling of this mix is near 0.6, not 1')
         out = {
-            'metric': 'env-steps/sec (whole node), PMC tracking env, random policy',
+            'metric': METRIC,
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -413,6 +526,7 @@ def main():
                          'algorithmic_bytes_per_env_step': algo_bytes, 'single_wave_issue': issue,
                          'note': 'bound by single-wave instruction issue, not HBM (%s instructions per wave per step, four envs, vs 2.5 KB per env); see DESIGN.md 5.1' % ('%.1fe4' % (issue['instructions_per_wave_per_control_step'] / 1e4) if issue else 'about 8e4')},
         }
+        out['build'] = build_record()
         if single is not None:
             out['single_step_launch'] = single
         if world == 1 and not args.no_cpu_baseline:
@@ -516,7 +630,7 @@ def main_epmc(args):
         achieved = n * EPMC_ALGO_BYTES_PER_ENV_STEP / (k_ms * 1e-3) / 1e9
         traffic, issue, tsrc = committed_counters('epmc_step_kernel', n, spl)
         extra = {'cpu_baseline': cpu_baseline_env('epmc', epmc_env_config(args.element))} if (world == 1 and not args.no_cpu_baseline) else {}
-        print(json.dumps({**extra, **{
+        print(json.dumps({**extra, 'build': build_record(), **{
             'metric': 'env-steps/sec (whole node), EPMC PlayGround env, random policy', 'value': world * n * args.steps / elapsed, 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -600,7 +714,7 @@ def main_sepmc(args):
         achieved = 2 * n_arenas * SEPMC_ALGO_BYTES_PER_ROBOT_STEP / (k_ms * 1e-3) / 1e9
         traffic, issue, tsrc = committed_counters('sepmc_step_kernel', 2 * n_arenas, spl)
         extra = {'cpu_baseline': cpu_baseline_env('sepmc', sepmc_env_config())} if (world == 1 and not args.no_cpu_baseline) else {}
-        print(json.dumps({**extra, **{
+        print(json.dumps({**extra, 'build': build_record(), **{
             'metric': 'robot-steps/sec (whole node), SEPMC chase-tag env, random policy', 'value': world * 2 * n_arenas * args.steps / elapsed, 'unit': 'robot-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',

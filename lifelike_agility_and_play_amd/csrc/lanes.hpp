@@ -366,6 +366,40 @@ struct GpuLanes {
     }
     for (int i = 0; i < 16; i++) g[i] = __uint_as_float(R[i]);
   }
+  // ---- the Gram blocks as a BACKGROUND job of the matrix cores (round 6; WithGramPipe below) -------------------------------------------------------------------
+  // Round 5's gram16 issued its six dependent MFMAs back to back and read the result at once: a wave issues in order, so it stood still for the whole chain
+  // (six 8-pass instructions, 32 cycles each, plus the result latency) -- 0.5 % gained of the 5 % the removed instructions were worth.  Here the chain is a job the caller
+  // feeds one MFMA at a time (gram_mfma<K>, K = 0 .. 5) between pieces of independent VALU work -- the next row's coefficients -- and collects much later
+  // (gram_collect: the 16-swap block transpose of gram16), when the matrix cores have long finished.  Each step is fenced by scheduling barriers: the compiler
+  // keeps the work between two steps between them.  Same arithmetic as gram16 (exact float32, accumulation order k = 0 .. 5 from zero).
+  static constexpr bool kGramPipe = false;
+  struct GramAcc { ll_f16v v; };
+  template <int K_>
+  static LL_D void gram_mfma(GramAcc& a, F x, F y) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (K_ == 0) {
+      ll_f16v z;
+      for (int i = 0; i < 16; i++) z[i] = 0.0f;
+      a.v = __builtin_amdgcn_mfma_f32_16x16x1f32(x, y, z, 0, 0, 0);
+    } else {
+      a.v = __builtin_amdgcn_mfma_f32_16x16x1f32(x, y, a.v, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // g[L] = sum_k y[k] * (x[k] of lane L of my row): the finished accumulator's 4 x 4 block transpose between register block and row group (see gram16)
+  static LL_D void gram_collect(const GramAcc& a, F* g) {
+    unsigned R[16];
+    for (int i = 0; i < 16; i++) R[i] = __float_as_uint(a.v[i]);
+    for (int r = 0; r < 4; r++) {
+      const auto p = __builtin_amdgcn_permlane32_swap(R[r], R[8 + r], true, false); R[r] = p[0]; R[8 + r] = p[1];
+      const auto q = __builtin_amdgcn_permlane32_swap(R[4 + r], R[12 + r], true, false); R[4 + r] = q[0]; R[12 + r] = q[1];
+    }
+    for (int r = 0; r < 4; r++) {
+      const auto p = __builtin_amdgcn_permlane16_swap(R[r], R[4 + r], true, false); R[r] = p[0]; R[4 + r] = p[1];
+      const auto q = __builtin_amdgcn_permlane16_swap(R[8 + r], R[12 + r], true, false); R[8 + r] = q[0]; R[12 + r] = q[1];
+    }
+    for (int i = 0; i < 16; i++) g[i] = __uint_as_float(R[i]);
+  }
   // Four Gauss-Seidel turns (lanes S, 4+S, 8+S, 12+S) as one block: v_med3 (clamp the pending increment), v_cndmask (the lane
   // whose turn it is keeps its increment; masks m0..m3 are the lane masks of the four turns), one wait state, v_fmac with a
   // DPP row broadcast (every lane's pending increment moves by nk * d).  4 issue slots per turn.
@@ -726,6 +760,13 @@ template <class Base, int N>
 struct WithRayChunk : Base {
   using Base::Base;
   static constexpr int kRayChunk = N;
+};
+
+// the Gram blocks of the contact rows as a background job of the matrix cores (GpuLanes::gram_mfma / gram_collect; pmc_step.hpp contact_rows_cone_piped): per kernel by A/B (llenv.hip LL_GRAM_PIPE*)
+template <class Base>
+struct WithGramPipe : Base {
+  using Base::Base;
+  static constexpr bool kGramPipe = true;
 };
 
 // the cone round keeps its cross scalars in the row's LDS scratch instead of 32 registers (the two-waves-per-SIMD PMC / EPMC builds and the

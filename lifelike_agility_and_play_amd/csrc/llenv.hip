@@ -68,7 +68,11 @@ typedef GpuLanesPinned<LC_COUNT> GpuLanes1;                   // the per-leg tab
 #ifndef LL_RELOAD_SEPMC2
 #define LL_RELOAD_SEPMC2 1      // (with the episode scalars parked in LDS the re-read pays here too: 32768 arenas 14.8 -> 16.0 M robot-steps/s)
 #endif
-typedef GpuLanesPinned<LC_COUNT, LL_PIN_PMC ? 7 : 0, LL_PIN_PMC ? BC_COUNT : 0, LL_PIN_PMC ? LK_BASE : 0> GpuLanesPmc1;  // PMC at one wave per SIMD: candidate fields and base constants too
+#ifndef LL_GRAM_PIPE_PMC1
+#define LL_GRAM_PIPE_PMC1 1     // the one-wave-per-SIMD PMC cone kernels form the Gram blocks of their contact rows on the matrix cores, in the background (lanes.hpp WithGramPipe)
+#endif
+typedef GpuLanesPinned<LC_COUNT, LL_PIN_PMC ? 7 : 0, LL_PIN_PMC ? BC_COUNT : 0, LL_PIN_PMC ? LK_BASE : 0> GpuLanesPmc1Plain;  // PMC at one wave per SIMD: candidate fields and base constants too
+typedef std::conditional<LL_GRAM_PIPE_PMC1 != 0, WithGramPipe<GpuLanesPmc1Plain>, GpuLanesPmc1Plain>::type GpuLanesPmc1;
 
 // PLE:235-240 for the batch, by one wavefront: fold the statistics published by finished episodes into the per-clip table
 // (lane = clip, 64 per pass), then rebuild p ~ (1 - avg_reward_sum)^factor and its inclusive CDF.  Called by the last
@@ -239,9 +243,11 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
       asm volatile("" : "+v"(env));      // ... and no address of the step's ~150 loads and stores either (they all derive from env)
       if (env < P.n_envs) {
         float act[3];
+        PMC_PHASE("step.actions");
         step_actions(P, ln, lds, env, sl, act);
         Pmc<Lanes>::template step_env<OBST, CONE>(ln, P, env, act, sl);
       }
+      PMC_PHASE("step.table_fold");
       const StepParams& Pr = kernarg_params();      // (re-read from the kernarg segment like the step itself: nothing of it is parked in spilled SGPRs across the step)
       step_done_fold(Pr, sl, sl == Pr.n_steps - 1, true);
     }
@@ -377,6 +383,11 @@ __global__ void pmc_actions_kernel(StepParams P, float* actions, float sigma) {
   reinterpret_cast<float4*>(actions)[gid] = random_action_group(P, (uint32_t)gid, sigma);
 }
 
+#if defined(LL_KERNELS_ONLY)
+// A listing of ONE step kernel (tools/issue_ledger.py, tools/isa_stats.py --one): -DLL_KERNELS_ONLY='pmc_step_kernel<1, false, true, true>(StepParams)' compiles that
+// instantiation alone, in seconds instead of minutes.  No library is built this way.
+template __global__ void LL_KERNELS_ONLY;
+#else
 struct HipBackend {
   int device;
   hipStream_t own = nullptr, stream = nullptr;
@@ -589,3 +600,4 @@ typedef SepmcEngine<HipBackend> SEPMC_ENGINE;
 #include "sepmc_capi.inc"
 #include "pmc_policy.inc"
 #include "xfer_capi.inc"
+#endif  // LL_KERNELS_ONLY

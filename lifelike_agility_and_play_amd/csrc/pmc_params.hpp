@@ -69,6 +69,14 @@ enum BaseConst {
 #define PMC_TS_SLOTS 0
 #define PMC_TS(k) do { } while (0)
 #endif
+// Static phase marks (tools/issue_ledger.py compiles an assembly LISTING with -DPMC_MARKS; no library is ever built with it): a comment in the instruction stream where a
+// phase of the step begins, fenced by a scheduling barrier so that the instructions of a phase stay between its marks.  The ledger attributes the static instructions of the
+// listing to phases with them (profiles/r06_issue_ledger.md); the shipped build has no marks and schedules across these points, so the marked listing is a close cousin, not the same code.
+#if defined(PMC_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+#define PMC_PHASE(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; LLPHASE " name ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PMC_PHASE(name) do { } while (0)
+#endif
 
 #define LL_MAX_STEPS_PER_LAUNCH 128   // control steps one launch of ll_step_random_n runs at most (longer calls are split); sizes the per-step table slots
 

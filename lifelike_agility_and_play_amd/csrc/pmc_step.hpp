@@ -708,6 +708,140 @@ struct Pmc {
     rw.inv = lm::sel(cvalid, ln.lane_f(1.0f) / nn, ln.lane_f(0.0f));
     finish_row<false>(ln, rw, gt, jt);
   }
+  // ---- the three rows of a contact with their five Gram blocks on the matrix cores, in the background (lane policies with kGramPipe: lanes.hpp WithGramPipe) ----
+  // Same rows, same scalars as contact_row x 3 + cross_gram x 2; what changes is WHO forms the base part of the Gram scalars and WHEN: the six MFMAs of a block
+  // are issued one at a time between pieces of the NEXT row's coefficient arithmetic (row_coeffs' tick points), the blocks of the last row and the two cross blocks
+  // between the pieces of the rows' own finishing work, and every block is collected (16 register swaps) long after the matrix cores have finished it.
+  struct RowCo { F gt[6], jt[3]; };                     // a row's whitened coefficients
+  struct NoTick { template <int K_> LL_HD void at() const {} };
+  struct GramTick {                                      // one block in the background: acc += outer(x[K], y[K]) at tick point K
+    typename L::GramAcc& a;
+    const F* x;
+    const F* y;
+    template <int K_> LL_HD void at() const { L::template gram_mfma<K_>(a, x[K_], y[K_]); }
+  };
+  // contact_row up to the whitened coefficients gt[6], jt[3], c and inv; tk.at<0..5>() are spread over its ~110 instructions
+  template <class TK>
+  static LL_HD void row_coeffs(const L& ln, Row& rw, RowCo& co, const V3l& uu, const V3l& Pb, const V3l& d1, const V3l& d2, const V3l& d3, const LegFactor& lf,
+                               const float* Sb, const float* Sd, const float* xi, const F* qs, const F& bias, const B& cvalid, const TK& tk) {
+    F* gt = co.gt;
+    F* jt = co.jt;
+    jt[0] = dot(uu, d1); jt[1] = dot(uu, d2); jt[2] = dot(uu, d3);
+    V3l pxu = cross(Pb, uu);
+    tk.template at<0>();
+    F vrow = pxu.x * xi[0] + pxu.y * xi[1] + pxu.z * xi[2] + uu.x * xi[3] + uu.y * xi[4] + uu.z * xi[5] + jt[0] * qs[0] + jt[1] * qs[1] + jt[2] * qs[2];
+    lm_fwd(lf, jt);
+    tk.template at<1>();
+    SV<F> yj = scale(lf.y1, jt[0]) + scale(lf.y2, jt[1]) + scale(lf.y3, jt[2]);
+    tk.template at<2>();
+    gt[0] = pxu.x - yj.a.x; gt[1] = pxu.y - yj.a.y; gt[2] = pxu.z - yj.a.z;
+    gt[3] = uu.x - yj.l.x; gt[4] = uu.y - yj.l.y; gt[5] = uu.z - yj.l.z;
+    for (int i = 0; i < 4; i++) {                        // fwd6, rows 0 .. 3
+      F sacc = gt[i];
+      for (int k = 0; k < i; k++) sacc = sacc - gt[k] * Sb[i * (i + 1) / 2 + k];
+      gt[i] = sacc * Sd[i];
+    }
+    tk.template at<3>();
+    for (int i = 4; i < 6; i++) {                        // fwd6, rows 4, 5
+      F sacc = gt[i];
+      for (int k = 0; k < i; k++) sacc = sacc - gt[k] * Sb[i * (i + 1) / 2 + k];
+      gt[i] = sacc * Sd[i];
+    }
+    tk.template at<4>();
+    F nn = jt[0] * jt[0] + jt[1] * jt[1] + jt[2] * jt[2];
+    for (int i = 0; i < 6; i++) nn = nn + gt[i] * gt[i];
+    rw.c = vrow + bias;
+    rw.inv = lm::sel(cvalid, ln.lane_f(1.0f) / nn, ln.lane_f(0.0f));
+    tk.template at<5>();
+  }
+  static LL_HD void neg_scaled(const L& ln, const F& inv, const RowCo& co, F* yg, F* yj) {      // finish_row's yg, yj: the coefficients times -inv
+    F ninv = ln.lane_f(0.0f) - inv;
+    for (int i = 0; i < 6; i++) yg[i] = co.gt[i] * ninv;
+    for (int i = 0; i < 3; i++) yj[i] = co.jt[i] * ninv;
+  }
+  static LL_HD void joint_part(const F* yj, const F* jt_oth, F* nj) {                             // the rows of one leg also meet in its joints (finish_row's nj)
+    nj[0] = yj[0] * L::template subbcast<0>(jt_oth[0]) + yj[1] * L::template subbcast<0>(jt_oth[1]) + yj[2] * L::template subbcast<0>(jt_oth[2]);
+    nj[1] = yj[0] * L::template subbcast<1>(jt_oth[0]) + yj[1] * L::template subbcast<1>(jt_oth[1]) + yj[2] * L::template subbcast<1>(jt_oth[2]);
+    nj[2] = yj[0] * L::template subbcast<2>(jt_oth[0]) + yj[1] * L::template subbcast<2>(jt_oth[1]) + yj[2] * L::template subbcast<2>(jt_oth[2]);
+    nj[3] = yj[0] * L::template subbcast<3>(jt_oth[0]) + yj[1] * L::template subbcast<3>(jt_oth[1]) + yj[2] * L::template subbcast<3>(jt_oth[2]);
+  }
+  // out[L] = (base part, collected from the matrix cores) + [leg of L == my leg] nj[L & 3]
+  static LL_HD void gram_finish(const typename L::GramAcc& a, const F* lf4, const F* nj, F* out) {
+    F d[16];
+    L::gram_collect(a, d);
+    for (int L_ = 0; L_ < 16; L_++) out[L_] = d[L_] + lf4[L_ >> 2] * nj[L_ & 3];
+  }
+  static LL_HD void row_perm_a(const L& ln, Row& r, const RowCo& co) {                             // finish_row's lane-permuted coefficients, in two pieces
+    F t[4];
+    permute4(ln, co.gt[0], co.gt[1], co.gt[2], co.gt[3], t);
+    r.ca01 = L::pair(t[0], t[1]); r.ca23 = L::pair(t[2], t[3]);
+    r.lam = ln.lane_f(0.0f);
+  }
+  static LL_HD void row_perm_b(const L& ln, Row& r, const RowCo& co) {
+    F t[4];
+    B odd = lm::odd_(ln.sub());
+    r.cb01 = L::pair(lm::sel(odd, co.gt[5], co.gt[4]), lm::sel(odd, co.gt[4], co.gt[5]));
+    permute4(ln, co.jt[0], co.jt[1], co.jt[2], ln.lane_f(0.0f), t);
+    r.cj01 = L::pair(t[0], t[1]); r.cj23 = L::pair(t[2], t[3]);
+  }
+  static LL_HD void contact_rows_cone_piped(const L& ln, Row& rn, Row& r1, Row& r2, ConeX& cx, const V3l& un, const V3l& ut1, const V3l& ut2, const V3l& Pb,
+                                            const V3l& d1, const V3l& d2, const V3l& d3, const LegFactor& lf, const float* Sb, const float* Sd, const float* xi,
+                                            const F* qs, const F& bias, const B& cvalid) {
+    const F zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f);
+    RowCo cn, c1, c2;
+    F ygn[6], yjn[3], yg1[6], yj1[3], yg2[6], yj2[3];
+    typename L::GramAcc an, a1, a2, a12, a21;
+    row_coeffs(ln, rn, cn, un, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, bias, cvalid, NoTick());
+    neg_scaled(ln, rn.inv, cn, ygn, yjn);
+    row_coeffs(ln, r1, c1, ut1, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid, GramTick{an, cn.gt, ygn});      // block (n, n) behind the t1 row's arithmetic
+    neg_scaled(ln, r1.inv, c1, yg1, yj1);
+    row_coeffs(ln, r2, c2, ut2, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid, GramTick{a1, c1.gt, yg1});      // block (t1, t1) behind the t2 row's
+    neg_scaled(ln, r2.inv, c2, yg2, yj2);
+    // the last three blocks -- (t2, t2), n12 = (t1 against the t2 rows), n21 = (t2 against the t1 rows) -- behind the rows' finishing work, round robin
+    const F lf4[4] = {lm::sel(ln.is_leg(0), one, zero), lm::sel(ln.is_leg(1), one, zero), lm::sel(ln.is_leg(2), one, zero), lm::sel(ln.is_leg(3), one, zero)};
+    F njn[4], nj1[4], nj2[4], nj12[4], nj21[4];
+#define LL_TK3(K_) do { L::template gram_mfma<K_>(a2, c2.gt[K_], yg2[K_]); } while (0)
+#define LL_TK12(K_) do { L::template gram_mfma<K_>(a12, c2.gt[K_], yg1[K_]); } while (0)
+#define LL_TK21(K_) do { L::template gram_mfma<K_>(a21, c1.gt[K_], yg2[K_]); } while (0)
+    LL_TK3(0);
+    joint_part(yjn, cn.jt, njn);
+    LL_TK12(0);
+    gram_finish(an, lf4, njn, rn.nk);                                   // (n, n): finished two rows ago
+    LL_TK21(0);
+    row_perm_a(ln, rn, cn);
+    LL_TK3(1);
+    row_perm_b(ln, rn, cn);
+    LL_TK12(1);
+    joint_part(yj1, c1.jt, nj1);
+    LL_TK21(1);
+    joint_part(yj2, c2.jt, nj2);
+    LL_TK3(2);
+    row_perm_a(ln, r1, c1);
+    LL_TK12(2);
+    row_perm_b(ln, r1, c1);
+    LL_TK21(2);
+    joint_part(yj1, c2.jt, nj12);
+    LL_TK3(3);
+    joint_part(yj2, c1.jt, nj21);
+    LL_TK12(3);
+    row_perm_a(ln, r2, c2);
+    LL_TK21(3);
+    row_perm_b(ln, r2, c2);
+    LL_TK3(4);
+    LL_TK12(4);
+    LL_TK21(4);
+    gram_finish(a1, lf4, nj1, r1.nk);                                   // (t1, t1): finished a row ago
+    LL_TK3(5);
+    LL_TK12(5);
+    LL_TK21(5);
+#undef LL_TK3
+#undef LL_TK12
+#undef LL_TK21
+    gram_finish(a2, lf4, nj2, r2.nk);
+    gram_finish(a12, lf4, nj12, cx.n12);
+    gram_finish(a21, lf4, nj21, cx.n21);
+  }
+
   // LR:137-141: tau = kp (target - q) + kd (0 - qd), clipped to +-max_tau -- the `forces=` the reference hands to
   // setJointMotorControlArray(TORQUE_CONTROL) before every stepSimulation (golden G8; ll_probe_pd_torque runs exactly this)
   static LL_HD void pd_torque(const L& ln, const StepParams& P, const F* q, const F* qd, const F* tgt, F* tau, float max_tau = 0.0f) {
@@ -750,6 +884,7 @@ struct Pmc {
   static LL_HD void substep_impl(const L& ln, const StepParams& P_in, Base& bs, F* q, F* qd, const F* tgt, int env, int sidx, const SubstepExtra* ex,
                                  const LinkC* held) {   // held: the own-link constants if the caller keeps them in registers, or null
 #define PMC_TSS(k) do { if (sidx == 5) PMC_TS(k); } while (0)
+    PMC_PHASE("sub.kinematics");
     const StepParams& P = (L::kParamsReload > 1) ? ln.params(P_in) : P_in;
     const float* legc = P.legc;
     const float* bc = P.basec;
@@ -851,6 +986,7 @@ struct Pmc {
     lf.y3 = scale(F3 + scale(lf.y1, zero - lf.l31) + scale(lf.y2, zero - lf.l32), lf.i33);
 
     PMC_TSS(21);
+    PMC_PHASE("sub.base_factor");
     // --- base: S = I_base + sum I^c_leg - sum Y Y^T ; packed lower triangle, index order [wx wy wz vx vy vz] ----
     float Sb[21], Sd[6];
     {
@@ -880,6 +1016,7 @@ struct Pmc {
     }
 
     PMC_TSS(22);
+    PMC_PHASE("sub.free_accel");
     // --- unconstrained accelerations ---------------------------------------------------------------------------
     lm_fwd(lf, b);                                              // bt = Lm^-1 (tau - C_l)
     SV<F> z = scale(lf.y1, b[0]) + scale(lf.y2, b[1]) + scale(lf.y3, b[2]);
@@ -923,6 +1060,7 @@ struct Pmc {
     clip_velocities(ln, xi, qs, vmax);
 
     PMC_TSS(23);
+    PMC_PHASE("sub.candidates");
     // --- contact candidates (DESIGN.md "contact candidates"): 28 points per leg, 7 per sub-lane, grouped by link --------------
     //   jj 0..3 -> group A, 4..5 -> group B, 6 -> group C;  links  A: [3,3,2,2]  B: [2,2,2,1]  C: [3,0,0,0]  by sub-lane
     const float inv_dt = 1.0f / dt;
@@ -1017,6 +1155,7 @@ struct Pmc {
         ex->touch_flag = L::rmin(tch_fl) < 0.5f ? 1.0f : 0.0f;
       }
     }
+    PMC_PHASE("sub.selection");
     // the leg keeps its 4 deepest candidates, slot s = s-th pick: four rounds of (quad min, claim).  Candidates within LLM_SELECT_EPS of
     // the deepest count as equally deep and the lowest candidate index (sub-lane, then position) wins: symmetric poses put several
     // points at the same depth up to rounding, and which of them is kept must not depend on the arithmetic.
@@ -1071,6 +1210,7 @@ struct Pmc {
     const bool any_contact = any_c[0] || any_c[1] || any_c[2] || any_c[3];
 
     PMC_TSS(24);
+    PMC_PHASE("sub.limit_rows");
     // --- rows -------------------------------------------------------------------------------------------------------------------
     Row rl, rn, r1, r2;
     ConeX cx;                          // (CONE builds only; otherwise never touched and never allocated)
@@ -1104,9 +1244,13 @@ struct Pmc {
       rl.inv = lm::sel(lvalid, one / nn, zero);
       any_l[0] = L::any(lm::and_(lvalid, ln.is_sub(0))); any_l[1] = L::any(lm::and_(lvalid, ln.is_sub(1)));
       any_l[2] = L::any(lm::and_(lvalid, ln.is_sub(2)));
-      if (any_l[0] || any_l[1] || any_l[2]) finish_row<true>(ln, rl, lgt, ljt);
+      if (any_l[0] || any_l[1] || any_l[2]) {
+        PMC_PHASE("sub.limit_gram");
+        finish_row<true>(ln, rl, lgt, ljt);
+      }
     }
     PMC_TSS(25);
+    PMC_PHASE("sub.contact_geometry");
     if (any_contact) {
       // geometry of this lane's contact: candidate (my_sub, my_jj) of the leg, re-evaluated from the table
       // (a reverse candidate, jj = 8, has no table entry: it reads entry 7's and replaces what it needs below)
@@ -1212,7 +1356,11 @@ struct Pmc {
         ut1 = mk3<F>(lm::sel(slides, a1.x, ut1.x), lm::sel(slides, a1.y, ut1.y), lm::sel(slides, a1.z, ut1.z));
         ut2 = mk3<F>(lm::sel(slides, a2.x, ut2.x), lm::sel(slides, a2.y, ut2.y), lm::sel(slides, a2.z, ut2.z));
       }
+      PMC_PHASE("sub.contact_rows");
       // rows n = +z, t1 = -y, t2 = +x (world), expressed in F0
+      if constexpr (CONE && L::kGramPipe && !L::kConeInLds) {
+        contact_rows_cone_piped(ln, rn, r1, r2, cx, un, ut1, ut2, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, bias, cvalid);
+      } else {
       contact_row(ln, rn, un, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, bias, cvalid);
       if (CONE) {
         F g1[6], j1[3], g2[6], j2[3];
@@ -1229,8 +1377,10 @@ struct Pmc {
         contact_row(ln, r1, ut1, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid);
         contact_row(ln, r2, ut2, Pb, d1, d2, d3, lf, Sb, Sd, xi, qs, zero, cvalid);
       }
+      }
     }
 
+    PMC_PHASE("sub.self_detect");
     // --- self-collision (LR:212-217: links of different legs): each leg is two capsules, the closest pairs within the
     //     margin give up to two frictionless rows.  Lane (leg g, sub s) tests capsule (s & 2 ? shank : thigh) of its own leg against
     //     capsule (s & 1 ? shank : thigh) of the previous leg, and -- legs 0 and 1 only -- of the leg two away: 24 pairs in two passes.
@@ -1286,6 +1436,7 @@ struct Pmc {
       }
       any_self = L::any(lm::min_(cd[0], cd[1]) < 1.0e29f) && !PMC_ABL(256) && P.max_self > 0;          // (ablation 256: detection only)
       if (any_self) {
+        PMC_PHASE("sub.self_rows");
         LL_UNROLL
         for (int slot = 0; slot < 2; slot++) {
           if (slot >= P.max_self) break;                                             // (spec override LLM_SPEC_MAX_SELF)
@@ -1514,6 +1665,7 @@ struct Pmc {
       }
     }
     PMC_TSS(26);
+    PMC_PHASE("sub.pgs_setup");
 #if defined(PMC_ABLATION)
     if (PMC_ABL(16) && ln.is_lane(0)) P.counters[4 + (long)env * PMC_TS_SLOTS + 28] += (unsigned long long)(any_self ? 1 : 0);
     if (PMC_ABL(16) && ln.is_lane(0)) {   // solver occupancy: active 4-turn blocks of this wave, contact and limit
@@ -1529,10 +1681,13 @@ struct Pmc {
     ln.prepare_turn_masks();
     LL_NOUNROLL
     for (int it = 0; it < P.n_iter; it++) {
+      PMC_PHASE("pgs.limit_round");
       if (any_limit) gs_round<true, true>(ln, rl, big, VA, VB, VJ);
+      PMC_PHASE("pgs.normal_round");
       if (any_contact) {
         gs_round<false, true>(ln, rn, big, VA, VB, VJ);
         F hi = mu * rn.lam;
+        PMC_PHASE("pgs.cone_round");
         if (CONE) {
           gs_cone_round(ln, r1, r2, cx, hi, VA, VB, VJ);
         } else {
@@ -1540,6 +1695,7 @@ struct Pmc {
           gs_round<false, false>(ln, r2, hi, VA, VB, VJ);
         }
       }
+      PMC_PHASE("pgs.self_turns");
       if (any_self) {                                                        // then the self-collision rows, one after the other
         self_turn(ln, sr[0], VA, VB, VJ);
         if (n_self_w > 1) self_turn(ln, sr[1], VA, VB, VJ);
@@ -1553,6 +1709,7 @@ struct Pmc {
     }
 
     PMC_TSS(27);
+    PMC_PHASE("sub.integrate");
     // back to velocities: d(xi) = Lb^-T dx ; d(qd) = Lm^-T (dq - Y^T d(xi))
     float dx[6] = {L::template vel_dx<0>(VA, VB), L::template vel_dx<1>(VA, VB), L::template vel_dx<2>(VA, VB),
                    L::template vel_dx<3>(VA, VB), L::template vel_dx<4>(VA, VB), L::template vel_dx<5>(VA, VB)};
@@ -1870,6 +2027,7 @@ struct Pmc {
     Base bs;
     F q[3], qd[3], act[3], tgt[3];
     PMC_TS(0);
+    PMC_PHASE("step.entry_loads");
     if (PMC_ABL(8)) return;
     load_state(ln, P.state, N, env, bs, q, qd);
     for (int j = 0; j < 3; j++) act[j] = act_in[j];
@@ -1903,6 +2061,7 @@ struct Pmc {
     LinkC lkh;
     const LinkC* held = nullptr;
     if (L::kHoldLink) { lkh = own_link_held(ln, P.legc); held = &lkh; }
+    PMC_PHASE("step.substep_loop");
     for (int s = 0; s < P.n_sub; s++) {                                      // PLE:202
       if (OBST) substep_impl<true, false, CONE>(ln, P, bs, q, qd, tgt, env, s, &ex, held);
       else substep_impl<false, false, CONE>(ln, P, bs, q, qd, tgt, env, s, nullptr, held);   // PLE:204-206
@@ -1910,6 +2069,7 @@ struct Pmc {
       t += P.dt_d;                                                           // PLE:210
     PMC_TS(10 + (s < 20 ? s : 20));
     }
+    PMC_PHASE("tail.mocap_gather");
     if (PMC_ABL(4)) { store_state(ln, P.state, N, env, bs, q, qd); P.time[env] = t; return; }
     int fid = (int)floor(t_loc / P.frame_step);                              // ML:66
     {                                                                        // keep a done-but-still-stepped env inside its clip
@@ -1939,6 +2099,7 @@ struct Pmc {
     RefPose rp = mocap_finish(rr, P.frame_step, true);
 
     PMC_TS(2);
+    PMC_PHASE("tail.reward");
     if (P.scripted_state) {   // parity hook: the caller plays PyBullet (how the golden harness drove the reference)
       const float* ss = P.scripted_state + (long)env * 37;
       bs.p = mk3<float>(ss[0], ss[1], ss[2]);
@@ -1985,6 +2146,7 @@ struct Pmc {
     if (bad) reward = 0.0f;
 
     PMC_TS(3);
+    PMC_PHASE("tail.termination");
     // --- termination (PLE:337-348) ---
     int reason = 0;
     {
@@ -1995,13 +2157,16 @@ struct Pmc {
       if (fabsf(angle) > 1.0f || e_p > 1.0f) reason |= LLS_DONE_DIVERGED;     // PLE:319-335
       if (bad) reason |= LLS_DONE_NONFINITE;
       if (P.set_obstacle && !bad) {
+        PMC_PHASE("tail.obstacle_check");
         LegKin kf = leg_fk(ln, P.legc, q[0], q[1], q[2]);
         if (obstacle_contact(ln, P, env, clip, t, bs.p, R, kf)) reason |= LLS_DONE_COLLISION;   // PLE:341-346
       }
     }
+    PMC_PHASE("tail.termination_end");
     const float rsum = rsum0 + reward;                                        // PLE:231
 
     PMC_TS(4);
+    PMC_PHASE("tail.unroll_row");
     // --- this transition's row of the env's unroll (distill_actor.py:118-162): the observation the policy acted on
     //     in the learner's flatten order (future first: dict keys sorted), its action, neglogp and value as the policy reported
     //     them, the reward and the not-done mask; R is filled in by ll_finish_unroll.  Written before the obs row is replaced. ---
@@ -2021,6 +2186,7 @@ struct Pmc {
     }
 
     PMC_TS(5);
+    PMC_PHASE("tail.episode_bookkeeping");
     // --- end of episode (PLE:235-240): publish the per-clip statistics; the last workgroup of the kernel folds them into the
     //     table (highest env index wins when several envs finish the same clip in one step == sequential overwrite order) ---
     int steps_out = steps, clip_out = clip;
@@ -2029,6 +2195,7 @@ struct Pmc {
     F oq[3] = {q[0], q[1], q[2]}, oqd[3] = {qd[0], qd[1], qd[2]}, oact[3] = {act[0], act[1], act[2]};
     F gjp[3] = {rp.jp[0], rp.jp[1], rp.jp[2]}, gjv[3] = {rp.jv[0], rp.jv[1], rp.jv[2]};
     if (reason) {
+      PMC_PHASE("tail.episode_end_reseed");
       float avg_r = (float)((double)rsum / max_steps), avg_l = (float)((double)steps / (max_steps + 1.0));
       if (bad) avg_r = 0.0f;
       // (every control step of a launch has its own slots -- folded by the last wave to finish that step, in step order: the later step wins, then
@@ -2073,9 +2240,11 @@ struct Pmc {
       }
     }
     PMC_TS(6);
+    PMC_PHASE("tail.obs_row");
     // --- observation (PLE:227), state, ghost, feet, bookkeeping ---
     obs_emit(ln, P, row, fill, oin, bs, R, oq, oqd, oact);
     PMC_TS(8);
+    PMC_PHASE("tail.state_stores");
     store_state(ln, P.state, N, env, bs, oq, oqd);
     store_state(ln, P.kin, N, env, gb, gjp, gjv);
     PMC_TS(9);

@@ -13,6 +13,7 @@
 #include "../../lifelike_agility_and_play_amd/csrc/pmc_step.hpp"
 
 typedef Pmc<HostLanes> K;
+typedef WithGramPipeHost<HostLanes> HostLanesPipe;      // what the one-wave-per-SIMD PMC cone kernels run (LL_EMUL_GRAM_PIPE): the contact rows' Gram blocks as a background job (lanes.hpp WithGramPipe)
 typedef WithConeInLdsHost<HostLanes> HostLanesLds;      // what the larger-batch GPU builds run (LL_EMUL_PARK): the cone round's cross scalars through the row scratch
 
 struct HostBackend {
@@ -40,6 +41,11 @@ struct HostBackend {
           HostLanesLds lq(P.candc);
           if (P.set_obstacle) Pmc<HostLanesLds>::step_env<true, true>(lq, P, env, act, sl);
           else Pmc<HostLanesLds>::step_env<false, true>(lq, P, env, act, sl);
+        }
+        else if (P.friction_mode == 2 && getenv("LL_EMUL_GRAM_PIPE")) {
+          HostLanesPipe lq(P.candc);
+          if (P.set_obstacle) Pmc<HostLanesPipe>::step_env<true, true>(lq, P, env, act, sl);
+          else Pmc<HostLanesPipe>::step_env<false, true>(lq, P, env, act, sl);
         }
         else if (P.set_obstacle && P.friction_mode == 2) K::step_env<true, true>(ln, P, env, act, sl);
         else if (P.set_obstacle) K::step_env<true>(ln, P, env, act, sl);

@@ -174,6 +174,13 @@ struct HostLanes {
       for (int i = 0; i < 6; i++) for (int l = 0; l < EW; l++) g[L_].v[l] = g[L_].v[l] + x[i].v[L_] * y[i].v[l];
     }
   }
+  // lanes.hpp GpuLanes::gram_mfma / gram_collect (WithGramPipe): the same sums, one k at a time, in the order the MFMA chain accumulates
+  static constexpr bool kGramPipe = false;           // (emul.cpp runs the piped variant under LL_EMUL_GRAM_PIPE)
+  struct GramAcc { fN g[EW]; };
+  template <int K_> static void gram_mfma(GramAcc& a, const F& x, const F& y) {
+    for (int L_ = 0; L_ < EW; L_++) for (int l = 0; l < EW; l++) a.g[L_].v[l] = (K_ == 0 ? 0.0f : a.g[L_].v[l]) + x.v[L_] * y.v[l];
+  }
+  static void gram_collect(const GramAcc& a, F* g) { for (int L_ = 0; L_ < EW; L_++) g[L_] = a.g[L_]; }
   template <int S_> static void gram4(const F* x, const F* y, F* g) {
     for (int t = 0; t < 4; t++) {
       const int L_ = 4 * t + S_;
@@ -281,6 +288,13 @@ struct HostLanes {
   static F d2f(const D& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = (float)x.v[i]; return r; }
   static F i2f(const I& x) { fN r; for (int i = 0; i < EW; i++) r.v[i] = (float)x.v[i]; return r; }
   static I f2i(const F& x) { iN r; for (int i = 0; i < EW; i++) r.v[i] = (int)x.v[i]; return r; }
+};
+
+// lanes.hpp WithGramPipe for the host lanes (emul.cpp: LL_EMUL_GRAM_PIPE runs the contact rows through the piped Gram statement)
+template <class Base>
+struct WithGramPipeHost : Base {
+  using Base::Base;
+  static constexpr bool kGramPipe = true;
 };
 
 // lanes.hpp WithConeInLds for the host lanes (emul.cpp: LL_EMUL_PARK runs the cone round's cross scalars through the row scratch)

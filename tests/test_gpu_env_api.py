@@ -281,6 +281,37 @@ def test_bench_eight_ranks_on_one_device():
             f.write(raw + '\n')
 
 
+def test_bench_eight_ranks_one_rank_killed():
+    """The N > 1 failure path (round-5 review #6): `python bench.py --gpus 8` with rank 5 killed without a word after the warm-up (LL_BENCH_KILL_RANK test
+    hook: SIGKILL at the start of the timed phase).  The launch must end non-zero within the launcher's own patience, and ONE JSON error line must reach
+    stdout -- from whichever surviving rank noticed first -- naming its rank and the phase, instead of a bare time-out."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import time
+    torch_cuda()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', LL_BENCH_KILL_RANK='5', LL_BENCH_KILL_PHASE='timed', LL_BENCH_PG_TIMEOUT_S='60', LL_BENCH_STALL_S='90', **ONE_DEVICE)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '256', '--warmup', '128', '--envs-per-gpu', '512'], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=900)
+    took = time.time() - t0
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')]
+    assert out.returncode != 0, out.stdout[-2000:]
+    assert len(lines) == 1, (out.stdout[-3000:], out.stderr[-3000:])
+    j = lines[0]
+    assert 'error' in j and j['value'] is None and j['world'] == 8 and j['rank'] in range(8) and j['rank'] != 5, j
+    assert j['phase'] in ('timed', 'gather', 'warmup'), j                      # (a survivor is told while it is stepping or waiting in the barrier behind the warm-up)
+    print('killed rank 5 -> error line from rank %d in phase %s after %.0f s: %s' % (j['rank'], j['phase'], took, j['error'][:160]))
+    log_dir = os.path.join(root, 'gpurun_out', 'two_rank')
+    os.makedirs(log_dir, exist_ok=True)
+    with open(os.path.join(log_dir, 'bench_eight_ranks_one_killed.json'), 'w') as f:
+        f.write(out.stdout)
+
+
 def test_gather_overlaps_with_the_next_unroll():
     """An overlap measurement that can fail: the same two-rank run three times -- without the gather (the steps alone), with every gather
     waited for before the next step is launched (--gather-mode blocking), and as shipped (async, double-buffered).  Blocking costs the

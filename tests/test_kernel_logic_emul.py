@@ -217,5 +217,41 @@ def test_cone_scalars_through_the_row_scratch_equal_registers(model_blob, mocap_
         A.close(); B.close()
 
 
+def test_gram_blocks_as_a_background_job_equal_the_shuffle_statement(orc, model_blob, mocap_table, emul_lib):
+    """lanes.hpp WithGramPipe -- what the one-wave-per-SIMD PMC cone kernels run since round 6: the five Gram blocks of a contact's rows are formed one k at a time
+    (on the GPU: one MFMA at a time, between pieces of the next row's arithmetic) and collected later.  Same scalars up to the order of two additions (the base part is
+    summed from zero and the joint part added last): the host build of the piped statement (LL_EMUL_GRAM_PIPE) stays within float32 rounding of the plain one over
+    25 free-running steps with contacts, and holds the standing bars against the oracle."""
+    import os
+    for kw in (dict(), dict(set_obstacle=1)):
+        A = pc.make_engine(model_blob, mocap_table, 8, emul_lib, seed=3, auto_reset=0, **kw)
+        B = pc.make_engine(model_blob, mocap_table, 8, emul_lib, seed=3, auto_reset=0, **kw)
+        A.reset(); B.reset()
+        worst = 0.0
+        try:
+            for t in range(25):
+                B.set_state(A.state())                               # compare ONE step at a time from identical states (a contact's discontinuities amplify rounding over many)
+                os.environ.pop('LL_EMUL_GRAM_PIPE', None)
+                A.step_random(pc.SIGMA)
+                os.environ['LL_EMUL_GRAM_PIPE'] = '1'
+                B.step_random(pc.SIGMA)
+                sa, sb = A.state(), B.state()
+                vel_scale = 1.0 + np.abs(sa[:, 25:37]).max(axis=1, keepdims=True)
+                worst = max(worst, np.abs(sa[:, :25] - sb[:, :25]).max(), (np.abs(sa[:, 25:37] - sb[:, 25:37]) / vel_scale).max())
+        finally:
+            os.environ.pop('LL_EMUL_GRAM_PIPE', None)
+        print('piped against plain, worst over 25 single steps:', worst)
+        assert worst < 2e-4, worst
+        assert np.abs(A.state()[:, 25:37]).max() > 0.1
+        A.close(); B.close()
+    os.environ['LL_EMUL_GRAM_PIPE'] = '1'
+    try:
+        golden = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'pmc_golden.npz'))
+        st = pc.check_single_step_parity(golden, orc, model_blob, mocap_table, emul_lib, n_envs=16, n_steps=6)
+        print('piped host build against the oracle: config err max %.2e' % st['config'].max())
+    finally:
+        os.environ.pop('LL_EMUL_GRAM_PIPE', None)
+
+
 def test_reset_onto_a_mocap_discontinuity(orc, model_blob, mocap_table, emul_lib):
     print('worst configuration error against the oracle: %.2e' % pc.check_reset_onto_a_mocap_discontinuity(orc, model_blob, mocap_table, emul_lib))

@@ -88,6 +88,7 @@ for KERNEL, prefix, benchlog in (('pmc_step_kernel', '', 'bench.log'), ('epmc_st
     units = int(meta['grid']) // 64 * 4
     spl = int(bench['config'].get('steps_per_launch', 1))          # control steps one launch runs (ll_step_random_n)
     counters['_kernel'] = meta
+    counters['_build'] = bench.get('build')            # hipcc's version and the sha256 of the code object the profiled command ran (bench.py build_record)
     counters['_notes'] = {
         'units': 'mean per launch of %s (%d env rows, %d waves of 4 rows, %d control steps per launch); SQ_*_CYCLES and SQ_ACTIVE/WAIT count quad-cycles summed over waves; '
                  'FETCH_SIZE / WRITE_SIZE in KB' % (KERNEL, units, units // 4, spl),
