@@ -21,6 +21,7 @@
 #define EPMC_BOX_WORDS 8
 #define EPMC_MAX_NEAR 8       // boxes within reach of the robot's contact candidates during one control step
 #define EPMC_EP_STRIDE 40
+#define EPMC_RAY_POSE 16        // floats per row in EpmcParams::ray_pose: pos 3 | R 9 | yaw | noise_z | n_boxes | -
 #define EPMC_LIST_A 320         // row-scratch words: behind the staged box records the three ray lists (height grid, fan, front rays), then 64 spare words.
 #define EPMC_LIST_A_MAX 10      // (PMC_ROW_SCRATCH = 688 words per row is what eight workgroups per CU can afford: 9392 B of tables + 4 x 2752 B <= 160 KB / 8)
 #define EPMC_LIST_B (EPMC_LIST_A + EPMC_LIST_A_MAX * EPMC_BOX_WORDS)
@@ -61,7 +62,8 @@ struct EpmcParams {
   float vforce_lo, vforce_hi, push_ratio, plane_friction;
   float spd_lo, spd_hi, aux_radius, hole_gap_lo;      // aux_radius < 0: no auxiliary cylinders
   float hole_gap_hi, box_friction;                    // lateralFriction of a body made by createMultiBody: Bullet's default 0.5
-  int32_t terrain_contacts, pad2;                     // 0: the boxes are seen by the rays only
+  int32_t terrain_contacts, split_rays;               // terrain_contacts 0: the boxes are seen by the rays only.  split_rays: the 778 rays of the observation are cast by a kernel of
+                                                      // their own behind the step kernel (round 6, percept_rays below): observe() leaves the row's ray pose in ray_pose instead of casting
   int32_t noise_on[4];
   float noise_lo[4], noise_hi[4];
   const float* init_state;  // [37] LeggedRobot.get_init_states_info(), LR:116-117
@@ -72,6 +74,7 @@ struct EpmcParams {
   float* boxes;            // [n_envs][EPMC_MAX_BOXES][8]  x0 x1 y0 y1 z0 z1 - - of what the rays (and later the contacts) see
   float* push_trace;       // [n_envs][n_sub][4]
   float* ray_trace;        // optional [n_envs][778][8]: from 3, to 3, hit, fraction
+  float* ray_pose;         // [n_envs][EPMC_RAY_POSE]: what percept_rays needs of a row (position with its noise, rotation, yaw, height noise, box count)
   // parity hooks (null in production)
   const float* scr_state;    // [n_envs][37]
   const uint8_t* scr_ray_hit;  // [n_envs][778]
@@ -465,6 +468,131 @@ struct Epmc {
       }
     }
   }
+  // ---- the rays as a kernel of their own (round 6; llenv.hip epmc_percept_kernel) ----------------------------------------------------------------------------
+  // Inside the one-wave-per-SIMD step kernel the 3.2 M slab tests of a step run at the lone wave's pace (one instruction per ~5 cycles, nothing to hide a read behind:
+  // 0.043 of the hurdle step's 0.289 ms, profiles/r04_epmc_ray_ablation.txt).  Cast by a second kernel -- a workgroup of four waves per row, sixteen waves per SIMD -- they
+  // are full-rate work.  observe() leaves the row's ray pose (leave_ray_pose), percept_rays() reads it back and writes the three percep arrays of the row: ray r of the row is
+  // taken by worker r_first + k r_stride.  Per ray the arithmetic is observe_rays' own, expression for expression (same helpers); a ray's answer is a minimum / maximum over
+  // boxes, so neither the order of the boxes nor the compact lists of observe_rays (exact pre-selections) change a bit of it: tests hold the two paths equal.
+  static LL_HD void leave_ray_pose(const L& ln, const EpmcParams& E, int row, const float* pos, const M3<float>& R, float yaw, const float* noise, int n_boxes) {
+    if (!ln.lane0()) return;
+    float* rec = E.ray_pose + (long)row * EPMC_RAY_POSE;
+    rec[0] = pos[0]; rec[1] = pos[1]; rec[2] = pos[2];
+    for (int i = 0; i < 9; i++) rec[3 + i] = R.m[i];
+    rec[12] = yaw; rec[13] = noise[3]; rec[14] = (float)n_boxes; rec[15] = 0.0f;
+  }
+  // which of the row's boxes a ray family can meet at all: observe_rays' three bounds tests (family 0 height grid, 1 fan, 2 front rays)
+  struct RayBounds { float hgx, hgy, flo[3], fhi[3]; };
+  static LL_HD RayBounds ray_bounds(const float* pos, const M3<float>& R) {
+    RayBounds b;
+    const float slack = 1.0e-3f;
+    b.hgx = fabsf(R.m[0]) * 1.2f + fabsf(R.m[1]) * 0.6f + slack; b.hgy = fabsf(R.m[3]) * 1.2f + fabsf(R.m[4]) * 0.6f + slack;
+    for (int a = 0; a < 3; a++) {
+      const float ry = fabsf(R.m[3 * a + 1]) * 0.25f, z0 = R.m[3 * a + 2] * -0.3f, z1 = R.m[3 * a + 2] * 0.1f, da = 3.0f * R.m[3 * a];
+      b.flo[a] = pos[a] - ry + fminf(z0, z1) + fminf(da, 0.0f) - slack;
+      b.fhi[a] = pos[a] + ry + fmaxf(z0, z1) + fmaxf(da, 0.0f) + slack;
+    }
+    return b;
+  }
+  static LL_HD bool box_in_family(int fam, const BoxRec& r, const float* pos, const RayBounds& b) {
+    if (fam == 0) return (r.a.y >= pos[0] - b.hgx) & (r.a.x <= pos[0] + b.hgx) & (r.a.w >= pos[1] - b.hgy) & (r.a.z <= pos[1] + b.hgy);
+    if (fam == 1) return (r.a.y >= pos[0] - 20.1f) & (r.a.x <= pos[0] + 20.1f) & (r.a.w >= pos[1] - 20.1f) & (r.a.z <= pos[1] + 20.1f) & (r.c.x <= pos[2]) & (r.c.y >= pos[2]);
+    return (r.a.y >= b.flo[0]) & (r.a.x <= b.fhi[0]) & (r.a.w >= b.flo[1]) & (r.a.z <= b.fhi[1]) & (r.c.y >= b.flo[2]) & (r.c.x <= b.fhi[2]);
+  }
+  // lists[fam]: box records a family can meet (n[fam] of them), in any order; percep: the row's 778 floats in the obs row
+  static LL_HD void percept_rays(const EpmcParams& E, int row, const float* rec, const float* const* lists, const int* n, float* percep, int r_first, int r_stride) {
+    const float pos[3] = {rec[0], rec[1], rec[2]};
+    M3<float> R;
+    for (int i = 0; i < 9; i++) R.m[i] = rec[3 + i];
+    const float yaw = rec[12], noise_z = rec[13];
+    float sy, cy;
+    sincos_f(yaw, &sy, &cy);
+    const float miss = sqrtf(pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2]);
+    const float d[3] = {3.0f * R.m[0], 3.0f * R.m[3], 3.0f * R.m[6]};
+    float inv[3];
+    for (int a = 0; a < 3; a++) inv[a] = d[a] != 0.0f ? 1.0f / d[a] : 0.0f;
+    for (int r = r_first; r < EPMC_N_RAYS; r += r_stride) {
+      float* tr = E.ray_trace ? E.ray_trace + ((long)row * EPMC_N_RAYS + r) * 8 : nullptr;
+      if (r < EPMC_N_HEIGHT) {                                                   // observe_rays: height grid
+        float gx, gy;
+        grid_point(r, -1.2f, 1.2f, -0.6f, 0.6f, &gx, &gy);
+        const float x = R.m[0] * gx + R.m[1] * gy + pos[0], y = R.m[3] * gx + R.m[4] * gy + pos[1];
+        float top = 0.0f;
+        for (int b = 0; b < n[0]; b++) {
+          const BoxRec bx = load_box(lists[0] + b * EPMC_BOX_WORDS);
+          const bool in = (x >= bx.a.x) & (x <= bx.a.y) & (y >= bx.a.z) & (y <= bx.a.w);
+          top = in ? fmaxf(top, bx.c.y) : top;
+        }
+        const float frac = (10.0f - top) * 0.05f;
+        float v = 10.0f + frac * -20.0f;
+        if (E.noise_on[3]) v = (v > 0.01f && v < 0.6f) ? v + noise_z : 0.0f;
+        percep[r] = v;
+        if (tr) { tr[0] = x; tr[1] = y; tr[2] = 10.0f; tr[3] = x; tr[4] = y; tr[5] = -10.0f; tr[6] = 1.0f; tr[7] = frac; }
+      } else if (r < EPMC_N_HEIGHT + EPMC_N_HORIZ) {                             // observe_rays: horizontal fan
+        const int k = r - EPMC_N_HEIGHT;
+        float sk, ck;
+        sincos_f(6.283185307179586f * (float)k * (1.0f / 128.0f), &sk, &ck);
+        const float dx = 20.0f * (cy * ck - sy * sk), dy = 20.0f * (sy * ck + cy * sk);
+        const float ix = dx != 0.0f ? 1.0f / dx : 0.0f, iy = dy != 0.0f ? 1.0f / dy : 0.0f;
+        float best = 3.0e38f;
+        for (int b = 0; b < n[1]; b++) {
+          const BoxRec bx = load_box(lists[1] + b * EPMC_BOX_WORDS);
+          float te = -3.0e38f, tl = 3.0e38f;
+          slab_axis(bx.a.x, bx.a.y, pos[0], dx, ix, te, tl);
+          slab_axis(bx.a.z, bx.a.w, pos[1], dy, iy, te, tl);
+          const bool ok = (pos[2] >= bx.c.x) & (pos[2] <= bx.c.y) & (te <= tl) & (te >= 0.0f) & (te <= 1.0f);
+          best = ok ? fminf(best, te) : best;
+        }
+        const bool hit = best < 2.0f;
+        percep[r] = hit ? best * 20.0f : miss;
+        if (tr) { tr[0] = pos[0]; tr[1] = pos[1]; tr[2] = pos[2]; tr[3] = pos[0] + dx; tr[4] = pos[1] + dy; tr[5] = pos[2]; tr[6] = hit ? 1.0f : 0.0f; tr[7] = hit ? best : 1.0f; }
+      } else {                                                                   // observe_rays: front rays
+        const int i = r - EPMC_N_HEIGHT - EPMC_N_HORIZ;
+        float gy, gz, o[3];
+        grid_point(i, -0.25f, 0.25f, -0.3f, 0.1f, &gy, &gz);
+        for (int a = 0; a < 3; a++) o[a] = R.m[3 * a + 1] * gy + R.m[3 * a + 2] * gz + pos[a];
+        float best = 3.0e38f;
+        if (d[2] < 0.0f) {
+          const float tz = -o[2] * inv[2];
+          if (tz >= 0.0f && tz <= 1.0f) best = tz;
+        }
+        for (int b = 0; b < n[2]; b++) {
+          const BoxRec bx = load_box(lists[2] + b * EPMC_BOX_WORDS);
+          float te = -3.0e38f, tl = 3.0e38f;
+          slab_axis(bx.a.x, bx.a.y, o[0], d[0], inv[0], te, tl);
+          slab_axis(bx.a.z, bx.a.w, o[1], d[1], inv[1], te, tl);
+          slab_axis(bx.c.x, bx.c.y, o[2], d[2], inv[2], te, tl);
+          const bool ok = (te <= tl) & (te >= 0.0f) & (te <= 1.0f);
+          best = ok ? fminf(best, te) : best;
+        }
+        const bool hit = best < 2.0f;
+        percep[r] = hit ? best * 3.0f : 3.0f;
+        if (tr) {
+          for (int a = 0; a < 3; a++) { tr[a] = o[a]; tr[3 + a] = o[a] + d[a]; }
+          tr[6] = hit ? 1.0f : 0.0f; tr[7] = hit ? best : 1.0f;
+        }
+      }
+    }
+  }
+  // the host statement of the second kernel for ONE row (emul.cpp, and the reference for the GPU kernel's staging): lists built by walking the row's boxes in order
+  static LL_HD void percept_row_host(const StepParams& P, const EpmcParams& E, int row) {
+    const float* rec = E.ray_pose + (long)row * EPMC_RAY_POSE;
+    const int nb = (int)rec[14];
+    const float* boxes = E.boxes + (long)row * EPMC_MAX_BOXES * EPMC_BOX_WORDS;
+    M3<float> R;
+    for (int i = 0; i < 9; i++) R.m[i] = rec[3 + i];
+    const RayBounds bd = ray_bounds(rec, R);
+    float buf[3][EPMC_MAX_BOXES * EPMC_BOX_WORDS];
+    int n[3] = {0, 0, 0};
+    for (int b = 0; b < nb; b++) {
+      const BoxRec r = load_box(boxes + b * EPMC_BOX_WORDS);
+      for (int fam = 0; fam < 3; fam++)
+        if (box_in_family(fam, r, rec, bd)) store_box(buf[fam] + (n[fam]++) * EPMC_BOX_WORDS, r);
+    }
+    const float* lists[3] = {buf[0], buf[1], buf[2]};
+    percept_rays(E, row, rec, lists, n, P.obs + (long)row * P.obs_dim + 3L * P.prop_dim + 36, 0, 1);
+  }
+
   // what the env makes of one ray's answer (PGE:395-447), for the scripted path
   static LL_HD void emit_ray(const EpmcParams& E, int env, int r, const float* f, const float* t, bool hit, float frac, const float* noise, float* percep) {
     if (E.ray_trace) {
@@ -501,8 +629,12 @@ struct Epmc {
     if (E.noise_on[2]) yaw += ep[EP_NOISE + 2];                                  // PGE:392-393
     const long a0 = 3L * P.prop_dim + 36;
     const int n_boxes = (int)ep[EP_N_BOXES];
-    const float* boxes = ln.stage_row(E.boxes + (long)env * EPMC_MAX_BOXES * EPMC_BOX_WORDS, n_boxes * EPMC_BOX_WORDS);   // LDS on the GPU
-    observe_rays(ln, P, E, env, pos, R, yaw, ep + EP_NOISE, boxes, n_boxes, row + a0);
+    if (E.split_rays && !E.scr_ray_hit) {
+      leave_ray_pose(ln, E, env, pos, R, yaw, ep + EP_NOISE, n_boxes);            // the rays of this observation are cast by the kernel behind this one
+    } else {
+      const float* boxes = ln.stage_row(E.boxes + (long)env * EPMC_MAX_BOXES * EPMC_BOX_WORDS, n_boxes * EPMC_BOX_WORDS);   // LDS on the GPU
+      observe_rays(ln, P, E, env, pos, R, yaw, ep + EP_NOISE, boxes, n_boxes, row + a0);
+    }
     // target_info (PGE:400-403): the (x, y) of R^-1 (target - position), normalised, then the commanded speed
     const float dx = target[0] - pos[0], dy = target[1] - pos[1], dz = target[2] - pos[2];
     const float lx = R.m[0] * dx + R.m[3] * dy + R.m[6] * dz, ly = R.m[1] * dx + R.m[4] * dy + R.m[7] * dz;

@@ -289,6 +289,16 @@ struct GpuLanes {
   static LL_D void subbcast6(const F* x, F* out) {
     if (K_ == 0) LL_BC6("[0,0,0,0]"); else if (K_ == 1) LL_BC6("[1,1,1,1]"); else if (K_ == 2) LL_BC6("[2,2,2,2]"); else LL_BC6("[3,3,3,3]");
   }
+  // the same, directly behind another subbcast6 of the SAME x (`after`: one of that call's outputs, which orders the two): x has settled, no wait states (round 6)
+#define LL_BC6S(P_)                                                                                                      \
+    asm(LL_BC(0, 6, P_) LL_BC(1, 7, P_) LL_BC(2, 8, P_) LL_BC(3, 9, P_) LL_BC(4, 10, P_) LL_BC(5, 11, P_)                \
+        : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5])                      \
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(after))
+  template <int K_>
+  static LL_D void subbcast6_after(const F* x, F* out, F after) {
+    if (K_ == 0) LL_BC6S("[0,0,0,0]"); else if (K_ == 1) LL_BC6S("[1,1,1,1]"); else if (K_ == 2) LL_BC6S("[2,2,2,2]"); else LL_BC6S("[3,3,3,3]");
+  }
+#undef LL_BC6S
   // the lower triangle of a 3 x 3 matrix whose column k lives in sub-lane k as d[0..2] (row index): m11 m12 m22 m13 m23 m33 to every sub-lane
   static LL_D void gather_tri3(const F* d, F* m) {
     asm("s_nop 1\n\t" LL_BC(0, 6, "[0,0,0,0]") LL_BC(1, 6, "[1,1,1,1]") LL_BC(2, 7, "[1,1,1,1]") LL_BC(3, 6, "[2,2,2,2]") LL_BC(4, 7, "[2,2,2,2]") LL_BC(5, 8, "[2,2,2,2]")
@@ -322,19 +332,22 @@ struct GpuLanes {
   // g[4t + S_] += sum_i y[i] * (x[i] of lane 4t + S_), t = 0..3: the Gram scalars of a row against the four rows of turn block S_,
   // 24 v_fmac_f32 with a DPP row-broadcast source.  x and y are not written inside the block, so after the leading wait states no
   // DPP read-after-write hazard can occur.
+  // (round 6) Blocks S_ = 1 .. 3 of one Gram chain follow block 0 directly: x has not been written since, so their two leading wait states -- s_nop 1 costs a lone wave
+  // 8.2 cycles, profiles/r06_issue_probe.txt -- are dropped.  They take block S_ - 1's first scalar as an (unread) operand: the chain stays in order behind block 0's wait states.
   template <int S_>
   static LL_D void gram4(const F* x, const F* y, F* g) {
     float g0 = g[S_], g1 = g[4 + S_], g2 = g[8 + S_], g3 = g[12 + S_];
+    const float after = S_ > 0 ? g[S_ - 1] : x[0];
 #define LL_G1(O, L_, X, Y) "v_fmac_f32_dpp " O ", " X ", " Y " row_newbcast:" L_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 #define LL_G6(O, L_) LL_G1(O, L_, "%4", "%10") LL_G1(O, L_, "%5", "%11") LL_G1(O, L_, "%6", "%12") LL_G1(O, L_, "%7", "%13") LL_G1(O, L_, "%8", "%14") LL_G1(O, L_, "%9", "%15")
-#define LL_G24(A_, B_, C_, D_)                                                                                                             \
-    asm("s_nop 1\n\t" LL_G6("%0", A_) LL_G6("%1", B_) LL_G6("%2", C_) LL_G6("%3", D_)                                                   \
+#define LL_G24(NOP_, A_, B_, C_, D_)                                                                                                       \
+    asm(NOP_ LL_G6("%0", A_) LL_G6("%1", B_) LL_G6("%2", C_) LL_G6("%3", D_)                                                             \
         : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3)                                                                                       \
-        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]))
-    if (S_ == 0) LL_G24("0", "4", "8", "12");
-    else if (S_ == 1) LL_G24("1", "5", "9", "13");
-    else if (S_ == 2) LL_G24("2", "6", "10", "14");
-    else LL_G24("3", "7", "11", "15");
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(after))
+    if (S_ == 0) LL_G24("s_nop 1\n\t", "0", "4", "8", "12");
+    else if (S_ == 1) LL_G24("", "1", "5", "9", "13");
+    else if (S_ == 2) LL_G24("", "2", "6", "10", "14");
+    else LL_G24("", "3", "7", "11", "15");
 #undef LL_G24
 #undef LL_G6
 #undef LL_G1

@@ -69,7 +69,13 @@ typedef GpuLanesPinned<LC_COUNT> GpuLanes1;                   // the per-leg tab
 #define LL_RELOAD_SEPMC2 1      // (with the episode scalars parked in LDS the re-read pays here too: 32768 arenas 14.8 -> 16.0 M robot-steps/s)
 #endif
 #ifndef LL_GRAM_PIPE_PMC1
-#define LL_GRAM_PIPE_PMC1 1     // the one-wave-per-SIMD PMC cone kernels form the Gram blocks of their contact rows on the matrix cores, in the background (lanes.hpp WithGramPipe)
+#define LL_GRAM_PIPE_PMC1 0     // 1: the one-wave-per-SIMD PMC cone kernels form the Gram blocks of their contact rows on the matrix cores, one MFMA at a time between pieces of the next
+                                // row's arithmetic (lanes.hpp WithGramPipe; round 6, the round-5 review's "pipelined producer").  Built, held to the oracle on the host build, and measured
+                                // (profiles/r06_gram_pipe_ab.txt, one box): single-step launches 0.2073 -> 0.2037 ms (- 1.7 %), the contract's multi-step launches 0.1896 -> 0.1910 (+ 0.7 %: 176 B of
+                                // scratch).  Why so little: a LONE wave does not overlap an MFMA with its own VALU work at all -- 6 x (v_mfma_f32_16x16x1_4b + k independent v_fma) takes 6 x (32 + 5.7 k)
+                                // cycles however they are interleaved (profiles/r06_issue_probe.txt) -- so a block costs 6 x 32 cycles of MFMA + 16 v_accvgpr_read + 16 v_permlane swaps at 8.6 cycles
+                                // + 16 v_fmac against 96 v_fmac_dpp + 16 selects: 500 against 600 cycles, before register pressure.  And MFMA ignores EXEC: in a wave whose last rows hold no env it
+                                // overwrites registers of the rows that sit the step out (a GPU fault in test_partial_wave_and_odd_batch_sizes).  OFF; the code, the host statement and its test stay
 #endif
 typedef GpuLanesPinned<LC_COUNT, LL_PIN_PMC ? 7 : 0, LL_PIN_PMC ? BC_COUNT : 0, LL_PIN_PMC ? LK_BASE : 0> GpuLanesPmc1Plain;  // PMC at one wave per SIMD: candidate fields and base constants too
 typedef std::conditional<LL_GRAM_PIPE_PMC1 != 0, WithGramPipe<GpuLanesPmc1Plain>, GpuLanesPmc1Plain>::type GpuLanesPmc1;
@@ -295,6 +301,33 @@ __global__ __launch_bounds__(PMC_WAVE) void epmc_reset_kernel(StepParams P, Epmc
   Epmc<GpuLanes>::reset_env(ln, P, E, env, draws ? draws + (long)i * EPMC_MAX_DRAWS : nullptr, prev_orn ? prev_orn + (long)i * 4 : nullptr);
 }
 
+// The 778 rays of a row's observation as a kernel of their own (round 6; epmc_step.hpp percept_rays): one workgroup of four waves per row -- sixteen waves per SIMD at 4096 rows, where the
+// step kernel has one -- stages the row's box records in LDS, sorts them into the three ray families' lists (any order: a ray's answer is a minimum / maximum over boxes), and thread t casts
+// rays t, t + 256, t + 512, (t + 768).  Launched behind a step kernel that ran with EpmcParams::split_rays (it left the row's pose in ray_pose); serves EPMC rows and SEPMC robot rows alike.
+#define PERCEPT_THREADS 256
+__global__ __launch_bounds__(PERCEPT_THREADS) void epmc_percept_kernel(StepParams P, EpmcParams E) {
+  __shared__ __attribute__((aligned(16))) float lists[3][EPMC_MAX_BOXES * EPMC_BOX_WORDS];
+  __shared__ int cnt[3];
+  const int row = blockIdx.x;
+  const float* rec = E.ray_pose + (long)row * EPMC_RAY_POSE;
+  if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  typedef Epmc<GpuLanes> EP;
+  const int nb = (int)rec[14];
+  if ((int)threadIdx.x < nb) {
+    M3<float> R;
+    for (int i = 0; i < 9; i++) R.m[i] = rec[3 + i];
+    const EP::RayBounds bd = EP::ray_bounds(rec, R);
+    const BoxRec r = load_box(E.boxes + ((long)row * EPMC_MAX_BOXES + threadIdx.x) * EPMC_BOX_WORDS);
+    for (int fam = 0; fam < 3; fam++)
+      if (EP::box_in_family(fam, r, rec, bd)) store_box(lists[fam] + atomicAdd(&cnt[fam], 1) * EPMC_BOX_WORDS, r);
+  }
+  __syncthreads();
+  const float* lp[3] = {lists[0], lists[1], lists[2]};
+  const int n[3] = {cnt[0], cnt[1], cnt[2]};
+  EP::percept_rays(E, row, rec, lp, n, P.obs + (long)row * P.obs_dim + 3L * P.prop_dim + 36, threadIdx.x, PERCEPT_THREADS);
+}
+
 // SEPMC (sepmc_step.hpp): one control step of ChaseTagGameEnv; row = 2 * arena + robot, the two robots of an arena are
 // neighbouring rows of one wave and exchange state with v_permlane16_swap.
 template <int OCC, bool MULTI = false, bool CONE = false>          // MULTI: see epmc_step_kernel; CONE: see pmc_step_kernel
@@ -415,6 +448,10 @@ struct HipBackend {
     // ends later by the full residency of that kernel (measured with an RCCL stand-in: profiles/r03_simd_sharing.txt).
     const char* sh = getenv("LL_SHARE_SIMDS");
     if (sh && sh[0] == '1') simds = 0;
+    // LL_SPLIT_RAYS (EPMC / SEPMC): 0 = the step kernel casts the 778 rays of a row itself (rounds 1 - 5); 1 = single-step launches leave them to epmc_percept_kernel behind the step
+    // kernel; 2 (default) = multi-step calls too run as single steps, each followed by the ray kernel (what the A/B on one box decided: profiles/r06_split_rays_ab.txt)
+    const char* sr = getenv("LL_SPLIT_RAYS");
+    split_rays = sr ? atoi(sr) : 2;
     stream = own;
   }
   ~HipBackend() {
@@ -424,6 +461,7 @@ struct HipBackend {
   }
   void use() { HIPCHK(hipSetDevice(device)); }
   int simds_hw = 1024;
+  int split_rays = 2;
   // can every workgroup of a step launch be on the chip at once?  (one 512-register wave per SIMD while the grid fits, two 256-register waves otherwise:
   // launch_step.)  A multi-step launch needs it -- its waves wait for each other's finished episodes (PmcEngine::step)
   bool co_resident(const StepParams& P) const {
@@ -471,21 +509,33 @@ struct HipBackend {
     HIPCHK(hipEventRecord(ev->first, stream));
     return ev;
   }
-  void launch_epmc_step(const StepParams& P, const EpmcParams& E) {
+  // the rays of the step's observation by the kernel of their own?  Not when the caller plays rayTestBatch (scripted rays) -- and a multi-step call only under LL_SPLIT_RAYS=2, as single steps
+  bool rays_split(const StepParams& P, const EpmcParams& E) const { return !E.scr_ray_hit && (P.n_steps == 1 ? split_rays >= 1 : split_rays >= 2); }
+  void launch_percept(const StepParams& P, const EpmcParams& E) {
+    hipLaunchKernelGGL(epmc_percept_kernel, dim3(P.n_envs), dim3(PERCEPT_THREADS), 0, stream, P, E);
+  }
+  void launch_epmc_step(const StepParams& P, const EpmcParams& E_in) {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
-    const bool cone = P.friction_mode == 2;
+    const bool cone = P.friction_mode == 2, split = rays_split(P, E_in);
+    EpmcParams E = E_in;
+    E.split_rays = split ? 1 : 0;
 #define LL_GO(KERNEL, PARAMS) hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, PARAMS, E)
     if (P.n_steps == 1) {
       if (blocks <= simds) { if (cone) LL_GO((epmc_step_kernel<1, false, true>), P); else LL_GO((epmc_step_kernel<1>), P); }
       else                 { if (cone) LL_GO((epmc_step_kernel<2, false, true>), P); else LL_GO((epmc_step_kernel<2>), P); }
-    } else if (blocks <= simds) {
+      if (split) launch_percept(P, E);
+    } else if (blocks <= simds && !split) {
       if (cone) LL_GO((epmc_step_kernel<1, true, true>), P); else LL_GO((epmc_step_kernel<1, true>), P);
     } else {
-      StepParams Q = P;                                  // larger batches: the steps of the call as single launches (see epmc_step_kernel)
+      StepParams Q = P;                                  // larger batches, and every batch with the rays split off: the steps of the call as single launches (see epmc_step_kernel)
       Q.n_steps = 1;
-      for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) { if (cone) LL_GO((epmc_step_kernel<2, false, true>), Q); else LL_GO((epmc_step_kernel<2>), Q); }
+      for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) {
+        if (blocks <= simds) { if (cone) LL_GO((epmc_step_kernel<1, false, true>), Q); else LL_GO((epmc_step_kernel<1>), Q); }
+        else                 { if (cone) LL_GO((epmc_step_kernel<2, false, true>), Q); else LL_GO((epmc_step_kernel<2>), Q); }
+        if (split) launch_percept(Q, E);
+      }
     }
 #undef LL_GO
     HIPCHK(hipGetLastError());
@@ -497,21 +547,28 @@ struct HipBackend {
     hipLaunchKernelGGL(epmc_reset_kernel, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P, E, ids, n, draws, prev_orn);
     HIPCHK(hipGetLastError());
   }
-  void launch_sepmc_step(const StepParams& P, const SepmcParams& S) {
+  void launch_sepmc_step(const StepParams& P, const SepmcParams& S_in) {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
-    const bool cone = P.friction_mode == 2;
+    const bool cone = P.friction_mode == 2, split = rays_split(P, S_in.e);
+    SepmcParams S = S_in;
+    S.e.split_rays = split ? 1 : 0;
 #define LL_GO(KERNEL, PARAMS) hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, PARAMS, S)
     if (P.n_steps == 1) {
       if (blocks <= simds) { if (cone) LL_GO((sepmc_step_kernel<1, false, true>), P); else LL_GO((sepmc_step_kernel<1>), P); }
       else                 { if (cone) LL_GO((sepmc_step_kernel<2, false, true>), P); else LL_GO((sepmc_step_kernel<2>), P); }
-    } else if (blocks <= simds) {
+      if (split) launch_percept(P, S.e);
+    } else if (blocks <= simds && !split) {
       if (cone) LL_GO((sepmc_step_kernel<1, true, true>), P); else LL_GO((sepmc_step_kernel<1, true>), P);
     } else {
-      StepParams Q = P;                                  // larger batches: single launches (see epmc_step_kernel)
+      StepParams Q = P;                                  // larger batches, and every batch with the rays split off: single launches (see epmc_step_kernel)
       Q.n_steps = 1;
-      for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) { if (cone) LL_GO((sepmc_step_kernel<2, false, true>), Q); else LL_GO((sepmc_step_kernel<2>), Q); }
+      for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) {
+        if (blocks <= simds) { if (cone) LL_GO((sepmc_step_kernel<1, false, true>), Q); else LL_GO((sepmc_step_kernel<1>), Q); }
+        else                 { if (cone) LL_GO((sepmc_step_kernel<2, false, true>), Q); else LL_GO((sepmc_step_kernel<2>), Q); }
+        if (split) launch_percept(Q, S.e);
+      }
     }
 #undef LL_GO
     HIPCHK(hipGetLastError());

@@ -965,7 +965,7 @@ struct Pmc {
     SV<F> Fk = apply(Ick, Sk);
     F Fk6[6], F16[6], F26[6], F36[6];
     sv_to6(Fk, Fk6);
-    L::template subbcast6<0>(Fk6, F16); L::template subbcast6<1>(Fk6, F26); L::template subbcast6<2>(Fk6, F36);
+    L::template subbcast6<0>(Fk6, F16); L::template subbcast6_after<1>(Fk6, F26, F16[0]); L::template subbcast6_after<2>(Fk6, F36, F26[0]);
     SV<F> F1, F2, F3;
     F1.a = mk3<F>(F16[0], F16[1], F16[2]); F1.l = mk3<F>(F16[3], F16[4], F16[5]);
     F2.a = mk3<F>(F26[0], F26[1], F26[2]); F2.l = mk3<F>(F26[3], F26[4], F26[5]);

@@ -59,6 +59,7 @@ struct SepmcEngine {
     base.bk.h2d(d_init, init, sizeof init);
     E.init_state = d_init;
     E.boxes = base.template dalloc<float>(N * EPMC_MAX_BOXES * EPMC_BOX_WORDS + EPMC_BOX_WORDS);   // + one record: the ray loops read one box ahead
+    E.ray_pose = base.template dalloc<float>(N * EPMC_RAY_POSE);                                    // what the ray kernel needs of a row (epmc_step.hpp percept_rays; backends that cast the rays inside the step never touch it)
     E.push_trace = base.template dalloc<float>(N * P.n_sub * 4);
     if (N <= 512) {
       E.ray_trace = base.template dalloc<float>(N * EPMC_N_RAYS * 8);      // diagnostics / parity only

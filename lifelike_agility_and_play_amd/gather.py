@@ -149,7 +149,7 @@ class TrajectoryBuffer(object):
         self.p2p_no_cu = True             # mode 'p2p': SDMA pulls (False: the runtime's default device-to-device path, the A/B leg)
         self._stage = None                # gloo test path: pinned staging buffers, side stream, worker thread
         self._thread = None
-        self._thread_error = None         # an exception raised inside a helper thread: re-raised on the launching thread at the next join
+        self._thread_errors = {}          # exceptions raised inside the helper threads, one slot per helper ('_thread': gather / pulls, '_watcher'): re-raised on the launching thread at its next join
         self._watcher = None              # mode 'p2p': the thread that turns "the learner has copied block k" (an interprocess event) into the signal word
 
     def half(self, k):
@@ -219,9 +219,9 @@ class TrajectoryBuffer(object):
         if t is not None:
             t.join()
             setattr(self, which, None)
-        if self._thread_error is not None:
-            e, self._thread_error = self._thread_error, None
-            raise RuntimeError('gather helper thread failed: %r' % (e,)) from e
+        e = self._thread_errors.pop(which, None)
+        if e is not None:
+            raise RuntimeError('gather helper thread %s failed: %r' % (which, e)) from e
 
     def _spawn(self, fn, which='_thread'):
         import threading
@@ -234,7 +234,7 @@ class TrajectoryBuffer(object):
                     xfer.set_device(dev)                     # a new thread starts on device 0
                 fn()
             except BaseException as e:                      # noqa: BLE001  (kept for the launching thread: _join)
-                self._thread_error = e
+                self._thread_errors[which] = e
         t = threading.Thread(target=run)
         setattr(self, which, t)
         t.start()
@@ -286,8 +286,12 @@ class TrajectoryBuffer(object):
                 self._stall_events.append((a, b))            # how long it actually stood still: stall_ms()
 
                 def watch():
-                    copied.synchronize()                     # (host-side, in this thread only)
-                    st['signal'].write(st['aux'].handle, k)
+                    # The engine's stream is ALREADY parked on the word: whatever happens in here, the word is raised (a failed wait would otherwise leave the stream --
+                    # and every later sync() or close() -- blocked for good); the exception itself reaches the launching thread at its next join of this helper.
+                    try:
+                        copied.synchronize()                 # (host-side, in this thread only)
+                    finally:
+                        st['signal'].write(st['aux'].handle, k)
                 self._spawn(watch, '_watcher')
             else:
                 copied.make_stream_wait(es)                  # (no hipStreamWaitValue32 on this device: the host-side wait of round 4)
@@ -328,7 +332,7 @@ class TrajectoryBuffer(object):
 
     def wait(self):
         import time
-        if self._thread is not None or self._watcher is not None or self._thread_error is not None:      # helper threads (gloo-staged gather; p2p pulls / watcher)
+        if self._thread is not None or self._watcher is not None or self._thread_errors:      # helper threads (gloo-staged gather; p2p pulls / watcher)
             t0 = time.perf_counter()
             self._join('_thread'); self._join('_watcher')
             self.host_stall_s += time.perf_counter() - t0
@@ -395,7 +399,7 @@ class TrajectoryBuffer(object):
                     ev.synchronize()
                     dist.gather(host, gather_list=outs, dst=dst, group=group)
                 except BaseException as e:                  # noqa: BLE001  (re-raised on the launching thread: _join)
-                    self._thread_error = e
+                    self._thread_errors['_thread'] = e
             self._thread = threading.Thread(target=run)
             self._thread.start()
             if rank == dst:

@@ -106,8 +106,12 @@ struct HostBackend {
     Q.step_count = P.step_count + (uint64_t)sl;
     launch_actions(Q, P.actions_out, P.action_sigma);
   }
-  void launch_epmc_step(const StepParams& P, const EpmcParams& E) {
+  // LL_SPLIT_RAYS (as llenv.hip HipBackend; read per call here so that a test can run both ways in one process): the 778 rays of a row after the step, by Epmc::percept_row_host
+  static bool rays_split(const EpmcParams& E) { const char* v = getenv("LL_SPLIT_RAYS"); return v && atoi(v) >= 1 && !E.scr_ray_hit; }
+  void launch_epmc_step(const StepParams& P, const EpmcParams& E_in) {
     HostLanes ln(P.candc);
+    EpmcParams E = E_in;
+    E.split_rays = rays_split(E_in) ? 1 : 0;
     for (int sl = 0; sl < P.n_steps; sl++) {
       draw_step_actions(P, sl);
       for (int env = 0; env < P.n_envs; env++) {
@@ -116,6 +120,7 @@ struct HostBackend {
         const bool park = getenv("LL_EMUL_PARK") != nullptr, cone = P.friction_mode == 2;      // park: the larger-batch GPU build's variant (tests)
         if (park) { if (cone) { HostLanesLds lq(P.candc); Epmc<HostLanesLds>::step_env<true, true>(lq, P, E, env, act); } else Epmc<HostLanes>::step_env<true>(ln, P, E, env, act); }
         else      { if (cone) Epmc<HostLanes>::step_env<false, true>(ln, P, E, env, act); else Epmc<HostLanes>::step_env(ln, P, E, env, act); }
+        if (E.split_rays) Epmc<HostLanes>::percept_row_host(P, E, env);
       }
     }
   }
@@ -139,7 +144,9 @@ struct HostBackend {
       t[0].join(); t[1].join();
     }
   }
-  void launch_sepmc_step(const StepParams& P, const SepmcParams& S) {
+  void launch_sepmc_step(const StepParams& P, const SepmcParams& S_in) {
+    SepmcParams S = S_in;
+    S.e.split_rays = rays_split(S_in.e) ? 1 : 0;
     for (int sl = 0; sl < P.n_steps; sl++) {
       draw_step_actions(P, sl);
       const bool park = getenv("LL_EMUL_PARK") != nullptr, cone = P.friction_mode == 2;
@@ -157,6 +164,8 @@ struct HostBackend {
           else if (cone) Sepmc<HostLanes>::step_env<false, true>(ln, P, S, row, act);
           else Sepmc<HostLanes>::step_env(ln, P, S, row, act);
         });
+      if (S.e.split_rays)
+        for (int row = 0; row < P.n_envs; row++) Epmc<HostLanes>::percept_row_host(P, S.e, row);
     }
   }
   void launch_sepmc_reset(const StepParams& P, const SepmcParams& S, const int32_t* ids, int n, const float* draws, const float* prev_orn) {

@@ -158,6 +158,7 @@ struct HostLanes {
     x = r;
   }
   template <int K_> static void subbcast6(const F* x, F* out) { for (int i = 0; i < 6; i++) out[i] = subbcast<K_>(x[i]); }
+  template <int K_> static void subbcast6_after(const F* x, F* out, const F&) { subbcast6<K_>(x, out); }
   static void gather_tri3(const F* d, F* m) {
     m[0] = subbcast<0>(d[0]); m[1] = subbcast<1>(d[0]); m[2] = subbcast<1>(d[1]); m[3] = subbcast<2>(d[0]); m[4] = subbcast<2>(d[1]); m[5] = subbcast<2>(d[2]);
   }

@@ -369,6 +369,59 @@ def check_parked_variant_equals_plain(lib_path, n=10, n_steps=40, element=1):
     A.close(); B.close()
 
 
+def check_split_rays_equal_fused(lib_path, n=10, n_steps=40, elements=(1, 2, 3), multi=(1, 4), noise=False):
+    """Round 6: the 778 rays of a row's observation cast by a kernel of their own behind the step kernel (epmc_step.hpp percept_rays, LL_SPLIT_RAYS) against the step
+    kernel casting them itself, BIT FOR BIT: observation (every percept column), ray traces (end points, hit, fraction), state, rewards, episode records -- over runs in which
+    episodes end and re-seed (new terrain) and, with `noise`, the observation noise of PGE:388-393 and :443-446 is on.  Per ray the two paths run the same expressions; a ray's
+    answer is a minimum / maximum over boxes, so the order and pre-selection of the boxes cannot show.  On the GPU the switch is read when the engine is created, on the host
+    build at every call: set for both."""
+    import os
+    sg = float(np.exp(-2.0))
+    for element in elements:
+        cfg = env_config(element)
+        cfg['max_steps'] = 15
+        if noise:
+            cfg['obs_randomization'] = {'pos_x_bias': [-0.05, 0.05], 'pos_y_bias': [-0.05, 0.05], 'yaw_bias': [-0.1, 0.1], 'pos_z_bias': [-0.02, 0.02]}
+        prev = os.environ.get('LL_SPLIT_RAYS')
+        try:
+            os.environ['LL_SPLIT_RAYS'] = '0'
+            A = make_engine(cfg, n, lib_path, auto_reset=1, seed=4)
+            os.environ['LL_SPLIT_RAYS'] = '2'
+            B = make_engine(cfg, n, lib_path, auto_reset=1, seed=4)
+            A.reset(); B.reset()
+            for t in range(n_steps):
+                k = multi[t % len(multi)]
+                os.environ['LL_SPLIT_RAYS'] = '0'
+                if k == 1:
+                    A.fill_random_actions(sg); A.step()
+                else:
+                    A.step_random_n(sg, k)
+                os.environ['LL_SPLIT_RAYS'] = '2'
+                if k == 1:
+                    B.fill_random_actions(sg); B.step()
+                else:
+                    B.step_random_n(sg, k)
+                np.testing.assert_array_equal(A.obs(), B.obs())
+                np.testing.assert_array_equal(A.state(), B.state())
+                for x, y in zip(A.reward_done(), B.reward_done()):
+                    np.testing.assert_array_equal(x, y)
+                ea, eb = A.episode(), B.episode()
+                for key in ea:
+                    np.testing.assert_array_equal(ea[key], eb[key])
+                if n <= 512:                                                              # (the ray trace is kept for engines of at most 512 rows)
+                    for x, y in zip(A.rays(), B.rays()):                                  # end points, hit flags and fractions of the step's 778 rays per row
+                        np.testing.assert_array_equal(x, y)
+            assert A.counters() == B.counters() and A.counters()['episodes'] > 0
+            o = A.obs()[:, 135:135 + 778]
+            assert np.isfinite(o).all() and (o[:, :325] > 0.02).any() and (o[:, 453:] < 2.99).any()       # boxes were seen from above and ahead
+            A.close(); B.close()
+        finally:
+            if prev is None:
+                os.environ.pop('LL_SPLIT_RAYS', None)
+            else:
+                os.environ['LL_SPLIT_RAYS'] = prev
+
+
 def check_trained_policies_traverse(lib_path, n_envs=8, horizon=(360, 560)):
     """SURVEY.md 8f-3 for the environmental level -- the only Bullet-facing check of this build's terrain contacts and 778 analytic rays: the
     reference's TRAINED EPMC policies (data/models/environmental_level_{hurdle,cube}.model, trained against PyBullet; the hole checkpoint
@@ -715,7 +768,7 @@ def _oracle_game(job):
     return len(us), why, u0, us
 
 
-def check_game_statistics(lib_path, n_per_policy=128, procs=None, policies=('hurdle', 'cube', 'hole'), frac_tol=0.03, len_tol=0.03, ks_p=0.5):
+def check_game_statistics(lib_path, n_per_policy=256, procs=None, policies=('hurdle', 'cube', 'hole'), frac_tol=0.03, len_tol=0.03, ks_p=0.5, n_se=2.0):
     """PMC has check_rollout_statistics; this is the same for the environmental level, at the level the game is decided on.  The engine and the
     float64 oracle env play the SAME episodes -- same terrain, friction, pushes (the oracle env's uniforms are recorded and handed to the engine
     draw by draw), same trained policy of the reference acting on each side's own observations -- every episode to its end on both sides
@@ -737,6 +790,7 @@ def check_game_statistics(lib_path, n_per_policy=128, procs=None, policies=('hur
         with mp.get_context('fork').Pool(procs) as p:
             res = p.map(_oracle_game, [(which, 1000 * (1 + policies.index(which)) + i) for i in range(n)], chunksize=1)
         len_o, why_o = np.array([r[0] for r in res]), np.array([r[1] for r in res])
+        print('%s policy: %d episodes, oracle seeds %d .. %d, engine seed 3, bars at %.1f standard errors (floors %.3f / %.3f)' % (which, n, 1000 * (1 + policies.index(which)), 1000 * (1 + policies.index(which)) + n - 1, n_se, frac_tol, len_tol))
         cfg = _game_cfg(which)
         E = make_engine(cfg, n, lib_path, seed=3)
         U = np.full((n, epmc_capi.LLE_MAX_DRAWS), 0.5, np.float32)
@@ -773,9 +827,9 @@ def check_game_statistics(lib_path, n_per_policy=128, procs=None, policies=('hur
               'KS p %.3f; same end reason %.3f, same end step %.3f' % ((which, n) + o['reached'] + o['fell'] + o['timed_out'] + o['mean_len'] + (o['ks_p'], o['same_end'], o['same_step'])))
         # The episodes of the two simulators decorrelate: a contact that makes or breaks one step apart sends the rest of a run down another path
         # (same end step: 0.2 - 0.3 of the runs for every policy; under cone-coupled friction the stairs policy ends 6 % of its runs for another
-        # reason).  Engine and oracle are two SAMPLES of one distribution: two-sample bars at three standard errors, never tighter than the
+        # reason).  Engine and oracle are two SAMPLES of one distribution: two-sample bars at `n_se` standard errors (round 6: two, on 256 episodes a policy), never tighter than the
         # floors (parity_common.two_sample_bars).  What the populations are was measured at 1024 episodes a side (profiles/r04_cone_decision.md:
         # stairs reached 988 engine / 981 oracle, hurdles 1013 / 1014).
         from parity_common import two_sample_bars
-        two_sample_bars(which, {k: o[k] for k in ('reached', 'fell', 'timed_out')}, len_e, len_o, o['ks_p'], n, floor_frac=frac_tol, floor_len=len_tol)
+        two_sample_bars(which, {k: o[k] for k in ('reached', 'fell', 'timed_out')}, len_e, len_o, o['ks_p'], n, floor_frac=frac_tol, floor_len=len_tol, n_se=n_se)
     return out

@@ -623,7 +623,10 @@ def check_reset_onto_a_mocap_discontinuity(orc, model_blob, table, lib_path):
     E.step_host(act)
     # (rounds 1 - 4: the float32 engine then overflowed -> LL_DONE_NONFINITE.  Under round 5's limit rule -- no speculative rows fighting a 700 rad/s joint -- it
     # may come through finite; what the clip is for still shows: rates beyond Bullet's m_maxCoordinateVelocity somewhere in the step's outcome, or the guard)
-    assert (E.reward_done()[2] & capi.LL_DONE_NONFINITE).any() or np.abs(E.state()[:, 25:37]).max() > 100.0 + 1e-3 or (E.reward_done()[1]).any()
+    # (round 6, advisor: a bare `done.any()` was accepted here too, which a clip end or a fall satisfies.  With auto-reset off the step's outcome stays in the state, so the
+    #  rates themselves are looked at; an env the step finished keeps its terminal state as well)
+    why2 = E.reward_done()[2]
+    assert (why2 & capi.LL_DONE_NONFINITE).any() or np.abs(E.state()[:, 25:37]).max() > 100.0 + 1e-3, (why2, np.abs(E.state()[:, 25:37]).max())
     E.close()
     return worst
 

@@ -616,6 +616,46 @@ def check_multi_step_launch(lib_path, sizes=(6,), k=5, n_launches=4):
         A.close(); B.close()
 
 
+def check_split_rays_equal_fused(lib_path, n=4, n_steps=30, multi=(1, 3)):
+    """The 2 x 778 perception rays of an arena cast by the ray kernel behind the step kernel (LL_SPLIT_RAYS; epmc_parity_common.check_split_rays_equal_fused) against the
+    step kernel casting them itself, bit for bit: every observation entry, the ray traces, states, rewards, episode records; arenas with elements, games ending and re-seeding."""
+    import os
+    sg = float(np.exp(-2.0))
+    cfg = env_config(ALL_ELEMENTS, max_steps=12)
+    prev = os.environ.get('LL_SPLIT_RAYS')
+    try:
+        os.environ['LL_SPLIT_RAYS'] = '0'
+        A = make_engine(cfg, n, lib_path, auto_reset=1, seed=4)
+        os.environ['LL_SPLIT_RAYS'] = '2'
+        B = make_engine(cfg, n, lib_path, auto_reset=1, seed=4)
+        A.reset(); B.reset()
+        for t in range(n_steps):
+            k = multi[t % len(multi)]
+            for X, mode in ((A, '0'), (B, '2')):
+                os.environ['LL_SPLIT_RAYS'] = mode
+                if k == 1:
+                    X.fill_random_actions(sg); X.step()
+                else:
+                    X.step_random_n(sg, k)
+            np.testing.assert_array_equal(A.obs(), B.obs())
+            np.testing.assert_array_equal(A.state(), B.state())
+            for x, y in zip(A.reward_done(), B.reward_done()):
+                np.testing.assert_array_equal(x, y)
+            ea, eb = A.episode(), B.episode()
+            for key in ea:
+                np.testing.assert_array_equal(ea[key], eb[key])
+            if 2 * n <= 512:
+                for x, y in zip(A.rays(), B.rays()):
+                    np.testing.assert_array_equal(x, y)
+        assert A.counters() == B.counters() and A.counters()['episodes'] > 0, A.counters()
+        A.close(); B.close()
+    finally:
+        if prev is None:
+            os.environ.pop('LL_SPLIT_RAYS', None)
+        else:
+            os.environ['LL_SPLIT_RAYS'] = prev
+
+
 def check_parked_variant_equals_plain(lib_path, n=4, n_steps=30):
     """step_env<PARK = true> (the larger-batch GPU build: episode scalars in the row scratch during the substep loop, history read after it) against
     the plain variant on the HOST build, bit for bit (LL_EMUL_PARK=1; see epmc_parity_common.check_parked_variant_equals_plain)."""
@@ -931,13 +971,13 @@ def _oracle_game(seed):
     return len(us), why, named, u0, us
 
 
-def check_game_statistics(lib_path, n_arenas=256, procs=None, frac_tol=0.03, len_tol=0.03, ks_p=0.5):
+def check_game_statistics(lib_path, n_arenas=512, procs=None, frac_tol=0.03, len_tol=0.03, ks_p=0.5, n_se=2.0, seed0=5000):
     """The strategic level's counterpart of parity_common.check_rollout_statistics, at the level the game is decided on: the engine and the float64
     oracle env play the SAME games -- same spawn poses, friction and pushes (the oracle env's uniforms are recorded and handed to the engine draw by
     draw), the reference's trained policy on both robots acting on each side's own observations -- every game to its end on both sides (a catch
     CTG:426-470 / robot 0 down / max_steps).  Distributions must agree: end-reason fractions, mean length and the Kolmogorov-Smirnov test on the
-    lengths under two-sample bars (`frac_tol` / `len_tol` or three standard errors, whichever is larger), and the fraction of arena-steps whose
-    first contact record of robot 0 names the other robot."""
+    lengths under two-sample bars (`frac_tol` / `len_tol` or `n_se` standard errors, whichever is larger -- round 6: 512 games at TWO standard errors; the games are
+    seeded seed0 + i, so a run is reproducible game by game), and the fraction of arena-steps whose first contact record of robot 0 names the other robot."""
     import gc
     import multiprocessing as mp
     from scipy import stats as sst
@@ -948,7 +988,8 @@ def check_game_statistics(lib_path, n_arenas=256, procs=None, frac_tol=0.03, len
     n = n_arenas
     gc.collect()                                              # (no dead engine objects for the forked workers to finalise)
     with mp.get_context('fork').Pool(procs) as p:
-        res = p.map(_oracle_game, [5000 + i for i in range(n)], chunksize=1)
+        res = p.map(_oracle_game, [seed0 + i for i in range(n)], chunksize=1)
+    print('chase-tag game statistics: %d games, oracle seeds %d .. %d, engine seed 3, bars at %.1f standard errors (floors %.3f / %.3f)' % (n, seed0, seed0 + n - 1, n_se, frac_tol, len_tol))
     len_o, why_o, named_o = np.array([r[0] for r in res]), np.array([r[1] for r in res]), np.array([r[2] for r in res])
     cfg = _game_cfg()
     E = make_engine(cfg, n, lib_path, seed=3)
@@ -991,6 +1032,6 @@ def check_game_statistics(lib_path, n_arenas=256, procs=None, frac_tol=0.03, len
     # (parity_common.two_sample_bars; measured on MI355X, 256 games: caught 0.742 / 0.727, robot 0 down 0.109 / 0.109, timed out 0.148 / 0.164,
     # mean length 312.7 / 335.2 with a standard error of the difference of 18, KS p 0.12)
     from parity_common import two_sample_bars
-    two_sample_bars('chase tag', {k: o[k] for k in ('caught', 'fell', 'timed_out')}, len_e, len_o, o['ks_p'], n, floor_frac=frac_tol, floor_len=len_tol, ks_floor=min(ks_p, 0.01))
+    two_sample_bars('chase tag', {k: o[k] for k in ('caught', 'fell', 'timed_out')}, len_e, len_o, o['ks_p'], n, floor_frac=frac_tol, floor_len=len_tol, n_se=n_se, ks_floor=min(ks_p, 0.01))
     assert abs(o['named'][0] - o['named'][1]) <= max(0.002, 0.5 * o['named'][1]), o['named']
     return o

@@ -88,7 +88,12 @@ def test_parked_variant_equals_plain(emul_lib):
 
 
 
+def test_rays_by_a_kernel_of_their_own_equal_the_fused_rays(emul_lib):
+    ec.check_split_rays_equal_fused(emul_lib, n=6, n_steps=24)
+    ec.check_split_rays_equal_fused(emul_lib, n=4, n_steps=12, elements=(1,), noise=True)
+
+
 def test_game_statistics_against_the_oracle_env(emul_lib):
     """the mechanism of the GPU test of the same name (recorded uniforms, both sides to the end of every episode) at a size the CPU build affords;
     the distribution bars proper are asserted on the GPU with 128 episodes per policy"""
-    ec.check_game_statistics(emul_lib, n_per_policy=6, policies=('hurdle',), frac_tol=0.35, len_tol=0.5, ks_p=0.01)
+    ec.check_game_statistics(emul_lib, n_per_policy=6, policies=('hurdle',), frac_tol=0.35, len_tol=0.5, ks_p=0.01, n_se=3.0)

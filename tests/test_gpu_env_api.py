@@ -395,7 +395,10 @@ def test_p2p_pull_occupies_no_compute_unit():
     # about an unroll's time, and the kernel beside it runs 1 - 2 % slower: the copy streams through the Infinity Cache that holds the mocap table -- a hypothesis,
     # the measurement is the point); the hand-off's own cost -- launch gaps the host causes -- is the unexplained rest and must stay within 1 % of the step.
     assert k <= 1.04 * k0, res                                                # the step kernel hardly notices the pulls (no compute unit taken; measured + 1.3 ... 2.7 %: it runs beside a 470 MB DMA stream)
-    assert w <= 1.5 * w0, res                                                 # sanity only, see below
+    # (round 6, advisor: the bare wall bound had been loosened to 1.5 x, which guards nothing.  What is stable on this rig is the wall time WITHOUT the stream's wait for the
+    #  copy -- the coin the box tosses -- and the part of it that neither the kernel nor that wait explains: the launch gaps of the hand-off, + 4 % measured)
+    assert (w - stall) <= 1.10 * w0, res                                      # stall-adjusted wall: measured + 5.6 ... 7.3 %
+    assert unexplained <= 0.07 * w0, (unexplained, res)                       # launch gaps of the host-side hand-off: measured 4.0 ... 4.4 % of the step
     # What is NOT asserted, because this one-device rig cannot decide it: the wall time.  A single SDMA engine moves 470 MB in about the time an unroll takes to simulate, so whether the
     # engine's stream ever stands still behind a copy is a coin the box tosses (measured over four runs of round 5: stall 0.0 - 9.7 % of the step, wall + 5.6 ... 17 %); on a node every pull has
     # its own link and engine and takes 3 - 6 ms of a 24 ms unroll.  Beyond kernel and stall there are + 4 % of launch gaps, present with the round-4 host-side wait too and not with the RCCL

@@ -31,9 +31,17 @@ def test_full_size_invariants_config_4():
         assert ec.check_free_running_invariants(None, n_envs=4096, n_steps=16, element=element) >= 0
 
 
+def test_rays_by_a_kernel_of_their_own_equal_the_fused_rays():
+    """Round 6 (LL_SPLIT_RAYS): epmc_percept_kernel behind the step kernel against the step kernel casting its rays itself, bit for bit -- a partial last wave, observation
+    noise on, and a batch of the two-waves-per-SIMD build"""
+    ec.check_split_rays_equal_fused(None, n=301, n_steps=24)
+    ec.check_split_rays_equal_fused(None, n=64, n_steps=16, elements=(1,), noise=True)
+    ec.check_split_rays_equal_fused(None, n=4200, n_steps=8, elements=(1,))
+
+
 def test_game_statistics_against_the_oracle_env():
-    """distribution-level engine-vs-oracle test of the environmental level: 3 x 128 episodes played to their end on both sides"""
-    ec.check_game_statistics(None, n_per_policy=128)
+    """distribution-level engine-vs-oracle test of the environmental level: 3 x 256 episodes played to their end on both sides, two-sample bars at two standard errors (round 6)"""
+    ec.check_game_statistics(None, n_per_policy=256)
 
 
 def test_env_api_contract_gpu():

@@ -29,8 +29,14 @@ def test_full_size_invariants_config_5_gpu():
 
 
 def test_game_statistics_against_the_oracle_env_gpu():
-    """distribution-level engine-vs-oracle test of the strategic level: 256 chase-tag games played to their end on both sides"""
-    SC.check_game_statistics(None, n_arenas=256)
+    """distribution-level engine-vs-oracle test of the strategic level: 512 chase-tag games played to their end on both sides, two-sample bars at two standard errors (round 6)"""
+    SC.check_game_statistics(None, n_arenas=512)
+
+
+def test_rays_by_a_kernel_of_their_own_equal_the_fused_rays_gpu():
+    """Round 6 (LL_SPLIT_RAYS): the 2 x 778 perception rays of an arena by epmc_percept_kernel behind the step kernel against the fused rays, bit for bit; a partial last wave and the larger-batch build"""
+    SC.check_split_rays_equal_fused(None, n=101, n_steps=24)
+    SC.check_split_rays_equal_fused(None, n=2100, n_steps=6)
 
 
 def test_flag_handover_by_physical_contact_gpu():

@@ -118,7 +118,11 @@ def test_parked_variant_equals_plain(emul_lib):
     SC.check_parked_variant_equals_plain(emul_lib)
 
 
+def test_rays_by_a_kernel_of_their_own_equal_the_fused_rays(emul_lib):
+    SC.check_split_rays_equal_fused(emul_lib)
+
+
 
 def test_game_statistics_against_the_oracle_env(emul_lib):
     """the mechanism of the GPU test of the same name at a size the CPU build affords (the distribution bars are asserted on the GPU, 256 games)"""
-    SC.check_game_statistics(emul_lib, n_arenas=4, frac_tol=0.6, len_tol=1.5, ks_p=0.0)
+    SC.check_game_statistics(emul_lib, n_arenas=4, frac_tol=0.6, len_tol=1.5, ks_p=0.0, n_se=3.0)

@@ -32,9 +32,9 @@ WEIGHTS = {
     'kernel.entry': 1.0 / 32,         # once per launch of 32 control steps
 }
 # single-wave issue cost per instruction class in shader cycles (tools/issue_probe.hip on MI355X: profiles/r06_issue_probe.txt; defaults = profiles/r04_valu_issue.txt)
-DEFAULT_COST = {'vop2': 4.44, 'vop3': 5.38, 'dpp': 5.38, 'pk': 5.94, 'trans': 8.44, 'accvgpr': 4.44, 'mov': 4.44, 'lane': 5.38, 'mfma': 8.0, 's_nop': 4.44, 's_waitcnt': 4.44,
-                'salu': 4.44, 'branch': 4.44, 'lds': 4.44, 'vmem': 4.44, 'smem': 4.44, 'other': 4.44}
-CLASSES = ['vop2', 'vop3', 'dpp', 'pk', 'trans', 'accvgpr', 'mov', 'lane', 'mfma', 's_nop', 's_waitcnt', 'salu', 'branch', 'lds', 'vmem', 'smem', 'other']
+DEFAULT_COST = {'vop2_add': 4.44, 'vop2_mul': 5.75, 'vop2': 5.38, 'vop3': 5.38, 'dpp': 5.38, 'pk': 5.61, 'trans': 8.16, 'accvgpr': 5.38, 'mov': 4.44, 'lane': 5.63, 'mfma': 30.3, 's_nop': 4.44, 's_nop1': 8.16,
+                's_waitcnt': 2.9, 'salu': 2.9, 'branch': 4.44, 'lds': 10.9, 'vmem': 4.44, 'smem': 2.9, 'other': 4.44}
+CLASSES = ['vop2_add', 'vop2_mul', 'vop2', 'vop3', 'dpp', 'pk', 'trans', 'accvgpr', 'mov', 'lane', 'mfma', 's_nop', 's_nop1', 's_waitcnt', 'salu', 'branch', 'lds', 'vmem', 'smem', 'other']
 
 
 def classify(line):
@@ -50,9 +50,12 @@ def classify(line):
         if re.match(r'v_(rcp|rsq|sqrt|sin|cos|exp|log)_', op): return 'trans'
         if op.startswith(('v_readlane', 'v_readfirstlane', 'v_writelane', 'v_permlane')): return 'lane'
         if op.startswith('v_mov_b32'): return 'mov'
-        if op.endswith('_e32') and 'lit' not in line and not re.search(r'0x[0-9a-f]{5,}', line): return 'vop2'
+        if op.endswith('_e32') and 'lit' not in line and not re.search(r'0x[0-9a-f]{5,}', line):
+            if re.match(r'v_(add|sub|subrev)_f32', op): return 'vop2_add'
+            if re.match(r'v_(mul|fmac|mac|lshlrev|lshrrev)_', op): return 'vop2_mul'
+            return 'vop2'
         return 'vop3'
-    if op == 's_nop': return 's_nop'
+    if op == 's_nop': return 's_nop' if re.search(r's_nop\s+0', line) else 's_nop1'
     if op == 's_waitcnt': return 's_waitcnt'
     if op.startswith(('s_cbranch', 's_branch')): return 'branch'
     if op.startswith(('s_load', 's_buffer_load', 's_memtime', 's_memrealtime')): return 'smem'
@@ -132,13 +135,21 @@ def read_costs(path):
             if all(x in k for x in keys):
                 return v
         return None
-    for cls, keys in (('vop2', ('v_fmac_f32_e32',)), ('vop3', ('v_fma_f32 (VOP3',)), ('dpp', ('v_fmac_f32_dpp',)), ('pk', ('v_pk_fma',)), ('trans', ('v_rsq',)), ('accvgpr', ('v_accvgpr_read_b32',)),
-                      ('mov', ('v_mov_b32_e32',)), ('lane', ('v_permlane16',)), ('s_nop', ('s_nop 0',)), ('salu', ('s_mov_b32',)), ('lds', ('ds_read_b32 (16',))):
+    base = pick('v_add_f32_e32 (VOP2')
+    k = (4.44 / base) if base else 1.0           # the probe's counter runs at a fixed clock, the shader does not: normalised to 4.44 shader cycles per v_add_f32 (profiles/r04_valu_issue.txt)
+    for cls, keys in (('vop2_add', ('v_add_f32_e32 (VOP2',)), ('vop2_mul', ('v_fmac_f32_e32',)), ('vop3', ('v_fma_f32 (VOP3',)), ('dpp', ('v_fmac_f32_dpp',)), ('pk', ('v_pk_fma',)), ('trans', ('v_rsq',)),
+                      ('accvgpr', ('v_accvgpr_read_b32',)), ('mov', ('v_mov_b32_e32',)), ('lane', ('v_readlane',)), ('s_nop', ('s_nop 0',)), ('s_nop1', ('s_nop 1',)), ('lds', ('ds_read_b32 (16',)),
+                      ('mfma', ('16x16x1_4b_f32, one acc',))):
         v = pick(*keys)
         if v:
-            cost[cls] = v
-    cost['s_waitcnt'] = cost['branch'] = cost['smem'] = cost['other'] = cost['salu']
-    cost['vmem'] = cost['lds']
+            cost[cls] = v * k
+    pair, fma = pick('v_fma_f32 + s_mov_b32'), pick('v_fma_f32 (VOP3')
+    if pair and fma:
+        cost['salu'] = (2 * pair - fma) * k         # what a scalar instruction ADDS next to a vector one (a pair costs less than the sum of the two alone)
+    cost['vop2'] = cost['vop3']
+    cost['s_waitcnt'] = cost['smem'] = cost['salu']
+    cost['branch'] = cost['other'] = cost['s_nop']
+    cost['vmem'] = cost['s_nop']
     return cost, path
 
 
@@ -173,7 +184,7 @@ def main():
         for ph in order:
             k = trips(ph, p_limit)
             for c in CLASSES:
-                if what == 'n' and c in ('vmem', 'branch', 'smem', 's_waitcnt', 's_nop'):
+                if what == 'n' and c in ('vmem', 'branch', 'smem', 's_waitcnt', 's_nop', 's_nop1'):
                     continue            # the counter sum is SQ_INSTS_VALU + SALU + LDS: no memory, branch, wait or nop instructions (SALU excludes s_nop / s_waitcnt on gfx9)
                 t += led[ph][c] * k * (cost[c] if what == 'cycles' else 1.0)
         return t
@@ -221,8 +232,10 @@ def main():
         w('')
         w('Reconciliation with %s: counted VALU + SALU + LDS instructions per wave per control step %.0f (ledger, same classes: %.0f); issue slots %.0f quad-cycles = %.0f cycles = %.1f us'
           % (os.path.relpath(args.counters, ROOT), meas_inst, total(p_limit), meas_slots, meas_slots * 4, meas_slots * 4 / args.clock_ghz / 1e3))
-        w('(ledger estimate from per-class issue costs: %.0f cycles = %.1f us; the difference is waiting the issue costs do not contain: memory at step entry and in the tail, s_waitcnt, MFMA results).'
-          % (grand_c, grand_c / args.clock_ghz / 1e3))
+        ratio = meas_slots * 4 / grand_c
+        w('(ledger estimate from per-class costs: %.0f cycles = %.1f us, %.2f x the measured cycles: the class costs are those of 64 instructions of ONE form back to back; a mixed stream pays a little less per '
+          'instruction.  Scaled by that ratio the groups read: %s.)' % (grand_c, grand_c / args.clock_ghz / 1e3, 1.0 / ratio,
+                                                                       '; '.join('%s %.1f us (%.0f %%)' % (k_, v[1] * ratio / args.clock_ghz / 1e3, 100.0 * v[1] / grand_c) for k_, v in groups.items())))
     text = '\n'.join(out) + '\n'
     print(text)
     if args.md:
