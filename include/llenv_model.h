@@ -62,6 +62,10 @@
 #define LLM_SELF_MARGIN 0.01            /* a capsule pair of two legs becomes a (speculative) row within this distance: covers closing
                                            speeds up to 5 m/s per 2 ms substep; the capsules themselves are 35 mm thick */
 #define LLM_MAX_SELF 2                  /* self-collision rows per robot */
+#define LLM_SELF_FRICTION 0.0           /* LLM_SPEC_SELF_FRICTION below: mu of a leg-leg contact's two tangential rows; 0 = frictionless (Bullet: 0.5 x 0.5 = 0.25) */
+#define LLM_PAIR_FRICTION 0.0           /* LLM_SPEC_PAIR_FRICTION below: the same for the robot-robot contacts of a chase-tag arena */
+#define LLM_MAX_PAIR 2                  /* LLM_SPEC_MAX_PAIR below: robot-robot rows per robot pair */
+#define LLM_MAX_PAIR_CAP 4              /* ... at most (a persistent manifold holds four points) */
 #define LLM_MAX_COORD_VEL 100.0          /* btMultiBody::m_maxCoordinateVelocity (its constructor's value): every generalized velocity -- base twist, joint rates -- is clipped
                                            to +- this after the unconstrained update and after the solve (applyDeltaVeeMultiDof as recalled; a NaN or an infinity is NOT made a bound: it stays
                                            non-finite for the engine's guard, LL_DONE_NONFINITE).  Inert in every gait
@@ -92,7 +96,7 @@
 #define LLM_SPEC_MAX_SELF 6              /* 0..2    default LLM_MAX_SELF */
 #define LLM_SPEC_ERP 7                   /*         default LLM_ERP */
 #define LLM_SPEC_CONTACT_MARGIN 8        /* m       default LLM_CONTACT_MARGIN */
-#define LLM_SPEC_SELF_FRICTION 9         /* mu of two tangential rows per leg-leg contact; default 0 (frictionless).  ORACLE ONLY */
+#define LLM_SPEC_SELF_FRICTION 9         /* mu of two tangential rows per leg-leg contact; default LLM_SELF_FRICTION.  Oracle and engine (round 6) */
 #define LLM_SPEC_WARM_START 10           /* factor applied to the previous substep's multipliers of persisting rows; default 0 = none.  ORACLE ONLY */
 #define LLM_SPEC_TRUNK_EDGES 11         /* 0 / 1   terrain edges under the body box are contact candidates; default 1.  ORACLE ONLY (a test instrument) */
 #define LLM_SPEC_SELECT_EPS 12          /* m       default LLM_SELECT_EPS.  ORACLE ONLY (a test instrument: parity cases on the rule's discontinuity) */
@@ -109,8 +113,8 @@
                                            contacts sorted by link index, then candidate index */
 #define LLM_SPEC_MAX_COORD_VEL 15       /* default LLM_MAX_COORD_VEL = 100 (the spec since round 4; Bullet's value).  1e30: no clip (rounds 1 - 3).  Oracle and engine */
 #define LLM_SPEC_LIMIT_ERP 16           /* ERP of the joint-limit rows; < 0 = LLM_SPEC_ERP (btMultiBodyJointLimitConstraint uses the world's m_erp, PyBullet's "erp", 0.2).  Oracle and engine */
-#define LLM_SPEC_PAIR_FRICTION 17       /* SEPMC robot-robot rows: mu of two tangential rows per contact; default 0 (frictionless); Bullet: 0.5 x 0.5 */
-#define LLM_SPEC_MAX_PAIR 18            /* SEPMC robot-robot rows per robot pair; default 2, up to 4 (a manifold holds four points) */
+#define LLM_SPEC_PAIR_FRICTION 17       /* SEPMC robot-robot rows: mu of two tangential rows per contact; default LLM_PAIR_FRICTION; Bullet: 0.5 x 0.5.  Oracle and engine (round 6) */
+#define LLM_SPEC_MAX_PAIR 18            /* SEPMC robot-robot rows per robot pair; default LLM_MAX_PAIR, up to LLM_MAX_PAIR_CAP (a manifold holds four points).  Oracle and engine (round 6) */
 #define LLM_SPEC_FRICTION_DIRS 19       /* 0 (spec): friction directions btPlaneSpace1(n), fixed in the world (-y, +x on the ground).  1: the first direction along
                                            the contact point's lateral velocity after the unconstrained update (Bullet's default rule in convertMultiBodyContact
                                            when SOLVER_DISABLE_VELOCITY_DEPENDENT_FRICTION_DIRECTION is not set), the second = t1 x n; btPlaneSpace1 when it

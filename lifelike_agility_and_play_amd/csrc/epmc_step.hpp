@@ -21,7 +21,7 @@
 #define EPMC_BOX_WORDS 8
 #define EPMC_MAX_NEAR 8       // boxes within reach of the robot's contact candidates during one control step
 #define EPMC_EP_STRIDE 40
-#define EPMC_RAY_POSE 16        // floats per row in EpmcParams::ray_pose: pos 3 | R 9 | yaw | noise_z | n_boxes | -
+#define EPMC_RAY_POSE 24        // floats per row in EpmcParams::ray_pose: pos 3 | R 9 | yaw | noise_z | n_boxes | 1 if the last box is overridden | that box record 8
 #define EPMC_LIST_A 320         // row-scratch words: behind the staged box records the three ray lists (height grid, fan, front rays), then 64 spare words.
 #define EPMC_LIST_A_MAX 10      // (PMC_ROW_SCRATCH = 688 words per row is what eight workgroups per CU can afford: 9392 B of tables + 4 x 2752 B <= 160 KB / 8)
 #define EPMC_LIST_B (EPMC_LIST_A + EPMC_LIST_A_MAX * EPMC_BOX_WORDS)
@@ -474,12 +474,19 @@ struct Epmc {
   // are full-rate work.  observe() leaves the row's ray pose (leave_ray_pose), percept_rays() reads it back and writes the three percep arrays of the row: ray r of the row is
   // taken by worker r_first + k r_stride.  Per ray the arithmetic is observe_rays' own, expression for expression (same helpers); a ray's answer is a minimum / maximum over
   // boxes, so neither the order of the boxes nor the compact lists of observe_rays (exact pre-selections) change a bit of it: tests hold the two paths equal.
-  static LL_HD void leave_ray_pose(const L& ln, const EpmcParams& E, int row, const float* pos, const M3<float>& R, float yaw, const float* noise, int n_boxes) {
+  // last_box: the record the rays must see in place of the row's LAST box, or null (SEPMC: the flag where it stood while the step ran -- the step kernel moves the flag's box
+  // behind the observation, CTG:515-579, and the ray kernel runs behind the step kernel)
+  static LL_HD void leave_ray_pose(const L& ln, const EpmcParams& E, int row, const float* pos, const M3<float>& R, float yaw, const float* noise, int n_boxes, const float* last_box = nullptr) {
     if (!ln.lane0()) return;
     float* rec = E.ray_pose + (long)row * EPMC_RAY_POSE;
     rec[0] = pos[0]; rec[1] = pos[1]; rec[2] = pos[2];
     for (int i = 0; i < 9; i++) rec[3 + i] = R.m[i];
-    rec[12] = yaw; rec[13] = noise[3]; rec[14] = (float)n_boxes; rec[15] = 0.0f;
+    rec[12] = yaw; rec[13] = noise[3]; rec[14] = (float)n_boxes; rec[15] = last_box ? 1.0f : 0.0f;
+    for (int i = 0; i < EPMC_BOX_WORDS; i++) rec[16 + i] = last_box ? last_box[i] : 0.0f;
+  }
+  // box b of the row as the rays of this observation must see it
+  static LL_HD BoxRec ray_box(const float* rec, const float* row_boxes, int b) {
+    return load_box((rec[15] != 0.0f && b == (int)rec[14] - 1) ? rec + 16 : row_boxes + b * EPMC_BOX_WORDS);
   }
   // which of the row's boxes a ray family can meet at all: observe_rays' three bounds tests (family 0 height grid, 1 fan, 2 front rays)
   struct RayBounds { float hgx, hgy, flo[3], fhi[3]; };
@@ -511,66 +518,69 @@ struct Epmc {
     const float d[3] = {3.0f * R.m[0], 3.0f * R.m[3], 3.0f * R.m[6]};
     float inv[3];
     for (int a = 0; a < 3; a++) inv[a] = d[a] != 0.0f ? 1.0f / d[a] : 0.0f;
-    for (int r = r_first; r < EPMC_N_RAYS; r += r_stride) {
+    // family by family (every worker walks the same loop at the same time: no divergence between ray kinds inside a wavefront)
+    for (int r = r_first; r < EPMC_N_HEIGHT; r += r_stride) {                    // observe_rays: height grid
       float* tr = E.ray_trace ? E.ray_trace + ((long)row * EPMC_N_RAYS + r) * 8 : nullptr;
-      if (r < EPMC_N_HEIGHT) {                                                   // observe_rays: height grid
-        float gx, gy;
-        grid_point(r, -1.2f, 1.2f, -0.6f, 0.6f, &gx, &gy);
-        const float x = R.m[0] * gx + R.m[1] * gy + pos[0], y = R.m[3] * gx + R.m[4] * gy + pos[1];
-        float top = 0.0f;
-        for (int b = 0; b < n[0]; b++) {
-          const BoxRec bx = load_box(lists[0] + b * EPMC_BOX_WORDS);
-          const bool in = (x >= bx.a.x) & (x <= bx.a.y) & (y >= bx.a.z) & (y <= bx.a.w);
-          top = in ? fmaxf(top, bx.c.y) : top;
-        }
-        const float frac = (10.0f - top) * 0.05f;
-        float v = 10.0f + frac * -20.0f;
-        if (E.noise_on[3]) v = (v > 0.01f && v < 0.6f) ? v + noise_z : 0.0f;
-        percep[r] = v;
-        if (tr) { tr[0] = x; tr[1] = y; tr[2] = 10.0f; tr[3] = x; tr[4] = y; tr[5] = -10.0f; tr[6] = 1.0f; tr[7] = frac; }
-      } else if (r < EPMC_N_HEIGHT + EPMC_N_HORIZ) {                             // observe_rays: horizontal fan
-        const int k = r - EPMC_N_HEIGHT;
-        float sk, ck;
-        sincos_f(6.283185307179586f * (float)k * (1.0f / 128.0f), &sk, &ck);
-        const float dx = 20.0f * (cy * ck - sy * sk), dy = 20.0f * (sy * ck + cy * sk);
-        const float ix = dx != 0.0f ? 1.0f / dx : 0.0f, iy = dy != 0.0f ? 1.0f / dy : 0.0f;
-        float best = 3.0e38f;
-        for (int b = 0; b < n[1]; b++) {
-          const BoxRec bx = load_box(lists[1] + b * EPMC_BOX_WORDS);
-          float te = -3.0e38f, tl = 3.0e38f;
-          slab_axis(bx.a.x, bx.a.y, pos[0], dx, ix, te, tl);
-          slab_axis(bx.a.z, bx.a.w, pos[1], dy, iy, te, tl);
-          const bool ok = (pos[2] >= bx.c.x) & (pos[2] <= bx.c.y) & (te <= tl) & (te >= 0.0f) & (te <= 1.0f);
-          best = ok ? fminf(best, te) : best;
-        }
-        const bool hit = best < 2.0f;
-        percep[r] = hit ? best * 20.0f : miss;
-        if (tr) { tr[0] = pos[0]; tr[1] = pos[1]; tr[2] = pos[2]; tr[3] = pos[0] + dx; tr[4] = pos[1] + dy; tr[5] = pos[2]; tr[6] = hit ? 1.0f : 0.0f; tr[7] = hit ? best : 1.0f; }
-      } else {                                                                   // observe_rays: front rays
-        const int i = r - EPMC_N_HEIGHT - EPMC_N_HORIZ;
-        float gy, gz, o[3];
-        grid_point(i, -0.25f, 0.25f, -0.3f, 0.1f, &gy, &gz);
-        for (int a = 0; a < 3; a++) o[a] = R.m[3 * a + 1] * gy + R.m[3 * a + 2] * gz + pos[a];
-        float best = 3.0e38f;
-        if (d[2] < 0.0f) {
-          const float tz = -o[2] * inv[2];
-          if (tz >= 0.0f && tz <= 1.0f) best = tz;
-        }
-        for (int b = 0; b < n[2]; b++) {
-          const BoxRec bx = load_box(lists[2] + b * EPMC_BOX_WORDS);
-          float te = -3.0e38f, tl = 3.0e38f;
-          slab_axis(bx.a.x, bx.a.y, o[0], d[0], inv[0], te, tl);
-          slab_axis(bx.a.z, bx.a.w, o[1], d[1], inv[1], te, tl);
-          slab_axis(bx.c.x, bx.c.y, o[2], d[2], inv[2], te, tl);
-          const bool ok = (te <= tl) & (te >= 0.0f) & (te <= 1.0f);
-          best = ok ? fminf(best, te) : best;
-        }
-        const bool hit = best < 2.0f;
-        percep[r] = hit ? best * 3.0f : 3.0f;
-        if (tr) {
-          for (int a = 0; a < 3; a++) { tr[a] = o[a]; tr[3 + a] = o[a] + d[a]; }
-          tr[6] = hit ? 1.0f : 0.0f; tr[7] = hit ? best : 1.0f;
-        }
+      float gx, gy;
+      grid_point(r, -1.2f, 1.2f, -0.6f, 0.6f, &gx, &gy);
+      const float x = R.m[0] * gx + R.m[1] * gy + pos[0], y = R.m[3] * gx + R.m[4] * gy + pos[1];
+      float top = 0.0f;
+      for (int b = 0; b < n[0]; b++) {
+        const BoxRec bx = load_box(lists[0] + b * EPMC_BOX_WORDS);
+        const bool in = (x >= bx.a.x) & (x <= bx.a.y) & (y >= bx.a.z) & (y <= bx.a.w);
+        top = in ? fmaxf(top, bx.c.y) : top;
+      }
+      const float frac = (10.0f - top) * 0.05f;
+      float v = 10.0f + frac * -20.0f;
+      if (E.noise_on[3]) v = (v > 0.01f && v < 0.6f) ? v + noise_z : 0.0f;
+      percep[r] = v;
+      if (tr) { tr[0] = x; tr[1] = y; tr[2] = 10.0f; tr[3] = x; tr[4] = y; tr[5] = -10.0f; tr[6] = 1.0f; tr[7] = frac; }
+    }
+    for (int k = r_first; k < EPMC_N_HORIZ; k += r_stride) {                     // observe_rays: horizontal fan
+      const int r = EPMC_N_HEIGHT + k;
+      float* tr = E.ray_trace ? E.ray_trace + ((long)row * EPMC_N_RAYS + r) * 8 : nullptr;
+      float sk, ck;
+      sincos_f(6.283185307179586f * (float)k * (1.0f / 128.0f), &sk, &ck);
+      const float dx = 20.0f * (cy * ck - sy * sk), dy = 20.0f * (sy * ck + cy * sk);
+      const float ix = dx != 0.0f ? 1.0f / dx : 0.0f, iy = dy != 0.0f ? 1.0f / dy : 0.0f;
+      float best = 3.0e38f;
+      for (int b = 0; b < n[1]; b++) {
+        const BoxRec bx = load_box(lists[1] + b * EPMC_BOX_WORDS);
+        float te = -3.0e38f, tl = 3.0e38f;
+        slab_axis(bx.a.x, bx.a.y, pos[0], dx, ix, te, tl);
+        slab_axis(bx.a.z, bx.a.w, pos[1], dy, iy, te, tl);
+        const bool ok = (pos[2] >= bx.c.x) & (pos[2] <= bx.c.y) & (te <= tl) & (te >= 0.0f) & (te <= 1.0f);
+        best = ok ? fminf(best, te) : best;
+      }
+      const bool hit = best < 2.0f;
+      percep[r] = hit ? best * 20.0f : miss;
+      if (tr) { tr[0] = pos[0]; tr[1] = pos[1]; tr[2] = pos[2]; tr[3] = pos[0] + dx; tr[4] = pos[1] + dy; tr[5] = pos[2]; tr[6] = hit ? 1.0f : 0.0f; tr[7] = hit ? best : 1.0f; }
+    }
+    for (int i = r_first; i < EPMC_N_FRONT; i += r_stride) {                     // observe_rays: front rays
+      const int r = EPMC_N_HEIGHT + EPMC_N_HORIZ + i;
+      float* tr = E.ray_trace ? E.ray_trace + ((long)row * EPMC_N_RAYS + r) * 8 : nullptr;
+      float gy, gz, o[3];
+      grid_point(i, -0.25f, 0.25f, -0.3f, 0.1f, &gy, &gz);
+      for (int a = 0; a < 3; a++) o[a] = R.m[3 * a + 1] * gy + R.m[3 * a + 2] * gz + pos[a];
+      float best = 3.0e38f;
+      if (d[2] < 0.0f) {
+        const float tz = -o[2] * inv[2];
+        if (tz >= 0.0f && tz <= 1.0f) best = tz;
+      }
+      for (int b = 0; b < n[2]; b++) {
+        const BoxRec bx = load_box(lists[2] + b * EPMC_BOX_WORDS);
+        float te = -3.0e38f, tl = 3.0e38f;
+        slab_axis(bx.a.x, bx.a.y, o[0], d[0], inv[0], te, tl);
+        slab_axis(bx.a.z, bx.a.w, o[1], d[1], inv[1], te, tl);
+        slab_axis(bx.c.x, bx.c.y, o[2], d[2], inv[2], te, tl);
+        const bool ok = (te <= tl) & (te >= 0.0f) & (te <= 1.0f);
+        best = ok ? fminf(best, te) : best;
+      }
+      const bool hit = best < 2.0f;
+      percep[r] = hit ? best * 3.0f : 3.0f;
+      if (tr) {
+        for (int a = 0; a < 3; a++) { tr[a] = o[a]; tr[3 + a] = o[a] + d[a]; }
+        tr[6] = hit ? 1.0f : 0.0f; tr[7] = hit ? best : 1.0f;
       }
     }
   }
@@ -585,7 +595,7 @@ struct Epmc {
     float buf[3][EPMC_MAX_BOXES * EPMC_BOX_WORDS];
     int n[3] = {0, 0, 0};
     for (int b = 0; b < nb; b++) {
-      const BoxRec r = load_box(boxes + b * EPMC_BOX_WORDS);
+      const BoxRec r = ray_box(rec, boxes, b);
       for (int fam = 0; fam < 3; fam++)
         if (box_in_family(fam, r, rec, bd)) store_box(buf[fam] + (n[fam]++) * EPMC_BOX_WORDS, r);
     }
@@ -729,7 +739,7 @@ struct Epmc {
   // the control step (PGE:299-364)
   // ------------------------------------------------------------------------------------------------------------
   // PARK (the larger-batch build): the 40 per-env scalars wait in LDS and the history chunks are read after the substep loop (sepmc_step.hpp)
-  template <bool PARK = false, bool CONE = false>   // CONE: the cone-coupled friction solve (LLM_SPEC_FRICTION_MODE = 2, Pmc::gs_cone_round)
+  template <bool PARK = false, bool CONE = false, bool XROWS = false>   // CONE: the cone-coupled friction solve (LLM_SPEC_FRICTION_MODE = 2, Pmc::gs_cone_round); XROWS: Pmc::substep_impl
   static LL_HD void step_env(const L& ln, const StepParams& P_in, const EpmcParams& E, int env, const F* act_in) {
     const StepParams& P = ln.params(P_in);
     const int N = P.n_envs;
@@ -805,7 +815,7 @@ struct Epmc {
         ptrace[s * 4 + 0] = ex.has_push ? 1.0f : 0.0f;
         for (int i = 0; i < 3; i++) ptrace[s * 4 + 1 + i] = ex.has_push ? ex.push[i] : 0.0f;
       }
-      if (!E.scr_state) K::template substep_impl<true, false, CONE>(ln, P, bs, q, qd, tgt, env, s, &ex, nullptr);   // PGE:328-330
+      if (!E.scr_state) K::template substep_impl<true, false, CONE, XROWS>(ln, P, bs, q, qd, tgt, env, s, &ex, nullptr);   // PGE:328-330
     }
     if (PARK) {
       const float keep[4] = {ep[EP_PUSH_COUNT], ep[EP_PUSH_FORCE], ep[EP_PUSH_FORCE + 1], ep[EP_PUSH_FORCE + 2]};
@@ -852,14 +862,14 @@ struct Epmc {
     if (E.element_id == 0) {                                                      // joystick, PGE:474-497
       const float r_vel = expf(-fabsf(spd - ep[EP_TARGET_SPD]));
       reward = r_vel * r_rot * inv_ms;
-      ep[EP_REW + 1] += r_rot * inv_ms;
-      ep[EP_REW + 0] += r_vel * inv_ms;
+      ep[EP_REW + 1] = __builtin_fmaf(r_rot, inv_ms, ep[EP_REW + 1]);      // (explicit fused multiply-adds: see `dist` above -- round 6: the multi-step and the single-step builds had
+      ep[EP_REW + 0] = __builtin_fmaf(r_vel, inv_ms, ep[EP_REW + 0]);      //  contracted these sums differently, a reward 50 ulp apart under cancellation)
     } else {                                                                      // average speed, PGE:499-539
       const float r_dist = ep[EP_INIT_DIFF] >= 0.0f ? (dist - ep[EP_LAST_DIFF]) / ep[EP_INIT_DIFF] : 0.0f;
       ep[EP_LAST_DIFF] = dist;
       const float s_rot = r_rot * inv_ms * 0.1f, s_dist = -r_dist * 0.1f;
-      reward = s_rot * 2.0f + s_dist;
-      ep[EP_REW + 1] += s_rot * 2.0f;
+      reward = __builtin_fmaf(s_rot, 2.0f, s_dist);
+      ep[EP_REW + 1] = __builtin_fmaf(s_rot, 2.0f, ep[EP_REW + 1]);
       ep[EP_REW + 2] += s_dist;
       if (reach) {
         const float r_avg = expf(-fabsf(ep[EP_TOTAL_SPD] / (float)cnt - ep[EP_TARGET_SPD]));

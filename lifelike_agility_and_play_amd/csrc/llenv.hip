@@ -216,7 +216,8 @@ __device__ __forceinline__ void step_actions(const StepParams& P, const Lanes& l
 // OBST = the set_obstacle build (Pmc::step_env<true>): the jump obstacle takes part in the substeps as a static box.
 // MULTI = the launch may run several control steps (ll_step_random_n); single-step launches run the loop-free build.
 // CONE = the cone-coupled friction solve (LLM_SPEC_FRICTION_MODE = 2, Pmc::gs_cone_round): its own instantiations of every step kernel.
-template <int OCC, bool OBST = false, bool MULTI = false, bool CONE = false>
+// XROWS = the build that can carry the extended contact rows (Pmc::substep_impl; launched when LLM_SPEC_SELF_FRICTION / _PAIR_FRICTION / _MAX_PAIR are off their defaults: cone builds only).
+template <int OCC, bool OBST = false, bool MULTI = false, bool CONE = false, bool XROWS = false>
 __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);      // one env = one 16-lane DPP row
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
     if (env0 < P.n_envs) {
       float act[3];
       step_actions(P, ln, lds, env0, 0, act);
-      Pmc<Lanes>::template step_env<OBST, CONE>(ln, P, env0, act, 0);
+      Pmc<Lanes>::template step_env<OBST, CONE, XROWS>(ln, P, env0, act, 0);
     }
     step_done_fold(P, 0, true, false);
   } else {
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
         float act[3];
         PMC_PHASE("step.actions");
         step_actions(P, ln, lds, env, sl, act);
-        Pmc<Lanes>::template step_env<OBST, CONE>(ln, P, env, act, sl);
+        Pmc<Lanes>::template step_env<OBST, CONE, XROWS>(ln, P, env, act, sl);
       }
       PMC_PHASE("step.table_fold");
       const StepParams& Pr = kernarg_params();      // (re-read from the kernarg segment like the step itself: nothing of it is parked in spilled SGPRs across the step)
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void pmc_step_kernel(StepParams P) {
 // not have (788 instead of 552 B of scratch per lane; 65536 envs: 18.6 -> 16.8 M env-steps/s), and a grid of sixteen wavefronts per SIMD has
 // neither a launch gap nor a slowest wave worth hiding, so multi-step launches exist for the one-wave-per-SIMD build only; larger batches
 // run their steps as single launches (same results: the step's draws are keyed on env, episode and draw index).
-template <int OCC, bool MULTI = false, bool CONE = false>   // CONE: see pmc_step_kernel
+template <int OCC, bool MULTI = false, bool CONE = false, bool XROWS = false>   // CONE, XROWS: see pmc_step_kernel
 __global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, EpmcParams E) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, 
   if constexpr (!MULTI) {
     float act[3];
     step_actions(P, ln, lds, env0, 0, act);
-    Epmc<Lanes>::template step_env<((OCC == 2 && LL_PARK) || LL_PARK > 1), CONE>(ln, P, E, env0, act);
+    Epmc<Lanes>::template step_env<((OCC == 2 && LL_PARK) || LL_PARK > 1), CONE, XROWS>(ln, P, E, env0, act);
   } else {
     for (int sl = 0; sl < P.n_steps; sl++) {               // ll_epmc_step_random_n: see pmc_step_kernel
       if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void epmc_step_kernel(StepParams P, 
       asm volatile("" : "+v"(env));
       float act[3];
       step_actions(P, ln, lds, env, sl, act);
-      Epmc<Lanes>::template step_env<(LL_PARK > 1), CONE>(ln, P, E, env, act);
+      Epmc<Lanes>::template step_env<(LL_PARK > 1), CONE, XROWS>(ln, P, E, env, act);
     }
   }
 }
@@ -301,10 +302,10 @@ __global__ __launch_bounds__(PMC_WAVE) void epmc_reset_kernel(StepParams P, Epmc
   Epmc<GpuLanes>::reset_env(ln, P, E, env, draws ? draws + (long)i * EPMC_MAX_DRAWS : nullptr, prev_orn ? prev_orn + (long)i * 4 : nullptr);
 }
 
-// The 778 rays of a row's observation as a kernel of their own (round 6; epmc_step.hpp percept_rays): one workgroup of four waves per row -- sixteen waves per SIMD at 4096 rows, where the
+// The 778 rays of a row's observation as a kernel of their own (round 6; epmc_step.hpp percept_rays): one workgroup of two waves per row -- eight waves per SIMD at 4096 rows, where the
 // step kernel has one -- stages the row's box records in LDS, sorts them into the three ray families' lists (any order: a ray's answer is a minimum / maximum over boxes), and thread t casts
-// rays t, t + 256, t + 512, (t + 768).  Launched behind a step kernel that ran with EpmcParams::split_rays (it left the row's pose in ray_pose); serves EPMC rows and SEPMC robot rows alike.
-#define PERCEPT_THREADS 256
+// its share of every ray family.  Launched behind a step kernel that ran with EpmcParams::split_rays (it left the row's pose in ray_pose); serves EPMC rows and SEPMC robot rows alike.
+#define PERCEPT_THREADS 128      // 325 + 128 + 325 rays in 3 + 1 + 3 passes of two waves: 87 % of the lanes busy (256 threads: 61 %)
 __global__ __launch_bounds__(PERCEPT_THREADS) void epmc_percept_kernel(StepParams P, EpmcParams E) {
   __shared__ __attribute__((aligned(16))) float lists[3][EPMC_MAX_BOXES * EPMC_BOX_WORDS];
   __shared__ int cnt[3];
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(PERCEPT_THREADS) void epmc_percept_kernel(StepParam
     M3<float> R;
     for (int i = 0; i < 9; i++) R.m[i] = rec[3 + i];
     const EP::RayBounds bd = EP::ray_bounds(rec, R);
-    const BoxRec r = load_box(E.boxes + ((long)row * EPMC_MAX_BOXES + threadIdx.x) * EPMC_BOX_WORDS);
+    const BoxRec r = EP::ray_box(rec, E.boxes + (long)row * EPMC_MAX_BOXES * EPMC_BOX_WORDS, threadIdx.x);
     for (int fam = 0; fam < 3; fam++)
       if (EP::box_in_family(fam, r, rec, bd)) store_box(lists[fam] + atomicAdd(&cnt[fam], 1) * EPMC_BOX_WORDS, r);
   }
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(PERCEPT_THREADS) void epmc_percept_kernel(StepParam
 
 // SEPMC (sepmc_step.hpp): one control step of ChaseTagGameEnv; row = 2 * arena + robot, the two robots of an arena are
 // neighbouring rows of one wave and exchange state with v_permlane16_swap.
-template <int OCC, bool MULTI = false, bool CONE = false>          // MULTI: see epmc_step_kernel; CONE: see pmc_step_kernel
+template <int OCC, bool MULTI = false, bool CONE = false, bool XROWS = false>          // MULTI: see epmc_step_kernel; CONE, XROWS: see pmc_step_kernel
 __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P, SepmcParams S) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int row0 = blockIdx.x * PMC_ENVS_PER_WAVE + (threadIdx.x >> 4);
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P,
   if constexpr (!MULTI) {
     float act[3];
     step_actions(P, ln, lds, row0, 0, act);
-    Sepmc<Lanes>::template step_env<((OCC == 2 && LL_PARK) || LL_PARK > 1), CONE>(ln, P, S, row0, act);
+    Sepmc<Lanes>::template step_env<((OCC == 2 && LL_PARK) || LL_PARK > 1), CONE, XROWS>(ln, P, S, row0, act);
   } else {
     for (int sl = 0; sl < P.n_steps; sl++) {               // ll_sepmc_step_random_n: see pmc_step_kernel
       if (sl) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(PMC_WAVE, OCC) void sepmc_step_kernel(StepParams P,
       asm volatile("" : "+v"(row));
       float act[3];
       step_actions(P, ln, lds, row, sl, act);
-      Sepmc<Lanes>::template step_env<(LL_PARK > 1), CONE>(ln, P, S, row, act);
+      Sepmc<Lanes>::template step_env<(LL_PARK > 1), CONE, XROWS>(ln, P, S, row, act);
     }
   }
 }
@@ -449,9 +450,11 @@ struct HipBackend {
     const char* sh = getenv("LL_SHARE_SIMDS");
     if (sh && sh[0] == '1') simds = 0;
     // LL_SPLIT_RAYS (EPMC / SEPMC): 0 = the step kernel casts the 778 rays of a row itself (rounds 1 - 5); 1 = single-step launches leave them to epmc_percept_kernel behind the step
-    // kernel; 2 (default) = multi-step calls too run as single steps, each followed by the ray kernel (what the A/B on one box decided: profiles/r06_split_rays_ab.txt)
+    // kernel; 2 = multi-step calls too run as single steps, each followed by the ray kernel.  Defaults by the A/B on one box (profiles/r06_split_rays_ab.txt): EPMC 2 (hurdles: single steps
+    // 0.2983 -> 0.2905 ms, 32-step calls 0.2894 -> 0.2898; cube stairs 0.3163 -> 0.2937), SEPMC 1 (single steps 0.3341 -> 0.3308; 32-step calls would lose 4 %: 0.3153 -> 0.3286)
     const char* sr = getenv("LL_SPLIT_RAYS");
-    split_rays = sr ? atoi(sr) : 2;
+    split_rays_epmc = sr ? atoi(sr) : 2;
+    split_rays_sepmc = sr ? atoi(sr) : 1;
     stream = own;
   }
   ~HipBackend() {
@@ -461,7 +464,7 @@ struct HipBackend {
   }
   void use() { HIPCHK(hipSetDevice(device)); }
   int simds_hw = 1024;
-  int split_rays = 2;
+  int split_rays_epmc = 2, split_rays_sepmc = 1;
   // can every workgroup of a step launch be on the chip at once?  (one 512-register wave per SIMD while the grid fits, two 256-register waves otherwise:
   // launch_step.)  A multi-step launch needs it -- its waves wait for each other's finished episodes (PmcEngine::step)
   bool co_resident(const StepParams& P) const {
@@ -510,7 +513,7 @@ struct HipBackend {
     return ev;
   }
   // the rays of the step's observation by the kernel of their own?  Not when the caller plays rayTestBatch (scripted rays) -- and a multi-step call only under LL_SPLIT_RAYS=2, as single steps
-  bool rays_split(const StepParams& P, const EpmcParams& E) const { return !E.scr_ray_hit && (P.n_steps == 1 ? split_rays >= 1 : split_rays >= 2); }
+  static bool rays_split(const StepParams& P, const EpmcParams& E, int mode) { return !E.scr_ray_hit && (P.n_steps == 1 ? mode >= 1 : mode >= 2); }
   void launch_percept(const StepParams& P, const EpmcParams& E) {
     hipLaunchKernelGGL(epmc_percept_kernel, dim3(P.n_envs), dim3(PERCEPT_THREADS), 0, stream, P, E);
   }
@@ -518,10 +521,19 @@ struct HipBackend {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
-    const bool cone = P.friction_mode == 2, split = rays_split(P, E_in);
+    const bool cone = P.friction_mode == 2, split = rays_split(P, E_in, split_rays_epmc);
     EpmcParams E = E_in;
     E.split_rays = split ? 1 : 0;
 #define LL_GO(KERNEL, PARAMS) hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, PARAMS, E)
+    if (pmc_wants_xrows(P)) {                            // the extended contact rows (round 6): the cone builds with XROWS, every step a launch of its own
+      if (!cone) throw PmcError(LL_EINVAL, "self_friction needs friction_mode 2 (the extended contact rows exist in the cone builds)");
+      StepParams Q = P;
+      Q.n_steps = 1;
+      for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) {
+        if (blocks <= simds) LL_GO((epmc_step_kernel<1, false, true, true>), Q); else LL_GO((epmc_step_kernel<2, false, true, true>), Q);
+        if (split) launch_percept(Q, E);
+      }
+    } else
     if (P.n_steps == 1) {
       if (blocks <= simds) { if (cone) LL_GO((epmc_step_kernel<1, false, true>), P); else LL_GO((epmc_step_kernel<1>), P); }
       else                 { if (cone) LL_GO((epmc_step_kernel<2, false, true>), P); else LL_GO((epmc_step_kernel<2>), P); }
@@ -551,10 +563,19 @@ struct HipBackend {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
-    const bool cone = P.friction_mode == 2, split = rays_split(P, S_in.e);
+    const bool cone = P.friction_mode == 2, split = rays_split(P, S_in.e, split_rays_sepmc);
     SepmcParams S = S_in;
     S.e.split_rays = split ? 1 : 0;
 #define LL_GO(KERNEL, PARAMS) hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, PARAMS, S)
+    if (pmc_wants_xrows(P)) {                            // the extended contact rows (round 6): see launch_epmc_step
+      if (!cone) throw PmcError(LL_EINVAL, "self_friction / pair_friction / max_pair need friction_mode 2 (the extended contact rows exist in the cone builds)");
+      StepParams Q = P;
+      Q.n_steps = 1;
+      for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) {
+        if (blocks <= simds) LL_GO((sepmc_step_kernel<1, false, true, true>), Q); else LL_GO((sepmc_step_kernel<2, false, true, true>), Q);
+        if (split) launch_percept(Q, S.e);
+      }
+    } else
     if (P.n_steps == 1) {
       if (blocks <= simds) { if (cone) LL_GO((sepmc_step_kernel<1, false, true>), P); else LL_GO((sepmc_step_kernel<1>), P); }
       else                 { if (cone) LL_GO((sepmc_step_kernel<2, false, true>), P); else LL_GO((sepmc_step_kernel<2>), P); }
@@ -585,6 +606,13 @@ struct HipBackend {
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
     const bool one = blocks <= simds, multi = P.n_steps > 1;
+    if (pmc_wants_xrows(P)) {                            // the extended contact rows (round 6): flat-ground cone builds with XROWS
+      if (P.friction_mode != 2 || P.set_obstacle) throw PmcError(LL_EINVAL, "self_friction needs friction_mode 2 and no jump obstacle (the extended contact rows exist in the flat-ground cone builds)");
+      if (one) { if (multi) hipLaunchKernelGGL((pmc_step_kernel<1, false, true, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P);
+                 else       hipLaunchKernelGGL((pmc_step_kernel<1, false, false, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes(), stream, P); }
+      else     { if (multi) hipLaunchKernelGGL((pmc_step_kernel<2, false, true, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
+                 else       hipLaunchKernelGGL((pmc_step_kernel<2, false, false, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P); }
+    } else
     if (P.set_obstacle && P.friction_mode == 2) {
       if (one) { if (multi) hipLaunchKernelGGL((pmc_step_kernel<1, true, true, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P);
                  else       hipLaunchKernelGGL((pmc_step_kernel<1, true, false, true>), dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, P); }

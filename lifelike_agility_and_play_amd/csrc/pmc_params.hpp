@@ -105,6 +105,9 @@ struct StepParams {
   int32_t limit_speculative;   // LLM_SPEC_LIMIT_SPECULATIVE: 1 = a limit row inside the range too (gated by limit_gate); 0 = Bullet's rule, a row only once the limit is passed
   float max_coord_vel;      // LLM_SPEC_MAX_COORD_VEL (btMultiBody::m_maxCoordinateVelocity, 100): base twist and joint rates clipped after the unconstrained update and after the solve
   int32_t max_contacts, max_self;   // deepest-K per leg (LLM_MAX_CONTACTS_PER_LEG), self-collision rows per robot (LLM_MAX_SELF)
+  float self_friction, pair_friction;   // LLM_SPEC_SELF_FRICTION / LLM_SPEC_PAIR_FRICTION (round 6: engine twins of the oracle switches): mu of the two tangential rows a leg-leg / robot-robot
+                                        // contact carries behind its normal row (box bounds +- mu x the normal multiplier, btPlaneSpace1 directions); 0 = frictionless (the spec of rounds 1 - 5)
+  int32_t max_pair, pad_spec;           // LLM_SPEC_MAX_PAIR: robot-robot rows per robot pair, 2 (rounds 1 - 5) .. 4 (a manifold's four points)
   double dt_d, frame_step, policy_step, sample_factor;
   uint64_t seed;
   uint64_t step_count;      // control steps executed so far (salts the Philox stream)
@@ -173,3 +176,6 @@ struct StepParams {
   const float* candc;       // [CAND_TABLE_WORDS][16]
   const float* basec;       // [BC_COUNT]
 };
+
+// the launch needs the build with the extended contact rows (Pmc::substep_impl<.., XROWS = true>): one of the round-6 switches is off its default
+LL_HD bool pmc_wants_xrows(const StepParams& P) { return P.self_friction > 0.0f || P.pair_friction > 0.0f || P.max_pair != LLM_MAX_PAIR; }

@@ -658,6 +658,87 @@ struct Pmc {
     self_row_apply(ln, rw, d, VA, VB, VJ);
   }
 
+  // a tangential row of a leg-leg contact (LLM_SPEC_SELF_FRICTION, round 6): box bounds +- hi = mu x the contact's normal multiplier, as the oracle's sweep takes them
+  static LL_HD void self_fric_turn(const L& ln, SelfRow& rw, float hi, F& VA, F& VB, F& VJ) {
+    const float w = rw.c + self_row_velocity(rw, VA, VB, VJ);
+    const float nl = fminf(fmaxf(rw.lam - w * rw.inv, -hi), hi);
+    const float d = nl - rw.lam;
+    rw.lam = nl;
+    self_row_apply(ln, rw, d, VA, VB, VJ);
+  }
+  // btPlaneSpace1(n): the two tangents Bullet pairs with a contact normal (world coordinates; the oracle's dirs[1], dirs[2])
+  static LL_HD void plane_space(const V3<float>& n, V3<float>& p, V3<float>& q) {
+    if (fabsf(n.z) > 0.7071067811865475f) {
+      const float a = n.y * n.y + n.z * n.z, kk = 1.0f / sqrtf(a);
+      p = mk3<float>(0.0f, -n.z * kk, n.y * kk);
+      q = mk3<float>(a * kk, -n.x * p.z, n.x * p.y);
+    } else {
+      const float a = n.x * n.x + n.y * n.y, kk = 1.0f / sqrtf(a);
+      p = mk3<float>(-n.y * kk, n.x * kk, 0.0f);
+      q = mk3<float>(-n.z * p.y, n.z * p.x, a * kk);
+    }
+  }
+  // one row of a leg-leg contact along direction ub (F0): the two points move with the base alike, so the row has joint parts only (sgn: + own leg, - other leg, 0 elsewhere;
+  // e1 .. e3: the lever arms of the lane's joints about the contact point)
+  static LL_HD void self_row_build(const L& ln, SelfRow& rw, const V3l& ub, const F& sgn, const V3l& e1, const V3l& e2, const V3l& e3, const LegFactor& lf,
+                                   const float* Sb, const float* Sd, const F* qs, float bias, bool have) {
+    const F zero = ln.lane_f(0.0f);
+    F sjt[3];
+    float sgt[6];
+    sjt[0] = sgn * dot(ub, e1); sjt[1] = sgn * dot(ub, e2); sjt[2] = sgn * dot(ub, e3);
+    float vrow = L::qsum(sjt[0] * qs[0] + sjt[1] * qs[1] + sjt[2] * qs[2]);      // the base moves both points alike: no base part
+    lm_fwd(lf, sjt);
+    SV<F> yj = scale(lf.y1, sjt[0]) + scale(lf.y2, sjt[1]) + scale(lf.y3, sjt[2]);
+    F g6[6] = {zero - yj.a.x, zero - yj.a.y, zero - yj.a.z, zero - yj.l.x, zero - yj.l.y, zero - yj.l.z};
+    L::qsum6(g6, sgt);
+    fwd6(Sb, Sd, sgt);
+    float nn = L::qsum(sjt[0] * sjt[0] + sjt[1] * sjt[1] + sjt[2] * sjt[2]);
+    for (int i = 0; i < 6; i++) nn += sgt[i] * sgt[i];
+    self_row_pack(ln, sjt, sgt, rw);
+    rw.c = vrow + bias;
+    rw.inv = have ? 1.0f / nn : 0.0f;
+    rw.lam = 0.0f;
+    if (!have) self_row_clear(ln, rw);
+  }
+
+  // one shared row of a robot-robot contact along direction ub_ (my F0; the world direction points from robot 1 to robot 0 and carries my sign) at point pb_: my half of it -- base
+  // part [pb_ x ub_; ub_] and the joints of the leg that holds my capsule (`mine`) -- whitened; free velocity and diagonal are summed with the other robot's half in a fixed
+  // order (robot 0's first), so both rows of the arena hold the same c and inv
+  static LL_HD void pair_row_build(const L& ln, SelfRow& rw, const V3<float>& ub_, const V3<float>& pb_, const B& mine, const V3l& e1, const V3l& e2, const V3l& e3,
+                                   const LegFactor& lf, const float* Sb, const float* Sd, const float* xi, const F* qs, float bias, bool have, int me) {
+    const F zero = ln.lane_f(0.0f);
+    const V3l ub = cvt3<F>(ub_);
+    F sjt[3];
+    float sgt[6];
+    sjt[0] = lm::sel(mine, dot(ub, e1), zero); sjt[1] = lm::sel(mine, dot(ub, e2), zero); sjt[2] = lm::sel(mine, dot(ub, e3), zero);
+    const V3<float> pxu = cross(pb_, ub_);
+    float vrow = L::qsum(sjt[0] * qs[0] + sjt[1] * qs[1] + sjt[2] * qs[2]) + pxu.x * xi[0] + pxu.y * xi[1] + pxu.z * xi[2] + ub_.x * xi[3] + ub_.y * xi[4] + ub_.z * xi[5];
+    lm_fwd(lf, sjt);
+    SV<F> yj = scale(lf.y1, sjt[0]) + scale(lf.y2, sjt[1]) + scale(lf.y3, sjt[2]);
+    F g6[6] = {zero - yj.a.x, zero - yj.a.y, zero - yj.a.z, zero - yj.l.x, zero - yj.l.y, zero - yj.l.z};
+    L::qsum6(g6, sgt);
+    sgt[0] += pxu.x; sgt[1] += pxu.y; sgt[2] += pxu.z; sgt[3] += ub_.x; sgt[4] += ub_.y; sgt[5] += ub_.z;
+    fwd6(Sb, Sd, sgt);
+    float nn = L::qsum(sjt[0] * sjt[0] + sjt[1] * sjt[1] + sjt[2] * sjt[2]);
+    for (int i = 0; i < 6; i++) nn += sgt[i] * sgt[i];
+    self_row_pack(ln, sjt, sgt, rw);
+    const float vo = ln.peer_u(vrow), no = ln.peer_u(nn);
+    rw.c = ((me == 0) ? vrow + vo : vo + vrow) + bias;
+    rw.inv = have ? 1.0f / ((me == 0) ? nn + no : no + nn) : 0.0f;
+    rw.lam = 0.0f;
+    if (!have) self_row_clear(ln, rw);
+  }
+  // a tangential shared row (LLM_SPEC_PAIR_FRICTION): pair_turn with the box bounds +- hi = mu x the contact's normal multiplier
+  static LL_HD void pair_fric_turn(const L& ln, SelfRow& rw, float hi, F& VA, F& VB, F& VJ, int me) {
+    const float mine = self_row_velocity(rw, VA, VB, VJ);
+    const float theirs = ln.peer_u(mine);
+    const float w = rw.c + ((me == 0) ? mine + theirs : theirs + mine);
+    const float nl = fminf(fmaxf(rw.lam - w * rw.inv, -hi), hi);
+    const float d = nl - rw.lam;
+    rw.lam = nl;
+    self_row_apply(ln, rw, d, VA, VB, VJ);
+  }
+
   // robot-robot row (SEPMC): the same frictionless turn, with the other robot's share of the row velocity fetched from its row; both
   // rows add the two shares in the same order (robot 0's first), so both apply the same multiplier
   static LL_HD void pair_turn(const L& ln, SelfRow& rw, F& VA, F& VB, F& VJ, int me) {
@@ -875,12 +956,17 @@ struct Pmc {
   }
   static LL_HD void substep(const L& ln, const StepParams& P, Base& bs, F* q, F* qd, const F* tgt, int env = 0, int sidx = -1,
                             const SubstepExtra* ex = nullptr) {
-    if (P.friction_mode == 2) substep_impl<false, false, true>(ln, P, bs, q, qd, tgt, env, sidx, ex, nullptr);      // (host tests: emu_substep)
+    if (P.friction_mode == 2 && pmc_wants_xrows(P)) substep_impl<false, false, true, true>(ln, P, bs, q, qd, tgt, env, sidx, ex, nullptr);
+    else if (P.friction_mode == 2) substep_impl<false, false, true>(ln, P, bs, q, qd, tgt, env, sidx, ex, nullptr);      // (host tests: emu_substep)
     else substep_impl<false>(ln, P, bs, q, qd, tgt, env, sidx, ex, nullptr);
   }
   // TERRAIN: contact candidates are also tested against ex->shapes, and a contact's normal is that of the shape it touches
   // PAIR: contacts with the other robot of a SEPMC arena (the neighbouring row) are found and solved too
-  template <bool TERRAIN, bool PAIR = false, bool CONE = false>
+  // XROWS (round 6): the build that can carry the extended contact rows -- the two tangential rows of a leg-leg contact (LLM_SPEC_SELF_FRICTION) and, with PAIR, of a robot-robot
+  // contact (LLM_SPEC_PAIR_FRICTION), and up to four robot-robot contacts per pair (LLM_SPEC_MAX_PAIR).  Engine twins of what had been oracle-only switches.  A build of its own because
+  // the rows cost the plain build registers even when they are switched off (the contract kernel ran 2.5 % slower with the code merely present: profiles/r06_self_friction_ab.txt);
+  // the launch picks it when one of the three switches is off its default (pmc_wants_xrows).
+  template <bool TERRAIN, bool PAIR = false, bool CONE = false, bool XROWS = false>
   static LL_HD void substep_impl(const L& ln, const StepParams& P_in, Base& bs, F* q, F* qd, const F* tgt, int env, int sidx, const SubstepExtra* ex,
                                  const LinkC* held) {   // held: the own-link constants if the caller keeps them in registers, or null
 #define PMC_TSS(k) do { if (sidx == 5) PMC_TS(k); } while (0)
@@ -1384,8 +1470,10 @@ struct Pmc {
     // --- self-collision (LR:212-217: links of different legs): each leg is two capsules, the closest pairs within the
     //     margin give up to two frictionless rows.  Lane (leg g, sub s) tests capsule (s & 2 ? shank : thigh) of its own leg against
     //     capsule (s & 1 ? shank : thigh) of the previous leg, and -- legs 0 and 1 only -- of the leg two away: 24 pairs in two passes.
-    SelfRow sr[2];
+    SelfRow sr[2], sf[2][2];             // sf[slot][0 / 1]: the contact's two tangential rows (LLM_SPEC_SELF_FRICTION > 0 only)
     self_row_clear(ln, sr[0]); self_row_clear(ln, sr[1]);
+    const bool self_fric = XROWS && P.self_friction > 0.0f;
+    if (self_fric) { self_row_clear(ln, sf[0][0]); self_row_clear(ln, sf[0][1]); self_row_clear(ln, sf[1][0]); self_row_clear(ln, sf[1][1]); }
     bool any_self = false;
     int n_self_w = 0;                   // self-collision slots in use by some env of the wave
     if (P.self_collision > 0.5f && !PMC_ABL(512)) {                                 // (ablation 512: no self-collision at all)
@@ -1469,34 +1557,30 @@ struct Pmc {
           F on3 = lm::sel(link > 2.5f, one, zero);
           V3l a1v = mk3<F>(one, zero, zero);
           V3l e1 = cross(a1v, Pb - k.p1), e2 = cross(k.a2, Pb - k.p2), e3 = scale(cross(k.a2, Pb - k.p3), on3);
-          SelfRow& rw = sr[slot];
-          F sjt[3];
-          float sgt[6];
-          sjt[0] = sgn * dot(nb, e1); sjt[1] = sgn * dot(nb, e2); sjt[2] = sgn * dot(nb, e3);
-          float vrow = L::qsum(sjt[0] * qs[0] + sjt[1] * qs[1] + sjt[2] * qs[2]);      // the base moves both points alike: no base part
-          lm_fwd(lf, sjt);
-          SV<F> yj = scale(lf.y1, sjt[0]) + scale(lf.y2, sjt[1]) + scale(lf.y3, sjt[2]);
-          F g6[6] = {zero - yj.a.x, zero - yj.a.y, zero - yj.a.z, zero - yj.l.x, zero - yj.l.y, zero - yj.l.z};
-          L::qsum6(g6, sgt);
-          fwd6(Sb, Sd, sgt);
-          float nn = L::qsum(sjt[0] * sjt[0] + sjt[1] * sjt[1] + sjt[2] * sjt[2]);
-          for (int i = 0; i < 6; i++) nn += sgt[i] * sgt[i];
-          self_row_pack(ln, sjt, sgt, rw);
-          rw.c = vrow + ((dsel > 0.0f) ? dsel * inv_dt : fmaxf(dsel * ((dsel > P.erp_deep_below ? P.erp : P.erp_deep) * inv_dt), -P.max_depen));
-          rw.inv = have ? 1.0f / nn : 0.0f;
-          rw.lam = 0.0f;
-          if (!have) self_row_clear(ln, rw);
+          self_row_build(ln, sr[slot], nb, sgn, e1, e2, e3, lf, Sb, Sd, qs,
+                         (dsel > 0.0f) ? dsel * inv_dt : fmaxf(dsel * ((dsel > P.erp_deep_below ? P.erp : P.erp_deep) * inv_dt), -P.max_depen), have);
+          if (self_fric) {
+            // LLM_SPEC_SELF_FRICTION (round 6, the engine twin of the oracle's switch): two tangential rows along btPlaneSpace1 of the WORLD normal, behind the normal row
+            V3<float> nw = mul(R, mk3<float>(u6[3], u6[4], u6[5])), t1w, t2w;
+            plane_space(nw, t1w, t2w);
+            self_row_build(ln, sf[slot][0], cvt3<F>(mulT(R, t1w)), sgn, e1, e2, e3, lf, Sb, Sd, qs, 0.0f, have);
+            self_row_build(ln, sf[slot][1], cvt3<F>(mulT(R, t2w)), sgn, e1, e2, e3, lf, Sb, Sd, qs, 0.0f, have);
+          }
         }
       }
     }
     // --- robot-robot contact (SEPMC): each robot is ten capsules -- thigh and shank-with-foot of every leg as in the
     //     self-collision test, and two for the trunk.  Both rows evaluate all 100 pairs with robot 0's capsule as the first segment, on
     //     bit-identical inputs (world end points computed once and copied across), so both find the same two deepest contacts.
-    SelfRow pr[2];
+    constexpr int NPAIR = (PAIR && XROWS) ? LLM_MAX_PAIR_CAP : 2;       // robot-robot contacts a build can carry (LLM_SPEC_MAX_PAIR: 2 by default, up to 4 in the XROWS build)
+    SelfRow pr[NPAIR], pf[(PAIR && XROWS) ? NPAIR : 1][2];              // pf[slot][0 / 1]: the contact's two tangential rows (LLM_SPEC_PAIR_FRICTION > 0, XROWS builds)
     bool any_pair = false;
     int n_pair_w = 0;
+    const bool pair_fric = PAIR && XROWS && P.pair_friction > 0.0f;
+    const int max_pair = (PAIR && XROWS) ? P.max_pair : 2;
     if (PAIR) {
-      self_row_clear(ln, pr[0]); self_row_clear(ln, pr[1]);
+      for (int i_ = 0; i_ < NPAIR; i_++) self_row_clear(ln, pr[i_]);
+      if (PAIR && XROWS) for (int i_ = 0; i_ < NPAIR; i_++) { self_row_clear(ln, pf[i_][0]); self_row_clear(ln, pf[i_][1]); }
       if (ex->want_touch) ex->touch_robot = 0.0f;
       if (L::any(ln.lane_f(ex->pair_active ? 1.0f : 0.0f) > 0.5f)) {
         const int me = ex->pair_me;
@@ -1522,7 +1606,12 @@ struct Pmc {
         const B s_odd = lm::odd_(ln.sub()), s_hi = lm::bit1_(ln.sub()), g_odd = lm::odd_(ln.leg());
         const F subf = L::i2f(ln.sub()), legf = ln.legf();
         const F lo_bit = lm::sel(s_odd, one, zero), hi_bit = lm::sel(s_hi, one, zero);
-        // per-lane two best (depth, pair id) with point and normal
+        // Every lane keeps its two best (depth, pair id) with point and normal: exact for the two deepest of the 100 pairs.  LLM_SPEC_MAX_PAIR > 2 (XROWS builds): the pairs are
+        // walked a second time without the two already taken, for the third and fourth deepest (a lane's own two best may both be among the row's four: one scan cannot know).
+        float taken[2] = {-1.0f, -1.0f};
+        LL_UNROLL
+        for (int scan = 0; scan < ((PAIR && XROWS) ? 2 : 1); scan++) {
+        if (scan == 1 && (max_pair <= 2 || !any_pair)) break;
         F bd[2] = {far_, far_}, bid[2] = {far_, far_};
         V3l bP[2], bN[2];
         bP[0] = bP[1] = bN[0] = bN[1] = mk3<F>(zero, zero, zero);
@@ -1591,6 +1680,7 @@ struct Pmc {
           V3l pp = scale((c1 - scale(nn_, r1)) + (c2 + scale(nn_, r2)), ln.lane_f(0.5f));
           F dep = len - r1 - r2;
           B valid = lm::and_(pass_ok, lm::and_(dep < P.margin_dist, len > 1e-9f));
+          if (scan == 1) valid = lm::and_(valid, lm::and_(lm::abs_(id - taken[0]) > 0.5f, lm::abs_(id - taken[1]) > 0.5f));
           // my side of it: a leg / wheel link unless it is the foot end of a shank capsule
           F my_par = lm::sel(i_am_0, ps, pt);
           B my_body = lm::and_(mi < 7.5f, lm::not_(lm::and_(lm::abs_(mi - lm::rint_(mi * 0.5f) * 2.0f) > 0.5f, my_par > 0.9f)));
@@ -1607,12 +1697,15 @@ struct Pmc {
           bP[0] = mk3<F>(lm::sel(beat0, pp.x, bP[0].x), lm::sel(beat0, pp.y, bP[0].y), lm::sel(beat0, pp.z, bP[0].z));
           bN[0] = mk3<F>(lm::sel(beat0, nn_.x, bN[0].x), lm::sel(beat0, nn_.y, bN[0].y), lm::sel(beat0, nn_.z, bN[0].z));
         }
-        if (ex->want_touch) ex->touch_robot = L::rmin(tch) < 0.5f ? 1.0f : 0.0f;
-        any_pair = L::any(bd[0] < 1.0e29f);
-        if (any_pair) {
+        if (scan == 0 && ex->want_touch) ex->touch_robot = L::rmin(tch) < 0.5f ? 1.0f : 0.0f;
+        const bool any_here = L::any(bd[0] < 1.0e29f);
+        if (scan == 0) any_pair = any_here && max_pair > 0;
+        if (any_here && max_pair > 0) {
           LL_UNROLL
-          for (int slot = 0; slot < 2; slot++) {
-            if (slot == 1 && !L::any(bd[0] < 1.0e29f)) break;
+          for (int s2 = 0; s2 < 2; s2++) {
+            const int slot = 2 * scan + s2;
+            if (slot >= max_pair) break;
+            if (s2 == 1 && !L::any(bd[0] < 1.0e29f)) break;
             n_pair_w = slot + 1;
             const float dmin = L::rmin(bd[0]);
             B at = bd[0] <= ln.lane_f(dmin + (float)LLM_SELECT_EPS);                       // equally deep within the tolerance: lower pair id
@@ -1640,27 +1733,19 @@ struct Pmc {
             F on3 = ln.lane_f((ic & 1) ? 1.0f : 0.0f);
             V3l a1v = mk3<F>(one, zero, zero);
             V3l e1 = cross(a1v, Pb - k.p1), e2 = cross(k.a2, Pb - k.p2), e3 = scale(cross(k.a2, Pb - k.p3), on3);
-            SelfRow& rw = pr[slot];
-            F sjt[3];
-            float sgt[6];
-            sjt[0] = lm::sel(mine, dot(nb, e1), zero); sjt[1] = lm::sel(mine, dot(nb, e2), zero); sjt[2] = lm::sel(mine, dot(nb, e3), zero);
-            const V3<float> pxu = cross(pb_, nb_);
-            float vrow = L::qsum(sjt[0] * qs[0] + sjt[1] * qs[1] + sjt[2] * qs[2]) + pxu.x * xi[0] + pxu.y * xi[1] + pxu.z * xi[2] + nb_.x * xi[3] + nb_.y * xi[4] + nb_.z * xi[5];
-            lm_fwd(lf, sjt);
-            SV<F> yj = scale(lf.y1, sjt[0]) + scale(lf.y2, sjt[1]) + scale(lf.y3, sjt[2]);
-            F g6[6] = {zero - yj.a.x, zero - yj.a.y, zero - yj.a.z, zero - yj.l.x, zero - yj.l.y, zero - yj.l.z};
-            L::qsum6(g6, sgt);
-            sgt[0] += pxu.x; sgt[1] += pxu.y; sgt[2] += pxu.z; sgt[3] += nb_.x; sgt[4] += nb_.y; sgt[5] += nb_.z;
-            fwd6(Sb, Sd, sgt);
-            float nn = L::qsum(sjt[0] * sjt[0] + sjt[1] * sjt[1] + sjt[2] * sjt[2]);
-            for (int i = 0; i < 6; i++) nn += sgt[i] * sgt[i];
-            self_row_pack(ln, sjt, sgt, rw);
-            const float vo = ln.peer_u(vrow), no = ln.peer_u(nn);
-            rw.c = ((me == 0) ? vrow + vo : vo + vrow) + ((dsel > 0.0f) ? dsel * inv_dt : fmaxf(dsel * ((dsel > P.erp_deep_below ? P.erp : P.erp_deep) * inv_dt), -P.max_depen));
-            rw.inv = have ? 1.0f / ((me == 0) ? nn + no : no + nn) : 0.0f;
-            rw.lam = 0.0f;
-            if (!have) self_row_clear(ln, rw);
+            if (scan == 0) taken[s2] = have ? imin : -1.0f;
+            const float nbias = (dsel > 0.0f) ? dsel * inv_dt : fmaxf(dsel * ((dsel > P.erp_deep_below ? P.erp : P.erp_deep) * inv_dt), -P.max_depen);
+            pair_row_build(ln, pr[slot], nb_, pb_, mine, e1, e2, e3, lf, Sb, Sd, xi, qs, nbias, have, me);
+            if (pair_fric) {
+              // LLM_SPEC_PAIR_FRICTION (round 6, the engine twin of the oracle's switch): two tangential rows along btPlaneSpace1 of the contact's WORLD normal (robot 1 -> robot 0,
+              // the same bits in both rows of the arena), each solved right behind its normal row inside +- mu x that row's multiplier
+              V3<float> t1w, t2w;
+              plane_space(mk3<float>(u6[3], u6[4], u6[5]), t1w, t2w);
+              pair_row_build(ln, pf[slot][0], mulT(R, scale(t1w, sg)), pb_, mine, e1, e2, e3, lf, Sb, Sd, xi, qs, 0.0f, have, me);
+              pair_row_build(ln, pf[slot][1], mulT(R, scale(t2w, sg)), pb_, mine, e1, e2, e3, lf, Sb, Sd, xi, qs, 0.0f, have, me);
+            }
           }
+        }
         }
       }
     }
@@ -1696,14 +1781,27 @@ struct Pmc {
         }
       }
       PMC_PHASE("pgs.self_turns");
-      if (any_self) {                                                        // then the self-collision rows, one after the other
+      if (any_self) {                                                        // then the self-collision rows, one after the other (with LLM_SPEC_SELF_FRICTION each followed by its two tangential rows)
         self_turn(ln, sr[0], VA, VB, VJ);
-        if (n_self_w > 1) self_turn(ln, sr[1], VA, VB, VJ);
+        if (self_fric) { self_fric_turn(ln, sf[0][0], P.self_friction * sr[0].lam, VA, VB, VJ); self_fric_turn(ln, sf[0][1], P.self_friction * sr[0].lam, VA, VB, VJ); }
+        if (n_self_w > 1) {
+          self_turn(ln, sr[1], VA, VB, VJ);
+          if (self_fric) { self_fric_turn(ln, sf[1][0], P.self_friction * sr[1].lam, VA, VB, VJ); self_fric_turn(ln, sf[1][1], P.self_friction * sr[1].lam, VA, VB, VJ); }
+        }
       }
       if (PAIR) {
-        if (any_pair) {                                                      // last, the rows shared with the other robot
-          pair_turn(ln, pr[0], VA, VB, VJ, ex->pair_me);
-          if (n_pair_w > 1) pair_turn(ln, pr[1], VA, VB, VJ, ex->pair_me);
+        if (any_pair) {                                                      // last, the rows shared with the other robot (each followed by its two tangential rows under LLM_SPEC_PAIR_FRICTION)
+          LL_UNROLL
+          for (int slot = 0; slot < NPAIR; slot++) {
+            if (slot >= n_pair_w) break;
+            pair_turn(ln, pr[slot], VA, VB, VJ, ex->pair_me);
+            if constexpr (PAIR && XROWS) {
+              if (pair_fric) {
+                pair_fric_turn(ln, pf[slot][0], P.pair_friction * pr[slot].lam, VA, VB, VJ, ex->pair_me);
+                pair_fric_turn(ln, pf[slot][1], P.pair_friction * pr[slot].lam, VA, VB, VJ, ex->pair_me);
+              }
+            }
+          }
         }
       }
     }
@@ -2020,7 +2118,7 @@ struct Pmc {
   // act_in: the env's actions, one register per joint of the lane's leg (read from P.actions or drawn by the caller)
   // OBST (set_obstacle builds): the jump obstacle of the episode is a static box the robot collides with during the substeps
   // sl: index of this control step inside its launch (ll_step_random_n runs n_steps of them back to back; 0 otherwise)
-  template <bool OBST = false, bool CONE = false>
+  template <bool OBST = false, bool CONE = false, bool XROWS = false>
   static LL_HD void step_env(const L& ln, const StepParams& P_in, int env, const F* act_in, int sl = 0) {
     const StepParams& P = ln.params(P_in);
     const int N = P.n_envs;
@@ -2063,8 +2161,8 @@ struct Pmc {
     if (L::kHoldLink) { lkh = own_link_held(ln, P.legc); held = &lkh; }
     PMC_PHASE("step.substep_loop");
     for (int s = 0; s < P.n_sub; s++) {                                      // PLE:202
-      if (OBST) substep_impl<true, false, CONE>(ln, P, bs, q, qd, tgt, env, s, &ex, held);
-      else substep_impl<false, false, CONE>(ln, P, bs, q, qd, tgt, env, s, nullptr, held);   // PLE:204-206
+      if (OBST) substep_impl<true, false, CONE, XROWS>(ln, P, bs, q, qd, tgt, env, s, &ex, held);
+      else substep_impl<false, false, CONE, XROWS>(ln, P, bs, q, qd, tgt, env, s, nullptr, held);   // PLE:204-206
       t_loc = t;                                                             // PLE:208 motion.step(time BEFORE the increment), quirk Q2
       t += P.dt_d;                                                           // PLE:210
     PMC_TS(10 + (s < 20 ? s : 20));

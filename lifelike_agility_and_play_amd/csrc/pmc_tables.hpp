@@ -257,6 +257,7 @@ static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
   P.self_collision = 1.0f;
   P.max_depen = (float)LLM_MAX_DEPEN_SPEED; P.self_margin = (float)LLM_SELF_MARGIN;
   P.max_contacts = LLM_MAX_CONTACTS_PER_LEG; P.max_self = LLM_MAX_SELF;
+  P.self_friction = (float)LLM_SELF_FRICTION; P.pair_friction = (float)LLM_PAIR_FRICTION; P.max_pair = LLM_MAX_PAIR;
   P.friction_mode = LLM_FRICTION_MODE;
   P.max_coord_vel = (float)LLM_MAX_COORD_VEL;
   P.limit_speculative = LLM_LIMIT_SPECULATIVE;
@@ -320,6 +321,14 @@ inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
       P.limit_speculative = (int)v; break;
     case LLM_SPEC_CONTACT_MARGIN: P.margin_dist = (float)v; break;
     case LLM_SPEC_SELF_FRICTION:
+      if (!(v >= 0.0 && v <= 4.0)) return "self_friction must be in [0, 4]";
+      P.self_friction = (float)v; break;
+    case LLM_SPEC_PAIR_FRICTION:
+      if (!(v >= 0.0 && v <= 4.0)) return "pair_friction must be in [0, 4]";
+      P.pair_friction = (float)v; break;
+    case LLM_SPEC_MAX_PAIR:
+      if (!(v >= 0 && v <= LLM_MAX_PAIR_CAP)) return "robot-robot rows per pair must be 0..4";
+      P.max_pair = (int)v; break;
     case LLM_SPEC_FRICTION_KEEP:
     case LLM_SPEC_WARM_START:
       if (v != 0.0) return "this switch exists in the oracle only (tools/deviation_table.py reports what it is worth)";
@@ -339,8 +348,7 @@ inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
     case LLM_SPEC_MAX_COORD_VEL:
       if (!(v > 0.0)) return "max_coord_vel must be positive (1e30: no clip)";
       P.max_coord_vel = (float)(v < 3.0e38 ? v : 3.0e38); break;
-    case LLM_SPEC_ROW_ORDER: case LLM_SPEC_PAIR_FRICTION:
-    case LLM_SPEC_MAX_PAIR: case LLM_SPEC_GYRO:
+    case LLM_SPEC_ROW_ORDER: case LLM_SPEC_GYRO:
       if (id == LLM_SPEC_GYRO && v == 1.0) break;
       return "this switch exists in the oracle only (round-3 audit against Bullet's published solver: profiles/r03_deviation_table.md)";
     default: return "unknown spec parameter id";
@@ -367,7 +375,9 @@ inline double pmc_get_spec_param(const StepParams& P, int id) {
     case LLM_SPEC_ERP_DEEP: return P.spec_erp_deep;
     case LLM_SPEC_ERP_DEEP_BELOW: return P.erp_deep_below;
     case LLM_SPEC_LIMIT_ERP_DEEP: return P.spec_limit_erp_deep;
-    case LLM_SPEC_MAX_PAIR: return 2.0;
+    case LLM_SPEC_MAX_PAIR: return P.max_pair;
+    case LLM_SPEC_SELF_FRICTION: return P.self_friction;
+    case LLM_SPEC_PAIR_FRICTION: return P.pair_friction;
     case LLM_SPEC_LIMIT_SPECULATIVE: return P.limit_speculative;
     case LLM_SPEC_GYRO: return 1.0;
     default: return 0.0;

@@ -248,7 +248,7 @@ struct Sepmc {
     const long a0 = 3L * P.prop_dim + 36;
     const int nb = (int)sp[SP_N_BOXES] + 1;                                                          // the arena and the flag
     const float* boxes = ln.stage_row(E.boxes + (long)row * EPMC_MAX_BOXES * EPMC_BOX_WORDS, nb * EPMC_BOX_WORDS);
-    if (E.split_rays && !E.scr_ray_hit) EP::leave_ray_pose(ln, E, row, pos, R, yaw, sp + SP_NOISE, nb);  // (round 6: the 778 rays by the kernel behind this one, epmc_step.hpp percept_rays)
+    if (E.split_rays && !E.scr_ray_hit) EP::leave_ray_pose(ln, E, row, pos, R, yaw, sp + SP_NOISE, nb, boxes + (nb - 1) * EPMC_BOX_WORDS);  // (round 6: the 778 rays by the kernel behind this one, epmc_step.hpp percept_rays; the flag's box as it stands NOW)
     else EP::observe_rays(ln, P, E, row, pos, R, yaw, sp + SP_NOISE, boxes, nb, orow + a0);           // CTG:515-531
     // --- visibility (CTG:472-493): lane (leg g, sub s) owns one segment: my head -> the other's foot g / wheel g / handle (g = 0, 2),
     //     and lane (0, 3) the segment between the two (biased) base positions
@@ -344,7 +344,7 @@ struct Sepmc {
   // ------------------------------------------------------------------------------------------------------------
   // PARK (the larger-batch build): the 40 per-row scalars wait in LDS and the history chunks are read after the substep loop instead of
   // before it (two waves per SIMD hide that round trip; one wave per SIMD would pay it)
-  template <bool PARK = false, bool CONE = false>   // CONE: the cone-coupled friction solve (LLM_SPEC_FRICTION_MODE = 2, Pmc::gs_cone_round)
+  template <bool PARK = false, bool CONE = false, bool XROWS = false>   // CONE: the cone-coupled friction solve (LLM_SPEC_FRICTION_MODE = 2, Pmc::gs_cone_round)
   static LL_HD void step_env(const L& ln, const StepParams& P_in, const SepmcParams& S, int row, const F* act_in) {
     const StepParams& P = ln.params(P_in);
     const EpmcParams& E = S.e;
@@ -428,7 +428,7 @@ struct Sepmc {
         for (int i = 0; i < 3; i++) ptrace[s * 4 + 1 + i] = ex.has_push ? ex.push[i] : 0.0f;
       }
       ex.want_touch = s == P.n_sub - 1;
-      if (!E.scr_state) K::template substep_impl<true, true, CONE>(ln, P, bs, q, qd, tgt, row, s, &ex, &lkh);
+      if (!E.scr_state) K::template substep_impl<true, true, CONE, XROWS>(ln, P, bs, q, qd, tgt, row, s, &ex, &lkh);
     }
     if (PARK) {
       const float keep[4] = {sp[SP_PUSH_COUNT], sp[SP_PUSH_FORCE], sp[SP_PUSH_FORCE + 1], sp[SP_PUSH_FORCE + 2]};

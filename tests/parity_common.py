@@ -825,15 +825,19 @@ def check_engine_against_host_build(model_blob, table, emul_lib, n_envs=4096, st
     return out
 
 
-def check_self_collision_parity(golden, orc, model_blob, table, lib_path, n_envs=16, seed=5):
+def check_self_collision_parity(golden, orc, model_blob, table, lib_path, n_envs=16, seed=5, spec=None):
     """Legs driven into one another in mid-air (same-side front/hind pairs, left/right pairs, diagonal): one control step,
     engine vs oracle -- same capsule spec, different formulations -- and the oracle WITHOUT self-collision as the control: the
-    legs must have been stopped, not passed through each other (LR:212-217 URDF_USE_SELF_COLLISION)."""
+    legs must have been stopped, not passed through each other (LR:212-217 URDF_USE_SELF_COLLISION).
+    `spec`: switches set on BOTH sides for the run (round 6: self_friction = 0.25, Bullet's 0.5 x 0.5 -- the leg-leg contact then carries two tangential rows behind its
+    normal row; the returned `moved` is how far the friction moved the oracle's own answer, so that a caller can see the switch had something to act on)."""
     import ctypes as C
     from oracle import oracle as orc_mod
     rng = np.random.default_rng(seed)
     clip, t0 = golden['g2_clip'][:n_envs], golden['g2_t0'][:n_envs]
     E = make_engine(model_blob, table, n_envs, lib_path)
+    if spec:
+        E.set_spec(**spec)
     B = make_oracle_batch(orc, model_blob, table, n_envs=n_envs)
     B0 = make_oracle_batch(orc, model_blob, table, n_envs=n_envs)
     E.reset(clip=clip, t0=t0)
@@ -870,13 +874,22 @@ def check_self_collision_parity(golden, orc, model_blob, table, lib_path, n_envs
             bb.set_state(i, st32[i])
     E.step_host(act)
     es = E.state().astype(np.float64)
-    cfg_err, vel_err, stopped = [], [], 0
+    cfg_err, vel_err, stopped, moved = [], [], 0, 0.0
+    orc.reset_spec()
     for i in range(n_envs):
+        if spec:
+            plain = make_oracle_batch(orc, model_blob, table, n_envs=1)                 # the spec's own answer (without the switches), for `moved`
+            plain.reset_env(0, int(clip[i]), float(t0[i])); plain.set_state(0, st32[i])
+            plain.step_env(0, act[i].astype(np.float64))
+            orc.set_spec(**spec)
         lib.orc_set_self_collision(C.c_int(1))
         B.step_env(i, act[i].astype(np.float64))
         lib.orc_set_self_collision(C.c_int(0))
         B0.step_env(i, act[i].astype(np.float64))
         lib.orc_set_self_collision(C.c_int(1))
+        if spec:
+            orc.reset_spec()
+            moved = max(moved, np.abs(B.get_state(i)[25:37] - plain.get_state(0)[25:37]).max())
         o1, o0 = B.get_state(i), B0.get_state(i)
         err = np.abs(quat_align(es[i], o1) - o1)
         cfg_err.append(max(err[0:7].max(), err[13:25].max()))
@@ -888,7 +901,7 @@ def check_self_collision_parity(golden, orc, model_blob, table, lib_path, n_envs
     assert stopped >= n_envs // 2, stopped
     assert cfg_err.max() < 1e-4, cfg_err              # every sample (measured: 8e-7 / 2.5e-5 -- since the closest-point routine takes the pair's
     assert vel_err.max() < 1e-3, vel_err              # segments in the spec's order (A first) in both implementations and is regularised for parallel axes)
-    return dict(config=cfg_err, vel=vel_err, stopped=stopped)
+    return dict(config=cfg_err, vel=vel_err, stopped=stopped, moved=moved)
 
 
 def check_nonfinite_guard(model_blob, table, lib_path):

@@ -688,13 +688,27 @@ def check_parked_variant_equals_plain(lib_path, n=4, n_steps=30):
     A.close(); B.close()
 
 
-def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5, total_arenas=None, cap_ill=1):
+def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5, total_arenas=None, cap_ill=1, spec=None):
     """Two robots within reach of each other (side by side, nose to tail, one partly above the other), random joint states and
     velocities, the push active: one control step of real physics, engine (float32, two rows exchanging registers) vs the float64
     oracle's two-robot substep (orc_substep_pair: explicit Jacobians, M^-1 by unit responses) given the same arena records,
     friction and push forces.  The two share the spec (capsules, pair order, row order) and nothing else.
     total_arenas: the engine runs that many arenas (above 2048: the larger-batch kernel build) and the n_arenas cases are spread over the
-    first, middle and last wavefronts of its grid."""
+    first, middle and last wavefronts of its grid.
+    spec: switches set on BOTH sides (round 6: pair_friction = 0.25, max_pair = 4, self_friction = 0.25 -- the engine twins of what had been oracle-only switches; the
+    engine then runs its XROWS build)."""
+    from conftest import make_oracle_batch
+    from oracle import oracle as orc
+    orc.reset_spec()
+    if spec:
+        orc.set_spec(**spec)
+    try:
+        return _check_pair_physics_against_oracle(lib_path, n_arenas, seed, total_arenas, cap_ill, spec)
+    finally:
+        orc.reset_spec()
+
+
+def _check_pair_physics_against_oracle(lib_path, n_arenas, seed, total_arenas, cap_ill, spec):
     from conftest import make_oracle_batch
     from oracle import oracle as orc
     from lifelike_agility_and_play_amd import mocap, urdf_model
@@ -705,6 +719,8 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5, total_arena
     third = n_arenas // 3
     idx = np.arange(n_arenas) if not total_arenas else np.concatenate([np.arange(third), NA // 2 - 5 + np.arange(third), NA - (n_arenas - 2 * third) + np.arange(n_arenas - 2 * third)])
     E = make_engine(cfg, NA, lib_path, seed=seed)
+    if spec:
+        E.set_spec(**spec)
     E.reset()
     rng = np.random.default_rng(seed)
     st = E.state().astype(np.float64)

@@ -244,6 +244,20 @@ def test_self_collision_parity(golden, orc, model_blob, mocap_table):
     assert out['stopped'] >= 16
 
 
+def test_self_collision_with_friction_parity(golden, orc, model_blob, mocap_table):
+    """LLM_SPEC_SELF_FRICTION = 0.25 on the GPU (round 6: engine twin of the oracle's switch), one-wave-per-SIMD build; see tests/test_kernel_logic_emul.py"""
+    out = pc.check_self_collision_parity(golden, orc, model_blob, mocap_table, None, n_envs=32, spec=dict(self_friction=0.25))
+    print('self friction 0.25 on the GPU: worst config %.2e vel %.2e, moved %.3f' % (out['config'].max(), out['vel'].max(), out['moved']))
+    assert out['stopped'] >= 16 and out['moved'] > 1e-3
+    import parity_common as pc2
+    E = pc2.make_engine(model_blob, mocap_table, 8)                       # the switch needs the cone builds and flat ground: anything else is refused, not ignored
+    E.set_spec(friction_mode=0, self_friction=0.25)
+    E.reset()
+    with pytest.raises(Exception):
+        E.step_random(pc2.SIGMA); E.sync()
+    E.close()
+
+
 def test_nonfinite_guard(model_blob, mocap_table):
     pc.check_nonfinite_guard(model_blob, mocap_table, None)
 

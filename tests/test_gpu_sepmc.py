@@ -33,6 +33,15 @@ def test_game_statistics_against_the_oracle_env_gpu():
     SC.check_game_statistics(None, n_arenas=512)
 
 
+def test_pair_physics_with_bullets_pair_rows_gpu():
+    """Round 6: the XROWS builds on the GPU -- LLM_SPEC_PAIR_FRICTION 0.25, LLM_SPEC_MAX_PAIR 4, LLM_SPEC_SELF_FRICTION 0.25 -- against the oracle under the same switches
+    (one-wave-per-SIMD build, and the larger-batch build with the cases spread over its grid)"""
+    print(SC.check_pair_physics_against_oracle(None, n_arenas=64, seed=9, spec=dict(pair_friction=0.25), cap_ill=2))
+    print(SC.check_pair_physics_against_oracle(None, n_arenas=64, seed=9, spec=dict(max_pair=4), cap_ill=3))
+    print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=7, spec=dict(pair_friction=0.25, max_pair=4, self_friction=0.25), cap_ill=3))
+    print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=11, total_arenas=3000, spec=dict(pair_friction=0.25, max_pair=4, self_friction=0.25), cap_ill=3))
+
+
 def test_rays_by_a_kernel_of_their_own_equal_the_fused_rays_gpu():
     """Round 6 (LL_SPLIT_RAYS): the 2 x 778 perception rays of an arena by epmc_percept_kernel behind the step kernel against the fused rays, bit for bit; a partial last wave and the larger-batch build"""
     SC.check_split_rays_equal_fused(None, n=101, n_steps=24)

@@ -104,6 +104,14 @@ def test_self_collision_parity(golden, orc, model_blob, mocap_table, emul_lib):
     assert out['stopped'] >= 8
 
 
+def test_self_collision_with_friction_parity(golden, orc, model_blob, mocap_table, emul_lib):
+    """LLM_SPEC_SELF_FRICTION = 0.25 (Bullet's 0.5 x 0.5 for two robot links; round 6: the engine twin of what had been an oracle-only switch): the leg-leg contact's two
+    tangential rows in the kernel source against the oracle's, standing bars; the friction must have had something to act on"""
+    out = pc.check_self_collision_parity(golden, orc, model_blob, mocap_table, emul_lib, spec=dict(self_friction=0.25))
+    print('self friction 0.25: worst config %.2e vel %.2e; the switch moved the oracle\'s joint rates by up to %.3f rad/s' % (out['config'].max(), out['vel'].max(), out['moved']))
+    assert out['stopped'] >= 8 and out['moved'] > 1e-3
+
+
 def test_nonfinite_guard(model_blob, mocap_table, emul_lib):
     pc.check_nonfinite_guard(model_blob, mocap_table, emul_lib)
 

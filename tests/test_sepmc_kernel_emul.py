@@ -118,6 +118,14 @@ def test_parked_variant_equals_plain(emul_lib):
     SC.check_parked_variant_equals_plain(emul_lib)
 
 
+def test_pair_physics_with_bullets_pair_rows(emul_lib):
+    """Round 6: the engine twins of LLM_SPEC_PAIR_FRICTION (0.25 = 0.5 x 0.5), LLM_SPEC_MAX_PAIR (4: a manifold's four points) and LLM_SPEC_SELF_FRICTION (0.25) -- the XROWS build of the
+    kernel source -- against the oracle under the same switches: two robots in contact, one control step, standing bars"""
+    print(SC.check_pair_physics_against_oracle(emul_lib, spec=dict(pair_friction=0.25)))
+    print(SC.check_pair_physics_against_oracle(emul_lib, spec=dict(max_pair=4), cap_ill=2))
+    print(SC.check_pair_physics_against_oracle(emul_lib, spec=dict(pair_friction=0.25, max_pair=4, self_friction=0.25), cap_ill=2))
+
+
 def test_rays_by_a_kernel_of_their_own_equal_the_fused_rays(emul_lib):
     SC.check_split_rays_equal_fused(emul_lib)
 
