@@ -508,7 +508,8 @@ def main_pmc(args):
                        'steps_per_launch_note': 'the timed region runs ll_step_random_n: up to %d control steps of the random-policy loop per kernel launch, at least three '
                                                 'launches (every step is complete: physics, mocap, obs, reward, termination, re-seed, unroll row, and the prioritized-sampling '
                                                 'table folded after EVERY step -- a re-seed at step s of a launch draws from the table steps 0 .. s - 1 left, PLE:235-240: k steps in one '
-                                                'launch are k launches bit for bit); --steps-per-launch 1 is one launch per control step' % spl_timed,
+                                                'launch are k launches bit for bit WHILE table_sync_stale_reseeds_rank0 IS 0, i.e. while the launch has the chip to itself; with another kernel resident a re-seed takes the newest '
+                                                'version there is and is counted there -- LL_DETERMINISTIC=1 makes the engine run such calls as single launches); --steps-per-launch 1 is one launch per control step' % spl_timed,
                        'table_sync_stale_reseeds_rank0': stale_reseeds,
                        'episodes_finished_rank0': counters['episodes'], 'nonfinite_resets_rank0': counters['nonfinite'],
                        'mean_episode_length_steps_rank0': (counters['env_steps'] / counters['episodes']) if counters['episodes'] else None,

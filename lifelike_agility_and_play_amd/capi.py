@@ -21,7 +21,7 @@ PLE_DEFAULT_REWARD_WEIGHTS = {'joint_pos': 0.6, 'joint_vel': 0.05, 'end_effector
 DONE_FALL, DONE_CLIP_END, DONE_DIVERGED, DONE_COLLISION, DONE_NONFINITE = 1, 2, 4, 8, 16
 SPEC_IDS = dict(limit_gate=0, max_depen_speed=1, link_damping=2, max_contacts_per_leg=3, self_collision=4, self_margin=5, max_self=6,
                 erp=7, contact_margin=8, self_friction=9, warm_start=10, trunk_edges=11, select_eps=12,
-                friction_mode=13, row_order=14, max_coord_vel=15, limit_erp=16, pair_friction=17, max_pair=18, friction_dirs=19, limit_speculative=20, gyro=21, friction_keep=22, erp_deep=23, erp_deep_below=24, limit_erp_deep=25)                                       # include/llenv_model.h LLM_SPEC_*
+                friction_mode=13, row_order=14, max_coord_vel=15, limit_erp=16, pair_friction=17, max_pair=18, friction_dirs=19, limit_speculative=20, gyro=21, friction_keep=22, erp_deep=23, erp_deep_below=24, limit_erp_deep=25, leg_edges=26)                                       # include/llenv_model.h LLM_SPEC_*
 LL_SELECT_EPS = 1e-5                                                                                         # include/llenv_model.h LLM_SELECT_EPS
 LLM_FRICTION_MODE = 2                                                                                        # include/llenv_model.h LLM_FRICTION_MODE: cone-coupled friction (0: the pyramid)
 LL_DONE_FALL, LL_DONE_CLIP_END, LL_DONE_DIVERGED, LL_DONE_COLLISION, LL_DONE_NONFINITE = 1, 2, 4, 8, 16      # include/llenv.h:65-69

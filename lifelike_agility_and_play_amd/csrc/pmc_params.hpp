@@ -107,7 +107,7 @@ struct StepParams {
   int32_t max_contacts, max_self;   // deepest-K per leg (LLM_MAX_CONTACTS_PER_LEG), self-collision rows per robot (LLM_MAX_SELF)
   float self_friction, pair_friction;   // LLM_SPEC_SELF_FRICTION / LLM_SPEC_PAIR_FRICTION (round 6: engine twins of the oracle switches): mu of the two tangential rows a leg-leg / robot-robot
                                         // contact carries behind its normal row (box bounds +- mu x the normal multiplier, btPlaneSpace1 directions); 0 = frictionless (the spec of rounds 1 - 5)
-  int32_t max_pair, pad_spec;           // LLM_SPEC_MAX_PAIR: robot-robot rows per robot pair, 2 (rounds 1 - 5) .. 4 (a manifold's four points)
+  int32_t max_pair, leg_edges;          // LLM_SPEC_MAX_PAIR: robot-robot rows per robot pair, 2 (rounds 1 - 5) .. 4 (a manifold's four points); LLM_SPEC_LEG_EDGES: terrain edges across the leg boxes are contact candidates (round 6)
   double dt_d, frame_step, policy_step, sample_factor;
   uint64_t seed;
   uint64_t step_count;      // control steps executed so far (salts the Philox stream)

@@ -602,6 +602,104 @@ struct Pmc {
     }
     Pb = mulT(R, mk3<F>(Pw.x - bs.p.x, Pw.y - bs.p.y, Pw.z - bs.p.z));
   }
+  // Terrain edges against the flat faces of the LEG boxes (round 6: the mirror of reverse_edge for thigh and shank; the oracle's leg_reverse_edge states the rule).  The robot's own
+  // candidates on a leg are vertices, rim points and two mid-span spheres per link: a shank laid ACROSS the edge of a hurdle between them sinks until one of those arrives.  So lane
+  // (leg l, sub-lane s) tests edge s (0: x = x0, 1: x = x1, 2: y = y0, 3: y = y1; at the top z1, or at the bottom z0 of a box that floats) of every listed terrain box against the
+  // leg's thigh box and shank box, each in the box's own frame exactly as reverse_edge does for the body box: the edge cut to the box grown by the margin, the middle of the rest
+  // naming the face, the piece cut to the other two axes, BOTH its ends evaluated.  The lane's candidate (jj = 9) is the deepest of all of them: depth = signed distance to the
+  // face's plane, point = the point of the terrain edge (returned in F0), normal = the face's inward normal (world), link = 2 (thigh) / 3 (shank).
+  // edgef: which edge, as a float (the lane's own sub-lane when candidates are collected; the kept candidate's sub-lane when its row is built).
+  static LL_HD void leg_edge(const L& ln, const StepParams& P, const SubstepExtra* ex, const Base& bs, const M3<float>& R, const LegKin& k, const float* legc, const F& edgef,
+                             F& depth, V3l& Pb, V3l& nw, F& link, F& shape) {
+    const F zero = ln.lane_f(0.0f), one = ln.lane_f(1.0f), far_ = ln.lane_f(1.0e30f);
+    shape = ln.lane_f(-1.0f);
+    const B e0 = edgef < 0.5f, e1 = lm::and_(edgef > 0.5f, edgef < 1.5f), e2 = lm::and_(edgef > 1.5f, edgef < 2.5f), e3 = edgef > 2.5f;
+    depth = far_;
+    link = ln.lane_f(3.0f);
+    V3l Pw = mk3<F>(zero, zero, zero);
+    nw = mk3<F>(zero, zero, one);
+    const float cwx = bs.p.x, cwy = bs.p.y, cwz = bs.p.z;
+    for (int lb = 0; lb < 2; lb++) {                        // 0: the thigh box, 1: the shank box
+      const M3<F>& Rk = lb == 0 ? k.R2 : k.R3;
+      const V3l& pk = lb == 0 ? k.p2 : k.p3;
+      const int f0 = lb == 0 ? LC_THBOX : LC_SHBOX;
+      // the box in world coordinates: centre, unit axes (rows of W), half extents
+      const V3l cb = pk + mul(Rk, ld3c(ln, legc, f0));
+      const V3l cwl = mul(R, cb);
+      const V3l cw = mk3<F>(cwl.x + cwx, cwl.y + cwy, cwl.z + cwz);
+      F h[3], W[9];
+      for (int a = 0; a < 3; a++) {
+        const V3l u = ld3c(ln, legc, f0 + 3 + 3 * a);
+        h[a] = lm::sqrt_(dot(u, u));
+        const V3l ub = mul(Rk, u), uw = mul(R, ub);
+        const F ih = one / h[a];
+        W[3 * a + 0] = uw.x * ih; W[3 * a + 1] = uw.y * ih; W[3 * a + 2] = uw.z * ih;
+      }
+      const F reach = lm::sqrt_(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]) + P.margin_dist;
+      for (int si = 0; si < ex->n_shapes; si++) {
+        const BoxRec rec = load_box(ex->shapes + si * 8);
+        F lx = cw.x, ly = cw.y;
+        if (ex->yawed) { const F dx = cw.x - ex->ycx, dy = cw.y - ex->ycy; lx = dx * ex->ycs + dy * ex->ysn; ly = dy * ex->ycs - dx * ex->ysn; }
+        const float ze = rec.c.x > (float)LLM_FLOATING_MIN_Z ? rec.c.x : rec.c.y;
+        const B near = lm::and_(lm::and_(lm::and_(lx > rec.a.x - reach, lx < rec.a.y + reach), lm::and_(ly > rec.a.z - reach, ly < rec.a.w + reach)), lm::abs_(cw.z - ze) < reach);
+        if (!L::any(near)) continue;                        // (an optimisation only: an edge point within the margin of the box is within `reach` of its centre)
+        F ax_ = lm::sel(e1, ln.lane_f(rec.a.y), ln.lane_f(rec.a.x)), ay_ = lm::sel(e3, ln.lane_f(rec.a.w), ln.lane_f(rec.a.z));
+        F bx_ = lm::sel(e0, ln.lane_f(rec.a.x), ln.lane_f(rec.a.y)), by_ = lm::sel(e2, ln.lane_f(rec.a.z), ln.lane_f(rec.a.w));
+        V3l aw = mk3<F>(ax_, ay_, ln.lane_f(ze)), bw = mk3<F>(bx_, by_, ln.lane_f(ze));
+        if (ex->yawed) {
+          aw = mk3<F>(ln.lane_f(ex->ycx) + ax_ * ex->ycs - ay_ * ex->ysn, ln.lane_f(ex->ycy) + ax_ * ex->ysn + ay_ * ex->ycs, aw.z);
+          bw = mk3<F>(ln.lane_f(ex->ycx) + bx_ * ex->ycs - by_ * ex->ysn, ln.lane_f(ex->ycy) + bx_ * ex->ysn + by_ * ex->ycs, bw.z);
+        }
+        V3l ra = aw - cw, dw = bw - aw;
+        F pa[3], dd[3], lo[3], hi[3];
+        F t0 = zero, t1 = one;
+        for (int i = 0; i < 3; i++) {
+          pa[i] = ra.x * W[3 * i] + ra.y * W[3 * i + 1] + ra.z * W[3 * i + 2];
+          dd[i] = dw.x * W[3 * i] + dw.y * W[3 * i + 1] + dw.z * W[3 * i + 2];
+          F inv = one / lm::sel(lm::abs_(dd[i]) < 1e-9f, ln.lane_f(1e-9f), dd[i]);
+          const F H = h[i] + P.margin_dist;
+          F ta = ((zero - H) - pa[i]) * inv, tb = (H - pa[i]) * inv;
+          t0 = lm::max_(t0, lm::min_(ta, tb)); t1 = lm::min_(t1, lm::max_(ta, tb));
+          F ea = ((zero - h[i]) - pa[i]) * inv, eb = (h[i] - pa[i]) * inv;
+          lo[i] = lm::min_(ea, eb); hi[i] = lm::max_(ea, eb);
+        }
+        F tm = (t0 + t1) * 0.5f;
+        F pm0 = pa[0] + tm * dd[0], pm1 = pa[1] + tm * dd[1], pm2 = pa[2] + tm * dd[2];
+        F q0 = lm::abs_(pm0) - h[0], q1 = lm::abs_(pm1) - h[1], q2 = lm::abs_(pm2) - h[2];
+        {   // the face must be one the edge runs ACROSS: the box axis the edge is most parallel to is no candidate (a thin leg box is pierced lengthwise through its two small faces)
+          const F d0 = lm::abs_(dd[0]), d1 = lm::abs_(dd[1]), d2 = lm::abs_(dd[2]);
+          const B par0 = lm::and_(d0 >= d1, d0 >= d2), par1 = lm::and_(lm::not_(par0), d1 >= d2);
+          const B par2 = lm::and_(lm::not_(par0), lm::not_(par1));
+          const F never = ln.lane_f(-3.0e38f);
+          q0 = lm::sel(par0, never, q0); q1 = lm::sel(par1, never, q1); q2 = lm::sel(par2, never, q2);
+        }
+        B is1 = q1 > q0;
+        F q = lm::sel(is1, q1, q0);
+        B is2 = q2 > q;
+        B a0 = lm::and_(lm::not_(is1), lm::not_(is2)), a1 = lm::and_(is1, lm::not_(is2));
+        F pmx = lm::sel(is2, pm2, lm::sel(is1, pm1, pm0));
+        F sg = lm::sel(pmx >= 0.0f, one, zero - one);
+        F u0 = lm::max_(zero, lm::sel(a0, lm::max_(lo[1], lo[2]), lm::sel(a1, lm::max_(lo[0], lo[2]), lm::max_(lo[0], lo[1]))));
+        F u1 = lm::min_(one, lm::sel(a0, lm::min_(hi[1], hi[2]), lm::sel(a1, lm::min_(hi[0], hi[2]), lm::min_(hi[0], hi[1]))));
+        B valid = lm::and_(lm::and_(t0 <= t1, u0 <= u1), near);
+        F pax = lm::sel(is2, pa[2], lm::sel(is1, pa[1], pa[0])), dax = lm::sel(is2, dd[2], lm::sel(is1, dd[1], dd[0]));
+        F hax = lm::sel(is2, h[2], lm::sel(is1, h[1], h[0]));
+        F dep0 = sg * (pax + u0 * dax) - hax, dep1 = sg * (pax + u1 * dax) - hax;
+        B second = dep1 < dep0;                              // the deeper of the piece's two ends (the first on a tie)
+        F dep = lm::sel(second, dep1, dep0), u = lm::sel(second, u1, u0);
+        B better = lm::and_(valid, dep < depth);
+        depth = lm::sel(better, dep, depth);
+        link = lm::sel(better, ln.lane_f(lb == 0 ? 2.0f : 3.0f), link);
+        shape = lm::sel(better, ln.lane_f((float)si), shape);
+        Pw = mk3<F>(lm::sel(better, aw.x + u * dw.x, Pw.x), lm::sel(better, aw.y + u * dw.y, Pw.y), lm::sel(better, aw.z + u * dw.z, Pw.z));
+        F nsg = zero - sg;
+        nw = mk3<F>(lm::sel(better, nsg * lm::sel(is2, W[6], lm::sel(is1, W[3], W[0])), nw.x),
+                    lm::sel(better, nsg * lm::sel(is2, W[7], lm::sel(is1, W[4], W[1])), nw.y),
+                    lm::sel(better, nsg * lm::sel(is2, W[8], lm::sel(is1, W[5], W[2])), nw.z));
+      }
+    }
+    Pb = mulT(R, mk3<F>(Pw.x - bs.p.x, Pw.y - bs.p.y, Pw.z - bs.p.z));
+  }
   // closest points of the segments p1-q1 and p2-q2 (Ericson 5.1.9; same branches as the oracle's seg_seg)
   static LL_HD void seg_seg(const L& ln, const V3l& p1, const V3l& q1, const V3l& p2, const V3l& q2, V3l& c1, V3l& c2) {
     F s, t;
@@ -1181,7 +1279,7 @@ struct Pmc {
       }
     }
     // candidates per sub-lane: the eighth (mid-link sphere) and the ninth (a terrain edge under the trunk, reverse_edge) only with terrain
-    constexpr int NT = TERRAIN ? 8 : 7, NC = TERRAIN ? 9 : 7;
+    constexpr int NT = TERRAIN ? 8 : 7, NC = TERRAIN ? 10 : 7;   // (terrain builds: jj = 7 mid-link sphere, 8 a terrain edge under the trunk, 9 a terrain edge across a leg box)
     constexpr float STRIDE = TERRAIN ? 16.0f : 8.0f;          // candidate index = STRIDE * sub + jj: the (sub, jj) order of the oracle's enumeration
     F depth[NC];
     const bool want_touch = TERRAIN && ex && ex->want_touch;
@@ -1228,13 +1326,25 @@ struct Pmc {
       }
       depth[jj] = lm::sel(lm::and_(dpt < P.margin_dist, link > -0.5f), dpt, far_);
     }
-    if (TERRAIN) {
-      depth[NC - 1] = far_;
+    if constexpr (TERRAIN) {
+      depth[8] = far_;
+      depth[9] = far_;
       if (terr) {                                             // sub-lanes 0, 1: the two ends of the leg's terrain edge under the body box
         F rd;
         V3l rP, rn;
         reverse_edge(ln, P, ex, bs, R, L::i2f(ln.sub()), rd, rP, rn);
-        depth[NC - 1] = lm::sel(lm::and_(sub_lt2, rd < P.margin_dist), rd, far_);
+        depth[8] = lm::sel(lm::and_(sub_lt2, rd < P.margin_dist), rd, far_);
+        if (P.leg_edges) {                                    // every sub-lane: terrain edge `sub` of the listed boxes across the leg's thigh and shank boxes (round 6)
+          F ld, ll, lsh;
+          V3l lP, lnw;
+          leg_edge(ln, P, ex, bs, R, k, legc, L::i2f(ln.sub()), ld, lP, lnw, ll, lsh);
+          depth[9] = lm::sel(ld < P.margin_dist, ld, far_);
+          if (want_touch) {                                   // a leg box on a box's edge is a leg link touching that box (the flag, or a static)
+            const B on = ld < P.margin_dist, isf = lm::abs_(lsh - (float)ex->flag_shape) < 0.5f;
+            tch_fl = lm::sel(lm::and_(on, isf), zero, tch_fl);
+            tch_st = lm::sel(lm::and_(on, lm::not_(isf)), zero, tch_st);
+          }
+        }
       }
       if (want_touch) {
         ex->touch_static = L::rmin(tch_st) < 0.5f ? 1.0f : 0.0f;
@@ -1340,7 +1450,8 @@ struct Pmc {
     if (any_contact) {
       // geometry of this lane's contact: candidate (my_sub, my_jj) of the leg, re-evaluated from the table
       // (a reverse candidate, jj = 8, has no table entry: it reads entry 7's and replaces what it needs below)
-      const B isrev = TERRAIN ? lm::and_(cvalid, my_jj > 7.5f) : (zero > one);
+      const B isrevl = TERRAIN ? lm::and_(cvalid, my_jj > 8.5f) : (zero > one);                     // a terrain edge across a leg box (leg_edge)
+      const B isrev = TERRAIN ? lm::and_(lm::and_(cvalid, my_jj > 7.5f), lm::not_(isrevl)) : (zero > one);   // a terrain edge under the trunk (reverse_edge)
       // (a slot without a candidate decodes the 'none' code to indices outside the table: clamped, its row is dead anyway)
       I wsub = L::f2i(lm::min_(my_sub, ln.lane_f(3.0f))), wbase = L::f2i(lm::min_(my_jj, ln.lane_f(7.0f))) * CF_WORDS;
       V3l A = mk3<F>(ln.candc_of(wsub, wbase + CF_A), ln.candc_of(wsub, wbase + CF_A + 1), ln.candc_of(wsub, wbase + CF_A + 2));
@@ -1403,6 +1514,16 @@ struct Pmc {
             nw = mk3<F>(lm::sel(isrev, rn.x, nw.x), lm::sel(isrev, rn.y, nw.y), lm::sel(isrev, rn.z, nw.z));
             scale_mu = lm::sel(isrev, ln.lane_f(ex->box_mu_scale), scale_mu);
             rs = lm::sel(isrev, zero, rs);
+          }
+          if (L::any(isrevl)) {                                 // ... or the terrain edge's point and the LEG box face's normal; the row acts on that box's link
+            F rd, rl, rsh;
+            V3l rP, rn;
+            leg_edge(ln, P, ex, bs, R, k, legc, my_sub, rd, rP, rn, rl, rsh);
+            Pb = mk3<F>(lm::sel(isrevl, rP.x, Pb.x), lm::sel(isrevl, rP.y, Pb.y), lm::sel(isrevl, rP.z, Pb.z));
+            nw = mk3<F>(lm::sel(isrevl, rn.x, nw.x), lm::sel(isrevl, rn.y, nw.y), lm::sel(isrevl, rn.z, nw.z));
+            scale_mu = lm::sel(isrevl, ln.lane_f(ex->box_mu_scale), scale_mu);
+            rs = lm::sel(isrevl, zero, rs);
+            link = lm::sel(isrevl, rl, link);
           }
           mu = mu * scale_mu;
           // btPlaneSpace1(n): two tangents; for n = +z they are -y and +x, the directions of the flat-ground rows
@@ -1782,11 +1903,17 @@ struct Pmc {
       }
       PMC_PHASE("pgs.self_turns");
       if (any_self) {                                                        // then the self-collision rows, one after the other (with LLM_SPEC_SELF_FRICTION each followed by its two tangential rows)
+        // (a tangential row whose normal multiplier is zero is bounded to [0, 0]: unless it still carries a multiplier of its own its turn changes nothing -- skipped when that holds
+        //  for every env of the wave: exact, and most leg-leg contacts of a step are within the margin without pressing)
         self_turn(ln, sr[0], VA, VB, VJ);
-        if (self_fric) { self_fric_turn(ln, sf[0][0], P.self_friction * sr[0].lam, VA, VB, VJ); self_fric_turn(ln, sf[0][1], P.self_friction * sr[0].lam, VA, VB, VJ); }
+        if (self_fric && L::any(ln.lane_f((sr[0].lam > 0.0f || sf[0][0].lam != 0.0f || sf[0][1].lam != 0.0f) ? 1.0f : 0.0f) > 0.5f)) {
+          self_fric_turn(ln, sf[0][0], P.self_friction * sr[0].lam, VA, VB, VJ); self_fric_turn(ln, sf[0][1], P.self_friction * sr[0].lam, VA, VB, VJ);
+        }
         if (n_self_w > 1) {
           self_turn(ln, sr[1], VA, VB, VJ);
-          if (self_fric) { self_fric_turn(ln, sf[1][0], P.self_friction * sr[1].lam, VA, VB, VJ); self_fric_turn(ln, sf[1][1], P.self_friction * sr[1].lam, VA, VB, VJ); }
+          if (self_fric && L::any(ln.lane_f((sr[1].lam > 0.0f || sf[1][0].lam != 0.0f || sf[1][1].lam != 0.0f) ? 1.0f : 0.0f) > 0.5f)) {
+            self_fric_turn(ln, sf[1][0], P.self_friction * sr[1].lam, VA, VB, VJ); self_fric_turn(ln, sf[1][1], P.self_friction * sr[1].lam, VA, VB, VJ);
+          }
         }
       }
       if (PAIR) {
@@ -1796,7 +1923,7 @@ struct Pmc {
             if (slot >= n_pair_w) break;
             pair_turn(ln, pr[slot], VA, VB, VJ, ex->pair_me);
             if constexpr (PAIR && XROWS) {
-              if (pair_fric) {
+              if (pair_fric && L::any(ln.lane_f((pr[slot].lam > 0.0f || pf[slot][0].lam != 0.0f || pf[slot][1].lam != 0.0f) ? 1.0f : 0.0f) > 0.5f)) {      // (see the leg-leg rows)
                 pair_fric_turn(ln, pf[slot][0], P.pair_friction * pr[slot].lam, VA, VB, VJ, ex->pair_me);
                 pair_fric_turn(ln, pf[slot][1], P.pair_friction * pr[slot].lam, VA, VB, VJ, ex->pair_me);
               }

@@ -257,7 +257,7 @@ static inline std::string pmc_fill_params(const ll_config& cfg, StepParams& P) {
   P.self_collision = 1.0f;
   P.max_depen = (float)LLM_MAX_DEPEN_SPEED; P.self_margin = (float)LLM_SELF_MARGIN;
   P.max_contacts = LLM_MAX_CONTACTS_PER_LEG; P.max_self = LLM_MAX_SELF;
-  P.self_friction = (float)LLM_SELF_FRICTION; P.pair_friction = (float)LLM_PAIR_FRICTION; P.max_pair = LLM_MAX_PAIR;
+  P.self_friction = (float)LLM_SELF_FRICTION; P.pair_friction = (float)LLM_PAIR_FRICTION; P.max_pair = LLM_MAX_PAIR; P.leg_edges = LLM_LEG_EDGES;
   P.friction_mode = LLM_FRICTION_MODE;
   P.max_coord_vel = (float)LLM_MAX_COORD_VEL;
   P.limit_speculative = LLM_LIMIT_SPECULATIVE;
@@ -329,6 +329,9 @@ inline std::string pmc_set_spec_param(StepParams& P, int id, double v) {
     case LLM_SPEC_MAX_PAIR:
       if (!(v >= 0 && v <= LLM_MAX_PAIR_CAP)) return "robot-robot rows per pair must be 0..4";
       P.max_pair = (int)v; break;
+    case LLM_SPEC_LEG_EDGES:
+      if (!(v == 0.0 || v == 1.0)) return "leg_edges must be 0 or 1";
+      P.leg_edges = (int)v; break;
     case LLM_SPEC_FRICTION_KEEP:
     case LLM_SPEC_WARM_START:
       if (v != 0.0) return "this switch exists in the oracle only (tools/deviation_table.py reports what it is worth)";
@@ -378,6 +381,7 @@ inline double pmc_get_spec_param(const StepParams& P, int id) {
     case LLM_SPEC_MAX_PAIR: return P.max_pair;
     case LLM_SPEC_SELF_FRICTION: return P.self_friction;
     case LLM_SPEC_PAIR_FRICTION: return P.pair_friction;
+    case LLM_SPEC_LEG_EDGES: return P.leg_edges;
     case LLM_SPEC_LIMIT_SPECULATIVE: return P.limit_speculative;
     case LLM_SPEC_GYRO: return 1.0;
     default: return 0.0;

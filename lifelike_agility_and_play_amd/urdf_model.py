@@ -330,8 +330,18 @@ def model_blob(inertia='collision_aabb'):
 
 
 def default_model_blob():
-    """The model every env uses unless told otherwise.  ``LL_MODEL_INERTIA=file`` selects the A/B leg."""
-    return model_blob(default_inertia_source())
+    """The model every env uses unless told otherwise.  ``LL_MODEL_INERTIA=file`` selects the A/B leg.
+    ``LL_MODEL_NO_WHEELS=1`` (an EXPERIMENT leg, round 6: the third of the bars policy's budgeted experiments) shrinks the four passive wheel cylinders at the knees to
+    a millimetre, so that they never touch anything before the thigh's other shapes do: collision shapes only -- the inertias were compiled before."""
+    import os
+    b = model_blob(default_inertia_source())
+    if os.environ.get('LL_MODEL_NO_WHEELS') == '1':
+        b = b.copy()
+        for l in range(N_LEGS):
+            off = OFF_LEG_PRIMS + (l * N_LEG_PRIMS + 4) * PRIM_STRIDE            # LEG_PRIM_SLOTS[4]: the wheel cylinder on the thigh
+            assert b[off] == PRIM_CYL
+            b[off + 1:off + 4] = 1.0e-3
+    return b
 
 
 def default_inertia_source():

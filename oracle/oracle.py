@@ -102,7 +102,7 @@ def f64(a):
 # ---- spec overrides (include/llenv_model.h LLM_SPEC_*; deviation study) ------------------------
 SPEC_IDS = dict(limit_gate=0, max_depen_speed=1, link_damping=2, max_contacts_per_leg=3, self_collision=4, self_margin=5, max_self=6,
                 erp=7, contact_margin=8, self_friction=9, warm_start=10, trunk_edges=11, select_eps=12,
-                friction_mode=13, row_order=14, max_coord_vel=15, limit_erp=16, pair_friction=17, max_pair=18, friction_dirs=19, limit_speculative=20, gyro=21, friction_keep=22, erp_deep=23, erp_deep_below=24, limit_erp_deep=25)
+                friction_mode=13, row_order=14, max_coord_vel=15, limit_erp=16, pair_friction=17, max_pair=18, friction_dirs=19, limit_speculative=20, gyro=21, friction_keep=22, erp_deep=23, erp_deep_below=24, limit_erp_deep=25, leg_edges=26)
 
 
 def set_spec(**kw):

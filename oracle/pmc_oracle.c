@@ -556,7 +556,7 @@ static int aba(const OModel* M, const OKin* K, const double* qd, const double* t
 /* Spec overrides (include/llenv_model.h LLM_SPEC_*): process-wide, defaults = the constants of that header.  The engine has the same
  * switches (ll_set_spec_param); tools/deviation_table.py moves them in both to measure what each of this build's own choices is worth. */
 static double g_spec[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, LLM_MAX_COORD_VEL, LLM_LIMIT_ERP, 0.0, 2.0, 0.0, LLM_LIMIT_SPECULATIVE, 1.0, 0.0, LLM_ERP_DEEP, LLM_ERP_DEEP_BELOW, LLM_LIMIT_ERP_DEEP};
+                                        LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, LLM_SELF_FRICTION, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, LLM_MAX_COORD_VEL, LLM_LIMIT_ERP, LLM_PAIR_FRICTION, LLM_MAX_PAIR, 0.0, LLM_LIMIT_SPECULATIVE, 1.0, 0.0, LLM_ERP_DEEP, LLM_ERP_DEEP_BELOW, LLM_LIMIT_ERP_DEEP, LLM_LEG_EDGES};
 int orc_set_spec_param(int id, double v) {
   if (id < 0 || id >= LLM_SPEC_COUNT) return -1;
   if (id == LLM_SPEC_MAX_CONTACTS_PER_LEG && !(v >= 1 && v <= LLM_MAX_CONTACTS_PER_LEG)) return -1;
@@ -569,7 +569,7 @@ int orc_set_spec_param(int id, double v) {
 double orc_get_spec_param(int id) { return (id >= 0 && id < LLM_SPEC_COUNT) ? g_spec[id] : NAN; }
 void orc_reset_spec(void) {
   const double d[LLM_SPEC_COUNT] = {LLM_LIMIT_GATE, LLM_MAX_DEPEN_SPEED, LLM_LINK_DAMPING, LLM_MAX_CONTACTS_PER_LEG, 1.0, LLM_SELF_MARGIN,
-                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, 0.0, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, LLM_MAX_COORD_VEL, LLM_LIMIT_ERP, 0.0, 2.0, 0.0, LLM_LIMIT_SPECULATIVE, 1.0, 0.0, LLM_ERP_DEEP, LLM_ERP_DEEP_BELOW, LLM_LIMIT_ERP_DEEP};
+                                    LLM_MAX_SELF, LLM_ERP, LLM_CONTACT_MARGIN, LLM_SELF_FRICTION, 0.0, 1.0, LLM_SELECT_EPS, LLM_FRICTION_MODE, 0.0, LLM_MAX_COORD_VEL, LLM_LIMIT_ERP, LLM_PAIR_FRICTION, LLM_MAX_PAIR, 0.0, LLM_LIMIT_SPECULATIVE, 1.0, 0.0, LLM_ERP_DEEP, LLM_ERP_DEEP_BELOW, LLM_LIMIT_ERP_DEEP, LLM_LEG_EDGES};
   memcpy(g_spec, d, sizeof d);
 }
 /* bias of a unilateral row from its signed distance: a separated row may close the gap within the substep; a penetrating one is pushed
@@ -680,8 +680,8 @@ static double shape_sdf(const double* s, const double* E, double* n, int* is_box
  *   14-17 thigh box v0-3 | 18,19 thigh cyl 1 caps | 20 body box vertex z+ | 21-24 thigh box v4-7 | 25,26 hip cyl caps | 27 handle
  * and keeps the KC candidates of smallest depth below the margin (ties: lower index); the kept ones fill the slots in
  * candidate-index order.  (The index order is the one of the kernel's table, pmc_tables.hpp pmc_build_cand_table.) */
-typedef struct { double P[3], depth, mu, rs, n[3]; int body, valid; } OCand;   /* rs: radius when the primitive is a sphere (tested at its centre) */
-#define NCAND 36   /* per leg: index = 9 * sub + jj; jj = 7 (mid-link spheres) and jj = 8 (terrain edges under the trunk) exist only with terrain */
+typedef struct { double P[3], depth, mu, rs, n[3]; int body, valid, shape; } OCand;   /* rs: radius when the primitive is a sphere (tested at its centre) */
+#define NCAND 40   /* per leg: index = 10 * sub + jj; jj = 7 (mid-link spheres), jj = 8 (terrain edges under the trunk) and jj = 9 (terrain edges across the leg boxes, round 6) exist only with terrain */
 
 static void cand_point(const OPrim* p, const double* Rw, const double* pw, int which, OCand* c) {
   double ctr[3], t[3], Rp[9];
@@ -710,7 +710,7 @@ static void cand_point(const OPrim* p, const double* Rw, const double* pw, int w
 }
 
 static void capsule(const OModel* M, const OKin* K, int leg, int which, double* a, double* b, double* r, int* body);
-/* the candidate points of leg l, index = 9 * sub + jj in the (sub, jj) order of the kernel's table; jj = 8 is left invalid here (reverse_edge) */
+/* the candidate points of leg l, index = 10 * sub + jj in the (sub, jj) order of the kernel's table; jj = 8, 9 are left invalid here (reverse_edge, leg_reverse_edge) */
 static void enum_cands(const OModel* M, const OKin* K, int l, double mu_foot, double mu_link, const OTerrain* T, OCand* c) {
   memset(c, 0, NCAND * sizeof(OCand));
   int hip = 1 + 3 * l, thigh = 2 + 3 * l, shank = 3 + 3 * l, k = 0;
@@ -726,21 +726,25 @@ static void enum_cands(const OModel* M, const OKin* K, int l, double mu_foot, do
   CAND(&lp[5], shank, 3, mu_link);                                        /*  6      shank box v3                 */
   MID(1, 1.0 / 3.0);                                                      /*  7      shank axis 1/3 (terrain)     */
   k++;                                                                    /*         (jj = 8: reverse_edge)       */
+  k++;                                                                    /*         (jj = 9: leg_reverse_edge)   */
   for (int v = 4; v < 8; v++) CAND(&lp[5], shank, v, mu_link);             /*  7-10   shank box v4..v7             */
   for (int s2 = 0; s2 < 2; s2++) CAND(&lp[2], thigh, s2, mu_link);         /*  11,12  thigh cylinder 0 caps        */
   CAND(&M->base_prims[0], 0, l, mu_link);                                 /*  13     body box vertex (leg, z-)    */
   MID(1, 2.0 / 3.0);                                                      /*         shank axis 2/3 (terrain)     */
   k++;                                                                    /*         (jj = 8: reverse_edge)       */
+  k++;                                                                    /*         (jj = 9: leg_reverse_edge)   */
   for (int v = 0; v < 4; v++) CAND(&lp[1], thigh, v, mu_link);             /*  14-17  thigh box v0..v3             */
   for (int s2 = 0; s2 < 2; s2++) CAND(&lp[3], thigh, s2, mu_link);         /*  18,19  thigh cylinder 1 caps        */
   CAND(&M->base_prims[0], 0, l + 4, mu_link);                             /*  20     body box vertex (leg, z+)    */
   MID(0, 1.0 / 3.0);                                                      /*         thigh axis 1/3 (terrain)     */
   k++;                                                                    /*         (jj = 8: reverse_edge)       */
+  k++;                                                                    /*         (jj = 9: leg_reverse_edge)   */
   for (int v = 4; v < 8; v++) CAND(&lp[1], thigh, v, mu_link);             /*  21-24  thigh box v4..v7             */
   for (int s2 = 0; s2 < 2; s2++) CAND(&lp[0], hip, s2, mu_link);           /*  25,26  hip cylinder caps            */
   if (l == 0 || l == 2) CAND(&M->base_prims[l == 0 ? 1 : 2], 0, 0, mu_link); else k++;   /* 27 handle sphere (legs 0, 2) */
   MID(0, 2.0 / 3.0);                                                      /*         thigh axis 2/3 (terrain)     */
   k++;                                                                    /*         (jj = 8: reverse_edge)       */
+  k++;                                                                    /*         (jj = 9: leg_reverse_edge)   */
 #undef CAND
 #undef MID
 }
@@ -755,41 +759,42 @@ static void enum_cands(const OModel* M, const OKin* K, int l, double mu_foot, do
  *      the leg, candidate jj = 8), each with depth = its signed distance to the face's plane, contact point = the point of the
  *      terrain edge, normal = the face's inward normal (the way the body is pushed), friction partner = the terrain box.
  * Over several boxes each candidate keeps the deepest.  Returns 0 / 1; P, n in world coordinates. */
-static int reverse_edge(const OModel* M, const OKin* K, const OTerrain* T, int l, int s, OCand* out) {
-  const OPrim* bx = &M->base_prims[0];
-  double Bt[9], cw[3], t[3];
-  m3m(K->Rw[0], bx->rot, Bt);
-  m3v(K->Rw[0], bx->pos, t);
-  for (int i = 0; i < 3; i++) cw[i] = K->pw[0][i] + t[i];
+/* one terrain edge family (edge index e of every box of T: 0: x = x0, 1: x = x1, 2: y = y0, 3: y = y1, at the top -- at the bottom of a floating box) against ONE box of the robot
+ * given in world coordinates (Bt: columns = the box's unit axes, cw: its centre, size: half extents): steps 1 - 3 of the rule above.  `end` = 0 / 1 evaluates that end of the
+ * clipped piece, `end` = 2 both and keeps the deeper (the first on a tie).  The candidate in `out` is replaced when a deeper one is found (found_before: `out` already holds one). */
+static int edge_vs_box(const OTerrain* T, int e, const double* Bt, const double* cw, const double* size, int end, int body, int found, int across, OCand* out) {
   const double margin = g_spec[LLM_SPEC_CONTACT_MARGIN];
-  int found = 0;
   for (int si = 0; si < T->n; si++) {
     const double* r = T->rec + 8 * si;
     const double ze = r[4] > LLM_FLOATING_MIN_Z ? r[4] : r[5];                      /* a floating box (a hanging bar) offers its bottom edges */
-    double al[3] = {l == 1 ? r[1] : r[0], l == 3 ? r[3] : r[2], ze}, bl[3] = {l == 0 ? r[0] : r[1], l == 2 ? r[2] : r[3], ze};
+    double al[3] = {e == 1 ? r[1] : r[0], e == 3 ? r[3] : r[2], ze}, bl[3] = {e == 0 ? r[0] : r[1], e == 2 ? r[2] : r[3], ze};
     double aw[3], bw[3], pa[3], d[3];
     if (T->yawed) {
       aw[0] = T->cx + al[0] * T->cs - al[1] * T->sn; aw[1] = T->cy + al[0] * T->sn + al[1] * T->cs; aw[2] = al[2];
       bw[0] = T->cx + bl[0] * T->cs - bl[1] * T->sn; bw[1] = T->cy + bl[0] * T->sn + bl[1] * T->cs; bw[2] = bl[2];
     } else { memcpy(aw, al, 24); memcpy(bw, bl, 24); }
-    for (int i = 0; i < 3; i++) {            /* into the body box's frame */
+    for (int i = 0; i < 3; i++) {            /* into the box's frame */
       pa[i] = 0; d[i] = 0;
       for (int k = 0; k < 3; k++) { pa[i] += Bt[3 * k + i] * (aw[k] - cw[k]); d[i] += Bt[3 * k + i] * (bw[k] - aw[k]); }
     }
     double lo[3], hi[3], t0 = 0, t1 = 1;
     for (int i = 0; i < 3; i++) {
-      const double ds = fabs(d[i]) < 1e-9 ? 1e-9 : d[i], H = bx->size[i] + margin;
+      const double ds = fabs(d[i]) < 1e-9 ? 1e-9 : d[i], H = size[i] + margin;
       const double ta = (-H - pa[i]) / ds, tb = (H - pa[i]) / ds;
       if ((ta < tb ? ta : tb) > t0) t0 = ta < tb ? ta : tb;
       if ((ta < tb ? tb : ta) < t1) t1 = ta < tb ? tb : ta;
-      const double ea = (-bx->size[i] - pa[i]) / ds, eb = (bx->size[i] - pa[i]) / ds;
+      const double ea = (-size[i] - pa[i]) / ds, eb = (size[i] - pa[i]) / ds;
       lo[i] = ea < eb ? ea : eb; hi[i] = ea < eb ? eb : ea;
     }
     if (t0 > t1) continue;
     const double tm = 0.5 * (t0 + t1);
     double q = -INFINITY, sg = 1; int ax = 0;
+    /* across (the leg boxes): the face must be one the edge runs ACROSS -- the box axis the edge is most parallel to is not a candidate (a thin leg box is pierced
+     * lengthwise by an edge through its two small faces; "the nearest face of the middle point" would be one of those, with a normal along the edge) */
+    const int par = across ? ((fabs(d[0]) >= fabs(d[1]) && fabs(d[0]) >= fabs(d[2])) ? 0 : (fabs(d[1]) >= fabs(d[2]) ? 1 : 2)) : -1;
     for (int i = 0; i < 3; i++) {
-      const double pm = pa[i] + tm * d[i], qi = fabs(pm) - bx->size[i];
+      if (i == par) continue;
+      const double pm = pa[i] + tm * d[i], qi = fabs(pm) - size[i];
       if (qi > q) { q = qi; ax = i; sg = pm >= 0 ? 1.0 : -1.0; }
     }
     double u0 = 0, u1 = 1;
@@ -799,14 +804,38 @@ static int reverse_edge(const OModel* M, const OKin* K, const OTerrain* T, int l
       if (hi[i] < u1) u1 = hi[i];
     }
     if (u0 > u1) continue;
-    const double u = s ? u1 : u0;
-    double p[3];
-    for (int i = 0; i < 3; i++) p[i] = pa[i] + u * d[i];
-    const double depth = sg * p[ax] - bx->size[ax];
+    const double dep0 = sg * (pa[ax] + u0 * d[ax]) - size[ax], dep1 = sg * (pa[ax] + u1 * d[ax]) - size[ax];
+    const double u = end == 0 ? u0 : (end == 1 ? u1 : (dep1 < dep0 ? u1 : u0));
+    const double depth = sg * (pa[ax] + u * d[ax]) - size[ax];
     if (found && depth >= out->depth) continue;
     found = 1;
-    out->depth = depth; out->rs = 0; out->body = 0; out->valid = 2;
+    out->depth = depth; out->rs = 0; out->body = body; out->valid = 2; out->shape = si;
     for (int i = 0; i < 3; i++) { out->P[i] = aw[i] + u * (bw[i] - aw[i]); out->n[i] = -sg * Bt[3 * i + ax]; }
+  }
+  return found;
+}
+static int reverse_edge(const OModel* M, const OKin* K, const OTerrain* T, int l, int s, OCand* out) {
+  const OPrim* bx = &M->base_prims[0];
+  double Bt[9], cw[3], t[3];
+  m3m(K->Rw[0], bx->rot, Bt);
+  m3v(K->Rw[0], bx->pos, t);
+  for (int i = 0; i < 3; i++) cw[i] = K->pw[0][i] + t[i];
+  return edge_vs_box(T, l, Bt, cw, bx->size, s, 0, 0, 0, out);
+}
+/* ... and the same for the LEG boxes (round 6): the robot's own candidates on a leg are vertices, rim points and two mid-span spheres per link, so a shank laid across the edge of a
+ * hurdle between them would sink until one of those arrives.  Candidate jj = 9 of sub-lane s of leg l: edge s of every terrain box against the leg's thigh box, then its shank box,
+ * both ends of every clipped piece -- the deepest of all of them (ties: the first in that order).  Normal = the leg box face's inward normal, body = the thigh / shank link. */
+static int leg_reverse_edge(const OModel* M, const OKin* K, const OTerrain* T, int l, int s, OCand* out) {
+  const OPrim* lp = M->leg_prims[l];
+  const int bodies[2] = {2 + 3 * l, 3 + 3 * l}, prims[2] = {1, 5};
+  int found = 0;
+  for (int b = 0; b < 2; b++) {
+    const OPrim* bx = &lp[prims[b]];
+    double Bt[9], cw[3], t[3];
+    m3m(K->Rw[bodies[b]], bx->rot, Bt);
+    m3v(K->Rw[bodies[b]], bx->pos, t);
+    for (int i = 0; i < 3; i++) cw[i] = K->pw[bodies[b]][i] + t[i];
+    found = edge_vs_box(T, s, Bt, cw, bx->size, 2, bodies[b], found, 1, out);
   }
   return found;
 }
@@ -833,7 +862,8 @@ static int find_contacts(const OModel* M, const OKin* K, double mu_foot, double 
           }
         }
       }
-      for (int s = 0; s < 2 && g_spec[LLM_SPEC_TRUNK_EDGES] > 0.5; s++) { c[9 * s + 8].mu = mu_link; reverse_edge(M, K, T, l, s, &c[9 * s + 8]); }
+      for (int s = 0; s < 2 && g_spec[LLM_SPEC_TRUNK_EDGES] > 0.5; s++) { c[10 * s + 8].mu = mu_link; reverse_edge(M, K, T, l, s, &c[10 * s + 8]); }
+      for (int s = 0; s < 4 && g_spec[LLM_SPEC_LEG_EDGES] > 0.5; s++) { c[10 * s + 9].mu = mu_link; leg_reverse_edge(M, K, T, l, s, &c[10 * s + 9]); }
     }
     int taken[NCAND] = {0}, nsel = 0;
     const int kc = (int)g_spec[LLM_SPEC_MAX_CONTACTS_PER_LEG];
@@ -1414,6 +1444,11 @@ static void touch_classes(const OModel* M, const OKin* K, const OTerrain* T, int
         double nn[3]; int isb;
         if (terrain_sdf(T, si, E, nn, &isb) - c[i].rs < LLM_CONTACT_MARGIN) { if (si == flag) *t_flag = 1; else *t_static = 1; }
       }
+    }
+    for (int s = 0; T && s < 4 && g_spec[LLM_SPEC_LEG_EDGES] > 0.5; s++) {      /* a leg box lying on a box's edge is a leg link touching that box (round 6) */
+      OCand e;
+      memset(&e, 0, sizeof e);
+      if (leg_reverse_edge(M, K, T, l, s, &e) && e.depth < LLM_CONTACT_MARGIN) { if (e.shape == flag) *t_flag = 1; else *t_static = 1; }
     }
   }
 }

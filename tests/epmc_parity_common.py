@@ -308,7 +308,22 @@ def check_free_running_invariants(lib_path, n_envs=64, n_steps=80, element=1):
 
 def check_multi_step_launch(lib_path, sizes=(12,), k=5, n_launches=4, element=1):
     """ll_epmc_step_random_n(sigma, k) == k x {ll_epmc_fill_random_actions(sigma); ll_epmc_step()}, bit for bit: state, the 916-float
-    observation (rays included), rewards, done reasons, episode records (terrain seeds, targets, push schedule), counters."""
+    observation (rays included), rewards, done reasons, episode records (terrain seeds, targets, push schedule), counters.
+    (Round 6: with the rays split off -- the default, LL_SPLIT_RAYS=2 -- a multi-step call IS a sequence of single launches; the fused multi-step build is what
+    LL_SPLIT_RAYS=0 runs, and that is the one this check is about: it pins the switch for its engines.)"""
+    import os
+    prev_split = os.environ.get('LL_SPLIT_RAYS')
+    os.environ['LL_SPLIT_RAYS'] = '0'
+    try:
+        return _check_multi_step_launch(lib_path, sizes, k, n_launches, element)
+    finally:
+        if prev_split is None:
+            os.environ.pop('LL_SPLIT_RAYS', None)
+        else:
+            os.environ['LL_SPLIT_RAYS'] = prev_split
+
+
+def _check_multi_step_launch(lib_path, sizes, k, n_launches, element):
     sg = float(np.exp(-2.0))
     for n in sizes:
         cfg = env_config(element)
@@ -403,11 +418,20 @@ def check_split_rays_equal_fused(lib_path, n=10, n_steps=40, elements=(1, 2, 3),
                     B.step_random_n(sg, k)
                 np.testing.assert_array_equal(A.obs(), B.obs())
                 np.testing.assert_array_equal(A.state(), B.state())
-                for x, y in zip(A.reward_done(), B.reward_done()):
-                    np.testing.assert_array_equal(x, y)
+                ra, rb = A.reward_done(), B.reward_done()
+                # (k > 1: A ran the fused MULTI-step build, B single-step launches.  The two builds round the reward's exp / division chain one ulp apart on the GPU -- state
+                #  and observation are bit-equal, and so is the reward between the fused and the split SINGLE-step paths: profiles/r06_epmc_multi_vs_single.txt)
+                if k == 1:
+                    np.testing.assert_array_equal(ra[0], rb[0])
+                else:
+                    np.testing.assert_allclose(ra[0], rb[0], rtol=3e-7, atol=1e-9)
+                np.testing.assert_array_equal(ra[1], rb[1]); np.testing.assert_array_equal(ra[2], rb[2])
                 ea, eb = A.episode(), B.episode()
                 for key in ea:
-                    np.testing.assert_array_equal(ea[key], eb[key])
+                    if np.asarray(ea[key]).dtype.kind == 'f' and k > 1:
+                        np.testing.assert_allclose(ea[key], eb[key], rtol=1e-6, atol=1e-7)      # (the episode's reward sums carry the same ulp)
+                    else:
+                        np.testing.assert_array_equal(ea[key], eb[key])
                 if n <= 512:                                                              # (the ray trace is kept for engines of at most 512 rows)
                     for x, y in zip(A.rays(), B.rays()):                                  # end points, hit flags and fractions of the step's 778 rays per row
                         np.testing.assert_array_equal(x, y)
@@ -664,6 +688,74 @@ def check_trunk_on_edges_against_oracle(lib_path, n_envs=16, seed=5, cap_ill=Non
         out.setdefault('felt_by_element', {})[element] = out['n_edge_felt'] - felt0
     assert out['n_edge_felt'] >= 8 and out['felt_by_element'][2] >= max(2, n_envs // 8), (out['n_edge_felt'], out['felt_by_element'])
     assert_within_bars(out, max_ill=0.07, max_tie=0.12, cap_ill=cap_ill, cap_tie=cap_tie)         # (bodies dropped flat onto edges: more make-and-break steps and more equal depths than among standing robots)
+    return out
+
+
+def check_legs_on_edges_against_oracle(lib_path, n_envs=16, seed=7, total_envs=None, cap_ill=None, cap_tie=None):
+    """DESIGN 8, round 6 "edges across the leg boxes" (LLM_SPEC_LEG_EDGES; BSE:310-364: a shank laid across a hurdle): robots lowered onto hurdles with their shanks level, one
+    shank's flat bottom within the margin of -- or a little into -- a hurdle's top edge somewhere between that shank's own candidate points; one control step of real physics, engine
+    vs oracle, standing bars -- and against the oracle with the leg edges switched off, to show that the cases are what they claim to be.
+    total_envs: as check_terrain_physics_against_oracle (the larger-batch build, cases spread over its grid)."""
+    from conftest import make_oracle_batch
+    from oracle import oracle as orc
+    from lifelike_agility_and_play_amd import mocap
+    from scipy.spatial.transform import Rotation as Rot
+    blob = urdf_model.default_model_blob()
+    jo = blob[urdf_model.OFF_JOINT_ORIGIN:urdf_model.OFF_JOINT_ORIGIN + 36].reshape(12, 3)
+    ax = blob[urdf_model.OFF_JOINT_AXIS:urdf_model.OFF_JOINT_AXIS + 36].reshape(12, 3)
+
+    def shank_box(s, l):                                                    # world centre of leg l's shank box, its lowest half extent, by an independent chain product
+        pos, rot = s[0:3].copy(), Rot.from_quat(s[3:7])
+        for j in range(3):
+            pos = pos + rot.apply(jo[3 * l + j]); rot = rot * Rot.from_rotvec(ax[3 * l + j] * s[13 + 3 * l + j])
+        bx = blob[urdf_model.OFF_LEG_PRIMS + (l * urdf_model.N_LEG_PRIMS + 5) * urdf_model.PRIM_STRIDE:][:16]
+        axes = (rot * Rot.from_matrix(bx[7:16].reshape(3, 3))).as_matrix()
+        return pos + rot.apply(bx[4:7]), float(sum(abs(axes[2, a]) * bx[1 + a] for a in range(3)))
+    out = dict(config=[], vel=[], n_edge_felt=0)
+    N = total_envs or n_envs
+    third = n_envs // 3
+    idx = np.arange(n_envs) if not total_envs else np.concatenate([np.arange(third), N // 2 - 5 + np.arange(third), N - (n_envs - 2 * third) + np.arange(n_envs - 2 * third)])
+    cfg = env_config(1)
+    E = make_engine(cfg, N, lib_path, seed=seed)
+    E.reset()
+    rows, cnt = E.statics()
+    rng = np.random.default_rng(seed)
+    st = E.state().astype(np.float64)
+    recs_all = [statics_to_records(rows[e, :cnt[e]].astype(np.float64)) for e in idx]
+    for k, i in enumerate(idx):
+        rec = recs_all[k]
+        cand = [b for b in rec[2:12] if b[4] < 0.01 and 0.04 < b[5] < 0.2]                # hurdles standing on the ground
+        b = cand[rng.integers(0, len(cand))]
+        l = int(rng.integers(0, 4))
+        st[i, 0:3] = [0.0, rng.uniform(-0.1, 0.1), 1.0]
+        st[i, 3:7] = Rot.from_euler('zyx', [rng.uniform(-0.4, 0.4), rng.uniform(-0.08, 0.08), rng.uniform(-0.08, 0.08)]).as_quat()
+        st[i, 13:25] = np.tile([0.0, -0.8, 0.8 + np.pi / 2], 4) + rng.normal(size=12) * 0.04     # thigh + shank = pi / 2: the shanks lie level
+        c, low = shank_box(st[i], l)
+        edge = b[0] if rng.uniform() < 0.5 else b[1]
+        st[i, 0] += edge - c[0] + rng.uniform(-0.03, 0.03)                                # the hurdle's edge under the middle third of that shank
+        st[i, 2] += b[5] - (c[2] - low) + rng.uniform(-0.012, 0.012)                       # its bottom within the margin of, or a little into, the hurdle's top
+        st[i, 7:13] = rng.normal(size=6) * 0.2; st[i, 9] -= 0.4
+        st[i, 25:37] = rng.normal(size=12) * 0.5
+    E.set_state(st)
+    st32 = E.state().astype(np.float64)
+    act = (rng.normal(size=(N, 12)) * 0.05).astype(np.float32)
+    ep = E.episode()
+    E.step_host(act)
+    es = E.state().astype(np.float64)
+    tr = E.push_trace().astype(np.float64)
+    B = make_oracle_batch(orc, blob, mocap.load_mocap('', 0.02), n_envs=1, kd=0.5, max_tau=16.0)
+    for k, i in enumerate(idx):
+        rec = recs_all[k]
+        p = st32[i, 0:3]
+        near = rec[(p[0] >= rec[:, 0] - 0.9) & (p[0] <= rec[:, 1] + 0.9) & (p[1] >= rec[:, 2] - 0.9) & (p[1] <= rec[:, 3] + 0.9) & (p[2] <= rec[:, 5] + 0.9)][:8]
+        mu_i = float(np.float32(ep['friction'][i]) * np.float32(0.9))
+        s = score_case(out, B, orc, es[i], st32[i], act[i], tr[i], mu_i, near)
+        s_off, _ = oracle_control_step(B, orc, st32[i], act[i], tr[i], mu_i, near, leg_edges=0)        # rounds 1 - 5: without the leg edges
+        if np.abs(s - s_off).max() > 1e-3:
+            out['n_edge_felt'] += 1
+    E.close()
+    assert out['n_edge_felt'] >= n_envs // 3, out['n_edge_felt']
+    assert_within_bars(out, max_ill=0.07, max_tie=0.12, cap_ill=cap_ill, cap_tie=cap_tie)
     return out
 
 

@@ -699,9 +699,10 @@ def check_pair_physics_against_oracle(lib_path, n_arenas=24, seed=5, total_arena
     engine then runs its XROWS build)."""
     from conftest import make_oracle_batch
     from oracle import oracle as orc
+    if not spec:                       # (possibly inside epmc_parity_common.spec_variant, which has set both sides)
+        return _check_pair_physics_against_oracle(lib_path, n_arenas, seed, total_arenas, cap_ill, spec)
     orc.reset_spec()
-    if spec:
-        orc.set_spec(**spec)
+    orc.set_spec(**spec)
     try:
         return _check_pair_physics_against_oracle(lib_path, n_arenas, seed, total_arenas, cap_ill, spec)
     finally:

@@ -74,6 +74,11 @@ def test_trunk_on_edges_against_oracle(emul_lib):
     print(out['n_edge_felt'], max(out['config']), max(out['vel']))
 
 
+def test_legs_on_edges_against_oracle(emul_lib):
+    out = ec.check_legs_on_edges_against_oracle(emul_lib)
+    print('legs on hurdle edges: %d of 16 cases feel the leg edges; worst config %.2e, velocity %.2e' % (out['n_edge_felt'], max(out['config']), max(out['vel'])))
+
+
 def test_free_running_against_the_oracle_env(emul_lib):
     print(ec.check_free_running_against_oracle_env(emul_lib))
 

@@ -49,6 +49,14 @@ def test_env_api_contract_gpu():
     check_single_env_contract(None)
 
 
+def test_legs_on_edges_against_oracle():
+    """Round 6 (LLM_SPEC_LEG_EDGES): hurdle edges across level shanks -- 48 cases on the one-wave-per-SIMD build, 48 spread over the grid of the larger-batch build"""
+    out = ec.check_legs_on_edges_against_oracle(None, n_envs=48, cap_ill=4, cap_tie=2)
+    print('legs on hurdle edges: %d of 48 cases feel the leg edges; worst config %.2e, velocity %.2e' % (out['n_edge_felt'], max(out['config']), max(out['vel'])))
+    out = ec.check_legs_on_edges_against_oracle(None, n_envs=48, seed=9, total_envs=4200, cap_ill=4, cap_tie=2)
+    print('... larger-batch build: %d of 48; worst config %.2e, velocity %.2e' % (out['n_edge_felt'], max(out['config']), max(out['vel'])))
+
+
 def test_terrain_physics_against_oracle():
     out = ec.check_terrain_physics_against_oracle(None, n_envs=48, cap_ill=3, cap_tie=1)        # observed on MI355X (round 4, 96 cases, cone friction): 2 / 2  (pyramid: 0 / 1)
     assert out['n_terrain'] >= 30 and out['n_felt'] >= 20

@@ -416,6 +416,63 @@ def test_hanging_bar_stops_the_back(golden, orc, model_blob, mocap_table):
         assert tops[0] > z0 + 0.1, (name, tops)                             # without the bottom edges the robot rises through it
 
 
+def shank_frame(model_blob, s, l):
+    """world position of the knee (the shank link's origin) and the shank link's rotation, by an independent scipy chain product (as test_fk_feet_matches_numpy)"""
+    from scipy.spatial.transform import Rotation as R
+    jo = model_blob[um.OFF_JOINT_ORIGIN:um.OFF_JOINT_ORIGIN + 36].reshape(12, 3)
+    ax = model_blob[um.OFF_JOINT_AXIS:um.OFF_JOINT_AXIS + 36].reshape(12, 3)
+    pos, rot = s[0:3].copy(), R.from_quat(s[3:7])
+    for j in range(3):
+        i = 3 * l + j
+        pos = pos + rot.apply(jo[i])
+        rot = rot * R.from_rotvec(ax[i] * s[13 + i])
+    return pos, rot
+
+
+def test_a_shank_across_a_hurdle_edge_rests_on_it(golden, orc, model_blob, mocap_table):
+    """DESIGN 8, round 6 (bullet_static_entities.py:310-364: hurdles 5 - 15 cm high; a shank laid across a hurdle's edge).  The robot's own candidates on a leg are vertices, rim
+    points and two mid-span spheres per link (a third and two thirds along): a thin wall whose top edge meets the flat of the shank box HALF way along it touches none of them.
+    Since round 6 the top edges of the terrain boxes are candidates against the thigh and shank boxes too (LLM_SPEC_LEG_EDGES): a robot dropped with its front-right shank level
+    across such a wall is caught by it -- the wall carries load and the shank stays on top of it -- and with the switch off (rounds 1 - 5) the same drop is, bit for bit, the
+    drop without any wall, the wall passing through the shank: the case is what it claims to be."""
+    from oracle import oracle as O
+    from scipy.spatial.transform import Rotation as R
+    B = make_oracle_batch(orc, model_blob, mocap_table)
+    s0 = standing_state(golden, z=1.0)                                   # in the air: nothing but the wall can touch the robot during the run
+    s0[13:25] = np.tile([0.0, -0.8, 0.8 + np.pi / 2], 4)                 # thigh + shank angle = pi / 2: the shanks lie level, pointing forward
+    hold = s0[13:25].copy()
+    knee, rot = shank_frame(model_blob, s0, 0)
+    box = model_blob[um.OFF_LEG_PRIMS + 5 * um.PRIM_STRIDE:um.OFF_LEG_PRIMS + 6 * um.PRIM_STRIDE]     # the FR shank box: type, size 3, pos 3, rot 9
+    size, bpos, brot = box[1:4], box[4:7], box[7:16].reshape(3, 3)
+    centre = knee + rot.apply(bpos)                                      # the middle of the shank box: half way between the two mid-span spheres
+    axes = (rot * R.from_matrix(brot)).as_matrix()                       # columns: the box's axes in the world
+    assert abs(axes[2, 0]) < 0.02                                        # the long axis is level
+    down = int(np.argmax(np.abs(axes[2])))                               # the box axis that points down: its half extent is the distance centre -> bottom face
+    bottom = centre[2] - size[down]
+    top = bottom - 0.03                                                  # the wall's top edge 3 cm under the shank's bottom face
+    wall = np.array([[centre[0] - 0.005, centre[0] + 0.005, centre[1] - 0.06, centre[1] + 0.06, 0.0, top, 0.0, 0.0]])    # 1 cm thick, across the FR shank only
+    runs = {}
+    try:
+        for name, spec, shapes in (('edges', dict(leg_edges=1), wall), ('no edges', dict(leg_edges=0), wall), ('no wall', dict(leg_edges=1), np.zeros((0, 8)))):
+            O.reset_spec(); O.set_spec(**spec)
+            s, load, zs = s0.copy(), [], []
+            for k in range(60):                                           # 0.12 s: a free fall of 7 cm, the shank ends 4 cm down the wall -- the wall has passed through it
+                tau = np.clip(50.0 * (hold - s[13:25]) - 0.5 * s[25:37], -18.0, 18.0)
+                s, nc, lam = B.substep_terrain(s, tau, 0.45, shapes, 1.0, None)
+                kz, rz = shank_frame(model_blob, s, 0)
+                zs.append((kz + rz.apply(bpos))[2] - size[down])          # the height of the shank box's bottom face (at its middle)
+                load.append(float(np.sum(lam[12:12 + 3 * max(nc, 0):3])) if nc else 0.0)
+            runs[name] = dict(z=np.array(zs), load=np.array(load), s=s)
+    finally:
+        O.reset_spec()
+    free, blind, caught = runs['no wall'], runs['no edges'], runs['edges']
+    assert blind['load'].max() == 0.0 and np.array_equal(blind['z'], free['z'])          # rounds 1 - 5: the wall is not there for this leg -- a free fall, bit for bit ...
+    assert blind['z'][-1] < top - 0.035                                                  # ... that ends with the wall's top edge above the shank: it went through it
+    assert caught['load'].max() > 0.1                                                    # with the edges the wall carries load (impulse per 2 ms substep: 0.19 N s = 95 N, most of the robot's weight) ...
+    assert caught['z'][-1] > top - 0.006 and caught['z'].min() > top - 0.008, (caught['z'][-1] - top, caught['z'].min() - top)   # ... and the shank stays on top of it (ERP band)
+    print('shank bottom against the wall top after 0.12 s: %.4f m with the edges, %.4f m without; peak normal impulse %.3f N s' % (caught['z'][-1] - top, blind['z'][-1] - top, caught['load'].max()))
+
+
 def test_bullet_audit_switches(golden, orc, model_blob, mocap_table):
     """The round-3 audit switches of the oracle (include/llenv_model.h LLM_SPEC_FRICTION_MODE / ROW_ORDER / MAX_COORD_VEL / LIMIT_ERP) are
     variants of the SAME constrained problem: a sliding robot obeys their friction bound (box for modes 0 / 1, cone for mode 2), a standing one
