@@ -65,7 +65,7 @@
 #define LLM_SELF_FRICTION 0.0           /* LLM_SPEC_SELF_FRICTION below: mu of a leg-leg contact's two tangential rows; 0 = frictionless (Bullet: 0.5 x 0.5 = 0.25) */
 #define LLM_PAIR_FRICTION 0.0           /* LLM_SPEC_PAIR_FRICTION below: the same for the robot-robot contacts of a chase-tag arena */
 #define LLM_MAX_PAIR 2                  /* LLM_SPEC_MAX_PAIR below: robot-robot rows per robot pair */
-#define LLM_LEG_EDGES 1                 /* LLM_SPEC_LEG_EDGES below */
+#define LLM_LEG_EDGES 0                 /* LLM_SPEC_LEG_EDGES below: 0 = a leg meets terrain with its own points only (vertices, rim points, mid-span spheres); 1 = the XROWS builds' edge rule */
 #define LLM_MAX_PAIR_CAP 4              /* ... at most (a persistent manifold holds four points) */
 #define LLM_MAX_COORD_VEL 100.0          /* btMultiBody::m_maxCoordinateVelocity (its constructor's value): every generalized velocity -- base twist, joint rates -- is clipped
                                            to +- this after the unconstrained update and after the solve (applyDeltaVeeMultiDof as recalled; a NaN or an infinity is NOT made a bound: it stays
@@ -141,8 +141,10 @@
                                            btMultiBodyJointLimitConstraint::createConstraintRows as recalled: with m_splitImpulse (btContactSolverInfo's default: true) and penetration
                                            below m_splitImpulsePenetrationThreshold the positional part goes to m_rhsPenetration -- which no multibody solver pass applies -- and
                                            m_rhs keeps the velocity part alone: the row stops the joint and does not push it back, i.e. ERP 0.  Oracle and engine */
-#define LLM_SPEC_LEG_EDGES 26           /* 1 (spec since round 6): the top edges of the terrain boxes (bottom edges of floating ones) are contact candidates against the flat faces of
-                                           the thigh and shank boxes too, as they are against the body box; 0: rounds 1 - 5, where mid-link spheres stood in.  Oracle and engine */
+#define LLM_SPEC_LEG_EDGES 26           /* 1: the top edges of the terrain boxes (bottom edges of floating ones) are contact candidates against the flat faces of the thigh and shank
+                                           boxes too, as they always are against the body box; the engine then runs its XROWS builds (cone friction only).  0 (default;
+                                           rounds 1 - 5): a leg meets terrain with its own points -- mid-link spheres stand in.  Built and priced in round 6: no policy tells
+                                           the two apart, the rule costs 5 - 22 % of a step, and it is ill-conditioned for a robot spawned INTO an arena element.  Oracle and engine */
 #define LLM_SPEC_COUNT 27
 
 #endif

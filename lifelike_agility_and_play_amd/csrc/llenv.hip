@@ -162,14 +162,17 @@ __device__ __forceinline__ void step_done_fold(const StepParams& P, int sl, bool
   if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(P.block_ticket + sl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   ticket = __builtin_amdgcn_readfirstlane(ticket);
   if (ticket != gridDim.x - 1) return;
-  if (multi && sl > 0)
+  if (multi && sl > 0) {
     while (__hip_atomic_load(P.ver_ready + (sl - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.launch_serial) __builtin_amdgcn_s_sleep(2);
+    LL_VER_FENCE(__ATOMIC_ACQUIRE);                    // the previous fold's version is read after its mark -- said in the memory model too (pmc_params.hpp LL_VER_FENCE)
+  }
   asm volatile("" ::: "memory");
   if (multi) table_fold_wave_out_of_line(P, sl, last_step);      // (P: a reference into the kernarg segment -- nothing is copied to the stack for the call)
   else table_fold_wave(P, sl, last_step);                        // the single-step kernels fold inline at their very end, as they always have
   if (threadIdx.x == 0) __hip_atomic_store(P.block_ticket + sl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (multi) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the version's (write-through, device-scope) stores are acknowledged before its mark goes out
+    LL_VER_FENCE(__ATOMIC_RELEASE);
     if (threadIdx.x == 0) {
       __hip_atomic_store(P.ver_ready + sl, P.launch_serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (last_step) __hip_atomic_store(P.resident, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -449,6 +452,11 @@ struct HipBackend {
     // ends later by the full residency of that kernel (measured with an RCCL stand-in: profiles/r03_simd_sharing.txt).
     const char* sh = getenv("LL_SHARE_SIMDS");
     if (sh && sh[0] == '1') simds = 0;
+    // LL_DETERMINISTIC=1: multi-step calls run as single launches.  A multi-step launch equals k single launches bit for bit only while every one of its waves is on the chip
+    // (ll_get_table_sync == 0); on a device it shares with other kernels -- a collective, other ranks -- a re-seed may have to take the newest table version there is, and which clip it
+    // draws then hangs on timing.  Single launches never do.
+    const char* det = getenv("LL_DETERMINISTIC");
+    deterministic = det && det[0] == '1';
     // LL_SPLIT_RAYS (EPMC / SEPMC): 0 = the step kernel casts the 778 rays of a row itself (rounds 1 - 5); 1 = single-step launches leave them to epmc_percept_kernel behind the step
     // kernel; 2 = multi-step calls too run as single steps, each followed by the ray kernel.  Defaults by the A/B on one box (profiles/r06_split_rays_ab.txt): EPMC 2 (hurdles: single steps
     // 0.2983 -> 0.2905 ms, 32-step calls 0.2894 -> 0.2898; cube stairs 0.3163 -> 0.2937), SEPMC 1 (single steps 0.3341 -> 0.3308; 32-step calls would lose 4 %: 0.3153 -> 0.3286)
@@ -467,8 +475,10 @@ struct HipBackend {
   int split_rays_epmc = 2, split_rays_sepmc = 1;
   // can every workgroup of a step launch be on the chip at once?  (one 512-register wave per SIMD while the grid fits, two 256-register waves otherwise:
   // launch_step.)  A multi-step launch needs it -- its waves wait for each other's finished episodes (PmcEngine::step)
+  bool deterministic = false;
   bool co_resident(const StepParams& P) const {
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
+    if (deterministic) return false;
     return blocks <= simds || blocks <= 2 * simds_hw;
   }
   void set_stream(void* s) { stream = s ? (hipStream_t)s : own; }
@@ -525,8 +535,8 @@ struct HipBackend {
     EpmcParams E = E_in;
     E.split_rays = split ? 1 : 0;
 #define LL_GO(KERNEL, PARAMS) hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, PARAMS, E)
-    if (pmc_wants_xrows(P)) {                            // the extended contact rows (round 6): the cone builds with XROWS, every step a launch of its own
-      if (!cone) throw PmcError(LL_EINVAL, "self_friction needs friction_mode 2 (the extended contact rows exist in the cone builds)");
+    if (pmc_wants_xrows_terrain(P)) {                    // the extended contact rows (round 6): the cone builds with XROWS, every step a launch of its own
+      if (!cone) throw PmcError(LL_EINVAL, "self_friction / leg_edges need friction_mode 2 (the extended contact rows exist in the cone builds)");
       StepParams Q = P;
       Q.n_steps = 1;
       for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) {
@@ -567,8 +577,8 @@ struct HipBackend {
     SepmcParams S = S_in;
     S.e.split_rays = split ? 1 : 0;
 #define LL_GO(KERNEL, PARAMS) hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, PARAMS, S)
-    if (pmc_wants_xrows(P)) {                            // the extended contact rows (round 6): see launch_epmc_step
-      if (!cone) throw PmcError(LL_EINVAL, "self_friction / pair_friction / max_pair need friction_mode 2 (the extended contact rows exist in the cone builds)");
+    if (pmc_wants_xrows_terrain(P)) {                    // the extended contact rows (round 6): see launch_epmc_step
+      if (!cone) throw PmcError(LL_EINVAL, "self_friction / pair_friction / max_pair / leg_edges need friction_mode 2 (the extended contact rows exist in the cone builds)");
       StepParams Q = P;
       Q.n_steps = 1;
       for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) {

@@ -69,6 +69,18 @@ enum BaseConst {
 #define PMC_TS_SLOTS 0
 #define PMC_TS(k) do { } while (0)
 #endif
+// The table versions of a multi-step launch (ver_ready, cdf_ver: llenv.hip step_done_fold, pmc_step.hpp table_for_reseed) travel by relaxed device-scope atomics, ordered by the
+// s_waitcnt / issue order of gfx950.  LL_VER_FENCE says the same in the memory model: a release fence ahead of a version's mark, an acquire fence behind the load that saw it
+// (agent scope; only the one folding wave per step and the re-seeding waves meet them).  -DLL_VER_FENCES=0 is the A/B leg without them.
+#ifndef LL_VER_FENCES
+#define LL_VER_FENCES 1
+#endif
+#if LL_VER_FENCES && defined(__HIP_DEVICE_COMPILE__)
+#define LL_VER_FENCE(order) __builtin_amdgcn_fence(order, "agent")
+#else
+#define LL_VER_FENCE(order) do { } while (0)
+#endif
+
 // Static phase marks (tools/issue_ledger.py compiles an assembly LISTING with -DPMC_MARKS; no library is ever built with it): a comment in the instruction stream where a
 // phase of the step begins, fenced by a scheduling barrier so that the instructions of a phase stay between its marks.  The ledger attributes the static instructions of the
 // listing to phases with them (profiles/r06_issue_ledger.md); the shipped build has no marks and schedules across these points, so the marked listing is a close cousin, not the same code.
@@ -179,3 +191,5 @@ struct StepParams {
 
 // the launch needs the build with the extended contact rows (Pmc::substep_impl<.., XROWS = true>): one of the round-6 switches is off its default
 LL_HD bool pmc_wants_xrows(const StepParams& P) { return P.self_friction > 0.0f || P.pair_friction > 0.0f || P.max_pair != LLM_MAX_PAIR; }
+// ... and in the terrain envs (EPMC, SEPMC) the same builds carry the terrain edges across leg boxes (LLM_SPEC_LEG_EDGES)
+LL_HD bool pmc_wants_xrows_terrain(const StepParams& P) { return pmc_wants_xrows(P) || P.leg_edges != 0; }

@@ -1279,7 +1279,7 @@ struct Pmc {
       }
     }
     // candidates per sub-lane: the eighth (mid-link sphere) and the ninth (a terrain edge under the trunk, reverse_edge) only with terrain
-    constexpr int NT = TERRAIN ? 8 : 7, NC = TERRAIN ? 10 : 7;   // (terrain builds: jj = 7 mid-link sphere, 8 a terrain edge under the trunk, 9 a terrain edge across a leg box)
+    constexpr int NT = TERRAIN ? 8 : 7, NC = TERRAIN ? (XROWS ? 10 : 9) : 7;   // (terrain builds: jj = 7 mid-link sphere, 8 a terrain edge under the trunk; their XROWS builds: 9 a terrain edge across a leg box)
     constexpr float STRIDE = TERRAIN ? 16.0f : 8.0f;          // candidate index = STRIDE * sub + jj: the (sub, jj) order of the oracle's enumeration
     F depth[NC];
     const bool want_touch = TERRAIN && ex && ex->want_touch;
@@ -1328,13 +1328,13 @@ struct Pmc {
     }
     if constexpr (TERRAIN) {
       depth[8] = far_;
-      depth[9] = far_;
+      if constexpr (XROWS) depth[9] = far_;
       if (terr) {                                             // sub-lanes 0, 1: the two ends of the leg's terrain edge under the body box
         F rd;
         V3l rP, rn;
         reverse_edge(ln, P, ex, bs, R, L::i2f(ln.sub()), rd, rP, rn);
         depth[8] = lm::sel(lm::and_(sub_lt2, rd < P.margin_dist), rd, far_);
-        if (P.leg_edges) {                                    // every sub-lane: terrain edge `sub` of the listed boxes across the leg's thigh and shank boxes (round 6)
+        if constexpr (XROWS) if (P.leg_edges) {               // every sub-lane: terrain edge `sub` of the listed boxes across the leg's thigh and shank boxes (round 6)
           F ld, ll, lsh;
           V3l lP, lnw;
           leg_edge(ln, P, ex, bs, R, k, legc, L::i2f(ln.sub()), ld, lP, lnw, ll, lsh);
@@ -1450,7 +1450,7 @@ struct Pmc {
     if (any_contact) {
       // geometry of this lane's contact: candidate (my_sub, my_jj) of the leg, re-evaluated from the table
       // (a reverse candidate, jj = 8, has no table entry: it reads entry 7's and replaces what it needs below)
-      const B isrevl = TERRAIN ? lm::and_(cvalid, my_jj > 8.5f) : (zero > one);                     // a terrain edge across a leg box (leg_edge)
+      const B isrevl = (TERRAIN && XROWS) ? lm::and_(cvalid, my_jj > 8.5f) : (zero > one);                     // a terrain edge across a leg box (leg_edge)
       const B isrev = TERRAIN ? lm::and_(lm::and_(cvalid, my_jj > 7.5f), lm::not_(isrevl)) : (zero > one);   // a terrain edge under the trunk (reverse_edge)
       // (a slot without a candidate decodes the 'none' code to indices outside the table: clamped, its row is dead anyway)
       I wsub = L::f2i(lm::min_(my_sub, ln.lane_f(3.0f))), wbase = L::f2i(lm::min_(my_jj, ln.lane_f(7.0f))) * CF_WORDS;
@@ -1515,7 +1515,7 @@ struct Pmc {
             scale_mu = lm::sel(isrev, ln.lane_f(ex->box_mu_scale), scale_mu);
             rs = lm::sel(isrev, zero, rs);
           }
-          if (L::any(isrevl)) {                                 // ... or the terrain edge's point and the LEG box face's normal; the row acts on that box's link
+          if constexpr (XROWS) if (L::any(isrevl)) {            // ... or the terrain edge's point and the LEG box face's normal; the row acts on that box's link
             F rd, rl, rsh;
             V3l rP, rn;
             leg_edge(ln, P, ex, bs, R, k, legc, my_sub, rd, rP, rn, rl, rsh);
@@ -2504,7 +2504,8 @@ struct Pmc {
       while (j >= 0 && __hip_atomic_load(P.ver_ready + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != serial) j--;
       if (j != sl - 1) count_add(ln, P.counters + 3);
     }
-    asm volatile("" ::: "memory");                 // the version is read after its mark (device-scope loads, issued in order)
+    LL_VER_FENCE(__ATOMIC_ACQUIRE);
+    asm volatile("" ::: "memory");                 // the version is read after its mark (device-scope loads, issued in order; and an acquire fence at agent scope: LL_VER_FENCE)
     return j < 0 ? P.cdf : P.cdf_ver + (long)(j + 1) * P.n_clips;
 #else
     (void)ln;

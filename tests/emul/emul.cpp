@@ -123,7 +123,7 @@ struct HostBackend {
         for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)env * 12 + j, 3);
         const bool park = getenv("LL_EMUL_PARK") != nullptr, cone = P.friction_mode == 2;      // park: the larger-batch GPU build's variant (tests)
         if (park) { if (cone) { HostLanesLds lq(P.candc); Epmc<HostLanesLds>::step_env<true, true>(lq, P, E, env, act); } else Epmc<HostLanes>::step_env<true>(ln, P, E, env, act); }
-        else if (cone && pmc_wants_xrows(P)) Epmc<HostLanes>::step_env<false, true, true>(ln, P, E, env, act);
+        else if (cone && pmc_wants_xrows_terrain(P)) Epmc<HostLanes>::step_env<false, true, true>(ln, P, E, env, act);
         else      { if (cone) Epmc<HostLanes>::step_env<false, true>(ln, P, E, env, act); else Epmc<HostLanes>::step_env(ln, P, E, env, act); }
         if (E.split_rays) Epmc<HostLanes>::percept_row_host(P, E, env);
       }
@@ -166,7 +166,7 @@ struct HostBackend {
           fN act[3];
           for (int j = 0; j < 3; j++) act[j] = ln.ldl(P.actions, (long)row * 12 + j, 3);
           if (park) Sepmc<HostLanes>::step_env<true>(ln, P, S, row, act);
-          else if (cone && pmc_wants_xrows(P)) Sepmc<HostLanes>::step_env<false, true, true>(ln, P, S, row, act);
+          else if (cone && pmc_wants_xrows_terrain(P)) Sepmc<HostLanes>::step_env<false, true, true>(ln, P, S, row, act);
           else if (cone) Sepmc<HostLanes>::step_env<false, true>(ln, P, S, row, act);
           else Sepmc<HostLanes>::step_env(ln, P, S, row, act);
         });

@@ -692,10 +692,15 @@ def check_trunk_on_edges_against_oracle(lib_path, n_envs=16, seed=5, cap_ill=Non
 
 
 def check_legs_on_edges_against_oracle(lib_path, n_envs=16, seed=7, total_envs=None, cap_ill=None, cap_tie=None):
-    """DESIGN 8, round 6 "edges across the leg boxes" (LLM_SPEC_LEG_EDGES; BSE:310-364: a shank laid across a hurdle): robots lowered onto hurdles with their shanks level, one
-    shank's flat bottom within the margin of -- or a little into -- a hurdle's top edge somewhere between that shank's own candidate points; one control step of real physics, engine
-    vs oracle, standing bars -- and against the oracle with the leg edges switched off, to show that the cases are what they claim to be.
+    """DESIGN 8, round 6 "edges across the leg boxes" (LLM_SPEC_LEG_EDGES = 1 on both sides: the engine runs its XROWS build; BSE:310-364: a shank laid across a hurdle): robots lowered
+    onto hurdles with their shanks level, one shank's flat bottom within the margin of -- or a little into -- a hurdle's top edge somewhere between that shank's own candidate points; one
+    control step of real physics, engine vs oracle, standing bars -- and against the oracle with the leg edges switched off, to show that the cases are what they claim to be.
     total_envs: as check_terrain_physics_against_oracle (the larger-batch build, cases spread over its grid)."""
+    with spec_variant(leg_edges=1):
+        return _check_legs_on_edges_against_oracle(lib_path, n_envs, seed, total_envs, cap_ill, cap_tie)
+
+
+def _check_legs_on_edges_against_oracle(lib_path, n_envs, seed, total_envs, cap_ill, cap_tie):
     from conftest import make_oracle_batch
     from oracle import oracle as orc
     from lifelike_agility_and_play_amd import mocap

@@ -210,6 +210,27 @@ def test_multi_step_launch(model_blob, mocap_table):
     pc.check_multi_step_launch(model_blob, mocap_table, None, read_ring, sizes=(70, 4200), k=7, n_launches=3, spec=dict(friction_mode=0))   # the pyramid builds
 
 
+def test_deterministic_mode_runs_multi_step_calls_as_single_launches(model_blob, mocap_table, monkeypatch):
+    """LL_DETERMINISTIC=1 (read when an engine is created): ll_step_random_n(k) is k single launches -- for a device that is shared with other kernels, where a multi-step
+    launch may have to re-seed from the newest table version there is (counted by ll_get_table_sync) and its result hangs on timing"""
+    import math
+    from lifelike_agility_and_play_amd import capi
+    RW = {'joint_pos': 0.3, 'joint_vel': 0.05, 'end_effector': 0.1, 'root_pose': 0.5, 'root_vel': 0.05}
+    PT = ['joint_pos', 'joint_vel', 'root_ang_vel_loc', 'root_lin_vel_loc', 'e_g']
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('LL_DETERMINISTIC', mode)
+        cfg = capi.make_config(256, control_freq=50.0, sim_freq=500.0, kd=0.5, reward_weights=RW, prop_type=PT, prioritized_sample_factor=3.0, auto_reset=1, seed=3)
+        E = capi.Engine(cfg, model_blob, mocap_table)
+        E.reset(); E.enable_kernel_timing(True)
+        E.step_random_n(math.exp(-2), 8); E.sync()
+        _, launches, steps = E.kernel_time_stats()
+        out[mode] = (launches, steps, E.state().copy(), E.table_sync())
+        E.close()
+    assert out['0'][:2] == (1, 8) and out['1'][:2] == (8, 8), (out['0'][:2], out['1'][:2])
+    np.testing.assert_array_equal(out['0'][2], out['1'][2])
+
+
 def test_contact_rich_parity(golden, orc, model_blob, mocap_table):
     out = pc.check_contact_rich_parity(golden, orc, model_blob, mocap_table, None)
     print('contact-rich: config err', np.percentile(out['config'], [50, 100]), 'vel', np.percentile(out['vel'], [50, 100]))
