@@ -132,7 +132,8 @@ def committed_counters(kernel, units, spl=1):
                  'valu_per_wave_per_control_step': c['SQ_INSTS_VALU'] / c['SQ_WAVES'] / k,
                  'control_steps_per_launch': k, 'frac': n_inst / c['SQ_WAVE_CYCLES'],
                  'source': t['counters_file'] + ' (rocprofv3 --pmc SQ_INSTS_*, SQ_WAVE_CYCLES in quad-cycles)'}
-        return t['traffic_bytes'], issue, 'profiles/traffic.json <- %s (bytes per launch, FETCH_SIZE + WRITE_SIZE, uncorrected; see DESIGN.md 5.1)' % t['counters_file']
+        traffic = t['traffic_bytes'] + (t.get('percept_traffic_bytes') or 0.0)          # (the ray kernel behind a step kernel whose rays were split off: one launch pair = one control step)
+        return traffic, issue, 'profiles/traffic.json <- %s (bytes per launch, FETCH_SIZE + WRITE_SIZE, uncorrected; see DESIGN.md 5.1)' % t['counters_file']
     except Exception:                    # noqa: BLE001
         return None, None, None
 
@@ -629,7 +630,12 @@ def main_epmc(args):
         elapsed = float(tt.item())
     if rank == 0:
         achieved = n * EPMC_ALGO_BYTES_PER_ENV_STEP / (k_ms * 1e-3) / 1e9
-        traffic, issue, tsrc = committed_counters('epmc_step_kernel', n, spl)
+        # how the engine ran a call of spl control steps (llenv.hip launch_epmc_step): ONE multi-step launch only with the rays fused and the grid at one wave per SIMD; otherwise
+        # spl single-step launches, each followed by epmc_percept_kernel when the rays are split off (LL_SPLIT_RAYS, default 2 for this env) -- the engine's HIP events bracket the call
+        ray_mode = int(os.environ.get('LL_SPLIT_RAYS', '2'))
+        kspl = spl if (spl > 1 and ray_mode < 2 and n <= 4096) else 1
+        split = ray_mode >= (1 if spl == 1 else 2)
+        traffic, issue, tsrc = committed_counters('epmc_step_kernel', n, kspl)
         extra = {'cpu_baseline': cpu_baseline_env('epmc', epmc_env_config(args.element))} if (world == 1 and not args.no_cpu_baseline) else {}
         print(json.dumps({**extra, 'build': build_record(), **{
             'metric': 'env-steps/sec (whole node), EPMC PlayGround env, random policy', 'value': world * n * args.steps / elapsed, 'unit': 'env-steps/s',
@@ -639,9 +645,13 @@ def main_epmc(args):
                                    'random-policy actions N(0, e^-2), auto-reset' % (n, args.element), 'envs_per_gpu': n, 'steps_per_launch': spl, 'episodes_finished_rank0': eng.counters()['episodes']},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'traffic_source': tsrc, 'traffic_note': 'counter traffic of a multi-step launch UNDER-counts HBM bytes: the rows a wave writes in one step of the launch and overwrites in the next (observation, state, bookkeeping) meet in its L2 / the Infinity Cache and need not reach HBM, so FETCH_SIZE + WRITE_SIZE can come out below the algorithmic bytes (0.8 - 0.9 x); single launches per step measure 1.1 - 1.5 x', 'single_wave_issue': issue,
-                         'kernel': 'epmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n, 'kernel_avg_launch_ms': k_launch_ms,
+                         'kernel': 'epmc_step_kernel' + (' + epmc_percept_kernel (the 778 rays per env, behind every step kernel)' if split else ''),
+                         'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n if kspl > 1 else k_steps, 'kernel_avg_launch_ms': k_launch_ms if kspl > 1 else k_ms,
+                         'control_steps_per_launch': kspl, 'control_steps_per_call': spl,
+                         'launch_note': ('one multi-step launch per call' if kspl > 1 else 'a call of %d control steps runs as %d single-step launches%s; HIP events bracket the call, so the per-launch '
+                                         'figure is the call\'s time / its steps (launch gaps included)' % (spl, spl, ', each followed by the ray kernel' if split else '')),
                          'algorithmic_bytes_per_env_step': EPMC_ALGO_BYTES_PER_ENV_STEP,
-                         'algorithmic_bytes_per_launch': n * EPMC_ALGO_BYTES_PER_ENV_STEP * (k_launch_ms / k_ms if k_ms > 0 else spl),       # x the control steps a timed launch ran
+                         'algorithmic_bytes_per_launch': n * EPMC_ALGO_BYTES_PER_ENV_STEP * kspl,
                          'note': 'bound by single-wave instruction issue, not HBM; see DESIGN.md 8'}}}), flush=True)
     eng.close()
     if world > 1:
@@ -713,7 +723,10 @@ def main_sepmc(args):
         elapsed = float(tt.item())
     if rank == 0:
         achieved = 2 * n_arenas * SEPMC_ALGO_BYTES_PER_ROBOT_STEP / (k_ms * 1e-3) / 1e9
-        traffic, issue, tsrc = committed_counters('sepmc_step_kernel', 2 * n_arenas, spl)
+        ray_mode = int(os.environ.get('LL_SPLIT_RAYS', '1'))          # (see main_epmc; this env's default leaves multi-step calls fused)
+        kspl = spl if (spl > 1 and ray_mode < 2 and 2 * n_arenas <= 4096) else 1
+        split = ray_mode >= (1 if spl == 1 else 2)
+        traffic, issue, tsrc = committed_counters('sepmc_step_kernel', 2 * n_arenas, kspl)
         extra = {'cpu_baseline': cpu_baseline_env('sepmc', sepmc_env_config())} if (world == 1 and not args.no_cpu_baseline) else {}
         print(json.dumps({**extra, 'build': build_record(), **{
             'metric': 'robot-steps/sec (whole node), SEPMC chase-tag env, random policy', 'value': world * 2 * n_arenas * args.steps / elapsed, 'unit': 'robot-steps/s',
@@ -724,9 +737,11 @@ def main_sepmc(args):
                        'arenas_per_gpu': n_arenas, 'steps_per_launch': spl, 'episodes_finished_rank0': eng.counters()['episodes']},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'traffic_source': tsrc, 'traffic_note': 'counter traffic of a multi-step launch UNDER-counts HBM bytes: the rows a wave writes in one step of the launch and overwrites in the next (observation, state, bookkeeping) meet in its L2 / the Infinity Cache and need not reach HBM, so FETCH_SIZE + WRITE_SIZE can come out below the algorithmic bytes (0.8 - 0.9 x); single launches per step measure 1.1 - 1.5 x', 'single_wave_issue': issue,
-                         'kernel': 'sepmc_step_kernel', 'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n, 'kernel_avg_launch_ms': k_launch_ms,
+                         'kernel': 'sepmc_step_kernel' + (' + epmc_percept_kernel (the 778 rays per robot, behind every step kernel)' if split else ''),
+                         'kernel_avg_ms': k_ms, 'kernel_launches_timed': k_n if kspl > 1 else k_steps, 'kernel_avg_launch_ms': k_launch_ms if kspl > 1 else k_ms,
+                         'control_steps_per_launch': kspl, 'control_steps_per_call': spl,
                          'algorithmic_bytes_per_robot_step': SEPMC_ALGO_BYTES_PER_ROBOT_STEP,
-                         'algorithmic_bytes_per_launch': 2 * n_arenas * SEPMC_ALGO_BYTES_PER_ROBOT_STEP * (k_launch_ms / k_ms if k_ms > 0 else spl),
+                         'algorithmic_bytes_per_launch': 2 * n_arenas * SEPMC_ALGO_BYTES_PER_ROBOT_STEP * kspl,
                          'note': 'bound by single-wave instruction issue, not HBM; see DESIGN.md 8b'}}}), flush=True)
     eng.close()
     if world > 1:

@@ -144,7 +144,7 @@
 #define LLM_SPEC_LEG_EDGES 26           /* 1: the top edges of the terrain boxes (bottom edges of floating ones) are contact candidates against the flat faces of the thigh and shank
                                            boxes too, as they always are against the body box; the engine then runs its XROWS builds (cone friction only).  0 (default;
                                            rounds 1 - 5): a leg meets terrain with its own points -- mid-link spheres stand in.  Built and priced in round 6: no policy tells
-                                           the two apart, the rule costs 5 - 22 % of a step, and it is ill-conditioned for a robot spawned INTO an arena element.  Oracle and engine */
+                                           the two apart, the rule costs 8 - 33 % of a step, and it is ill-conditioned for a robot spawned INTO an arena element.  Oracle and engine */
 #define LLM_SPEC_COUNT 27
 
 #endif

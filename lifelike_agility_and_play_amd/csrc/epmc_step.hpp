@@ -21,6 +21,10 @@
 #define EPMC_BOX_WORDS 8
 #define EPMC_MAX_NEAR 8       // boxes within reach of the robot's contact candidates during one control step
 #define EPMC_EP_STRIDE 40
+// -DLL_NO_FUSED_RAYS=1: an A/B build whose step kernels carry no ray code at all (they always leave the ray pose; run it with LL_SPLIT_RAYS=2) -- what the dead code costs the split path
+#ifndef LL_NO_FUSED_RAYS
+#define LL_NO_FUSED_RAYS 0
+#endif
 #define EPMC_RAY_POSE 24        // floats per row in EpmcParams::ray_pose: pos 3 | R 9 | yaw | noise_z | n_boxes | 1 if the last box is overridden | that box record 8
 #define EPMC_LIST_A 320         // row-scratch words: behind the staged box records the three ray lists (height grid, fan, front rays), then 64 spare words.
 #define EPMC_LIST_A_MAX 10      // (PMC_ROW_SCRATCH = 688 words per row is what eight workgroups per CU can afford: 9392 B of tables + 4 x 2752 B <= 160 KB / 8)
@@ -639,7 +643,7 @@ struct Epmc {
     if (E.noise_on[2]) yaw += ep[EP_NOISE + 2];                                  // PGE:392-393
     const long a0 = 3L * P.prop_dim + 36;
     const int n_boxes = (int)ep[EP_N_BOXES];
-    if (E.split_rays && !E.scr_ray_hit) {
+    if (LL_NO_FUSED_RAYS || (E.split_rays && !E.scr_ray_hit)) {
       leave_ray_pose(ln, E, env, pos, R, yaw, ep + EP_NOISE, n_boxes);            // the rays of this observation are cast by the kernel behind this one
     } else {
       const float* boxes = ln.stage_row(E.boxes + (long)env * EPMC_MAX_BOXES * EPMC_BOX_WORDS, n_boxes * EPMC_BOX_WORDS);   // LDS on the GPU

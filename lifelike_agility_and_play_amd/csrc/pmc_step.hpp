@@ -776,6 +776,10 @@ struct Pmc {
       q = mk3<float>(-n.z * p.y, n.z * p.x, a * kk);
     }
   }
+  // the bias of a leg-leg / robot-robot NORMAL row at depth d (a separated point within the margin may close its gap; a penetrating one is pushed out at the ERP of its depth)
+  static LL_HD float row_bias(const StepParams& P, float d, float inv_dt) {
+    return (d > 0.0f) ? d * inv_dt : fmaxf(d * ((d > P.erp_deep_below ? P.erp : P.erp_deep) * inv_dt), -P.max_depen);
+  }
   // one row of a leg-leg contact along direction ub (F0): the two points move with the base alike, so the row has joint parts only (sgn: + own leg, - other leg, 0 elsewhere;
   // e1 .. e3: the lever arms of the lane's joints about the contact point)
   static LL_HD void self_row_build(const L& ln, SelfRow& rw, const V3l& ub, const F& sgn, const V3l& e1, const V3l& e2, const V3l& e3, const LegFactor& lf,
@@ -803,7 +807,7 @@ struct Pmc {
   // part [pb_ x ub_; ub_] and the joints of the leg that holds my capsule (`mine`) -- whitened; free velocity and diagonal are summed with the other robot's half in a fixed
   // order (robot 0's first), so both rows of the arena hold the same c and inv
   static LL_HD void pair_row_build(const L& ln, SelfRow& rw, const V3<float>& ub_, const V3<float>& pb_, const B& mine, const V3l& e1, const V3l& e2, const V3l& e3,
-                                   const LegFactor& lf, const float* Sb, const float* Sd, const float* xi, const F* qs, float bias, bool have, int me) {
+                                   const LegFactor& lf, const float* Sb, const float* Sd, const float* xi, const F* qs, const StepParams& P, float dsel, float inv_dt, bool normal, bool have, int me) {
     const F zero = ln.lane_f(0.0f);
     const V3l ub = cvt3<F>(ub_);
     F sjt[3];
@@ -821,7 +825,7 @@ struct Pmc {
     for (int i = 0; i < 6; i++) nn += sgt[i] * sgt[i];
     self_row_pack(ln, sjt, sgt, rw);
     const float vo = ln.peer_u(vrow), no = ln.peer_u(nn);
-    rw.c = ((me == 0) ? vrow + vo : vo + vrow) + bias;
+    rw.c = ((me == 0) ? vrow + vo : vo + vrow) + (normal ? row_bias(P, dsel, inv_dt) : 0.0f);      // (the bias is formed HERE: handed in as a finished value it cost the larger-batch chase-tag build 26 spilt registers and 12 % of its time, profiles/r06_row_bias_ab.txt)
     rw.inv = have ? 1.0f / ((me == 0) ? nn + no : no + nn) : 0.0f;
     rw.lam = 0.0f;
     if (!have) self_row_clear(ln, rw);
@@ -1678,8 +1682,7 @@ struct Pmc {
           F on3 = lm::sel(link > 2.5f, one, zero);
           V3l a1v = mk3<F>(one, zero, zero);
           V3l e1 = cross(a1v, Pb - k.p1), e2 = cross(k.a2, Pb - k.p2), e3 = scale(cross(k.a2, Pb - k.p3), on3);
-          self_row_build(ln, sr[slot], nb, sgn, e1, e2, e3, lf, Sb, Sd, qs,
-                         (dsel > 0.0f) ? dsel * inv_dt : fmaxf(dsel * ((dsel > P.erp_deep_below ? P.erp : P.erp_deep) * inv_dt), -P.max_depen), have);
+          self_row_build(ln, sr[slot], nb, sgn, e1, e2, e3, lf, Sb, Sd, qs, row_bias(P, dsel, inv_dt), have);
           if (self_fric) {
             // LLM_SPEC_SELF_FRICTION (round 6, the engine twin of the oracle's switch): two tangential rows along btPlaneSpace1 of the WORLD normal, behind the normal row
             V3<float> nw = mul(R, mk3<float>(u6[3], u6[4], u6[5])), t1w, t2w;
@@ -1855,15 +1858,14 @@ struct Pmc {
             V3l a1v = mk3<F>(one, zero, zero);
             V3l e1 = cross(a1v, Pb - k.p1), e2 = cross(k.a2, Pb - k.p2), e3 = scale(cross(k.a2, Pb - k.p3), on3);
             if (scan == 0) taken[s2] = have ? imin : -1.0f;
-            const float nbias = (dsel > 0.0f) ? dsel * inv_dt : fmaxf(dsel * ((dsel > P.erp_deep_below ? P.erp : P.erp_deep) * inv_dt), -P.max_depen);
-            pair_row_build(ln, pr[slot], nb_, pb_, mine, e1, e2, e3, lf, Sb, Sd, xi, qs, nbias, have, me);
+            pair_row_build(ln, pr[slot], nb_, pb_, mine, e1, e2, e3, lf, Sb, Sd, xi, qs, P, dsel, inv_dt, true, have, me);
             if (pair_fric) {
               // LLM_SPEC_PAIR_FRICTION (round 6, the engine twin of the oracle's switch): two tangential rows along btPlaneSpace1 of the contact's WORLD normal (robot 1 -> robot 0,
               // the same bits in both rows of the arena), each solved right behind its normal row inside +- mu x that row's multiplier
               V3<float> t1w, t2w;
               plane_space(mk3<float>(u6[3], u6[4], u6[5]), t1w, t2w);
-              pair_row_build(ln, pf[slot][0], mulT(R, scale(t1w, sg)), pb_, mine, e1, e2, e3, lf, Sb, Sd, xi, qs, 0.0f, have, me);
-              pair_row_build(ln, pf[slot][1], mulT(R, scale(t2w, sg)), pb_, mine, e1, e2, e3, lf, Sb, Sd, xi, qs, 0.0f, have, me);
+              pair_row_build(ln, pf[slot][0], mulT(R, scale(t1w, sg)), pb_, mine, e1, e2, e3, lf, Sb, Sd, xi, qs, P, 0.0f, inv_dt, false, have, me);
+              pair_row_build(ln, pf[slot][1], mulT(R, scale(t2w, sg)), pb_, mine, e1, e2, e3, lf, Sb, Sd, xi, qs, P, 0.0f, inv_dt, false, have, me);
             }
           }
         }

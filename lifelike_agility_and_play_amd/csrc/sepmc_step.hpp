@@ -248,7 +248,7 @@ struct Sepmc {
     const long a0 = 3L * P.prop_dim + 36;
     const int nb = (int)sp[SP_N_BOXES] + 1;                                                          // the arena and the flag
     const float* boxes = ln.stage_row(E.boxes + (long)row * EPMC_MAX_BOXES * EPMC_BOX_WORDS, nb * EPMC_BOX_WORDS);
-    if (E.split_rays && !E.scr_ray_hit) EP::leave_ray_pose(ln, E, row, pos, R, yaw, sp + SP_NOISE, nb, boxes + (nb - 1) * EPMC_BOX_WORDS);  // (round 6: the 778 rays by the kernel behind this one, epmc_step.hpp percept_rays; the flag's box as it stands NOW)
+    if (LL_NO_FUSED_RAYS || (E.split_rays && !E.scr_ray_hit)) EP::leave_ray_pose(ln, E, row, pos, R, yaw, sp + SP_NOISE, nb, boxes + (nb - 1) * EPMC_BOX_WORDS);  // (round 6: the 778 rays by the kernel behind this one, epmc_step.hpp percept_rays; the flag's box as it stands NOW)
     else EP::observe_rays(ln, P, E, row, pos, R, yaw, sp + SP_NOISE, boxes, nb, orow + a0);           // CTG:515-531
     // --- visibility (CTG:472-493): lane (leg g, sub s) owns one segment: my head -> the other's foot g / wheel g / handle (g = 0, 2),
     //     and lane (0, 3) the segment between the two (biased) base positions

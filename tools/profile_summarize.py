@@ -59,7 +59,7 @@ def is_multi(name):
 
 
 for KERNEL, prefix, benchlog in (('pmc_step_kernel', '', 'bench.log'), ('epmc_step_kernel', 'epmc_', 'epmc_bench.log'), ('sepmc_step_kernel', 'sepmc_', 'sepmc_bench.log')):
-    counters, meta = {}, {}
+    counters, meta, percept = {}, {}, {}
     if not glob.glob(os.path.join(src, prefix + 'pmc_sq/**/*counter_collection.csv'), recursive=True):
         continue
     for sub in ('pmc_sq', 'pmc_fetch', 'pmc_write'):
@@ -77,6 +77,13 @@ for KERNEL, prefix, benchlog in (('pmc_step_kernel', '', 'bench.log'), ('epmc_st
                                           'LDS_Block_Size': row['LDS_Block_Size'], 'Scratch_Size': row['Scratch_Size']}}
         for k in acc:
             counters[k] = acc[k] / n[k]
+        # round 6: with the rays split off (LL_SPLIT_RAYS) every step kernel is followed by epmc_percept_kernel -- its counters ride along
+        pacc, pn = {}, {}
+        for row in csv.DictReader(open(one(prefix + sub + '/**/*counter_collection.csv'))):
+            if 'epmc_percept_kernel' in row['Kernel_Name'] and prefix:
+                pacc[row['Counter_Name']] = pacc.get(row['Counter_Name'], 0.0) + float(row['Counter_Value']); pn[row['Counter_Name']] = pn.get(row['Counter_Name'], 0) + 1
+        for k in pacc:
+            percept[k] = pacc[k] / pn[k]
     bench = json.loads([l for l in open(os.path.join(src, benchlog)) if l.startswith('{')][-1])
     targs = [a.strip() for a in re.search(r'_step_kernel<([^>]*)>', meta['kernel_name']).group(1).split(',')]      # the profiled instantiation, as rocprofv3 names it ...
     mangled = 'ILi%sE' % targs[0] + ''.join('Lb%dE' % (a == 'true') for a in targs[1:]) + 'E'                        # ... and as the assembly does
@@ -86,7 +93,9 @@ for KERNEL, prefix, benchlog in (('pmc_step_kernel', '', 'bench.log'), ('epmc_st
     rl = bench['roofline']
     algo_unit = rl.get('algorithmic_bytes_per_env_step', rl.get('algorithmic_bytes_per_robot_step'))
     units = int(meta['grid']) // 64 * 4
-    spl = int(bench['config'].get('steps_per_launch', 1))          # control steps one launch runs (ll_step_random_n)
+    spl = int(bench['config'].get('steps_per_launch', 1))          # control steps one CALL runs (ll_step_random_n) ...
+    if not is_multi(meta['kernel_name']):
+        spl = 1                                                    # ... which the engine ran as single-step launches (larger batches; EPMC since round 6: the rays by a kernel of their own behind every step)
     counters['_kernel'] = meta
     counters['_build'] = bench.get('build')            # hipcc's version and the sha256 of the code object the profiled command ran (bench.py build_record)
     counters['_notes'] = {
@@ -103,8 +112,13 @@ for KERNEL, prefix, benchlog in (('pmc_step_kernel', '', 'bench.log'), ('epmc_st
         'instructions_per_wave_per_control_step': (counters['SQ_INSTS_VALU'] + counters['SQ_INSTS_SALU'] + counters['SQ_INSTS_LDS']) / counters['SQ_WAVES'] / spl,
         'issue_slots_per_wave_per_control_step': counters['SQ_WAVE_CYCLES'] / counters['SQ_WAVES'] / spl,
     }
+    if percept:
+        ptraffic = (percept.get('FETCH_SIZE', 0.0) + percept.get('WRITE_SIZE', 0.0)) * 1024.0
+        counters['_percept_kernel'] = dict(percept, traffic_bytes_uncorrected=ptraffic,
+                                           note='epmc_percept_kernel, mean per launch: one launch behind every step kernel whose rays were split off (one workgroup of two waves per env row)')
     json.dump(counters, open(os.path.join(dst, '%s_%s_counters.json' % (tag, KERNEL)), 'w'), indent=1)
     traffic_all[KERNEL] = {'units_per_launch': units, 'control_steps_per_launch': spl, 'fetch_kb': counters['FETCH_SIZE'], 'write_kb': counters['WRITE_SIZE'], 'traffic_bytes': traffic,
+                           'percept_traffic_bytes': (counters['_percept_kernel']['traffic_bytes_uncorrected'] if percept else None),
                            'counters_file': 'profiles/%s_%s_counters.json' % (tag, KERNEL)}
     statsf = os.path.join(dst, '%s_%skernel_stats.csv' % (tag, prefix))
     for row in csv.DictReader(open(statsf)):
