@@ -2,7 +2,7 @@
 phases of a control step, multiplied by trip counts, priced per instruction class with the single-wave issue costs of tools/issue_probe.hip, and reconciled with the
 instruction and cycle counters of the committed rocprofv3 --pmc pass.  No GPU needed (hipcc cross-compiles the listing in seconds).
 
-    python tools/issue_ledger.py [--kernel 'pmc_step_kernel<1, false, true, true>(StepParams)'] [--costs profiles/r06_issue_probe.txt] [--counters profiles/r05_pmc_step_kernel_counters.json]
+    python tools/issue_ledger.py [--kernel 'pmc_step_kernel<1, false, true, true>(StepParams)'] [--costs profiles/r06_issue_probe.txt] [--counters profiles/r06_pmc_step_kernel_counters.json]
                                  [--define LL_MFMA_GRAM=1 ...] [--md profiles/r06_issue_ledger.md]
 
 How: the source carries PMC_PHASE("name") marks (pmc_params.hpp); compiled with -DPMC_MARKS each becomes a comment in the listing fenced by scheduling barriers, so the
@@ -157,7 +157,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--kernel', default='pmc_step_kernel<1, false, true, true>(StepParams)')
     ap.add_argument('--costs', default=os.path.join(ROOT, 'profiles', 'r06_issue_probe.txt'))
-    ap.add_argument('--counters', default=os.path.join(ROOT, 'profiles', 'r05_pmc_step_kernel_counters.json'))
+    ap.add_argument('--counters', default=os.path.join(ROOT, 'profiles', 'r06_pmc_step_kernel_counters.json'))
     ap.add_argument('--define', action='append', default=[])
     ap.add_argument('--p-limit', type=float, default=None, help='share of wave-substeps with a limit row (default: fitted to the instruction counter)')
     ap.add_argument('--traj', type=float, default=0.0, help='1: the step records unroll rows (N > 1)')
