@@ -723,8 +723,11 @@ def main_sepmc(args):
         elapsed = float(tt.item())
     if rank == 0:
         achieved = 2 * n_arenas * SEPMC_ALGO_BYTES_PER_ROBOT_STEP / (k_ms * 1e-3) / 1e9
-        ray_mode = int(os.environ.get('LL_SPLIT_RAYS', '1'))          # (see main_epmc; this env's default leaves multi-step calls fused)
-        kspl = spl if (spl > 1 and ray_mode < 2 and 2 * n_arenas <= 4096) else 1
+        ray_mode = int(os.environ.get('LL_SPLIT_RAYS', '1'))          # (see main_epmc; this env's default leaves multi-step calls fused -- up to one wave per SIMD)
+        if ray_mode == 1 and 2 * n_arenas > 4096:
+            ray_mode = 2
+        one_wave = os.environ.get('LL_SEPMC_ONE_WAVE', '1') == '1' and os.environ.get('LL_SHARE_SIMDS', '0') != '1'      # (llenv.hip: the one-wave-per-SIMD build at every batch size)
+        kspl = spl if (spl > 1 and ray_mode < 2 and (2 * n_arenas <= 4096 or one_wave)) else 1
         split = ray_mode >= (1 if spl == 1 else 2)
         traffic, issue, tsrc = committed_counters('sepmc_step_kernel', 2 * n_arenas, kspl)
         extra = {'cpu_baseline': cpu_baseline_env('sepmc', sepmc_env_config())} if (world == 1 and not args.no_cpu_baseline) else {}

@@ -68,6 +68,9 @@ typedef GpuLanesPinned<LC_COUNT> GpuLanes1;                   // the per-leg tab
 #ifndef LL_RELOAD_SEPMC2
 #define LL_RELOAD_SEPMC2 1      // (with the episode scalars parked in LDS the re-read pays here too: 32768 arenas 14.8 -> 16.0 M robot-steps/s)
 #endif
+#ifndef LL_SEPMC_ONE_WAVE_DEFAULT
+#define LL_SEPMC_ONE_WAVE_DEFAULT 1
+#endif
 #ifndef LL_GRAM_PIPE_PMC1
 #define LL_GRAM_PIPE_PMC1 0     // 1: the one-wave-per-SIMD PMC cone kernels form the Gram blocks of their contact rows on the matrix cores, one MFMA at a time between pieces of the next
                                 // row's arithmetic (lanes.hpp WithGramPipe; round 6, the round-5 review's "pipelined producer").  Built, held to the oracle on the host build, and measured
@@ -455,6 +458,14 @@ struct HipBackend {
     // LL_DETERMINISTIC=1: multi-step calls run as single launches.  A multi-step launch equals k single launches bit for bit only while every one of its waves is on the chip
     // (ll_get_table_sync == 0); on a device it shares with other kernels -- a collective, other ranks -- a re-seed may have to take the newest table version there is, and which clip it
     // draws then hangs on timing.  Single launches never do.
+    // LL_SEPMC_ONE_WAVE (default 1): which chase-tag build runs batches beyond one wave per SIMD.  1: the one-wave-per-SIMD build at EVERY size -- a grid of 16 x the chip's SIMDs runs as
+    // waves that follow each other on a SIMD without waiting for a step's slowest wave, and none of them spills (the 256-register chase-tag build carries 868 B of scratch per lane):
+    // 32768 arenas 5.18 -> 4.37 ms per step, 8192 arenas 1.45 -> 1.16, 4096 arenas 0.80 -> 0.61 (profiles/r06_sepmc_one_wave_ab.txt).  0: the 256-register build, two waves per SIMD
+    // (rounds 2 - 5; still what LL_SHARE_SIMDS=1 selects).  PMC and EPMC keep their 256-register builds for larger batches: those do not spill and win there.
+    const char* ow = getenv("LL_SEPMC_ONE_WAVE");
+    sepmc_simds = (simds != 0 && (ow ? ow[0] == '1' : LL_SEPMC_ONE_WAVE_DEFAULT)) ? 0x7fffffff : simds;
+    const char* ow2 = getenv("LL_EPMC_ONE_WAVE");                    // the same choice for the PlayGround env (default 0: its 256-register build does not spill and wins at larger batches)
+    epmc_simds = (simds != 0 && ow2 && ow2[0] == '1') ? 0x7fffffff : simds;
     const char* det = getenv("LL_DETERMINISTIC");
     deterministic = det && det[0] == '1';
     // LL_SPLIT_RAYS (EPMC / SEPMC): 0 = the step kernel casts the 778 rays of a row itself (rounds 1 - 5); 1 = single-step launches leave them to epmc_percept_kernel behind the step
@@ -473,6 +484,7 @@ struct HipBackend {
   void use() { HIPCHK(hipSetDevice(device)); }
   int simds_hw = 1024;
   int split_rays_epmc = 2, split_rays_sepmc = 1;
+  int sepmc_simds = 1024, epmc_simds = 1024;
   // can every workgroup of a step launch be on the chip at once?  (one 512-register wave per SIMD while the grid fits, two 256-register waves otherwise:
   // launch_step.)  A multi-step launch needs it -- its waves wait for each other's finished episodes (PmcEngine::step)
   bool deterministic = false;
@@ -540,21 +552,21 @@ struct HipBackend {
       StepParams Q = P;
       Q.n_steps = 1;
       for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) {
-        if (blocks <= simds) LL_GO((epmc_step_kernel<1, false, true, true>), Q); else LL_GO((epmc_step_kernel<2, false, true, true>), Q);
+        if (blocks <= epmc_simds) LL_GO((epmc_step_kernel<1, false, true, true>), Q); else LL_GO((epmc_step_kernel<2, false, true, true>), Q);
         if (split) launch_percept(Q, E);
       }
     } else
     if (P.n_steps == 1) {
-      if (blocks <= simds) { if (cone) LL_GO((epmc_step_kernel<1, false, true>), P); else LL_GO((epmc_step_kernel<1>), P); }
+      if (blocks <= epmc_simds) { if (cone) LL_GO((epmc_step_kernel<1, false, true>), P); else LL_GO((epmc_step_kernel<1>), P); }
       else                 { if (cone) LL_GO((epmc_step_kernel<2, false, true>), P); else LL_GO((epmc_step_kernel<2>), P); }
       if (split) launch_percept(P, E);
-    } else if (blocks <= simds && !split) {
+    } else if (blocks <= epmc_simds && !split) {
       if (cone) LL_GO((epmc_step_kernel<1, true, true>), P); else LL_GO((epmc_step_kernel<1, true>), P);
     } else {
       StepParams Q = P;                                  // larger batches, and every batch with the rays split off: the steps of the call as single launches (see epmc_step_kernel)
       Q.n_steps = 1;
       for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) {
-        if (blocks <= simds) { if (cone) LL_GO((epmc_step_kernel<1, false, true>), Q); else LL_GO((epmc_step_kernel<1>), Q); }
+        if (blocks <= epmc_simds) { if (cone) LL_GO((epmc_step_kernel<1, false, true>), Q); else LL_GO((epmc_step_kernel<1>), Q); }
         else                 { if (cone) LL_GO((epmc_step_kernel<2, false, true>), Q); else LL_GO((epmc_step_kernel<2>), Q); }
         if (split) launch_percept(Q, E);
       }
@@ -573,7 +585,8 @@ struct HipBackend {
     use();
     const int blocks = (P.n_envs + PMC_ENVS_PER_WAVE - 1) / PMC_ENVS_PER_WAVE;
     std::pair<hipEvent_t, hipEvent_t>* ev = timing_begin(P.n_steps);
-    const bool cone = P.friction_mode == 2, split = rays_split(P, S_in.e, split_rays_sepmc);
+    // (beyond one wave per SIMD a multi-step call is better off as single steps with the rays split off: 32768 arenas 4.52 -> 4.37 ms per step, profiles/r06_sepmc_one_wave_ab.txt)
+    const bool cone = P.friction_mode == 2, split = rays_split(P, S_in.e, (split_rays_sepmc == 1 && blocks > simds_hw) ? 2 : split_rays_sepmc);
     SepmcParams S = S_in;
     S.e.split_rays = split ? 1 : 0;
 #define LL_GO(KERNEL, PARAMS) hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(PMC_WAVE), lds_bytes_epmc(), stream, PARAMS, S)
@@ -582,21 +595,21 @@ struct HipBackend {
       StepParams Q = P;
       Q.n_steps = 1;
       for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) {
-        if (blocks <= simds) LL_GO((sepmc_step_kernel<1, false, true, true>), Q); else LL_GO((sepmc_step_kernel<2, false, true, true>), Q);
+        if (blocks <= sepmc_simds) LL_GO((sepmc_step_kernel<1, false, true, true>), Q); else LL_GO((sepmc_step_kernel<2, false, true, true>), Q);
         if (split) launch_percept(Q, S.e);
       }
     } else
     if (P.n_steps == 1) {
-      if (blocks <= simds) { if (cone) LL_GO((sepmc_step_kernel<1, false, true>), P); else LL_GO((sepmc_step_kernel<1>), P); }
+      if (blocks <= sepmc_simds) { if (cone) LL_GO((sepmc_step_kernel<1, false, true>), P); else LL_GO((sepmc_step_kernel<1>), P); }
       else                 { if (cone) LL_GO((sepmc_step_kernel<2, false, true>), P); else LL_GO((sepmc_step_kernel<2>), P); }
       if (split) launch_percept(P, S.e);
-    } else if (blocks <= simds && !split) {
+    } else if (blocks <= sepmc_simds && !split) {
       if (cone) LL_GO((sepmc_step_kernel<1, true, true>), P); else LL_GO((sepmc_step_kernel<1, true>), P);
     } else {
       StepParams Q = P;                                  // larger batches, and every batch with the rays split off: single launches (see epmc_step_kernel)
       Q.n_steps = 1;
       for (int sl = 0; sl < P.n_steps; sl++, Q.step_count++) {
-        if (blocks <= simds) { if (cone) LL_GO((sepmc_step_kernel<1, false, true>), Q); else LL_GO((sepmc_step_kernel<1>), Q); }
+        if (blocks <= sepmc_simds) { if (cone) LL_GO((sepmc_step_kernel<1, false, true>), Q); else LL_GO((sepmc_step_kernel<1>), Q); }
         else                 { if (cone) LL_GO((sepmc_step_kernel<2, false, true>), Q); else LL_GO((sepmc_step_kernel<2>), Q); }
         if (split) launch_percept(Q, S.e);
       }

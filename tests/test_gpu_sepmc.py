@@ -33,7 +33,16 @@ def test_game_statistics_against_the_oracle_env_gpu():
     SC.check_game_statistics(None, n_arenas=512)
 
 
-def test_pair_physics_with_bullets_pair_rows_gpu():
+@pytest.fixture(params=['1', '0'], ids=['one_wave_per_simd_at_every_size', 'the_256_register_build'])
+def large_batch_build(request, monkeypatch):
+    """LL_SEPMC_ONE_WAVE, read when an engine is created: which chase-tag build runs more than 2048 arenas -- the one-wave-per-SIMD build at every size (default since round 6) or the
+    256-register build of rounds 2 - 5 (still what LL_SHARE_SIMDS=1 selects).  Tests that go beyond 2048 arenas run under both."""
+    monkeypatch.setenv('LL_SEPMC_ONE_WAVE', request.param)
+    return request.param
+
+
+
+def test_pair_physics_with_bullets_pair_rows_gpu(large_batch_build):
     """Round 6: the XROWS builds on the GPU -- LLM_SPEC_PAIR_FRICTION 0.25, LLM_SPEC_MAX_PAIR 4, LLM_SPEC_SELF_FRICTION 0.25 -- against the oracle under the same switches
     (one-wave-per-SIMD build, and the larger-batch build with the cases spread over its grid)"""
     print(SC.check_pair_physics_against_oracle(None, n_arenas=64, seed=9, spec=dict(pair_friction=0.25), cap_ill=2))
@@ -42,7 +51,7 @@ def test_pair_physics_with_bullets_pair_rows_gpu():
     print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=11, total_arenas=3000, spec=dict(pair_friction=0.25, max_pair=4, self_friction=0.25), cap_ill=3))
 
 
-def test_rays_by_a_kernel_of_their_own_equal_the_fused_rays_gpu():
+def test_rays_by_a_kernel_of_their_own_equal_the_fused_rays_gpu(large_batch_build):
     """Round 6 (LL_SPLIT_RAYS): the 2 x 778 perception rays of an arena by epmc_percept_kernel behind the step kernel against the fused rays, bit for bit; a partial last wave and the larger-batch build"""
     SC.check_split_rays_equal_fused(None, n=101, n_steps=24)
     SC.check_split_rays_equal_fused(None, n=2100, n_steps=6)
@@ -64,13 +73,13 @@ def test_pair_physics_against_oracle_gpu():
     print(SC.check_pair_physics_against_oracle(None, n_arenas=64, seed=9))
 
 
-def test_larger_batch_build_against_the_oracle_gpu():
+def test_larger_batch_build_against_the_oracle_gpu(large_batch_build):
     """sepmc_step_kernel<2> (above 2048 arenas) against the float64 two-robot oracle DIRECTLY: pair-physics cases spread over the first, middle
     and last wavefronts of a 2048 + 128 arena grid, every robot within the bars of the occupancy-1 build."""
     print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=9, total_arenas=2048 + 128))
 
 
-def test_pyramid_friction_variant_gpu():
+def test_pyramid_friction_variant_gpu(large_batch_build):
     """LLM_SPEC_FRICTION_MODE = 0 (ll_sepmc_set_spec_param: the pyramid of rounds 1 - 3) against the two-robot oracle under the same switch, both
     register budgets, and its multi-step launch against single launches."""
     import epmc_parity_common as ec
@@ -80,7 +89,7 @@ def test_pyramid_friction_variant_gpu():
         SC.check_multi_step_launch(None, sizes=(35, 2048, 2100), k=7, n_launches=3)
 
 
-def test_round4_spec_variant_gpu():
+def test_round4_spec_variant_gpu(large_batch_build):
     """The spec of rounds 1 - 4 (speculative limit rows + gate, ERP 0.2, push-out capped at 0.5 m/s: ll_sepmc_set_spec_param) as an A/B leg against the two-robot
     oracle under the same switches, both register budgets, and its multi-step launch against single launches; then the two-ERP rule."""
     import epmc_parity_common as ec
@@ -92,7 +101,7 @@ def test_round4_spec_variant_gpu():
         print(SC.check_pair_physics_against_oracle(None, n_arenas=48, seed=9, cap_ill=3))
 
 
-def test_every_observation_field_against_the_host_build_of_the_kernel_source():
+def test_every_observation_field_against_the_host_build_of_the_kernel_source(large_batch_build):
     """2048 arenas (BASELINE config 5's size: the one-wave-per-SIMD kernels), every observation field against the CPU build of the same source, both
     friction modes -- including the arenas that re-seed inside the step (sepmc_parity_common.check_engine_against_emulation)."""
     import os
@@ -102,7 +111,7 @@ def test_every_observation_field_against_the_host_build_of_the_kernel_source():
     lib = os.path.join(emul_dir, '_build', 'libllenv_emul.so')
     print('cone friction:', SC.check_engine_against_emulation(lib, n_arenas=2048, steps=2))
     print('pyramid:', SC.check_engine_against_emulation(lib, n_arenas=2048, steps=1, spec=dict(friction_mode=0)))
-    print('4096 arenas (the 256-register build):', SC.check_engine_against_emulation(lib, n_arenas=4096, steps=1, seed=9))
+    print('4096 arenas (LL_SEPMC_ONE_WAVE=%s):' % large_batch_build, SC.check_engine_against_emulation(lib, n_arenas=4096, steps=1, seed=9))
 
 
 def test_trained_reference_policy_plays_chase_tag_gpu():
@@ -146,7 +155,7 @@ def test_zero_copy_torch_views_gpu():
     E.close()
 
 
-def test_both_register_budgets_compute_the_same_gpu():
+def test_both_register_budgets_compute_the_same_gpu(monkeypatch):
     """sepmc_step_kernel<1> (up to 2048 arenas: what the oracle parity tests run) against sepmc_step_kernel<2> (larger batches): same seed ->
     same arena, spawn poses and pushes per arena; re-synchronised after each control step.  The two kernels are compiled from the same source
     but not to the same float32 instruction sequence (the larger-batch build parks its episode scalars in LDS around the substep loop, and
@@ -155,6 +164,7 @@ def test_both_register_budgets_compute_the_same_gpu():
     1920 row-steps outside the oracle bars, none by more than 2e-2.  (The larger-batch kernel is held to the oracle itself in
     test_larger_batch_build_against_the_oracle_gpu.)"""
     from parity_common import quat_align
+    monkeypatch.setenv('LL_SEPMC_ONE_WAVE', '0')           # (the default since round 6 runs the one-wave-per-SIMD build at every size: the comparison would be of a build with itself)
     n_small, n_big = 32, 2048 + 64
     cfg = SC.env_config(SC.ALL_ELEMENTS)
     A = SC.make_engine(cfg, n_small, None, seed=6)
