@@ -865,6 +865,29 @@ def _oracle_game(job):
     return len(us), why, u0, us
 
 
+def game_cache_extra(which):
+    """What besides the source files decides an oracle episode: the game config as the tests build it"""
+    import json
+    return 'epmc %s ' % which + json.dumps(_game_cfg(which), sort_keys=True, default=str)
+
+
+def oracle_games(which, seeds, procs=None):
+    """The oracle env's episodes of `seeds` under policy `which` as (length, why, 0, reset uniforms, step uniforms): from tests/golden/oracle_games.npz while that fixture
+    is the CURRENT oracle's (tests/oracle_game_cache.py; LL_LIVE_ORACLE_GAMES=1 ignores it), otherwise played now on `procs` host processes."""
+    import gc
+    import multiprocessing as mp
+    import bench
+    import oracle_game_cache as C
+    res = C.load('epmc_' + which, game_cache_extra(which), seeds)
+    if res is not None:
+        return res, 'the oracle episodes come from tests/golden/oracle_games.npz, whose source key is current'
+    procs = procs or bench.effective_cores()[0]
+    gc.collect()                                              # (no dead engine objects for the forked workers to finalise)
+    with mp.get_context('fork').Pool(procs) as p:
+        res = p.map(_oracle_game, [(which, s) for s in seeds], chunksize=1)
+    return [(r[0], r[1], 0, r[2], r[3]) for r in res], 'played live on %d processes' % procs
+
+
 def check_game_statistics(lib_path, n_per_policy=256, procs=None, policies=('hurdle', 'cube', 'hole'), frac_tol=0.03, len_tol=0.03, ks_p=0.5, n_se=2.0):
     """PMC has check_rollout_statistics; this is the same for the environmental level, at the level the game is decided on.  The engine and the
     float64 oracle env play the SAME episodes -- same terrain, friction, pushes (the oracle env's uniforms are recorded and handed to the engine
@@ -879,26 +902,24 @@ def check_game_statistics(lib_path, n_per_policy=256, procs=None, policies=('hur
     from scipy import stats as sst
     from oracle.epmc_policy import EpmcPolicy
     import bench
-    procs = procs or bench.effective_cores()[0]
     out = {}
     for which in policies:
         n = n_per_policy
-        gc.collect()                                          # (no dead engine objects for the forked workers to finalise)
-        with mp.get_context('fork').Pool(procs) as p:
-            res = p.map(_oracle_game, [(which, 1000 * (1 + policies.index(which)) + i) for i in range(n)], chunksize=1)
+        res, src = oracle_games(which, [1000 * (1 + policies.index(which)) + i for i in range(n)], procs)
+        print('%s policy: %s' % (which, src))
         len_o, why_o = np.array([r[0] for r in res]), np.array([r[1] for r in res])
         print('%s policy: %d episodes, oracle seeds %d .. %d, engine seed 3, bars at %.1f standard errors (floors %.3f / %.3f)' % (which, n, 1000 * (1 + policies.index(which)), 1000 * (1 + policies.index(which)) + n - 1, n_se, frac_tol, len_tol))
         cfg = _game_cfg(which)
         E = make_engine(cfg, n, lib_path, seed=3)
         U = np.full((n, epmc_capi.LLE_MAX_DRAWS), 0.5, np.float32)
         for i, r in enumerate(res):
-            U[i, :len(r[2])] = r[2]
+            U[i, :len(r[3])] = r[3]
         E.reset(draws=U)
         pol = EpmcPolicy(os.path.join(ROOT, 'tests', 'golden', 'epmc_policy_%s.npz' % which), n)
         obs = E.obs()
         alive = np.ones(n, bool); len_e = np.zeros(n, int); why_e = np.zeros(n, int)
         for t in range(cfg['max_steps'] + 1):
-            used = [r[3][t] if t < len(r[3]) else [] for r in res]
+            used = [r[4][t] if t < len(r[4]) else [] for r in res]
             D = np.full((n, max(1, max(len(u) for u in used))), 0.5, np.float32)      # (beyond the oracle episode's end: mid-range pushes)
             for i, u in enumerate(used):
                 D[i, :len(u)] = u

@@ -247,11 +247,14 @@ def check_policy_driven_parity(golden, orc, model_blob, table, lib_path, n_envs=
     return st
 
 
-def check_rollout_statistics(golden, orc, model_blob, table, lib_path, n_envs=256, max_steps=160, seed=11, threads=4):
+def check_rollout_statistics(golden, orc, model_blob, table, lib_path, n_envs=256, max_steps=160, seed=11, threads=None):
     """Free-running episodes (no resync) of engine and oracle from the same starts with the same action streams.  Contact dynamics are
     chaotic, so trajectories diverge sample-wise within a few steps; what must agree are the DISTRIBUTIONS: episode length
     (two-sample Kolmogorov-Smirnov), mean reward per step, and how episodes end."""
     from scipy import stats as sst
+    if threads is None:                                       # the oracle's envs are independent of each other: the thread count changes the wall time only
+        import bench
+        threads = max(1, min(16, bench.effective_cores()[0]))
     rng = np.random.default_rng(seed)
     clip = rng.integers(0, table.n_clips, n_envs).astype(np.int32)
     dur = table.frame_step * (np.asarray(table.clip_len)[clip] - table.margin - 1)

@@ -988,6 +988,28 @@ def _oracle_game(seed):
     return len(us), why, named, u0, us
 
 
+def game_cache_extra():
+    """What besides the source files decides an oracle game: the game config as the tests build it"""
+    import json
+    return 'sepmc ' + json.dumps(_game_cfg(), sort_keys=True, default=str)
+
+
+def oracle_games(seeds, procs=None):
+    """The oracle env's games of `seeds` as (length, why, named, reset uniforms, step uniforms): from tests/golden/oracle_games.npz while that fixture is the CURRENT
+    oracle's (tests/oracle_game_cache.py: a sha256 over every file a game depends on; LL_LIVE_ORACLE_GAMES=1 ignores it), otherwise played now on `procs` host processes."""
+    import gc
+    import multiprocessing as mp
+    import bench
+    import oracle_game_cache as C
+    res = C.load('sepmc', game_cache_extra(), seeds)
+    if res is not None:
+        return res, 'the oracle games come from tests/golden/oracle_games.npz, whose source key is current'
+    procs = procs or bench.effective_cores()[0]
+    gc.collect()                                              # (no dead engine objects for the forked workers to finalise)
+    with mp.get_context('fork').Pool(procs) as p:
+        return p.map(_oracle_game, list(seeds), chunksize=1), 'played live on %d processes' % procs
+
+
 def check_game_statistics(lib_path, n_arenas=512, procs=None, frac_tol=0.03, len_tol=0.03, ks_p=0.5, n_se=2.0, seed0=5000):
     """The strategic level's counterpart of parity_common.check_rollout_statistics, at the level the game is decided on: the engine and the float64
     oracle env play the SAME games -- same spawn poses, friction and pushes (the oracle env's uniforms are recorded and handed to the engine draw by
@@ -1001,12 +1023,9 @@ def check_game_statistics(lib_path, n_arenas=512, procs=None, frac_tol=0.03, len
     from oracle.sepmc_policy import SepmcPolicy
     from lifelike_agility_and_play_amd import sepmc_capi
     import bench
-    procs = procs or bench.effective_cores()[0]
     n = n_arenas
-    gc.collect()                                              # (no dead engine objects for the forked workers to finalise)
-    with mp.get_context('fork').Pool(procs) as p:
-        res = p.map(_oracle_game, [seed0 + i for i in range(n)], chunksize=1)
-    print('chase-tag game statistics: %d games, oracle seeds %d .. %d, engine seed 3, bars at %.1f standard errors (floors %.3f / %.3f)' % (n, seed0, seed0 + n - 1, n_se, frac_tol, len_tol))
+    res, src = oracle_games([seed0 + i for i in range(n)], procs)
+    print('chase-tag game statistics: %d games, oracle seeds %d .. %d (%s), engine seed 3, bars at %.1f standard errors (floors %.3f / %.3f)' % (n, seed0, seed0 + n - 1, src, n_se, frac_tol, len_tol))
     len_o, why_o, named_o = np.array([r[0] for r in res]), np.array([r[1] for r in res]), np.array([r[2] for r in res])
     cfg = _game_cfg()
     E = make_engine(cfg, n, lib_path, seed=3)
