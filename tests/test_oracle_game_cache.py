@@ -77,3 +77,29 @@ def test_the_key_sees_a_changed_source(tmp_path, monkeypatch):
         f.write(b'\n')
     assert C.source_key('x') != k0
     assert C.source_key('y') != C.source_key('x')
+
+
+def test_the_row_blocked_policy_of_the_game_statistics_is_the_policy_bit_for_bit():
+    """sepmc_parity_common.blocked_policy (the engine side of the 512-game statistic evaluates up to 1024 rows a step) against oracle.sepmc_policy.SepmcPolicy:
+    the same actions, heading and LSTM state to the last bit over several steps, with a last block that is not full; and with rows dropping out of `.alive`
+    step by step the rows still alive keep the plain policy's numbers (the others are not looked at)"""
+    from oracle.sepmc_policy import SepmcPolicy
+    npz = os.path.join(ROOT, 'tests', 'golden', 'sepmc_policy.npz')
+    n = 150
+    rng = np.random.default_rng(4)
+    plain, blocked, masked = SepmcPolicy(npz, n), SC.blocked_policy(npz, n, block=64), SC.blocked_policy(npz, n, block=64)
+    alive = np.ones(n, bool)
+    for step in range(4):
+        obs = rng.normal(size=(n, 965)) * 0.5
+        a, b = plain.act(obs), blocked.act(obs)
+        assert np.array_equal(a, b) and np.array_equal(plain.last_heading, blocked.last_heading)
+        for k in plain.h:
+            assert np.array_equal(plain.h[k], blocked.h[k]) and np.array_equal(plain.c[k], blocked.c[k])
+        alive &= rng.random(n) > 0.3                               # rows leave for good, as finished arenas do
+        assert 0 < alive.sum() < n
+        masked.alive = alive.copy()
+        c = masked.act(obs)
+        assert np.array_equal(a[alive], c[alive]) and np.array_equal(plain.last_heading[alive], masked.last_heading[alive])
+        for k in plain.h:
+            assert np.array_equal(plain.h[k][alive], masked.h[k][alive]) and np.array_equal(plain.c[k][alive], masked.c[k][alive])
+        assert np.isfinite(c).all()
