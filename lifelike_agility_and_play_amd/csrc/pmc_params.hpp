@@ -90,6 +90,17 @@ enum BaseConst {
 #define PMC_PHASE(name) do { } while (0)
 #endif
 
+#ifndef PMC_PGS_HOIST
+#define PMC_PGS_HOIST 1           // pmc_step.hpp: the solver's iteration loop in six copies (limit rows? x 0 / 1 / 2 leg-leg slots) with its wave-uniform tests decided outside (0: the one generic loop)
+#endif
+
+#ifndef PMC_PGS_HOIST_PAIR
+#define PMC_PGS_HOIST_PAIR 1      // the chase-tag builds too (- 0.5 % at 2048 arenas, - 1.4 % at 32768; 0: their one generic loop)
+#endif
+#ifndef PMC_PGS_HOIST_TERRAIN
+#define PMC_PGS_HOIST_TERRAIN 0   // 1: the one-wave-per-SIMD playground build too (measured: no difference; its 256-register build has the copies, - 9 % at 65536 envs)
+#endif
+
 #define LL_MAX_STEPS_PER_LAUNCH 128   // control steps one launch of ll_step_random_n runs at most (longer calls are split); sizes the per-step table slots
 
 struct StepParams {

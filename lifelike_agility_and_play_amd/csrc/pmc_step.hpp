@@ -21,6 +21,7 @@
 #include "../../include/llenv_model.h"
 #include "pmc_math.hpp"
 #include "pmc_params.hpp"
+#include <type_traits>
 
 #define LLS_DONE_FALL 1
 #define LLS_DONE_CLIP_END 2
@@ -1887,52 +1888,71 @@ struct Pmc {
     const F big = ln.lane_f(3.0e38f);
     const bool any_limit = any_l[0] || any_l[1] || any_l[2];
     ln.prepare_turn_masks();
-    LL_NOUNROLL
-    for (int it = 0; it < P.n_iter; it++) {
-      PMC_PHASE("pgs.limit_round");
-      if (any_limit) gs_round<true, true>(ln, rl, big, VA, VB, VJ);
-      PMC_PHASE("pgs.normal_round");
-      if (any_contact) {
-        gs_round<false, true>(ln, rn, big, VA, VB, VJ);
-        F hi = mu * rn.lam;
-        PMC_PHASE("pgs.cone_round");
-        if (CONE) {
-          gs_cone_round(ln, r1, r2, cx, hi, VA, VB, VJ);
-        } else {
-          gs_round<false, false>(ln, r1, hi, VA, VB, VJ);
-          gs_round<false, false>(ln, r2, hi, VA, VB, VJ);
-        }
-      }
-      PMC_PHASE("pgs.self_turns");
-      if (any_self) {                                                        // then the self-collision rows, one after the other (with LLM_SPEC_SELF_FRICTION each followed by its two tangential rows)
-        // (a tangential row whose normal multiplier is zero is bounded to [0, 0]: unless it still carries a multiplier of its own its turn changes nothing -- skipped when that holds
-        //  for every env of the wave: exact, and most leg-leg contacts of a step are within the margin without pressing)
-        self_turn(ln, sr[0], VA, VB, VJ);
-        if (self_fric && L::any(ln.lane_f((sr[0].lam > 0.0f || sf[0][0].lam != 0.0f || sf[0][1].lam != 0.0f) ? 1.0f : 0.0f) > 0.5f)) {
-          self_fric_turn(ln, sf[0][0], P.self_friction * sr[0].lam, VA, VB, VJ); self_fric_turn(ln, sf[0][1], P.self_friction * sr[0].lam, VA, VB, VJ);
-        }
-        if (n_self_w > 1) {
-          self_turn(ln, sr[1], VA, VB, VJ);
-          if (self_fric && L::any(ln.lane_f((sr[1].lam > 0.0f || sf[1][0].lam != 0.0f || sf[1][1].lam != 0.0f) ? 1.0f : 0.0f) > 0.5f)) {
-            self_fric_turn(ln, sf[1][0], P.self_friction * sr[1].lam, VA, VB, VJ); self_fric_turn(ln, sf[1][1], P.self_friction * sr[1].lam, VA, VB, VJ);
+    // The iteration loop, with the wave-uniform tests of its body (limit rows? contact rows? leg-leg rows?) hoisted out of it where the build is worth the code: a lone wave
+    // pays ~12 cycles for a branch it does not take and ~29 for one it takes (tools/branch_probe.hip, profiles/r06_branch_probe.txt; the issue ledger had charged 4.4), and the
+    // three tests ran a hundred times a control step.  LIM_K / CON_K: 1 = known true, 0 = known false, -1 = tested inside (the generic loop); SELF_K: the number of leg-leg slots in use (0, 1, 2), -1 = tested.  Same operations in
+    // the same order whichever copy runs: bit-identical.
+    auto pgs_loop = [&](auto lim_k, auto con_k, auto self_k) __attribute__((always_inline)) {
+      constexpr int LIM_K = decltype(lim_k)::value, CON_K = decltype(con_k)::value, SELF_K = decltype(self_k)::value;
+      LL_NOUNROLL
+      for (int it = 0; it < P.n_iter; it++) {
+        PMC_PHASE("pgs.limit_round");
+        if (LIM_K > 0 || (LIM_K < 0 && any_limit)) gs_round<true, true>(ln, rl, big, VA, VB, VJ);
+        PMC_PHASE("pgs.normal_round");
+        if (CON_K > 0 || (CON_K < 0 && any_contact)) {
+          gs_round<false, true>(ln, rn, big, VA, VB, VJ);
+          F hi = mu * rn.lam;
+          PMC_PHASE("pgs.cone_round");
+          if (CONE) {
+            gs_cone_round(ln, r1, r2, cx, hi, VA, VB, VJ);
+          } else {
+            gs_round<false, false>(ln, r1, hi, VA, VB, VJ);
+            gs_round<false, false>(ln, r2, hi, VA, VB, VJ);
           }
         }
-      }
-      if (PAIR) {
-        if (any_pair) {                                                      // last, the rows shared with the other robot (each followed by its two tangential rows under LLM_SPEC_PAIR_FRICTION)
-          LL_UNROLL
-          for (int slot = 0; slot < NPAIR; slot++) {
-            if (slot >= n_pair_w) break;
-            pair_turn(ln, pr[slot], VA, VB, VJ, ex->pair_me);
-            if constexpr (PAIR && XROWS) {
-              if (pair_fric && L::any(ln.lane_f((pr[slot].lam > 0.0f || pf[slot][0].lam != 0.0f || pf[slot][1].lam != 0.0f) ? 1.0f : 0.0f) > 0.5f)) {      // (see the leg-leg rows)
-                pair_fric_turn(ln, pf[slot][0], P.pair_friction * pr[slot].lam, VA, VB, VJ, ex->pair_me);
-                pair_fric_turn(ln, pf[slot][1], P.pair_friction * pr[slot].lam, VA, VB, VJ, ex->pair_me);
+        PMC_PHASE("pgs.self_turns");
+        if (SELF_K > 0 || (SELF_K < 0 && any_self)) {                          // then the self-collision rows, one after the other (with LLM_SPEC_SELF_FRICTION each followed by its two tangential rows)
+          // (a tangential row whose normal multiplier is zero is bounded to [0, 0]: unless it still carries a multiplier of its own its turn changes nothing -- skipped when that holds
+          //  for every env of the wave: exact, and most leg-leg contacts of a step are within the margin without pressing)
+          self_turn(ln, sr[0], VA, VB, VJ);
+          if (self_fric && L::any(ln.lane_f((sr[0].lam > 0.0f || sf[0][0].lam != 0.0f || sf[0][1].lam != 0.0f) ? 1.0f : 0.0f) > 0.5f)) {
+            self_fric_turn(ln, sf[0][0], P.self_friction * sr[0].lam, VA, VB, VJ); self_fric_turn(ln, sf[0][1], P.self_friction * sr[0].lam, VA, VB, VJ);
+          }
+          if (SELF_K > 1 || (SELF_K < 0 && n_self_w > 1)) {
+            self_turn(ln, sr[1], VA, VB, VJ);
+            if (self_fric && L::any(ln.lane_f((sr[1].lam > 0.0f || sf[1][0].lam != 0.0f || sf[1][1].lam != 0.0f) ? 1.0f : 0.0f) > 0.5f)) {
+              self_fric_turn(ln, sf[1][0], P.self_friction * sr[1].lam, VA, VB, VJ); self_fric_turn(ln, sf[1][1], P.self_friction * sr[1].lam, VA, VB, VJ);
+            }
+          }
+        }
+        if (PAIR) {
+          if (any_pair) {                                                      // last, the rows shared with the other robot (each followed by its two tangential rows under LLM_SPEC_PAIR_FRICTION)
+            LL_UNROLL
+            for (int slot = 0; slot < NPAIR; slot++) {
+              if (slot >= n_pair_w) break;
+              pair_turn(ln, pr[slot], VA, VB, VJ, ex->pair_me);
+              if constexpr (PAIR && XROWS) {
+                if (pair_fric && L::any(ln.lane_f((pr[slot].lam > 0.0f || pf[slot][0].lam != 0.0f || pf[slot][1].lam != 0.0f) ? 1.0f : 0.0f) > 0.5f)) {      // (see the leg-leg rows)
+                  pair_fric_turn(ln, pf[slot][0], P.pair_friction * pr[slot].lam, VA, VB, VJ, ex->pair_me);
+                  pair_fric_turn(ln, pf[slot][1], P.pair_friction * pr[slot].lam, VA, VB, VJ, ex->pair_me);
+                }
               }
             }
           }
         }
       }
+    };
+    {
+      typedef std::integral_constant<int, 1> K1;
+      typedef std::integral_constant<int, 0> K0;
+      typedef std::integral_constant<int, -1> KT;
+      constexpr bool HOIST = PMC_PGS_HOIST && (!PAIR || PMC_PGS_HOIST_PAIR) && !XROWS && (!TERRAIN || L::kConeInLds || PMC_PGS_HOIST_TERRAIN);      // (the XROWS builds keep the one generic loop; which of the other builds take the copies was decided by A/B: profiles/r06_pgs_hoist_ab.txt)
+      if (HOIST && any_contact) {
+        typedef std::integral_constant<int, 2> K2;
+        const int ns = any_self ? (n_self_w > 1 ? 2 : 1) : 0;           // leg-leg slots in use by some env of the wave
+        if (any_limit) { if (ns == 0) pgs_loop(K1(), K1(), K0()); else if (ns == 1) pgs_loop(K1(), K1(), K1()); else pgs_loop(K1(), K1(), K2()); }
+        else           { if (ns == 0) pgs_loop(K0(), K1(), K0()); else if (ns == 1) pgs_loop(K0(), K1(), K1()); else pgs_loop(K0(), K1(), K2()); }
+      } else pgs_loop(KT(), KT(), KT());
     }
 
     PMC_TSS(27);
