@@ -23,7 +23,7 @@ def pmc_config(**kw):
 
 @pytest.fixture(scope='module')
 def emul_lib():
-    subprocess.check_call(['make', '-C', EMUL_DIR, '-s'])
+    subprocess.check_call(['make', '-C', EMUL_DIR, '-s', '-j2'])
     return EMUL_LIB
 
 
@@ -132,7 +132,7 @@ def test_a_forked_child_does_not_destroy_the_parents_engine(model_blob, mocap_ta
     import os
     import subprocess
     emul_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emul')
-    subprocess.check_call(['make', '-C', emul_dir, '-s'])
+    subprocess.check_call(['make', '-C', emul_dir, '-s', '-j2'])
     from lifelike_agility_and_play_amd import capi
     import parity_common as pc
     E = pc.make_engine(model_blob, mocap_table, 4, os.path.join(emul_dir, '_build', 'libllenv_emul.so'))

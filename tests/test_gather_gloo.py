@@ -100,7 +100,7 @@ def _ring_worker(rank, world, port, q, emul_lib):
 def test_async_ring_gather_two_ranks():
     import subprocess
     emul_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emul')
-    subprocess.check_call(['make', '-C', emul_dir, '-s'])
+    subprocess.check_call(['make', '-C', emul_dir, '-s', '-j2'])
     emul_lib = os.path.join(emul_dir, '_build', 'libllenv_emul.so')
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')

@@ -144,7 +144,7 @@ def test_every_observation_entry_against_the_host_build_of_the_kernel_source():
     import os
     import subprocess
     emul_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emul')
-    subprocess.check_call(['make', '-C', emul_dir, '-s'])
+    subprocess.check_call(['make', '-C', emul_dir, '-s', '-j2'])
     lib = os.path.join(emul_dir, '_build', 'libllenv_emul.so')
     for element in (1, 3):
         print('4096 envs, element', element, ec.check_engine_against_host_build(lib, element=element))

@@ -292,7 +292,7 @@ def test_every_observation_entry_against_the_host_build_of_the_kernel_source(mod
     import os
     import subprocess
     emul_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emul')
-    subprocess.check_call(['make', '-C', emul_dir, '-s'])
+    subprocess.check_call(['make', '-C', emul_dir, '-s', '-j2'])
     lib = os.path.join(emul_dir, '_build', 'libllenv_emul.so')
     print('4096 envs (one wave per SIMD):', pc.check_engine_against_host_build(model_blob, mocap_table, lib))
     print('8192 envs (the 256-register build):', pc.check_engine_against_host_build(model_blob, mocap_table, lib, n_envs=8192, steps=8, seed=23))

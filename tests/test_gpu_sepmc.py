@@ -107,7 +107,7 @@ def test_every_observation_field_against_the_host_build_of_the_kernel_source(lar
     import os
     import subprocess
     emul_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emul')
-    subprocess.check_call(['make', '-C', emul_dir, '-s'])
+    subprocess.check_call(['make', '-C', emul_dir, '-s', '-j2'])
     lib = os.path.join(emul_dir, '_build', 'libllenv_emul.so')
     print('cone friction:', SC.check_engine_against_emulation(lib, n_arenas=2048, steps=2))
     print('pyramid:', SC.check_engine_against_emulation(lib, n_arenas=2048, steps=1, spec=dict(friction_mode=0)))

@@ -16,7 +16,7 @@ EMUL_LIB = os.path.join(EMUL_DIR, '_build', 'libllenv_emul.so')
 
 @pytest.fixture(scope='session')
 def emul_lib():
-    subprocess.check_call(['make', '-C', EMUL_DIR, '-s'])
+    subprocess.check_call(['make', '-C', EMUL_DIR, '-s', '-j2'])
     return EMUL_LIB
 
 
